@@ -1,0 +1,45 @@
+# Builds libsparsex.so (host preprocessor + HIP executor for gfx950) and the
+# parity oracle.  hipcc cross-compiles the device code without a GPU present.
+ROCM      ?= /opt/rocm
+HIPCC     ?= $(ROCM)/bin/hipcc
+CXX       ?= g++
+CC        ?= gcc
+ARCH      ?= gfx950
+
+CSRC      := sparsex_amd/csrc
+LIBDIR    := sparsex_amd/lib
+OBJDIR    := build/obj
+LIB       := $(LIBDIR)/libsparsex.so
+
+HOST_SRCS := common.cpp config.cpp partition.cpp stats.cpp encoder.cpp input.cpp \
+             csx_emit.cpp gpu_emit.cpp api.cpp
+HOST_OBJS := $(HOST_SRCS:%.cpp=$(OBJDIR)/%.o)
+HIP_OBJ   := $(OBJDIR)/spmv_kernels.o
+
+CXXFLAGS  := -std=c++17 -O2 -g -fPIC -Wall -Iinclude -I$(CSRC) -pthread
+HIPFLAGS  := --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -munsafe-fp-atomics \
+             -Iinclude -I$(CSRC)
+
+.PHONY: all lib oracle clean
+all: lib oracle
+
+lib: $(LIB)
+
+$(OBJDIR)/%.o: $(CSRC)/%.cpp $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.h) \
+               $(wildcard include/sparsex/*.h) include/sparsex_hip.h
+	@mkdir -p $(OBJDIR)
+	$(CXX) $(CXXFLAGS) -c $< -o $@
+
+$(HIP_OBJ): $(CSRC)/spmv_kernels.hip $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.h)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(HOST_OBJS) $(HIP_OBJ)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -pthread
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf build $(LIBDIR)/*.so oracle/*.so oracle/_ref

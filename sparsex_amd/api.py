@@ -1,0 +1,285 @@
+"""ctypes binding of libsparsex.so.
+
+Names follow the C API one to one (``spx_input_load_csr`` ->
+:func:`input_load_csr` etc.; reference ``include/sparsex/matvec.h:39-535``).
+There is no Python or CPU fallback for the multiplication: if the shared
+library (or, at call time, a HIP device) is missing, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+SPX_SUCCESS = 0
+SPX_FAILURE = -1
+SPX_MAT_REORDER = 42
+SPX_VEC_AS_IS = 43
+SPX_VEC_TUNE = 44
+SPX_INDEX_ZERO_BASED = 45
+SPX_INDEX_ONE_BASED = 46
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libsparsex.so")
+
+
+class SpxError(RuntimeError):
+    pass
+
+
+class VectorStruct(C.Structure):
+    """``struct vector_struct`` -- public ABI (include/sparsex/common.h)."""
+    _fields_ = [("elements", C.POINTER(C.c_double)), ("size", C.c_size_t),
+                ("alloc_type", C.c_int), ("vec_mode", C.c_int)]
+
+
+class HipInfo(C.Structure):
+    _fields_ = [("nnz", C.c_int64), ("nnz_stored", C.c_int64),
+                ("n_unit_elems", C.c_int64), ("n_delta_elems", C.c_int64),
+                ("n_units", C.c_int64), ("n_rowblocks", C.c_int64),
+                ("n_shared_rows", C.c_int64), ("value_bytes", C.c_int64),
+                ("index_bytes", C.c_int64), ("nr_partitions", C.c_int32),
+                ("first_partition", C.c_int32), ("last_partition", C.c_int32),
+                ("row_lo", C.c_int32), ("row_hi", C.c_int32),
+                ("symmetric", C.c_int32), ("on_device", C.c_int32),
+                ("device", C.c_int32), ("tune_seconds", C.c_double),
+                ("emit_seconds", C.c_double)]
+
+
+class CsxExport(C.Structure):
+    _fields_ = [("values", C.POINTER(C.c_double)), ("ctl", C.POINTER(C.c_uint8)),
+                ("ctl_size", C.c_int64), ("nnz", C.c_int), ("ncols", C.c_int),
+                ("nrows", C.c_int), ("row_start", C.c_int),
+                ("row_jumps", C.c_int32), ("full_colind", C.c_int32),
+                ("id_map", C.c_long * 64), ("rows_info", C.POINTER(C.c_int)),
+                ("dvalues", C.POINTER(C.c_double))]
+
+
+class UnitRecord(C.Structure):
+    _fields_ = [("type", C.c_int32), ("delta", C.c_int32), ("size", C.c_int32),
+                ("row", C.c_int32), ("col", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    """Loads libsparsex.so (once).  Raises SpxError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise SpxError(
+            "libsparsex.so is not built (%s); run `make lib` or "
+            "__graft_entry__.build() -- there is no fallback path" % path)
+    L = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    vp, i, d = C.c_void_p, C.c_int, C.c_double
+    L.spx_input_load_csr.restype = vp
+    L.spx_input_load_mmf.restype = vp
+    L.spx_input_load_mmf.argtypes = [C.c_char_p]
+    L.spx_input_destroy.argtypes = [vp]
+    L.spx_mat_tune.restype = vp
+    L.spx_mat_destroy.argtypes = [vp]
+    L.spx_mat_get_nrows.argtypes = [vp]
+    L.spx_mat_get_ncols.argtypes = [vp]
+    L.spx_mat_get_nnz.argtypes = [vp]
+    L.spx_mat_get_partition.restype = vp
+    L.spx_mat_get_partition.argtypes = [vp]
+    L.spx_partition_get_rs.restype = C.POINTER(C.c_int)
+    L.spx_partition_get_rs.argtypes = [vp]
+    L.spx_partition_get_re.restype = C.POINTER(C.c_int)
+    L.spx_partition_get_re.argtypes = [vp]
+    L.spx_partition_destroy.argtypes = [vp]
+    L.spx_option_set.argtypes = [C.c_char_p, C.c_char_p]
+    L.spx_option_set.restype = None
+    L.spx_hip_options_reset.restype = None
+    L.spx_vec_create_from_buff.restype = C.POINTER(VectorStruct)
+    L.spx_vec_create_from_buff.argtypes = [C.POINTER(C.c_double), vp, C.c_size_t, vp,
+                                           C.c_uint]
+    L.spx_vec_destroy.argtypes = [C.POINTER(VectorStruct)]
+    L.spx_vec_destroy.restype = None
+    L.spx_matvec_mult.argtypes = [d, vp, C.POINTER(VectorStruct), C.POINTER(VectorStruct)]
+    L.spx_matvec_kernel.argtypes = [d, vp, C.POINTER(VectorStruct), d,
+                                    C.POINTER(VectorStruct)]
+    L.spx_hip_matvec_mult.argtypes = [d, vp, vp, vp, vp]
+    L.spx_hip_matvec_kernel.argtypes = [d, vp, vp, d, vp, vp]
+    L.spx_hip_mat_info.argtypes = [vp, C.POINTER(HipInfo)]
+    L.spx_hip_mat_export_csx.argtypes = [vp, i, C.POINTER(CsxExport)]
+    L.spx_hip_mat_export_units.restype = C.c_int64
+    L.spx_hip_mat_export_units.argtypes = [vp, i, C.POINTER(UnitRecord), C.c_int64]
+    L.spx_hip_mat_tune_log.restype = C.c_char_p
+    L.spx_hip_mat_tune_log.argtypes = [vp]
+    L.spx_log_disable_all.restype = None
+    L.spx_log_error_console.restype = None
+    _lib = L
+    return L
+
+
+def option_set(option, value):
+    """``spx_option_set(option, value)`` (reference src/api/matvec.c:753-756)."""
+    lib().spx_option_set(str(option).encode(), str(value).encode())
+
+
+def options_reset():
+    lib().spx_hip_options_reset()
+
+
+class Input:
+    """``spx_input_t`` handle; keeps the borrowed CSR arrays alive."""
+
+    def __init__(self, handle, keep=()):
+        self.handle = handle
+        self._keep = keep
+
+    def destroy(self):
+        if self.handle:
+            lib().spx_input_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def input_load_csr(rowptr, colind, values, nrows, ncols, indexing=SPX_INDEX_ZERO_BASED):
+    """``spx_input_load_csr`` -- wraps (does not copy) the CSR arrays."""
+    rp = np.ascontiguousarray(rowptr, dtype=np.int32)
+    ci = np.ascontiguousarray(colind, dtype=np.int32)
+    va = np.ascontiguousarray(values, dtype=np.float64)
+    h = lib().spx_input_load_csr(
+        rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p),
+        va.ctypes.data_as(C.c_void_p), C.c_int(nrows), C.c_int(ncols), C.c_int(indexing))
+    if not h:
+        raise SpxError("spx_input_load_csr failed")
+    return Input(h, keep=(rp, ci, va))
+
+
+def input_load_mmf(filename):
+    """``spx_input_load_mmf``."""
+    h = lib().spx_input_load_mmf(str(filename).encode())
+    if not h:
+        raise SpxError("spx_input_load_mmf failed for %s" % filename)
+    return Input(h)
+
+
+class Matrix:
+    """``spx_matrix_t`` handle with the multiplication entry points."""
+
+    def __init__(self, handle):
+        self.handle = handle
+        L = lib()
+        self.nrows = L.spx_mat_get_nrows(handle)
+        self.ncols = L.spx_mat_get_ncols(handle)
+        self.nnz = L.spx_mat_get_nnz(handle)
+
+    # -- reference API ---------------------------------------------------
+    def matvec_mult(self, alpha, x, y):
+        """``spx_matvec_mult(alpha, A, x, y)`` on host numpy vectors."""
+        return self._host(alpha, x, None, y)
+
+    def matvec_kernel(self, alpha, x, beta, y):
+        """``spx_matvec_kernel(alpha, A, x, beta, y)`` on host numpy vectors."""
+        return self._host(alpha, x, beta, y)
+
+    def _host(self, alpha, x, beta, y):
+        L = lib()
+        assert x.dtype == np.float64 and y.dtype == np.float64
+        assert x.flags.c_contiguous and y.flags.c_contiguous
+        xv = L.spx_vec_create_from_buff(x.ctypes.data_as(C.POINTER(C.c_double)), None,
+                                        x.size, None, SPX_VEC_AS_IS)
+        yv = L.spx_vec_create_from_buff(y.ctypes.data_as(C.POINTER(C.c_double)), None,
+                                        y.size, None, SPX_VEC_AS_IS)
+        try:
+            if beta is None:
+                rc = L.spx_matvec_mult(alpha, self.handle, xv, yv)
+            else:
+                rc = L.spx_matvec_kernel(alpha, self.handle, xv, beta, yv)
+        finally:
+            L.spx_vec_destroy(xv)
+            L.spx_vec_destroy(yv)
+        if rc != SPX_SUCCESS:
+            raise SpxError("spx_matvec failed (see stderr)")
+        return y
+
+    def partition(self):
+        L = lib()
+        p = L.spx_mat_get_partition(self.handle)
+        n = self.info().nr_partitions
+        rs = [L.spx_partition_get_rs(p)[i] for i in range(n)]
+        re = [L.spx_partition_get_re(p)[i] for i in range(n)]
+        L.spx_partition_destroy(p)
+        return rs, re
+
+    # -- device-resident extension (include/sparsex_hip.h) -------------------
+    def hip_matvec_mult(self, alpha, x_ptr, y_ptr, stream=0):
+        rc = lib().spx_hip_matvec_mult(alpha, self.handle, x_ptr, y_ptr, stream)
+        if rc != SPX_SUCCESS:
+            raise SpxError("spx_hip_matvec_mult failed (see stderr)")
+
+    def hip_matvec_kernel(self, alpha, x_ptr, beta, y_ptr, stream=0):
+        rc = lib().spx_hip_matvec_kernel(alpha, self.handle, x_ptr, beta, y_ptr, stream)
+        if rc != SPX_SUCCESS:
+            raise SpxError("spx_hip_matvec_kernel failed (see stderr)")
+
+    def info(self):
+        inf = HipInfo()
+        if lib().spx_hip_mat_info(self.handle, C.byref(inf)) != SPX_SUCCESS:
+            raise SpxError("spx_hip_mat_info failed")
+        return inf
+
+    def export_csx(self, part=0):
+        """Reference-format CSX arrays of one partition as numpy copies."""
+        ex = CsxExport()
+        if lib().spx_hip_mat_export_csx(self.handle, part, C.byref(ex)) != SPX_SUCCESS:
+            raise SpxError("spx_hip_mat_export_csx failed")
+        out = {
+            "values": np.ctypeslib.as_array(ex.values, shape=(max(ex.nnz, 0),)).copy()
+            if ex.nnz else np.zeros(0),
+            "ctl": np.ctypeslib.as_array(ex.ctl, shape=(ex.ctl_size,)).copy()
+            if ex.ctl_size else np.zeros(0, dtype=np.uint8),
+            "nnz": ex.nnz, "ncols": ex.ncols, "nrows": ex.nrows,
+            "row_start": ex.row_start, "row_jumps": int(ex.row_jumps),
+            "full_colind": int(ex.full_colind),
+            "id_map": [int(v) for v in ex.id_map],
+            "rows_info": np.ctypeslib.as_array(ex.rows_info, shape=(ex.nrows, 3)).copy()
+            if ex.nrows else np.zeros((0, 3), dtype=np.int32),
+            "dvalues": (np.ctypeslib.as_array(ex.dvalues, shape=(ex.nrows,)).copy()
+                        if bool(ex.dvalues) and ex.nrows else None),
+        }
+        return out
+
+    def export_units(self, part=0):
+        L = lib()
+        n = L.spx_hip_mat_export_units(self.handle, part, None, 0)
+        if n < 0:
+            raise SpxError("spx_hip_mat_export_units failed")
+        recs = (UnitRecord * max(n, 1))()
+        L.spx_hip_mat_export_units(self.handle, part, recs, n)
+        return [(r.type, r.delta, r.size, r.row, r.col) for r in recs[:n]]
+
+    def tune_log(self):
+        return lib().spx_hip_mat_tune_log(self.handle).decode()
+
+    def destroy(self):
+        if self.handle:
+            lib().spx_mat_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def mat_tune(inp, reorder=False):
+    """``spx_mat_tune(input[, SPX_MAT_REORDER])``."""
+    h = lib().spx_mat_tune(C.c_void_p(inp.handle), C.c_int(SPX_MAT_REORDER if reorder else 0))
+    if not h:
+        raise SpxError("spx_mat_tune failed (see stderr)")
+    return Matrix(h)

@@ -1,0 +1,1083 @@
+// api.cpp -- the SparseX C API (include/sparsex/*.h) on top of the host
+// preprocessor and the HIP executor, plus the extensions of sparsex_hip.h.
+//
+// Function-by-function counterpart of the reference's src/api/matvec.c,
+// src/api/common.c, src/api/error.c and the facade they call
+// (src/internals/Facade.cpp:30-212).  Argument checks, return values and the
+// error-handler protocol follow those files; the machinery behind tune and
+// matvec is this repository's own.
+#include <sparsex/sparsex.h>
+#include <sparsex_hip.h>
+
+#include "config.hpp"
+#include "csx_emit.hpp"
+#include "device.hpp"
+#include "encoder.hpp"
+#include "gpu_emit.hpp"
+#include "input.hpp"
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <sstream>
+#include <thread>
+#include <unistd.h>
+
+using namespace spx;
+
+// ---- handle types (opaque to clients) ----------------------------------------------
+
+struct input {
+    spx_index_t nrows, ncols, nnz;
+    char type;                         // 'C' (CSR) or 'M' (MMF)
+    MatrixInput *mat;
+};
+
+struct partition {
+    size_t nr_partitions;
+    size_t *parts;
+    int *nodes;
+    int *affinity;
+    spx_index_t *row_start;
+    spx_index_t *row_end;
+};
+
+struct matrix {
+    spx_index_t nrows, ncols, nnz;
+    int symmetric;
+    spx_perm_t *permutation;
+    // tuned representation
+    size_t nr_partitions;              // P, over all processes
+    size_t first_part, last_part;      // owned partitions [first, last)
+    std::vector<PartBounds> bounds;    // all P partitions
+    std::vector<Partition> parts;      // encoded, horizontal order (owned ones)
+    std::vector<std::vector<val_t>> diag;   // symmetric: per owned partition
+    std::vector<std::unique_ptr<CsxStream>> exported;
+    std::vector<std::vector<spx_index_t>> exported_rows_info;
+    bool full_colind;
+    DeviceMatrix *dev;
+    // accounting
+    size_t nnz_stored, n_unit_elems, n_delta_elems, n_units;
+    size_t value_bytes, index_bytes, n_rowblocks, n_shared;
+    double tune_seconds, emit_seconds;
+    std::string log;
+    std::mutex mtx;
+};
+
+namespace {
+
+enum { ALLOC_STD = 1, ALLOC_OTHER = 4 };       // Vector.cpp:36-41
+enum { VEC_MODE_INVALID = 45 };                // Vector.cpp:43-47
+
+double now_sec()
+{
+    using namespace std::chrono;
+    return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+extern "C" {
+
+// ======================================================================================
+//  error.h
+// ======================================================================================
+
+static spx_errhandler_t g_handler = err_handle;
+
+static const char *const kErrors[] = {
+    "invalid argument", "file error", "loading of input matrix failed",
+    "conversion to CSX failed", "vector creation failed",
+    "partitioning object wasn't properly created",
+    "reordering failed to produce a permutation",
+    "incompatible matrix and vector dimensions", "incompatible vector dimensions",
+    "matrix entry doesn't exist", "index out of bounds", "dummy", "dummy", "dummy",
+    "failed to open file", "failed to read from file", "failed to write to file",
+    "memory allocation failed", "memory deallocation failed"};
+static const char *const kWarnings[] = {
+    "no specific file given to save CSX, using default: \"csx_file\"",
+    "invalid tuning option", "invalid runtime option",
+    "reordering wasn't feasible on this matrix", "entry not set"};
+
+static const char *default_message(spx_error_t code)
+{
+    if (code > SPX_ERR_MIN_VALUE && code < SPX_ERR_MAX_VALUE)
+        return kErrors[code - SPX_ERR_MIN_VALUE - 1];
+    if (code > SPX_ERR_MAX_VALUE && code < SPX_WARN_MAX_VALUE)
+        return kWarnings[code - SPX_ERR_MAX_VALUE - 1];
+    return NULL;
+}
+
+void err_handle(spx_error_t code, const char *sourcefile, unsigned long lineno,
+                const char *function, const char *fmt, ...)
+{
+    // library errors are reported and returned, OS-level errors are fatal,
+    // warnings are reported (reference src/api/error.c:64-88)
+    int errno_saved = errno;
+    if (!fmt) fmt = default_message(code);
+    if (!fmt) fmt = "unknown error code";
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    size_t len = strlen(buf);
+    bool is_sys = code > SPX_ERR_SYSTEM && code < SPX_ERR_MAX_VALUE;
+    if (is_sys) {
+        snprintf(buf + len, sizeof(buf) - len, ": %s", strerror(errno_saved));
+        len = strlen(buf);
+    }
+    snprintf(buf + len, sizeof(buf) - len, " [\"%s\":%ld:%s()]\n", sourcefile,
+             (long) lineno, function);
+    if (code > SPX_ERR_MIN_VALUE && code < SPX_ERR_MAX_VALUE) {
+        log_msg(LOG_ERR, "%s", buf);
+        if (is_sys) exit(1);
+    } else if (code > SPX_ERR_MAX_VALUE && code < SPX_WARN_MAX_VALUE) {
+        log_msg(LOG_WARN, "%s", buf);
+    }
+}
+
+spx_errhandler_t spx_err_get_handler() { return g_handler; }
+
+void spx_err_set_handler(spx_errhandler_t new_handler)
+{
+    g_handler = new_handler ? new_handler : err_handle;
+}
+
+// ======================================================================================
+//  common.h
+// ======================================================================================
+
+void spx_log_disable_all() { log_set_level(LOG_NONE); }
+void spx_log_error_console() { log_set_file(NULL); log_set_level(LOG_ERR); }
+void spx_log_warning_console() { log_set_file(NULL); log_set_level(LOG_WARN); }
+void spx_log_info_console() { log_set_file(NULL); log_set_level(LOG_INFO); }
+void spx_log_verbose_console() { log_set_file(NULL); log_set_level(LOG_VERB); }
+void spx_log_debug_console() { log_set_file(NULL); log_set_level(LOG_DBG); }
+static const char *g_logfile = "sparsex.log";
+void spx_log_error_file() { log_set_file(g_logfile); log_set_level(LOG_ERR); }
+void spx_log_warning_file() { log_set_file(g_logfile); log_set_level(LOG_WARN); }
+void spx_log_info_file() { log_set_file(g_logfile); log_set_level(LOG_INFO); }
+void spx_log_verbose_file() { log_set_file(g_logfile); log_set_level(LOG_VERB); }
+void spx_log_debug_file() { log_set_file(g_logfile); log_set_level(LOG_DBG); }
+void spx_log_all_console() { log_set_file(NULL); log_set_level(LOG_DBG); }
+void spx_log_all_file(const char *file)
+{
+    log_set_file(file ? file : g_logfile);
+    log_set_level(LOG_DBG);
+}
+void spx_log_set_file(const char *file) { log_set_file(file); }
+
+void spx_init() { log_set_level(LOG_WARN); }
+void spx_finalize() {}
+
+void *malloc_internal(size_t x, const char *sourcefile, unsigned long lineno,
+                      const char *function)
+{
+    void *ret = malloc(x);
+    if (!ret) {
+        err_handle(SPX_ERR_MEM_ALLOC, sourcefile, lineno, function, NULL);
+        exit(1);
+    }
+    return ret;
+}
+
+void free_internal(void *ptr, const char *sourcefile, unsigned long lineno,
+                   const char *function)
+{
+    if (!ptr) {
+        err_handle(SPX_ERR_MEM_FREE, sourcefile, lineno, function, NULL);
+        exit(1);
+    }
+    free(ptr);
+}
+
+// ======================================================================================
+//  input
+// ======================================================================================
+
+spx_input_t *spx_input_load_csr(const spx_index_t *rowptr, const spx_index_t *colind,
+                                const spx_value_t *values, spx_index_t nrows,
+                                spx_index_t ncols, ...)
+{
+    va_list ap;
+    va_start(ap, ncols);
+    spx_option_t indexing = va_arg(ap, spx_option_t);
+    va_end(ap);
+    // The optional flag selects 0- or 1-based arrays; anything else means
+    // 0-based.  (The reference subtracts SPX_INDEX_ZERO_BASED before
+    // validating, src/api/matvec.c:174-177, which makes every input 0-based;
+    // the documented meaning is implemented here.)
+    bool one_based = (indexing == SPX_INDEX_ONE_BASED);
+
+    if (!check_mat_dim(nrows) || !check_mat_dim(ncols)) {
+        SETERROR_1(SPX_ERR_ARG_INVALID, "invalid matrix dimensions");
+        return SPX_INVALID_INPUT;
+    }
+    if (!rowptr) {
+        SETERROR_1(SPX_ERR_ARG_INVALID, "invalid rowptr argument");
+        return SPX_INVALID_INPUT;
+    }
+    if (!colind) {
+        SETERROR_1(SPX_ERR_ARG_INVALID, "invalid colind argument");
+        return SPX_INVALID_INPUT;
+    }
+    if (!values) {
+        SETERROR_1(SPX_ERR_ARG_INVALID, "invalid values argument");
+        return SPX_INVALID_INPUT;
+    }
+    spx_input_t *A = new input;
+    A->type = 'C';
+    A->nrows = nrows;
+    A->ncols = ncols;
+    A->nnz = rowptr[nrows] - (one_based ? 1 : 0);
+    A->mat = new CsrInput(rowptr, colind, values, nrows, ncols, !one_based);
+    return A;
+}
+
+spx_input_t *spx_input_load_mmf(const char *filename)
+{
+    if (!filename) {
+        SETERROR_0(SPX_ERR_FILE);
+        return SPX_INVALID_INPUT;
+    }
+    if (access(filename, F_OK | R_OK) == -1) {
+        SETERROR_0(SPX_ERR_FILE);
+        return SPX_INVALID_INPUT;
+    }
+    MmfInput *m = nullptr;
+    try {
+        m = new MmfInput(filename);
+    } catch (const FatalError &) {
+        SETERROR_1(SPX_ERR_INPUT_MAT, "loading matrix from MMF file failed");
+        return SPX_INVALID_INPUT;
+    }
+    spx_input_t *A = new input;
+    A->type = 'M';
+    A->mat = m;
+    A->nrows = (spx_index_t) m->nr_rows;
+    A->ncols = (spx_index_t) m->nr_cols;
+    A->nnz = (spx_index_t) m->nnz;
+    return A;
+}
+
+spx_error_t spx_input_destroy(spx_input_t *A)
+{
+    if (!A) {
+        SETERROR_1(SPX_ERR_ARG_INVALID, "invalid input handle");
+        return SPX_FAILURE;
+    }
+    delete A->mat;
+    delete A;
+    return SPX_SUCCESS;
+}
+
+// ======================================================================================
+//  tuning
+// ======================================================================================
+
+static void encode_partition(Partition &p, const EncoderParams &prm, const XformSeq &seq,
+                             std::ostream *log)
+{
+    Encoder enc(&p, prm);
+    if (seq.explicit_deltas) {
+        enc.encode_serial(seq);
+    } else {
+        enc.remove_ignore(seq);
+        enc.encode_all(log);
+    }
+}
+
+static spx_matrix_t *do_tune(spx_input_t *in)
+{
+    Config &cfg = Config::instance();
+    const double t0 = now_sec();
+    const size_t P = cfg.nr_partitions();
+    long world = std::max<long>(1, cfg.get_long("spx.rt.gpu_world"));
+    long rank = cfg.get_long("spx.rt.gpu_rank");
+    if (rank < 0 || rank >= world || P % (size_t) world != 0) {
+        log_msg(LOG_ERR, "spx.rt.gpu_rank/gpu_world (%ld/%ld) do not divide "
+                "spx.rt.nr_threads=%zu partitions\n", rank, world, P);
+        throw FatalError("bad gpu_rank/gpu_world");
+    }
+    const size_t first = (size_t) rank * (P / (size_t) world);
+    const size_t last = first + P / (size_t) world;
+    const bool sym = cfg.get_bool("spx.matrix.symmetric");
+    const bool host_only = cfg.get_bool("spx.rt.host_only");
+    EncoderParams prm = EncoderParams::from_config(cfg);
+    XformSeq seq = cfg.xform();
+    cfg.cpu_affinity();   // validates the list
+    log_msg(LOG_INFO, "Format: %s\n", sym ? "CSX-sym" : "CSX");
+    if (!host_only && device_count() <= 0) {
+        log_msg(LOG_ERR, "no usable HIP device: this library multiplies on an MI355X "
+                "only (spx.rt.host_only=true preprocesses without one)\n");
+        throw FatalError("no HIP device");
+    }
+
+    std::unique_ptr<matrix> A(new matrix);
+    A->nrows = in->nrows;
+    A->ncols = in->ncols;
+    A->nnz = in->nnz;
+    A->symmetric = sym ? 1 : 0;
+    A->permutation = SPX_INVALID_PERM;
+    A->nr_partitions = P;
+    A->first_part = first;
+    A->last_part = last;
+    A->full_colind = cfg.get_bool("spx.matrix.full_colind");
+    A->dev = nullptr;
+
+    const size_t nown = last - first;
+    std::vector<std::ostringstream> logs(nown);
+    std::vector<std::string> errors(nown);
+    std::vector<PartitionSym> sparts;
+    if (sym) {
+        build_partitions_sym(*in->mat, P, first, last, sparts, A->bounds);
+        A->diag.resize(nown);
+    } else {
+        build_partitions(*in->mat, P, first, last, A->parts, A->bounds);
+    }
+
+    // one preprocessing thread per owned partition, as the reference does
+    // (CsxBuild.hpp:290-326, :344-380)
+    auto work = [&](size_t i) {
+        try {
+            std::ostream *lg = &logs[i];
+            *lg << "==> Thread: #" << (first + i) << "\n==== ENCODING STATISTICS ====\n";
+            if (sym) {
+                PartitionSym &ps = sparts[i];
+                ps.divide();
+                // the first partition has nothing left of its own rows
+                // (CsxBuild.hpp:236-244)
+                Encoder e1(&ps.m1, prm), e2(&ps.m2, prm);
+                if (seq.explicit_deltas) {
+                    e1.encode_serial(seq);
+                    e2.encode_serial(seq);
+                } else {
+                    e1.remove_ignore(seq);
+                    e2.remove_ignore(seq);
+                    if (first + i) e1.encode_all(lg);
+                    e2.encode_all(lg);
+                }
+                ps.merge();
+            } else {
+                encode_partition(A->parts[i], prm, seq, lg);
+            }
+        } catch (const FatalError &e) {
+            errors[i] = e.what;
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (size_t i = 1; i < nown; ++i) th.emplace_back(work, i);
+        if (nown) work(0);
+        for (auto &t : th) t.join();
+    }
+    for (auto &e : errors)
+        if (!e.empty()) throw FatalError(e);
+    if (sym) {
+        A->parts.resize(nown);
+        for (size_t i = 0; i < nown; ++i) {
+            A->parts[i] = std::move(sparts[i].lower);
+            A->diag[i] = std::move(sparts[i].diagonal);
+        }
+    }
+    for (size_t i = 0; i < nown; ++i) A->log += logs[i].str();
+    log_msg(LOG_VERB, "%s", A->log.c_str());
+    A->tune_seconds = now_sec() - t0;
+
+    // descriptor stream + upload
+    const double t1 = now_sec();
+    GpuEmitParams gp;
+    gp.target_elems = (size_t) std::max<long>(64, cfg.get_long("spx.gpu.rowblock_elems"));
+    gp.max_rows = (size_t) std::max<long>(1, cfg.get_long("spx.gpu.rowblock_rows"));
+    GpuStream gs;
+    if (sym) gs.dvalues.assign((size_t) A->nrows, 0.0);
+    for (size_t i = 0; i < nown; ++i) {
+        emit_gpu(A->parts[i], gp, gs);
+        if (sym) {
+            const PartBounds &b = A->bounds[first + i];
+            for (size_t r = 0; r < A->diag[i].size() && r < (size_t) b.nr_rows; ++r)
+                gs.dvalues[(size_t) b.row_start + r] = A->diag[i][r];
+        }
+    }
+    A->nnz_stored = gs.nnz_stored;
+    A->n_unit_elems = gs.n_unit_elems;
+    A->n_delta_elems = gs.n_delta_elems;
+    A->n_units = gs.n_units;
+    A->value_bytes = gs.values.size() * sizeof(val_t);
+    A->index_bytes = gs.index_bytes();
+    A->n_rowblocks = gs.rbs.size();
+    A->n_shared = gs.shared.size();
+    if (!host_only) {
+        idx_t lo = nown ? A->bounds[first].row_start : 0;
+        idx_t hi = nown ? A->bounds[last - 1].row_start + A->bounds[last - 1].nr_rows : 0;
+        if (last == P) hi = A->nrows;     // trailing empty rows belong to the last slice
+        A->dev = device_upload(gs, (size_t) A->nrows, (size_t) A->ncols, sym, lo, hi,
+                               (int) cfg.get_long("spx.rt.device"));
+    }
+    if (!cfg.get_bool("spx.rt.keep_encoded")) {
+        A->parts.clear();
+        A->parts.shrink_to_fit();
+    }
+    A->emit_seconds = now_sec() - t1;
+    return A.release();
+}
+
+spx_matrix_t *spx_mat_tune(spx_input_t *in, ...)
+{
+    if (!in) {
+        SETERROR_1(SPX_ERR_ARG_INVALID, "invalid input matrix");
+        return SPX_INVALID_MAT;
+    }
+    va_list ap;
+    va_start(ap, in);
+    spx_option_t option = va_arg(ap, spx_option_t);
+    va_end(ap);
+    if (option == SPX_MAT_REORDER) {
+        // RCM reordering (reference Rcm.hpp, Boost.Graph) is outside this
+        // build's scope; the matrix is tuned in its given order
+        SETWARNING(SPX_WARN_REORDER);
+    }
+    spx_matrix_t *A = SPX_INVALID_MAT;
+    try {
+        A = do_tune(in);
+    } catch (const FatalError &e) {
+        SETERROR_0(SPX_ERR_TUNED_MAT);
+        return SPX_INVALID_MAT;
+    }
+    return A;
+}
+
+spx_error_t spx_mat_destroy(spx_matrix_t *A)
+{
+    if (!A) {
+        SETERROR_1(SPX_ERR_ARG_INVALID, "invalid matrix handle");
+        return SPX_FAILURE;
+    }
+    try { device_free(A->dev); } catch (...) {}
+    if (A->permutation) free(A->permutation);
+    delete A;
+    return SPX_SUCCESS;
+}
+
+// get/set entry, save/restore: not on the tune/matvec path
+spx_error_t spx_mat_get_entry(const spx_matrix_t *A, spx_index_t row, spx_index_t column,
+                              spx_value_t *value, ...)
+{
+    if (!A) {
+        SETERROR_1(SPX_ERR_ARG_INVALID, "invalid matrix handle");
+        return SPX_FAILURE;
+    }
+    (void) row; (void) column; (void) value;
+    SETERROR_1(SPX_ERR_ENTRY_NOT_FOUND, "spx_mat_get_entry is not available in this build");
+    return SPX_FAILURE;
+}
+
+spx_error_t spx_mat_set_entry(spx_matrix_t *A, spx_index_t row, spx_index_t column,
+                              spx_value_t value, ...)
+{
+    if (!A) {
+        SETERROR_1(SPX_ERR_ARG_INVALID, "invalid matrix handle");
+        return SPX_FAILURE;
+    }
+    (void) row; (void) column; (void) value;
+    SETERROR_1(SPX_ERR_ENTRY_NOT_FOUND, "spx_mat_set_entry is not available in this build");
+    return SPX_FAILURE;
+}
+
+spx_error_t spx_mat_save(const spx_matrix_t *A, const char *filename)
+{
+    if (!A) {
+        SETERROR_1(SPX_ERR_ARG_INVALID, "invalid matrix handle");
+        return SPX_FAILURE;
+    }
+    (void) filename;
+    SETERROR_1(SPX_ERR_FILE_WRITE, "spx_mat_save is not available in this build");
+    return SPX_FAILURE;
+}
+
+spx_matrix_t *spx_mat_restore(const char *filename)
+{
+    (void) filename;
+    SETERROR_1(SPX_ERR_FILE, "spx_mat_restore is not available in this build");
+    return SPX_INVALID_MAT;
+}
+
+spx_index_t spx_mat_get_nrows(const spx_matrix_t *A)
+{
+    if (!A) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid matrix handle"); return SPX_FAILURE; }
+    return A->nrows;
+}
+
+spx_index_t spx_mat_get_ncols(const spx_matrix_t *A)
+{
+    if (!A) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid matrix handle"); return SPX_FAILURE; }
+    return A->ncols;
+}
+
+spx_index_t spx_mat_get_nnz(const spx_matrix_t *A)
+{
+    if (!A) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid matrix handle"); return SPX_FAILURE; }
+    return A->nnz;
+}
+
+static spx_partition_t *part_alloc(size_t n)
+{
+    spx_partition_t *p = (spx_partition_t *) malloc(sizeof(spx_partition_t));
+    p->nr_partitions = n;
+    p->parts = NULL;
+    p->nodes = NULL;
+    p->affinity = NULL;
+    p->row_start = (spx_index_t *) malloc(sizeof(spx_index_t) * (n ? n : 1));
+    p->row_end = (spx_index_t *) malloc(sizeof(spx_index_t) * (n ? n : 1));
+    return p;
+}
+
+spx_partition_t *spx_mat_get_partition(const spx_matrix_t *A)
+{
+    if (!A) {
+        SETERROR_1(SPX_ERR_ARG_INVALID, "invalid matrix handle");
+        return SPX_INVALID_PART;
+    }
+    spx_partition_t *p = part_alloc(A->nr_partitions);
+    for (size_t i = 0; i < A->nr_partitions; ++i) {
+        p->row_start[i] = A->bounds[i].row_start;
+        p->row_end[i] = A->bounds[i].row_start + A->bounds[i].nr_rows;
+    }
+    return p;
+}
+
+spx_index_t *spx_partition_get_rs(const spx_partition_t *p)
+{
+    if (!p) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid partition handle"); return NULL; }
+    return p->row_start;
+}
+
+spx_index_t *spx_partition_get_re(const spx_partition_t *p)
+{
+    if (!p) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid partition handle"); return NULL; }
+    return p->row_end;
+}
+
+spx_perm_t *spx_mat_get_perm(const spx_matrix_t *A)
+{
+    if (!A) {
+        SETERROR_1(SPX_ERR_ARG_INVALID, "invalid matrix handle");
+        return SPX_INVALID_PERM;
+    }
+    if (!A->permutation) {
+        SETERROR_1(SPX_ERR_ARG_INVALID, "a permutation is not available");
+        return SPX_INVALID_PERM;
+    }
+    return A->permutation;
+}
+
+spx_partition_t *spx_partition_csr(const spx_index_t *rowptr, spx_index_t nr_rows,
+                                   size_t nr_threads)
+{
+    // src/api/matvec.c:689-737
+    spx_partition_t *ret = part_alloc(nr_threads);
+    size_t nnz_per_split = (size_t)(rowptr[nr_rows] - 1) / nr_threads;
+    size_t curr_nnz = 0, row_start = 0, split_cnt = 0;
+    spx_index_t i;
+    ret->row_start[0] = 0;
+    for (i = 0; i < nr_rows; i++) {
+        curr_nnz += (size_t)(rowptr[i + 1] - rowptr[i]);
+        if (curr_nnz >= nnz_per_split && split_cnt < nr_threads) {
+            ret->row_end[split_cnt] = i + 1;
+            row_start = (size_t) i + 1;
+            curr_nnz = 0;
+            ++split_cnt;
+            if (split_cnt < nr_threads) ret->row_start[split_cnt] = (spx_index_t) row_start;
+        }
+    }
+    if (curr_nnz < nnz_per_split && split_cnt < nr_threads)
+        ret->row_end[split_cnt] = i + 1;
+    return ret;
+}
+
+spx_error_t spx_partition_destroy(spx_partition_t *p)
+{
+    if (!p) {
+        SETERROR_1(SPX_ERR_ARG_INVALID, "invalid partition handle");
+        return SPX_FAILURE;
+    }
+    free(p->parts); free(p->nodes); free(p->affinity);
+    free(p->row_start); free(p->row_end);
+    free(p);
+    return SPX_SUCCESS;
+}
+
+// ======================================================================================
+//  options
+// ======================================================================================
+
+void spx_option_set(const char *option, const char *value)
+{
+    if (!option || !value) { SETWARNING(SPX_WARN_TUNING_OPT); return; }
+    try {
+        Config::instance().set(option, value);
+    } catch (const FatalError &) {
+        exit(1);    // invalid enumerated value: the reference exits (Encodings.cpp:171-186)
+    }
+}
+
+void spx_options_set_from_env()
+{
+    try {
+        Config::instance().load_from_env();
+    } catch (const FatalError &) {
+        exit(1);
+    }
+}
+
+void spx_hip_options_reset(void) { Config::instance().reset_defaults(); }
+
+// ======================================================================================
+//  SpMV
+// ======================================================================================
+
+static spx_error_t check_mv(const spx_matrix_t *A, const spx_vector_t *x, spx_vector_t *y)
+{
+    if (!A) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid matrix handle"); return SPX_FAILURE; }
+    if (!x) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid vector x"); return SPX_FAILURE; }
+    if (!y) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid vector y"); return SPX_FAILURE; }
+    // Either vector of the wrong length is rejected.  (The reference tests
+    // `!x_ok && !y_ok`, src/api/matvec.c:571, and so lets a single mismatch
+    // through to an out-of-bounds access; a GPU kernel must not do that.)
+    if (!check_vec_dim(x, (unsigned long) A->ncols) ||
+        !check_vec_dim(y, (unsigned long) A->nrows)) {
+        SETERROR_0(SPX_ERR_DIM);
+        return SPX_FAILURE;
+    }
+    return SPX_SUCCESS;
+}
+
+static spx_error_t run_host(const spx_matrix_t *A, spx_value_t alpha, const spx_vector_t *x,
+                            spx_value_t beta, spx_vector_t *y)
+{
+    if (!A->dev) {
+        SETERROR_1(SPX_ERR_TUNED_MAT,
+                   "matrix was tuned with spx.rt.host_only=true: no HIP executor");
+        return SPX_FAILURE;
+    }
+    try {
+        device_spmv_host(A->dev, alpha, x->elements, beta, y->elements);
+    } catch (const FatalError &e) {
+        SETERROR_1(SPX_ERR_TUNED_MAT, e.what.c_str());
+        return SPX_FAILURE;
+    }
+    return SPX_SUCCESS;
+}
+
+spx_error_t spx_matvec_mult(spx_value_t alpha, const spx_matrix_t *A, const spx_vector_t *x,
+                            spx_vector_t *y)
+{
+    if (check_mv(A, x, y) != SPX_SUCCESS) return SPX_FAILURE;
+    return run_host(A, alpha, x, 0.0, y);
+}
+
+spx_error_t spx_matvec_kernel(spx_value_t alpha, const spx_matrix_t *A, const spx_vector_t *x,
+                              spx_value_t beta, spx_vector_t *y)
+{
+    if (check_mv(A, x, y) != SPX_SUCCESS) return SPX_FAILURE;
+    return run_host(A, alpha, x, beta, y);
+}
+
+spx_error_t spx_matvec_kernel_csr(spx_matrix_t **A, spx_index_t nrows, spx_index_t ncols,
+                                  const spx_index_t *rowptr, const spx_index_t *colind,
+                                  const spx_value_t *values, spx_value_t alpha,
+                                  const spx_vector_t *x, spx_value_t beta, spx_vector_t *y)
+{
+    if (!x) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid vector x"); return SPX_FAILURE; }
+    if (!y) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid vector y"); return SPX_FAILURE; }
+    if (!A) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid matrix handle"); return SPX_FAILURE; }
+    if (!*A) {
+        if (!check_mat_dim(nrows) || !check_mat_dim(ncols)) {
+            SETERROR_1(SPX_ERR_ARG_INVALID, "invalid matrix dimensions");
+            return SPX_FAILURE;
+        }
+        if (!rowptr) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid rowptr argument"); return SPX_FAILURE; }
+        if (!colind) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid colind argument"); return SPX_FAILURE; }
+        if (!values) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid values argument"); return SPX_FAILURE; }
+        spx_input_t *in = spx_input_load_csr(rowptr, colind, values, nrows, ncols,
+                                             SPX_INDEX_ZERO_BASED);
+        if (!in) return SPX_FAILURE;
+        *A = spx_mat_tune(in, 0);
+        spx_input_destroy(in);
+        if (!*A) return SPX_FAILURE;
+    }
+    return spx_matvec_kernel(alpha, *A, x, beta, y);
+}
+
+static spx_error_t check_dev(const spx_matrix_t *A, const void *x, const void *y)
+{
+    if (!A) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid matrix handle"); return SPX_FAILURE; }
+    if (!x) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid vector x"); return SPX_FAILURE; }
+    if (!y) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid vector y"); return SPX_FAILURE; }
+    if (!A->dev) {
+        SETERROR_1(SPX_ERR_TUNED_MAT,
+                   "matrix was tuned with spx.rt.host_only=true: no HIP executor");
+        return SPX_FAILURE;
+    }
+    return SPX_SUCCESS;
+}
+
+spx_error_t spx_hip_matvec_mult(spx_value_t alpha, const spx_matrix_t *A,
+                                const spx_value_t *x_dev, spx_value_t *y_dev, void *stream)
+{
+    return spx_hip_matvec_kernel(alpha, A, x_dev, 0.0, y_dev, stream);
+}
+
+spx_error_t spx_hip_matvec_kernel(spx_value_t alpha, const spx_matrix_t *A,
+                                  const spx_value_t *x_dev, spx_value_t beta,
+                                  spx_value_t *y_dev, void *stream)
+{
+    if (check_dev(A, x_dev, y_dev) != SPX_SUCCESS) return SPX_FAILURE;
+    try {
+        device_spmv(A->dev, alpha, x_dev, beta, y_dev, stream);
+    } catch (const FatalError &e) {
+        SETERROR_1(SPX_ERR_TUNED_MAT, e.what.c_str());
+        return SPX_FAILURE;
+    }
+    return SPX_SUCCESS;
+}
+
+// ======================================================================================
+//  extensions: info / export
+// ======================================================================================
+
+spx_error_t spx_hip_mat_info(const spx_matrix_t *A, spx_hip_info_t *info)
+{
+    if (!A || !info) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid argument"); return SPX_FAILURE; }
+    memset(info, 0, sizeof(*info));
+    info->nnz = A->nnz;
+    info->nnz_stored = (int64_t) A->nnz_stored;
+    info->n_unit_elems = (int64_t) A->n_unit_elems;
+    info->n_delta_elems = (int64_t) A->n_delta_elems;
+    info->n_units = (int64_t) A->n_units;
+    info->n_rowblocks = (int64_t) A->n_rowblocks;
+    info->n_shared_rows = (int64_t) A->n_shared;
+    info->value_bytes = (int64_t) A->value_bytes;
+    info->index_bytes = (int64_t) A->index_bytes;
+    info->nr_partitions = (int32_t) A->nr_partitions;
+    info->first_partition = (int32_t) A->first_part;
+    info->last_partition = (int32_t) A->last_part;
+    if (A->last_part > A->first_part) {
+        info->row_lo = A->bounds[A->first_part].row_start;
+        const PartBounds &b = A->bounds[A->last_part - 1];
+        info->row_hi = (A->last_part == A->nr_partitions) ? A->nrows
+                                                           : b.row_start + b.nr_rows;
+    }
+    info->symmetric = A->symmetric;
+    info->on_device = A->dev ? 1 : 0;
+    if (A->dev) {
+        DeviceMatrixInfo di;
+        device_info(A->dev, di);
+        info->device = di.device;
+    }
+    info->tune_seconds = A->tune_seconds;
+    info->emit_seconds = A->emit_seconds;
+    return SPX_SUCCESS;
+}
+
+static bool owned_part(const spx_matrix_t *A, int part)
+{
+    return part >= (int) A->first_part && part < (int) A->last_part &&
+           (size_t)(part - (int) A->first_part) < A->parts.size();
+}
+
+spx_error_t spx_hip_mat_export_csx(const spx_matrix_t *A_, int part, spx_csx_export_t *out)
+{
+    spx_matrix_t *A = const_cast<spx_matrix_t *>(A_);
+    if (!A || !out) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid argument"); return SPX_FAILURE; }
+    if (!owned_part(A, part)) {
+        SETERROR_1(SPX_ERR_ARG_INVALID, "partition not held by this process "
+                   "(or dropped: spx.rt.keep_encoded=false)");
+        return SPX_FAILURE;
+    }
+    std::lock_guard<std::mutex> lk(A->mtx);
+    size_t li = (size_t) part - A->first_part;
+    if (A->exported.size() < A->parts.size()) {
+        A->exported.resize(A->parts.size());
+        A->exported_rows_info.resize(A->parts.size());
+    }
+    if (!A->exported[li]) {
+        std::unique_ptr<CsxStream> s(new CsxStream);
+        emit_csx(A->parts[li], A->full_colind, A->symmetric != 0, *s);
+        if (A->symmetric) {
+            s->dvalues = A->diag[li];
+            s->dvalues.resize((size_t) s->nrows, 0.0);
+        }
+        std::vector<spx_index_t> &ri = A->exported_rows_info[li];
+        ri.resize(s->rows_info.size() * 3);
+        for (size_t i = 0; i < s->rows_info.size(); ++i) {
+            ri[3 * i] = s->rows_info[i].rowptr;
+            ri[3 * i + 1] = s->rows_info[i].valptr;
+            ri[3 * i + 2] = s->rows_info[i].span;
+        }
+        A->exported[li] = std::move(s);
+    }
+    const CsxStream &s = *A->exported[li];
+    memset(out, 0, sizeof(*out));
+    out->values = s.values.data();
+    out->ctl = s.ctl.data();
+    out->ctl_size = (int64_t) s.ctl.size();
+    out->nnz = s.nnz;
+    out->ncols = s.ncols;
+    out->nrows = s.nrows;
+    out->row_start = s.row_start;
+    out->row_jumps = s.row_jumps;
+    out->full_colind = s.full_colind;
+    for (int i = 0; i < 64; ++i) out->id_map[i] = s.id_map[i];
+    out->rows_info = A->exported_rows_info[li].data();
+    out->dvalues = A->symmetric ? s.dvalues.data() : NULL;
+    return SPX_SUCCESS;
+}
+
+int64_t spx_hip_mat_export_units(const spx_matrix_t *A, int part, spx_unit_record_t *recs,
+                                 int64_t cap)
+{
+    if (!A || !owned_part(A, part)) {
+        SETERROR_1(SPX_ERR_ARG_INVALID, "partition not held by this process");
+        return -1;
+    }
+    const Partition &p = A->parts[(size_t) part - A->first_part];
+    for (size_t i = 0; i < p.elems_size && (int64_t) i < cap && recs; ++i) {
+        const Elem &e = p.elems[i];
+        recs[i].type = e.type;
+        recs[i].delta = (int32_t) e.delta;
+        recs[i].size = e.size;
+        recs[i].row = e.row;
+        recs[i].col = e.col;
+    }
+    return (int64_t) p.elems_size;
+}
+
+const char *spx_hip_mat_tune_log(const spx_matrix_t *A)
+{
+    return A ? A->log.c_str() : "";
+}
+
+// ======================================================================================
+//  vectors (host side; reference src/internals/Vector.cpp)
+// ======================================================================================
+
+static spx_vector_t *vec_alloc(size_t size)
+{
+    spx_vector_t *v = (spx_vector_t *) malloc(sizeof(spx_vector_t));
+    if (!v) { log_msg(LOG_ERR, "malloc failed\n"); exit(1); }
+    v->elements = (spx_value_t *) calloc(size ? size : 1, sizeof(spx_value_t));
+    if (!v->elements) { log_msg(LOG_ERR, "malloc failed\n"); exit(1); }
+    v->size = size;
+    v->alloc_type = ALLOC_STD;
+    v->vec_mode = VEC_MODE_INVALID;
+    return v;
+}
+
+spx_vector_t *spx_vec_create(size_t size, const spx_partition_t *p)
+{
+    if (p == SPX_INVALID_PART) {
+        SETERROR_1(SPX_ERR_ARG_INVALID, "invalid partition handle");
+        return SPX_INVALID_VEC;
+    }
+    return vec_alloc(size);
+}
+
+spx_vector_t *spx_vec_create_from_buff(spx_value_t *buff, spx_value_t **tuned, size_t size,
+                                       const spx_partition_t *p, spx_vecmode_t mode)
+{
+    if (!buff) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid buffer"); return SPX_INVALID_VEC; }
+    if (!check_vecmode(mode)) {
+        SETERROR_1(SPX_ERR_ARG_INVALID, "invalid vector mode");
+        return SPX_INVALID_VEC;
+    }
+    if (p == SPX_INVALID_PART && mode == SPX_VEC_TUNE) {
+        SETERROR_1(SPX_ERR_ARG_INVALID, "invalid partition handle");
+        return SPX_INVALID_VEC;
+    }
+    // both modes alias the user buffer, as on the reference's non-NUMA build
+    spx_vector_t *v = (spx_vector_t *) malloc(sizeof(spx_vector_t));
+    if (!v) { log_msg(LOG_ERR, "malloc failed\n"); exit(1); }
+    v->elements = buff;
+    v->size = size;
+    v->alloc_type = ALLOC_OTHER;
+    v->vec_mode = (int) mode;
+    if (tuned) *tuned = buff;
+    return v;
+}
+
+void spx_vec_init_rand_range(spx_vector_t *v, spx_value_t max, spx_value_t min)
+{
+    for (size_t i = 0; i < v->size; i++) {
+        spx_value_t val = ((spx_value_t)(rand() + i) / ((spx_value_t) RAND_MAX + 1));
+        v->elements[i] = min + val * (max - min);
+    }
+}
+
+spx_vector_t *spx_vec_create_random(size_t size, const spx_partition_t *p)
+{
+    if (p == SPX_INVALID_PART) {
+        SETERROR_1(SPX_ERR_ARG_INVALID, "invalid partition handle");
+        return SPX_INVALID_VEC;
+    }
+    spx_vector_t *v = vec_alloc(size);
+    // values in (-0.1, 0.1], same argument order as Vector.cpp:161-167
+    spx_vec_init_rand_range(v, (spx_value_t) -0.1, (spx_value_t) 0.1);
+    return v;
+}
+
+void spx_vec_init(spx_vector_t *v, spx_value_t val)
+{
+    for (size_t i = 0; i < v->size; i++) v->elements[i] = val;
+}
+
+void spx_vec_init_part(spx_vector_t *v, spx_value_t val, spx_index_t start, spx_index_t end)
+{
+    for (spx_index_t i = start; i < end; i++) v->elements[i] = val;
+}
+
+spx_error_t spx_vec_set_entry(spx_vector_t *v, spx_index_t idx, spx_value_t val, ...)
+{
+    va_list ap;
+    va_start(ap, val);
+    spx_option_t indexing = va_arg(ap, spx_option_t);
+    va_end(ap);
+    bool one_based = (indexing == SPX_INDEX_ONE_BASED);
+    long pos = (long) idx - (one_based ? 1 : 0);
+    if (!v || pos < 0 || (size_t) pos >= v->size) {
+        SETERROR_0(SPX_OUT_OF_BOUNDS);
+        SETWARNING(SPX_WARN_ENTRY_NOT_SET);
+        return SPX_FAILURE;
+    }
+    v->elements[pos] = val;
+    return SPX_SUCCESS;
+}
+
+void spx_vec_scale(spx_vector_t *v1, spx_vector_t *v2, spx_value_t num)
+{
+    for (size_t i = 0; i < v1->size; i++) v2->elements[i] = num * v1->elements[i];
+}
+
+void spx_vec_scale_add(spx_vector_t *v1, spx_vector_t *v2, spx_vector_t *v3, spx_value_t num)
+{
+    for (size_t i = 0; i < v1->size; i++)
+        v3->elements[i] = v1->elements[i] + num * v2->elements[i];
+}
+
+void spx_vec_scale_add_part(spx_vector_t *v1, spx_vector_t *v2, spx_vector_t *v3,
+                            spx_value_t num, spx_index_t start, spx_index_t end)
+{
+    for (spx_index_t i = start; i < end; i++)
+        v3->elements[i] = v1->elements[i] + num * v2->elements[i];
+}
+
+void spx_vec_add(spx_vector_t *v1, spx_vector_t *v2, spx_vector_t *v3)
+{
+    if (v1->size != v2->size || v1->size != v3->size) {
+        fprintf(stderr, "v1->size=%lu v2->size=%lu v3->size=%lu differ\n",
+                (unsigned long) v1->size, (unsigned long) v2->size, (unsigned long) v3->size);
+        exit(1);
+    }
+    for (size_t i = 0; i < v1->size; i++) v3->elements[i] = v1->elements[i] + v2->elements[i];
+}
+
+void spx_vec_add_part(spx_vector_t *v1, spx_vector_t *v2, spx_vector_t *v3,
+                      spx_index_t start, spx_index_t end)
+{
+    for (spx_index_t i = start; i < end; i++)
+        v3->elements[i] = v1->elements[i] + v2->elements[i];
+}
+
+void spx_vec_sub(spx_vector_t *v1, spx_vector_t *v2, spx_vector_t *v3)
+{
+    for (size_t i = 0; i < v1->size; i++) v3->elements[i] = v1->elements[i] - v2->elements[i];
+}
+
+void spx_vec_sub_part(spx_vector_t *v1, spx_vector_t *v2, spx_vector_t *v3,
+                      spx_index_t start, spx_index_t end)
+{
+    for (spx_index_t i = start; i < end; i++)
+        v3->elements[i] = v1->elements[i] - v2->elements[i];
+}
+
+spx_value_t spx_vec_mul(const spx_vector_t *v1, const spx_vector_t *v2)
+{
+    spx_value_t ret = 0;
+    for (size_t i = 0; i < v1->size; i++) ret += v1->elements[i] * v2->elements[i];
+    return ret;
+}
+
+spx_value_t spx_vec_mul_part(const spx_vector_t *v1, const spx_vector_t *v2,
+                             spx_index_t start, spx_index_t end)
+{
+    spx_value_t ret = 0;
+    for (spx_index_t i = start; i < end; i++) ret += v1->elements[i] * v2->elements[i];
+    return ret;
+}
+
+spx_error_t spx_vec_reorder(spx_vector_t *v, spx_perm_t *p)
+{
+    if (p == SPX_INVALID_PERM) {
+        SETERROR_1(SPX_ERR_ARG_INVALID, "invalid permutation");
+        return SPX_FAILURE;
+    }
+    std::vector<spx_value_t> tmp(v->size);
+    for (size_t i = 0; i < v->size; i++) tmp[(size_t) p[i]] = v->elements[i];
+    memcpy(v->elements, tmp.data(), v->size * sizeof(spx_value_t));
+    return SPX_SUCCESS;
+}
+
+spx_error_t spx_vec_inv_reorder(spx_vector_t *v, spx_perm_t *p)
+{
+    if (p == SPX_INVALID_PERM) {
+        SETERROR_1(SPX_ERR_ARG_INVALID, "invalid permutation");
+        return SPX_FAILURE;
+    }
+    std::vector<spx_value_t> tmp(v->size);
+    for (size_t i = 0; i < v->size; i++) tmp[i] = v->elements[(size_t) p[i]];
+    memcpy(v->elements, tmp.data(), v->size * sizeof(spx_value_t));
+    return SPX_SUCCESS;
+}
+
+void spx_vec_copy(const spx_vector_t *v1, spx_vector_t *v2)
+{
+    memcpy(v2->elements, v1->elements, v1->size * sizeof(spx_value_t));
+}
+
+int spx_vec_compare(const spx_vector_t *v1, const spx_vector_t *v2)
+{
+    // relative tolerance 1e-6 per element (Vector.cpp:51-57, :396-413)
+    if (v1->size != v2->size) {
+        fprintf(stderr, "v1->size=%lu v2->size=%lu differ\n", (unsigned long) v1->size,
+                (unsigned long) v2->size);
+        return -2;
+    }
+    for (size_t i = 0; i < v1->size; i++) {
+        double a = v1->elements[i], b = v2->elements[i];
+        if (fabs((a - b) / a) > 1.e-6) {
+            fprintf(stderr, "element %ld differs: %10.20f != %10.20f\n", (long) i, a, b);
+            return -1;
+        }
+    }
+    return 0;
+}
+
+void spx_vec_print(const spx_vector_t *v)
+{
+    printf("[ ");
+    for (size_t i = 0; i < v->size; i++) printf("%g ", v->elements[i]);
+    printf("]\n");
+}
+
+void spx_vec_destroy(spx_vector_t *v)
+{
+    if (!v) return;
+    if (v->alloc_type == ALLOC_STD) free(v->elements);
+    free(v);
+}
+
+}  // extern "C"

@@ -1,0 +1,191 @@
+// config.cpp -- option table.  Names/defaults: reference Runtime.cpp:37-95
+// (non-NUMA build: heuristic "ratio", full_colind "false").
+#include "config.hpp"
+
+#include <cstdlib>
+#include <regex>
+#include <sstream>
+
+namespace spx {
+
+Config &Config::instance()
+{
+    static Config c;
+    return c;
+}
+
+Config::Config() { reset_defaults(); }
+
+void Config::reset_defaults()
+{
+    props_.clear();
+    props_["spx.rt.nr_threads"] = "1";
+    props_["spx.rt.cpu_affinity"] = "0";
+    props_["spx.preproc.heuristic"] = "ratio";
+    props_["spx.preproc.xform"] = "all";
+    props_["spx.preproc.sampling"] = "portion";
+    props_["spx.preproc.sampling.nr_samples"] = "48";
+    props_["spx.preproc.sampling.portion"] = "0.01";
+    props_["spx.preproc.sampling.window_size"] = "0";
+    props_["spx.matrix.symmetric"] = "false";
+    props_["spx.matrix.split_blocks"] = "true";
+    props_["spx.matrix.full_colind"] = "false";
+    props_["spx.matrix.min_unit_size"] = "4";
+    props_["spx.matrix.max_unit_size"] = "255";
+    props_["spx.matrix.min_coverage"] = "0.1";
+    // no mnemonic in the reference (Runtime.cpp:60); kept settable here
+    props_["spx.matrix.onedim_blocks"] = "false";
+    // ---- extensions of this build (DESIGN.md "Options") ----------------
+    props_["spx.rt.host_only"] = "false";    // tune without uploading to a GPU
+    props_["spx.rt.gpu_rank"] = "0";         // this process' slice of the partitions
+    props_["spx.rt.gpu_world"] = "1";
+    props_["spx.rt.device"] = "-1";          // HIP device ordinal, -1 = current
+    props_["spx.rt.keep_encoded"] = "true";  // keep the encoded partitions for export
+    props_["spx.gpu.rowblock_elems"] = "2048"; // target value elements per row-block
+    props_["spx.gpu.rowblock_rows"] = "512";   // max rows owned by one row-block
+}
+
+bool Config::set(const std::string &key, const std::string &value)
+{
+    auto it = props_.find(key);
+    if (it == props_.end()) {
+        log_msg(LOG_WARN, "mnemonic \"%s\" not found\n", key.c_str());
+        return false;
+    }
+    if (key == "spx.preproc.heuristic" && value != "ratio" && value != "cost") {
+        log_msg(LOG_ERR, "invalid value \"%s\" while setting property "
+                "\"spx.preproc.heuristic\"\n", value.c_str());
+        throw FatalError("invalid heuristic");
+    }
+    if (key == "spx.preproc.sampling" && value != "none" && value != "window" &&
+        value != "portion") {
+        log_msg(LOG_ERR, "invalid value \"%s\" while setting property "
+                "\"spx.preproc.sampling\"\n", value.c_str());
+        throw FatalError("invalid sampling method");
+    }
+    it->second = value;
+    return true;
+}
+
+void Config::load_from_env()
+{
+    const char *s;
+    if ((s = getenv("SYMMETRIC"))) set("spx.matrix.symmetric", s);
+    if ((s = getenv("CPU_AFFINITY"))) set("spx.rt.cpu_affinity", s);
+    if ((s = getenv("NUM_THREADS"))) set("spx.rt.nr_threads", s);
+    if ((s = getenv("XFORM_CONF"))) set("spx.preproc.xform", s);
+    if ((s = getenv("WINDOW_SIZE"))) {
+        set("spx.preproc.sampling", "window");
+        set("spx.preproc.sampling.window_size", s);
+    }
+    if ((s = getenv("SAMPLES"))) set("spx.preproc.sampling.nr_samples", s);
+    if ((s = getenv("SAMPLING_PORTION"))) {
+        set("spx.preproc.sampling", "portion");
+        set("spx.preproc.sampling.portion", s);
+    }
+    if ((s = getenv("SAMPLING"))) set("spx.preproc.sampling", s);
+}
+
+std::string Config::get_str(const std::string &key) const
+{
+    auto it = props_.find(key);
+    if (it == props_.end()) {
+        log_msg(LOG_ERR, "property \"%s\" not found\n", key.c_str());
+        throw FatalError("unknown property");
+    }
+    return it->second;
+}
+
+long Config::get_long(const std::string &key) const
+{
+    std::string v = get_str(key);
+    char *end = nullptr;
+    long r = strtol(v.c_str(), &end, 10);
+    if (end == v.c_str() || *end != '\0') {
+        log_msg(LOG_ERR, "invalid value \"%s\" while setting property \"%s\"\n",
+                v.c_str(), key.c_str());
+        throw FatalError("bad integer property");
+    }
+    return r;
+}
+
+double Config::get_double(const std::string &key) const
+{
+    std::string v = get_str(key);
+    char *end = nullptr;
+    double r = strtod(v.c_str(), &end);
+    if (end == v.c_str() || *end != '\0') {
+        log_msg(LOG_ERR, "invalid value \"%s\" while setting property \"%s\"\n",
+                v.c_str(), key.c_str());
+        throw FatalError("bad floating-point property");
+    }
+    return r;
+}
+
+bool Config::get_bool(const std::string &key) const
+{
+    // `true'/`false' only, like the boolalpha extraction in Runtime.hpp:158-166
+    return get_str(key) == "true";
+}
+
+size_t Config::nr_partitions() const
+{
+    long n = get_long("spx.rt.nr_threads");
+    if (n < 1) n = 1;
+    return (size_t) n;
+}
+
+std::vector<size_t> Config::cpu_affinity() const
+{
+    // Runtime.cpp:151-205: comma list; when its length differs from the
+    // thread count, cpus 1..T-1 are appended to whatever was parsed.
+    std::vector<size_t> aff;
+    std::stringstream ss(get_str("spx.rt.cpu_affinity"));
+    std::string tok;
+    while (std::getline(ss, tok, ',')) {
+        if (tok.empty()) continue;
+        char *end = nullptr;
+        long v = strtol(tok.c_str(), &end, 10);
+        if (end == tok.c_str() || *end != '\0' || v < 0) {
+            log_msg(LOG_ERR, "invalid value \"%s\" while setting property "
+                    "\"spx.rt.cpu_affinity\"\n", tok.c_str());
+            throw FatalError("bad affinity");
+        }
+        aff.push_back((size_t) v);
+    }
+    size_t nt = nr_partitions();
+    if (aff.size() != nt)
+        for (size_t i = 1; i < nt; ++i) aff.push_back(i);
+    return aff;
+}
+
+XformSeq Config::xform() const
+{
+    XformSeq out;
+    const std::string s = get_str("spx.preproc.xform");
+    static const std::regex syntax("([a-z]+([0-9]*))(\\{([0-9]+(,[0-9]+)*)\\})?");
+    auto it = std::sregex_iterator(s.begin(), s.end(), syntax);
+    for (; it != std::sregex_iterator(); ++it) {
+        const std::smatch &m = *it;
+        std::string name = m[1].str();
+        int t = enc_from_short_name(name);
+        if (t < 0) {
+            log_msg(LOG_ERR, "invalid value \"%s\" while setting property "
+                    "\"spx.preproc.xform\"\n", name.c_str());
+            throw FatalError("bad xform name");
+        }
+        XformSpec spec;
+        spec.type = t;
+        std::stringstream ds(m[4].str());
+        std::string tok;
+        while (std::getline(ds, tok, ',')) {
+            if (tok.empty()) continue;
+            out.explicit_deltas = true;
+            spec.deltas.push_back((size_t) strtoul(tok.c_str(), nullptr, 10));
+        }
+        out.seq.push_back(spec);
+    }
+    return out;
+}
+
+}  // namespace spx

@@ -1,0 +1,40 @@
+// device.hpp -- HBM-resident form of a tuned matrix and the launch entry
+// points of the HIP interpreter kernel (implemented in spmv_kernels.hip).
+//
+// Replaces the reference's JIT'd per-partition spmv_fn + thread-pool dispatch
+// (src/internals/CsxKernels.cpp:35-129, src/internals/CsxSpmv.cpp:28-86).
+#pragma once
+
+#include "gpu_emit.hpp"
+
+#include <string>
+
+namespace spx {
+
+struct DeviceMatrix;   // opaque; owns device allocations
+
+// Throws FatalError (message includes the HIP error string) on any failure.
+int device_count();                       // 0 when no usable HIP device
+DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
+                            bool symmetric, idx_t own_row_lo, idx_t own_row_hi,
+                            int device);
+void device_free(DeviceMatrix *m);
+
+// y <- alpha*A*x + beta*y on device pointers, asynchronous on `stream`
+// (a hipStream_t passed as void*; NULL = default stream).
+void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
+                 double *d_y, void *stream);
+
+// host-vector convenience path used by spx_matvec_*: H2D x (and y when
+// beta != 0), kernel, D2H y; synchronous.
+void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x,
+                      double beta, double *h_y);
+
+struct DeviceMatrixInfo {
+    size_t n_rowblocks, n_shared_rows;
+    size_t value_bytes, index_bytes;
+    int device;
+};
+void device_info(const DeviceMatrix *m, DeviceMatrixInfo &info);
+
+}  // namespace spx

@@ -1,0 +1,72 @@
+// gpu_emit.hpp -- re-tiles encoded CSX partitions into the row-block
+// descriptor stream of gpu_format.h (host side; the arrays are uploaded to
+// HBM as they are).
+//
+// Plays the role CsxManager::MakeCsx plays for the CPU format in the
+// reference (include/sparsex/internals/CsxManager.hpp:301-437): it walks the
+// encoded partition and lays units and values out for the executor.
+#pragma once
+
+#include "gpu_format.h"
+#include "partition.hpp"
+
+#include <vector>
+
+namespace spx {
+
+struct GpuStream {
+    std::vector<val_t> values;
+    std::vector<SpxUnitDesc> descs;
+    std::vector<uint32_t> bits;
+    std::vector<uint8_t> cidx;
+    std::vector<uint16_t> segrows;
+    std::vector<SpxRowBlock> rbs;
+    std::vector<SpxSharedRow> shared;
+    uint32_t n_carry = 0;
+    // symmetric path: diagonal of the rows covered by the emitted partitions,
+    // indexed by global row (zero elsewhere)
+    std::vector<val_t> dvalues;
+    // accounting
+    size_t nnz_stored = 0;        // nonzeros held in `values` (without padding)
+    size_t n_unit_elems = 0;
+    size_t n_delta_elems = 0;
+    size_t n_units = 0;
+
+    size_t index_bytes() const
+    {
+        return descs.size() * sizeof(SpxUnitDesc) + bits.size() * 4 + cidx.size() +
+               segrows.size() * 2 + rbs.size() * sizeof(SpxRowBlock);
+    }
+};
+
+struct GpuEmitParams {
+    size_t target_elems = 2048;   // spx.gpu.rowblock_elems
+    size_t max_rows = SPX_MAX_RB_ROWS;   // spx.gpu.rowblock_rows (<= SPX_MAX_RB_ROWS)
+};
+
+// Appends the row-blocks of partition `p` (horizontal order) to `out`.
+// Rows are numbered globally (p.row_start + local row).
+void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out);
+
+// coordinates (1-based, horizontal order) of element k of a unit
+inline void unit_elem_coords(const Elem &u, size_t k, idx_t &r, idx_t &c)
+{
+    const idx_t d = (idx_t) u.delta;
+    switch (u.type) {
+    case ENC_H:  r = u.row;               c = u.col + (idx_t) k * d; return;
+    case ENC_V:  r = u.row + (idx_t) k * d; c = u.col;               return;
+    case ENC_D:  r = u.row + (idx_t) k * d; c = u.col + (idx_t) k * d; return;
+    case ENC_AD: r = u.row + (idx_t) k * d; c = u.col - (idx_t) k * d; return;
+    default: break;
+    }
+    const idx_t a = (idx_t) enc_block_align(u.type);
+    if (enc_is_block_row(u.type)) {        // a rows x delta cols, column-major
+        r = u.row + (idx_t) k % a;
+        c = u.col + (idx_t) k / a;
+    } else {                               // delta rows x a cols, row-major
+        r = u.row + (idx_t) k / a;
+        c = u.col + (idx_t) k % a;
+    }
+}
+
+}  // namespace spx

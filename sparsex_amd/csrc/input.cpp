@@ -1,0 +1,417 @@
+// input.cpp -- see input.hpp.
+#include "input.hpp"
+
+#include <algorithm>
+#include <cassert>
+#include <cstdlib>
+#include <limits>
+#include <sstream>
+
+namespace spx {
+
+// ---- CSR ------------------------------------------------------------------------
+
+CsrInput::CsrInput(const idx_t *rowptr, const idx_t *colind, const val_t *values,
+                   idx_t nrows, idx_t ncols, bool zero_based)
+    : rowptr_(rowptr), colind_(colind), values_(values), zero_based_(zero_based)
+{
+    nr_rows = (size_t) nrows;
+    nr_cols = (size_t) ncols;
+    nnz = (size_t)(rowptr[nrows] - (zero_based ? 0 : 1));   // Csr.hpp:66
+    rewind();
+}
+
+void CsrInput::rewind()
+{
+    row_ = 0;
+    pos_ = 0;
+    sorted_for_row_ = (size_t) -1;
+    skip_empty();
+}
+
+void CsrInput::skip_empty()
+{
+    const idx_t base = zero_based_ ? 0 : 1;
+    while (row_ < nr_rows && pos_ >= (size_t)(rowptr_[row_ + 1] - base)) ++row_;
+}
+
+bool CsrInput::peek(Triplet &t)
+{
+    if (pos_ >= nnz || row_ >= nr_rows) return false;
+    const idx_t base = zero_based_ ? 0 : 1;
+    size_t rs = (size_t)(rowptr_[row_] - base), re = (size_t)(rowptr_[row_ + 1] - base);
+    if (sorted_for_row_ != row_) {
+        bool ascending = true;
+        for (size_t j = rs + 1; j < re; ++j)
+            if (colind_[j] <= colind_[j - 1]) { ascending = false; break; }
+        sorted_row_.clear();
+        if (!ascending) {
+            for (size_t j = rs; j < re; ++j)
+                sorted_row_.push_back(std::make_pair(colind_[j], values_[j]));
+            std::sort(sorted_row_.begin(), sorted_row_.end());
+        }
+        sorted_for_row_ = row_;
+    }
+    t.row = (idx_t) row_ + 1;
+    if (sorted_row_.empty()) {
+        t.col = colind_[pos_] + (zero_based_ ? 1 : 0);
+        t.val = values_[pos_];
+    } else {
+        t.col = sorted_row_[pos_ - rs].first + (zero_based_ ? 1 : 0);
+        t.val = sorted_row_[pos_ - rs].second;
+    }
+    return true;
+}
+
+void CsrInput::advance()
+{
+    ++pos_;
+    skip_empty();
+}
+
+// ---- Matrix Market ------------------------------------------------------------------
+
+static std::string trim(const std::string &s)
+{
+    size_t a = s.find_first_not_of(" \t\r\n");
+    if (a == std::string::npos) return "";
+    size_t b = s.find_last_not_of(" \t\r\n");
+    return s.substr(a, b - a + 1);
+}
+
+bool MmfInput::read_line(std::vector<std::string> &args)
+{
+    std::string buff;
+    if (!std::getline(in_, buff)) return false;
+    buff = trim(buff);
+    args.clear();
+    std::istringstream ss(buff);
+    std::string tok;
+    while (ss >> tok) args.push_back(tok);
+    return true;
+}
+
+static bool parse3(const std::vector<std::string> &a, long &y, long &x, double &v)
+{
+    if (a.size() != 3) return false;
+    char *e1 = nullptr, *e2 = nullptr, *e3 = nullptr;
+    y = strtol(a[0].c_str(), &e1, 10);
+    x = strtol(a[1].c_str(), &e2, 10);
+    v = strtod(a[2].c_str(), &e3);
+    return *e1 == '\0' && *e2 == '\0' && *e3 == '\0';
+}
+
+MmfInput::MmfInput(const char *filename) : filename_(filename)
+{
+    in_.open(filename);
+    if (!in_.is_open()) {
+        log_msg(LOG_ERR, "MMF file error\n");
+        throw FatalError("cannot open MMF file");
+    }
+    std::vector<std::string> args;
+    if (!read_line(args) || args.empty()) {
+        log_msg(LOG_ERR, "size line error in MMF file\n");
+        throw FatalError("empty MMF file");
+    }
+    bool headerless = false;
+    if (args[0] != "%%MatrixMarket") {
+        if (args[0].length() > 2 && args[0][0] == '%' && args[0][1] == '%') {
+            log_msg(LOG_ERR, "invalid header line in MMF file\n");
+            throw FatalError("bad banner");
+        }
+        // no banner: a plain "rows cols nnz" file whose entries must already
+        // be sorted row-major (Mmf.hpp:372-380)
+        headerless = true;
+        col_wise = false;
+    } else {
+        if (args.size() < 5) {
+            log_msg(LOG_ERR, "less arguments in header line of MMF file\n");
+            throw FatalError("short banner");
+        }
+        for (auto &s : args)
+            std::transform(s.begin(), s.end(), s.begin(), ::tolower);
+        if (args[1] != "matrix") {
+            log_msg(LOG_ERR, "unsupported object in header line of MMF file\n");
+            throw FatalError("banner object");
+        }
+        if (args[2] != "coordinate") {
+            log_msg(LOG_ERR, "unsupported matrix format in header line of MMF file\n");
+            throw FatalError("banner format");
+        }
+        if (args[4] == "general") symmetric = false;
+        else if (args[4] == "symmetric") symmetric = true;
+        else {
+            log_msg(LOG_ERR, "unsupported symmetry in header line of MMF file\n");
+            throw FatalError("banner symmetry");
+        }
+        for (size_t i = 5; i < args.size(); ++i) {
+            if (args[i] == "0-base") zero_based = true;
+            else if (args[i] == "1-base") zero_based = false;
+            else if (args[i] == "column") col_wise = true;
+            else if (args[i] == "row") col_wise = false;
+        }
+    }
+    // size line (after optional comment lines)
+    bool skip_comments = !headerless || (!args.empty() && args[0][0] == '%');
+    if (skip_comments) {
+        while (in_.peek() == '%')
+            in_.ignore(std::numeric_limits<std::streamsize>::max(), '\n');
+        if (!read_line(args)) {
+            log_msg(LOG_ERR, "size line error in MMF file\n");
+            throw FatalError("size line");
+        }
+    }
+    long r, c; double n;
+    if (!parse3(args, r, c, n)) {
+        log_msg(LOG_ERR, "bad input, less arguments in line of MMF file\n");
+        throw FatalError("size line");
+    }
+    nr_rows = (size_t) r;
+    nr_cols = (size_t) c;
+    declared_nnz_ = (size_t) n;
+    data_start_ = in_.tellg();
+    if (symmetric || col_wise) {
+        load_all();
+        nnz = matrix_.size();    // Mmf.hpp:86-92
+    } else {
+        nnz = declared_nnz_;
+    }
+    rewind();
+}
+
+bool MmfInput::next_from_file(Triplet &t)
+{
+    std::vector<std::string> args;
+    if (!read_line(args)) return false;
+    long r, c; double v;
+    if (!parse3(args, r, c, v)) {
+        log_msg(LOG_ERR, "bad input, less arguments in line of MMF file\n");
+        throw FatalError("bad entry line");
+    }
+    if (zero_based) { ++r; ++c; }
+    t.row = (idx_t) r; t.col = (idx_t) c; t.val = v;
+    return true;
+}
+
+void MmfInput::load_all()
+{
+    // Mmf.hpp:445-478: read everything, mirror the stored triangle of a
+    // symmetric file, sort row-major
+    matrix_.reserve(symmetric ? declared_nnz_ * 2 : declared_nnz_);
+    for (size_t i = 0; i < declared_nnz_; ++i) {
+        Triplet t;
+        if (!next_from_file(t)) {
+            log_msg(LOG_ERR, "Requesting dereference, but mmf ended.\n");
+            throw FatalError("short MMF file");
+        }
+        matrix_.push_back(t);
+        if (symmetric && t.row != t.col) {
+            Triplet m = t;
+            std::swap(m.row, m.col);
+            matrix_.push_back(m);
+        }
+    }
+    std::sort(matrix_.begin(), matrix_.end(), [](const Triplet &a, const Triplet &b) {
+        return a.row < b.row || (a.row == b.row && a.col < b.col);
+    });
+    loaded_ = true;
+}
+
+void MmfInput::rewind()
+{
+    cursor_ = 0;
+    if (!loaded_) {
+        in_.clear();
+        in_.seekg(data_start_);
+        have_cur_ = false;
+        streamed_ = 0;
+        row_prev_ = 1;
+        col_prev_ = 1;
+    }
+}
+
+bool MmfInput::peek(Triplet &t)
+{
+    if (loaded_) {
+        if (cursor_ >= matrix_.size()) return false;
+        t = matrix_[cursor_];
+        return true;
+    }
+    if (streamed_ >= nnz) return false;
+    if (!have_cur_) {
+        if (!next_from_file(cur_)) {
+            log_msg(LOG_ERR, "Requesting dereference, but mmf ended (cnt: %zu/%zu).\n",
+                    streamed_, nnz);
+            throw FatalError("short MMF file");
+        }
+        // entries of a header-less file must come sorted (Mmf.hpp:259-263)
+        if (cur_.row < row_prev_ || (cur_.row == row_prev_ && cur_.col < col_prev_)) {
+            log_msg(LOG_ERR, "indices are not sorted in MMF file\n");
+            throw FatalError("unsorted MMF file");
+        }
+        col_prev_ = cur_.col;
+        row_prev_ = cur_.row;
+        have_cur_ = true;
+    }
+    t = cur_;
+    return true;
+}
+
+void MmfInput::advance()
+{
+    if (loaded_) { ++cursor_; return; }
+    have_cur_ = false;
+    ++streamed_;
+}
+
+// ---- partitioning ---------------------------------------------------------------------
+
+namespace {
+
+// general case: SparsePartition::SetElems, SparsePartition.hpp:508-541
+size_t take_partition(MatrixInput &in, idx_t row_start, size_t limit,
+                      Partition *dst, idx_t &last_row)
+{
+    idx_t row_prev = 1;
+    size_t cnt = 0;
+    Triplet t;
+    if (dst) dst->elems.clear();
+    while (in.peek(t)) {
+        idx_t row = t.row - row_start;     // 1-based inside the partition
+        if (row != row_prev) {
+            if (limit && cnt >= limit) break;
+            row_prev = row;
+        }
+        if (dst) dst->elems.push_back(make_single(row, t.col, t.val));
+        ++cnt;
+        in.advance();
+    }
+    last_row = cnt ? row_prev : 0;
+    return cnt;
+}
+
+// symmetric case: SparsePartitionSym::SetElems, SparsePartition.hpp:1087-1129
+size_t take_partition_sym(MatrixInput &in, idx_t row_start, size_t limit,
+                          PartitionSym *dst, idx_t &last_lower_row,
+                          size_t &diag_cnt)
+{
+    idx_t row_prev = 1;
+    size_t cnt = 0;
+    diag_cnt = 0;
+    bool any_lower = false;
+    Triplet t;
+    while (in.peek(t)) {
+        idx_t row = t.row - row_start;
+        idx_t col = t.col;
+        if (row_start + row > col) {           // strictly lower
+            if (row != row_prev) {
+                if (limit && diag_cnt + cnt >= limit && row_prev == row - 1) break;
+                row_prev = row;
+            }
+            if (dst) dst->lower.elems.push_back(make_single(row, col, t.val));
+            ++cnt;
+            any_lower = true;
+        } else if (row_start + row == col) {   // diagonal
+            if (dst) dst->diagonal.push_back(t.val);
+            ++diag_cnt;
+        }
+        in.advance();
+    }
+    last_lower_row = any_lower ? row_prev : 0;
+    return cnt;
+}
+
+}  // namespace
+
+void build_partitions(MatrixInput &in, size_t nr, size_t first, size_t last,
+                      std::vector<Partition> &parts, std::vector<PartBounds> &bounds)
+{
+    in.rewind();
+    parts.clear();
+    parts.resize(last - first);
+    bounds.clear();
+    const size_t total = in.nnz;
+    size_t cnt = 0;
+    idx_t row_start = 0;
+    for (size_t i = 0; i < nr; ++i) {
+        size_t limit = (total - cnt) / (nr - i);
+        Partition *p = (i >= first && i < last) ? &parts[i - first] : nullptr;
+        idx_t last_row = 0;
+        size_t got = take_partition(in, row_start, limit, p, last_row);
+        if (p) {
+            p->elems_size = p->elems.size();
+            p->set_rowptr(p->elems_size);
+            p->nnz = got;
+            p->nr_rows = p->rowptr.size() - 1;
+            p->nr_cols = in.nr_cols;
+            p->row_start = row_start;
+            p->type = ENC_H;
+        }
+        PartBounds b;
+        b.row_start = row_start;
+        b.nr_rows = last_row;
+        b.nnz = got;
+        bounds.push_back(b);
+        row_start += last_row;
+        cnt += got;
+    }
+    if (cnt != total) {
+        log_msg(LOG_ERR, "error in input matrix (matrix has less elements than "
+                "claimed)\n");
+        throw FatalError("element count mismatch");
+    }
+}
+
+void build_partitions_sym(MatrixInput &in, size_t nr, size_t first, size_t last,
+                          std::vector<PartitionSym> &parts,
+                          std::vector<PartBounds> &bounds)
+{
+    if (in.nr_rows != in.nr_cols) {
+        log_msg(LOG_ERR, "symmetric format requested for a non-square matrix\n");
+        throw FatalError("non-square symmetric");
+    }
+    in.rewind();
+    parts.clear();
+    parts.resize(last - first);
+    bounds.clear();
+    // lower triangle + diagonal of a matrix given in full; presumes a full
+    // diagonal (SparseInternal.hpp:83-96)
+    const size_t total = (in.nnz + in.nr_cols) / 2;
+    size_t cnt = 0;
+    idx_t row_start = 0;
+    for (size_t i = 0; i < nr; ++i) {
+        size_t limit = (total - cnt) / (nr - i);
+        PartitionSym *p = (i >= first && i < last) ? &parts[i - first] : nullptr;
+        idx_t last_lower = 0;
+        size_t diag = 0;
+        size_t lower = take_partition_sym(in, row_start, limit, p, last_lower, diag);
+        // The reference sizes the partition by its last row holding a lower
+        // element and so loses trailing rows that only have a diagonal entry;
+        // here every row that delivered its diagonal belongs to the partition.
+        idx_t nrows = std::max<idx_t>(last_lower, (idx_t) diag);
+        if (p) {
+            Partition &lm = p->lower;
+            lm.elems_size = lm.elems.size();
+            lm.set_rowptr(lm.elems_size);
+            lm.nnz = lower;
+            lm.nr_rows = (size_t) nrows;
+            lm.nr_cols = in.nr_cols;
+            lm.row_start = row_start;
+            lm.type = ENC_H;
+        }
+        PartBounds b;
+        b.row_start = row_start;
+        b.nr_rows = nrows;
+        b.nnz = lower + diag;
+        bounds.push_back(b);
+        row_start += nrows;
+        cnt += lower + diag;
+    }
+    if (cnt != total) {
+        log_msg(LOG_ERR, "error in input matrix (matrix has less elements than "
+                "claimed)\n");
+        throw FatalError("element count mismatch");
+    }
+}
+
+}  // namespace spx

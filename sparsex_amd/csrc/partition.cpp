@@ -1,0 +1,222 @@
+// partition.cpp -- see partition.hpp.
+#include "partition.hpp"
+
+#include <algorithm>
+#include <cassert>
+
+namespace spx {
+
+// ---- coordinate transforms (reference Xform.hpp:37-248) --------------------
+
+static inline void xf_block_row(int R, idx_t &r, idx_t &c)
+{
+    idx_t nr = (r - 1) / R + 1;
+    idx_t nc = (r - 1) % R + R * (c - 1) + 1;
+    r = nr; c = nc;
+}
+
+static inline void rxf_block_row(int R, idx_t &r, idx_t &c)
+{
+    idx_t nr = R * (r - 1) + (c - 1) % R + 1;
+    idx_t nc = (c - 1) / R + 1;
+    r = nr; c = nc;
+}
+
+void xform_from_horiz(int to, idx_t &r, idx_t &c, idx_t nr_rows, idx_t nr_cols)
+{
+    switch (to) {
+    case ENC_H:
+        return;
+    case ENC_V:
+        std::swap(r, c);
+        return;
+    case ENC_D: {
+        idx_t nr = nr_rows + c - r;
+        idx_t nc = (c < r) ? c : r;
+        assert(nr > 0);
+        r = nr; c = nc;
+        return;
+    }
+    case ENC_AD: {
+        idx_t nr = r + c - 1;
+        idx_t nc = (nr <= nr_cols) ? r : nr_cols - c + 1;
+        r = nr; c = nc;
+        return;
+    }
+    default:
+        if (enc_is_block_row(to)) {
+            xf_block_row(enc_block_align(to), r, c);
+        } else if (enc_is_block_col(to)) {
+            std::swap(r, c);
+            xf_block_row(enc_block_align(to), r, c);
+        } else {
+            assert(false && "unhandled iteration order");
+        }
+    }
+}
+
+void xform_to_horiz(int from, idx_t &r, idx_t &c, idx_t nr_rows, idx_t nr_cols)
+{
+    switch (from) {
+    case ENC_H:
+        return;
+    case ENC_V:
+        std::swap(r, c);
+        return;
+    case ENC_D: {
+        idx_t nr, nc;
+        if (r < nr_rows) { nr = nr_rows + c - r; nc = c; }
+        else             { nr = c; nc = r + c - nr_rows; }
+        r = nr; c = nc;
+        return;
+    }
+    case ENC_AD: {
+        idx_t nr, nc;
+        if (r <= nr_cols) { nr = c; nc = r - c + 1; }
+        else              { nr = r + c - nr_cols; nc = nr_cols - c + 1; }
+        r = nr; c = nc;
+        return;
+    }
+    default:
+        if (enc_is_block_row(from)) {
+            rxf_block_row(enc_block_align(from), r, c);
+        } else if (enc_is_block_col(from)) {
+            rxf_block_row(enc_block_align(from), r, c);
+            std::swap(r, c);
+        } else {
+            assert(false && "unhandled iteration order");
+        }
+    }
+}
+
+// ---- Partition ----------------------------------------------------------------
+
+void Partition::set_rowptr(size_t count)
+{
+    // rowptr[i] = index of the first element of (1-based) row i+1; rows after
+    // the last non-empty one are not represented (Builder::NewRow/Finalize,
+    // SparsePartition.hpp:866-891).
+    rowptr.clear();
+    rowptr.push_back(0);
+    idx_t row_prev = 1;
+    for (size_t i = 0; i < count; ++i) {
+        idx_t row = elems[i].row;
+        if (row != row_prev) {
+            assert(row > row_prev);
+            rowptr.insert(rowptr.end(), (size_t)(row - row_prev), (idx_t) i);
+            row_prev = row;
+        }
+    }
+    if ((size_t) rowptr.back() != count) rowptr.push_back((idx_t) count);
+}
+
+void Partition::transform(int t)
+{
+    if (type == t) return;
+    const idx_t nr = (idx_t) nr_rows, nc = (idx_t) nr_cols;
+    const int from = type;
+    for (size_t i = 0; i < elems_size; ++i)
+        xform(from, t, elems[i].row, elems[i].col, nr, nc);
+    // The reference sorts band-by-band when both orders belong to the same
+    // row/column family (SparsePartition.hpp:704-734); coordinates are unique,
+    // so a full sort yields the same order.
+    std::sort(elems.begin(), elems.begin() + elems_size, elem_less);
+    if (elems_size) set_rowptr(elems_size);
+    type = t;
+}
+
+void Partition::get_window(idx_t rs, idx_t length, Partition &win)
+{
+    if ((size_t)(rs + length) > rowptr.size() - 1)
+        length = (idx_t)(rowptr.size() - 1) - rs;
+    win = Partition();
+    idx_t es = rowptr[rs];
+    idx_t ee = rowptr[rs + length];
+    if (es == ee) return;
+    win.elems.assign(elems.begin() + es, elems.begin() + ee);
+    win.elems_size = (size_t)(ee - es);
+    for (size_t i = 0; i < win.elems_size; ++i) win.elems[i].row -= rs;
+    win.set_rowptr(win.elems_size);
+    win.nr_rows = (size_t) length;
+    win.nr_cols = nr_cols;
+    win.nnz = win.elems_size;
+    win.row_start = row_start + rs;
+    win.type = type;
+}
+
+void Partition::put_window(Partition &win)
+{
+    assert(type == win.type);
+    idx_t rs = win.row_start - row_start;
+    idx_t es = rowptr[rs];
+    if (type == ENC_H)
+        for (size_t i = 0; i < win.elems_size; ++i) win.elems[i].row += rs;
+    std::copy(win.elems.begin(), win.elems.begin() + win.elems_size,
+              elems.begin() + es);
+}
+
+// ---- PartitionSym ---------------------------------------------------------------
+
+static void split_rows(const Partition &src, Partition &dst, bool first_half)
+{
+    // DivideMatrix, SparsePartition.hpp:965-1024: an element goes to m1 when
+    // its column lies left of the partition's own row range.
+    dst = Partition();
+    dst.type = ENC_H;
+    dst.row_start = src.row_start;
+    dst.nr_cols = src.nr_cols;
+    dst.pool = std::vector<val_t>();
+    for (size_t j = 0; j < src.elems_size; ++j) {
+        const Elem &e = src.elems[j];
+        bool left = e.col < src.row_start + 1;
+        if (left == first_half) dst.elems.push_back(e);
+    }
+    dst.elems_size = dst.elems.size();
+    dst.nnz = dst.elems_size;
+    dst.set_rowptr(dst.elems_size);
+    dst.nr_rows = dst.rowptr.size() - 1;
+}
+
+void PartitionSym::divide()
+{
+    split_rows(lower, m1, true);
+    split_rows(lower, m2, false);
+}
+
+void PartitionSym::merge()
+{
+    // MergeMatrix, SparsePartition.hpp:1026-1074: per row, m1's elements
+    // followed by m2's.  Unit values move into the merged pool.
+    Partition out;
+    out.type = ENC_H;
+    out.row_start = lower.row_start;
+    out.nr_cols = lower.nr_cols;
+    out.nnz = lower.nnz;
+    size_t nr = lower.rowptr.size() - 1;
+    out.rowptr.clear();
+    out.rowptr.push_back(0);
+    auto take = [&](Partition &m, size_t i) {
+        if (m.rowptr.size() - 1 <= i) return;
+        for (idx_t j = m.rowptr[i]; j < m.rowptr[i + 1]; ++j) {
+            Elem e = m.elems[j];
+            if (e.is_unit())
+                e.voff = out.pool_alloc(&m.pool[e.voff], e.size);
+            out.elems.push_back(e);
+        }
+    };
+    for (size_t i = 0; i < nr; ++i) {
+        take(m1, i);
+        take(m2, i);
+        out.rowptr.push_back((idx_t) out.elems.size());
+    }
+    out.elems_size = out.elems.size();
+    // Builder::Finalize appends nothing more: the last entry already equals
+    // the element count.  Rows that lost all their anchors stay represented.
+    // keep the partition's row count: it may exceed the last anchored row
+    out.nr_rows = std::max(lower.nr_rows, out.rowptr.size() - 1);
+    lower = std::move(out);
+    m1 = Partition();
+    m2 = Partition();
+}
+
+}  // namespace spx
