@@ -384,6 +384,16 @@ static spx_matrix_t *do_tune(spx_input_t *in)
             A->diag[i] = std::move(sparts[i].diagonal);
         }
     }
+    // Rows after the last stored nonzero belong to the last partition: the
+    // executor has to write them (y = beta*y there).  The reference leaves
+    // them to the caller-side VecInit (CsxKernels.cpp:93).
+    if (last == P && nown) {
+        PartBounds &b = A->bounds[P - 1];
+        if (b.row_start + b.nr_rows < A->nrows) {
+            b.nr_rows = A->nrows - b.row_start;
+            A->parts[nown - 1].nr_rows = (size_t) b.nr_rows;
+        }
+    }
     for (size_t i = 0; i < nown; ++i) A->log += logs[i].str();
     log_msg(LOG_VERB, "%s", A->log.c_str());
     A->tune_seconds = now_sec() - t0;

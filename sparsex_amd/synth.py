@@ -1,0 +1,153 @@
+"""Deterministic synthetic stand-ins for the SuiteSparse matrices named in
+BASELINE.json (the real files are not available offline).  Structure follows
+SURVEY.md section 8(d): same dimensions, nonzeros per row and pattern classes
+as cant / nd24k / webbase-1M / nlpkkt, so that the same CSX unit types
+dominate.  All generators return zero-based CSR arrays
+``(rowptr int32, colind int32 (sorted per row), values float64, n)``.
+
+Host-side input generation only -- nothing here takes part in the SpMV.
+"""
+import numpy as np
+import scipy.sparse as sp
+
+SEED_BASE = 0x5EED0000
+
+
+def _finish(coo_rows, coo_cols, n, rng, symmetric):
+    """Unique pattern -> CSR with values U(-1,1) (symmetric if requested)."""
+    a = sp.coo_matrix((np.ones(coo_rows.size, dtype=np.int8), (coo_rows, coo_cols)),
+                      shape=(n, n)).tocsr()
+    a.sum_duplicates()
+    a.sort_indices()
+    if symmetric:
+        low = sp.tril(a, k=-1, format="coo")
+        vals = rng.uniform(-1.0, 1.0, low.nnz)
+        lowv = sp.coo_matrix((vals, (low.row, low.col)), shape=(n, n))
+        full = (lowv + lowv.T).tocsr()
+        # full, strictly positive diagonal (the symmetric path requires one)
+        rowsum = np.asarray(abs(full).sum(axis=1)).ravel()
+        full = (full + sp.diags(rowsum + 1.0)).tocsr()
+        full.sort_indices()
+        a = full
+    else:
+        a = a.astype(np.float64)
+        a.data = rng.uniform(-1.0, 1.0, a.nnz)
+    return (a.indptr.astype(np.int32), a.indices.astype(np.int32),
+            a.data.astype(np.float64), n)
+
+
+def syn_cant(scale=1.0, seed=SEED_BASE + 1):
+    """FEM-like banded matrix: 3-dof nodes, ~21 coupled nodes within +-600,
+    ~63 nnz/row (cant: 62451 rows, ~4.0M nnz, symmetric)."""
+    rng = np.random.RandomState(seed & 0x7FFFFFFF)
+    nodes = max(64, int(20817 * scale))
+    n = nodes * 3
+    band = max(8, int(600 * min(1.0, scale * 4)))
+    # regular mesh offsets (a few short ones and mesh-line strides), symmetric
+    base = np.unique(np.concatenate([[1, 2, 3], rng.randint(4, band, 7)]))
+    i = np.arange(nodes)
+    rows, cols = [i], [i]
+    for s in base:
+        keep = rng.rand(nodes) > 0.03          # irregularity: dropped couplings
+        src = i[keep & (i + s < nodes)]
+        rows += [src, src + s]
+        cols += [src + s, src]
+    nr = np.concatenate(rows)
+    nc = np.concatenate(cols)
+    # expand nodes to 3x3 dof blocks
+    a, b = np.meshgrid(np.arange(3), np.arange(3), indexing="ij")
+    r = (nr[:, None] * 3 + a.ravel()[None, :]).ravel()
+    c = (nc[:, None] * 3 + b.ravel()[None, :]).ravel()
+    return _finish(r, c, n, rng, symmetric=True)
+
+
+def syn_nd24k(scale=1.0, seed=SEED_BASE + 2):
+    """3-D mesh-like matrix of dense 8x8 blocks, ~50 blocks per block row
+    inside a +-6000 band, ~400 nnz/row (nd24k: 72000 rows, 28.7M nnz)."""
+    rng = np.random.RandomState(seed & 0x7FFFFFFF)
+    nb = max(32, int(9000 * scale))
+    n = nb * 8
+    band = max(30, int(750 * min(1.0, scale * 4)))
+    per_row = 25 if scale >= 0.05 else 8
+    i = np.repeat(np.arange(nb), per_row)
+    off = rng.randint(1, band, i.size)
+    j = i + off
+    ok = j < nb
+    i, j = i[ok], j[ok]
+    br = np.concatenate([np.arange(nb), i, j])
+    bc = np.concatenate([np.arange(nb), j, i])
+    a, b = np.meshgrid(np.arange(8), np.arange(8), indexing="ij")
+    r = (br[:, None] * 8 + a.ravel()[None, :]).ravel()
+    c = (bc[:, None] * 8 + b.ravel()[None, :]).ravel()
+    return _finish(r, c, n, rng, symmetric=True)
+
+
+def syn_webbase(scale=1.0, seed=SEED_BASE + 3):
+    """Power-law web graph: Zipf row lengths (mean ~3.1, max 4700), 70 % of
+    the links uniform, 30 % near the diagonal, ~15 % empty rows, unsymmetric
+    (webbase-1M: 1000005 rows, 3.1M nnz)."""
+    rng = np.random.RandomState(seed & 0x7FFFFFFF)
+    n = max(256, int(1000005 * scale))
+    lens = rng.zipf(2.1, n).astype(np.int64)
+    lens = np.minimum(lens, min(4700, n // 2))
+    lens[rng.rand(n) < 0.15] = 0
+    lens = np.minimum(lens, np.where(lens > 3, lens, 3))
+    rows = np.repeat(np.arange(n), lens)
+    uni = rng.rand(rows.size) < 0.7
+    cols = np.where(uni, rng.randint(0, n, rows.size),
+                    np.clip(rows + rng.randint(-1000, 1001, rows.size), 0, n - 1))
+    return _finish(rows, cols, n, rng, symmetric=False)
+
+
+def syn_nlpkkt(N=12, seed=SEED_BASE + 4):
+    """KKT system [H A^T; A D] from 27-point stencils on an N^3 grid
+    (nlpkkt240 is N=240: 27 993 600 rows, ~760M nnz; tests use small N)."""
+    rng = np.random.RandomState(seed & 0x7FFFFFFF)
+    n1 = 2 * N ** 3
+    n2 = 6 * N ** 2 if N >= 3 else 0
+    n = n1 + n2
+    idx = np.arange(N ** 3)
+    z, y, x = idx // (N * N), (idx // N) % N, idx % N
+    rows, cols = [], []
+    for dz in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                zz, yy, xx = z + dz, y + dy, x + dx
+                ok = (zz >= 0) & (zz < N) & (yy >= 0) & (yy < N) & (xx >= 0) & (xx < N)
+                src = idx[ok]
+                dst = (zz * N * N + yy * N + xx)[ok]
+                # H block (two interleaved fields) and their coupling
+                rows += [2 * src, 2 * src + 1, 2 * src]
+                cols += [2 * dst, 2 * dst + 1, 2 * dst + 1]
+    # constraint rows couple boundary faces to the fields
+    if n2:
+        face = np.arange(n2)
+        tgt = (face * 7919) % n1
+        rows += [n1 + face, tgt, n1 + face]
+        cols += [tgt, n1 + face, (tgt + 1) % n1]
+        rows += [(tgt + 1) % n1]
+        cols += [n1 + face]
+    r = np.concatenate(rows)
+    c = np.concatenate(cols)
+    r, c = np.concatenate([r, c]), np.concatenate([c, r])     # symmetrise pattern
+    return _finish(r, c, n, rng, symmetric=True)
+
+
+def lower_plus_diag_nnz(rowptr, colind):
+    """nnz_lower + n for a symmetric matrix given in full."""
+    n = rowptr.size - 1
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    return int((colind < rows).sum()) + n
+
+
+def random_x(ncols, seed=42):
+    """x ~ U(-0.1, 0.1), the range of the reference's VecCreateRandom
+    (src/internals/Vector.cpp:161-167)."""
+    return np.random.RandomState(seed).uniform(-0.1, 0.1, ncols)
+
+
+WORKLOADS = {
+    "syn-cant": syn_cant,
+    "syn-nd24k": syn_nd24k,
+    "syn-webbase": syn_webbase,
+}
