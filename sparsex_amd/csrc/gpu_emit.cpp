@@ -47,7 +47,16 @@ void RbBuilder::put_bits(const std::vector<uint32_t> &starts, size_t n)
     size_t passes = (n + SPX_PASS_ELEMS - 1) / SPX_PASS_ELEMS;
     size_t base = out_.bits.size();
     out_.bits.resize(base + passes * SPX_PASS_WORDS, 0u);
-    for (uint32_t s : starts) out_.bits[base + s / 32] |= 1u << (s % 32);
+    std::vector<uint32_t> per_pass(passes, 0);
+    for (uint32_t s : starts) {
+        out_.bits[base + s / 32] |= 1u << (s % 32);
+        ++per_pass[s / SPX_PASS_ELEMS];
+    }
+    uint32_t acc = 0;
+    for (size_t p = 0; p < passes; ++p) {
+        out_.pass_rank.push_back((uint16_t) acc);
+        acc += per_pass[p];
+    }
 }
 
 void RbBuilder::emit(idx_t lo, idx_t hi, const std::vector<Piece> &pieces,
@@ -81,14 +90,12 @@ void RbBuilder::emit(idx_t lo, idx_t hi, const std::vector<Piece> &pieces,
             const size_t R = (size_t) enc_block_align(u.type);
             const size_t cdim = u.size / R;
             const size_t rr = pc.b - pc.a;
+            // stored transposed: rows of cdim consecutive columns
             d.col0 = (uint32_t)(u.col - 1);
             d.row0 = (uint16_t)(u.row - 1 + pc.a - lo);
-            d.mod = (uint8_t) rr;
-            d.inner = 1;
-            d.dcol_out = 1;
-            d.drow_out = 0;
-            for (size_t i = 0; i < cdim; ++i)
-                for (size_t j = pc.a; j < pc.b; ++j)
+            d.mod = (uint8_t) cdim;
+            for (size_t j = pc.a; j < pc.b; ++j)
+                for (size_t i = 0; i < cdim; ++i)
                     out_.values.push_back(src[i * R + j]);
             cnt = rr * cdim;
         } else {
@@ -100,16 +107,12 @@ void RbBuilder::emit(idx_t lo, idx_t hi, const std::vector<Piece> &pieces,
             if (enc_is_block_col(u.type)) {
                 // whole rows of a rdim x C row-major block (cuts fall on rows)
                 d.mod = (uint8_t) enc_block_align(u.type);
-                d.inner = 0;
-                d.dcol_out = 0;
-                d.drow_out = 1;
             } else {
                 const int32_t dl = (int32_t) u.delta;
                 d.mod = 0;
-                d.inner = 0;
-                d.dcol_out = (u.type == ENC_H || u.type == ENC_D) ? dl
-                           : (u.type == ENC_AD) ? -dl : 0;
-                d.drow_out = (int16_t)((u.type == ENC_H) ? 0 : dl);
+                d.dcol = (u.type == ENC_H || u.type == ENC_D) ? dl
+                       : (u.type == ENC_AD) ? -dl : 0;
+                d.drow = (int16_t)((u.type == ENC_H) ? 0 : dl);
             }
             out_.values.insert(out_.values.end(), src + pc.a, src + pc.b);
         }

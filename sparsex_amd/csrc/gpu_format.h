@@ -12,17 +12,22 @@
  *   unit region   values of the substructure units, in descriptor order; one
  *                 16-byte SpxUnitDesc per unit gives anchor and strides, and
  *                 element k of the unit sits at
- *                    row = row0 + (k % mod) * drow_in  + (k / mod) * drow_out
- *                    col = col0 + (k % mod) * dcol_in  + (k / mod) * dcol_out
- *                 (linear units: mod = 0 => row0 + k*drow_out, col0 + k*dcol_out)
+ *                    linear unit (mod == 0): row0 + k*drow,  col0 + k*dcol
+ *                       (horizontal: drow 0; vertical: dcol 0; diagonal:
+ *                        drow = dcol; anti-diagonal: dcol = -drow)
+ *                    dense block (mod == c): row0 + k / c,   col0 + k % c
+ *                       (row-major r x c; the CPU format's column-major
+ *                        block-row units are transposed when emitted)
  *   delta region  the leftover nonzeros, row-major; one u16 row per row
  *                 segment and one column offset (u16 or u32, relative to
  *                 cbase) per nonzero -- the GPU form of CSX delta units
  *
  * Both regions carry one "segment start" bit per nonzero (a new unit / a new
  * row segment begins here); lanes rank those bits to find their descriptor.
- * One wavefront walks one row-block in passes of SPX_PASS_ELEMS nonzeros
- * (64 lanes x SPX_LANE_ELEMS consecutive nonzeros).
+ * A region is cut into passes of SPX_PASS_ELEMS nonzeros (64 lanes x
+ * SPX_LANE_ELEMS consecutive nonzeros); pass_rank[] holds the number of
+ * segment starts in front of each pass, which makes passes independent: one
+ * workgroup owns a row-block and its wavefronts take the passes in turn.
  */
 #ifndef SPX_GPU_FORMAT_H
 #define SPX_GPU_FORMAT_H
@@ -37,18 +42,19 @@
 
 typedef struct {
     uint32_t col0;       /* anchor column (0-based, absolute)                  */
-    int32_t  dcol_out;   /* column stride of k / mod  (or of k when mod == 0)  */
+    int32_t  dcol;       /* linear: column stride per element                  */
     uint16_t estart;     /* first nonzero of the unit inside the unit region   */
     uint16_t row0;       /* anchor row relative to the row-block               */
-    int16_t  drow_out;   /* row stride of k / mod (or of k when mod == 0)      */
-    uint8_t  mod;        /* inner dimension of a block unit, 0 = linear        */
-    uint8_t  inner;      /* bit0: k % mod walks rows (else columns)            */
+    int16_t  drow;       /* linear: row stride per element                     */
+    uint8_t  mod;        /* dense block: row length c; 0 = linear unit         */
+    uint8_t  pad_;
 } SpxUnitDesc;           /* 16 bytes */
 
 typedef struct {
     uint64_t val_off;     /* first value of the row-block in values[]          */
     uint32_t desc_off;    /* first SpxUnitDesc                                  */
-    uint32_t bits_off;    /* first u32 word of start bits (unit passes first)  */
+    uint32_t bits_off;    /* first u32 word of start bits (unit passes first);
+                             bits_off / SPX_PASS_WORDS indexes pass_rank[]      */
     uint32_t cidx_off;    /* byte offset of the delta region's column offsets  */
     uint32_t seg_off;     /* first u16 row of the delta region's row segments  */
     uint32_t cbase;       /* column base of the delta region                    */

@@ -42,10 +42,11 @@ def test_mult_general(name, gen, opts):
     yo, _ = oracle_y(A, x, 0.5)
     check_y(csr, x, y, 0.5)
     check_y(csr, x, yo, 0.5)
-    # run-to-run determinism of the general path (no atomics on y)
+    # repeated calls agree to rounding (the wavefronts of a row-block add into
+    # its LDS tile in no fixed order) and never depend on y's previous contents
     y2 = np.zeros(n)
     A.matvec_mult(0.5, x, y2)
-    assert np.array_equal(y, y2)
+    check_y(csr, x, y2, 0.5)
 
 
 @pytest.mark.parametrize("name,gen", CASES)
