@@ -104,6 +104,13 @@ int64_t spx_hip_mat_export_units(const spx_matrix_t *A, int part,
  * per round, chosen encodings); NUL-terminated, owned by the matrix. */
 const char *spx_hip_mat_tune_log(const spx_matrix_t *A);
 
+/* The coordinate maps between iteration orders used by the preprocessor
+ * (reference include/sparsex/internals/Xform.hpp:37-248): transforms the
+ * 1-based (*row, *col) from order `from` to order `to` (EncType numbering:
+ * 1 h, 2 v, 3 d, 4 ad, 5..12 br1..8, 13..20 bc1..8).  Exposed for tests. */
+void spx_hip_xform(int from, int to, spx_index_t *row, spx_index_t *col,
+                   spx_index_t nr_rows, spx_index_t nr_cols);
+
 /* Restores every option to its default (the reference keeps options in a
  * process-wide singleton with no reset; tests need one). */
 void spx_hip_options_reset(void);

@@ -142,7 +142,7 @@ def build(id_map, symmetric=False, row_jumps=False, full_colind=False, opt="-O2"
     ids = [int(i) for i in id_map if int(i) >= 0]
     if not ids:
         return None
-    key = "%s|%d|%d|%d|%s" % (",".join(map(str, ids)), symmetric, row_jumps, full_colind, opt)
+    key = "v2|%s|%d|%d|%d|%s" % (",".join(map(str, ids)), symmetric, row_jumps, full_colind, opt)
     tag = hashlib.sha1(key.encode()).hexdigest()[:16]
     so = os.path.join(REF_DIR, "csxref_%s.so" % tag)
     if os.path.exists(so):
@@ -153,7 +153,11 @@ def build(id_map, symmetric=False, row_jumps=False, full_colind=False, opt="-O2"
     src = os.path.join(REF_DIR, "csxref_%s.c" % tag)
     with open(src, "w") as f:
         f.write(generate_source(ids, symmetric, row_jumps, full_colind))
-    cmd = ["gcc", "-std=gnu99", opt, "-fPIC", "-shared", "-w", "-I" + inc,
+    # CtlUtil.hpp's u16_get/u32_get advance the byte cursor through a
+    # (uint32_t **) cast of it; under gcc's strict-aliasing rules that is
+    # undefined (seen to break the full_colind stream at -O2), so the templates
+    # are built with the aliasing assumption off
+    cmd = ["gcc", "-std=gnu99", opt, "-fno-strict-aliasing", "-fPIC", "-shared", "-w", "-I" + inc,
            "-I" + os.path.join(REF_ROOT, "include"), src, "-o", so]
     subprocess.check_call(cmd)
     return so
@@ -162,7 +166,7 @@ def build(id_map, symmetric=False, row_jumps=False, full_colind=False, opt="-O2"
 def lookup(id_map, symmetric=False, row_jumps=False, full_colind=False, opt="-O2"):
     """Path of a previously built .so for this configuration, or None."""
     ids = [int(i) for i in id_map if int(i) >= 0]
-    key = "%s|%d|%d|%d|%s" % (",".join(map(str, ids)), symmetric, row_jumps, full_colind, opt)
+    key = "v2|%s|%d|%d|%d|%s" % (",".join(map(str, ids)), symmetric, row_jumps, full_colind, opt)
     so = os.path.join(REF_DIR, "csxref_%s.so" % hashlib.sha1(key.encode()).hexdigest()[:16])
     return so if os.path.exists(so) else None
 

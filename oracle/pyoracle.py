@@ -132,7 +132,7 @@ def ref_matvec(exports, symmetric, x, nrows, alpha=1.0, build=True):
         ids = [i for i in e["id_map"] if i >= 0]
         if not ids:
             # a symmetric partition without lower elements: diagonal only
-            if symmetric:
+            if symmetric and e["nrows"] > 0:
                 rs, nr = e["row_start"], e["nrows"]
                 y[rs:rs + nr] += x[rs:rs + nr] * e["dvalues"][:nr] * alpha
             continue

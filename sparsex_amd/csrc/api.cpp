@@ -646,6 +646,12 @@ void spx_options_set_from_env()
 
 void spx_hip_options_reset(void) { Config::instance().reset_defaults(); }
 
+void spx_hip_xform(int from, int to, spx_index_t *row, spx_index_t *col,
+                   spx_index_t nr_rows, spx_index_t nr_cols)
+{
+    xform(from, to, *row, *col, nr_rows, nr_cols);
+}
+
 // ======================================================================================
 //  SpMV
 // ======================================================================================
