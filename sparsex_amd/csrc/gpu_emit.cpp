@@ -23,10 +23,21 @@ struct Plan {
     bool split;             // one over-long row, chunked
 };
 
-void pad_to(std::vector<val_t> &v, size_t mult)
+inline void pad_to(std::vector<val_t> &v, size_t mult)
 {
     while (v.size() % mult) v.push_back(0.0);
 }
+
+// a run of equally wide row segments, values segment-major [nseg][width]
+struct Group {
+    uint16_t row0;       // relative to the row-block
+    uint32_t col0;
+    uint16_t nseg;
+    uint8_t width;
+    int16_t drow;
+    int32_t dcol;
+    uint32_t voff;       // into RbBuilder::gvals_
+};
 
 class RbBuilder {
 public:
@@ -37,139 +48,232 @@ public:
               std::vector<Single> &singles, uint8_t flags, uint32_t carry_slot);
 
 private:
-    void put_bits(const std::vector<uint32_t> &starts, size_t n);
+    void add_group(idx_t row, idx_t col, size_t nseg, size_t width, int drow, int dcol)
+    {
+        Group g;
+        g.row0 = (uint16_t) row;
+        g.col0 = (uint32_t) col;
+        g.nseg = (uint16_t) nseg;
+        g.width = (uint8_t) width;
+        g.drow = (int16_t) drow;
+        g.dcol = (int32_t) dcol;
+        g.voff = (uint32_t) gvals_.size();
+        groups_.push_back(g);
+    }
+    void groups_from_piece(const Piece &pc, idx_t lo);
+    void emit_unit_passes(SpxRowBlock &rb);
+    void emit_delta_passes(SpxRowBlock &rb, std::vector<Single> &singles, idx_t lo);
+
     const Partition &p_;
     GpuStream &out_;
+    std::vector<Group> groups_;
+    std::vector<val_t> gvals_;
 };
 
-void RbBuilder::put_bits(const std::vector<uint32_t> &starts, size_t n)
+void RbBuilder::groups_from_piece(const Piece &pc, idx_t lo)
 {
-    size_t passes = (n + SPX_PASS_ELEMS - 1) / SPX_PASS_ELEMS;
-    size_t base = out_.bits.size();
-    out_.bits.resize(base + passes * SPX_PASS_WORDS, 0u);
-    std::vector<uint32_t> per_pass(passes, 0);
-    for (uint32_t s : starts) {
-        out_.bits[base + s / 32] |= 1u << (s % 32);
-        ++per_pass[s / SPX_PASS_ELEMS];
+    const Elem &u = p_.elems[pc.elem];
+    const val_t *src = &p_.pool[u.voff];
+    const size_t WMAX = SPX_MAX_SEG_WIDTH;
+    if (enc_is_block_row(u.type)) {
+        // rows [a,b) of an R x cdim column-major block, emitted row-major in
+        // column chunks of at most WMAX
+        const size_t R = (size_t) enc_block_align(u.type);
+        const size_t cdim = u.size / R;
+        const size_t rr = pc.b - pc.a;
+        for (size_t c0 = 0; c0 < cdim; c0 += WMAX) {
+            size_t w = std::min(WMAX, cdim - c0);
+            add_group(u.row - 1 + (idx_t) pc.a - lo, u.col - 1 + (idx_t) c0, rr, w, 1, 0);
+            for (size_t s = 0; s < rr; ++s)
+                for (size_t i = 0; i < w; ++i)
+                    gvals_.push_back(src[(c0 + i) * R + (pc.a + s)]);
+        }
+        return;
     }
-    uint32_t acc = 0;
-    for (size_t p = 0; p < passes; ++p) {
-        out_.pass_rank.push_back((uint16_t) acc);
-        acc += per_pass[p];
+    idx_t r0, c0;
+    unit_elem_coords(u, pc.a, r0, c0);
+    const size_t n = pc.b - pc.a;
+    if (enc_is_block_col(u.type)) {
+        // whole rows of a rdim x C row-major block (cuts fall on row borders)
+        const size_t C = (size_t) enc_block_align(u.type);
+        const size_t rr = n / C;
+        for (size_t cc = 0; cc < C; cc += WMAX) {
+            size_t w = std::min(WMAX, C - cc);
+            add_group(r0 - 1 - lo, c0 - 1 + (idx_t) cc, rr, w, 1, 0);
+            for (size_t s = 0; s < rr; ++s)
+                for (size_t i = 0; i < w; ++i)
+                    gvals_.push_back(src[pc.a + s * C + cc + i]);
+        }
+        return;
+    }
+    const int d = (int) u.delta;
+    if (u.type == ENC_H && d == 1) {
+        const size_t CH = SPX_HORIZ_CHUNK;
+        const size_t nf = n / CH, m = n % CH;
+        if (nf) {
+            add_group(r0 - 1 - lo, c0 - 1, nf, CH, 0, (int) CH);
+            gvals_.insert(gvals_.end(), src + pc.a, src + pc.a + nf * CH);
+        }
+        if (m) {
+            add_group(r0 - 1 - lo, c0 - 1 + (idx_t)(nf * CH), 1, m, 0, 0);
+            gvals_.insert(gvals_.end(), src + pc.a + nf * CH, src + pc.b);
+        }
+        return;
+    }
+    int drow = 0, dcol = 0;
+    switch (u.type) {
+    case ENC_H: dcol = d; break;
+    case ENC_V: drow = d; break;
+    case ENC_D: drow = d; dcol = d; break;
+    case ENC_AD: drow = d; dcol = -d; break;
+    default: assert(false);
+    }
+    add_group(r0 - 1 - lo, c0 - 1, n, 1, drow, dcol);
+    gvals_.insert(gvals_.end(), src + pc.a, src + pc.b);
+}
+
+void RbBuilder::emit_unit_passes(SpxRowBlock &rb)
+{
+    // passes hold segments of one width: order the groups by width
+    std::vector<uint32_t> order(groups_.size());
+    for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        return groups_[a].width < groups_[b].width;
+    });
+    struct Slot { uint32_t desc; uint32_t grp; uint16_t s; };
+    std::vector<Slot> lanes;
+    uint32_t seg_counter = 0;
+    auto flush = [&](uint8_t width) {
+        if (lanes.empty()) return;
+        SpxPass ps;
+        std::memset(&ps, 0, sizeof(ps));
+        if (out_.values.size() % 2) out_.values.push_back(0.0);
+        ps.val_off = (uint32_t)(out_.values.size() - rb.val_off);
+        ps.rank0 = (uint16_t) lanes[0].desc;
+        ps.seg0 = (uint16_t)(seg_counter - lanes.size());
+        ps.nseg = (uint8_t) lanes.size();
+        ps.width = width;
+        ps.kind = SPX_PASS_UNIT;
+        const size_t nseg = lanes.size();
+        size_t base = out_.values.size();
+        out_.values.resize(base + nseg * width, 0.0);
+        for (size_t l = 0; l < nseg; ++l) {
+            if (l > 0 && lanes[l].desc != lanes[l - 1].desc) ps.mask |= 1ull << l;
+            const Group &g = groups_[lanes[l].grp];
+            for (uint32_t w = 0; w < width; ++w)
+                out_.values[base + spx_pass_value_index((uint32_t) l, w, (uint32_t) nseg, width)] =
+                    gvals_[g.voff + (size_t) lanes[l].s * width + w];
+        }
+        out_.passes.push_back(ps);
+        ++rb.n_pass;
+        lanes.clear();
+    };
+    uint8_t cur_w = 0;
+    for (uint32_t gi : order) {
+        const Group &g = groups_[gi];
+        if (g.width != cur_w) {
+            flush(cur_w);
+            cur_w = g.width;
+        }
+        SpxUnitDesc d;
+        std::memset(&d, 0, sizeof(d));
+        d.col0 = g.col0;
+        d.dcol = g.dcol;
+        d.row0 = g.row0;
+        d.drow = g.drow;
+        d.sstart = (uint16_t) seg_counter;
+        uint32_t di = (uint32_t)(out_.descs.size() - rb.desc_off);
+        out_.descs.push_back(d);
+        ++out_.n_units;
+        for (uint16_t s = 0; s < g.nseg; ++s) {
+            lanes.push_back(Slot{di, gi, s});
+            ++seg_counter;
+            if (lanes.size() == SPX_PASS_SEGS) flush(cur_w);
+        }
+    }
+    flush(cur_w);
+}
+
+void RbBuilder::emit_delta_passes(SpxRowBlock &rb, std::vector<Single> &singles, idx_t lo)
+{
+    std::sort(singles.begin(), singles.end(), [](const Single &x, const Single &y) {
+        return x.row < y.row || (x.row == y.row && x.col < y.col);
+    });
+    const size_t n = singles.size();
+    rb.seg_off = (uint32_t) out_.segrows.size();
+    while (out_.cidx.size() % 16) out_.cidx.push_back(0);
+    rb.cidx_off = (uint32_t) out_.cidx.size();
+    rb.cidx_width = 2;
+    if (!n) return;
+    idx_t cmin = singles[0].col, cmax = singles[0].col;
+    for (const Single &s : singles) {
+        cmin = std::min(cmin, s.col);
+        cmax = std::max(cmax, s.col);
+    }
+    rb.cbase = (uint32_t) cmin;
+    rb.cidx_width = ((size_t)(cmax - cmin) < 65536) ? 2 : 4;
+    uint32_t rowseg = 0;          // index of the current row segment
+    idx_t prev_row = -1;
+    for (size_t b = 0; b < n; b += SPX_PASS_SEGS) {
+        const size_t e = std::min(n, b + SPX_PASS_SEGS);
+        SpxPass ps;
+        std::memset(&ps, 0, sizeof(ps));
+        if (out_.values.size() % 2) out_.values.push_back(0.0);
+        ps.val_off = (uint32_t)(out_.values.size() - rb.val_off);
+        ps.seg0 = (uint16_t) b;
+        ps.nseg = (uint8_t)(e - b);
+        ps.width = 1;
+        ps.kind = SPX_PASS_DELTA;
+        for (size_t i = b; i < e; ++i) {
+            const Single &s = singles[i];
+            if (s.row != prev_row) {
+                out_.segrows.push_back((uint16_t)(s.row - lo));
+                if (i > 0) ++rowseg;
+                if (i > b) ps.mask |= 1ull << (i - b);
+                prev_row = s.row;
+            }
+            if (i == b) ps.rank0 = (uint16_t) rowseg;
+            uint32_t off = (uint32_t)(s.col - cmin);
+            if (rb.cidx_width == 2) {
+                uint16_t o = (uint16_t) off;
+                const uint8_t *bp = reinterpret_cast<const uint8_t *>(&o);
+                out_.cidx.insert(out_.cidx.end(), bp, bp + 2);
+            } else {
+                const uint8_t *bp = reinterpret_cast<const uint8_t *>(&off);
+                out_.cidx.insert(out_.cidx.end(), bp, bp + 4);
+            }
+            out_.values.push_back(s.val);
+        }
+        out_.passes.push_back(ps);
+        ++rb.n_pass;
     }
 }
 
 void RbBuilder::emit(idx_t lo, idx_t hi, const std::vector<Piece> &pieces,
-                     std::vector<Single> &singles, uint8_t flags,
-                     uint32_t carry_slot)
+                     std::vector<Single> &singles, uint8_t flags, uint32_t carry_slot)
 {
     SpxRowBlock rb;
     std::memset(&rb, 0, sizeof(rb));
-    pad_to(out_.values, 4);
+    pad_to(out_.values, 2);
     rb.val_off = out_.values.size();
+    rb.pass_off = (uint32_t) out_.passes.size();
     rb.desc_off = (uint32_t) out_.descs.size();
-    rb.bits_off = (uint32_t) out_.bits.size();
     rb.row0 = (uint32_t)(p_.row_start + lo);
     rb.n_rows = (uint16_t)(hi - lo);
     rb.flags = flags;
     rb.carry_slot = carry_slot;
 
-    // ---- unit region --------------------------------------------------------
-    std::vector<uint32_t> starts;
-    size_t n_unit = 0;
-    for (const Piece &pc : pieces) {
-        const Elem &u = p_.elems[pc.elem];
-        const val_t *src = &p_.pool[u.voff];
-        SpxUnitDesc d;
-        std::memset(&d, 0, sizeof(d));
-        d.estart = (uint16_t) n_unit;
-        starts.push_back((uint32_t) n_unit);
-        size_t cnt;
-        if (enc_is_block_row(u.type)) {
-            // rows [a,b) of an R x cdim column-major block
-            const size_t R = (size_t) enc_block_align(u.type);
-            const size_t cdim = u.size / R;
-            const size_t rr = pc.b - pc.a;
-            // stored transposed: rows of cdim consecutive columns
-            d.col0 = (uint32_t)(u.col - 1);
-            d.row0 = (uint16_t)(u.row - 1 + pc.a - lo);
-            d.mod = (uint8_t) cdim;
-            for (size_t j = pc.a; j < pc.b; ++j)
-                for (size_t i = 0; i < cdim; ++i)
-                    out_.values.push_back(src[i * R + j]);
-            cnt = rr * cdim;
-        } else {
-            idx_t r0, c0;
-            unit_elem_coords(u, pc.a, r0, c0);
-            d.col0 = (uint32_t)(c0 - 1);
-            d.row0 = (uint16_t)(r0 - 1 - lo);
-            cnt = pc.b - pc.a;
-            if (enc_is_block_col(u.type)) {
-                // whole rows of a rdim x C row-major block (cuts fall on rows)
-                d.mod = (uint8_t) enc_block_align(u.type);
-            } else {
-                const int32_t dl = (int32_t) u.delta;
-                d.mod = 0;
-                d.dcol = (u.type == ENC_H || u.type == ENC_D) ? dl
-                       : (u.type == ENC_AD) ? -dl : 0;
-                d.drow = (int16_t)((u.type == ENC_H) ? 0 : dl);
-            }
-            out_.values.insert(out_.values.end(), src + pc.a, src + pc.b);
-        }
-        out_.descs.push_back(d);
-        n_unit += cnt;
-        ++out_.n_units;
-    }
-    assert(n_unit <= SPX_MAX_RB_ELEMS);
-    rb.n_unit_elems = (uint16_t) n_unit;
-    put_bits(starts, n_unit);
-    pad_to(out_.values, 4);
-
-    // ---- delta region ---------------------------------------------------------
-    std::sort(singles.begin(), singles.end(), [](const Single &x, const Single &y) {
-        return x.row < y.row || (x.row == y.row && x.col < y.col);
-    });
+    groups_.clear();
+    gvals_.clear();
+    for (const Piece &pc : pieces) groups_from_piece(pc, lo);
+    const size_t n_unit = gvals_.size();
+    emit_unit_passes(rb);
     const size_t n_delta = singles.size();
-    assert(n_delta <= SPX_MAX_RB_ELEMS);
-    rb.n_delta_elems = (uint16_t) n_delta;
-    rb.seg_off = (uint32_t) out_.segrows.size();
-    while (out_.cidx.size() % 16) out_.cidx.push_back(0);
-    rb.cidx_off = (uint32_t) out_.cidx.size();
-    starts.clear();
-    if (n_delta) {
-        idx_t cmin = singles[0].col, cmax = singles[0].col;
-        for (const Single &s : singles) {
-            cmin = std::min(cmin, s.col);
-            cmax = std::max(cmax, s.col);
-        }
-        rb.cbase = (uint32_t) cmin;
-        rb.cidx_width = ((size_t)(cmax - cmin) < 65536) ? 2 : 4;
-        idx_t prev_row = -1;
-        for (size_t i = 0; i < n_delta; ++i) {
-            const Single &s = singles[i];
-            if (s.row != prev_row) {
-                starts.push_back((uint32_t) i);
-                out_.segrows.push_back((uint16_t)(s.row - lo));
-                prev_row = s.row;
-            }
-            uint32_t off = (uint32_t)(s.col - cmin);
-            if (rb.cidx_width == 2) {
-                uint16_t o = (uint16_t) off;
-                const uint8_t *b = reinterpret_cast<const uint8_t *>(&o);
-                out_.cidx.insert(out_.cidx.end(), b, b + 2);
-            } else {
-                const uint8_t *b = reinterpret_cast<const uint8_t *>(&off);
-                out_.cidx.insert(out_.cidx.end(), b, b + 4);
-            }
-            out_.values.push_back(s.val);
-        }
-    } else {
-        rb.cidx_width = 2;
-    }
-    put_bits(starts, n_delta);
-    // lanes read SPX_LANE_ELEMS offsets / values at once: keep the tail readable
-    for (size_t i = 0; i < SPX_LANE_ELEMS * 4; ++i) out_.cidx.push_back(0);
-    pad_to(out_.values, 4);
+    emit_delta_passes(rb, singles, lo);
+    // keep whole-lane over-reads of the last pass inside the arrays
+    for (size_t i = 0; i < 16; ++i) out_.cidx.push_back(0);
+    pad_to(out_.values, 2);
+    assert(n_unit + n_delta <= 2 * SPX_MAX_RB_ELEMS);
 
     out_.n_unit_elems += n_unit;
     out_.n_delta_elems += n_delta;

@@ -17,8 +17,7 @@ namespace spx {
 struct GpuStream {
     std::vector<val_t> values;
     std::vector<SpxUnitDesc> descs;
-    std::vector<uint32_t> bits;
-    std::vector<uint16_t> pass_rank;   // segment starts in front of each pass
+    std::vector<SpxPass> passes;
     std::vector<uint8_t> cidx;
     std::vector<uint16_t> segrows;
     std::vector<SpxRowBlock> rbs;
@@ -35,8 +34,8 @@ struct GpuStream {
 
     size_t index_bytes() const
     {
-        return descs.size() * sizeof(SpxUnitDesc) + bits.size() * 4 +
-               pass_rank.size() * 2 + cidx.size() +
+        return descs.size() * sizeof(SpxUnitDesc) + passes.size() * sizeof(SpxPass) +
+               cidx.size() +
                segrows.size() * 2 + rbs.size() * sizeof(SpxRowBlock);
     }
 };

@@ -6,66 +6,83 @@
  * A *row-block* owns a contiguous range of rows and every nonzero that lands
  * in them.  CSX units produced by the preprocessor are re-tiled onto
  * row-blocks (multi-row units are cut at row-block borders), so a row-block
- * never writes y outside its rows.  Inside a row-block the nonzeros are
- * stored in two regions:
+ * never writes y outside its rows.
  *
- *   unit region   values of the substructure units, in descriptor order; one
- *                 16-byte SpxUnitDesc per unit gives anchor and strides, and
- *                 element k of the unit sits at
- *                    linear unit (mod == 0): row0 + k*drow,  col0 + k*dcol
- *                       (horizontal: drow 0; vertical: dcol 0; diagonal:
- *                        drow = dcol; anti-diagonal: dcol = -drow)
- *                    dense block (mod == c): row0 + k / c,   col0 + k % c
- *                       (row-major r x c; the CPU format's column-major
- *                        block-row units are transposed when emitted)
- *   delta region  the leftover nonzeros, row-major; one u16 row per row
- *                 segment and one column offset (u16 or u32, relative to
- *                 cbase) per nonzero -- the GPU form of CSX delta units
+ * Inside a row-block every unit is expressed as a run of *row segments*: a
+ * row segment is up to SPX_MAX_SEG_WIDTH consecutive columns of one row.
+ *     dense r x c block        r segments of width c (wider blocks are cut
+ *                              into column chunks); CSX block-row units,
+ *                              column-major on the CPU, are transposed
+ *     horizontal unit (d = 1)  chunks of SPX_HORIZ_CHUNK columns, same row
+ *     vertical / diagonal /    one segment of width 1 per nonzero
+ *     anti-diagonal / h (d>1)
+ * Segment s of a unit sits at row0 + s*drow, columns col0 + s*dcol ... +W-1.
+ * One 16-byte SpxUnitDesc describes the whole run.
  *
- * Both regions carry one "segment start" bit per nonzero (a new unit / a new
- * row segment begins here); lanes rank those bits to find their descriptor.
- * A region is cut into passes of SPX_PASS_ELEMS nonzeros (64 lanes x
- * SPX_LANE_ELEMS consecutive nonzeros); pass_rank[] holds the number of
- * segment starts in front of each pass, which makes passes independent: one
- * workgroup owns a row-block and its wavefronts take the passes in turn.
+ * Work is cut into *passes*: a pass is up to 64 row segments of the SAME
+ * width W, one per lane of a wavefront.  Its values are stored interleaved
+ * (pairs of columns, segment-minor) so that every load of a wavefront is one
+ * contiguous block; a lane multiplies its W values with x[col..col+W-1] and
+ * adds ONE partial sum to the row-block's y tile in LDS.  Segment-start bits
+ * (one 64-bit mask per pass) tell a lane which descriptor it belongs to.
+ *
+ * The leftover nonzeros (CSX delta units) form *delta passes*: 64 nonzeros,
+ * one per lane, row-major, with a u16/u32 column offset per nonzero (relative
+ * to cbase) and one u16 row per row change.
  */
 #ifndef SPX_GPU_FORMAT_H
 #define SPX_GPU_FORMAT_H
 
 #include <stdint.h>
 
-#define SPX_LANE_ELEMS   4      /* consecutive nonzeros per lane and pass      */
-#define SPX_PASS_ELEMS   256    /* 64 * SPX_LANE_ELEMS                         */
-#define SPX_PASS_WORDS   8      /* u32 words of start bits per pass            */
-#define SPX_MAX_RB_ROWS  512    /* y tile per wavefront in LDS (doubles)       */
-#define SPX_MAX_RB_ELEMS 8192   /* nonzeros per region (estart is 16 bit)      */
+#define SPX_MAX_RB_ROWS    512    /* y tile of a row-block in LDS (doubles)      */
+#define SPX_MAX_RB_ELEMS   8192   /* nonzeros per row-block (16-bit counters)    */
+#define SPX_MAX_SEG_WIDTH  8      /* columns per row segment                      */
+#define SPX_HORIZ_CHUNK    8      /* horizontal units are cut into such chunks   */
+#define SPX_PASS_SEGS      64     /* row segments (lanes) per pass                */
+
+#define SPX_PASS_UNIT   0
+#define SPX_PASS_DELTA  1
 
 typedef struct {
-    uint32_t col0;       /* anchor column (0-based, absolute)                  */
-    int32_t  dcol;       /* linear: column stride per element                  */
-    uint16_t estart;     /* first nonzero of the unit inside the unit region   */
-    uint16_t row0;       /* anchor row relative to the row-block               */
-    int16_t  drow;       /* linear: row stride per element                     */
-    uint8_t  mod;        /* dense block: row length c; 0 = linear unit         */
-    uint8_t  pad_;
+    uint32_t col0;       /* first column of segment 0 (0-based, absolute)       */
+    int32_t  dcol;       /* column step per segment                              */
+    uint16_t row0;       /* row of segment 0, relative to the row-block          */
+    int16_t  drow;       /* row step per segment                                  */
+    uint16_t sstart;     /* number of segments of this row-block in front of it  */
+    uint16_t pad_;
 } SpxUnitDesc;           /* 16 bytes */
 
 typedef struct {
+    uint64_t mask;       /* bit l: lane l's segment starts a new unit (unit
+                            pass) / a new row (delta pass); bit 0 is never set  */
+    uint32_t val_off;    /* first value of the pass, relative to the row-block  */
+    uint16_t rank0;      /* unit pass: descriptor of lane 0's segment
+                            delta pass: row-segment index of lane 0's nonzero   */
+    uint16_t seg0;       /* unit pass: segments in front of lane 0
+                            delta pass: nonzeros of the delta region in front   */
+    uint8_t  nseg;       /* active lanes, 1..64                                  */
+    uint8_t  width;      /* W: columns per segment (1 for delta passes)          */
+    uint8_t  kind;       /* SPX_PASS_UNIT / SPX_PASS_DELTA                       */
+    uint8_t  pad_;
+    uint32_t pad2_;
+} SpxPass;               /* 24 bytes */
+
+typedef struct {
     uint64_t val_off;     /* first value of the row-block in values[]          */
+    uint32_t pass_off;    /* first SpxPass                                      */
     uint32_t desc_off;    /* first SpxUnitDesc                                  */
-    uint32_t bits_off;    /* first u32 word of start bits (unit passes first);
-                             bits_off / SPX_PASS_WORDS indexes pass_rank[]      */
-    uint32_t cidx_off;    /* byte offset of the delta region's column offsets  */
-    uint32_t seg_off;     /* first u16 row of the delta region's row segments  */
-    uint32_t cbase;       /* column base of the delta region                    */
-    uint32_t row0;        /* first row owned (relative to the partition slice) */
+    uint32_t cidx_off;    /* byte offset of the delta nonzeros' column offsets  */
+    uint32_t seg_off;     /* first u16 row of the delta row segments            */
+    uint32_t cbase;       /* column base of the delta nonzeros                  */
+    uint32_t row0;        /* first row owned (global)                           */
     uint16_t n_rows;      /* rows owned                                         */
-    uint16_t n_unit_elems;
-    uint16_t n_delta_elems;
+    uint16_t n_pass;
     uint8_t  cidx_width;  /* 2 or 4 bytes per column offset                     */
     uint8_t  flags;       /* SPX_RB_* */
+    uint16_t pad_;
     uint32_t carry_slot;  /* SPX_RB_SHARED: slot of the partial sum             */
-    uint32_t pad_;
+    uint32_t pad2_;
 } SpxRowBlock;            /* 48 bytes */
 
 #define SPX_RB_SHARED 1u  /* owns one chunk of an over-long row; the partial
@@ -77,5 +94,16 @@ typedef struct {
     uint32_t first_slot;
     uint32_t n_slots;
 } SpxSharedRow;
+
+/* Position of value (segment lane, column w) inside a unit pass of nseg
+ * segments of width W: columns are stored in pairs so that a lane reads 16
+ * bytes at a time; an odd last column is stored alone. */
+static inline uint32_t spx_pass_value_index(uint32_t lane, uint32_t w, uint32_t nseg,
+                                            uint32_t width)
+{
+    uint32_t pair = w >> 1;
+    if ((width & 1u) && w == width - 1u) return pair * 2u * nseg + lane;
+    return pair * 2u * nseg + lane * 2u + (w & 1u);
+}
 
 #endif /* SPX_GPU_FORMAT_H */

@@ -1,10 +1,13 @@
 // spmv_kernels.hip -- the CSX interpreter for gfx950 (MI355X).
 //
-// One wavefront walks one row-block of the descriptor stream (gpu_format.h):
-// coalesced 32-byte-per-lane reads of the packed values, segment-start bits
-// ranked with ballot/mbcnt to find each nonzero's unit descriptor, strided
-// decode of (row, col), gathered x, wave-level segmented reduction, an LDS
-// y tile per wavefront, and one coalesced write of the owned rows of y.
+// One workgroup walks one row-block of the descriptor stream (gpu_format.h).
+// A pass is 64 row segments of equal width, one per lane: contiguous 16-byte
+// per-lane reads of the interleaved values, the pass' segment-start mask
+// ranked with mbcnt to find each lane's unit descriptor, strided decode of
+// (row, first column), x gathered through L2, W fused multiply-adds per lane,
+// one LDS add per lane into the row-block's y tile, and one coalesced write
+// of the owned rows of y.  Leftover nonzeros run as delta passes (one nonzero
+// per lane, segmented wave scan for long rows).
 //
 // Semantics restated from the reference's SpMV templates
 // (src/templates/csx_spmv_tmpl.c:66-101 and the per-unit bodies
@@ -35,10 +38,9 @@ namespace spx {
 
 struct KernelArgs {
     const SpxRowBlock *rbs;
+    const SpxPass *passes;
     const double *values;
     const SpxUnitDesc *descs;
-    const uint32_t *bits;
-    const uint16_t *pass_rank;
     const uint8_t *cidx;
     const uint16_t *segrows;
     const double *x;
@@ -46,290 +48,123 @@ struct KernelArgs {
     double *carry;
     double alpha, beta;
     uint32_t n_rb;
-    uint32_t ablate;   // debugging only (env SPX_ABLATE): 1 no reduction, 2 no x gather
 };
 
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int BLOCK_THREADS = 64 * WAVES_PER_BLOCK;
 
-__device__ __forceinline__ uint32_t lanes_below(uint64_t mask)
+// set bits of `mask` in lanes 1..lane (bit 0 is never set by the emitter)
+__device__ __forceinline__ uint32_t starts_upto(uint64_t mask, int lane)
 {
-    // number of set bits of `mask` in lanes below the caller
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                     __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
+    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
+    return below + (uint32_t)((mask >> lane) & 1ull);
 }
 
-// Segment starts in front of the caller's first nonzero of this pass
-// (nib = the lane's SPX_LANE_ELEMS start bits), not counting its own.
-__device__ __forceinline__ uint32_t rank_before(uint32_t nib)
+// A unit pass: lane l owns one row segment of W consecutive columns.
+template <bool SYM, int W>
+__device__ __forceinline__ void unit_pass(const KernelArgs &a, const SpxRowBlock &rb,
+                                          const SpxPass &ps, double *tile, int lane)
 {
-    const uint64_t m0 = __ballot(nib & 1u), m1 = __ballot(nib & 2u),
-                   m2 = __ballot(nib & 4u), m3 = __ballot(nib & 8u);
-    return lanes_below(m0) + lanes_below(m1) + lanes_below(m2) + lanes_below(m3);
-}
-
-// Adds the lane's SPX_LANE_ELEMS products into the row-block's LDS tile.
-// Consecutive lanes hold consecutive nonzeros.  Products of equal rows are
-// first merged inside the lane (branch-free run sums); when many lanes
-// continue their neighbour's row (long rows) a segmented wave scan merges
-// across lanes as well, otherwise every run end adds to the tile directly.
-// valid[j] == false marks padding behind the region's last nonzero.
-template <bool FULL>
-__device__ __forceinline__ void reduce_into_tile(double *tile, const int (&rows)[SPX_LANE_ELEMS],
-                                                 const double (&prods)[SPX_LANE_ELEMS],
-                                                 int n_valid, int lane)
-{
-    // run sums: a[j] = sum of the products of the run ending at j (inside the lane)
-    double a[SPX_LANE_ELEMS];
-    a[0] = prods[0];
+    const uint32_t nseg = ps.nseg;
+    const bool active = (uint32_t) lane < nseg;
+    const uint32_t l = active ? (uint32_t) lane : 0u;     // idle lanes shadow lane 0
+    const uint32_t rank = (uint32_t) ps.rank0 + (active ? starts_upto(ps.mask, lane) : 0u);
+    const uint4 q = *reinterpret_cast<const uint4 *>(a.descs + rb.desc_off + rank);
+    // segment index inside its unit, then its row / first column
+    const int s = (int) ((ps.seg0 + l - (q.w & 0xffffu)) & 0xffffu);
+    const int row = (int) (q.z & 0xffffu) + s * (int) (int16_t) (q.z >> 16);
+    const uint32_t col = q.x + (uint32_t) (s * (int) q.y);
+    const double *vals = a.values + rb.val_off + ps.val_off;
+    const double *xp = a.x + col;
+    double acc = 0.0;
 #pragma unroll
-    for (int j = 1; j < SPX_LANE_ELEMS; ++j)
-        a[j] = prods[j] + ((rows[j] == rows[j - 1]) ? a[j - 1] : 0.0);
-    const bool active = FULL || n_valid > 0;
-    const int last_row = rows[SPX_LANE_ELEMS - 1];
-    const bool single = rows[0] == last_row;     // rows are never interleaved inside a lane
-    const int prev_last = __shfl_up(last_row, 1);
-    const bool cont = active && lane != 0 && single && prev_last == last_row;
-    const uint64_t cont_mask = __ballot(cont);
-    double tail = a[SPX_LANE_ELEMS - 1];
-    bool tail_adds = active;
-    if (__popcll(cont_mask) >= 8) {
-        // segmented inclusive scan over the lanes' last runs
-        int head = !cont;
+    for (int p = 0; p < W / 2; ++p) {
+        const double2 v = *reinterpret_cast<const double2 *>(vals + (uint32_t) p * 2u * nseg + l * 2u);
+        acc = fma(v.x, xp[2 * p], acc);
+        acc = fma(v.y, xp[2 * p + 1], acc);
+        if (SYM && active) {
+            const double xr = a.x[rb.row0 + (uint32_t) row] * a.alpha;
+            atomicAdd(&a.y[col + 2 * p], v.x * xr);
+            atomicAdd(&a.y[col + 2 * p + 1], v.y * xr);
+        }
+    }
+    if (W & 1) {
+        const double v = vals[(uint32_t) (W / 2) * 2u * nseg + l];
+        acc = fma(v, xp[W - 1], acc);
+        if (SYM && active) atomicAdd(&a.y[col + W - 1], v * a.x[rb.row0 + (uint32_t) row] * a.alpha);
+    }
+    if (active) atomicAdd(&tile[row], acc);
+}
+
+// A delta pass: lane l owns one leftover nonzero (row-major order).
+template <bool SYM>
+__device__ __forceinline__ void delta_pass(const KernelArgs &a, const SpxRowBlock &rb,
+                                           const SpxPass &ps, double *tile, int lane)
+{
+    const uint32_t nseg = ps.nseg;
+    const bool active = (uint32_t) lane < nseg;
+    const uint32_t l = active ? (uint32_t) lane : 0u;
+    const uint32_t rank = (uint32_t) ps.rank0 + (active ? starts_upto(ps.mask, lane) : 0u);
+    const int row = a.segrows[rb.seg_off + rank];
+    const uint32_t e = (uint32_t) ps.seg0 + l;
+    const uint8_t *cidx = a.cidx + rb.cidx_off;
+    const uint32_t off = (rb.cidx_width == 4) ? reinterpret_cast<const uint32_t *>(cidx)[e]
+                                              : reinterpret_cast<const uint16_t *>(cidx)[e];
+    const uint32_t col = rb.cbase + off;
+    const double v = a.values[rb.val_off + ps.val_off + l];
+    double acc = active ? v * a.x[col] : 0.0;
+    if (SYM && active) atomicAdd(&a.y[col], v * a.x[rb.row0 + (uint32_t) row] * a.alpha);
+
+    // long rows: merge the lanes of a row with a segmented wave scan first
+    const int n_rowsegs = __popcll(ps.mask) + 1;
+    bool adds = active;
+    if ((int) nseg - n_rowsegs >= 16) {
+        int head = (lane == 0) || ((ps.mask >> lane) & 1ull) || !active;
         const int head0 = head;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            const double a2 = __shfl_up(tail, d);
+            const double a2 = __shfl_up(acc, d);
             const int h2 = __shfl_up(head, d);
             if (lane >= d && !head) {
-                tail += a2;
+                acc += a2;
                 head |= h2;
             }
         }
         const int next_head = __shfl_down(head0, 1);
-        tail_adds = active && (lane == 63 || next_head);
+        adds = active && (lane == 63 || next_head);
     }
-#pragma unroll
-    for (int j = 0; j < SPX_LANE_ELEMS - 1; ++j) {
-        const bool ends = rows[j] != rows[j + 1];
-        if (ends && (FULL || j < n_valid)) atomicAdd(&tile[rows[j]], a[j]);
-    }
-    if (tail_adds) atomicAdd(&tile[last_row], tail);
-}
-
-// What a wavefront loads for one pass before it can decode anything: issued
-// one pass ahead of the arithmetic so that the latency of the value stream
-// hides behind the previous pass (software pipeline, 2 stages).
-struct PassLoad {
-    double2 v01, v23;     // the lane's SPX_LANE_ELEMS values
-    uint4 q;              // unit pass: descriptor #(first_desc + lane)
-                          // delta pass: the lane's column offsets
-    uint32_t nib;         // the lane's segment-start bits
-    uint32_t rank0;       // segment starts in front of the pass
-    uint32_t seg;         // delta pass: row of segment #(first_seg + lane)
-    int e0;               // first nonzero of the lane inside the region
-    int n_valid;
-};
-
-template <bool DELTA>
-__device__ __forceinline__ PassLoad issue_pass(const KernelArgs &a, const SpxRowBlock &rb,
-                                               int pass, int n_unit_passes, int lane)
-{
-    PassLoad L;
-    const int n = DELTA ? rb.n_delta_elems : rb.n_unit_elems;
-    L.e0 = pass * SPX_PASS_ELEMS + lane * SPX_LANE_ELEMS;
-    L.n_valid = min(max(n - L.e0, 0), SPX_LANE_ELEMS);
-    const uint32_t gpass = (rb.bits_off >> 3) + (uint32_t) (DELTA ? n_unit_passes + pass : pass);
-    const uint32_t w = a.bits[gpass * SPX_PASS_WORDS + ((uint32_t) lane >> 3)];
-    L.nib = (w >> ((lane & 7) * 4)) & 0xFu;
-    L.rank0 = a.pass_rank[gpass];
-    const double *vals = a.values + rb.val_off + (DELTA ? ((rb.n_unit_elems + 3) & ~3) : 0);
-    // regions are padded to whole lanes with zeros, so whole-lane loads are safe
-    L.v01 = *reinterpret_cast<const double2 *>(vals + (uint32_t) L.e0);
-    L.v23 = *reinterpret_cast<const double2 *>(vals + (uint32_t) L.e0 + 2);
-    L.q = make_uint4(0, 0, 0, 0);
-    L.seg = 0;
-    // descriptors / segment rows this pass can touch start at index
-    // max(rank0 - 1, 0); each lane fetches one of the next 64 (the arrays
-    // carry slack, so reading past a row-block's own entries is harmless)
-    const uint32_t first = L.rank0 ? L.rank0 - 1 : 0;
-    if (DELTA) {
-        const uint8_t *cidx = a.cidx + rb.cidx_off;
-        if (rb.cidx_width == 4) {
-            L.q = *reinterpret_cast<const uint4 *>(cidx + (uint32_t) L.e0 * 4u);
-        } else {
-            const uint2 o = *reinterpret_cast<const uint2 *>(cidx + (uint32_t) L.e0 * 2u);
-            L.q = make_uint4(o.x & 0xffffu, o.x >> 16, o.y & 0xffffu, o.y >> 16);
-        }
-        L.seg = a.segrows[rb.seg_off + first + (uint32_t) lane];
-    } else {
-        L.q = *reinterpret_cast<const uint4 *>(a.descs + rb.desc_off + first + (uint32_t) lane);
-    }
-    return L;
-}
-
-// decoded view of a unit descriptor, ready for stepping
-struct Walk {
-    int rr, cc;        // row (inside the row-block) and column of the current nonzero
-    int in;            // position inside the block row (dense blocks)
-    int mod;           // block row length, 0 for linear units
-    int sr, sc;        // per-nonzero strides (linear), (0, 1) for blocks
-};
-
-__device__ __forceinline__ Walk walk_begin(const uint4 &q)
-{
-    Walk w;
-    w.cc = (int) q.x;
-    w.rr = (int) (q.z >> 16);
-    w.mod = (int) ((q.w >> 16) & 0xffu);
-    w.in = 0;
-    w.sr = w.mod ? 0 : (int) (int16_t) (q.w & 0xffffu);
-    w.sc = w.mod ? 1 : (int) q.y;
-    return w;
-}
-
-__device__ __forceinline__ void walk_step(Walk &w)
-{
-    const int in1 = w.in + 1;
-    const bool wrap = in1 == w.mod;          // never true for linear units (mod == 0)
-    w.cc += wrap ? 1 - w.mod : w.sc;
-    w.rr += wrap ? 1 : w.sr;
-    w.in = wrap ? 0 : in1;
-}
-
-// Decode + multiply + reduce one pass of the unit region.
-template <bool SYM, bool FULL>
-__device__ __forceinline__ void compute_unit_pass(const KernelArgs &a, const SpxRowBlock &rb,
-                                                  double *tile, uint4 *stage,
-                                                  const PassLoad &L, int lane)
-{
-    // exchange the 64 prefetched descriptors through LDS
-    stage[lane] = L.q;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    const uint32_t first = L.rank0 ? L.rank0 - 1 : 0;
-    const uint32_t idx0 = L.rank0 + rank_before(L.nib) + (L.nib & 1u) - 1u;   // lane's first unit
-    const uint32_t rel0 = idx0 - first;
-    const uint4 *gdescs = reinterpret_cast<const uint4 *>(a.descs + rb.desc_off);
-    // more than 64 units in reach of one pass: rare, read those from memory
-    const bool far = __any((rel0 + (uint32_t) __popc(L.nib >> 1)) >= 64u);
-
-    const uint4 q0 = (!far || rel0 < 64u) ? stage[rel0 & 63u] : gdescs[idx0];
-    Walk w = walk_begin(q0);
-    {
-        // position of the lane's first nonzero inside its unit
-        const int k = L.e0 - (int) (q0.z & 0xffffu);
-        if (w.mod) {
-            const int out = (int) (((float) k + 0.5f) * __frcp_rn((float) w.mod));
-            w.in = k - out * w.mod;
-            w.rr += out;
-            w.cc += w.in;
-        } else {
-            w.rr += k * w.sr;
-            w.cc += k * w.sc;
-        }
-    }
-    const double v[SPX_LANE_ELEMS] = {L.v01.x, L.v01.y, L.v23.x, L.v23.y};
-    int rows[SPX_LANE_ELEMS];
-    double prods[SPX_LANE_ELEMS];
-    const bool inner_starts = __any(L.nib & 0xEu);
-#pragma unroll
-    for (int j = 0; j < SPX_LANE_ELEMS; ++j) {
-        if (j > 0) {
-            walk_step(w);
-            if (inner_starts) {
-                // a new unit may start at this nonzero: fetch its descriptor
-                // for every lane and select (no divergent branch)
-                const uint32_t rel = rel0 + (uint32_t) __popc(L.nib & ((2u << j) - 2u));
-                const uint4 qj = (!far || rel < 64u) ? stage[rel & 63u] : gdescs[first + rel];
-                const Walk nw = walk_begin(qj);
-                const bool fresh = (L.nib >> j) & 1u;
-                w.rr = fresh ? nw.rr : w.rr;
-                w.cc = fresh ? nw.cc : w.cc;
-                w.in = fresh ? 0 : w.in;
-                w.mod = fresh ? nw.mod : w.mod;
-                w.sr = fresh ? nw.sr : w.sr;
-                w.sc = fresh ? nw.sc : w.sc;
-            }
-        }
-        const bool ok = FULL || j < L.n_valid;
-        // padding keeps the previous row (it merges into that run with a zero)
-        rows[j] = ok ? w.rr : (j ? rows[j - 1] : 0);
-        const uint32_t c = ok ? (uint32_t) w.cc : 0u;
-        const double xv = (a.ablate & 2u) ? 1.0 : a.x[c];
-        prods[j] = ok ? v[j] * xv : 0.0;
-        if (SYM && ok) atomicAdd(&a.y[c], a.alpha * v[j] * a.x[rb.row0 + (uint32_t) w.rr]);
-    }
-    if (a.ablate & 1u) {
-        const double sacc = prods[0] + prods[1] + prods[2] + prods[3];
-        if (sacc == 123.456) tile[0] = sacc;
-        return;
-    }
-    reduce_into_tile<FULL>(tile, rows, prods, L.n_valid, lane);
-}
-
-// Same for the delta region (leftover nonzeros, row-major).
-template <bool SYM, bool FULL>
-__device__ __forceinline__ void compute_delta_pass(const KernelArgs &a, const SpxRowBlock &rb,
-                                                   double *tile, uint4 *stage,
-                                                   const PassLoad &L, int lane)
-{
-    uint32_t *stage32 = reinterpret_cast<uint32_t *>(stage);
-    stage32[lane] = L.seg;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    const uint32_t first = L.rank0 ? L.rank0 - 1 : 0;
-    const uint32_t idx0 = L.rank0 + rank_before(L.nib) + (L.nib & 1u) - 1u;
-    const uint32_t rel0 = idx0 - first;
-    const uint16_t *segrows = a.segrows + rb.seg_off;
-    const bool far = __any((rel0 + (uint32_t) __popc(L.nib >> 1)) >= 64u);
-
-    const double v[SPX_LANE_ELEMS] = {L.v01.x, L.v01.y, L.v23.x, L.v23.y};
-    const uint32_t off[SPX_LANE_ELEMS] = {L.q.x, L.q.y, L.q.z, L.q.w};
-    int rows[SPX_LANE_ELEMS];
-    double prods[SPX_LANE_ELEMS];
-#pragma unroll
-    for (int j = 0; j < SPX_LANE_ELEMS; ++j) {
-        const uint32_t rel = rel0 + (uint32_t) __popc(L.nib & ((2u << j) - 2u));
-        const int r = (!far || rel < 64u) ? (int) stage32[rel & 63u] : (int) segrows[first + rel];
-        const bool ok = FULL || j < L.n_valid;
-        rows[j] = ok ? r : (j ? rows[j - 1] : 0);
-        const uint32_t c = ok ? rb.cbase + off[j] : 0u;
-        const double xv = (a.ablate & 2u) ? 1.0 : a.x[c];
-        prods[j] = ok ? v[j] * xv : 0.0;
-        if (SYM && ok) atomicAdd(&a.y[c], a.alpha * v[j] * a.x[rb.row0 + (uint32_t) r]);
-    }
-    if (a.ablate & 1u) {
-        const double sacc = prods[0] + prods[1] + prods[2] + prods[3];
-        if (sacc == 123.456) tile[0] = sacc;
-        return;
-    }
-    reduce_into_tile<FULL>(tile, rows, prods, L.n_valid, lane);
+    if (adds) atomicAdd(&tile[row], acc);
 }
 
 template <bool SYM>
-__device__ __forceinline__ void compute_pass(const KernelArgs &a, const SpxRowBlock &rb,
-                                             double *tile, uint4 *stage, const PassLoad &L,
-                                             int t, int n_unit_passes, int lane)
+__device__ __forceinline__ void run_pass(const KernelArgs &a, const SpxRowBlock &rb,
+                                         const SpxPass &ps, double *tile, int lane)
 {
-    // all lanes hold SPX_LANE_ELEMS real nonzeros except in a region's last pass
-    const bool full = __all(L.n_valid == SPX_LANE_ELEMS);
-    if (t < n_unit_passes) {
-        if (full) compute_unit_pass<SYM, true>(a, rb, tile, stage, L, lane);
-        else compute_unit_pass<SYM, false>(a, rb, tile, stage, L, lane);
-    } else {
-        if (full) compute_delta_pass<SYM, true>(a, rb, tile, stage, L, lane);
-        else compute_delta_pass<SYM, false>(a, rb, tile, stage, L, lane);
+    if (ps.kind == SPX_PASS_DELTA) {
+        delta_pass<SYM>(a, rb, ps, tile, lane);
+        return;
+    }
+    switch (ps.width) {         // wave-uniform
+    case 1: unit_pass<SYM, 1>(a, rb, ps, tile, lane); break;
+    case 2: unit_pass<SYM, 2>(a, rb, ps, tile, lane); break;
+    case 3: unit_pass<SYM, 3>(a, rb, ps, tile, lane); break;
+    case 4: unit_pass<SYM, 4>(a, rb, ps, tile, lane); break;
+    case 5: unit_pass<SYM, 5>(a, rb, ps, tile, lane); break;
+    case 6: unit_pass<SYM, 6>(a, rb, ps, tile, lane); break;
+    case 7: unit_pass<SYM, 7>(a, rb, ps, tile, lane); break;
+    default: unit_pass<SYM, 8>(a, rb, ps, tile, lane); break;
     }
 }
 
 // One workgroup owns one row-block; its wavefronts take the passes in turn
-// (wave w: passes w, w+4, ...), loading pass t+4 while computing pass t, and
-// accumulate into one y tile in LDS, which is written out at the end.
+// (wave w: passes w, w+4, ...) and accumulate into one y tile in LDS, which
+// is written out (y = alpha*tile + beta*y) at the end.
 template <bool SYM>
 __global__ __launch_bounds__(BLOCK_THREADS)
 void csx_spmv_kernel(KernelArgs a)
 {
     __shared__ double tile[SPX_MAX_RB_ROWS];
-    __shared__ uint4 stage_all[WAVES_PER_BLOCK][64];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -341,30 +176,13 @@ void csx_spmv_kernel(KernelArgs a)
 
     const SpxRowBlock rb = a.rbs[rb_idx];
     const int n_rows = rb.n_rows;
-    const int n_unit_passes = (rb.n_unit_elems + SPX_PASS_ELEMS - 1) / SPX_PASS_ELEMS;
-    const int n_delta_passes = (rb.n_delta_elems + SPX_PASS_ELEMS - 1) / SPX_PASS_ELEMS;
-    const int n_pass = n_unit_passes + n_delta_passes;
-    uint4 *stage = stage_all[wave];
-
-    // first loads go out before the tile is even zeroed
-    int t = wave;
-    PassLoad cur;
-    if (t < n_pass)
-        cur = (t < n_unit_passes) ? issue_pass<false>(a, rb, t, n_unit_passes, lane)
-                                  : issue_pass<true>(a, rb, t - n_unit_passes, n_unit_passes, lane);
     for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS) tile[i] = 0.0;
     __syncthreads();
 
-    while (t < n_pass) {
-        const int tn = t + WAVES_PER_BLOCK;
-        PassLoad nxt;
-        if (tn < n_pass)
-            nxt = (tn < n_unit_passes)
-                      ? issue_pass<false>(a, rb, tn, n_unit_passes, lane)
-                      : issue_pass<true>(a, rb, tn - n_unit_passes, n_unit_passes, lane);
-        compute_pass<SYM>(a, rb, tile, stage, cur, t, n_unit_passes, lane);
-        cur = nxt;
-        t = tn;
+    const SpxPass *passes = a.passes + rb.pass_off;
+    for (int t = wave; t < (int) rb.n_pass; t += WAVES_PER_BLOCK) {
+        const SpxPass ps = passes[t];
+        run_pass<SYM>(a, rb, ps, tile, lane);
     }
     __syncthreads();
 
@@ -426,8 +244,7 @@ struct DeviceMatrix {
     SpxRowBlock *rbs = nullptr;
     double *values = nullptr;
     SpxUnitDesc *descs = nullptr;
-    uint32_t *bits = nullptr;
-    uint16_t *pass_rank = nullptr;
+    SpxPass *passes = nullptr;
     uint8_t *cidx = nullptr;
     uint16_t *segrows = nullptr;
     SpxSharedRow *shared = nullptr;
@@ -478,10 +295,9 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
     m->n_shared = (uint32_t) s.shared.size();
     m->n_carry = s.n_carry;
     m->rbs = upload(s.rbs);
-    m->values = upload(s.values, 8);
+    m->values = upload(s.values, 160);
     m->descs = upload(s.descs, 72);
-    m->bits = upload(s.bits, SPX_PASS_WORDS);
-    m->pass_rank = upload(s.pass_rank, 4);
+    m->passes = upload(s.passes, 1);
     m->cidx = upload(s.cidx, 64);
     m->segrows = upload(s.segrows, 80);
     m->shared = upload(s.shared);
@@ -501,7 +317,7 @@ void device_free(DeviceMatrix *m)
 {
     if (!m) return;
     (void) hipFree(m->rbs); (void) hipFree(m->values); (void) hipFree(m->descs);
-    (void) hipFree(m->bits); (void) hipFree(m->pass_rank);
+    (void) hipFree(m->passes);
     (void) hipFree(m->cidx); (void) hipFree(m->segrows); (void) hipFree(m->shared);
     (void) hipFree(m->carry);
     if (m->dvalues) (void) hipFree(m->dvalues);
@@ -515,12 +331,10 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     KernelArgs a;
-    a.rbs = m->rbs; a.values = m->values; a.descs = m->descs; a.bits = m->bits;
-    a.pass_rank = m->pass_rank;
+    a.rbs = m->rbs; a.values = m->values; a.descs = m->descs; a.passes = m->passes;
     a.cidx = m->cidx; a.segrows = m->segrows; a.x = d_x; a.y = d_y;
     a.carry = m->carry; a.alpha = alpha; a.beta = beta; a.n_rb = m->n_rb;
-    static const char *abl = getenv("SPX_ABLATE");
-    a.ablate = abl ? (uint32_t) atoi(abl) : 0u;
+
     uint32_t blocks = (m->n_rb + 7u) & ~7u;
     if (m->symmetric) {
         const int t = 256;
