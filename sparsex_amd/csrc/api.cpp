@@ -401,7 +401,16 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     // descriptor stream + upload
     const double t1 = now_sec();
     GpuEmitParams gp;
-    gp.target_elems = (size_t) std::max<long>(64, cfg.get_long("spx.gpu.rowblock_elems"));
+    long rbe = cfg.get_long("spx.gpu.rowblock_elems");
+    if (rbe <= 0) {
+        // auto: about one row-block per workgroup slot of the chip (256 CUs x
+        // 8 workgroups), so that a small matrix runs as a single full round
+        size_t local = 0;
+        for (size_t i = 0; i < nown; ++i) local += A->parts[i].nnz;
+        rbe = (long) (local / 1280 + 1);
+        rbe = std::min<long>(std::max<long>(rbe, 1024), 4096);
+    }
+    gp.target_elems = (size_t) std::max<long>(64, rbe);
     gp.max_rows = (size_t) std::max<long>(1, cfg.get_long("spx.gpu.rowblock_rows"));
     GpuStream gs;
     if (sym) gs.dvalues.assign((size_t) A->nrows, 0.0);

@@ -41,7 +41,7 @@ void Config::reset_defaults()
     props_["spx.rt.gpu_world"] = "1";
     props_["spx.rt.device"] = "-1";          // HIP device ordinal, -1 = current
     props_["spx.rt.keep_encoded"] = "true";  // keep the encoded partitions for export
-    props_["spx.gpu.rowblock_elems"] = "1024"; // target value elements per row-block
+    props_["spx.gpu.rowblock_elems"] = "0";    // target value elements per row-block
     props_["spx.gpu.rowblock_rows"] = "512";   // max rows owned by one row-block
 }
 

@@ -214,22 +214,29 @@ void RbBuilder::emit_delta_passes(SpxRowBlock &rb, std::vector<Single> &singles,
     rb.cidx_width = ((size_t)(cmax - cmin) < 65536) ? 2 : 4;
     uint32_t rowseg = 0;          // index of the current row segment
     idx_t prev_row = -1;
-    for (size_t b = 0; b < n; b += SPX_PASS_SEGS) {
-        const size_t e = std::min(n, b + SPX_PASS_SEGS);
+    const size_t PASS = (size_t) SPX_PASS_SEGS * SPX_DELTA_ROUNDS;
+    for (size_t b = 0; b < n; b += PASS) {
+        const size_t e = std::min(n, b + PASS);
         SpxPass ps;
         std::memset(&ps, 0, sizeof(ps));
         if (out_.values.size() % 2) out_.values.push_back(0.0);
         ps.val_off = (uint32_t)(out_.values.size() - rb.val_off);
         ps.seg0 = (uint16_t) b;
-        ps.nseg = (uint8_t)(e - b);
+        ps.nseg = (uint8_t)(e - b - 1);
         ps.width = 1;
         ps.kind = SPX_PASS_DELTA;
+        ps.dmask_off = (uint32_t) out_.dmasks.size();
+        uint64_t mask_hi[3] = {0, 0, 0};
         for (size_t i = b; i < e; ++i) {
             const Single &s = singles[i];
             if (s.row != prev_row) {
                 out_.segrows.push_back((uint16_t)(s.row - lo));
                 if (i > 0) ++rowseg;
-                if (i > b) ps.mask |= 1ull << (i - b);
+                if (i > b) {
+                    size_t k = i - b;
+                    if (k < 64) ps.mask |= 1ull << k;
+                    else mask_hi[k / 64 - 1] |= 1ull << (k % 64);
+                }
                 prev_row = s.row;
             }
             if (i == b) ps.rank0 = (uint16_t) rowseg;
@@ -244,6 +251,7 @@ void RbBuilder::emit_delta_passes(SpxRowBlock &rb, std::vector<Single> &singles,
             }
             out_.values.push_back(s.val);
         }
+        out_.dmasks.insert(out_.dmasks.end(), mask_hi, mask_hi + 3);
         out_.passes.push_back(ps);
         ++rb.n_pass;
     }

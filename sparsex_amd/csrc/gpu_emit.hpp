@@ -18,6 +18,7 @@ struct GpuStream {
     std::vector<val_t> values;
     std::vector<SpxUnitDesc> descs;
     std::vector<SpxPass> passes;
+    std::vector<uint64_t> dmasks;     // 3 words per delta pass
     std::vector<uint8_t> cidx;
     std::vector<uint16_t> segrows;
     std::vector<SpxRowBlock> rbs;
@@ -34,7 +35,7 @@ struct GpuStream {
 
     size_t index_bytes() const
     {
-        return descs.size() * sizeof(SpxUnitDesc) + passes.size() * sizeof(SpxPass) +
+        return descs.size() * sizeof(SpxUnitDesc) + passes.size() * sizeof(SpxPass) + dmasks.size() * 8 +
                cidx.size() +
                segrows.size() * 2 + rbs.size() * sizeof(SpxRowBlock);
     }

@@ -26,9 +26,9 @@
  * adds ONE partial sum to the row-block's y tile in LDS.  Segment-start bits
  * (one 64-bit mask per pass) tell a lane which descriptor it belongs to.
  *
- * The leftover nonzeros (CSX delta units) form *delta passes*: 64 nonzeros,
- * one per lane, row-major, with a u16/u32 column offset per nonzero (relative
- * to cbase) and one u16 row per row change.
+ * The leftover nonzeros (CSX delta units) form *delta passes*: up to 256
+ * nonzeros, four per lane, row-major, with a u16/u32 column offset per
+ * nonzero (relative to cbase) and one u16 row per row change.
  */
 #ifndef SPX_GPU_FORMAT_H
 #define SPX_GPU_FORMAT_H
@@ -39,7 +39,9 @@
 #define SPX_MAX_RB_ELEMS   8192   /* nonzeros per row-block (16-bit counters)    */
 #define SPX_MAX_SEG_WIDTH  8      /* columns per row segment                      */
 #define SPX_HORIZ_CHUNK    8      /* horizontal units are cut into such chunks   */
-#define SPX_PASS_SEGS      64     /* row segments (lanes) per pass                */
+#define SPX_PASS_SEGS      64     /* row segments (lanes) per unit pass           */
+#define SPX_DELTA_ROUNDS   4      /* a delta pass is up to 4 x 64 nonzeros: lane l
+                                     owns nonzeros l, l+64, l+128, l+192          */
 
 #define SPX_PASS_UNIT   0
 #define SPX_PASS_DELTA  1
@@ -55,17 +57,20 @@ typedef struct {
 
 typedef struct {
     uint64_t mask;       /* bit l: lane l's segment starts a new unit (unit
-                            pass) / a new row (delta pass); bit 0 is never set  */
+                            pass) / a new row (delta pass, first 64 nonzeros);
+                            bit 0 is never set                                  */
     uint32_t val_off;    /* first value of the pass, relative to the row-block  */
     uint16_t rank0;      /* unit pass: descriptor of lane 0's segment
                             delta pass: row-segment index of lane 0's nonzero   */
     uint16_t seg0;       /* unit pass: segments in front of lane 0
                             delta pass: nonzeros of the delta region in front   */
-    uint8_t  nseg;       /* active lanes, 1..64                                  */
+    uint8_t  nseg;       /* unit pass: active lanes, 1..64
+                            delta pass: nonzeros - 1 (0..255)                    */
     uint8_t  width;      /* W: columns per segment (1 for delta passes)          */
     uint8_t  kind;       /* SPX_PASS_UNIT / SPX_PASS_DELTA                       */
     uint8_t  pad_;
-    uint32_t pad2_;
+    uint32_t dmask_off;  /* delta pass: index into dmasks[] of the three masks
+                            holding the row-start bits of nonzeros 64..255       */
 } SpxPass;               /* 24 bytes */
 
 typedef struct {

@@ -39,6 +39,7 @@ namespace spx {
 struct KernelArgs {
     const SpxRowBlock *rbs;
     const SpxPass *passes;
+    const uint64_t *dmasks;
     const double *values;
     const SpxUnitDesc *descs;
     const uint8_t *cidx;
@@ -97,44 +98,70 @@ __device__ __forceinline__ void unit_pass(const KernelArgs &a, const SpxRowBlock
     if (active) atomicAdd(&tile[row], acc);
 }
 
-// A delta pass: lane l owns one leftover nonzero (row-major order).
+// A delta pass: up to 4 x 64 leftover nonzeros in row-major order; lane l
+// owns nonzeros l, l+64, l+128, l+192 (every load of the wavefront is one
+// contiguous block).  Row changes are marked in a 256-bit mask.
 template <bool SYM>
 __device__ __forceinline__ void delta_pass(const KernelArgs &a, const SpxRowBlock &rb,
                                            const SpxPass &ps, double *tile, int lane)
 {
-    const uint32_t nseg = ps.nseg;
-    const bool active = (uint32_t) lane < nseg;
-    const uint32_t l = active ? (uint32_t) lane : 0u;
-    const uint32_t rank = (uint32_t) ps.rank0 + (active ? starts_upto(ps.mask, lane) : 0u);
-    const int row = a.segrows[rb.seg_off + rank];
-    const uint32_t e = (uint32_t) ps.seg0 + l;
+    const uint32_t n = (uint32_t) ps.nseg + 1u;
     const uint8_t *cidx = a.cidx + rb.cidx_off;
-    const uint32_t off = (rb.cidx_width == 4) ? reinterpret_cast<const uint32_t *>(cidx)[e]
-                                              : reinterpret_cast<const uint16_t *>(cidx)[e];
-    const uint32_t col = rb.cbase + off;
-    const double v = a.values[rb.val_off + ps.val_off + l];
-    double acc = active ? v * a.x[col] : 0.0;
-    if (SYM && active) atomicAdd(&a.y[col], v * a.x[rb.row0 + (uint32_t) row] * a.alpha);
-
-    // long rows: merge the lanes of a row with a segmented wave scan first
-    const int n_rowsegs = __popcll(ps.mask) + 1;
-    bool adds = active;
-    if ((int) nseg - n_rowsegs >= 16) {
-        int head = (lane == 0) || ((ps.mask >> lane) & 1ull) || !active;
-        const int head0 = head;
+    const double *vals = a.values + rb.val_off + ps.val_off;
+    const uint64_t *mh = a.dmasks + ps.dmask_off;
+    const uint64_t masks[SPX_DELTA_ROUNDS] = {ps.mask, mh[0], mh[1], mh[2]};
+    bool active[SPX_DELTA_ROUNDS];
+    int row[SPX_DELTA_ROUNDS];
+    uint32_t off[SPX_DELTA_ROUNDS];
+    double v[SPX_DELTA_ROUNDS];
+    uint32_t before = ps.rank0;           // row segments in front of this round
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const double a2 = __shfl_up(acc, d);
-            const int h2 = __shfl_up(head, d);
-            if (lane >= d && !head) {
-                acc += a2;
-                head |= h2;
-            }
-        }
-        const int next_head = __shfl_down(head0, 1);
-        adds = active && (lane == 63 || next_head);
+    for (int k = 0; k < SPX_DELTA_ROUNDS; ++k) {
+        const uint32_t i = (uint32_t) (k * 64 + lane);
+        active[k] = i < n;
+        const uint32_t ii = active[k] ? i : 0u;
+        const uint32_t rank = before + (active[k] ? starts_upto(masks[k], lane) : 0u);
+        before += (uint32_t) __popcll(masks[k]);
+        row[k] = a.segrows[rb.seg_off + (active[k] ? rank : (uint32_t) ps.rank0)];
+        const uint32_t e = (uint32_t) ps.seg0 + ii;
+        off[k] = (rb.cidx_width == 4) ? reinterpret_cast<const uint32_t *>(cidx)[e]
+                                      : reinterpret_cast<const uint16_t *>(cidx)[e];
+        v[k] = vals[ii];
     }
-    if (adds) atomicAdd(&tile[row], acc);
+    double acc[SPX_DELTA_ROUNDS];
+#pragma unroll
+    for (int k = 0; k < SPX_DELTA_ROUNDS; ++k) {
+        const uint32_t col = rb.cbase + off[k];
+        acc[k] = active[k] ? v[k] * a.x[col] : 0.0;
+        if (SYM && active[k])
+            atomicAdd(&a.y[col], v[k] * a.x[rb.row0 + (uint32_t) row[k]] * a.alpha);
+    }
+    // long rows: merge the lanes of a row with a segmented wave scan first
+    const int n_rowsegs = __popcll(masks[0]) + __popcll(masks[1]) + __popcll(masks[2]) +
+                          __popcll(masks[3]) + 1;
+    const bool long_rows = (int) n - n_rowsegs >= (int) n / 4 + 8;
+#pragma unroll
+    for (int k = 0; k < SPX_DELTA_ROUNDS; ++k) {
+        if ((uint32_t) (k * 64) >= n) break;       // wave-uniform
+        bool adds = active[k];
+        double t = acc[k];
+        if (long_rows) {
+            int head = (lane == 0) || ((masks[k] >> lane) & 1ull) || !active[k];
+            const int head0 = head;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const double a2 = __shfl_up(t, d);
+                const int h2 = __shfl_up(head, d);
+                if (lane >= d && !head) {
+                    t += a2;
+                    head |= h2;
+                }
+            }
+            const int next_head = __shfl_down(head0, 1);
+            adds = active[k] && (lane == 63 || next_head);
+        }
+        if (adds) atomicAdd(&tile[row[k]], t);
+    }
 }
 
 template <bool SYM>
@@ -179,10 +206,16 @@ void csx_spmv_kernel(KernelArgs a)
     for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS) tile[i] = 0.0;
     __syncthreads();
 
+    // wave w takes passes w, w+4, ...; the next pass header is fetched while
+    // the current pass runs
     const SpxPass *passes = a.passes + rb.pass_off;
-    for (int t = wave; t < (int) rb.n_pass; t += WAVES_PER_BLOCK) {
-        const SpxPass ps = passes[t];
+    const int n_pass = rb.n_pass;
+    int t = wave;
+    SpxPass ps = passes[min(t, max(n_pass - 1, 0))];
+    for (; t < n_pass; t += WAVES_PER_BLOCK) {
+        const SpxPass nxt = passes[min(t + WAVES_PER_BLOCK, n_pass - 1)];
         run_pass<SYM>(a, rb, ps, tile, lane);
+        ps = nxt;
     }
     __syncthreads();
 
@@ -245,6 +278,7 @@ struct DeviceMatrix {
     double *values = nullptr;
     SpxUnitDesc *descs = nullptr;
     SpxPass *passes = nullptr;
+    uint64_t *dmasks = nullptr;
     uint8_t *cidx = nullptr;
     uint16_t *segrows = nullptr;
     SpxSharedRow *shared = nullptr;
@@ -298,6 +332,7 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
     m->values = upload(s.values, 160);
     m->descs = upload(s.descs, 72);
     m->passes = upload(s.passes, 1);
+    m->dmasks = upload(s.dmasks, 4);
     m->cidx = upload(s.cidx, 64);
     m->segrows = upload(s.segrows, 80);
     m->shared = upload(s.shared);
@@ -317,7 +352,7 @@ void device_free(DeviceMatrix *m)
 {
     if (!m) return;
     (void) hipFree(m->rbs); (void) hipFree(m->values); (void) hipFree(m->descs);
-    (void) hipFree(m->passes);
+    (void) hipFree(m->passes); (void) hipFree(m->dmasks);
     (void) hipFree(m->cidx); (void) hipFree(m->segrows); (void) hipFree(m->shared);
     (void) hipFree(m->carry);
     if (m->dvalues) (void) hipFree(m->dvalues);
@@ -332,6 +367,7 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     KernelArgs a;
     a.rbs = m->rbs; a.values = m->values; a.descs = m->descs; a.passes = m->passes;
+    a.dmasks = m->dmasks;
     a.cidx = m->cidx; a.segrows = m->segrows; a.x = d_x; a.y = d_y;
     a.carry = m->carry; a.alpha = alpha; a.beta = beta; a.n_rb = m->n_rb;
 
