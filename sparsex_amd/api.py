@@ -22,7 +22,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libsparsex.so")
+    # SPX_LIB_PATH selects an alternative build of the same library (kernel
+    # experiments); the default is the in-tree product build
+    return os.environ.get("SPX_LIB_PATH") or os.path.join(_HERE, "lib", "libsparsex.so")
 
 
 class SpxError(RuntimeError):

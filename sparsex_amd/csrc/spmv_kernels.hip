@@ -51,7 +51,10 @@ struct KernelArgs {
     uint32_t n_rb;
 };
 
-constexpr int WAVES_PER_BLOCK = 4;
+#ifndef SPX_WAVES
+#define SPX_WAVES 4
+#endif
+constexpr int WAVES_PER_BLOCK = SPX_WAVES;
 constexpr int BLOCK_THREADS = 64 * WAVES_PER_BLOCK;
 
 // set bits of `mask` in lanes 1..lane (bit 0 is never set by the emitter)
@@ -62,40 +65,94 @@ __device__ __forceinline__ uint32_t starts_upto(uint64_t mask, int lane)
     return below + (uint32_t)((mask >> lane) & 1ull);
 }
 
-// A unit pass: lane l owns one row segment of W consecutive columns.
-template <bool SYM, int W>
-__device__ __forceinline__ void unit_pass(const KernelArgs &a, const SpxRowBlock &rb,
-                                          const SpxPass &ps, double *tile, int lane)
+// B unit passes of the same width at once: lane l owns one row segment of W
+// consecutive columns in each of them.  All descriptor loads go out first,
+// then all value loads, then the x gathers: one memory round trip per stage
+// for the whole batch instead of one per pass.
+template <bool SYM, int W, int B>
+__device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlock &rb,
+                                            const SpxPass (&ps)[B], double *tile, int lane)
 {
-    const uint32_t nseg = ps.nseg;
-    const bool active = (uint32_t) lane < nseg;
-    const uint32_t l = active ? (uint32_t) lane : 0u;     // idle lanes shadow lane 0
-    const uint32_t rank = (uint32_t) ps.rank0 + (active ? starts_upto(ps.mask, lane) : 0u);
-    const uint4 q = *reinterpret_cast<const uint4 *>(a.descs + rb.desc_off + rank);
-    // segment index inside its unit, then its row / first column
-    const int s = (int) ((ps.seg0 + l - (q.w & 0xffffu)) & 0xffffu);
-    const int row = (int) (q.z & 0xffffu) + s * (int) (int16_t) (q.z >> 16);
-    const uint32_t col = q.x + (uint32_t) (s * (int) q.y);
-    const double *vals = a.values + rb.val_off + ps.val_off;
-    const double *xp = a.x + col;
-    double acc = 0.0;
+    bool active[B];
+    uint32_t l[B], nseg[B];
+    uint4 q[B];
 #pragma unroll
-    for (int p = 0; p < W / 2; ++p) {
-        const double2 v = *reinterpret_cast<const double2 *>(vals + (uint32_t) p * 2u * nseg + l * 2u);
-        acc = fma(v.x, xp[2 * p], acc);
-        acc = fma(v.y, xp[2 * p + 1], acc);
-        if (SYM && active) {
-            const double xr = a.x[rb.row0 + (uint32_t) row] * a.alpha;
-            atomicAdd(&a.y[col + 2 * p], v.x * xr);
-            atomicAdd(&a.y[col + 2 * p + 1], v.y * xr);
+    for (int b = 0; b < B; ++b) {
+        nseg[b] = ps[b].nseg;
+        active[b] = (uint32_t) lane < nseg[b];
+        l[b] = active[b] ? (uint32_t) lane : 0u;         // idle lanes shadow lane 0
+        const uint32_t rank = (uint32_t) ps[b].rank0 + (active[b] ? starts_upto(ps[b].mask, lane) : 0u);
+        q[b] = *reinterpret_cast<const uint4 *>(a.descs + rb.desc_off + rank);
+    }
+    double2 v2[B][W / 2 > 0 ? W / 2 : 1];
+    double v1[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        const double *vals = a.values + rb.val_off + ps[b].val_off;
+#pragma unroll
+        for (int p = 0; p < W / 2; ++p)
+            v2[b][p] = *reinterpret_cast<const double2 *>(vals + (uint32_t) p * 2u * nseg[b] + l[b] * 2u);
+        if (W & 1) v1[b] = vals[(uint32_t) (W / 2) * 2u * nseg[b] + l[b]];
+    }
+#ifdef SPX_ABL_VALSONLY
+    {
+        double t = 0.0;
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+#pragma unroll
+            for (int p = 0; p < W / 2; ++p) t += v2[b][p].x + v2[b][p].y;
+            if (W & 1) t += v1[b];
+            t += (double) q[b].x;
+        }
+        if (t == 1.2345) tile[0] = t;
+        return;
+    }
+#endif
+    int row[B];
+    double acc[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        // segment index inside its unit, then its row / first column
+        const int s = (int) ((ps[b].seg0 + l[b] - (q[b].w & 0xffffu)) & 0xffffu);
+        row[b] = (int) (q[b].z & 0xffffu) + s * (int) (int16_t) (q[b].z >> 16);
+        const uint32_t col = q[b].x + (uint32_t) (s * (int) q[b].y);
+        const double *xp = a.x + col;
+        double x[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+#ifdef SPX_ABL_NOX
+            x[w] = (double) col;
+#else
+            x[w] = xp[w];
+#endif
+        }
+        double t = 0.0;
+#pragma unroll
+        for (int p = 0; p < W / 2; ++p) {
+            t = fma(v2[b][p].x, x[2 * p], t);
+            t = fma(v2[b][p].y, x[2 * p + 1], t);
+        }
+        if (W & 1) t = fma(v1[b], x[W - 1], t);
+        acc[b] = t;
+        if (SYM && active[b]) {
+            const double xr = a.x[rb.row0 + (uint32_t) row[b]] * a.alpha;
+#pragma unroll
+            for (int p = 0; p < W / 2; ++p) {
+                atomicAdd(&a.y[col + 2 * p], v2[b][p].x * xr);
+                atomicAdd(&a.y[col + 2 * p + 1], v2[b][p].y * xr);
+            }
+            if (W & 1) atomicAdd(&a.y[col + W - 1], v1[b] * xr);
         }
     }
-    if (W & 1) {
-        const double v = vals[(uint32_t) (W / 2) * 2u * nseg + l];
-        acc = fma(v, xp[W - 1], acc);
-        if (SYM && active) atomicAdd(&a.y[col + W - 1], v * a.x[rb.row0 + (uint32_t) row] * a.alpha);
-    }
-    if (active) atomicAdd(&tile[row], acc);
+#ifdef SPX_ABL_NOATOMIC
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+        if (active[b] && acc[b] == 1.2345) tile[row[b]] = acc[b];
+#else
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+        if (active[b]) atomicAdd(&tile[row[b]], acc[b]);
+#endif
 }
 
 // A delta pass: up to 4 x 64 leftover nonzeros in row-major order; lane l
@@ -164,24 +221,36 @@ __device__ __forceinline__ void delta_pass(const KernelArgs &a, const SpxRowBloc
     }
 }
 
+template <bool SYM, int B>
+__device__ __forceinline__ void run_units(const KernelArgs &a, const SpxRowBlock &rb,
+                                          const SpxPass (&ps)[B], double *tile, int lane)
+{
+    switch (ps[0].width) {         // wave-uniform
+    case 1: unit_passes<SYM, 1, B>(a, rb, ps, tile, lane); break;
+    case 2: unit_passes<SYM, 2, B>(a, rb, ps, tile, lane); break;
+    case 3: unit_passes<SYM, 3, B>(a, rb, ps, tile, lane); break;
+    case 4: unit_passes<SYM, 4, B>(a, rb, ps, tile, lane); break;
+    case 5: unit_passes<SYM, 5, 1>(a, rb, {ps[0]}, tile, lane);
+            if (B > 1) unit_passes<SYM, 5, 1>(a, rb, {ps[B - 1]}, tile, lane);
+            break;
+    case 6: unit_passes<SYM, 6, 1>(a, rb, {ps[0]}, tile, lane);
+            if (B > 1) unit_passes<SYM, 6, 1>(a, rb, {ps[B - 1]}, tile, lane);
+            break;
+    case 7: unit_passes<SYM, 7, 1>(a, rb, {ps[0]}, tile, lane);
+            if (B > 1) unit_passes<SYM, 7, 1>(a, rb, {ps[B - 1]}, tile, lane);
+            break;
+    default: unit_passes<SYM, 8, 1>(a, rb, {ps[0]}, tile, lane);
+            if (B > 1) unit_passes<SYM, 8, 1>(a, rb, {ps[B - 1]}, tile, lane);
+            break;
+    }
+}
+
 template <bool SYM>
 __device__ __forceinline__ void run_pass(const KernelArgs &a, const SpxRowBlock &rb,
                                          const SpxPass &ps, double *tile, int lane)
 {
-    if (ps.kind == SPX_PASS_DELTA) {
-        delta_pass<SYM>(a, rb, ps, tile, lane);
-        return;
-    }
-    switch (ps.width) {         // wave-uniform
-    case 1: unit_pass<SYM, 1>(a, rb, ps, tile, lane); break;
-    case 2: unit_pass<SYM, 2>(a, rb, ps, tile, lane); break;
-    case 3: unit_pass<SYM, 3>(a, rb, ps, tile, lane); break;
-    case 4: unit_pass<SYM, 4>(a, rb, ps, tile, lane); break;
-    case 5: unit_pass<SYM, 5>(a, rb, ps, tile, lane); break;
-    case 6: unit_pass<SYM, 6>(a, rb, ps, tile, lane); break;
-    case 7: unit_pass<SYM, 7>(a, rb, ps, tile, lane); break;
-    default: unit_pass<SYM, 8>(a, rb, ps, tile, lane); break;
-    }
+    if (ps.kind == SPX_PASS_DELTA) delta_pass<SYM>(a, rb, ps, tile, lane);
+    else run_units<SYM, 1>(a, rb, {ps}, tile, lane);
 }
 
 // One workgroup owns one row-block; its wavefronts take the passes in turn
@@ -210,12 +279,25 @@ void csx_spmv_kernel(KernelArgs a)
     // the current pass runs
     const SpxPass *passes = a.passes + rb.pass_off;
     const int n_pass = rb.n_pass;
-    int t = wave;
-    SpxPass ps = passes[min(t, max(n_pass - 1, 0))];
-    for (; t < n_pass; t += WAVES_PER_BLOCK) {
-        const SpxPass nxt = passes[min(t + WAVES_PER_BLOCK, n_pass - 1)];
-        run_pass<SYM>(a, rb, ps, tile, lane);
-        ps = nxt;
+    // two of the wave's passes at a time when they have the same shape (they
+    // mostly do: passes are sorted by width), so that their loads overlap
+#ifdef SPX_ABL_NOPASS
+    if (a.alpha == 123.0)
+#endif
+    for (int t = wave; t < n_pass; t += 2 * WAVES_PER_BLOCK) {
+        const SpxPass p0 = passes[t];
+        const int t1 = t + WAVES_PER_BLOCK;
+        if (t1 < n_pass) {
+            const SpxPass p1 = passes[t1];
+            if (p0.kind == SPX_PASS_UNIT && p1.kind == SPX_PASS_UNIT && p0.width == p1.width) {
+                run_units<SYM, 2>(a, rb, {p0, p1}, tile, lane);
+            } else {
+                run_pass<SYM>(a, rb, p0, tile, lane);
+                run_pass<SYM>(a, rb, p1, tile, lane);
+            }
+        } else {
+            run_pass<SYM>(a, rb, p0, tile, lane);
+        }
     }
     __syncthreads();
 
