@@ -402,7 +402,8 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     const double t1 = now_sec();
     GpuEmitParams gp;
     long rbe = cfg.get_long("spx.gpu.rowblock_elems");
-    if (rbe <= 0) {
+    const bool auto_rb = rbe <= 0;
+    if (auto_rb) {
         // auto: about one row-block per workgroup slot of the chip (256 CUs x
         // 8 workgroups), so that a small matrix runs as a single full round
         size_t local = 0;
@@ -413,14 +414,25 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     gp.target_elems = (size_t) std::max<long>(64, rbe);
     gp.max_rows = (size_t) std::max<long>(1, cfg.get_long("spx.gpu.rowblock_rows"));
     GpuStream gs;
-    if (sym) gs.dvalues.assign((size_t) A->nrows, 0.0);
-    for (size_t i = 0; i < nown; ++i) {
-        emit_gpu(A->parts[i], gp, gs);
-        if (sym) {
+    if (sym) {
+        // The GPU stream holds the stored lower triangle and its mirror image
+        // as one general matrix over rows [0, last owned row): every row is
+        // then owned by exactly one row-block of this process and no atomics
+        // are needed; the diagonal goes through csx_sym_init_kernel.
+        gs.dvalues.assign((size_t) A->nrows, 0.0);
+        Partition full;
+        for (size_t i = 0; i < nown; ++i) {
+            append_sym_expanded(A->parts[i], full);
             const PartBounds &b = A->bounds[first + i];
             for (size_t r = 0; r < A->diag[i].size() && r < (size_t) b.nr_rows; ++r)
                 gs.dvalues[(size_t) b.row_start + r] = A->diag[i][r];
         }
+        gp.skip_empty = true;
+        if (auto_rb)
+            gp.target_elems = std::min<size_t>(std::max<size_t>(full.nnz / 1280 + 1, 1024), 4096);
+        emit_gpu(full, gp, gs);
+    } else {
+        for (size_t i = 0; i < nown; ++i) emit_gpu(A->parts[i], gp, gs);
     }
     A->nnz_stored = gs.nnz_stored;
     A->n_unit_elems = gs.n_unit_elems;

@@ -291,6 +291,54 @@ void RbBuilder::emit(idx_t lo, idx_t hi, const std::vector<Piece> &pieces,
 
 }  // namespace
 
+void append_sym_expanded(const Partition &lower, Partition &out)
+{
+    const idx_t rs = lower.row_start;
+    out.type = ENC_H;
+    out.row_start = 0;
+    out.nr_cols = lower.nr_cols;
+    out.nr_rows = std::max<size_t>(out.nr_rows, (size_t) rs + lower.nr_rows);
+    for (size_t i = 0; i < lower.elems_size; ++i) {
+        Elem e = lower.elems[i];
+        e.row += rs;                       // global row
+        if (!e.is_unit()) {
+            out.elems.push_back(e);
+            out.elems.push_back(make_single(e.col, e.row, e.val));
+            continue;
+        }
+        const val_t *src = &lower.pool[e.voff];
+        e.voff = out.pool_alloc(src, e.size);
+        out.elems.push_back(e);
+        Elem t = e;                        // the mirror image
+        t.row = e.col;
+        t.col = e.row;
+        switch (e.type) {
+        case ENC_H: t.type = ENC_V; break;
+        case ENC_V: t.type = ENC_H; break;
+        case ENC_D: break;
+        case ENC_AD: {
+            // (r + k*d, c - k*d) mirrors to (c - k*d, r + k*d): walked from
+            // its top-right end, i.e. in reverse
+            const idx_t span = (idx_t)(e.size - 1) * (idx_t) e.delta;
+            t.row = e.col - span;
+            t.col = e.row + span;
+            std::vector<val_t> rev(src, src + e.size);
+            std::reverse(rev.begin(), rev.end());
+            t.voff = out.pool_alloc(rev.data(), e.size);
+            break;
+        }
+        default:
+            // R x c column-major block-row  <->  c x R row-major block-col
+            // (same value order); the free dimension stays in `delta`
+            if (enc_is_block_row(e.type)) t.type = (uint8_t)(ENC_BC1 + (e.type - ENC_BR1));
+            else t.type = (uint8_t)(ENC_BR1 + (e.type - ENC_BC1));
+        }
+        out.elems.push_back(t);
+    }
+    out.elems_size = out.elems.size();
+    out.nnz += 2 * lower.nnz;
+}
+
 void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out)
 {
     assert(p.type == ENC_H);
@@ -403,6 +451,7 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out)
     RbBuilder bld(p, out);
     for (size_t i = 0; i < plans.size(); ++i) {
         const Plan &pl = plans[i];
+        if (prm.skip_empty && pieces[i].empty() && singles[i].empty()) continue;
         if (!pl.split) {
             bld.emit(pl.row_lo, pl.row_hi, pieces[i], singles[i], 0, 0);
             continue;

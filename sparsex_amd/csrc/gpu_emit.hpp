@@ -44,11 +44,19 @@ struct GpuStream {
 struct GpuEmitParams {
     size_t target_elems = 2048;   // spx.gpu.rowblock_elems
     size_t max_rows = SPX_MAX_RB_ROWS;   // spx.gpu.rowblock_rows (<= SPX_MAX_RB_ROWS)
+    bool skip_empty = false;      // accumulate mode: rows without nonzeros need no write
 };
 
 // Appends the row-blocks of partition `p` (horizontal order) to `out`.
 // Rows are numbered globally (p.row_start + local row).
 void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out);
+
+// Symmetric path: the strictly lower triangle held by `lower` (rows local to
+// the partition) plus the mirror image of every unit, as one general
+// partition in global row numbering (row_start 0).  Mirrors keep the unit
+// structure: horizontal <-> vertical, diagonal and anti-diagonal stay,
+// block-row R x c <-> block-col c x R.  Appends to `out`.
+void append_sym_expanded(const Partition &lower, Partition &out);
 
 // coordinates (1-based, horizontal order) of element k of a unit
 inline void unit_elem_coords(const Elem &u, size_t k, idx_t &r, idx_t &c)

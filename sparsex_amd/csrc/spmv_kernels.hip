@@ -13,7 +13,8 @@
 // (src/templates/csx_spmv_tmpl.c:66-101 and the per-unit bodies
 // delta/horiz/vert/diag/rdiag/block_row/block_col _tmpl.c; symmetric:
 // csx_sym_spmv_tmpl.c:60-106): every stored nonzero a(r,c) contributes
-// alpha*a*x[c] to y[r] (and alpha*a*x[r] to y[c] on the symmetric path).
+// alpha*a*x[c] to y[r]; on the symmetric path the stream also holds the mirror
+// image of every stored unit, so a(r,c) contributes alpha*a*x[r] to y[c] too.
 #include "device.hpp"
 
 #include <hip/hip_runtime.h>
@@ -69,7 +70,7 @@ __device__ __forceinline__ uint32_t starts_upto(uint64_t mask, int lane)
 // consecutive columns in each of them.  All descriptor loads go out first,
 // then all value loads, then the x gathers: one memory round trip per stage
 // for the whole batch instead of one per pass.
-template <bool SYM, int W, int B>
+template <int W, int B>
 __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlock &rb,
                                             const SpxPass (&ps)[B], double *tile, int lane)
 {
@@ -134,15 +135,6 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
         }
         if (W & 1) t = fma(v1[b], x[W - 1], t);
         acc[b] = t;
-        if (SYM && active[b]) {
-            const double xr = a.x[rb.row0 + (uint32_t) row[b]] * a.alpha;
-#pragma unroll
-            for (int p = 0; p < W / 2; ++p) {
-                atomicAdd(&a.y[col + 2 * p], v2[b][p].x * xr);
-                atomicAdd(&a.y[col + 2 * p + 1], v2[b][p].y * xr);
-            }
-            if (W & 1) atomicAdd(&a.y[col + W - 1], v1[b] * xr);
-        }
     }
 #ifdef SPX_ABL_NOATOMIC
 #pragma unroll
@@ -158,7 +150,6 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
 // A delta pass: up to 4 x 64 leftover nonzeros in row-major order; lane l
 // owns nonzeros l, l+64, l+128, l+192 (every load of the wavefront is one
 // contiguous block).  Row changes are marked in a 256-bit mask.
-template <bool SYM>
 __device__ __forceinline__ void delta_pass(const KernelArgs &a, const SpxRowBlock &rb,
                                            const SpxPass &ps, double *tile, int lane)
 {
@@ -190,8 +181,6 @@ __device__ __forceinline__ void delta_pass(const KernelArgs &a, const SpxRowBloc
     for (int k = 0; k < SPX_DELTA_ROUNDS; ++k) {
         const uint32_t col = rb.cbase + off[k];
         acc[k] = active[k] ? v[k] * a.x[col] : 0.0;
-        if (SYM && active[k])
-            atomicAdd(&a.y[col], v[k] * a.x[rb.row0 + (uint32_t) row[k]] * a.alpha);
     }
     // long rows: merge the lanes of a row with a segmented wave scan first
     const int n_rowsegs = __popcll(masks[0]) + __popcll(masks[1]) + __popcll(masks[2]) +
@@ -221,42 +210,40 @@ __device__ __forceinline__ void delta_pass(const KernelArgs &a, const SpxRowBloc
     }
 }
 
-template <bool SYM, int B>
+template <int B>
 __device__ __forceinline__ void run_units(const KernelArgs &a, const SpxRowBlock &rb,
                                           const SpxPass (&ps)[B], double *tile, int lane)
 {
     switch (ps[0].width) {         // wave-uniform
-    case 1: unit_passes<SYM, 1, B>(a, rb, ps, tile, lane); break;
-    case 2: unit_passes<SYM, 2, B>(a, rb, ps, tile, lane); break;
-    case 3: unit_passes<SYM, 3, B>(a, rb, ps, tile, lane); break;
-    case 4: unit_passes<SYM, 4, B>(a, rb, ps, tile, lane); break;
-    case 5: unit_passes<SYM, 5, 1>(a, rb, {ps[0]}, tile, lane);
-            if (B > 1) unit_passes<SYM, 5, 1>(a, rb, {ps[B - 1]}, tile, lane);
+    case 1: unit_passes<1, B>(a, rb, ps, tile, lane); break;
+    case 2: unit_passes<2, B>(a, rb, ps, tile, lane); break;
+    case 3: unit_passes<3, B>(a, rb, ps, tile, lane); break;
+    case 4: unit_passes<4, B>(a, rb, ps, tile, lane); break;
+    case 5: unit_passes<5, 1>(a, rb, {ps[0]}, tile, lane);
+            if (B > 1) unit_passes<5, 1>(a, rb, {ps[B - 1]}, tile, lane);
             break;
-    case 6: unit_passes<SYM, 6, 1>(a, rb, {ps[0]}, tile, lane);
-            if (B > 1) unit_passes<SYM, 6, 1>(a, rb, {ps[B - 1]}, tile, lane);
+    case 6: unit_passes<6, 1>(a, rb, {ps[0]}, tile, lane);
+            if (B > 1) unit_passes<6, 1>(a, rb, {ps[B - 1]}, tile, lane);
             break;
-    case 7: unit_passes<SYM, 7, 1>(a, rb, {ps[0]}, tile, lane);
-            if (B > 1) unit_passes<SYM, 7, 1>(a, rb, {ps[B - 1]}, tile, lane);
+    case 7: unit_passes<7, 1>(a, rb, {ps[0]}, tile, lane);
+            if (B > 1) unit_passes<7, 1>(a, rb, {ps[B - 1]}, tile, lane);
             break;
-    default: unit_passes<SYM, 8, 1>(a, rb, {ps[0]}, tile, lane);
-            if (B > 1) unit_passes<SYM, 8, 1>(a, rb, {ps[B - 1]}, tile, lane);
+    default: unit_passes<8, 1>(a, rb, {ps[0]}, tile, lane);
+            if (B > 1) unit_passes<8, 1>(a, rb, {ps[B - 1]}, tile, lane);
             break;
     }
 }
 
-template <bool SYM>
 __device__ __forceinline__ void run_pass(const KernelArgs &a, const SpxRowBlock &rb,
                                          const SpxPass &ps, double *tile, int lane)
 {
-    if (ps.kind == SPX_PASS_DELTA) delta_pass<SYM>(a, rb, ps, tile, lane);
-    else run_units<SYM, 1>(a, rb, {ps}, tile, lane);
+    if (ps.kind == SPX_PASS_DELTA) delta_pass(a, rb, ps, tile, lane);
+    else run_units<1>(a, rb, {ps}, tile, lane);
 }
 
 // One workgroup owns one row-block; its wavefronts take the passes in turn
 // (wave w: passes w, w+4, ...) and accumulate into one y tile in LDS, which
 // is written out (y = alpha*tile + beta*y) at the end.
-template <bool SYM>
 __global__ __launch_bounds__(BLOCK_THREADS)
 void csx_spmv_kernel(KernelArgs a)
 {
@@ -290,22 +277,19 @@ void csx_spmv_kernel(KernelArgs a)
         if (t1 < n_pass) {
             const SpxPass p1 = passes[t1];
             if (p0.kind == SPX_PASS_UNIT && p1.kind == SPX_PASS_UNIT && p0.width == p1.width) {
-                run_units<SYM, 2>(a, rb, {p0, p1}, tile, lane);
+                run_units<2>(a, rb, {p0, p1}, tile, lane);
             } else {
-                run_pass<SYM>(a, rb, p0, tile, lane);
-                run_pass<SYM>(a, rb, p1, tile, lane);
+                run_pass(a, rb, p0, tile, lane);
+                run_pass(a, rb, p1, tile, lane);
             }
         } else {
-            run_pass<SYM>(a, rb, p0, tile, lane);
+            run_pass(a, rb, p0, tile, lane);
         }
     }
     __syncthreads();
 
     // ---------------- write the owned rows ------------------------------------------------
-    if (SYM) {
-        for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS)
-            atomicAdd(&a.y[rb.row0 + i], a.alpha * tile[i]);
-    } else if (rb.flags & SPX_RB_SHARED) {
+    if (rb.flags & SPX_RB_SHARED) {
         if (threadIdx.x == 0) a.carry[rb.carry_slot] = tile[0];
     } else if (a.beta == 0.0) {
         for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS)
@@ -332,8 +316,8 @@ __global__ void csx_fixup_kernel(const SpxSharedRow *shared, uint32_t n_shared,
 }
 
 // symmetric path, first step: y <- beta*y + alpha*diag(A)*x on the owned
-// rows, 0 elsewhere (the main kernel then accumulates with atomics; on
-// several GPUs the per-GPU vectors are summed afterwards)
+// rows, 0 elsewhere (the main kernel then accumulates; on several GPUs the
+// per-GPU vectors are summed afterwards)
 __global__ void csx_sym_init_kernel(double *y, const double *x, const double *dvalues,
                                     size_t nrows, size_t own_lo, size_t own_hi,
                                     double alpha, double beta)
@@ -455,22 +439,20 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
 
     uint32_t blocks = (m->n_rb + 7u) & ~7u;
     if (m->symmetric) {
+        // y <- beta*y + alpha*diag*x on the owned rows, 0 elsewhere; the
+        // row-blocks (stored lower triangle and its mirror image) then
+        // accumulate on top of that
         const int t = 256;
         hipLaunchKernelGGL(csx_sym_init_kernel, dim3((unsigned)((m->nrows + t - 1) / t)),
                            dim3(t), 0, stream, d_y, d_x, m->dvalues, m->nrows,
                            m->own_lo, m->own_hi, alpha, beta);
-        if (blocks)
-            hipLaunchKernelGGL(csx_spmv_kernel<true>, dim3(blocks),
-                               dim3(BLOCK_THREADS), 0, stream, a);
-    } else {
-        if (blocks)
-            hipLaunchKernelGGL(csx_spmv_kernel<false>, dim3(blocks),
-                               dim3(BLOCK_THREADS), 0, stream, a);
-        if (m->n_shared)
-            hipLaunchKernelGGL(csx_fixup_kernel, dim3((m->n_shared + 63) / 64), dim3(64),
-                               0, stream, m->shared, m->n_shared, m->carry, d_y, alpha,
-                               beta);
+        a.beta = beta = 1.0;
     }
+    if (blocks)
+        hipLaunchKernelGGL(csx_spmv_kernel, dim3(blocks), dim3(BLOCK_THREADS), 0, stream, a);
+    if (m->n_shared)
+        hipLaunchKernelGGL(csx_fixup_kernel, dim3((m->n_shared + 63) / 64), dim3(64), 0,
+                           stream, m->shared, m->n_shared, m->carry, d_y, alpha, beta);
     HIP_CHECK(hipGetLastError());
 }
 

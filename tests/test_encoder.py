@@ -126,7 +126,8 @@ def test_symmetric_partitions_and_product():
              host_only=True)
     inf = A.info()
     assert inf.symmetric == 1
-    assert inf.nnz_stored == synth.lower_plus_diag_nnz(rp, ci) - n   # strictly lower part
+    # HBM holds the strictly lower triangle and its mirror image
+    assert inf.nnz_stored == 2 * (synth.lower_plus_diag_nnz(rp, ci) - n)
     x = synth.random_x(n)
     yo, ex = oracle_y(A, x, 0.5)
     check_y(csr, x, yo, 0.5)
