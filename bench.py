@@ -170,8 +170,8 @@ def cpu_baseline(csr, symmetric, budget_s=20.0):
     cores = host_cores()
     nnz = int(rp[-1])
     x = synth.random_x(n)
-    cands = [t for t in REF_BASELINE_THREADS if t <= cores and t >= min(8, cores)]
-    cands = cands[-5:]                      # the largest few counts that fit
+    cands = [t for t in (8, 16, 32, 64, 128, 256) if t <= cores] or [cores]
+    cands = cands[-5:]
     best = None
     share = budget_s / max(len(cands), 1)
     tried = {}
@@ -189,6 +189,18 @@ def cpu_baseline(csr, symmetric, budget_s=20.0):
             "sample": "median of 5 batches x %d SpMVs (alpha=0.5) of the same matrix, one "
                       "partition per pinned thread; thread counts tried (GFLOP/s): %s; "
                       "host has %d cores" % (loops, json.dumps(tried), cores)}
+
+
+def measured_traffic(workload):
+    """HBM bytes per launch from the committed PMC passes (profiles/traffic.json,
+    produced by tools/profile.sh: FETCH_SIZE and WRITE_SIZE in separate
+    rocprofv3 --pmc runs, FETCH_SIZE doubled per the gfx950 note of the
+    microarchitecture guide); None when this workload was not profiled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f)[workload]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def main():
@@ -309,7 +321,10 @@ def main():
                            else "no collective")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None, "kernel": "csx_spmv_kernel",
+                         "traffic": (measured_traffic(args.workload)
+                                     if world == 1 and not args.symmetric and args.scale == 1.0
+                                     and not args.opt else None),
+                         "kernel": "csx_spmv_kernel",
                          "algorithmic_bytes_per_launch": int(b_alg),
                          "avg_launch_us": round(1e6 * launch_s, 3)},
             "format": {"nnz_stored": nnz_local, "unit_elems": int(info.n_unit_elems),
