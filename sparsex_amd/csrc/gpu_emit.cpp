@@ -34,8 +34,8 @@ struct Group {
     uint32_t col0;
     uint16_t nseg;
     uint8_t width;
-    int16_t drow;
-    int32_t dcol;
+    uint8_t kind;        // SPX_KIND_*
+    uint8_t step;
     uint32_t voff;       // into RbBuilder::gvals_
 };
 
@@ -48,15 +48,15 @@ public:
               std::vector<Single> &singles, uint8_t flags, uint32_t carry_slot);
 
 private:
-    void add_group(idx_t row, idx_t col, size_t nseg, size_t width, int drow, int dcol)
+    void add_group(idx_t row, idx_t col, size_t nseg, size_t width, unsigned kind, unsigned step)
     {
         Group g;
         g.row0 = (uint16_t) row;
         g.col0 = (uint32_t) col;
         g.nseg = (uint16_t) nseg;
         g.width = (uint8_t) width;
-        g.drow = (int16_t) drow;
-        g.dcol = (int32_t) dcol;
+        g.kind = (uint8_t) kind;
+        g.step = (uint8_t) step;
         g.voff = (uint32_t) gvals_.size();
         groups_.push_back(g);
     }
@@ -83,7 +83,7 @@ void RbBuilder::groups_from_piece(const Piece &pc, idx_t lo)
         const size_t rr = pc.b - pc.a;
         for (size_t c0 = 0; c0 < cdim; c0 += WMAX) {
             size_t w = std::min(WMAX, cdim - c0);
-            add_group(u.row - 1 + (idx_t) pc.a - lo, u.col - 1 + (idx_t) c0, rr, w, 1, 0);
+            add_group(u.row - 1 + (idx_t) pc.a - lo, u.col - 1 + (idx_t) c0, rr, w, SPX_KIND_BLOCK, 0);
             for (size_t s = 0; s < rr; ++s)
                 for (size_t i = 0; i < w; ++i)
                     gvals_.push_back(src[(c0 + i) * R + (pc.a + s)]);
@@ -99,7 +99,7 @@ void RbBuilder::groups_from_piece(const Piece &pc, idx_t lo)
         const size_t rr = n / C;
         for (size_t cc = 0; cc < C; cc += WMAX) {
             size_t w = std::min(WMAX, C - cc);
-            add_group(r0 - 1 - lo, c0 - 1 + (idx_t) cc, rr, w, 1, 0);
+            add_group(r0 - 1 - lo, c0 - 1 + (idx_t) cc, rr, w, SPX_KIND_BLOCK, 0);
             for (size_t s = 0; s < rr; ++s)
                 for (size_t i = 0; i < w; ++i)
                     gvals_.push_back(src[pc.a + s * C + cc + i]);
@@ -111,24 +111,25 @@ void RbBuilder::groups_from_piece(const Piece &pc, idx_t lo)
         const size_t CH = SPX_HORIZ_CHUNK;
         const size_t nf = n / CH, m = n % CH;
         if (nf) {
-            add_group(r0 - 1 - lo, c0 - 1, nf, CH, 0, (int) CH);
+            add_group(r0 - 1 - lo, c0 - 1, nf, CH, SPX_KIND_HORIZ, (unsigned) CH);
             gvals_.insert(gvals_.end(), src + pc.a, src + pc.a + nf * CH);
         }
         if (m) {
-            add_group(r0 - 1 - lo, c0 - 1 + (idx_t)(nf * CH), 1, m, 0, 0);
+            add_group(r0 - 1 - lo, c0 - 1 + (idx_t)(nf * CH), 1, m, SPX_KIND_HORIZ, 0);
             gvals_.insert(gvals_.end(), src + pc.a + nf * CH, src + pc.b);
         }
         return;
     }
-    int drow = 0, dcol = 0;
+    unsigned kind = SPX_KIND_HORIZ;
     switch (u.type) {
-    case ENC_H: dcol = d; break;
-    case ENC_V: drow = d; break;
-    case ENC_D: drow = d; dcol = d; break;
-    case ENC_AD: drow = d; dcol = -d; break;
+    case ENC_H: kind = SPX_KIND_HORIZ; break;
+    case ENC_V: kind = SPX_KIND_VERT; break;
+    case ENC_D: kind = SPX_KIND_DIAG; break;
+    case ENC_AD: kind = SPX_KIND_ADIAG; break;
     default: assert(false);
     }
-    add_group(r0 - 1 - lo, c0 - 1, n, 1, drow, dcol);
+    assert((unsigned) d <= SPX_MAX_STEP);
+    add_group(r0 - 1 - lo, c0 - 1, n, 1, kind, (unsigned) d);
     gvals_.insert(gvals_.end(), src + pc.a, src + pc.b);
 }
 
@@ -176,12 +177,8 @@ void RbBuilder::emit_unit_passes(SpxRowBlock &rb)
             cur_w = g.width;
         }
         SpxUnitDesc d;
-        std::memset(&d, 0, sizeof(d));
         d.col0 = g.col0;
-        d.dcol = g.dcol;
-        d.row0 = g.row0;
-        d.drow = g.drow;
-        d.sstart = (uint16_t) seg_counter;
+        d.bits = spx_desc_bits(g.row0, seg_counter, g.kind, g.step);
         uint32_t di = (uint32_t)(out_.descs.size() - rb.desc_off);
         out_.descs.push_back(d);
         ++out_.n_units;
@@ -441,7 +438,9 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out)
                 if (plan_of_row[(size_t) r - 1] != pl) break;
                 ++k1;
             }
-            if (plans[pl].split || k1 - k0 <= 2) add_singles(e, k0, k1);
+            const bool wide_step = e.delta > SPX_MAX_STEP && !enc_is_block(e.type) &&
+                                   !(e.type == ENC_H && e.delta == 1);
+            if (plans[pl].split || k1 - k0 <= 2 || wide_step) add_singles(e, k0, k1);
             else pieces[pl].push_back(Piece{(uint32_t) i, (uint16_t) k0, (uint16_t) k1});
             k0 = k1;
         }

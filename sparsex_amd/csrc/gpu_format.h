@@ -17,7 +17,9 @@
  *     vertical / diagonal /    one segment of width 1 per nonzero
  *     anti-diagonal / h (d>1)
  * Segment s of a unit sits at row0 + s*drow, columns col0 + s*dcol ... +W-1.
- * One 16-byte SpxUnitDesc describes the whole run.
+ * One 8-byte SpxUnitDesc describes the whole run (strides come from a 3-bit
+ * kind and a 7-bit step; linear units with a step above 127 are rare and go
+ * to the delta passes instead).
  *
  * Work is cut into *passes*: a pass is up to 64 row segments of the SAME
  * width W, one per lane of a wavefront.  Its values are stored interleaved
@@ -46,14 +48,25 @@
 #define SPX_PASS_UNIT   0
 #define SPX_PASS_DELTA  1
 
+#define SPX_KIND_BLOCK  0u   /* rows of a dense block: drow 1, dcol 0             */
+#define SPX_KIND_HORIZ  1u   /* same row, column step `step`                      */
+#define SPX_KIND_VERT   2u   /* same column, row step `step`                      */
+#define SPX_KIND_DIAG   3u   /* row and column step `step`                        */
+#define SPX_KIND_ADIAG  4u   /* row step `step`, column step -`step`              */
+#define SPX_MAX_STEP    127u
+
 typedef struct {
     uint32_t col0;       /* first column of segment 0 (0-based, absolute)       */
-    int32_t  dcol;       /* column step per segment                              */
-    uint16_t row0;       /* row of segment 0, relative to the row-block          */
-    int16_t  drow;       /* row step per segment                                  */
-    uint16_t sstart;     /* number of segments of this row-block in front of it  */
-    uint16_t pad_;
-} SpxUnitDesc;           /* 16 bytes */
+    uint32_t bits;       /* [0,9) row of segment 0 relative to the row-block
+                            [9,22) segments of this row-block in front of it
+                            [22,25) SPX_KIND_*      [25,32) step                 */
+} SpxUnitDesc;           /* 8 bytes */
+
+static inline uint32_t spx_desc_bits(uint32_t row0, uint32_t sstart, uint32_t kind,
+                                     uint32_t step)
+{
+    return (row0 & 511u) | ((sstart & 8191u) << 9) | ((kind & 7u) << 22) | ((step & 127u) << 25);
+}
 
 typedef struct {
     uint64_t mask;       /* bit l: lane l's segment starts a new unit (unit

@@ -76,14 +76,14 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
 {
     bool active[B];
     uint32_t l[B], nseg[B];
-    uint4 q[B];
+    uint2 q[B];
 #pragma unroll
     for (int b = 0; b < B; ++b) {
         nseg[b] = ps[b].nseg;
         active[b] = (uint32_t) lane < nseg[b];
         l[b] = active[b] ? (uint32_t) lane : 0u;         // idle lanes shadow lane 0
         const uint32_t rank = (uint32_t) ps[b].rank0 + (active[b] ? starts_upto(ps[b].mask, lane) : 0u);
-        q[b] = *reinterpret_cast<const uint4 *>(a.descs + rb.desc_off + rank);
+        q[b] = *reinterpret_cast<const uint2 *>(a.descs + rb.desc_off + rank);
     }
     double2 v2[B][W / 2 > 0 ? W / 2 : 1];
     double v1[B];
@@ -114,9 +114,15 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
 #pragma unroll
     for (int b = 0; b < B; ++b) {
         // segment index inside its unit, then its row / first column
-        const int s = (int) ((ps[b].seg0 + l[b] - (q[b].w & 0xffffu)) & 0xffffu);
-        row[b] = (int) (q[b].z & 0xffffu) + s * (int) (int16_t) (q[b].z >> 16);
-        const uint32_t col = q[b].x + (uint32_t) (s * (int) q[b].y);
+        const uint32_t bits = q[b].y;
+        const int s = (int) ((ps[b].seg0 + l[b] - ((bits >> 9) & 8191u)) & 0xffffu);
+        const uint32_t kind = (bits >> 22) & 7u;
+        const int step = (int) (bits >> 25);
+        const int drow = kind == SPX_KIND_BLOCK ? 1 : (kind >= SPX_KIND_VERT ? step : 0);
+        const int dcol = (kind == SPX_KIND_HORIZ || kind == SPX_KIND_DIAG)
+                             ? step : (kind == SPX_KIND_ADIAG ? -step : 0);
+        row[b] = (int) (bits & 511u) + s * drow;
+        const uint32_t col = q[b].x + (uint32_t) (s * dcol);
         const double *xp = a.x + col;
         double x[W];
 #pragma unroll
@@ -396,7 +402,7 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
     m->n_carry = s.n_carry;
     m->rbs = upload(s.rbs);
     m->values = upload(s.values, 160);
-    m->descs = upload(s.descs, 72);
+    m->descs = upload(s.descs, 8);
     m->passes = upload(s.passes, 1);
     m->dmasks = upload(s.dmasks, 4);
     m->cidx = upload(s.cidx, 64);
