@@ -302,7 +302,8 @@ void Encoder::gen_all_stats(StatsCollection &stats)
         Partition window;
         for (size_t i = 0; i < samples_max_; ++i) {
             size_t sel = selected_splits_[i];
-            if (sel + 1 >= sort_splits_.size()) break;   // out of range in the reference
+            // out of range in the reference (it reads past its vectors here)
+            if (sel + 1 >= sort_splits_.size() || sel >= sort_splits_nzeros_.size()) break;
             size_t ws = sort_splits_[sel];
             size_t wsize = sort_splits_[sel + 1] - ws;
             // windows of at most one row end the sampling (:720-722)

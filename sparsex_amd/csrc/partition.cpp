@@ -127,9 +127,13 @@ void Partition::transform(int t)
 
 void Partition::get_window(idx_t rs, idx_t length, Partition &win)
 {
+    win = Partition();
+    // rows at the end may have lost all their anchors to units encoded in an
+    // earlier round; a window starting beyond the last represented row is
+    // empty (the reference reads past its rowptr array there)
+    if ((size_t) rs >= rowptr.size() - 1) return;
     if ((size_t)(rs + length) > rowptr.size() - 1)
         length = (idx_t)(rowptr.size() - 1) - rs;
-    win = Partition();
     idx_t es = rowptr[rs];
     idx_t ee = rowptr[rs + length];
     if (es == ee) return;
