@@ -33,9 +33,24 @@ ALPHA = 0.5
 REF_BASELINE_THREADS = [1, 2, 4, 8, 16, 24, 32, 48, 64, 96, 128, 192, 256]
 
 
-def make_workload(name, scale, copies=1):
+def load_mtx(path):
+    """A real Matrix Market file (e.g. SuiteSparse cant.mtx) as zero-based CSR;
+    symmetric files are mirrored to the full matrix like the reference's reader
+    does (include/sparsex/internals/Mmf.hpp:445-478 in the reference tree)."""
+    import scipy.io
+    import scipy.sparse as sp
+    a = sp.csr_matrix(scipy.io.mmread(path), dtype=np.float64)
+    a.sum_duplicates()
+    a.sort_indices()
+    if a.shape[0] != a.shape[1]:
+        raise SystemExit("bench.py expects a square matrix")
+    return (a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data.astype(np.float64),
+            a.shape[0])
+
+
+def make_workload(name, scale, copies=1, mtx=None):
     from sparsex_amd import synth
-    rp, ci, va, n = synth.WORKLOADS[name](scale)
+    rp, ci, va, n = load_mtx(mtx) if mtx else synth.WORKLOADS[name](scale)
     if copies > 1:
         nnz = int(rp[-1])
         rp = np.concatenate([[0]] + [rp[1:].astype(np.int64) + k * nnz for k in range(copies)])
@@ -210,6 +225,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--workload", default="syn-cant", choices=["syn-cant", "syn-nd24k", "syn-webbase"])
     ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--mtx", default=None,
+                    help="Matrix Market file to use instead of the synthetic stand-in")
     ap.add_argument("--symmetric", action="store_true")
     ap.add_argument("--host-threads", type=int, default=0,
                     help="host preprocessing partitions per GPU (default: min(cores, 8))")
@@ -233,7 +250,7 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
 
-    csr = make_workload(args.workload, args.scale, copies=world)
+    csr = make_workload(args.workload, args.scale, copies=world, mtx=args.mtx)
     rp, ci, va, n = csr
     nnz = int(rp[-1])
     T = args.host_threads or min(host_cores() // max(world, 1), 8) or 1
@@ -310,10 +327,11 @@ def main():
             "value": round(gflops, 3), "unit": "GFLOP/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 6), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s (stand-in for SuiteSparse %s)%s" % (
-                           args.workload, args.workload.replace("syn-", ""),
-                           " x%d block-diagonal" % world if world > 1 else ""),
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "file" if args.mtx else "synthetic",
+            "config": {"workload": (os.path.basename(args.mtx) if args.mtx else
+                                    "%s (stand-in for SuiteSparse %s)" % (
+                                        args.workload, args.workload.replace("syn-", ""))) +
+                                   (" x%d block-diagonal" % world if world > 1 else ""),
                        "nrows": n, "nnz": nnz, "symmetric_path": bool(args.symmetric),
                        "partitions_per_gpu": T,
                        "parallelism": "row-partitioned x%d, %s" % (
@@ -323,7 +341,7 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": (measured_traffic(args.workload)
                                      if world == 1 and not args.symmetric and args.scale == 1.0
-                                     and not args.opt else None),
+                                     and not args.opt and not args.mtx else None),
                          "kernel": "csx_spmv_kernel",
                          "algorithmic_bytes_per_launch": int(b_alg),
                          "avg_launch_us": round(1e6 * launch_s, 3)},

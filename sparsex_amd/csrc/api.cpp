@@ -413,6 +413,7 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     }
     gp.target_elems = (size_t) std::max<long>(64, rbe);
     gp.max_rows = (size_t) std::max<long>(1, cfg.get_long("spx.gpu.rowblock_rows"));
+    gp.col_panel = (size_t) std::max<long>(0, cfg.get_long("spx.gpu.col_panel"));
     GpuStream gs;
     if (sym) {
         // The GPU stream holds the stored lower triangle and its mirror image

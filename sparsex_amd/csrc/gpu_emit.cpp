@@ -41,7 +41,8 @@ struct Group {
 
 class RbBuilder {
 public:
-    RbBuilder(const Partition &p, GpuStream &out) : p_(p), out_(out) {}
+    RbBuilder(const Partition &p, GpuStream &out, size_t col_panel = 0)
+        : p_(p), out_(out), col_panel_(col_panel) {}
 
     // emits one row-block for rows [lo, hi) from the given pieces/singles
     void emit(idx_t lo, idx_t hi, const std::vector<Piece> &pieces,
@@ -66,6 +67,7 @@ private:
 
     const Partition &p_;
     GpuStream &out_;
+    size_t col_panel_;
     std::vector<Group> groups_;
     std::vector<val_t> gvals_;
 };
@@ -193,7 +195,12 @@ void RbBuilder::emit_unit_passes(SpxRowBlock &rb)
 
 void RbBuilder::emit_delta_passes(SpxRowBlock &rb, std::vector<Single> &singles, idx_t lo)
 {
-    std::sort(singles.begin(), singles.end(), [](const Single &x, const Single &y) {
+    const size_t panel = col_panel_;
+    std::sort(singles.begin(), singles.end(), [panel](const Single &x, const Single &y) {
+        if (panel) {
+            size_t px = (size_t) x.col / panel, py = (size_t) y.col / panel;
+            if (px != py) return px < py;
+        }
         return x.row < y.row || (x.row == y.row && x.col < y.col);
     });
     const size_t n = singles.size();
@@ -447,7 +454,7 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out)
     }
 
     // 4. emit
-    RbBuilder bld(p, out);
+    RbBuilder bld(p, out, prm.col_panel);
     for (size_t i = 0; i < plans.size(); ++i) {
         const Plan &pl = plans[i];
         if (prm.skip_empty && pieces[i].empty() && singles[i].empty()) continue;

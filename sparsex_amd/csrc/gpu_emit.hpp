@@ -45,6 +45,8 @@ struct GpuEmitParams {
     size_t target_elems = 2048;   // spx.gpu.rowblock_elems
     size_t max_rows = SPX_MAX_RB_ROWS;   // spx.gpu.rowblock_rows (<= SPX_MAX_RB_ROWS)
     bool skip_empty = false;      // accumulate mode: rows without nonzeros need no write
+    size_t col_panel = 0;         // > 0: leftover nonzeros are visited panel by panel of
+                                  // this many columns (keeps the x slice in L2)
 };
 
 // Appends the row-blocks of partition `p` (horizontal order) to `out`.
