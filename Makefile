@@ -14,7 +14,7 @@ LIB       := $(LIBDIR)/libsparsex.so
 HOST_SRCS := common.cpp config.cpp partition.cpp stats.cpp encoder.cpp input.cpp \
              csx_emit.cpp gpu_emit.cpp api.cpp
 HOST_OBJS := $(HOST_SRCS:%.cpp=$(OBJDIR)/%.o)
-HIP_OBJ   := $(OBJDIR)/spmv_kernels.o
+HIP_OBJ   := $(OBJDIR)/spmv_kernels.o $(OBJDIR)/vec_kernels.o
 
 CXXFLAGS  := -std=c++17 -O2 -g -fPIC -Wall -Iinclude -I$(CSRC) -pthread
 HIPFLAGS  := --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -munsafe-fp-atomics \
@@ -30,7 +30,8 @@ $(OBJDIR)/%.o: $(CSRC)/%.cpp $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.h) \
 	@mkdir -p $(OBJDIR)
 	$(CXX) $(CXXFLAGS) -c $< -o $@
 
-$(HIP_OBJ): $(CSRC)/spmv_kernels.hip $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.h)
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.h) \
+               $(wildcard include/sparsex/*.h) include/sparsex_hip.h
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

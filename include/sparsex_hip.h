@@ -47,6 +47,45 @@ spx_error_t spx_hip_matvec_kernel(spx_value_t alpha, const spx_matrix_t *A,
                                   const spx_value_t *x_dev, spx_value_t beta,
                                   spx_value_t *y_dev, void *stream);
 
+/* ---- device-resident vectors ---------------------------------------------------
+ * HBM counterparts of the reference's host vector helpers (spx_vec_init,
+ * spx_vec_scale, spx_vec_scale_add, spx_vec_add, spx_vec_sub, spx_vec_mul,
+ * spx_vec_copy; reference src/api/matvec.c:838-931, src/internals/
+ * Vector.cpp:206-394) so that a CG / GMRES iteration never leaves the GPU.
+ * Same argument order and meaning as the host versions; every call enqueues on
+ * `stream` (NULL = default stream) and returns immediately, except
+ * spx_hip_vec_mul and the download, which synchronise the stream.
+ */
+typedef struct spx_hip_vec spx_hip_vec_t;
+
+spx_hip_vec_t *spx_hip_vec_create(size_t size);                 /* zero-filled        */
+spx_hip_vec_t *spx_hip_vec_create_from_host(const spx_vector_t *v);
+spx_error_t spx_hip_vec_destroy(spx_hip_vec_t *v);
+spx_value_t *spx_hip_vec_data(spx_hip_vec_t *v);               /* HBM pointer        */
+size_t spx_hip_vec_size(const spx_hip_vec_t *v);
+spx_error_t spx_hip_vec_upload(spx_hip_vec_t *dst, const spx_vector_t *src, void *stream);
+spx_error_t spx_hip_vec_download(const spx_hip_vec_t *src, spx_vector_t *dst, void *stream);
+spx_error_t spx_hip_vec_init(spx_hip_vec_t *v, spx_value_t val, void *stream);
+/* v2 <- num * v1 */
+spx_error_t spx_hip_vec_scale(const spx_hip_vec_t *v1, spx_hip_vec_t *v2, spx_value_t num,
+                              void *stream);
+/* v3 <- v1 + num * v2 */
+spx_error_t spx_hip_vec_scale_add(const spx_hip_vec_t *v1, const spx_hip_vec_t *v2,
+                                  spx_hip_vec_t *v3, spx_value_t num, void *stream);
+/* v3 <- v1 + v2,  v3 <- v1 - v2 */
+spx_error_t spx_hip_vec_add(const spx_hip_vec_t *v1, const spx_hip_vec_t *v2,
+                            spx_hip_vec_t *v3, void *stream);
+spx_error_t spx_hip_vec_sub(const spx_hip_vec_t *v1, const spx_hip_vec_t *v2,
+                            spx_hip_vec_t *v3, void *stream);
+/* *result <- v1 . v2   (deterministic two-stage reduction) */
+spx_error_t spx_hip_vec_mul(const spx_hip_vec_t *v1, const spx_hip_vec_t *v2,
+                            spx_value_t *result, void *stream);
+spx_error_t spx_hip_vec_copy(const spx_hip_vec_t *v1, spx_hip_vec_t *v2, void *stream);
+/* y <- alpha*A*x + beta*y on device vectors (spx_matvec_kernel, matvec.c:586-620) */
+spx_error_t spx_hip_matvec_kernel_vec(spx_value_t alpha, const spx_matrix_t *A,
+                                      const spx_hip_vec_t *x, spx_value_t beta,
+                                      spx_hip_vec_t *y, void *stream);
+
 /* ---- introspection ---------------------------------------------------------- */
 typedef struct {
     int64_t nnz;             /* logical nonzeros of the whole matrix            */

@@ -114,6 +114,23 @@ def lib():
     L.spx_hip_mat_export_units.argtypes = [vp, i, C.POINTER(UnitRecord), C.c_int64]
     L.spx_hip_mat_tune_log.restype = C.c_char_p
     L.spx_hip_mat_tune_log.argtypes = [vp]
+    L.spx_hip_vec_create.restype = vp
+    L.spx_hip_vec_create.argtypes = [C.c_size_t]
+    L.spx_hip_vec_destroy.argtypes = [vp]
+    L.spx_hip_vec_data.restype = vp
+    L.spx_hip_vec_data.argtypes = [vp]
+    L.spx_hip_vec_size.restype = C.c_size_t
+    L.spx_hip_vec_size.argtypes = [vp]
+    L.spx_hip_vec_upload.argtypes = [vp, C.POINTER(VectorStruct), vp]
+    L.spx_hip_vec_download.argtypes = [vp, C.POINTER(VectorStruct), vp]
+    L.spx_hip_vec_init.argtypes = [vp, d, vp]
+    L.spx_hip_vec_scale.argtypes = [vp, vp, d, vp]
+    L.spx_hip_vec_scale_add.argtypes = [vp, vp, vp, d, vp]
+    L.spx_hip_vec_add.argtypes = [vp, vp, vp, vp]
+    L.spx_hip_vec_sub.argtypes = [vp, vp, vp, vp]
+    L.spx_hip_vec_mul.argtypes = [vp, vp, C.POINTER(C.c_double), vp]
+    L.spx_hip_vec_copy.argtypes = [vp, vp, vp]
+    L.spx_hip_matvec_kernel_vec.argtypes = [d, vp, vp, d, vp, vp]
     L.spx_log_disable_all.restype = None
     L.spx_log_error_console.restype = None
     _lib = L
@@ -277,6 +294,87 @@ class Matrix:
             self.destroy()
         except Exception:
             pass
+
+
+class DeviceVector:
+    """``spx_hip_vec_t``: a vector resident in HBM with the BLAS-1 helpers of
+    include/sparsex_hip.h (device counterparts of the reference's spx_vec_*)."""
+
+    def __init__(self, size=None, host=None):
+        L = lib()
+        if host is not None:
+            size = host.size
+        self.handle = L.spx_hip_vec_create(size)
+        if not self.handle:
+            raise SpxError("spx_hip_vec_create failed (see stderr)")
+        self.size = size
+        if host is not None:
+            self.upload(host)
+
+    def _check(self, rc, what):
+        if rc != SPX_SUCCESS:
+            raise SpxError(what + " failed (see stderr)")
+
+    def _view(self, arr):
+        assert arr.dtype == np.float64 and arr.flags.c_contiguous
+        return lib().spx_vec_create_from_buff(arr.ctypes.data_as(C.POINTER(C.c_double)), None,
+                                              arr.size, None, SPX_VEC_AS_IS)
+
+    def upload(self, arr, stream=0):
+        v = self._view(arr)
+        try:
+            self._check(lib().spx_hip_vec_upload(self.handle, v, stream), "spx_hip_vec_upload")
+        finally:
+            lib().spx_vec_destroy(v)
+
+    def download(self, stream=0):
+        out = np.empty(self.size)
+        v = self._view(out)
+        try:
+            self._check(lib().spx_hip_vec_download(self.handle, v, stream), "spx_hip_vec_download")
+        finally:
+            lib().spx_vec_destroy(v)
+        return out
+
+    def data_ptr(self):
+        return lib().spx_hip_vec_data(self.handle)
+
+    def init(self, val, stream=0):
+        self._check(lib().spx_hip_vec_init(self.handle, val, stream), "spx_hip_vec_init")
+
+    def scale_into(self, dst, num, stream=0):          # dst <- num * self
+        self._check(lib().spx_hip_vec_scale(self.handle, dst.handle, num, stream), "spx_hip_vec_scale")
+
+    def scale_add_into(self, other, dst, num, stream=0):   # dst <- self + num * other
+        self._check(lib().spx_hip_vec_scale_add(self.handle, other.handle, dst.handle, num, stream),
+                    "spx_hip_vec_scale_add")
+
+    def dot(self, other, stream=0):
+        r = C.c_double(0.0)
+        self._check(lib().spx_hip_vec_mul(self.handle, other.handle, C.byref(r), stream),
+                    "spx_hip_vec_mul")
+        return r.value
+
+    def copy_into(self, dst, stream=0):
+        self._check(lib().spx_hip_vec_copy(self.handle, dst.handle, stream), "spx_hip_vec_copy")
+
+    def destroy(self):
+        if self.handle:
+            lib().spx_hip_vec_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def matvec_kernel_vec(A, alpha, x, beta, y, stream=0):
+    """``spx_hip_matvec_kernel_vec``: y <- alpha*A*x + beta*y on DeviceVectors."""
+    rc = lib().spx_hip_matvec_kernel_vec(alpha, A.handle, x.handle, beta, y.handle, stream)
+    if rc != SPX_SUCCESS:
+        raise SpxError("spx_hip_matvec_kernel_vec failed (see stderr)")
 
 
 def mat_tune(inp, reorder=False):
