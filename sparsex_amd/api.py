@@ -281,6 +281,13 @@ class Matrix:
         L.spx_hip_mat_export_units(self.handle, part, recs, n)
         return [(r.type, r.delta, r.size, r.row, r.col) for r in recs[:n]]
 
+    def save(self, filename):
+        """``spx_mat_save`` -- the tuned matrix (descriptor stream) to a file."""
+        L = lib()
+        L.spx_mat_save.argtypes = [C.c_void_p, C.c_char_p]
+        if L.spx_mat_save(self.handle, str(filename).encode()) != SPX_SUCCESS:
+            raise SpxError("spx_mat_save failed (see stderr)")
+
     def tune_log(self):
         return lib().spx_hip_mat_tune_log(self.handle).decode()
 
@@ -375,6 +382,17 @@ def matvec_kernel_vec(A, alpha, x, beta, y, stream=0):
     rc = lib().spx_hip_matvec_kernel_vec(alpha, A.handle, x.handle, beta, y.handle, stream)
     if rc != SPX_SUCCESS:
         raise SpxError("spx_hip_matvec_kernel_vec failed (see stderr)")
+
+
+def mat_restore(filename):
+    """``spx_mat_restore`` -- a matrix saved by :meth:`Matrix.save`; no re-tuning."""
+    L = lib()
+    L.spx_mat_restore.restype = C.c_void_p
+    L.spx_mat_restore.argtypes = [C.c_char_p]
+    h = L.spx_mat_restore(str(filename).encode())
+    if not h:
+        raise SpxError("spx_mat_restore failed (see stderr)")
+    return Matrix(h)
 
 
 def mat_tune(inp, reorder=False):

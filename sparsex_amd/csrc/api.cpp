@@ -59,6 +59,8 @@ struct matrix {
     std::vector<std::vector<spx_index_t>> exported_rows_info;
     bool full_colind;
     DeviceMatrix *dev;
+    std::unique_ptr<GpuStream> host_stream;   // kept for host-only matrices (save/restore)
+    idx_t own_lo, own_hi;
     // accounting
     size_t nnz_stored, n_unit_elems, n_delta_elems, n_units;
     size_t value_bytes, index_bytes, n_rowblocks, n_shared;
@@ -443,12 +445,17 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     A->index_bytes = gs.index_bytes();
     A->n_rowblocks = gs.rbs.size();
     A->n_shared = gs.shared.size();
-    if (!host_only) {
+    {
         idx_t lo = nown ? A->bounds[first].row_start : 0;
         idx_t hi = nown ? A->bounds[last - 1].row_start + A->bounds[last - 1].nr_rows : 0;
         if (last == P) hi = A->nrows;     // trailing empty rows belong to the last slice
-        A->dev = device_upload(gs, (size_t) A->nrows, (size_t) A->ncols, sym, lo, hi,
-                               (int) cfg.get_long("spx.rt.device"));
+        A->own_lo = lo;
+        A->own_hi = hi;
+        if (!host_only)
+            A->dev = device_upload(gs, (size_t) A->nrows, (size_t) A->ncols, sym, lo, hi,
+                                   (int) cfg.get_long("spx.rt.device"));
+        else
+            A->host_stream.reset(new GpuStream(std::move(gs)));
     }
     if (!cfg.get_bool("spx.rt.keep_encoded")) {
         A->parts.clear();
@@ -520,22 +527,170 @@ spx_error_t spx_mat_set_entry(spx_matrix_t *A, spx_index_t row, spx_index_t colu
     return SPX_FAILURE;
 }
 
+// ---- save / restore -----------------------------------------------------------------
+// The reference archives every partition's ctl/values/id_map/rows_info with
+// Boost.Serialization and re-runs its JIT on restore
+// (include/sparsex/internals/CsxSaveRestore.hpp:77-371).  Here the file holds the
+// row-block descriptor stream as it lies in HBM plus the matrix header, so a
+// restore is a read and an upload -- no preprocessing.
+
+}  // extern "C"
+
+namespace {
+
+const char kMagic[8] = {'S', 'P', 'X', 'H', 'I', 'P', '0', '2'};
+
+template <typename T>
+bool put_vec(FILE *f, const std::vector<T> &v)
+{
+    uint64_t n = v.size();
+    if (fwrite(&n, sizeof(n), 1, f) != 1) return false;
+    return n == 0 || fwrite(v.data(), sizeof(T), n, f) == n;
+}
+
+template <typename T>
+bool get_vec(FILE *f, std::vector<T> &v)
+{
+    uint64_t n = 0;
+    if (fread(&n, sizeof(n), 1, f) != 1) return false;
+    if (n > (uint64_t) 1 << 40) return false;
+    v.resize(n);
+    return n == 0 || fread(v.data(), sizeof(T), n, f) == n;
+}
+
+struct SavedHeader {
+    int32_t nrows, ncols, nnz, symmetric;
+    uint64_t nr_partitions, first_part, last_part;
+    int32_t own_lo, own_hi;
+    uint64_t nnz_stored, n_unit_elems, n_delta_elems, n_units;
+    uint32_t n_carry, pad;
+};
+
+}  // namespace
+
+extern "C" {
+
 spx_error_t spx_mat_save(const spx_matrix_t *A, const char *filename)
 {
     if (!A) {
         SETERROR_1(SPX_ERR_ARG_INVALID, "invalid matrix handle");
         return SPX_FAILURE;
     }
-    (void) filename;
-    SETERROR_1(SPX_ERR_FILE_WRITE, "spx_mat_save is not available in this build");
-    return SPX_FAILURE;
+    if (!filename) {
+        SETWARNING(SPX_WARN_CSXFILE);
+        filename = "csx_file";
+    }
+    GpuStream tmp;
+    const GpuStream *gs = A->host_stream.get();
+    if (!gs) {
+        if (!A->dev) {
+            SETERROR_1(SPX_ERR_TUNED_MAT, "matrix holds no descriptor stream");
+            return SPX_FAILURE;
+        }
+        try {
+            device_download(A->dev, tmp);
+        } catch (const FatalError &e) {
+            SETERROR_1(SPX_ERR_TUNED_MAT, e.what.c_str());
+            return SPX_FAILURE;
+        }
+        gs = &tmp;
+    }
+    // (the SPX_ERR_FILE_* codes are "system" errors on which the default
+    // handler exits, as in the reference; a bad file name is not worth that)
+    FILE *f = fopen(filename, "wb");
+    if (!f) {
+        SETERROR_1(SPX_ERR_FILE, "cannot open file for writing");
+        return SPX_FAILURE;
+    }
+    SavedHeader h;
+    memset(&h, 0, sizeof(h));
+    h.nrows = A->nrows; h.ncols = A->ncols; h.nnz = A->nnz; h.symmetric = A->symmetric;
+    h.nr_partitions = A->nr_partitions; h.first_part = A->first_part; h.last_part = A->last_part;
+    h.own_lo = A->own_lo; h.own_hi = A->own_hi;
+    h.nnz_stored = A->nnz_stored; h.n_unit_elems = A->n_unit_elems;
+    h.n_delta_elems = A->n_delta_elems; h.n_units = A->n_units;
+    h.n_carry = gs->n_carry;
+    bool good = fwrite(kMagic, 1, 8, f) == 8 && fwrite(&h, sizeof(h), 1, f) == 1;
+    std::vector<int32_t> bnd;
+    for (const PartBounds &b : A->bounds) {
+        bnd.push_back(b.row_start);
+        bnd.push_back(b.nr_rows);
+        bnd.push_back((int32_t) b.nnz);
+    }
+    good = good && put_vec(f, bnd) && put_vec(f, gs->rbs) && put_vec(f, gs->passes) &&
+           put_vec(f, gs->dmasks) && put_vec(f, gs->descs) && put_vec(f, gs->cidx) &&
+           put_vec(f, gs->segrows) && put_vec(f, gs->shared) && put_vec(f, gs->dvalues) &&
+           put_vec(f, gs->values);
+    good = (fclose(f) == 0) && good;
+    if (!good) {
+        SETERROR_1(SPX_ERR_FILE, "writing the tuned matrix failed");
+        return SPX_FAILURE;
+    }
+    return SPX_SUCCESS;
 }
 
 spx_matrix_t *spx_mat_restore(const char *filename)
 {
-    (void) filename;
-    SETERROR_1(SPX_ERR_FILE, "spx_mat_restore is not available in this build");
-    return SPX_INVALID_MAT;
+    if (!filename) {
+        SETERROR_0(SPX_ERR_FILE);
+        return SPX_INVALID_MAT;
+    }
+    if (access(filename, F_OK | R_OK) == -1) {
+        SETERROR_0(SPX_ERR_FILE);
+        return SPX_INVALID_MAT;
+    }
+    FILE *f = fopen(filename, "rb");
+    if (!f) {
+        SETERROR_0(SPX_ERR_FILE);
+        return SPX_INVALID_MAT;
+    }
+    char magic[8];
+    SavedHeader h;
+    std::unique_ptr<GpuStream> gs(new GpuStream);
+    std::vector<int32_t> bnd;
+    bool good = fread(magic, 1, 8, f) == 8 && memcmp(magic, kMagic, 8) == 0 &&
+                fread(&h, sizeof(h), 1, f) == 1 && get_vec(f, bnd) && get_vec(f, gs->rbs) &&
+                get_vec(f, gs->passes) && get_vec(f, gs->dmasks) && get_vec(f, gs->descs) &&
+                get_vec(f, gs->cidx) && get_vec(f, gs->segrows) && get_vec(f, gs->shared) &&
+                get_vec(f, gs->dvalues) && get_vec(f, gs->values);
+    fclose(f);
+    if (!good || bnd.size() != 3 * h.nr_partitions) {
+        SETERROR_1(SPX_ERR_FILE, "not a tuned-matrix file of this build");
+        return SPX_INVALID_MAT;
+    }
+    gs->n_carry = h.n_carry;
+    gs->nnz_stored = h.nnz_stored; gs->n_unit_elems = h.n_unit_elems;
+    gs->n_delta_elems = h.n_delta_elems; gs->n_units = h.n_units;
+    std::unique_ptr<matrix> A(new matrix);
+    A->nrows = h.nrows; A->ncols = h.ncols; A->nnz = h.nnz; A->symmetric = h.symmetric;
+    A->permutation = SPX_INVALID_PERM;
+    A->nr_partitions = h.nr_partitions; A->first_part = h.first_part; A->last_part = h.last_part;
+    for (size_t i = 0; i < h.nr_partitions; ++i)
+        A->bounds.push_back(PartBounds{bnd[3 * i], bnd[3 * i + 1], (size_t) bnd[3 * i + 2]});
+    A->full_colind = false;
+    A->dev = nullptr;
+    A->own_lo = h.own_lo; A->own_hi = h.own_hi;
+    A->nnz_stored = h.nnz_stored; A->n_unit_elems = h.n_unit_elems;
+    A->n_delta_elems = h.n_delta_elems; A->n_units = h.n_units;
+    A->value_bytes = gs->values.size() * sizeof(val_t);
+    A->index_bytes = gs->index_bytes();
+    A->n_rowblocks = gs->rbs.size();
+    A->n_shared = gs->shared.size();
+    A->tune_seconds = 0.0;
+    const double t0 = now_sec();
+    Config &cfg = Config::instance();
+    try {
+        if (!cfg.get_bool("spx.rt.host_only"))
+            A->dev = device_upload(*gs, (size_t) A->nrows, (size_t) A->ncols, A->symmetric != 0,
+                                   A->own_lo, A->own_hi, (int) cfg.get_long("spx.rt.device"));
+        else
+            A->host_stream = std::move(gs);
+    } catch (const FatalError &) {
+        SETERROR_0(SPX_ERR_TUNED_MAT);
+        return SPX_INVALID_MAT;
+    }
+    A->emit_seconds = now_sec() - t0;
+    return A.release();
 }
 
 spx_index_t spx_mat_get_nrows(const spx_matrix_t *A)

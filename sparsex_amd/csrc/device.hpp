@@ -30,6 +30,9 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
 void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x,
                       double beta, double *h_y);
 
+// copies the descriptor stream back from HBM (for spx_mat_save)
+void device_download(const DeviceMatrix *m, GpuStream &s);
+
 struct DeviceMatrixInfo {
     size_t n_rowblocks, n_shared_rows;
     size_t value_bytes, index_bytes;

@@ -359,6 +359,7 @@ struct DeviceMatrix {
     // staging vectors of the host-pointer path
     double *d_x = nullptr, *d_y = nullptr;
     size_t value_bytes = 0, index_bytes = 0;
+    size_t n_values = 0, n_descs = 0, n_passes = 0, n_dmasks = 0, n_cidx = 0, n_segrows = 0;
 };
 
 int device_count()
@@ -415,6 +416,8 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
         dv.resize(nrows, 0.0);
         m->dvalues = upload(dv);
     }
+    m->n_values = s.values.size(); m->n_descs = s.descs.size(); m->n_passes = s.passes.size();
+    m->n_dmasks = s.dmasks.size(); m->n_cidx = s.cidx.size(); m->n_segrows = s.segrows.size();
     m->value_bytes = s.values.size() * sizeof(double);
     m->index_bytes = s.index_bytes();
     return m;
@@ -476,6 +479,28 @@ void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x, double b
     device_spmv(m, alpha, m->d_x, beta, m->d_y, nullptr);
     HIP_CHECK(hipDeviceSynchronize());
     HIP_CHECK(hipMemcpy(h_y, m->d_y, m->nrows * sizeof(double), hipMemcpyDeviceToHost));
+}
+
+template <typename T>
+static void download(std::vector<T> &v, const T *d, size_t n)
+{
+    v.resize(n);
+    if (n) HIP_CHECK(hipMemcpy(v.data(), d, n * sizeof(T), hipMemcpyDeviceToHost));
+}
+
+void device_download(const DeviceMatrix *m, GpuStream &s)
+{
+    HIP_CHECK(hipSetDevice(m->device));
+    download(s.rbs, m->rbs, m->n_rb);
+    download(s.values, m->values, m->n_values);
+    download(s.descs, m->descs, m->n_descs);
+    download(s.passes, m->passes, m->n_passes);
+    download(s.dmasks, m->dmasks, m->n_dmasks);
+    download(s.cidx, m->cidx, m->n_cidx);
+    download(s.segrows, m->segrows, m->n_segrows);
+    download(s.shared, m->shared, m->n_shared);
+    s.n_carry = m->n_carry;
+    if (m->symmetric) download(s.dvalues, m->dvalues, m->nrows);
 }
 
 void device_info(const DeviceMatrix *m, DeviceMatrixInfo &info)
