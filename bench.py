@@ -242,13 +242,28 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # SPX_BENCH_BACKEND=gloo lets the multi-rank path be exercised on a box with
+    # fewer GPUs than ranks (ranks then share devices); the default is RCCL
+    backend = os.environ.get("SPX_BENCH_BACKEND", "nccl")
     if args.gpus > 1 or world > 1:
         assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dev_id = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(dev_id)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_id))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
+
+    def all_reduce(t, op=dist.ReduceOp.SUM):
+        if backend == "nccl":
+            dist.all_reduce(t, op=op)
+        else:                               # test-only path: gloo reduces on the host
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
 
     csr = make_workload(args.workload, args.scale, copies=world, mtx=args.mtx)
     rp, ci, va, n = csr
@@ -271,7 +286,7 @@ def main():
     def step():
         A.hip_matvec_mult(ALPHA, x.data_ptr(), y.data_ptr(), stream)
         if args.symmetric and world > 1:
-            dist.all_reduce(y)
+            all_reduce(y)
 
     def barrier():
         if world > 1:
@@ -303,7 +318,7 @@ def main():
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
 
     if rank == 0:
