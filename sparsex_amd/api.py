@@ -281,6 +281,22 @@ class Matrix:
         L.spx_hip_mat_export_units(self.handle, part, recs, n)
         return [(r.type, r.delta, r.size, r.row, r.col) for r in recs[:n]]
 
+    def get_entry(self, row, col, indexing=SPX_INDEX_ZERO_BASED):
+        """``spx_mat_get_entry`` -- value of a stored nonzero (raises if absent)."""
+        v = C.c_double(0.0)
+        rc = lib().spx_mat_get_entry(C.c_void_p(self.handle), C.c_int(row), C.c_int(col),
+                                     C.byref(v), C.c_int(indexing))
+        if rc != SPX_SUCCESS:
+            raise SpxError("entry (%d, %d) not found" % (row, col))
+        return v.value
+
+    def set_entry(self, row, col, value, indexing=SPX_INDEX_ZERO_BASED):
+        """``spx_mat_set_entry`` -- overwrite the value of a stored nonzero."""
+        rc = lib().spx_mat_set_entry(C.c_void_p(self.handle), C.c_int(row), C.c_int(col),
+                                     C.c_double(value), C.c_int(indexing))
+        if rc != SPX_SUCCESS:
+            raise SpxError("entry (%d, %d) not set" % (row, col))
+
     def save(self, filename):
         """``spx_mat_save`` -- the tuned matrix (descriptor stream) to a file."""
         L = lib()

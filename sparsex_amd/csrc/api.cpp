@@ -61,6 +61,13 @@ struct matrix {
     DeviceMatrix *dev;
     std::unique_ptr<GpuStream> host_stream;   // kept for host-only matrices (save/restore)
     idx_t own_lo, own_hi;
+    GpuEmitParams emit_params;
+    bool auto_rb;
+    bool host_only;
+    int device_ordinal;
+    bool dirty;                               // values changed since the last upload
+    std::vector<std::vector<idx_t>> spans;    // per partition and row: reach of its units
+    std::vector<idx_t> max_span;              // per partition
     // accounting
     size_t nnz_stored, n_unit_elems, n_delta_elems, n_units;
     size_t value_bytes, index_bytes, n_rowblocks, n_shared;
@@ -293,6 +300,60 @@ static void encode_partition(Partition &p, const EncoderParams &prm, const Xform
     }
 }
 
+// Builds the row-block descriptor stream from the encoded partitions and puts
+// it into HBM (or keeps it on the host for host-only matrices).
+static void emit_and_upload(spx_matrix_t *A)
+{
+    const size_t nown = A->parts.size();
+    const size_t first = A->first_part;
+    const bool sym = A->symmetric != 0;
+    GpuEmitParams gp = A->emit_params;
+    if (A->auto_rb) {
+        // auto: about five row-blocks per compute unit, so that a small matrix
+        // runs as a single round of workgroups
+        size_t local = 0;
+        for (size_t i = 0; i < nown; ++i) local += A->parts[i].nnz * (sym ? 2 : 1);
+        gp.target_elems = std::min<size_t>(std::max<size_t>(local / 1280 + 1, 1024), 4096);
+    }
+    GpuStream gs;
+    if (sym) {
+        // The GPU stream holds the stored lower triangle and its mirror image
+        // as one general matrix over rows [0, last owned row): every row is
+        // then owned by exactly one row-block of this process and no atomics
+        // are needed; the diagonal goes through csx_sym_init_kernel.
+        gs.dvalues.assign((size_t) A->nrows, 0.0);
+        Partition full;
+        for (size_t i = 0; i < nown; ++i) {
+            append_sym_expanded(A->parts[i], full);
+            const PartBounds &b = A->bounds[first + i];
+            for (size_t r = 0; r < A->diag[i].size() && r < (size_t) b.nr_rows; ++r)
+                gs.dvalues[(size_t) b.row_start + r] = A->diag[i][r];
+        }
+        gp.skip_empty = true;
+        emit_gpu(full, gp, gs);
+    } else {
+        for (size_t i = 0; i < nown; ++i) emit_gpu(A->parts[i], gp, gs);
+    }
+    A->nnz_stored = gs.nnz_stored;
+    A->n_unit_elems = gs.n_unit_elems;
+    A->n_delta_elems = gs.n_delta_elems;
+    A->n_units = gs.n_units;
+    A->value_bytes = gs.values.size() * sizeof(val_t);
+    A->index_bytes = gs.index_bytes();
+    A->n_rowblocks = gs.rbs.size();
+    A->n_shared = gs.shared.size();
+    if (A->dev) {
+        device_free(A->dev);
+        A->dev = nullptr;
+    }
+    if (!A->host_only)
+        A->dev = device_upload(gs, (size_t) A->nrows, (size_t) A->ncols, sym, A->own_lo, A->own_hi,
+                               A->device_ordinal);
+    else
+        A->host_stream.reset(new GpuStream(std::move(gs)));
+    A->dirty = false;
+}
+
 static spx_matrix_t *do_tune(spx_input_t *in)
 {
     Config &cfg = Config::instance();
@@ -330,6 +391,9 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     A->last_part = last;
     A->full_colind = cfg.get_bool("spx.matrix.full_colind");
     A->dev = nullptr;
+    A->dirty = false;
+    A->host_only = host_only;
+    A->device_ordinal = (int) cfg.get_long("spx.rt.device");
 
     const size_t nown = last - first;
     std::vector<std::ostringstream> logs(nown);
@@ -402,61 +466,19 @@ static spx_matrix_t *do_tune(spx_input_t *in)
 
     // descriptor stream + upload
     const double t1 = now_sec();
-    GpuEmitParams gp;
     long rbe = cfg.get_long("spx.gpu.rowblock_elems");
-    const bool auto_rb = rbe <= 0;
-    if (auto_rb) {
-        // auto: about one row-block per workgroup slot of the chip (256 CUs x
-        // 8 workgroups), so that a small matrix runs as a single full round
-        size_t local = 0;
-        for (size_t i = 0; i < nown; ++i) local += A->parts[i].nnz;
-        rbe = (long) (local / 1280 + 1);
-        rbe = std::min<long>(std::max<long>(rbe, 1024), 4096);
-    }
-    gp.target_elems = (size_t) std::max<long>(64, rbe);
-    gp.max_rows = (size_t) std::max<long>(1, cfg.get_long("spx.gpu.rowblock_rows"));
-    gp.col_panel = (size_t) std::max<long>(0, cfg.get_long("spx.gpu.col_panel"));
-    GpuStream gs;
-    if (sym) {
-        // The GPU stream holds the stored lower triangle and its mirror image
-        // as one general matrix over rows [0, last owned row): every row is
-        // then owned by exactly one row-block of this process and no atomics
-        // are needed; the diagonal goes through csx_sym_init_kernel.
-        gs.dvalues.assign((size_t) A->nrows, 0.0);
-        Partition full;
-        for (size_t i = 0; i < nown; ++i) {
-            append_sym_expanded(A->parts[i], full);
-            const PartBounds &b = A->bounds[first + i];
-            for (size_t r = 0; r < A->diag[i].size() && r < (size_t) b.nr_rows; ++r)
-                gs.dvalues[(size_t) b.row_start + r] = A->diag[i][r];
-        }
-        gp.skip_empty = true;
-        if (auto_rb)
-            gp.target_elems = std::min<size_t>(std::max<size_t>(full.nnz / 1280 + 1, 1024), 4096);
-        emit_gpu(full, gp, gs);
-    } else {
-        for (size_t i = 0; i < nown; ++i) emit_gpu(A->parts[i], gp, gs);
-    }
-    A->nnz_stored = gs.nnz_stored;
-    A->n_unit_elems = gs.n_unit_elems;
-    A->n_delta_elems = gs.n_delta_elems;
-    A->n_units = gs.n_units;
-    A->value_bytes = gs.values.size() * sizeof(val_t);
-    A->index_bytes = gs.index_bytes();
-    A->n_rowblocks = gs.rbs.size();
-    A->n_shared = gs.shared.size();
+    A->auto_rb = rbe <= 0;
+    A->emit_params.target_elems = (size_t) std::max<long>(64, rbe);
+    A->emit_params.max_rows = (size_t) std::max<long>(1, cfg.get_long("spx.gpu.rowblock_rows"));
+    A->emit_params.col_panel = (size_t) std::max<long>(0, cfg.get_long("spx.gpu.col_panel"));
     {
         idx_t lo = nown ? A->bounds[first].row_start : 0;
         idx_t hi = nown ? A->bounds[last - 1].row_start + A->bounds[last - 1].nr_rows : 0;
         if (last == P) hi = A->nrows;     // trailing empty rows belong to the last slice
         A->own_lo = lo;
         A->own_hi = hi;
-        if (!host_only)
-            A->dev = device_upload(gs, (size_t) A->nrows, (size_t) A->ncols, sym, lo, hi,
-                                   (int) cfg.get_long("spx.rt.device"));
-        else
-            A->host_stream.reset(new GpuStream(std::move(gs)));
     }
+    emit_and_upload(A.get());
     if (!cfg.get_bool("spx.rt.keep_encoded")) {
         A->parts.clear();
         A->parts.shrink_to_fit();
@@ -502,29 +524,167 @@ spx_error_t spx_mat_destroy(spx_matrix_t *A)
     return SPX_SUCCESS;
 }
 
-// get/set entry, save/restore: not on the tune/matvec path
-spx_error_t spx_mat_get_entry(const spx_matrix_t *A, spx_index_t row, spx_index_t column,
+// ---- get / set entry ------------------------------------------------------------------
+// Random access into the tuned matrix (reference: src/api/matvec.c:324-407,
+// include/sparsex/internals/CsxGetSet.hpp:195-320).  The reference walks the
+// ctl stream of the row and of the rows above it within `span`; here the
+// encoded partitions are searched the same way: the units anchored in row i
+// can reach down to row i + span[i].  A changed value is written to the host
+// copy and the descriptor stream is rebuilt before the next multiplication.
+
+}  // extern "C"
+
+namespace {
+
+// rows a unit anchored in (row) reaches below its anchor
+idx_t unit_span(const Elem &e)
+{
+    if (!e.is_unit()) return 0;
+    if (e.type == ENC_V || e.type == ENC_D || e.type == ENC_AD)
+        return (idx_t)(e.size - 1) * (idx_t) e.delta;
+    if (enc_is_block_row(e.type)) return (idx_t) enc_block_align(e.type) - 1;
+    if (enc_is_block_col(e.type)) return (idx_t) e.size / enc_block_align(e.type) - 1;
+    return 0;
+}
+
+void build_spans(spx_matrix_t *A)
+{
+    if (A->spans.size() == A->parts.size()) return;
+    A->spans.assign(A->parts.size(), std::vector<idx_t>());
+    A->max_span.assign(A->parts.size(), 0);
+    for (size_t p = 0; p < A->parts.size(); ++p) {
+        const Partition &pt = A->parts[p];
+        std::vector<idx_t> &sp = A->spans[p];
+        sp.assign(pt.rowptr.size() - 1, 0);
+        for (size_t i = 0; i + 1 < pt.rowptr.size(); ++i)
+            for (idx_t j = pt.rowptr[i]; j < pt.rowptr[i + 1]; ++j)
+                sp[i] = std::max(sp[i], unit_span(pt.elems[j]));
+        for (idx_t v : sp) A->max_span[p] = std::max(A->max_span[p], v);
+    }
+}
+
+// pointer to the stored value of (row, col), 1-based global; NULL if absent
+val_t *locate(spx_matrix_t *A, idx_t row, idx_t col)
+{
+    if (A->symmetric) {
+        if (col > row) std::swap(row, col);
+        if (row == col) {
+            for (size_t p = 0; p < A->parts.size(); ++p) {
+                const PartBounds &b = A->bounds[A->first_part + p];
+                idx_t r = row - 1 - b.row_start;
+                if (r >= 0 && r < b.nr_rows && (size_t) r < A->diag[p].size()) return &A->diag[p][r];
+            }
+            return nullptr;
+        }
+    }
+    for (size_t p = 0; p < A->parts.size(); ++p) {
+        const PartBounds &b = A->bounds[A->first_part + p];
+        idx_t r = row - b.row_start;          // 1-based inside the partition
+        if (r < 1 || r > b.nr_rows) continue;
+        Partition &pt = A->parts[p];
+        const std::vector<idx_t> &sp = A->spans[p];
+        const idx_t nr = (idx_t) pt.rowptr.size() - 1;
+        for (idx_t i = std::min(r, nr); i >= 1 && r - i <= A->max_span[p]; --i) {
+            if (sp[(size_t) i - 1] < r - i) continue;   // nothing anchored in row i reaches row r
+            for (idx_t j = pt.rowptr[i - 1]; j < pt.rowptr[i]; ++j) {
+                Elem &e = pt.elems[j];
+                if (!e.is_unit()) {
+                    if (e.row == r && e.col == col) return &e.val;
+                    continue;
+                }
+                for (size_t k = 0; k < e.size; ++k) {
+                    idx_t er, ec;
+                    unit_elem_coords(e, k, er, ec);
+                    if (er == r && ec == col) return &pt.pool[e.voff + k];
+                }
+            }
+        }
+        return nullptr;
+    }
+    return nullptr;
+}
+
+bool entry_args(const spx_matrix_t *A, spx_option_t indexing, spx_index_t &row, spx_index_t &col)
+{
+    const int base = (indexing == SPX_INDEX_ONE_BASED) ? 1 : 0;
+    if (row - base < 0 || row - base >= A->nrows || col - base < 0 || col - base >= A->ncols) {
+        SETERROR_0(SPX_OUT_OF_BOUNDS);
+        return false;
+    }
+    row = row - base + 1;      // internally 1-based
+    col = col - base + 1;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+spx_error_t spx_mat_get_entry(const spx_matrix_t *A_, spx_index_t row, spx_index_t column,
                               spx_value_t *value, ...)
 {
+    va_list ap;
+    va_start(ap, value);
+    spx_option_t indexing = va_arg(ap, spx_option_t);
+    va_end(ap);
+    spx_matrix_t *A = const_cast<spx_matrix_t *>(A_);
     if (!A) {
         SETERROR_1(SPX_ERR_ARG_INVALID, "invalid matrix handle");
         return SPX_FAILURE;
     }
-    (void) row; (void) column; (void) value;
-    SETERROR_1(SPX_ERR_ENTRY_NOT_FOUND, "spx_mat_get_entry is not available in this build");
-    return SPX_FAILURE;
+    if (!value) {
+        SETERROR_1(SPX_ERR_ARG_INVALID, "invalid value pointer");
+        return SPX_FAILURE;
+    }
+    if (!entry_args(A, indexing, row, column)) return SPX_FAILURE;
+    if (A->parts.empty() && A->nnz) {
+        SETERROR_1(SPX_ERR_ENTRY_NOT_FOUND,
+                   "the encoded partitions were dropped (spx.rt.keep_encoded=false or a restored matrix)");
+        return SPX_FAILURE;
+    }
+    std::lock_guard<std::mutex> lk(A->mtx);
+    build_spans(A);
+    const val_t *v = locate(A, row, column);
+    if (!v) {
+        SETERROR_0(SPX_ERR_ENTRY_NOT_FOUND);
+        return SPX_FAILURE;
+    }
+    *value = *v;
+    return SPX_SUCCESS;
 }
 
 spx_error_t spx_mat_set_entry(spx_matrix_t *A, spx_index_t row, spx_index_t column,
                               spx_value_t value, ...)
 {
+    va_list ap;
+    va_start(ap, value);
+    spx_option_t indexing = va_arg(ap, spx_option_t);
+    va_end(ap);
     if (!A) {
         SETERROR_1(SPX_ERR_ARG_INVALID, "invalid matrix handle");
         return SPX_FAILURE;
     }
-    (void) row; (void) column; (void) value;
-    SETERROR_1(SPX_ERR_ENTRY_NOT_FOUND, "spx_mat_set_entry is not available in this build");
-    return SPX_FAILURE;
+    if (!entry_args(A, indexing, row, column)) {
+        SETWARNING(SPX_WARN_ENTRY_NOT_SET);
+        return SPX_FAILURE;
+    }
+    if (A->parts.empty() && A->nnz) {
+        SETERROR_1(SPX_ERR_ENTRY_NOT_FOUND,
+                   "the encoded partitions were dropped (spx.rt.keep_encoded=false or a restored matrix)");
+        return SPX_FAILURE;
+    }
+    std::lock_guard<std::mutex> lk(A->mtx);
+    build_spans(A);
+    val_t *v = locate(A, row, column);
+    if (!v) {
+        SETERROR_0(SPX_ERR_ENTRY_NOT_FOUND);
+        return SPX_FAILURE;
+    }
+    *v = value;
+    A->dirty = true;           // the HBM copy is refreshed before the next SpMV
+    A->exported.clear();
+    A->exported_rows_info.clear();
+    return SPX_SUCCESS;
 }
 
 // ---- save / restore -----------------------------------------------------------------
@@ -849,9 +1009,26 @@ static spx_error_t check_mv(const spx_matrix_t *A, const spx_vector_t *x, spx_ve
     return SPX_SUCCESS;
 }
 
+// values changed through spx_mat_set_entry: rebuild the stream once
+static bool refresh_if_dirty(const spx_matrix_t *A_)
+{
+    spx_matrix_t *A = const_cast<spx_matrix_t *>(A_);
+    if (!A->dirty) return true;
+    std::lock_guard<std::mutex> lk(A->mtx);
+    if (!A->dirty) return true;
+    try {
+        emit_and_upload(A);
+    } catch (const FatalError &e) {
+        SETERROR_1(SPX_ERR_TUNED_MAT, e.what.c_str());
+        return false;
+    }
+    return true;
+}
+
 static spx_error_t run_host(const spx_matrix_t *A, spx_value_t alpha, const spx_vector_t *x,
                             spx_value_t beta, spx_vector_t *y)
 {
+    if (!refresh_if_dirty(A)) return SPX_FAILURE;
     if (!A->dev) {
         SETERROR_1(SPX_ERR_TUNED_MAT,
                    "matrix was tuned with spx.rt.host_only=true: no HIP executor");
@@ -930,6 +1107,7 @@ spx_error_t spx_hip_matvec_kernel(spx_value_t alpha, const spx_matrix_t *A,
                                   spx_value_t *y_dev, void *stream)
 {
     if (check_dev(A, x_dev, y_dev) != SPX_SUCCESS) return SPX_FAILURE;
+    if (!refresh_if_dirty(A)) return SPX_FAILURE;
     try {
         device_spmv(A->dev, alpha, x_dev, beta, y_dev, stream);
     } catch (const FatalError &e) {
