@@ -11,7 +11,7 @@ LIBDIR    := sparsex_amd/lib
 OBJDIR    := build/obj
 LIB       := $(LIBDIR)/libsparsex.so
 
-HOST_SRCS := common.cpp config.cpp partition.cpp stats.cpp encoder.cpp input.cpp \
+HOST_SRCS := common.cpp config.cpp partition.cpp stats.cpp encoder.cpp input.cpp reorder.cpp \
              csx_emit.cpp gpu_emit.cpp api.cpp
 HOST_OBJS := $(HOST_SRCS:%.cpp=$(OBJDIR)/%.o)
 HIP_OBJ   := $(OBJDIR)/spmv_kernels.o $(OBJDIR)/vec_kernels.o

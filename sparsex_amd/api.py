@@ -297,6 +297,17 @@ class Matrix:
         if rc != SPX_SUCCESS:
             raise SpxError("entry (%d, %d) not set" % (row, col))
 
+    def get_perm(self):
+        """``spx_mat_get_perm`` -- perm[old index] = new index of a matrix tuned with
+        ``reorder=True``; ``None`` when the matrix was not reordered."""
+        L = lib()
+        L.spx_mat_get_perm.restype = C.POINTER(C.c_int)
+        L.spx_mat_get_perm.argtypes = [C.c_void_p]
+        p = L.spx_mat_get_perm(self.handle)
+        if not p:
+            return None
+        return np.ctypeslib.as_array(p, shape=(self.nrows,)).copy()
+
     def save(self, filename):
         """``spx_mat_save`` -- the tuned matrix (descriptor stream) to a file."""
         L = lib()
@@ -409,6 +420,31 @@ def mat_restore(filename):
     if not h:
         raise SpxError("spx_mat_restore failed (see stderr)")
     return Matrix(h)
+
+
+def _vec_permute(fn, v, perm):
+    L = lib()
+    assert v.dtype == np.float64 and v.flags.c_contiguous
+    perm = np.ascontiguousarray(perm, dtype=np.int32)
+    getattr(L, fn).argtypes = [C.POINTER(VectorStruct), C.POINTER(C.c_int)]
+    vv = L.spx_vec_create_from_buff(v.ctypes.data_as(C.POINTER(C.c_double)), None,
+                                    v.size, None, SPX_VEC_AS_IS)
+    try:
+        if getattr(L, fn)(vv, perm.ctypes.data_as(C.POINTER(C.c_int))) != SPX_SUCCESS:
+            raise SpxError("%s failed" % fn)
+    finally:
+        L.spx_vec_destroy(vv)
+    return v
+
+
+def vec_reorder(v, perm):
+    """``spx_vec_reorder(v, p)`` in place: new[p[i]] = old[i]."""
+    return _vec_permute("spx_vec_reorder", v, perm)
+
+
+def vec_inv_reorder(v, perm):
+    """``spx_vec_inv_reorder(v, p)`` in place: new[i] = old[p[i]]."""
+    return _vec_permute("spx_vec_inv_reorder", v, perm)
 
 
 def mat_tune(inp, reorder=False):

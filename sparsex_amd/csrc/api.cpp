@@ -15,6 +15,7 @@
 #include "encoder.hpp"
 #include "gpu_emit.hpp"
 #include "input.hpp"
+#include "reorder.hpp"
 
 #include <chrono>
 #include <cmath>
@@ -497,10 +498,24 @@ spx_matrix_t *spx_mat_tune(spx_input_t *in, ...)
     va_start(ap, in);
     spx_option_t option = va_arg(ap, spx_option_t);
     va_end(ap);
+    // RCM reordering replaces the input by P A P^T, as the reference does
+    // (src/api/matvec.c:280-288: input->mat = ReorderCSR/ReorderMMF(...)); a
+    // matrix that cannot be reordered is tuned in its given order.
+    std::vector<idx_t> perm;
     if (option == SPX_MAT_REORDER) {
-        // RCM reordering (reference Rcm.hpp, Boost.Graph) is outside this
-        // build's scope; the matrix is tuned in its given order
-        SETWARNING(SPX_WARN_REORDER);
+        TripletInput *re = nullptr;
+        try {
+            re = reorder_rcm(*in->mat, perm);
+        } catch (const FatalError &) {
+            re = nullptr;
+            perm.clear();
+        }
+        if (re) {
+            delete in->mat;
+            in->mat = re;
+        } else {
+            SETWARNING(SPX_WARN_REORDER);
+        }
     }
     spx_matrix_t *A = SPX_INVALID_MAT;
     try {
@@ -508,6 +523,10 @@ spx_matrix_t *spx_mat_tune(spx_input_t *in, ...)
     } catch (const FatalError &e) {
         SETERROR_0(SPX_ERR_TUNED_MAT);
         return SPX_INVALID_MAT;
+    }
+    if (!perm.empty()) {
+        A->permutation = (spx_perm_t *) malloc(perm.size() * sizeof(spx_perm_t));
+        std::copy(perm.begin(), perm.end(), A->permutation);
     }
     return A;
 }
@@ -611,8 +630,14 @@ bool entry_args(const spx_matrix_t *A, spx_option_t indexing, spx_index_t &row, 
         SETERROR_0(SPX_OUT_OF_BOUNDS);
         return false;
     }
-    row = row - base + 1;      // internally 1-based
-    col = col - base + 1;
+    row = row - base;
+    col = col - base;
+    if (A->permutation != SPX_INVALID_PERM) {   // reordered matrix: src/api/matvec.c:351-354
+        row = A->permutation[row];
+        col = A->permutation[col];
+    }
+    row += 1;                  // internally 1-based
+    col += 1;
     return true;
 }
 
@@ -698,7 +723,7 @@ spx_error_t spx_mat_set_entry(spx_matrix_t *A, spx_index_t row, spx_index_t colu
 
 namespace {
 
-const char kMagic[8] = {'S', 'P', 'X', 'H', 'I', 'P', '0', '2'};
+const char kMagic[8] = {'S', 'P', 'X', 'H', 'I', 'P', '0', '3'};
 
 template <typename T>
 bool put_vec(FILE *f, const std::vector<T> &v)
@@ -781,6 +806,9 @@ spx_error_t spx_mat_save(const spx_matrix_t *A, const char *filename)
            put_vec(f, gs->dmasks) && put_vec(f, gs->descs) && put_vec(f, gs->cidx) &&
            put_vec(f, gs->segrows) && put_vec(f, gs->shared) && put_vec(f, gs->dvalues) &&
            put_vec(f, gs->values);
+    std::vector<int32_t> perm;
+    if (A->permutation) perm.assign(A->permutation, A->permutation + A->nrows);
+    good = good && put_vec(f, perm);
     good = (fclose(f) == 0) && good;
     if (!good) {
         SETERROR_1(SPX_ERR_FILE, "writing the tuned matrix failed");
@@ -813,8 +841,10 @@ spx_matrix_t *spx_mat_restore(const char *filename)
                 get_vec(f, gs->passes) && get_vec(f, gs->dmasks) && get_vec(f, gs->descs) &&
                 get_vec(f, gs->cidx) && get_vec(f, gs->segrows) && get_vec(f, gs->shared) &&
                 get_vec(f, gs->dvalues) && get_vec(f, gs->values);
+    std::vector<int32_t> perm;
+    good = good && get_vec(f, perm);
     fclose(f);
-    if (!good || bnd.size() != 3 * h.nr_partitions) {
+    if (!good || bnd.size() != 3 * h.nr_partitions || (!perm.empty() && perm.size() != (size_t) h.nrows)) {
         SETERROR_1(SPX_ERR_FILE, "not a tuned-matrix file of this build");
         return SPX_INVALID_MAT;
     }
@@ -824,6 +854,10 @@ spx_matrix_t *spx_mat_restore(const char *filename)
     std::unique_ptr<matrix> A(new matrix);
     A->nrows = h.nrows; A->ncols = h.ncols; A->nnz = h.nnz; A->symmetric = h.symmetric;
     A->permutation = SPX_INVALID_PERM;
+    if (!perm.empty()) {
+        A->permutation = (spx_perm_t *) malloc(perm.size() * sizeof(spx_perm_t));
+        std::copy(perm.begin(), perm.end(), A->permutation);
+    }
     A->nr_partitions = h.nr_partitions; A->first_part = h.first_part; A->last_part = h.last_part;
     for (size_t i = 0; i < h.nr_partitions; ++i)
         A->bounds.push_back(PartBounds{bnd[3 * i], bnd[3 * i + 1], (size_t) bnd[3 * i + 2]});

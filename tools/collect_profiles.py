@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Copies the summaries tools/refresh_profiles.sh left under gpurun_out/<round>_<w>/
+into profiles/<round>/ and regenerates profiles/traffic.json from the PMC passes.
+usage: tools/collect_profiles.py r01"""
+import json, os, re, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+dst = os.path.join(ROOT, "profiles", rnd)
+os.makedirs(dst, exist_ok=True)
+traffic = {}
+for w in ("cant", "nd24k", "webbase"):
+    src = os.path.join(ROOT, "gpurun_out", "%s_%s" % (rnd, w))
+    if not os.path.isdir(src):
+        continue
+    for a, b in (("kernel_stats.csv", "%s_kernel_stats.csv"), ("bench_line.json", "%s_bench_line_under_rocprof.json"),
+                 ("pmc_FETCH_SIZE.txt", "%s_pmc_FETCH_SIZE.txt"), ("pmc_WRITE_SIZE.txt", "%s_pmc_WRITE_SIZE.txt"),
+                 ("bench_plain.json", "bench_%s.json"), ("bench_plain_sym.json", "bench_%s_sym.json")):
+        p = os.path.join(src, a)
+        if os.path.exists(p) and os.path.getsize(p) > 0:
+            shutil.copy(p, os.path.join(dst, b % w))
+    kib = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        p = os.path.join(src, "pmc_%s.txt" % c)
+        if not os.path.exists(p):
+            continue
+        for line in open(p):
+            if line.startswith("csx_spmv_kernel"):
+                kib[c] = float(re.search(r"per_launch=([0-9.]+)", line).group(1))
+    if len(kib) == 2:
+        traffic["syn-" + w] = {
+            "fetch_size_kib_per_launch": kib["FETCH_SIZE"],
+            "write_size_kib_per_launch": kib["WRITE_SIZE"],
+            "hbm_bytes_per_launch": int((2 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024),
+            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, csx_spmv_kernel only; "
+                    "FETCH_SIZE doubled per the gfx950 correction",
+        }
+if traffic:
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    old = json.load(open(path)) if os.path.exists(path) else {}
+    old.update(traffic)
+    json.dump(old, open(path, "w"), indent=1)
+print(json.dumps(traffic, indent=1))
