@@ -325,7 +325,7 @@ static void emit_and_upload(spx_matrix_t *A)
         gs.dvalues.assign((size_t) A->nrows, 0.0);
         Partition full;
         for (size_t i = 0; i < nown; ++i) {
-            append_sym_expanded(A->parts[i], full);
+            append_sym_expanded(A->parts[i], full, gp.sym_remine);
             const PartBounds &b = A->bounds[first + i];
             for (size_t r = 0; r < A->diag[i].size() && r < (size_t) b.nr_rows; ++r)
                 gs.dvalues[(size_t) b.row_start + r] = A->diag[i][r];
@@ -471,6 +471,8 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     A->auto_rb = rbe <= 0;
     A->emit_params.target_elems = (size_t) std::max<long>(64, rbe);
     A->emit_params.max_rows = (size_t) std::max<long>(1, cfg.get_long("spx.gpu.rowblock_rows"));
+    A->emit_params.sym_remine = cfg.get_bool("spx.gpu.sym_remine");
+    A->emit_params.stack_segments = cfg.get_bool("spx.gpu.stack_segments");
     A->emit_params.col_panel = (size_t) std::max<long>(0, cfg.get_long("spx.gpu.col_panel"));
     {
         idx_t lo = nown ? A->bounds[first].row_start : 0;

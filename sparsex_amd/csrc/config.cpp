@@ -43,6 +43,8 @@ void Config::reset_defaults()
     props_["spx.rt.keep_encoded"] = "true";  // keep the encoded partitions for export
     props_["spx.gpu.rowblock_elems"] = "0";    // target value elements per row-block
     props_["spx.gpu.rowblock_rows"] = "512";   // max rows owned by one row-block
+    props_["spx.gpu.stack_segments"] = "true"; // merge stacked row segments into block descriptors
+    props_["spx.gpu.sym_remine"] = "true";     // symmetric: re-cut the mirrored triangle into row segments
     props_["spx.gpu.col_panel"] = "0";         // columns per x panel for leftovers (0: off)
 }
 

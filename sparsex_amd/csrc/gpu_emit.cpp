@@ -41,8 +41,8 @@ struct Group {
 
 class RbBuilder {
 public:
-    RbBuilder(const Partition &p, GpuStream &out, size_t col_panel = 0)
-        : p_(p), out_(out), col_panel_(col_panel) {}
+    RbBuilder(const Partition &p, GpuStream &out, size_t col_panel = 0, bool stack = true)
+        : p_(p), out_(out), col_panel_(col_panel), stack_(stack) {}
 
     // emits one row-block for rows [lo, hi) from the given pieces/singles
     void emit(idx_t lo, idx_t hi, const std::vector<Piece> &pieces,
@@ -62,12 +62,14 @@ private:
         groups_.push_back(g);
     }
     void groups_from_piece(const Piece &pc, idx_t lo);
+    void stack_groups();
     void emit_unit_passes(SpxRowBlock &rb);
     void emit_delta_passes(SpxRowBlock &rb, std::vector<Single> &singles, idx_t lo);
 
     const Partition &p_;
     GpuStream &out_;
     size_t col_panel_;
+    bool stack_;
     std::vector<Group> groups_;
     std::vector<val_t> gvals_;
 };
@@ -133,6 +135,89 @@ void RbBuilder::groups_from_piece(const Piece &pc, idx_t lo)
     assert((unsigned) d <= SPX_MAX_STEP);
     add_group(r0 - 1 - lo, c0 - 1, n, 1, kind, (unsigned) d);
     gvals_.insert(gvals_.end(), src + pc.a, src + pc.b);
+}
+
+// Row segments that sit on top of each other (same columns, consecutive rows)
+// share one descriptor as a dense block, whatever units they came from: the
+// pieces of a cut block, horizontal units of neighbouring rows, chunks of wide
+// horizontal units.  Fewer descriptors, same lanes.
+void RbBuilder::stack_groups()
+{
+    struct Run { uint16_t row0, nrows; uint32_t col0; uint32_t voff; uint8_t width; };
+    std::vector<Run> runs;
+    std::vector<Group> kept;
+    for (const Group &g : groups_) {
+        if (g.kind == SPX_KIND_BLOCK || g.nseg == 1) {
+            runs.push_back(Run{g.row0, g.nseg, g.col0, g.voff, g.width});
+        } else if (g.kind == SPX_KIND_HORIZ && g.step == SPX_HORIZ_CHUNK && g.width == SPX_HORIZ_CHUNK) {
+            for (uint32_t s = 0; s < g.nseg; ++s)
+                runs.push_back(Run{g.row0, 1, g.col0 + s * SPX_HORIZ_CHUNK, g.voff + s * SPX_HORIZ_CHUNK,
+                                   g.width});
+        } else {
+            kept.push_back(g);
+        }
+    }
+    if (runs.empty()) return;
+    std::sort(runs.begin(), runs.end(), [](const Run &a, const Run &b) {
+        if (a.width != b.width) return a.width < b.width;
+        if (a.col0 != b.col0) return a.col0 < b.col0;
+        return a.row0 < b.row0;
+    });
+    std::vector<val_t> vals;
+    vals.reserve(gvals_.size());
+    auto copy_vals = [&](const Group &g) {
+        uint32_t off = (uint32_t) vals.size();
+        vals.insert(vals.end(), gvals_.begin() + g.voff, gvals_.begin() + g.voff + (size_t) g.nseg * g.width);
+        return off;
+    };
+    for (Group &g : kept) g.voff = copy_vals(g);
+    std::vector<Group> lone;     // width-8 segments left alone: chained along their row again
+    for (size_t i = 0; i < runs.size();) {
+        Group g;
+        g.row0 = runs[i].row0;
+        g.col0 = runs[i].col0;
+        g.width = runs[i].width;
+        g.kind = SPX_KIND_BLOCK;
+        g.step = 0;
+        g.voff = (uint32_t) vals.size();
+        size_t rows = 0, j = i;
+        while (j < runs.size() && runs[j].width == g.width && runs[j].col0 == g.col0 &&
+               runs[j].row0 == g.row0 + rows) {
+            vals.insert(vals.end(), gvals_.begin() + runs[j].voff,
+                        gvals_.begin() + runs[j].voff + (size_t) runs[j].nrows * g.width);
+            rows += runs[j].nrows;
+            ++j;
+        }
+        g.nseg = (uint16_t) rows;
+        if (rows == 1 && g.width == SPX_HORIZ_CHUNK) lone.push_back(g);
+        else kept.push_back(g);
+        i = j;
+    }
+    std::sort(lone.begin(), lone.end(), [](const Group &a, const Group &b) {
+        return a.row0 != b.row0 ? a.row0 < b.row0 : a.col0 < b.col0;
+    });
+    for (size_t i = 0; i < lone.size();) {
+        Group g = lone[i];
+        g.kind = SPX_KIND_HORIZ;
+        g.step = SPX_HORIZ_CHUNK;
+        g.voff = (uint32_t) vals.size();
+        size_t j = i;
+        while (j < lone.size() && lone[j].row0 == g.row0 &&
+               lone[j].col0 == g.col0 + (uint32_t)((j - i) * SPX_HORIZ_CHUNK)) {
+            // values of lone[j] were appended to `vals` above; move them behind each other
+            ++j;
+        }
+        g.nseg = (uint16_t)(j - i);
+        std::vector<val_t> tmp;
+        for (size_t k = i; k < j; ++k)
+            tmp.insert(tmp.end(), vals.begin() + lone[k].voff, vals.begin() + lone[k].voff + g.width);
+        g.voff = (uint32_t) vals.size();
+        vals.insert(vals.end(), tmp.begin(), tmp.end());
+        kept.push_back(g);
+        i = j;
+    }
+    groups_.swap(kept);
+    gvals_.swap(vals);
 }
 
 void RbBuilder::emit_unit_passes(SpxRowBlock &rb)
@@ -279,6 +364,7 @@ void RbBuilder::emit(idx_t lo, idx_t hi, const std::vector<Piece> &pieces,
     gvals_.clear();
     for (const Piece &pc : pieces) groups_from_piece(pc, lo);
     const size_t n_unit = gvals_.size();
+    if (stack_) stack_groups();
     emit_unit_passes(rb);
     const size_t n_delta = singles.size();
     emit_delta_passes(rb, singles, lo);
@@ -295,50 +381,134 @@ void RbBuilder::emit(idx_t lo, idx_t hi, const std::vector<Piece> &pieces,
 
 }  // namespace
 
-void append_sym_expanded(const Partition &lower, Partition &out)
+// Mirror image of one unit (see gpu_emit.hpp).
+static Elem mirror_unit(const Elem &e, const val_t *src, Partition &out)
+{
+    Elem t = e;
+    t.row = e.col;
+    t.col = e.row;
+    switch (e.type) {
+    case ENC_H: t.type = ENC_V; break;
+    case ENC_V: t.type = ENC_H; break;
+    case ENC_D: break;
+    case ENC_AD: {
+        // (r + k*d, c - k*d) mirrors to (c - k*d, r + k*d): walked from
+        // its top-right end, i.e. in reverse
+        const idx_t span = (idx_t)(e.size - 1) * (idx_t) e.delta;
+        t.row = e.col - span;
+        t.col = e.row + span;
+        std::vector<val_t> rev(src, src + e.size);
+        std::reverse(rev.begin(), rev.end());
+        t.voff = out.pool_alloc(rev.data(), e.size);
+        break;
+    }
+    default:
+        // R x c column-major block-row  <->  c x R row-major block-col
+        // (same value order); the free dimension stays in `delta`
+        if (enc_is_block_row(e.type)) t.type = (uint8_t)(ENC_BC1 + (e.type - ENC_BR1));
+        else t.type = (uint8_t)(ENC_BR1 + (e.type - ENC_BC1));
+    }
+    return t;
+}
+
+// The upper triangle as the GPU wants it: the mirrored nonzeros are cut into
+// row segments (runs of consecutive columns, at most SPX_MAX_SEG_WIDTH wide)
+// and equal segments in consecutive rows are stacked into dense blocks.  The
+// mirror image of what CSX found in the lower triangle is mostly column
+// shaped (a horizontal unit becomes a vertical one: one lane and one LDS add
+// per nonzero), while eight stacked horizontal units mirror to a dense block
+// that this finds again.
+static void append_upper_segments(std::vector<Single> &pts, Partition &out)
+{
+    std::sort(pts.begin(), pts.end(), [](const Single &a, const Single &b) {
+        return a.row < b.row || (a.row == b.row && a.col < b.col);
+    });
+    struct Seg { idx_t row, col; uint32_t first; uint32_t width; };
+    std::vector<Seg> segs;
+    for (size_t i = 0; i < pts.size();) {
+        size_t j = i + 1;
+        while (j < pts.size() && j - i < SPX_MAX_SEG_WIDTH && pts[j].row == pts[i].row &&
+               pts[j].col == pts[j - 1].col + 1)
+            ++j;
+        segs.push_back(Seg{pts[i].row, pts[i].col, (uint32_t) i, (uint32_t)(j - i)});
+        i = j;
+    }
+    std::sort(segs.begin(), segs.end(), [](const Seg &a, const Seg &b) {
+        if (a.col != b.col) return a.col < b.col;
+        if (a.width != b.width) return a.width < b.width;
+        return a.row < b.row;
+    });
+    std::vector<val_t> vals;
+    for (size_t i = 0; i < segs.size();) {
+        const size_t w = segs[i].width;
+        const size_t max_rows = 4096 / w;
+        size_t j = i + 1;
+        while (j < segs.size() && j - i < max_rows && segs[j].col == segs[i].col &&
+               segs[j].width == w && segs[j].row == segs[j - 1].row + 1)
+            ++j;
+        const size_t rows = j - i;
+        if (rows * w == 1) {
+            const Single &s = pts[segs[i].first];
+            out.elems.push_back(make_single(s.row, s.col, s.val));
+        } else {
+            vals.clear();
+            for (size_t k = i; k < j; ++k)
+                for (size_t x = 0; x < w; ++x) vals.push_back(pts[segs[k].first + x].val);
+            Elem u;
+            u.row = segs[i].row;
+            u.col = segs[i].col;
+            u.val = 0;
+            u.voff = out.pool_alloc(vals.data(), vals.size());
+            u.size = (uint16_t) vals.size();
+            u.pad_ = 0;
+            if (rows == 1) {            // one row segment
+                u.type = ENC_H;
+                u.delta = 1;
+            } else if (w == 1) {        // a column
+                u.type = ENC_V;
+                u.delta = 1;
+            } else {                    // rows x w, row-major
+                u.type = (uint8_t)(ENC_BC1 + (w - 1));
+                u.delta = (uint32_t) rows;
+            }
+            out.elems.push_back(u);
+        }
+        i = j;
+    }
+}
+
+void append_sym_expanded(const Partition &lower, Partition &out, bool remine_upper)
 {
     const idx_t rs = lower.row_start;
     out.type = ENC_H;
     out.row_start = 0;
     out.nr_cols = lower.nr_cols;
     out.nr_rows = std::max<size_t>(out.nr_rows, (size_t) rs + lower.nr_rows);
+    std::vector<Single> upper;      // 1-based coordinates of the mirrored nonzeros
+    if (remine_upper) upper.reserve(lower.nnz);
     for (size_t i = 0; i < lower.elems_size; ++i) {
         Elem e = lower.elems[i];
         e.row += rs;                       // global row
         if (!e.is_unit()) {
             out.elems.push_back(e);
-            out.elems.push_back(make_single(e.col, e.row, e.val));
+            if (remine_upper) upper.push_back(Single{e.col, e.row, e.val});
+            else out.elems.push_back(make_single(e.col, e.row, e.val));
             continue;
         }
         const val_t *src = &lower.pool[e.voff];
         e.voff = out.pool_alloc(src, e.size);
         out.elems.push_back(e);
-        Elem t = e;                        // the mirror image
-        t.row = e.col;
-        t.col = e.row;
-        switch (e.type) {
-        case ENC_H: t.type = ENC_V; break;
-        case ENC_V: t.type = ENC_H; break;
-        case ENC_D: break;
-        case ENC_AD: {
-            // (r + k*d, c - k*d) mirrors to (c - k*d, r + k*d): walked from
-            // its top-right end, i.e. in reverse
-            const idx_t span = (idx_t)(e.size - 1) * (idx_t) e.delta;
-            t.row = e.col - span;
-            t.col = e.row + span;
-            std::vector<val_t> rev(src, src + e.size);
-            std::reverse(rev.begin(), rev.end());
-            t.voff = out.pool_alloc(rev.data(), e.size);
-            break;
+        if (remine_upper) {
+            for (size_t k = 0; k < e.size; ++k) {
+                idx_t r, c;
+                unit_elem_coords(e, k, r, c);
+                upper.push_back(Single{c, r, src[k]});
+            }
+        } else {
+            out.elems.push_back(mirror_unit(e, src, out));
         }
-        default:
-            // R x c column-major block-row  <->  c x R row-major block-col
-            // (same value order); the free dimension stays in `delta`
-            if (enc_is_block_row(e.type)) t.type = (uint8_t)(ENC_BC1 + (e.type - ENC_BR1));
-            else t.type = (uint8_t)(ENC_BR1 + (e.type - ENC_BC1));
-        }
-        out.elems.push_back(t);
     }
+    if (remine_upper) append_upper_segments(upper, out);
     out.elems_size = out.elems.size();
     out.nnz += 2 * lower.nnz;
 }
@@ -454,7 +624,7 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out)
     }
 
     // 4. emit
-    RbBuilder bld(p, out, prm.col_panel);
+    RbBuilder bld(p, out, prm.col_panel, prm.stack_segments);
     for (size_t i = 0; i < plans.size(); ++i) {
         const Plan &pl = plans[i];
         if (prm.skip_empty && pieces[i].empty() && singles[i].empty()) continue;

@@ -45,6 +45,9 @@ struct GpuEmitParams {
     size_t target_elems = 2048;   // spx.gpu.rowblock_elems
     size_t max_rows = SPX_MAX_RB_ROWS;   // spx.gpu.rowblock_rows (<= SPX_MAX_RB_ROWS)
     bool skip_empty = false;      // accumulate mode: rows without nonzeros need no write
+    bool stack_segments = true;   // spx.gpu.stack_segments: equal row segments of consecutive
+                                  // rows share one descriptor as a dense block
+    bool sym_remine = true;       // spx.gpu.sym_remine (see append_sym_expanded)
     size_t col_panel = 0;         // > 0: leftover nonzeros are visited panel by panel of
                                   // this many columns (keeps the x slice in L2)
 };
@@ -54,11 +57,13 @@ struct GpuEmitParams {
 void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out);
 
 // Symmetric path: the strictly lower triangle held by `lower` (rows local to
-// the partition) plus the mirror image of every unit, as one general
-// partition in global row numbering (row_start 0).  Mirrors keep the unit
-// structure: horizontal <-> vertical, diagonal and anti-diagonal stay,
-// block-row R x c <-> block-col c x R.  Appends to `out`.
-void append_sym_expanded(const Partition &lower, Partition &out);
+// the partition) plus its mirror image, as one general partition in global
+// row numbering (row_start 0).  Appends to `out`.  The mirrored nonzeros are
+// either re-cut into row segments and dense blocks (`remine_upper`, the
+// default: what the kernel's lanes want) or mirrored unit by unit
+// (horizontal <-> vertical, diagonal and anti-diagonal stay, block-row
+// R x c <-> block-col c x R).
+void append_sym_expanded(const Partition &lower, Partition &out, bool remine_upper = true);
 
 // coordinates (1-based, horizontal order) of element k of a unit
 inline void unit_elem_coords(const Elem &u, size_t k, idx_t &r, idx_t &c)

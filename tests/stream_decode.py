@@ -1,0 +1,131 @@
+"""Independent numpy decoder of the row-block descriptor stream (the file
+``spx_mat_save`` writes; layout: sparsex_amd/csrc/gpu_format.h and the
+SavedHeader of api.cpp).  Test infrastructure: it lets the CPU suite check the
+HBM layout the kernel walks -- every lane's row, column and value -- without a
+GPU.  It shares no code with the emitter or the kernel."""
+import struct
+
+import numpy as np
+
+RB = np.dtype([("val_off", "<u8"), ("pass_off", "<u4"), ("desc_off", "<u4"), ("cidx_off", "<u4"),
+               ("seg_off", "<u4"), ("cbase", "<u4"), ("row0", "<u4"), ("n_rows", "<u2"),
+               ("n_pass", "<u2"), ("cidx_width", "u1"), ("flags", "u1"), ("pad", "<u2"),
+               ("carry_slot", "<u4"), ("pad2", "<u4")])
+PASS = np.dtype([("mask", "<u8"), ("val_off", "<u4"), ("rank0", "<u2"), ("seg0", "<u2"),
+                 ("nseg", "u1"), ("width", "u1"), ("kind", "u1"), ("pad", "u1"), ("dmask_off", "<u4")])
+DESC = np.dtype([("col0", "<u4"), ("bits", "<u4")])
+SHARED = np.dtype([("row", "<u4"), ("first_slot", "<u4"), ("n_slots", "<u4")])
+assert RB.itemsize == 48 and PASS.itemsize == 24 and DESC.itemsize == 8
+
+KIND_BLOCK, KIND_HORIZ, KIND_VERT, KIND_DIAG, KIND_ADIAG = range(5)
+
+
+class Stream:
+    def __init__(self, path):
+        with open(path, "rb") as f:
+            buf = f.read()
+        assert buf[:8] == b"SPXHIP03", buf[:8]
+        hdr = struct.unpack_from("<4i3Q2i4Q2I", buf, 8)
+        (self.nrows, self.ncols, self.nnz, self.symmetric, self.nr_partitions, self.first_part,
+         self.last_part, self.own_lo, self.own_hi, self.nnz_stored, self.n_unit_elems,
+         self.n_delta_elems, self.n_units, self.n_carry, _) = hdr
+        self.off = 8 + struct.calcsize("<4i3Q2i4Q2I")
+        self.buf = buf
+
+        def vec(dt):
+            (n,) = struct.unpack_from("<Q", self.buf, self.off)
+            self.off += 8
+            a = np.frombuffer(self.buf, dtype=dt, count=n, offset=self.off)
+            self.off += n * np.dtype(dt).itemsize
+            return a
+        self.bounds = vec("<i4").reshape(-1, 3)
+        self.rbs = vec(RB)
+        self.passes = vec(PASS)
+        self.dmasks = vec("<u8")
+        self.descs = vec(DESC)
+        self.cidx = vec("u1")
+        self.segrows = vec("<u2")
+        self.shared = vec(SHARED)
+        self.dvalues = vec("<f8")
+        self.values = vec("<f8")
+        self.perm = vec("<i4")
+        assert self.off == len(buf)
+
+    def triplets(self):
+        """(row, col, value, rowblock) of every stored nonzero, as the kernel's lanes see them."""
+        R, Cc, V, B = [], [], [], []
+        for bi, rb in enumerate(self.rbs):
+            vbase = int(rb["val_off"])
+            for ps in self.passes[int(rb["pass_off"]):int(rb["pass_off"]) + int(rb["n_pass"])]:
+                pv = vbase + int(ps["val_off"])
+                assert pv % 2 == 0                    # 16-byte aligned lane loads
+                if ps["kind"] == 0:
+                    nseg, W, mask = int(ps["nseg"]), int(ps["width"]), int(ps["mask"])
+                    assert 1 <= nseg <= 64 and 1 <= W <= 8 and not (mask & 1)
+                    lanes = np.arange(nseg)
+                    starts = np.array([(mask >> l) & 1 for l in range(nseg)])
+                    rank = int(ps["rank0"]) + np.cumsum(starts)
+                    d = self.descs[int(rb["desc_off"]) + rank]
+                    bits = d["bits"].astype(np.int64)
+                    s = (int(ps["seg0"]) + lanes - ((bits >> 9) & 8191)) & 0xffff
+                    kind, step = (bits >> 22) & 7, bits >> 25
+                    drow = np.where(kind == KIND_BLOCK, 1, np.where(kind >= KIND_VERT, step, 0))
+                    dcol = np.where((kind == KIND_HORIZ) | (kind == KIND_DIAG), step,
+                                    np.where(kind == KIND_ADIAG, -step, 0))
+                    row = (bits & 511) + s * drow
+                    col = d["col0"].astype(np.int64) + s * dcol
+                    assert (row < int(rb["n_rows"])).all(), "segment leaves its row-block"
+                    for w in range(W):
+                        pair = w >> 1
+                        if (W & 1) and w == W - 1:
+                            idx = pair * 2 * nseg + lanes
+                        else:
+                            idx = pair * 2 * nseg + lanes * 2 + (w & 1)
+                        R.append(row + int(rb["row0"])); Cc.append(col + w)
+                        V.append(self.values[pv + idx]); B.append(np.full(nseg, bi))
+                else:
+                    cnt = int(ps["nseg"]) + 1
+                    k = np.arange(cnt)
+                    m = [int(ps["mask"])] + [int(x) for x in self.dmasks[int(ps["dmask_off"]):int(ps["dmask_off"]) + 3]]
+                    starts = np.array([(m[i >> 6] >> (i & 63)) & 1 for i in range(cnt)])
+                    assert starts[0] == 0
+                    seg = int(ps["rank0"]) + np.cumsum(starts)
+                    row = self.segrows[int(rb["seg_off"]) + seg].astype(np.int64)
+                    assert (row < int(rb["n_rows"])).all()
+                    cw = int(rb["cidx_width"])
+                    o = int(rb["cidx_off"]) + (int(ps["seg0"]) + k) * cw
+                    assert int(rb["cidx_off"]) % 16 == 0
+                    if cw == 2:
+                        off = self.cidx[o].astype(np.int64) | (self.cidx[o + 1].astype(np.int64) << 8)
+                    else:
+                        off = sum(self.cidx[o + b].astype(np.int64) << (8 * b) for b in range(4))
+                    R.append(row + int(rb["row0"])); Cc.append(off + int(rb["cbase"]))
+                    V.append(self.values[pv + k]); B.append(np.full(cnt, bi))
+        if not R:
+            z = np.zeros(0, dtype=np.int64)
+            return z, z, np.zeros(0), z
+        return np.concatenate(R), np.concatenate(Cc), np.concatenate(V), np.concatenate(B)
+
+    def matvec(self, x):
+        """y = A x as the stream defines it (symmetric: the diagonal comes from dvalues)."""
+        r, c, v, _ = self.triplets()
+        y = np.zeros(self.nrows)
+        np.add.at(y, r, v * x[c])
+        if self.symmetric:
+            y[self.own_lo:self.own_hi] += (self.dvalues * x[:self.dvalues.size])[self.own_lo:self.own_hi]
+        return y
+
+    def check_ownership(self):
+        """Unshared row-blocks own disjoint row ranges; shared ones own single rows listed in `shared`."""
+        owner = np.zeros(self.nrows + 1, dtype=np.int64)
+        for rb in self.rbs:
+            if rb["flags"] & 1:
+                assert rb["n_rows"] == 1
+                continue
+            owner[int(rb["row0"]):int(rb["row0"]) + int(rb["n_rows"])] += 1
+        assert owner.max(initial=0) <= 1
+        srows = set(int(s["row"]) for s in self.shared)
+        for rb in self.rbs:
+            if rb["flags"] & 1:
+                assert int(rb["row0"]) in srows and owner[int(rb["row0"])] == 0
+        return owner

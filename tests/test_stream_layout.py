@@ -1,0 +1,135 @@
+"""The HBM layout on the CPU: an independent numpy decoder (tests/stream_decode.py)
+reads the saved row-block descriptor stream lane by lane and must reproduce the
+input matrix exactly -- every nonzero once, in the row-block that owns its row."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import sparsex_amd as sx
+from sparsex_amd import synth
+from helpers import tune
+from stream_decode import Stream
+
+def zoo(n=1500, seed=9):
+    """Vertical / diagonal / anti-diagonal lines with strides 1..4, strided horizontal runs, blocks."""
+    rng = np.random.RandomState(seed)
+    rows, cols = [np.arange(n)], [np.arange(n)]
+    for k in range(60):
+        r0, c0 = rng.randint(0, n - 400), rng.randint(200, n - 400)
+        ln, st = rng.randint(5, 90), 1 + k % 4
+        t = np.arange(ln) * st
+        shape = k % 5
+        if shape == 0: rows.append(r0 + t); cols.append(np.full(ln, c0))            # vertical
+        elif shape == 1: rows.append(r0 + t); cols.append(c0 + t)                   # diagonal
+        elif shape == 2: rows.append(r0 + t); cols.append(c0 + 380 - t)             # anti-diagonal
+        elif shape == 3: rows.append(np.full(ln, r0)); cols.append(c0 + t)          # horizontal
+        else:                                                                        # dense block
+            a, b = np.meshgrid(np.arange(rng.randint(2, 9)), np.arange(rng.randint(2, 20)), indexing="ij")
+            rows.append(r0 + a.ravel()); cols.append(c0 + b.ravel())
+    m = sp.coo_matrix((np.ones(sum(x.size for x in rows)), (np.concatenate(rows), np.concatenate(cols))),
+                      shape=(n, n)).tocsr()
+    m.sum_duplicates(); m.sort_indices()
+    m.data = rng.uniform(0.5, 1.5, m.nnz)
+    return (m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data.copy(), n)
+
+
+CASES = [
+    ("zoo-all", zoo, {"spx.preproc.xform": "all", "spx.preproc.sampling": "none"}),
+    ("zoo-v", zoo, {"spx.preproc.xform": "v", "spx.preproc.sampling": "none", "spx.gpu.rowblock_rows": "37"}),
+    ("zoo-ad", zoo, {"spx.preproc.xform": "ad", "spx.preproc.sampling": "none", "spx.gpu.rowblock_rows": "50"}),
+    ("zoo-d", zoo, {"spx.preproc.xform": "d", "spx.preproc.sampling": "none", "spx.gpu.rowblock_rows": "19"}),
+    ("zoo-strided", zoo, {"spx.preproc.xform": "v{2},ad{3},d{2},h{4}", "spx.gpu.rowblock_rows": "23"}),
+    ("zoo-h", zoo, {"spx.preproc.xform": "h", "spx.preproc.sampling": "none"}),
+    ("zoo-br", zoo, {"spx.preproc.xform": "br", "spx.preproc.sampling": "none", "spx.gpu.rowblock_rows": "3"}),
+    ("cant", lambda: synth.syn_cant(0.04), {"spx.preproc.sampling": "none"}),
+    ("cant-p3", lambda: synth.syn_cant(0.04), {"spx.preproc.sampling": "none", "spx.rt.nr_threads": "3"}),
+    ("cant-small-rb", lambda: synth.syn_cant(0.02), {"spx.preproc.sampling": "none", "spx.gpu.rowblock_elems": "300",
+                                                     "spx.gpu.rowblock_rows": "7"}),
+    ("nd24k", lambda: synth.syn_nd24k(0.02), {"spx.preproc.sampling": "none"}),
+    ("nd24k-nostack", lambda: synth.syn_nd24k(0.02), {"spx.preproc.sampling": "none", "spx.gpu.stack_segments": "false"}),
+    ("webbase", lambda: synth.syn_webbase(0.01), {}),
+    ("webbase-panel", lambda: synth.syn_webbase(0.01), {"spx.gpu.col_panel": "2048"}),
+    ("nlpkkt", lambda: synth.syn_nlpkkt(7), {"spx.preproc.sampling": "none", "spx.rt.nr_threads": "2"}),
+    ("all-types", lambda: synth.syn_nlpkkt(6), {"spx.preproc.xform": "all", "spx.preproc.sampling": "none"}),
+]
+
+
+def dense_of(stream):
+    r, c, v, b = stream.triplets()
+    m = sp.coo_matrix((v, (r, c)), shape=(stream.nrows, stream.ncols))
+    return r, c, v, b, m
+
+
+@pytest.mark.parametrize("name,gen,opts", CASES, ids=[c[0] for c in CASES])
+def test_general_stream_holds_the_matrix_exactly(tmp_path, name, gen, opts):
+    csr = gen()
+    rp, ci, va, n = csr
+    A = tune(csr, opts, host_only=True)
+    f = str(tmp_path / "m.spx")
+    A.save(f)
+    s = Stream(f)
+    r, c, v, b, m = dense_of(s)
+    assert r.size == rp[-1] == s.nnz_stored               # every nonzero exactly once
+    a = sp.csr_matrix((va, ci, rp), shape=(n, n))
+    assert abs(m.tocsr() - a).max() == 0                  # values bit-identical, right places
+    assert np.unique(r * n + c).size == r.size            # no duplicates hiding behind a sum
+    s.check_ownership()
+    row0 = s.rbs["row0"].astype(np.int64)[b]
+    assert ((r >= row0) & (r < row0 + s.rbs["n_rows"].astype(np.int64)[b])).all()
+
+
+@pytest.mark.parametrize("remine", ["true", "false"])
+@pytest.mark.parametrize("name,gen,opts", [
+    ("cant", lambda: synth.syn_cant(0.04), {"spx.preproc.sampling": "none", "spx.rt.nr_threads": "2"}),
+    ("nd24k", lambda: synth.syn_nd24k(0.02), {"spx.preproc.sampling": "none"}),
+    ("nlpkkt-all", lambda: synth.syn_nlpkkt(6), {"spx.preproc.xform": "all", "spx.preproc.sampling": "none"}),
+], ids=["cant", "nd24k", "nlpkkt-all"])
+def test_symmetric_stream_is_lower_plus_mirror(tmp_path, name, gen, opts, remine):
+    csr = gen()
+    rp, ci, va, n = csr
+    o = dict(opts)
+    o["spx.gpu.sym_remine"] = remine
+    A = tune(csr, o, sym=True, host_only=True)
+    f = str(tmp_path / "m.spx")
+    A.save(f)
+    s = Stream(f)
+    r, c, v, b, m = dense_of(s)
+    a = sp.csr_matrix((va, ci, rp), shape=(n, n))
+    off = a - sp.diags(a.diagonal())
+    assert abs(m.tocsr() - off.tocsr()).max() == 0        # strict lower + strict upper
+    assert np.array_equal(s.dvalues, a.diagonal())
+    s.check_ownership()
+    x = synth.random_x(n)
+    assert np.allclose(s.matvec(x), a @ x, rtol=1e-12, atol=1e-14)
+
+
+def test_zoo_cases_cover_every_descriptor_kind(tmp_path):
+    seen = set()
+    for xf in ("v", "ad", "d", "h", "br", "v{2},ad{3},d{2},h{4}"):
+        A = tune(zoo(), {"spx.preproc.xform": xf, "spx.preproc.sampling": "none"}, host_only=True)
+        f = str(tmp_path / "m.spx")
+        A.save(f)
+        s = Stream(f)
+        bits = s.descs["bits"].astype(np.int64)
+        seen |= set(zip(((bits >> 22) & 7).tolist(), (bits >> 25).tolist()))
+    kinds = {k for k, _ in seen}
+    assert kinds == {0, 1, 2, 3, 4}, kinds
+    assert any(st > 1 for k, st in seen if k == 2) and any(st > 1 for k, st in seen if k == 4)
+
+
+def test_long_rows_are_shared_and_complete(tmp_path):
+    n = 30000
+    rng = np.random.RandomState(5)
+    rows = np.concatenate([np.full(20000, 7), np.full(9000, 11), np.arange(n)])
+    cols = np.concatenate([rng.choice(n, 20000, replace=False), rng.choice(n, 9000, replace=False), np.arange(n)])
+    a = sp.coo_matrix((rng.uniform(0.5, 1.5, rows.size), (rows, cols)), shape=(n, n)).tocsr()
+    a.sum_duplicates(); a.sort_indices()
+    csr = (a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data.copy(), n)
+    A = tune(csr, {}, host_only=True)
+    f = str(tmp_path / "m.spx")
+    A.save(f)
+    s = Stream(f)
+    assert len(s.shared) == 2 and s.n_carry == sum(int(x["n_slots"]) for x in s.shared)
+    r, c, v, b, m = dense_of(s)
+    assert abs(m.tocsr() - a).max() == 0
+    s.check_ownership()
