@@ -198,6 +198,10 @@ def cpu_baseline(csr, symmetric, budget_s=20.0):
         tried[t] = round(2.0 * nnz / sec / 1e9, 3)
         if best is None or sec < best[0]:
             best = (sec, kind, t, loops)
+        elif sec > 2.0 * best[0]:
+            # well past the knee (spinning threads sharing cores, or a CPU quota
+            # below the core count): larger counts only burn the time budget
+            break
     sec, kind, t, loops = best
     return {"value": round(2.0 * nnz / sec / 1e9, 3), "unit": "GFLOP/s", "cores": t,
             "kind": kind,

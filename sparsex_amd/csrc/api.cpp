@@ -330,7 +330,13 @@ static void emit_and_upload(spx_matrix_t *A)
             for (size_t r = 0; r < A->diag[i].size() && r < (size_t) b.nr_rows; ++r)
                 gs.dvalues[(size_t) b.row_start + r] = A->diag[i][r];
         }
-        gp.skip_empty = true;
+        // One process holding every partition writes each row exactly once:
+        // the diagonal term and beta*y go into the kernel's write-out.  A
+        // process with a slice produces a partial vector instead (rows it
+        // does not touch are zeroed by the init kernel) to be summed later.
+        gs.sym_fused = A->own_lo == 0 && A->own_hi == A->nrows;
+        if (gs.sym_fused) full.nr_rows = (size_t) A->nrows;
+        gp.skip_empty = !gs.sym_fused;
         emit_gpu(full, gp, gs);
     } else {
         for (size_t i = 0; i < nown; ++i) emit_gpu(A->parts[i], gp, gs);
@@ -797,6 +803,7 @@ spx_error_t spx_mat_save(const spx_matrix_t *A, const char *filename)
     h.nnz_stored = A->nnz_stored; h.n_unit_elems = A->n_unit_elems;
     h.n_delta_elems = A->n_delta_elems; h.n_units = A->n_units;
     h.n_carry = gs->n_carry;
+    h.pad = gs->sym_fused ? 1u : 0u;
     bool good = fwrite(kMagic, 1, 8, f) == 8 && fwrite(&h, sizeof(h), 1, f) == 1;
     std::vector<int32_t> bnd;
     for (const PartBounds &b : A->bounds) {
@@ -851,6 +858,7 @@ spx_matrix_t *spx_mat_restore(const char *filename)
         return SPX_INVALID_MAT;
     }
     gs->n_carry = h.n_carry;
+    gs->sym_fused = (h.pad & 1u) != 0;
     gs->nnz_stored = h.nnz_stored; gs->n_unit_elems = h.n_unit_elems;
     gs->n_delta_elems = h.n_delta_elems; gs->n_units = h.n_units;
     std::unique_ptr<matrix> A(new matrix);

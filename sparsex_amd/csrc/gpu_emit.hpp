@@ -27,6 +27,9 @@ struct GpuStream {
     // symmetric path: diagonal of the rows covered by the emitted partitions,
     // indexed by global row (zero elsewhere)
     std::vector<val_t> dvalues;
+    // symmetric path, whole matrix in this process: every row has a row-block
+    // and the diagonal term is added in the kernel's write-out (no init pass)
+    bool sym_fused = false;
     // accounting
     size_t nnz_stored = 0;        // nonzeros held in `values` (without padding)
     size_t n_unit_elems = 0;

@@ -48,6 +48,7 @@ struct KernelArgs {
     const double *x;
     double *y;
     double *carry;
+    const double *dvalues;   // symmetric, fused: diagonal added at the write-out (else null)
     double alpha, beta;
     uint32_t n_rb;
 };
@@ -297,13 +298,14 @@ void csx_spmv_kernel(KernelArgs a)
     // ---------------- write the owned rows ------------------------------------------------
     if (rb.flags & SPX_RB_SHARED) {
         if (threadIdx.x == 0) a.carry[rb.carry_slot] = tile[0];
-    } else if (a.beta == 0.0) {
-        for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS)
-            a.y[rb.row0 + i] = a.alpha * tile[i];
     } else {
         for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS) {
             const size_t g = (size_t) rb.row0 + i;
-            a.y[g] = a.alpha * tile[i] + a.beta * a.y[g];
+            double t = tile[i];
+            if (a.dvalues) t += a.dvalues[g] * a.x[g];
+            t *= a.alpha;
+            if (a.beta != 0.0) t += a.beta * a.y[g];
+            a.y[g] = t;
         }
     }
 }
@@ -311,12 +313,12 @@ void csx_spmv_kernel(KernelArgs a)
 // rows split over several row-blocks: sum their partials
 __global__ void csx_fixup_kernel(const SpxSharedRow *shared, uint32_t n_shared,
                                  const double *carry, double *y, double alpha,
-                                 double beta)
+                                 double beta, const double *dvalues, const double *x)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_shared) return;
     const SpxSharedRow sr = shared[i];
-    double s = 0.0;
+    double s = dvalues ? dvalues[sr.row] * x[sr.row] : 0.0;
     for (uint32_t k = 0; k < sr.n_slots; ++k) s += carry[sr.first_slot + k];
     y[sr.row] = (beta == 0.0) ? alpha * s : alpha * s + beta * y[sr.row];
 }
@@ -344,6 +346,7 @@ struct DeviceMatrix {
     int device = 0;
     size_t nrows = 0, ncols = 0;
     bool symmetric = false;
+    bool sym_fused = false;
     size_t own_lo = 0, own_hi = 0;
     uint32_t n_rb = 0, n_shared = 0, n_carry = 0;
     SpxRowBlock *rbs = nullptr;
@@ -396,6 +399,7 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
     m->nrows = nrows;
     m->ncols = ncols;
     m->symmetric = symmetric;
+    m->sym_fused = symmetric && s.sym_fused;
     m->own_lo = (size_t) own_lo;
     m->own_hi = (size_t) own_hi;
     m->n_rb = (uint32_t) s.rbs.size();
@@ -445,9 +449,10 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
     a.dmasks = m->dmasks;
     a.cidx = m->cidx; a.segrows = m->segrows; a.x = d_x; a.y = d_y;
     a.carry = m->carry; a.alpha = alpha; a.beta = beta; a.n_rb = m->n_rb;
+    a.dvalues = m->sym_fused ? m->dvalues : nullptr;
 
     uint32_t blocks = (m->n_rb + 7u) & ~7u;
-    if (m->symmetric) {
+    if (m->symmetric && !m->sym_fused) {
         // y <- beta*y + alpha*diag*x on the owned rows, 0 elsewhere; the
         // row-blocks (stored lower triangle and its mirror image) then
         // accumulate on top of that
@@ -461,7 +466,8 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
         hipLaunchKernelGGL(csx_spmv_kernel, dim3(blocks), dim3(BLOCK_THREADS), 0, stream, a);
     if (m->n_shared)
         hipLaunchKernelGGL(csx_fixup_kernel, dim3((m->n_shared + 63) / 64), dim3(64), 0,
-                           stream, m->shared, m->n_shared, m->carry, d_y, alpha, beta);
+                           stream, m->shared, m->n_shared, m->carry, d_y, alpha, beta,
+                           a.dvalues, d_x);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -500,6 +506,7 @@ void device_download(const DeviceMatrix *m, GpuStream &s)
     download(s.segrows, m->segrows, m->n_segrows);
     download(s.shared, m->shared, m->n_shared);
     s.n_carry = m->n_carry;
+    s.sym_fused = m->sym_fused;
     if (m->symmetric) download(s.dvalues, m->dvalues, m->nrows);
 }
 

@@ -28,7 +28,8 @@ class Stream:
         hdr = struct.unpack_from("<4i3Q2i4Q2I", buf, 8)
         (self.nrows, self.ncols, self.nnz, self.symmetric, self.nr_partitions, self.first_part,
          self.last_part, self.own_lo, self.own_hi, self.nnz_stored, self.n_unit_elems,
-         self.n_delta_elems, self.n_units, self.n_carry, _) = hdr
+         self.n_delta_elems, self.n_units, self.n_carry, flags) = hdr
+        self.sym_fused = bool(flags & 1)
         self.off = 8 + struct.calcsize("<4i3Q2i4Q2I")
         self.buf = buf
 

@@ -98,7 +98,10 @@ def test_symmetric_stream_is_lower_plus_mirror(tmp_path, name, gen, opts, remine
     off = a - sp.diags(a.diagonal())
     assert abs(m.tocsr() - off.tocsr()).max() == 0        # strict lower + strict upper
     assert np.array_equal(s.dvalues, a.diagonal())
-    s.check_ownership()
+    owner = s.check_ownership()
+    # the whole matrix in one process: every row has exactly one owner, whose
+    # write-out adds the diagonal term (no separate init pass)
+    assert s.sym_fused and owner[:n].sum() + len(s.shared) == n
     x = synth.random_x(n)
     assert np.allclose(s.matvec(x), a @ x, rtol=1e-12, atol=1e-14)
 

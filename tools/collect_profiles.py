@@ -25,7 +25,7 @@ for w in ("cant", "nd24k", "webbase"):
         if not os.path.exists(p):
             continue
         for line in open(p):
-            if line.startswith("csx_spmv_kernel"):
+            if "csx_spmv_kernel" in line:
                 kib[c] = float(re.search(r"per_launch=([0-9.]+)", line).group(1))
     if len(kib) == 2:
         traffic["syn-" + w] = {
