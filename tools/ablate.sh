@@ -1,20 +1,19 @@
 #!/bin/bash
-# quick ablations: prints us/step for several SPX_ABLATE masks (parity gate is skipped)
-for w in syn-cant syn-nd24k; do for m in 0 1 2 3; do
-SPX_ABLATE=$m python - $w $m <<'PY'
-import sys, time, numpy as np, torch
-sys.path.insert(0, '.')
-import bench, sparsex_amd as sx
-from sparsex_amd import synth
-w, m = sys.argv[1], sys.argv[2]
-csr = bench.make_workload(w, 1.0)
-A = bench.tune(csr, {"spx.rt.nr_threads": 8, "spx.gpu.rowblock_elems": 2048})
-n = csr[3]
-x = torch.from_numpy(synth.random_x(n)).cuda(); y = torch.zeros(n, dtype=torch.float64, device="cuda")
-st = torch.cuda.current_stream().cuda_stream
-for _ in range(50): A.hip_matvec_mult(0.5, x.data_ptr(), y.data_ptr(), st)
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(300): A.hip_matvec_mult(0.5, x.data_ptr(), y.data_ptr(), st)
-torch.cuda.synchronize(); print(w, "ablate", m, "us/step %.2f" % ((time.perf_counter() - t0) / 300 * 1e6))
-PY
-done; done
+# Where the kernel's time goes: launch-time (HIP events) of the full kernel and of
+# variants with parts compiled out (tools/build_variant.sh; results are wrong on
+# purpose, the parity gate is skipped and the lines are marked invalid).
+#   EMPTY     every workgroup returns at once: launch + dispatch floor
+#   NOPASS    row-block header, tile init, write-out; no passes
+#   VALSONLY  pass headers, descriptors and values streamed; no x, no LDS adds
+#   NOX       everything but the x gathers
+#   NOATOMIC  everything but the LDS adds
+cd "$(dirname "$0")/.."
+for w in ${WORKLOADS:-syn-cant syn-nd24k syn-webbase}; do
+  for v in FULL EMPTY NOPASS VALSONLY NOX NOATOMIC; do
+    if [ $v = FULL ]; then unset SPX_LIB_PATH; else export SPX_LIB_PATH=$PWD/sparsex_amd/lib/variants/libsparsex_$v.so; fi
+    SPX_BENCH_ABLATION=1 python bench.py --no-cpu-baseline --steps 400 --workload $w "$@" 2>&1 | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.readline())
+print('%-12s %-9s launch %7.2f us   step %7.2f us' % (d['config']['workload'][:11], '$v', d['roofline']['avg_launch_us'], d['ms_per_step'] * 1e3))"
+  done
+done
