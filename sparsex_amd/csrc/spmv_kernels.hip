@@ -500,10 +500,13 @@ void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x, double b
     if (!m->d_y) HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&m->d_y),
                                      (m->nrows ? m->nrows : 1) * sizeof(double)));
     HIP_CHECK(hipMemcpy(m->d_x, h_x, m->ncols * sizeof(double), hipMemcpyHostToDevice));
-    // rows outside this process' slice keep the caller's values
-    HIP_CHECK(hipMemcpy(m->d_y, h_y, m->nrows * sizeof(double), hipMemcpyHostToDevice));
+    // y travels to the device only when it is read: beta != 0, or this process
+    // owns a slice of the rows and the others must keep the caller's values
+    const bool whole = m->own_lo == 0 && m->own_hi == m->nrows && (!m->symmetric || m->sym_fused);
+    if (beta != 0.0 || !whole)
+        HIP_CHECK(hipMemcpy(m->d_y, h_y, m->nrows * sizeof(double), hipMemcpyHostToDevice));
     device_spmv(m, alpha, m->d_x, beta, m->d_y, nullptr);
-    HIP_CHECK(hipDeviceSynchronize());
+    // (the blocking copy below is ordered behind the kernels of the null stream)
     HIP_CHECK(hipMemcpy(h_y, m->d_y, m->nrows * sizeof(double), hipMemcpyDeviceToHost));
 }
 
