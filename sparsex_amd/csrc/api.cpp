@@ -482,7 +482,6 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     A->emit_params.max_rows = (size_t) std::max<long>(1, cfg.get_long("spx.gpu.rowblock_rows"));
     A->emit_params.sym_remine = cfg.get_bool("spx.gpu.sym_remine");
     A->emit_params.stack_segments = cfg.get_bool("spx.gpu.stack_segments");
-    A->emit_params.col_panel = (size_t) std::max<long>(0, cfg.get_long("spx.gpu.col_panel"));
     {
         idx_t lo = nown ? A->bounds[first].row_start : 0;
         idx_t hi = nown ? A->bounds[last - 1].row_start + A->bounds[last - 1].nr_rows : 0;
@@ -734,7 +733,7 @@ spx_error_t spx_mat_set_entry(spx_matrix_t *A, spx_index_t row, spx_index_t colu
 
 namespace {
 
-const char kMagic[8] = {'S', 'P', 'X', 'H', 'I', 'P', '0', '3'};
+const char kMagic[8] = {'S', 'P', 'X', 'H', 'I', 'P', '0', '4'};
 
 template <typename T>
 bool put_vec(FILE *f, const std::vector<T> &v)
@@ -815,7 +814,7 @@ spx_error_t spx_mat_save(const spx_matrix_t *A, const char *filename)
         bnd.push_back((int32_t) b.nnz);
     }
     good = good && put_vec(f, bnd) && put_vec(f, gs->rbs) && put_vec(f, gs->passes) &&
-           put_vec(f, gs->dmasks) && put_vec(f, gs->descs) && put_vec(f, gs->cidx) &&
+           put_vec(f, gs->descs) && put_vec(f, gs->cidx) &&
            put_vec(f, gs->segrows) && put_vec(f, gs->shared) && put_vec(f, gs->dvalues) &&
            put_vec(f, gs->values);
     std::vector<int32_t> perm;
@@ -850,7 +849,7 @@ spx_matrix_t *spx_mat_restore(const char *filename)
     std::vector<int32_t> bnd;
     bool good = fread(magic, 1, 8, f) == 8 && memcmp(magic, kMagic, 8) == 0 &&
                 fread(&h, sizeof(h), 1, f) == 1 && get_vec(f, bnd) && get_vec(f, gs->rbs) &&
-                get_vec(f, gs->passes) && get_vec(f, gs->dmasks) && get_vec(f, gs->descs) &&
+                get_vec(f, gs->passes) && get_vec(f, gs->descs) &&
                 get_vec(f, gs->cidx) && get_vec(f, gs->segrows) && get_vec(f, gs->shared) &&
                 get_vec(f, gs->dvalues) && get_vec(f, gs->values);
     std::vector<int32_t> perm;

@@ -45,7 +45,6 @@ void Config::reset_defaults()
     props_["spx.gpu.rowblock_rows"] = "512";   // max rows owned by one row-block
     props_["spx.gpu.stack_segments"] = "true"; // merge stacked row segments into block descriptors
     props_["spx.gpu.sym_remine"] = "true";     // symmetric: re-cut the mirrored triangle into row segments
-    props_["spx.gpu.col_panel"] = "0";         // columns per x panel for leftovers (0: off)
 }
 
 bool Config::set(const std::string &key, const std::string &value)

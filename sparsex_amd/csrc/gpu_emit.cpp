@@ -41,8 +41,8 @@ struct Group {
 
 class RbBuilder {
 public:
-    RbBuilder(const Partition &p, GpuStream &out, size_t col_panel = 0, bool stack = true)
-        : p_(p), out_(out), col_panel_(col_panel), stack_(stack) {}
+    RbBuilder(const Partition &p, GpuStream &out, bool stack = true)
+        : p_(p), out_(out), stack_(stack) {}
 
     // emits one row-block for rows [lo, hi) from the given pieces/singles
     void emit(idx_t lo, idx_t hi, const std::vector<Piece> &pieces,
@@ -64,11 +64,10 @@ private:
     void groups_from_piece(const Piece &pc, idx_t lo);
     void stack_groups();
     void emit_unit_passes(SpxRowBlock &rb);
-    void emit_delta_passes(SpxRowBlock &rb, std::vector<Single> &singles, idx_t lo);
+    void emit_gather_passes(SpxRowBlock &rb, std::vector<Single> &singles, idx_t lo);
 
     const Partition &p_;
     GpuStream &out_;
-    size_t col_panel_;
     bool stack_;
     std::vector<Group> groups_;
     std::vector<val_t> gvals_;
@@ -278,14 +277,15 @@ void RbBuilder::emit_unit_passes(SpxRowBlock &rb)
     flush(cur_w);
 }
 
-void RbBuilder::emit_delta_passes(SpxRowBlock &rb, std::vector<Single> &singles, idx_t lo)
+// Leftover nonzeros as row pieces: every row's leftovers are cut into pieces of
+// at most SPX_MAX_SEG_WIDTH nonzeros; a lane owns one piece (its values, its
+// column offsets) and adds ONE partial sum to the y tile -- no cross-lane
+// reduction, and lanes of a pass mostly hit different rows (same-address LDS
+// adds are serialised at ~3 clocks each).  Pieces are grouped by size so that a
+// pass is uniform, like the unit passes.
+void RbBuilder::emit_gather_passes(SpxRowBlock &rb, std::vector<Single> &singles, idx_t lo)
 {
-    const size_t panel = col_panel_;
-    std::sort(singles.begin(), singles.end(), [panel](const Single &x, const Single &y) {
-        if (panel) {
-            size_t px = (size_t) x.col / panel, py = (size_t) y.col / panel;
-            if (px != py) return px < py;
-        }
+    std::sort(singles.begin(), singles.end(), [](const Single &x, const Single &y) {
         return x.row < y.row || (x.row == y.row && x.col < y.col);
     });
     const size_t n = singles.size();
@@ -301,48 +301,57 @@ void RbBuilder::emit_delta_passes(SpxRowBlock &rb, std::vector<Single> &singles,
     }
     rb.cbase = (uint32_t) cmin;
     rb.cidx_width = ((size_t)(cmax - cmin) < 65536) ? 2 : 4;
-    uint32_t rowseg = 0;          // index of the current row segment
-    idx_t prev_row = -1;
-    const size_t PASS = (size_t) SPX_PASS_SEGS * SPX_DELTA_ROUNDS;
-    for (size_t b = 0; b < n; b += PASS) {
-        const size_t e = std::min(n, b + PASS);
+    struct Piece2 { uint32_t first; uint8_t width; };
+    std::vector<Piece2> pcs;
+    for (size_t i = 0; i < n;) {
+        size_t j = i;
+        while (j < n && singles[j].row == singles[i].row) ++j;
+        for (size_t k = i; k < j; k += SPX_MAX_SEG_WIDTH)
+            pcs.push_back(Piece2{(uint32_t) k, (uint8_t) std::min<size_t>(SPX_MAX_SEG_WIDTH, j - k)});
+        i = j;
+    }
+    std::stable_sort(pcs.begin(), pcs.end(),
+                     [](const Piece2 &a, const Piece2 &b) { return a.width < b.width; });
+    auto put_off = [&](size_t at, uint32_t off) {
+        if (rb.cidx_width == 2) {
+            uint16_t o = (uint16_t) off;
+            std::memcpy(&out_.cidx[rb.cidx_off + at * 2], &o, 2);
+        } else {
+            std::memcpy(&out_.cidx[rb.cidx_off + at * 4], &off, 4);
+        }
+    };
+    out_.cidx.resize(rb.cidx_off + n * rb.cidx_width, 0);
+    size_t elems_before = 0, pieces_before = 0;
+    for (size_t b = 0; b < pcs.size();) {
+        const uint32_t W = pcs[b].width;
+        size_t e = b;
+        while (e < pcs.size() && e - b < SPX_PASS_SEGS && pcs[e].width == W) ++e;
+        const size_t nseg = e - b;
         SpxPass ps;
         std::memset(&ps, 0, sizeof(ps));
         if (out_.values.size() % 2) out_.values.push_back(0.0);
         ps.val_off = (uint32_t)(out_.values.size() - rb.val_off);
-        ps.seg0 = (uint16_t) b;
-        ps.nseg = (uint8_t)(e - b - 1);
-        ps.width = 1;
-        ps.kind = SPX_PASS_DELTA;
-        ps.dmask_off = (uint32_t) out_.dmasks.size();
-        uint64_t mask_hi[3] = {0, 0, 0};
-        for (size_t i = b; i < e; ++i) {
-            const Single &s = singles[i];
-            if (s.row != prev_row) {
-                out_.segrows.push_back((uint16_t)(s.row - lo));
-                if (i > 0) ++rowseg;
-                if (i > b) {
-                    size_t k = i - b;
-                    if (k < 64) ps.mask |= 1ull << k;
-                    else mask_hi[k / 64 - 1] |= 1ull << (k % 64);
-                }
-                prev_row = s.row;
+        ps.seg0 = (uint16_t) pieces_before;
+        ps.nseg = (uint8_t) nseg;
+        ps.width = (uint8_t) W;
+        ps.kind = SPX_PASS_GATHER;
+        ps.elem0 = (uint32_t) elems_before;
+        const size_t base = out_.values.size();
+        out_.values.resize(base + nseg * W, 0.0);
+        for (size_t l = 0; l < nseg; ++l) {
+            const Piece2 &pc = pcs[b + l];
+            out_.segrows.push_back((uint16_t)(singles[pc.first].row - lo));
+            for (uint32_t w = 0; w < W; ++w) {
+                const Single &s = singles[pc.first + w];
+                out_.values[base + spx_pass_value_index((uint32_t) l, w, (uint32_t) nseg, W)] = s.val;
+                put_off(elems_before + (size_t) w * nseg + l, (uint32_t)(s.col - cmin));
             }
-            if (i == b) ps.rank0 = (uint16_t) rowseg;
-            uint32_t off = (uint32_t)(s.col - cmin);
-            if (rb.cidx_width == 2) {
-                uint16_t o = (uint16_t) off;
-                const uint8_t *bp = reinterpret_cast<const uint8_t *>(&o);
-                out_.cidx.insert(out_.cidx.end(), bp, bp + 2);
-            } else {
-                const uint8_t *bp = reinterpret_cast<const uint8_t *>(&off);
-                out_.cidx.insert(out_.cidx.end(), bp, bp + 4);
-            }
-            out_.values.push_back(s.val);
         }
-        out_.dmasks.insert(out_.dmasks.end(), mask_hi, mask_hi + 3);
         out_.passes.push_back(ps);
         ++rb.n_pass;
+        elems_before += nseg * W;
+        pieces_before += nseg;
+        b = e;
     }
 }
 
@@ -367,7 +376,7 @@ void RbBuilder::emit(idx_t lo, idx_t hi, const std::vector<Piece> &pieces,
     if (stack_) stack_groups();
     emit_unit_passes(rb);
     const size_t n_delta = singles.size();
-    emit_delta_passes(rb, singles, lo);
+    emit_gather_passes(rb, singles, lo);
     // keep whole-lane over-reads of the last pass inside the arrays
     for (size_t i = 0; i < 16; ++i) out_.cidx.push_back(0);
     pad_to(out_.values, 2);
@@ -624,7 +633,7 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out)
     }
 
     // 4. emit
-    RbBuilder bld(p, out, prm.col_panel, prm.stack_segments);
+    RbBuilder bld(p, out, prm.stack_segments);
     for (size_t i = 0; i < plans.size(); ++i) {
         const Plan &pl = plans[i];
         if (prm.skip_empty && pieces[i].empty() && singles[i].empty()) continue;

@@ -18,7 +18,6 @@ struct GpuStream {
     std::vector<val_t> values;
     std::vector<SpxUnitDesc> descs;
     std::vector<SpxPass> passes;
-    std::vector<uint64_t> dmasks;     // 3 words per delta pass
     std::vector<uint8_t> cidx;
     std::vector<uint16_t> segrows;
     std::vector<SpxRowBlock> rbs;
@@ -38,8 +37,7 @@ struct GpuStream {
 
     size_t index_bytes() const
     {
-        return descs.size() * sizeof(SpxUnitDesc) + passes.size() * sizeof(SpxPass) + dmasks.size() * 8 +
-               cidx.size() +
+        return descs.size() * sizeof(SpxUnitDesc) + passes.size() * sizeof(SpxPass) + cidx.size() +
                segrows.size() * 2 + rbs.size() * sizeof(SpxRowBlock);
     }
 };
@@ -51,8 +49,6 @@ struct GpuEmitParams {
     bool stack_segments = true;   // spx.gpu.stack_segments: equal row segments of consecutive
                                   // rows share one descriptor as a dense block
     bool sym_remine = true;       // spx.gpu.sym_remine (see append_sym_expanded)
-    size_t col_panel = 0;         // > 0: leftover nonzeros are visited panel by panel of
-                                  // this many columns (keeps the x slice in L2)
 };
 
 // Appends the row-blocks of partition `p` (horizontal order) to `out`.

@@ -28,9 +28,11 @@
  * adds ONE partial sum to the row-block's y tile in LDS.  Segment-start bits
  * (one 64-bit mask per pass) tell a lane which descriptor it belongs to.
  *
- * The leftover nonzeros (CSX delta units) form *delta passes*: up to 256
- * nonzeros, four per lane, row-major, with a u16/u32 column offset per
- * nonzero (relative to cbase) and one u16 row per row change.
+ * The leftover nonzeros (CSX delta units) form *gather passes*: every row's
+ * leftovers are cut into pieces of at most SPX_MAX_SEG_WIDTH nonzeros; a lane
+ * owns one piece -- W values, W u16/u32 column offsets (relative to cbase,
+ * element-major [W][nseg]), one u16 row -- and adds one partial sum, exactly
+ * like a unit pass whose columns are not consecutive.
  */
 #ifndef SPX_GPU_FORMAT_H
 #define SPX_GPU_FORMAT_H
@@ -42,11 +44,12 @@
 #define SPX_MAX_SEG_WIDTH  8      /* columns per row segment                      */
 #define SPX_HORIZ_CHUNK    8      /* horizontal units are cut into such chunks   */
 #define SPX_PASS_SEGS      64     /* row segments (lanes) per unit pass           */
-#define SPX_DELTA_ROUNDS   4      /* a delta pass is up to 4 x 64 nonzeros: lane l
-                                     owns nonzeros l, l+64, l+128, l+192          */
 
 #define SPX_PASS_UNIT   0
-#define SPX_PASS_DELTA  1
+#define SPX_PASS_GATHER 2    /* leftover nonzeros as row pieces: lane l owns up to
+                                SPX_MAX_SEG_WIDTH nonzeros of ONE row with explicit
+                                column offsets; values interleaved like a unit
+                                pass, offsets element-major [W][nseg]             */
 
 #define SPX_KIND_BLOCK  0u   /* rows of a dense block: drow 1, dcol 0             */
 #define SPX_KIND_HORIZ  1u   /* same row, column step `step`                      */
@@ -69,30 +72,28 @@ static inline uint32_t spx_desc_bits(uint32_t row0, uint32_t sstart, uint32_t ki
 }
 
 typedef struct {
-    uint64_t mask;       /* bit l: lane l's segment starts a new unit (unit
-                            pass) / a new row (delta pass, first 64 nonzeros);
+    uint64_t mask;       /* unit pass, bit l: lane l's segment starts a new unit;
                             bit 0 is never set                                  */
     uint32_t val_off;    /* first value of the pass, relative to the row-block  */
-    uint16_t rank0;      /* unit pass: descriptor of lane 0's segment
-                            delta pass: row-segment index of lane 0's nonzero   */
+    uint16_t rank0;      /* unit pass: descriptor of lane 0's segment           */
     uint16_t seg0;       /* unit pass: segments in front of lane 0
-                            delta pass: nonzeros of the delta region in front   */
-    uint8_t  nseg;       /* unit pass: active lanes, 1..64
-                            delta pass: nonzeros - 1 (0..255)                    */
-    uint8_t  width;      /* W: columns per segment (1 for delta passes)          */
-    uint8_t  kind;       /* SPX_PASS_UNIT / SPX_PASS_DELTA                       */
+                            gather pass: row pieces in front (index into the
+                            row-block's u16 rows at seg_off)                     */
+    uint8_t  nseg;       /* active lanes, 1..64                                  */
+    uint8_t  width;      /* W: nonzeros per lane                                 */
+    uint8_t  kind;       /* SPX_PASS_UNIT / SPX_PASS_GATHER                      */
     uint8_t  pad_;
-    uint32_t dmask_off;  /* delta pass: index into dmasks[] of the three masks
-                            holding the row-start bits of nonzeros 64..255       */
+    uint32_t elem0;      /* gather pass: leftover nonzeros of the row-block in
+                            front of this pass (index of its first column offset) */
 } SpxPass;               /* 24 bytes */
 
 typedef struct {
     uint64_t val_off;     /* first value of the row-block in values[]          */
     uint32_t pass_off;    /* first SpxPass                                      */
     uint32_t desc_off;    /* first SpxUnitDesc                                  */
-    uint32_t cidx_off;    /* byte offset of the delta nonzeros' column offsets  */
-    uint32_t seg_off;     /* first u16 row of the delta row segments            */
-    uint32_t cbase;       /* column base of the delta nonzeros                  */
+    uint32_t cidx_off;    /* byte offset of the leftovers' column offsets       */
+    uint32_t seg_off;     /* first u16 row of the leftover row pieces           */
+    uint32_t cbase;       /* column base of the leftovers                       */
     uint32_t row0;        /* first row owned (global)                           */
     uint16_t n_rows;      /* rows owned                                         */
     uint16_t n_pass;

@@ -6,8 +6,9 @@
 // ranked with mbcnt to find each lane's unit descriptor, strided decode of
 // (row, first column), x gathered through L2, W fused multiply-adds per lane,
 // one LDS add per lane into the row-block's y tile, and one coalesced write
-// of the owned rows of y.  Leftover nonzeros run as delta passes (one nonzero
-// per lane, segmented wave scan for long rows).
+// of the owned rows of y.  Leftover nonzeros (CSX delta units) run through the
+// same code as gather passes: a lane owns up to 8 leftovers of one row, each
+// with its own column offset.
 //
 // Semantics restated from the reference's SpMV templates
 // (src/templates/csx_spmv_tmpl.c:66-101 and the per-unit bodies
@@ -40,7 +41,6 @@ namespace spx {
 struct KernelArgs {
     const SpxRowBlock *rbs;
     const SpxPass *passes;
-    const uint64_t *dmasks;
     const double *values;
     const SpxUnitDesc *descs;
     const uint8_t *cidx;
@@ -71,20 +71,40 @@ __device__ __forceinline__ uint32_t starts_upto(uint64_t mask, int lane)
 // consecutive columns in each of them.  All descriptor loads go out first,
 // then all value loads, then the x gathers: one memory round trip per stage
 // for the whole batch instead of one per pass.
-template <int W, int B>
+//
+// G (gather pass): the lane's segment is a piece of one row's leftover
+// nonzeros; its row comes from the row-block's u16 rows and every nonzero has
+// its own column offset (element-major [W][nseg]) instead of a descriptor.
+template <int W, int B, bool G>
 __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlock &rb,
                                             const SpxPass (&ps)[B], double *tile, int lane)
 {
     bool active[B];
     uint32_t l[B], nseg[B];
     uint2 q[B];
+    uint32_t goff[B][G ? W : 1];
 #pragma unroll
     for (int b = 0; b < B; ++b) {
         nseg[b] = ps[b].nseg;
         active[b] = (uint32_t) lane < nseg[b];
         l[b] = active[b] ? (uint32_t) lane : 0u;         // idle lanes shadow lane 0
-        const uint32_t rank = (uint32_t) ps[b].rank0 + (active[b] ? starts_upto(ps[b].mask, lane) : 0u);
-        q[b] = *reinterpret_cast<const uint2 *>(a.descs + rb.desc_off + rank);
+        if (G) {
+            q[b].x = a.segrows[rb.seg_off + ps[b].seg0 + l[b]];
+            const uint8_t *cidx = a.cidx + rb.cidx_off;
+            const uint32_t e0 = ps[b].elem0 + l[b];
+            if (rb.cidx_width == 4) {
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                    goff[b][w] = reinterpret_cast<const uint32_t *>(cidx)[e0 + (uint32_t) w * nseg[b]];
+            } else {
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                    goff[b][w] = reinterpret_cast<const uint16_t *>(cidx)[e0 + (uint32_t) w * nseg[b]];
+            }
+        } else {
+            const uint32_t rank = (uint32_t) ps[b].rank0 + (active[b] ? starts_upto(ps[b].mask, lane) : 0u);
+            q[b] = *reinterpret_cast<const uint2 *>(a.descs + rb.desc_off + rank);
+        }
     }
     double2 v2[B][W / 2 > 0 ? W / 2 : 1];
     double v1[B];
@@ -114,25 +134,38 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
     double acc[B];
 #pragma unroll
     for (int b = 0; b < B; ++b) {
-        // segment index inside its unit, then its row / first column
-        const uint32_t bits = q[b].y;
-        const int s = (int) ((ps[b].seg0 + l[b] - ((bits >> 9) & 8191u)) & 0xffffu);
-        const uint32_t kind = (bits >> 22) & 7u;
-        const int step = (int) (bits >> 25);
-        const int drow = kind == SPX_KIND_BLOCK ? 1 : (kind >= SPX_KIND_VERT ? step : 0);
-        const int dcol = (kind == SPX_KIND_HORIZ || kind == SPX_KIND_DIAG)
-                             ? step : (kind == SPX_KIND_ADIAG ? -step : 0);
-        row[b] = (int) (bits & 511u) + s * drow;
-        const uint32_t col = q[b].x + (uint32_t) (s * dcol);
-        const double *xp = a.x + col;
         double x[W];
+        if (G) {
+            row[b] = (int) q[b].x;
+            const double *xp = a.x + rb.cbase;
 #pragma unroll
-        for (int w = 0; w < W; ++w) {
+            for (int w = 0; w < W; ++w) {
 #ifdef SPX_ABL_NOX
-            x[w] = (double) col;
+                x[w] = (double) goff[b][w];
 #else
-            x[w] = xp[w];
+                x[w] = xp[goff[b][w]];
 #endif
+            }
+        } else {
+            // segment index inside its unit, then its row / first column
+            const uint32_t bits = q[b].y;
+            const int s = (int) ((ps[b].seg0 + l[b] - ((bits >> 9) & 8191u)) & 0xffffu);
+            const uint32_t kind = (bits >> 22) & 7u;
+            const int step = (int) (bits >> 25);
+            const int drow = kind == SPX_KIND_BLOCK ? 1 : (kind >= SPX_KIND_VERT ? step : 0);
+            const int dcol = (kind == SPX_KIND_HORIZ || kind == SPX_KIND_DIAG)
+                                 ? step : (kind == SPX_KIND_ADIAG ? -step : 0);
+            row[b] = (int) (bits & 511u) + s * drow;
+            const uint32_t col = q[b].x + (uint32_t) (s * dcol);
+            const double *xp = a.x + col;
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+#ifdef SPX_ABL_NOX
+                x[w] = (double) col;
+#else
+                x[w] = xp[w];
+#endif
+            }
         }
         double t = 0.0;
 #pragma unroll
@@ -148,112 +181,42 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
     for (int b = 0; b < B; ++b)
         if (active[b] && acc[b] == 1.2345) tile[row[b]] = acc[b];
 #else
+    if (G && rb.n_rows == 1) {
+        // a chunk of one over-long row: every lane targets tile[0]
+        double t = 0.0;
+#pragma unroll
+        for (int b = 0; b < B; ++b) t += active[b] ? acc[b] : 0.0;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) t += __shfl_xor(t, d);
+        if (lane == 0) atomicAdd(&tile[0], t);
+        return;
+    }
 #pragma unroll
     for (int b = 0; b < B; ++b)
         if (active[b]) atomicAdd(&tile[row[b]], acc[b]);
 #endif
 }
 
-// A delta pass: up to 4 x 64 leftover nonzeros in row-major order; lane l
-// owns nonzeros l, l+64, l+128, l+192 (every load of the wavefront is one
-// contiguous block).  Row changes are marked in a 256-bit mask.
-__device__ __forceinline__ void delta_pass(const KernelArgs &a, const SpxRowBlock &rb,
-                                           const SpxPass &ps, double *tile, int lane)
-{
-    const uint32_t n = (uint32_t) ps.nseg + 1u;
-    const uint8_t *cidx = a.cidx + rb.cidx_off;
-    const double *vals = a.values + rb.val_off + ps.val_off;
-    const uint64_t *mh = a.dmasks + ps.dmask_off;
-    const uint64_t masks[SPX_DELTA_ROUNDS] = {ps.mask, mh[0], mh[1], mh[2]};
-    bool active[SPX_DELTA_ROUNDS];
-    int row[SPX_DELTA_ROUNDS];
-    uint32_t off[SPX_DELTA_ROUNDS];
-    double v[SPX_DELTA_ROUNDS];
-    uint32_t before = ps.rank0;           // row segments in front of this round
-#pragma unroll
-    for (int k = 0; k < SPX_DELTA_ROUNDS; ++k) {
-        const uint32_t i = (uint32_t) (k * 64 + lane);
-        active[k] = i < n;
-        const uint32_t ii = active[k] ? i : 0u;
-        const uint32_t rank = before + (active[k] ? starts_upto(masks[k], lane) : 0u);
-        before += (uint32_t) __popcll(masks[k]);
-        row[k] = a.segrows[rb.seg_off + (active[k] ? rank : (uint32_t) ps.rank0)];
-        const uint32_t e = (uint32_t) ps.seg0 + ii;
-        off[k] = (rb.cidx_width == 4) ? reinterpret_cast<const uint32_t *>(cidx)[e]
-                                      : reinterpret_cast<const uint16_t *>(cidx)[e];
-        v[k] = vals[ii];
-    }
-    double acc[SPX_DELTA_ROUNDS];
-#pragma unroll
-    for (int k = 0; k < SPX_DELTA_ROUNDS; ++k) {
-        const uint32_t col = rb.cbase + off[k];
-#if defined(SPX_ABL_NOX) || defined(SPX_ABL_VALSONLY)
-        acc[k] = active[k] ? v[k] * (double) col : 0.0;
-#else
-        acc[k] = active[k] ? v[k] * a.x[col] : 0.0;
-#endif
-    }
-#ifdef SPX_ABL_VALSONLY
-    if (acc[0] + acc[1] + acc[2] + acc[3] + (double) row[0] + (double) row[1] + (double) row[2] + (double) row[3] == 1.2345)
-        tile[0] = acc[0];
-    return;
-#endif
-    // long rows: merge the lanes of a row with a segmented wave scan first
-    const int n_rowsegs = __popcll(masks[0]) + __popcll(masks[1]) + __popcll(masks[2]) +
-                          __popcll(masks[3]) + 1;
-#ifdef SPX_ABL_NOSCAN
-    const bool long_rows = false;
-#else
-    const bool long_rows = (int) n - n_rowsegs >= (int) n / 4 + 8;
-#endif
-#pragma unroll
-    for (int k = 0; k < SPX_DELTA_ROUNDS; ++k) {
-        if ((uint32_t) (k * 64) >= n) break;       // wave-uniform
-        bool adds = active[k];
-        double t = acc[k];
-        if (long_rows) {
-            int head = (lane == 0) || ((masks[k] >> lane) & 1ull) || !active[k];
-            const int head0 = head;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const double a2 = __shfl_up(t, d);
-                const int h2 = __shfl_up(head, d);
-                if (lane >= d && !head) {
-                    t += a2;
-                    head |= h2;
-                }
-            }
-            const int next_head = __shfl_down(head0, 1);
-            adds = active[k] && (lane == 63 || next_head);
-        }
-#ifdef SPX_ABL_NOATOMIC
-        if (adds && t == 1.2345) tile[row[k]] = t;
-#else
-        if (adds) atomicAdd(&tile[row[k]], t);
-#endif
-    }
-}
-
-template <int B>
+template <int B, bool G>
 __device__ __forceinline__ void run_units(const KernelArgs &a, const SpxRowBlock &rb,
                                           const SpxPass (&ps)[B], double *tile, int lane)
 {
     switch (ps[0].width) {         // wave-uniform
-    case 1: unit_passes<1, B>(a, rb, ps, tile, lane); break;
-    case 2: unit_passes<2, B>(a, rb, ps, tile, lane); break;
-    case 3: unit_passes<3, B>(a, rb, ps, tile, lane); break;
-    case 4: unit_passes<4, B>(a, rb, ps, tile, lane); break;
-    case 5: unit_passes<5, 1>(a, rb, {ps[0]}, tile, lane);
-            if (B > 1) unit_passes<5, 1>(a, rb, {ps[B - 1]}, tile, lane);
+    case 1: unit_passes<1, B, G>(a, rb, ps, tile, lane); break;
+    case 2: unit_passes<2, B, G>(a, rb, ps, tile, lane); break;
+    case 3: unit_passes<3, B, G>(a, rb, ps, tile, lane); break;
+    case 4: unit_passes<4, B, G>(a, rb, ps, tile, lane); break;
+    case 5: unit_passes<5, 1, G>(a, rb, {ps[0]}, tile, lane);
+            if (B > 1) unit_passes<5, 1, G>(a, rb, {ps[B - 1]}, tile, lane);
             break;
-    case 6: unit_passes<6, 1>(a, rb, {ps[0]}, tile, lane);
-            if (B > 1) unit_passes<6, 1>(a, rb, {ps[B - 1]}, tile, lane);
+    case 6: unit_passes<6, 1, G>(a, rb, {ps[0]}, tile, lane);
+            if (B > 1) unit_passes<6, 1, G>(a, rb, {ps[B - 1]}, tile, lane);
             break;
-    case 7: unit_passes<7, 1>(a, rb, {ps[0]}, tile, lane);
-            if (B > 1) unit_passes<7, 1>(a, rb, {ps[B - 1]}, tile, lane);
+    case 7: unit_passes<7, 1, G>(a, rb, {ps[0]}, tile, lane);
+            if (B > 1) unit_passes<7, 1, G>(a, rb, {ps[B - 1]}, tile, lane);
             break;
-    default: unit_passes<8, 1>(a, rb, {ps[0]}, tile, lane);
-            if (B > 1) unit_passes<8, 1>(a, rb, {ps[B - 1]}, tile, lane);
+    default: unit_passes<8, 1, G>(a, rb, {ps[0]}, tile, lane);
+            if (B > 1) unit_passes<8, 1, G>(a, rb, {ps[B - 1]}, tile, lane);
             break;
     }
 }
@@ -261,8 +224,8 @@ __device__ __forceinline__ void run_units(const KernelArgs &a, const SpxRowBlock
 __device__ __forceinline__ void run_pass(const KernelArgs &a, const SpxRowBlock &rb,
                                          const SpxPass &ps, double *tile, int lane)
 {
-    if (ps.kind == SPX_PASS_DELTA) delta_pass(a, rb, ps, tile, lane);
-    else run_units<1>(a, rb, {ps}, tile, lane);
+    if (ps.kind == SPX_PASS_GATHER) run_units<1, true>(a, rb, {ps}, tile, lane);
+    else run_units<1, false>(a, rb, {ps}, tile, lane);
 }
 
 // One workgroup owns one row-block; its wavefronts take the passes in turn
@@ -303,8 +266,9 @@ void csx_spmv_kernel(KernelArgs a)
         const int t1 = t + WAVES_PER_BLOCK;
         if (t1 < n_pass) {
             const SpxPass p1 = passes[t1];
-            if (p0.kind == SPX_PASS_UNIT && p1.kind == SPX_PASS_UNIT && p0.width == p1.width) {
-                run_units<2>(a, rb, {p0, p1}, tile, lane);
+            if (p0.kind == p1.kind && p0.width == p1.width) {
+                if (p0.kind == SPX_PASS_GATHER) run_units<2, true>(a, rb, {p0, p1}, tile, lane);
+                else run_units<2, false>(a, rb, {p0, p1}, tile, lane);
             } else {
                 run_pass(a, rb, p0, tile, lane);
                 run_pass(a, rb, p1, tile, lane);
@@ -373,7 +337,6 @@ struct DeviceMatrix {
     double *values = nullptr;
     SpxUnitDesc *descs = nullptr;
     SpxPass *passes = nullptr;
-    uint64_t *dmasks = nullptr;
     uint8_t *cidx = nullptr;
     uint16_t *segrows = nullptr;
     SpxSharedRow *shared = nullptr;
@@ -382,7 +345,7 @@ struct DeviceMatrix {
     // staging vectors of the host-pointer path
     double *d_x = nullptr, *d_y = nullptr;
     size_t value_bytes = 0, index_bytes = 0;
-    size_t n_values = 0, n_descs = 0, n_passes = 0, n_dmasks = 0, n_cidx = 0, n_segrows = 0;
+    size_t n_values = 0, n_descs = 0, n_passes = 0, n_cidx = 0, n_segrows = 0;
 };
 
 int device_count()
@@ -429,7 +392,6 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
     m->values = upload(s.values, 160);
     m->descs = upload(s.descs, 8);
     m->passes = upload(s.passes, 1);
-    m->dmasks = upload(s.dmasks, 4);
     m->cidx = upload(s.cidx, 64);
     m->segrows = upload(s.segrows, 80);
     m->shared = upload(s.shared);
@@ -441,7 +403,7 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
         m->dvalues = upload(dv);
     }
     m->n_values = s.values.size(); m->n_descs = s.descs.size(); m->n_passes = s.passes.size();
-    m->n_dmasks = s.dmasks.size(); m->n_cidx = s.cidx.size(); m->n_segrows = s.segrows.size();
+    m->n_cidx = s.cidx.size(); m->n_segrows = s.segrows.size();
     m->value_bytes = s.values.size() * sizeof(double);
     m->index_bytes = s.index_bytes();
     return m;
@@ -451,7 +413,7 @@ void device_free(DeviceMatrix *m)
 {
     if (!m) return;
     (void) hipFree(m->rbs); (void) hipFree(m->values); (void) hipFree(m->descs);
-    (void) hipFree(m->passes); (void) hipFree(m->dmasks);
+    (void) hipFree(m->passes);
     (void) hipFree(m->cidx); (void) hipFree(m->segrows); (void) hipFree(m->shared);
     (void) hipFree(m->carry);
     if (m->dvalues) (void) hipFree(m->dvalues);
@@ -466,7 +428,6 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     KernelArgs a;
     a.rbs = m->rbs; a.values = m->values; a.descs = m->descs; a.passes = m->passes;
-    a.dmasks = m->dmasks;
     a.cidx = m->cidx; a.segrows = m->segrows; a.x = d_x; a.y = d_y;
     a.carry = m->carry; a.alpha = alpha; a.beta = beta; a.n_rb = m->n_rb;
     a.dvalues = m->sym_fused ? m->dvalues : nullptr;
@@ -524,7 +485,6 @@ void device_download(const DeviceMatrix *m, GpuStream &s)
     download(s.values, m->values, m->n_values);
     download(s.descs, m->descs, m->n_descs);
     download(s.passes, m->passes, m->n_passes);
-    download(s.dmasks, m->dmasks, m->n_dmasks);
     download(s.cidx, m->cidx, m->n_cidx);
     download(s.segrows, m->segrows, m->n_segrows);
     download(s.shared, m->shared, m->n_shared);

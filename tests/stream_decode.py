@@ -12,7 +12,7 @@ RB = np.dtype([("val_off", "<u8"), ("pass_off", "<u4"), ("desc_off", "<u4"), ("c
                ("n_pass", "<u2"), ("cidx_width", "u1"), ("flags", "u1"), ("pad", "<u2"),
                ("carry_slot", "<u4"), ("pad2", "<u4")])
 PASS = np.dtype([("mask", "<u8"), ("val_off", "<u4"), ("rank0", "<u2"), ("seg0", "<u2"),
-                 ("nseg", "u1"), ("width", "u1"), ("kind", "u1"), ("pad", "u1"), ("dmask_off", "<u4")])
+                 ("nseg", "u1"), ("width", "u1"), ("kind", "u1"), ("pad", "u1"), ("elem0", "<u4")])
 DESC = np.dtype([("col0", "<u4"), ("bits", "<u4")])
 SHARED = np.dtype([("row", "<u4"), ("first_slot", "<u4"), ("n_slots", "<u4")])
 assert RB.itemsize == 48 and PASS.itemsize == 24 and DESC.itemsize == 8
@@ -24,7 +24,7 @@ class Stream:
     def __init__(self, path):
         with open(path, "rb") as f:
             buf = f.read()
-        assert buf[:8] == b"SPXHIP03", buf[:8]
+        assert buf[:8] == b"SPXHIP04", buf[:8]
         hdr = struct.unpack_from("<4i3Q2i4Q2I", buf, 8)
         (self.nrows, self.ncols, self.nnz, self.symmetric, self.nr_partitions, self.first_part,
          self.last_part, self.own_lo, self.own_hi, self.nnz_stored, self.n_unit_elems,
@@ -42,7 +42,6 @@ class Stream:
         self.bounds = vec("<i4").reshape(-1, 3)
         self.rbs = vec(RB)
         self.passes = vec(PASS)
-        self.dmasks = vec("<u8")
         self.descs = vec(DESC)
         self.cidx = vec("u1")
         self.segrows = vec("<u2")
@@ -84,24 +83,28 @@ class Stream:
                             idx = pair * 2 * nseg + lanes * 2 + (w & 1)
                         R.append(row + int(rb["row0"])); Cc.append(col + w)
                         V.append(self.values[pv + idx]); B.append(np.full(nseg, bi))
-                else:
-                    cnt = int(ps["nseg"]) + 1
-                    k = np.arange(cnt)
-                    m = [int(ps["mask"])] + [int(x) for x in self.dmasks[int(ps["dmask_off"]):int(ps["dmask_off"]) + 3]]
-                    starts = np.array([(m[i >> 6] >> (i & 63)) & 1 for i in range(cnt)])
-                    assert starts[0] == 0
-                    seg = int(ps["rank0"]) + np.cumsum(starts)
-                    row = self.segrows[int(rb["seg_off"]) + seg].astype(np.int64)
+                elif ps["kind"] == 2:
+                    # gather pass: lane l owns W leftover nonzeros of one row
+                    nseg, W = int(ps["nseg"]), int(ps["width"])
+                    assert 1 <= nseg <= 64 and 1 <= W <= 8
+                    lanes = np.arange(nseg)
+                    row = self.segrows[int(rb["seg_off"]) + int(ps["seg0"]) + lanes].astype(np.int64)
                     assert (row < int(rb["n_rows"])).all()
                     cw = int(rb["cidx_width"])
-                    o = int(rb["cidx_off"]) + (int(ps["seg0"]) + k) * cw
                     assert int(rb["cidx_off"]) % 16 == 0
-                    if cw == 2:
-                        off = self.cidx[o].astype(np.int64) | (self.cidx[o + 1].astype(np.int64) << 8)
-                    else:
-                        off = sum(self.cidx[o + b].astype(np.int64) << (8 * b) for b in range(4))
-                    R.append(row + int(rb["row0"])); Cc.append(off + int(rb["cbase"]))
-                    V.append(self.values[pv + k]); B.append(np.full(cnt, bi))
+                    e0 = int(ps["elem0"])
+                    for w in range(W):
+                        pair = w >> 1
+                        if (W & 1) and w == W - 1:
+                            idx = pair * 2 * nseg + lanes
+                        else:
+                            idx = pair * 2 * nseg + lanes * 2 + (w & 1)
+                        o = int(rb["cidx_off"]) + (e0 + w * nseg + lanes) * cw
+                        off = sum(self.cidx[o + b].astype(np.int64) << (8 * b) for b in range(cw))
+                        R.append(row + int(rb["row0"])); Cc.append(off + int(rb["cbase"]))
+                        V.append(self.values[pv + idx]); B.append(np.full(nseg, bi))
+                else:
+                    raise AssertionError("unknown pass kind %d" % int(ps["kind"]))
         if not R:
             z = np.zeros(0, dtype=np.int64)
             return z, z, np.zeros(0), z

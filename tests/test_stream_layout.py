@@ -48,7 +48,8 @@ CASES = [
     ("nd24k", lambda: synth.syn_nd24k(0.02), {"spx.preproc.sampling": "none"}),
     ("nd24k-nostack", lambda: synth.syn_nd24k(0.02), {"spx.preproc.sampling": "none", "spx.gpu.stack_segments": "false"}),
     ("webbase", lambda: synth.syn_webbase(0.01), {}),
-    ("webbase-panel", lambda: synth.syn_webbase(0.01), {"spx.gpu.col_panel": "2048"}),
+    ("webbase-wide", lambda: synth.syn_webbase(0.08), {}),            # u32 column offsets
+    ("webbase-tiny-rb", lambda: synth.syn_webbase(0.01), {"spx.gpu.rowblock_elems": "100", "spx.gpu.rowblock_rows": "11"}),
     ("nlpkkt", lambda: synth.syn_nlpkkt(7), {"spx.preproc.sampling": "none", "spx.rt.nr_threads": "2"}),
     ("all-types", lambda: synth.syn_nlpkkt(6), {"spx.preproc.xform": "all", "spx.preproc.sampling": "none"}),
 ]
