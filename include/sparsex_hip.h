@@ -15,8 +15,15 @@
  *   spx.rt.device           HIP device ordinal (default: current device)
  *   spx.rt.gpu_rank/world   this process owns partitions
  *                           [rank*P/world, (rank+1)*P/world), P = spx.rt.nr_threads
- *   spx.gpu.rowblock_elems  target nonzeros per row-block (default 2048)
+ *   spx.gpu.rowblock_elems  target nonzeros per row-block (default 0 = auto:
+ *                           nnz/1280 clamped to [1024, 4096]; 8192 beyond 64 M)
  *   spx.gpu.rowblock_rows   max rows per row-block (default and cap 512)
+ *   spx.gpu.stack_segments  "false": one descriptor per CSX unit piece instead
+ *                           of merging equal row segments of consecutive rows
+ *   spx.gpu.sym_remine      "false": symmetric path mirrors unit by unit
+ *                           instead of re-cutting the upper triangle
+ *   spx.rt.keep_encoded     "false": drop the encoded partitions after the
+ *                           upload (no get/set entry, no CSX export)
  *   spx.matrix.onedim_blocks  "true" enables br1/bc1 (MatrixOneDimBlocks,
  *                           no mnemonic in the reference: Runtime.cpp:60)
  */
@@ -35,7 +42,8 @@ extern "C" {
  * spx_matvec_mult / spx_matvec_kernel (reference src/api/matvec.c:551-620).
  * x_dev: ncols doubles, y_dev: nrows doubles, both HBM pointers on the
  * matrix's device.  `stream` is a hipStream_t (NULL = default stream); the
- * call only enqueues work.  With several processes (spx.rt.gpu_world > 1)
+ * call only enqueues work (so loops of these calls can be captured into a
+ * hipGraph by stream capture).  With several processes (spx.rt.gpu_world > 1)
  * only the rows of this process' partitions are written on the general path;
  * on the symmetric path y_dev receives this process' partial vector, to be
  * summed over processes by the caller (RCCL all-reduce).

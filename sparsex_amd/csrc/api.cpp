@@ -344,6 +344,7 @@ static void emit_and_upload(spx_matrix_t *A)
     } else {
         for (size_t i = 0; i < nown; ++i) emit_gpu(A->parts[i], gp, gs);
     }
+    finalize_stream(gs);
     A->nnz_stored = gs.nnz_stored;
     A->n_unit_elems = gs.n_unit_elems;
     A->n_delta_elems = gs.n_delta_elems;
@@ -733,7 +734,7 @@ spx_error_t spx_mat_set_entry(spx_matrix_t *A, spx_index_t row, spx_index_t colu
 
 namespace {
 
-const char kMagic[8] = {'S', 'P', 'X', 'H', 'I', 'P', '0', '4'};
+const char kMagic[8] = {'S', 'P', 'X', 'H', 'I', 'P', '0', '5'};
 
 template <typename T>
 bool put_vec(FILE *f, const std::vector<T> &v)
@@ -805,7 +806,7 @@ spx_error_t spx_mat_save(const spx_matrix_t *A, const char *filename)
     h.nnz_stored = A->nnz_stored; h.n_unit_elems = A->n_unit_elems;
     h.n_delta_elems = A->n_delta_elems; h.n_units = A->n_units;
     h.n_carry = gs->n_carry;
-    h.pad = gs->sym_fused ? 1u : 0u;
+    h.pad = (gs->sym_fused ? 1u : 0u) | (gs->pass_stride << 1);
     bool good = fwrite(kMagic, 1, 8, f) == 8 && fwrite(&h, sizeof(h), 1, f) == 1;
     std::vector<int32_t> bnd;
     for (const PartBounds &b : A->bounds) {
@@ -861,6 +862,7 @@ spx_matrix_t *spx_mat_restore(const char *filename)
     }
     gs->n_carry = h.n_carry;
     gs->sym_fused = (h.pad & 1u) != 0;
+    gs->pass_stride = h.pad >> 1;
     gs->nnz_stored = h.nnz_stored; gs->n_unit_elems = h.n_unit_elems;
     gs->n_delta_elems = h.n_delta_elems; gs->n_units = h.n_units;
     std::unique_ptr<matrix> A(new matrix);

@@ -522,6 +522,23 @@ void append_sym_expanded(const Partition &lower, Partition &out, bool remine_upp
     out.nnz += 2 * lower.nnz;
 }
 
+void finalize_stream(GpuStream &s)
+{
+    if (s.pass_stride) return;
+    uint32_t stride = 1;
+    for (const SpxRowBlock &rb : s.rbs) stride = std::max<uint32_t>(stride, rb.n_pass);
+    std::vector<SpxPass> strided(s.rbs.size() * (size_t) stride);
+    std::memset(strided.data(), 0, strided.size() * sizeof(SpxPass));
+    for (size_t i = 0; i < s.rbs.size(); ++i) {
+        SpxRowBlock &rb = s.rbs[i];
+        std::copy(s.passes.begin() + rb.pass_off, s.passes.begin() + rb.pass_off + rb.n_pass,
+                  strided.begin() + i * (size_t) stride);
+        rb.pass_off = (uint32_t)(i * (size_t) stride);
+    }
+    s.passes.swap(strided);
+    s.pass_stride = stride;
+}
+
 void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out)
 {
     assert(p.type == ENC_H);

@@ -29,15 +29,24 @@ struct GpuStream {
     // symmetric path, whole matrix in this process: every row has a row-block
     // and the diagonal term is added in the kernel's write-out (no init pass)
     bool sym_fused = false;
+    // pass headers of row-block i start at passes[i * pass_stride] once
+    // finalize_stream() ran (0: packed, as the emitter appends them)
+    uint32_t pass_stride = 0;
     // accounting
     size_t nnz_stored = 0;        // nonzeros held in `values` (without padding)
     size_t n_unit_elems = 0;
     size_t n_delta_elems = 0;
     size_t n_units = 0;
 
+    size_t n_pass_used() const
+    {
+        size_t n = 0;
+        for (const SpxRowBlock &rb : rbs) n += rb.n_pass;
+        return n;
+    }
     size_t index_bytes() const
     {
-        return descs.size() * sizeof(SpxUnitDesc) + passes.size() * sizeof(SpxPass) + cidx.size() +
+        return descs.size() * sizeof(SpxUnitDesc) + n_pass_used() * sizeof(SpxPass) + cidx.size() +
                segrows.size() * 2 + rbs.size() * sizeof(SpxRowBlock);
     }
 };
@@ -54,6 +63,12 @@ struct GpuEmitParams {
 // Appends the row-blocks of partition `p` (horizontal order) to `out`.
 // Rows are numbered globally (p.row_start + local row).
 void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out);
+
+// Lays the pass headers out at a fixed stride per row-block (the largest pass
+// count), so that a workgroup can fetch its first headers without waiting for
+// its row-block header: one dependent memory round trip less per workgroup.
+// Only the used entries are ever read.  Call once, after the last emit_gpu().
+void finalize_stream(GpuStream &s);
 
 // Symmetric path: the strictly lower triangle held by `lower` (rows local to
 // the partition) plus its mirror image, as one general partition in global

@@ -51,6 +51,7 @@ struct KernelArgs {
     const double *dvalues;   // symmetric, fused: diagonal added at the write-out (else null)
     double alpha, beta;
     uint32_t n_rb;
+    uint32_t pass_stride;    // pass headers of row-block i start at passes[i * pass_stride]
 };
 
 #ifndef SPX_WAVES
@@ -231,6 +232,9 @@ __device__ __forceinline__ void run_pass(const KernelArgs &a, const SpxRowBlock 
 // One workgroup owns one row-block; its wavefronts take the passes in turn
 // (wave w: passes w, w+4, ...) and accumulate into one y tile in LDS, which
 // is written out (y = alpha*tile + beta*y) at the end.
+#ifdef SPX_FORCE_OCC8
+__attribute__((amdgpu_waves_per_eu(8, 8)))
+#endif
 __global__ __launch_bounds__(BLOCK_THREADS)
 void csx_spmv_kernel(KernelArgs a)
 {
@@ -247,14 +251,17 @@ void csx_spmv_kernel(KernelArgs a)
     const uint32_t rb_idx = (blockIdx.x & 7u) * (nb >> 3) + (blockIdx.x >> 3);
     if (rb_idx >= a.n_rb) return;
 
+    // the pass headers sit at a fixed stride, so the wave's first two are
+    // fetched together with the row-block header, not after it
+    const SpxPass *passes = a.passes + (size_t) rb_idx * a.pass_stride;
     const SpxRowBlock rb = a.rbs[rb_idx];
+    SpxPass first0 = passes[wave];
+    SpxPass first1 = passes[wave + WAVES_PER_BLOCK];     // (the table is padded by one stride)
     const int n_rows = rb.n_rows;
     for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS) tile[i] = 0.0;
     __syncthreads();
 
-    // wave w takes passes w, w+4, ...; the next pass header is fetched while
-    // the current pass runs
-    const SpxPass *passes = a.passes + rb.pass_off;
+    // wave w takes passes w, w+4, ...
     const int n_pass = rb.n_pass;
     // two of the wave's passes at a time when they have the same shape (they
     // mostly do: passes are sorted by width), so that their loads overlap
@@ -262,10 +269,10 @@ void csx_spmv_kernel(KernelArgs a)
     if (a.alpha == 123.0)
 #endif
     for (int t = wave; t < n_pass; t += 2 * WAVES_PER_BLOCK) {
-        const SpxPass p0 = passes[t];
+        const SpxPass p0 = (t == wave) ? first0 : passes[t];
         const int t1 = t + WAVES_PER_BLOCK;
         if (t1 < n_pass) {
-            const SpxPass p1 = passes[t1];
+            const SpxPass p1 = (t == wave) ? first1 : passes[t1];
             if (p0.kind == p1.kind && p0.width == p1.width) {
                 if (p0.kind == SPX_PASS_GATHER) run_units<2, true>(a, rb, {p0, p1}, tile, lane);
                 else run_units<2, false>(a, rb, {p0, p1}, tile, lane);
@@ -331,6 +338,7 @@ struct DeviceMatrix {
     size_t nrows = 0, ncols = 0;
     bool symmetric = false;
     bool sym_fused = false;
+    uint32_t pass_stride = 1;
     size_t own_lo = 0, own_hi = 0;
     uint32_t n_rb = 0, n_shared = 0, n_carry = 0;
     SpxRowBlock *rbs = nullptr;
@@ -377,12 +385,14 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
         throw FatalError("no HIP device");
     }
     if (device >= 0) HIP_CHECK(hipSetDevice(device));
+    if (!s.pass_stride && !s.rbs.empty()) throw FatalError("descriptor stream was not finalized");
     DeviceMatrix *m = new DeviceMatrix;
     HIP_CHECK(hipGetDevice(&m->device));
     m->nrows = nrows;
     m->ncols = ncols;
     m->symmetric = symmetric;
     m->sym_fused = symmetric && s.sym_fused;
+    m->pass_stride = s.pass_stride;
     m->own_lo = (size_t) own_lo;
     m->own_hi = (size_t) own_hi;
     m->n_rb = (uint32_t) s.rbs.size();
@@ -391,7 +401,7 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
     m->rbs = upload(s.rbs);
     m->values = upload(s.values, 160);
     m->descs = upload(s.descs, 8);
-    m->passes = upload(s.passes, 1);
+    m->passes = upload(s.passes, (size_t) s.pass_stride + 2 * WAVES_PER_BLOCK);
     m->cidx = upload(s.cidx, 64);
     m->segrows = upload(s.segrows, 80);
     m->shared = upload(s.shared);
@@ -431,6 +441,7 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
     a.cidx = m->cidx; a.segrows = m->segrows; a.x = d_x; a.y = d_y;
     a.carry = m->carry; a.alpha = alpha; a.beta = beta; a.n_rb = m->n_rb;
     a.dvalues = m->sym_fused ? m->dvalues : nullptr;
+    a.pass_stride = m->pass_stride;
 
     uint32_t blocks = (m->n_rb + 7u) & ~7u;
     if (m->symmetric && !m->sym_fused) {
@@ -490,6 +501,7 @@ void device_download(const DeviceMatrix *m, GpuStream &s)
     download(s.shared, m->shared, m->n_shared);
     s.n_carry = m->n_carry;
     s.sym_fused = m->sym_fused;
+    s.pass_stride = m->pass_stride;
     if (m->symmetric) download(s.dvalues, m->dvalues, m->nrows);
 }
 

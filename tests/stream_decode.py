@@ -24,7 +24,7 @@ class Stream:
     def __init__(self, path):
         with open(path, "rb") as f:
             buf = f.read()
-        assert buf[:8] == b"SPXHIP04", buf[:8]
+        assert buf[:8] == b"SPXHIP05", buf[:8]
         hdr = struct.unpack_from("<4i3Q2i4Q2I", buf, 8)
         (self.nrows, self.ncols, self.nnz, self.symmetric, self.nr_partitions, self.first_part,
          self.last_part, self.own_lo, self.own_hi, self.nnz_stored, self.n_unit_elems,
