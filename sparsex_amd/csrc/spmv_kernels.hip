@@ -235,9 +235,21 @@ __device__ __forceinline__ void run_pass(const KernelArgs &a, const SpxRowBlock 
 #ifdef SPX_FORCE_OCC8
 __attribute__((amdgpu_waves_per_eu(8, 8)))
 #endif
+// (Individual scalar arguments, most urgent first.  Preloading them into SGPRs
+// at wave launch -- hipcc -mllvm -amdgpu-kernarg-preload-count=16 -- was
+// measured: it removes the kernarg fetch in front of the first real load but
+// costs more at dispatch, cant 7.5 -> 8.0 us; not used.)
 __global__ __launch_bounds__(BLOCK_THREADS)
-void csx_spmv_kernel(KernelArgs a)
+void csx_spmv_kernel(const SpxRowBlock *rbs_, const SpxPass *passes_, uint32_t n_rb_,
+                     uint32_t pass_stride_, uint32_t blocks_per_xcd, uint32_t /*pad*/,
+                     const double *values_, const SpxUnitDesc *descs_,
+                     const uint8_t *cidx_, const uint16_t *segrows_, const double *x_, double *y_,
+                     double *carry_, const double *dvalues_, double alpha_, double beta_)
 {
+    KernelArgs a;
+    a.rbs = rbs_; a.passes = passes_; a.n_rb = n_rb_; a.pass_stride = pass_stride_;
+    a.values = values_; a.descs = descs_; a.cidx = cidx_; a.segrows = segrows_; a.x = x_;
+    a.y = y_; a.carry = carry_; a.dvalues = dvalues_; a.alpha = alpha_; a.beta = beta_;
     __shared__ double tile[SPX_MAX_RB_ROWS];
 
 #ifdef SPX_ABL_EMPTY
@@ -247,32 +259,28 @@ void csx_spmv_kernel(KernelArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // XCD-aware order: workgroup b runs on XCD b % 8; give each XCD one
     // contiguous eighth of the row-blocks (gridDim.x is a multiple of 8)
-    const uint32_t nb = gridDim.x;
-    const uint32_t rb_idx = (blockIdx.x & 7u) * (nb >> 3) + (blockIdx.x >> 3);
+    const uint32_t rb_idx = (blockIdx.x & 7u) * blocks_per_xcd + (blockIdx.x >> 3);
     if (rb_idx >= a.n_rb) return;
 
     // the pass headers sit at a fixed stride, so the wave's first two are
     // fetched together with the row-block header, not after it
     const SpxPass *passes = a.passes + (size_t) rb_idx * a.pass_stride;
     const SpxRowBlock rb = a.rbs[rb_idx];
-    SpxPass first0 = passes[wave];
-    SpxPass first1 = passes[wave + WAVES_PER_BLOCK];     // (the table is padded by one stride)
+    SpxPass p0 = passes[wave];
+    SpxPass p1 = passes[wave + WAVES_PER_BLOCK];         // (the table is padded by one stride)
     const int n_rows = rb.n_rows;
     for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS) tile[i] = 0.0;
     __syncthreads();
 
-    // wave w takes passes w, w+4, ...
+    // wave w takes passes w, w+4, ..., two at a time when they have the same
+    // shape (they mostly do: passes are sorted by width), so that their loads
+    // overlap
     const int n_pass = rb.n_pass;
-    // two of the wave's passes at a time when they have the same shape (they
-    // mostly do: passes are sorted by width), so that their loads overlap
 #ifdef SPX_ABL_NOPASS
     if (a.alpha == 123.0)
 #endif
     for (int t = wave; t < n_pass; t += 2 * WAVES_PER_BLOCK) {
-        const SpxPass p0 = (t == wave) ? first0 : passes[t];
-        const int t1 = t + WAVES_PER_BLOCK;
-        if (t1 < n_pass) {
-            const SpxPass p1 = (t == wave) ? first1 : passes[t1];
+        if (t + WAVES_PER_BLOCK < n_pass) {
             if (p0.kind == p1.kind && p0.width == p1.width) {
                 if (p0.kind == SPX_PASS_GATHER) run_units<2, true>(a, rb, {p0, p1}, tile, lane);
                 else run_units<2, false>(a, rb, {p0, p1}, tile, lane);
@@ -282,6 +290,10 @@ void csx_spmv_kernel(KernelArgs a)
             }
         } else {
             run_pass(a, rb, p0, tile, lane);
+        }
+        if (t + 2 * WAVES_PER_BLOCK < n_pass) {
+            p0 = passes[t + 2 * WAVES_PER_BLOCK];
+            p1 = passes[t + 3 * WAVES_PER_BLOCK];
         }
     }
     __syncthreads();
@@ -455,7 +467,10 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
         a.beta = beta = 1.0;
     }
     if (blocks)
-        hipLaunchKernelGGL(csx_spmv_kernel, dim3(blocks), dim3(BLOCK_THREADS), 0, stream, a);
+        hipLaunchKernelGGL(csx_spmv_kernel, dim3(blocks), dim3(BLOCK_THREADS), 0, stream, a.rbs,
+                           a.passes, a.n_rb, a.pass_stride, blocks >> 3, 0u, a.values, a.descs,
+                           a.cidx, a.segrows,
+                           a.x, a.y, a.carry, a.dvalues, a.alpha, a.beta);
     if (m->n_shared)
         hipLaunchKernelGGL(csx_fixup_kernel, dim3((m->n_shared + 63) / 64), dim3(64), 0,
                            stream, m->shared, m->n_shared, m->carry, d_y, alpha, beta,
