@@ -364,6 +364,8 @@ struct DeviceMatrix {
     double *dvalues = nullptr;
     // staging vectors of the host-pointer path
     double *d_x = nullptr, *d_y = nullptr;
+    double *p_x = nullptr, *p_y = nullptr;      // pinned
+    hipStream_t host_stream = nullptr;
     size_t value_bytes = 0, index_bytes = 0;
     size_t n_values = 0, n_descs = 0, n_passes = 0, n_cidx = 0, n_segrows = 0;
 };
@@ -441,6 +443,9 @@ void device_free(DeviceMatrix *m)
     if (m->dvalues) (void) hipFree(m->dvalues);
     if (m->d_x) (void) hipFree(m->d_x);
     if (m->d_y) (void) hipFree(m->d_y);
+    if (m->p_x) (void) hipHostFree(m->p_x);
+    if (m->p_y) (void) hipHostFree(m->p_y);
+    if (m->host_stream) (void) hipStreamDestroy(m->host_stream);
     delete m;
 }
 
@@ -478,23 +483,35 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
     HIP_CHECK(hipGetLastError());
 }
 
+// Host-vector entry point: x (and y when it is read) go through pinned staging
+// buffers and asynchronous copies on one private stream -- a pageable
+// hipMemcpy stages internally as well, but synchronously and chunk by chunk.
 void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x, double beta,
                       double *h_y)
 {
     HIP_CHECK(hipSetDevice(m->device));
-    if (!m->d_x) HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&m->d_x),
-                                     (m->ncols ? m->ncols : 1) * sizeof(double)));
-    if (!m->d_y) HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&m->d_y),
-                                     (m->nrows ? m->nrows : 1) * sizeof(double)));
-    HIP_CHECK(hipMemcpy(m->d_x, h_x, m->ncols * sizeof(double), hipMemcpyHostToDevice));
+    const size_t xb = m->ncols * sizeof(double), yb = m->nrows * sizeof(double);
+    if (!m->d_x) {
+        HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&m->d_x), xb ? xb : 8));
+        HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&m->d_y), yb ? yb : 8));
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&m->p_x), xb ? xb : 8, hipHostMallocDefault));
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&m->p_y), yb ? yb : 8, hipHostMallocDefault));
+        HIP_CHECK(hipStreamCreateWithFlags(&m->host_stream, hipStreamNonBlocking));
+    }
+    hipStream_t st = m->host_stream;
+    std::memcpy(m->p_x, h_x, xb);
+    HIP_CHECK(hipMemcpyAsync(m->d_x, m->p_x, xb, hipMemcpyHostToDevice, st));
     // y travels to the device only when it is read: beta != 0, or this process
     // owns a slice of the rows and the others must keep the caller's values
     const bool whole = m->own_lo == 0 && m->own_hi == m->nrows && (!m->symmetric || m->sym_fused);
-    if (beta != 0.0 || !whole)
-        HIP_CHECK(hipMemcpy(m->d_y, h_y, m->nrows * sizeof(double), hipMemcpyHostToDevice));
-    device_spmv(m, alpha, m->d_x, beta, m->d_y, nullptr);
-    // (the blocking copy below is ordered behind the kernels of the null stream)
-    HIP_CHECK(hipMemcpy(h_y, m->d_y, m->nrows * sizeof(double), hipMemcpyDeviceToHost));
+    if (beta != 0.0 || !whole) {
+        std::memcpy(m->p_y, h_y, yb);
+        HIP_CHECK(hipMemcpyAsync(m->d_y, m->p_y, yb, hipMemcpyHostToDevice, st));
+    }
+    device_spmv(m, alpha, m->d_x, beta, m->d_y, st);
+    HIP_CHECK(hipMemcpyAsync(m->p_y, m->d_y, yb, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    std::memcpy(h_y, m->p_y, yb);
 }
 
 template <typename T>

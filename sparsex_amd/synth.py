@@ -146,8 +146,16 @@ def random_x(ncols, seed=42):
     return np.random.RandomState(seed).uniform(-0.1, 0.1, ncols)
 
 
+def syn_nlpkkt_scaled(scale=1.0):
+    """syn_nlpkkt with the grid edge derived from a size factor: scale 1 is
+    nlpkkt240 itself (N = 240, ~760 M nonzeros); the default single-GPU stand-in
+    uses scale = 1/64 (N = 60, ~22.7 M nonzeros)."""
+    return syn_nlpkkt(max(3, int(round(240.0 * scale ** (1.0 / 3.0)))))
+
+
 WORKLOADS = {
     "syn-cant": syn_cant,
     "syn-nd24k": syn_nd24k,
     "syn-webbase": syn_webbase,
+    "syn-nlpkkt": syn_nlpkkt_scaled,
 }
