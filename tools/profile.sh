@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 400 --warmup 50 --no-cpu-baseline $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o run -- \
     python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_trace.log" 2>&1
-tail -1 "$OUT/bench_trace.log" > "$OUT/bench_line.json"
+grep '^{"metric"' "$OUT/bench_trace.log" | tail -1 > "$OUT/bench_line.json"
 find "$OUT/trace" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats.csv" \;
 rm -rf "$OUT/trace"/*/*kernel_trace.csv "$OUT/trace"/*kernel_trace.csv 2>/dev/null
 # counters: one pass each (FETCH_SIZE and WRITE_SIZE do not fit one pass)
