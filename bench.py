@@ -397,7 +397,9 @@ def main():
         if args.symmetric:
             # symmetric storage: strictly lower values + diagonal, once each
             # (the GPU stream mirrors the lower triangle, which is overhead)
-            nnz_alg = nnz_local // 2 + rows_local
+            # (one process: from the matrix itself -- the stream may hold tiles once
+            # and the rest twice; several processes: half of the mirrored stream)
+            nnz_alg = (nnz - n) // 2 + n if world == 1 else nnz_local // 2 + rows_local
             b_alg = 8.0 * nnz_alg + 8.0 * n + 8.0 * (n if world > 1 else rows_local)
         else:
             b_alg = 8.0 * nnz_local + 8.0 * n + 8.0 * rows_local

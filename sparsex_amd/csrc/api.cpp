@@ -328,7 +328,6 @@ static void emit_and_upload(spx_matrix_t *A)
         gs.dvalues.assign((size_t) A->nrows, 0.0);
         Partition full;
         for (size_t i = 0; i < nown; ++i) {
-            append_sym_expanded(A->parts[i], full, gp.sym_remine);
             const PartBounds &b = A->bounds[first + i];
             for (size_t r = 0; r < A->diag[i].size() && r < (size_t) b.nr_rows; ++r)
                 gs.dvalues[(size_t) b.row_start + r] = A->diag[i][r];
@@ -338,13 +337,23 @@ static void emit_and_upload(spx_matrix_t *A)
         // process with a slice produces a partial vector instead (rows it
         // does not touch are zeroed by the init kernel) to be summed later.
         gs.sym_fused = A->own_lo == 0 && A->own_hi == A->nrows;
+        std::vector<SymTile> tiles;
+        if (gs.sym_fused && gp.sym_once) {
+            // ... and it can read the dense 8x8 tiles of the lower triangle once
+            // and use them twice (SPX_PASS_SYMTILE); everything else is
+            // mirrored as below
+            build_sym_once(A->parts, full, tiles);
+            gp.tiles = &tiles;
+        } else {
+            for (size_t i = 0; i < nown; ++i) append_sym_expanded(A->parts[i], full, gp.sym_remine);
+        }
         if (gs.sym_fused) full.nr_rows = (size_t) A->nrows;
         gp.skip_empty = !gs.sym_fused;
         emit_gpu(full, gp, gs);
     } else {
         for (size_t i = 0; i < nown; ++i) emit_gpu(A->parts[i], gp, gs);
     }
-    finalize_stream(gs);
+    finalize_stream(gs, (size_t) A->nrows);
     A->nnz_stored = gs.nnz_stored;
     A->n_unit_elems = gs.n_unit_elems;
     A->n_delta_elems = gs.n_delta_elems;
@@ -482,6 +491,7 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     A->emit_params.target_elems = (size_t) std::max<long>(64, rbe);
     A->emit_params.max_rows = (size_t) std::max<long>(1, cfg.get_long("spx.gpu.rowblock_rows"));
     A->emit_params.sym_remine = cfg.get_bool("spx.gpu.sym_remine");
+    A->emit_params.sym_once = cfg.get_bool("spx.gpu.sym_once");
     A->emit_params.stack_segments = cfg.get_bool("spx.gpu.stack_segments");
     {
         idx_t lo = nown ? A->bounds[first].row_start : 0;
@@ -734,7 +744,7 @@ spx_error_t spx_mat_set_entry(spx_matrix_t *A, spx_index_t row, spx_index_t colu
 
 namespace {
 
-const char kMagic[8] = {'S', 'P', 'X', 'H', 'I', 'P', '0', '5'};
+const char kMagic[8] = {'S', 'P', 'X', 'H', 'I', 'P', '0', '6'};
 
 template <typename T>
 bool put_vec(FILE *f, const std::vector<T> &v)
@@ -760,6 +770,7 @@ struct SavedHeader {
     int32_t own_lo, own_hi;
     uint64_t nnz_stored, n_unit_elems, n_delta_elems, n_units;
     uint32_t n_carry, pad;
+    uint32_t n_spill, lds_doubles;
 };
 
 }  // namespace
@@ -807,6 +818,8 @@ spx_error_t spx_mat_save(const spx_matrix_t *A, const char *filename)
     h.n_delta_elems = A->n_delta_elems; h.n_units = A->n_units;
     h.n_carry = gs->n_carry;
     h.pad = (gs->sym_fused ? 1u : 0u) | (gs->pass_stride << 1);
+    h.n_spill = gs->n_spill;
+    h.lds_doubles = gs->lds_doubles;
     bool good = fwrite(kMagic, 1, 8, f) == 8 && fwrite(&h, sizeof(h), 1, f) == 1;
     std::vector<int32_t> bnd;
     for (const PartBounds &b : A->bounds) {
@@ -817,7 +830,7 @@ spx_error_t spx_mat_save(const spx_matrix_t *A, const char *filename)
     good = good && put_vec(f, bnd) && put_vec(f, gs->rbs) && put_vec(f, gs->passes) &&
            put_vec(f, gs->descs) && put_vec(f, gs->cidx) &&
            put_vec(f, gs->segrows) && put_vec(f, gs->shared) && put_vec(f, gs->dvalues) &&
-           put_vec(f, gs->values);
+           put_vec(f, gs->values) && put_vec(f, gs->fix_ptr) && put_vec(f, gs->fix_idx);
     std::vector<int32_t> perm;
     if (A->permutation) perm.assign(A->permutation, A->permutation + A->nrows);
     good = good && put_vec(f, perm);
@@ -852,7 +865,8 @@ spx_matrix_t *spx_mat_restore(const char *filename)
                 fread(&h, sizeof(h), 1, f) == 1 && get_vec(f, bnd) && get_vec(f, gs->rbs) &&
                 get_vec(f, gs->passes) && get_vec(f, gs->descs) &&
                 get_vec(f, gs->cidx) && get_vec(f, gs->segrows) && get_vec(f, gs->shared) &&
-                get_vec(f, gs->dvalues) && get_vec(f, gs->values);
+                get_vec(f, gs->dvalues) && get_vec(f, gs->values) && get_vec(f, gs->fix_ptr) &&
+                get_vec(f, gs->fix_idx);
     std::vector<int32_t> perm;
     good = good && get_vec(f, perm);
     fclose(f);
@@ -863,6 +877,8 @@ spx_matrix_t *spx_mat_restore(const char *filename)
     gs->n_carry = h.n_carry;
     gs->sym_fused = (h.pad & 1u) != 0;
     gs->pass_stride = h.pad >> 1;
+    gs->n_spill = h.n_spill;
+    gs->lds_doubles = h.lds_doubles;
     gs->nnz_stored = h.nnz_stored; gs->n_unit_elems = h.n_unit_elems;
     gs->n_delta_elems = h.n_delta_elems; gs->n_units = h.n_units;
     std::unique_ptr<matrix> A(new matrix);

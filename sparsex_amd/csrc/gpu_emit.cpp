@@ -46,7 +46,8 @@ public:
 
     // emits one row-block for rows [lo, hi) from the given pieces/singles
     void emit(idx_t lo, idx_t hi, const std::vector<Piece> &pieces,
-              std::vector<Single> &singles, uint8_t flags, uint32_t carry_slot);
+              std::vector<Single> &singles, uint8_t flags, uint32_t carry_slot,
+              const std::vector<const SymTile *> *tiles = nullptr);
 
 private:
     void add_group(idx_t row, idx_t col, size_t nseg, size_t width, unsigned kind, unsigned step)
@@ -65,6 +66,7 @@ private:
     void stack_groups();
     void emit_unit_passes(SpxRowBlock &rb);
     void emit_gather_passes(SpxRowBlock &rb, std::vector<Single> &singles, idx_t lo);
+    void emit_tile_passes(SpxRowBlock &rb, const std::vector<const SymTile *> &tiles);
 
     const Partition &p_;
     GpuStream &out_;
@@ -355,8 +357,65 @@ void RbBuilder::emit_gather_passes(SpxRowBlock &rb, std::vector<Single> &singles
     }
 }
 
+// Symmetric tiles of this row-block: eight tiles per pass, lanes 8t..8t+7 the
+// rows of tile t.  The transposed sums of a tile's eight columns go to
+// consecutive slots: columns in front of the row-block's first row are ranked
+// (slot = number of touched columns in front), columns inside the row-block
+// continue behind them at n_slots + (column - row0), i.e. in the y tile itself.
+void RbBuilder::emit_tile_passes(SpxRowBlock &rb, const std::vector<const SymTile *> &tiles)
+{
+    if (tiles.empty()) return;
+    const idx_t row0 = (idx_t) rb.row0;
+    std::vector<idx_t> cols;
+    for (const SymTile *t : tiles)
+        for (idx_t c = t->col0; c < t->col0 + 8 && c < row0; ++c) cols.push_back(c);
+    std::sort(cols.begin(), cols.end());
+    cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+    assert(cols.size() <= SPX_MAX_TILE_SLOTS);
+    rb.n_slots = (uint16_t) cols.size();
+    rb.spill_off = (uint32_t) out_.spill_col.size();
+    for (idx_t c : cols) out_.spill_col.push_back((uint32_t) c);
+    out_.lds_doubles = std::max<uint32_t>(out_.lds_doubles, (uint32_t) rb.n_slots + rb.n_rows);
+    for (size_t b = 0; b < tiles.size(); b += 8) {
+        const size_t nt = std::min<size_t>(8, tiles.size() - b);
+        const uint32_t nseg = (uint32_t)(8 * nt);
+        SpxPass ps;
+        std::memset(&ps, 0, sizeof(ps));
+        if (out_.values.size() % 2) out_.values.push_back(0.0);
+        ps.val_off = (uint32_t)(out_.values.size() - rb.val_off);
+        ps.rank0 = (uint16_t)(out_.descs.size() - rb.desc_off);
+        ps.nseg = (uint8_t) nseg;
+        ps.width = 8;
+        ps.kind = SPX_PASS_SYMTILE;
+        const size_t base = out_.values.size();
+        out_.values.resize(base + (size_t) nseg * 8, 0.0);
+        for (size_t k = 0; k < nt; ++k) {
+            const SymTile &t = *tiles[b + k];
+            uint32_t slot;
+            if (t.col0 < row0)
+                slot = (uint32_t)(std::lower_bound(cols.begin(), cols.end(), t.col0) - cols.begin());
+            else
+                slot = (uint32_t) rb.n_slots + (uint32_t)(t.col0 - row0);
+            SpxUnitDesc d;
+            d.col0 = (uint32_t) t.col0;
+            d.bits = (uint32_t)(t.row0 - row0) | (slot << 9);
+            out_.descs.push_back(d);
+            ++out_.n_units;
+            for (uint32_t i = 0; i < 8; ++i)
+                for (uint32_t w = 0; w < 8; ++w)
+                    out_.values[base + spx_pass_value_index((uint32_t)(8 * k) + i, w, nseg, 8)] =
+                        t.v[i * 8 + w];
+        }
+        out_.passes.push_back(ps);
+        ++rb.n_pass;
+    }
+    out_.n_unit_elems += 64 * tiles.size();
+    out_.nnz_stored += 64 * tiles.size();
+}
+
 void RbBuilder::emit(idx_t lo, idx_t hi, const std::vector<Piece> &pieces,
-                     std::vector<Single> &singles, uint8_t flags, uint32_t carry_slot)
+                     std::vector<Single> &singles, uint8_t flags, uint32_t carry_slot,
+                     const std::vector<const SymTile *> *tiles)
 {
     SpxRowBlock rb;
     std::memset(&rb, 0, sizeof(rb));
@@ -369,6 +428,7 @@ void RbBuilder::emit(idx_t lo, idx_t hi, const std::vector<Piece> &pieces,
     rb.flags = flags;
     rb.carry_slot = carry_slot;
 
+    if (tiles) emit_tile_passes(rb, *tiles);      // the bulk of the work first
     groups_.clear();
     gvals_.clear();
     for (const Piece &pc : pieces) groups_from_piece(pc, lo);
@@ -522,9 +582,115 @@ void append_sym_expanded(const Partition &lower, Partition &out, bool remine_upp
     out.nnz += 2 * lower.nnz;
 }
 
-void finalize_stream(GpuStream &s)
+// Cuts the strictly lower points into dense 8x8 tiles (eight stacked row
+// segments of width 8) and the rest.
+static void extract_tiles(std::vector<Single> &pts, std::vector<SymTile> &tiles,
+                          std::vector<Single> &rest)
+{
+    std::sort(pts.begin(), pts.end(), [](const Single &a, const Single &b) {
+        return a.row < b.row || (a.row == b.row && a.col < b.col);
+    });
+    struct Seg { idx_t row, col; uint32_t first; uint32_t width; };
+    std::vector<Seg> segs;
+    for (size_t i = 0; i < pts.size();) {
+        size_t j = i + 1;
+        while (j < pts.size() && j - i < 8 && pts[j].row == pts[i].row &&
+               pts[j].col == pts[j - 1].col + 1)
+            ++j;
+        segs.push_back(Seg{pts[i].row, pts[i].col, (uint32_t) i, (uint32_t)(j - i)});
+        i = j;
+    }
+    std::sort(segs.begin(), segs.end(), [](const Seg &a, const Seg &b) {
+        if (a.col != b.col) return a.col < b.col;
+        if (a.width != b.width) return a.width < b.width;
+        return a.row < b.row;
+    });
+    for (size_t i = 0; i < segs.size();) {
+        size_t j = i + 1;
+        while (j < segs.size() && segs[j].col == segs[i].col && segs[j].width == segs[i].width &&
+               segs[j].row == segs[j - 1].row + 1)
+            ++j;
+        size_t k = i;
+        if (segs[i].width == 8)
+            for (; k + 8 <= j; k += 8) {
+                SymTile t;
+                t.row0 = segs[k].row - 1;          // points are 1-based
+                t.col0 = segs[k].col - 1;
+                for (size_t r = 0; r < 8; ++r)
+                    for (size_t w = 0; w < 8; ++w) t.v[r * 8 + w] = pts[segs[k + r].first + w].val;
+                tiles.push_back(t);
+            }
+        for (; k < j; ++k)
+            for (uint32_t w = 0; w < segs[k].width; ++w) rest.push_back(pts[segs[k].first + w]);
+        i = j;
+    }
+    std::sort(tiles.begin(), tiles.end(), [](const SymTile &a, const SymTile &b) {
+        return a.row0 != b.row0 ? a.row0 < b.row0 : a.col0 < b.col0;
+    });
+}
+
+void build_sym_once(const std::vector<Partition> &lowers, Partition &out,
+                    std::vector<SymTile> &tiles)
+{
+    std::vector<Single> pts, rest;
+    out.type = ENC_H;
+    out.row_start = 0;
+    for (const Partition &lower : lowers) {
+        const idx_t rs = lower.row_start;
+        out.nr_cols = lower.nr_cols;
+        out.nr_rows = std::max<size_t>(out.nr_rows, (size_t) rs + lower.nr_rows);
+        for (size_t i = 0; i < lower.elems_size; ++i) {
+            const Elem &e = lower.elems[i];
+            if (!e.is_unit()) {
+                pts.push_back(Single{e.row + rs, e.col, e.val});
+                continue;
+            }
+            const val_t *src = &lower.pool[e.voff];
+            Elem g = e;
+            g.row += rs;
+            for (size_t k = 0; k < e.size; ++k) {
+                idx_t r, c;
+                unit_elem_coords(g, k, r, c);
+                pts.push_back(Single{r, c, src[k]});
+            }
+        }
+    }
+    const size_t n_lower = pts.size();
+    extract_tiles(pts, tiles, rest);
+    // what is not in a tile: lower triangle and mirror image, both as row segments
+    const size_t n_rest = rest.size();
+    rest.reserve(2 * n_rest);
+    for (size_t i = 0; i < n_rest; ++i) rest.push_back(Single{rest[i].col, rest[i].row, rest[i].val});
+    // The diagonal itself is held apart (dvalues), which splits every row's run
+    // around it in two.  Where a(r,r-1) exists (and so does its mirror image
+    // a(r-1,r)), an explicit zero at (r,r) joins the runs of row r again: the
+    // triangular blocks along the diagonal become dense blocks of one width
+    // instead of eight ragged ones.
+    {
+        std::vector<char> has_sub(out.nr_rows + 2, 0);
+        for (size_t i = 0; i < n_rest; ++i)
+            if (rest[i].col + 1 == rest[i].row) has_sub[(size_t) rest[i].row] = 1;
+        for (size_t r = 2; r + 1 <= out.nr_rows; ++r)
+            if (has_sub[r] && has_sub[r + 1]) rest.push_back(Single{(idx_t) r, (idx_t) r, 0.0});
+    }
+    append_upper_segments(rest, out);
+    out.elems_size = out.elems.size();
+    out.nnz += 2 * n_lower;
+}
+
+void finalize_stream(GpuStream &s, size_t nrows)
 {
     if (s.pass_stride) return;
+    s.n_spill = (uint32_t) s.spill_col.size();
+    if (!s.spill_col.empty()) {
+        // per row: the spill slots whose sums belong to it (counting sort by column)
+        s.fix_ptr.assign(nrows + 1, 0);
+        for (uint32_t c : s.spill_col) ++s.fix_ptr[(size_t) c + 1];
+        for (size_t i = 0; i < nrows; ++i) s.fix_ptr[i + 1] += s.fix_ptr[i];
+        s.fix_idx.resize(s.spill_col.size());
+        std::vector<uint32_t> fill(s.fix_ptr.begin(), s.fix_ptr.end() - 1);
+        for (size_t k = 0; k < s.spill_col.size(); ++k) s.fix_idx[fill[s.spill_col[k]]++] = (uint32_t) k;
+    }
     uint32_t stride = 1;
     for (const SpxRowBlock &rb : s.rbs) stride = std::max<uint32_t>(stride, rb.n_pass);
     std::vector<SpxPass> strided(s.rbs.size() * (size_t) stride);
@@ -560,8 +726,15 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out)
             ++cnt[(size_t) r - 1];
         }
     }
+    static const std::vector<SymTile> no_tiles;
+    const std::vector<SymTile> &tiles = prm.tiles ? *prm.tiles : no_tiles;
+    for (const SymTile &t : tiles)
+        for (idx_t r = 0; r < 8; ++r) cnt[(size_t)(t.row0 - p.row_start + r)] += 8;
 
     // 2. row ranges of the row-blocks
+    std::vector<char> inside_tile((size_t) nrows + 1, 0);   // a border in front of row r cuts a tile
+    for (const SymTile &t : tiles)
+        for (idx_t r = 1; r < 8; ++r) inside_tile[(size_t)(t.row0 - p.row_start + r)] = 1;
     std::vector<Plan> plans;
     {
         idx_t start = 0;
@@ -575,7 +748,10 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out)
                 acc = 0;
                 continue;
             }
-            if ((acc > 0 && acc + c > target) || (size_t)(r - start) >= max_rows) {
+            // (a border inside a symmetric tile would cost the tile: such rows
+            // only close a row-block when a hard limit says so)
+            const bool hard = acc + c > SPX_MAX_RB_ELEMS || (size_t)(r - start) >= max_rows;
+            if (hard || (acc > 0 && acc + c > target && !inside_tile[(size_t) r])) {
                 plans.push_back(Plan{start, r, false});
                 start = r;
                 acc = 0;
@@ -649,13 +825,54 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out)
         }
     }
 
+    // 3b. symmetric tiles: a tile lives in the row-block of its eight rows; one
+    // that a row-block border cuts (or that would overflow the slots of its
+    // row-block) is given up and goes, with its mirror image, to the leftovers
+    std::vector<std::vector<const SymTile *>> rb_tiles(plans.size());
+    {
+        std::vector<std::vector<idx_t>> touched(plans.size());
+        auto demote = [&](const SymTile &t) {
+            for (idx_t i = 0; i < 8; ++i)
+                for (idx_t w = 0; w < 8; ++w) {
+                    const idx_t r = t.row0 - p.row_start + i, c = t.col0 + w;   // 0-based
+                    const val_t v = t.v[i * 8 + w];
+                    singles[plan_of_row[(size_t) r]].push_back(Single{r, c, v});
+                    singles[plan_of_row[(size_t)(c - p.row_start)]].push_back(
+                        Single{c - p.row_start, r + p.row_start, v});
+                }
+        };
+        for (const SymTile &t : tiles) {
+            const size_t r = (size_t)(t.row0 - p.row_start);
+            const uint32_t pl = plan_of_row[r];
+            if (plan_of_row[r + 7] != pl || plans[pl].split) {
+                demote(t);
+                continue;
+            }
+            // distinct columns in front of the row-block so far (upper bound: 8 more)
+            std::vector<idx_t> &tc = touched[pl];
+            const idx_t lo_g = p.row_start + plans[pl].row_lo;
+            size_t add = 0;
+            for (idx_t c = t.col0; c < t.col0 + 8 && c < lo_g; ++c)
+                if (!std::binary_search(tc.begin(), tc.end(), c)) ++add;
+            if (tc.size() + add > SPX_MAX_TILE_SLOTS) {
+                demote(t);
+                continue;
+            }
+            for (idx_t c = t.col0; c < t.col0 + 8 && c < lo_g; ++c) {
+                auto it = std::lower_bound(tc.begin(), tc.end(), c);
+                if (it == tc.end() || *it != c) tc.insert(it, c);
+            }
+            rb_tiles[pl].push_back(&t);
+        }
+    }
+
     // 4. emit
     RbBuilder bld(p, out, prm.stack_segments);
     for (size_t i = 0; i < plans.size(); ++i) {
         const Plan &pl = plans[i];
-        if (prm.skip_empty && pieces[i].empty() && singles[i].empty()) continue;
+        if (prm.skip_empty && pieces[i].empty() && singles[i].empty() && rb_tiles[i].empty()) continue;
         if (!pl.split) {
-            bld.emit(pl.row_lo, pl.row_hi, pieces[i], singles[i], 0, 0);
+            bld.emit(pl.row_lo, pl.row_hi, pieces[i], singles[i], 0, 0, &rb_tiles[i]);
             continue;
         }
         // an over-long row: everything is a single here; chunk it

@@ -14,6 +14,12 @@
 
 namespace spx {
 
+// A dense 8x8 tile of the strictly lower triangle (symmetric path).
+struct SymTile {
+    idx_t row0, col0;      // 0-based, global
+    val_t v[64];           // row-major
+};
+
 struct GpuStream {
     std::vector<val_t> values;
     std::vector<SpxUnitDesc> descs;
@@ -29,6 +35,12 @@ struct GpuStream {
     // symmetric path, whole matrix in this process: every row has a row-block
     // and the diagonal term is added in the kernel's write-out (no init pass)
     bool sym_fused = false;
+    // symmetric path with tiles (SPX_PASS_SYMTILE): column of every spill slot
+    // (host side only) and, per row, the slots whose sums belong to it
+    std::vector<uint32_t> spill_col;
+    std::vector<uint32_t> fix_ptr, fix_idx;
+    uint32_t n_spill = 0;                      // spill slots (= spill_col.size() after emission)
+    uint32_t lds_doubles = SPX_MAX_RB_ROWS;    // largest n_slots + n_rows
     // pass headers of row-block i start at passes[i * pass_stride] once
     // finalize_stream() ran (0: packed, as the emitter appends them)
     uint32_t pass_stride = 0;
@@ -47,6 +59,7 @@ struct GpuStream {
     size_t index_bytes() const
     {
         return descs.size() * sizeof(SpxUnitDesc) + n_pass_used() * sizeof(SpxPass) + cidx.size() +
+               (fix_ptr.size() + fix_idx.size()) * 4 +
                segrows.size() * 2 + rbs.size() * sizeof(SpxRowBlock);
     }
 };
@@ -58,6 +71,9 @@ struct GpuEmitParams {
     bool stack_segments = true;   // spx.gpu.stack_segments: equal row segments of consecutive
                                   // rows share one descriptor as a dense block
     bool sym_remine = true;       // spx.gpu.sym_remine (see append_sym_expanded)
+    bool sym_once = true;         // spx.gpu.sym_once: dense 8x8 tiles of a symmetric matrix are
+                                  // read once (one process holding the whole matrix only)
+    const std::vector<SymTile> *tiles = nullptr;   // symmetric, fused: tiles read once (sorted by row0)
 };
 
 // Appends the row-blocks of partition `p` (horizontal order) to `out`.
@@ -68,7 +84,7 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out);
 // count), so that a workgroup can fetch its first headers without waiting for
 // its row-block header: one dependent memory round trip less per workgroup.
 // Only the used entries are ever read.  Call once, after the last emit_gpu().
-void finalize_stream(GpuStream &s);
+void finalize_stream(GpuStream &s, size_t nrows);
 
 // Symmetric path: the strictly lower triangle held by `lower` (rows local to
 // the partition) plus its mirror image, as one general partition in global
@@ -78,6 +94,13 @@ void finalize_stream(GpuStream &s);
 // (horizontal <-> vertical, diagonal and anti-diagonal stay, block-row
 // R x c <-> block-col c x R).
 void append_sym_expanded(const Partition &lower, Partition &out, bool remine_upper = true);
+
+// Symmetric path, whole matrix in one process, values read once where it pays:
+// the strictly lower triangle held by `lowers` (global numbering) is split into
+// dense 8x8 tiles (-> `tiles`, sorted by row) and the rest, which goes to `out`
+// together with its mirror image, both re-cut into row segments and blocks.
+void build_sym_once(const std::vector<Partition> &lowers, Partition &out,
+                    std::vector<SymTile> &tiles);
 
 // coordinates (1-based, horizontal order) of element k of a unit
 inline void unit_elem_coords(const Elem &u, size_t k, idx_t &r, idx_t &c)

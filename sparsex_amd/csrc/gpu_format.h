@@ -39,6 +39,7 @@
 
 #include <stdint.h>
 
+#define SPX_MAX_TILE_SLOTS 3072   /* transposed-sum slots per row-block (LDS)          */
 #define SPX_MAX_RB_ROWS    512    /* y tile of a row-block in LDS (doubles)      */
 #define SPX_MAX_RB_ELEMS   8192   /* nonzeros per row-block (16-bit counters)    */
 #define SPX_MAX_SEG_WIDTH  8      /* columns per row segment                      */
@@ -46,6 +47,15 @@
 #define SPX_PASS_SEGS      64     /* row segments (lanes) per unit pass           */
 
 #define SPX_PASS_UNIT   0
+#define SPX_PASS_SYMTILE 3   /* symmetric path, whole matrix in one process: up to 8
+                                dense 8x8 tiles of the stored lower triangle, lanes
+                                8t..8t+7 = the rows of tile t, W = 8.  Each value is
+                                read ONCE and used twice: the lane's row sum goes to
+                                the y tile as usual, the tile's column sums (reduced
+                                over its 8 lanes in registers) go to the row-block's
+                                transposed-sum slots.  One descriptor per tile:
+                                col0, bits = row0 (9 bits) | first slot << 9         */
+
 #define SPX_PASS_GATHER 2    /* leftover nonzeros as row pieces: lane l owns up to
                                 SPX_MAX_SEG_WIDTH nonzeros of ONE row with explicit
                                 column offsets; values interleaved like a unit
@@ -99,9 +109,13 @@ typedef struct {
     uint16_t n_pass;
     uint8_t  cidx_width;  /* 2 or 4 bytes per column offset                     */
     uint8_t  flags;       /* SPX_RB_* */
-    uint16_t pad_;
+    uint16_t n_slots;     /* transposed-sum slots (SPX_PASS_SYMTILE): one per
+                             distinct column in front of row0 that a tile of this
+                             row-block touches; they sit in LDS in front of the y
+                             tile, so that slot n_slots + i is owned row i        */
     uint32_t carry_slot;  /* SPX_RB_SHARED: slot of the partial sum             */
-    uint32_t pad2_;
+    uint32_t spill_off;   /* the n_slots sums go to spill[spill_off ...]; a second
+                             kernel adds them to the rows they belong to          */
 } SpxRowBlock;            /* 48 bytes */
 
 #define SPX_RB_SHARED 1u  /* owns one chunk of an over-long row; the partial

@@ -49,6 +49,7 @@ struct KernelArgs {
     double *y;
     double *carry;
     const double *dvalues;   // symmetric, fused: diagonal added at the write-out (else null)
+    double *spill;           // symmetric tiles: transposed sums of columns owned by other row-blocks
     double alpha, beta;
     uint32_t n_rb;
     uint32_t pass_stride;    // pass headers of row-block i start at passes[i * pass_stride]
@@ -222,6 +223,79 @@ __device__ __forceinline__ void run_units(const KernelArgs &a, const SpxRowBlock
     }
 }
 
+// A pass of symmetric tiles (SPX_PASS_SYMTILE): lanes 8t..8t+7 hold the rows of
+// the dense 8x8 tile t of the stored lower triangle.  Each value is read once
+// and used twice: a(r,c)*x[c] summed along the lane's row goes to the y tile,
+// a(r,c)*x[r] summed over the tile's eight lanes goes to the slot of column c.
+// The column sums are formed in registers by a three-step exchange within the
+// eight lanes (4 + 2 + 1 values travel), so that each lane ends up with ONE
+// column and the LDS adds of a tile hit eight different addresses -- lanes
+// that add to the same address are serialised at ~3 clocks each.
+__device__ __forceinline__ void symtile_pass(const KernelArgs &a, const SpxRowBlock &rb,
+                                             const SpxPass &ps, double *slots, double *tile,
+                                             int lane)
+{
+    const uint32_t nseg = ps.nseg;
+    const bool active = (uint32_t) lane < nseg;
+    const uint32_t l = active ? (uint32_t) lane : 0u;
+    const uint2 q = *reinterpret_cast<const uint2 *>(a.descs + rb.desc_off + ps.rank0 + (l >> 3));
+    const double *vals = a.values + rb.val_off + ps.val_off;
+    double2 v2[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        v2[p] = *reinterpret_cast<const double2 *>(vals + (uint32_t) p * 2u * nseg + l * 2u);
+    const int i = (int) (l & 7u);
+    const int row = (int) (q.y & 511u) + i;
+    const uint32_t slot = q.y >> 9;
+    const double xr = a.x[rb.row0 + (uint32_t) row];
+    const double *xp = a.x + q.x;
+    double v[8], t = 0.0, p8[8];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        v[2 * p] = v2[p].x;
+        v[2 * p + 1] = v2[p].y;
+    }
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        t = fma(v[w], xp[w], t);
+        p8[w] = active ? v[w] * xr : 0.0;
+    }
+    // exchange with lane^4: lanes 0-3 collect columns 0-3, lanes 4-7 columns 4-7
+    double p4[4];
+    {
+        const bool hi = (i & 4) != 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const double send = hi ? p8[w] : p8[w + 4];
+            const double keep = hi ? p8[w + 4] : p8[w];
+            p4[w] = keep + __shfl_xor(send, 4);
+        }
+    }
+    // lane^2: lanes with bit 1 clear keep the lower two of their four columns
+    double p2[2];
+    {
+        const bool hi = (i & 2) != 0;
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const double send = hi ? p4[w] : p4[w + 2];
+            const double keep = hi ? p4[w + 2] : p4[w];
+            p2[w] = keep + __shfl_xor(send, 2);
+        }
+    }
+    // lane^1: one column each -- lane i of the tile holds column i
+    double cs;
+    {
+        const bool hi = (i & 1) != 0;
+        const double send = hi ? p2[0] : p2[1];
+        const double keep = hi ? p2[1] : p2[0];
+        cs = keep + __shfl_xor(send, 1);
+    }
+    if (active) {
+        atomicAdd(&tile[row], t);
+        atomicAdd(&slots[slot + (uint32_t) i], cs);
+    }
+}
+
 __device__ __forceinline__ void run_pass(const KernelArgs &a, const SpxRowBlock &rb,
                                          const SpxPass &ps, double *tile, int lane)
 {
@@ -232,33 +306,20 @@ __device__ __forceinline__ void run_pass(const KernelArgs &a, const SpxRowBlock 
 // One workgroup owns one row-block; its wavefronts take the passes in turn
 // (wave w: passes w, w+4, ...) and accumulate into one y tile in LDS, which
 // is written out (y = alpha*tile + beta*y) at the end.
-#ifdef SPX_FORCE_OCC8
-__attribute__((amdgpu_waves_per_eu(8, 8)))
-#endif
-// (Individual scalar arguments, most urgent first.  Preloading them into SGPRs
-// at wave launch -- hipcc -mllvm -amdgpu-kernarg-preload-count=16 -- was
-// measured: it removes the kernarg fetch in front of the first real load but
-// costs more at dispatch, cant 7.5 -> 8.0 us; not used.)
-__global__ __launch_bounds__(BLOCK_THREADS)
-void csx_spmv_kernel(const SpxRowBlock *rbs_, const SpxPass *passes_, uint32_t n_rb_,
-                     uint32_t pass_stride_, uint32_t blocks_per_xcd, uint32_t /*pad*/,
-                     const double *values_, const SpxUnitDesc *descs_,
-                     const uint8_t *cidx_, const uint16_t *segrows_, const double *x_, double *y_,
-                     double *carry_, const double *dvalues_, double alpha_, double beta_)
+// SYM: the symmetric variant with tiles (dynamic LDS: the row-block's
+// transposed-sum slots in front of its y tile; the sums of columns owned by
+// other row-blocks are spilled for csx_symfix_kernel).
+template <bool SYM>
+__device__ __forceinline__ void spmv_body(const KernelArgs &a, uint32_t blocks_per_xcd,
+                                          double *lds)
 {
-    KernelArgs a;
-    a.rbs = rbs_; a.passes = passes_; a.n_rb = n_rb_; a.pass_stride = pass_stride_;
-    a.values = values_; a.descs = descs_; a.cidx = cidx_; a.segrows = segrows_; a.x = x_;
-    a.y = y_; a.carry = carry_; a.dvalues = dvalues_; a.alpha = alpha_; a.beta = beta_;
-    __shared__ double tile[SPX_MAX_RB_ROWS];
-
 #ifdef SPX_ABL_EMPTY
     if (a.alpha != 123.0) return;
 #endif
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // XCD-aware order: workgroup b runs on XCD b % 8; give each XCD one
-    // contiguous eighth of the row-blocks (gridDim.x is a multiple of 8)
+    // contiguous eighth of the row-blocks (the grid is a multiple of 8)
     const uint32_t rb_idx = (blockIdx.x & 7u) * blocks_per_xcd + (blockIdx.x >> 3);
     if (rb_idx >= a.n_rb) return;
 
@@ -269,7 +330,9 @@ void csx_spmv_kernel(const SpxRowBlock *rbs_, const SpxPass *passes_, uint32_t n
     SpxPass p0 = passes[wave];
     SpxPass p1 = passes[wave + WAVES_PER_BLOCK];         // (the table is padded by one stride)
     const int n_rows = rb.n_rows;
-    for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS) tile[i] = 0.0;
+    const int n_slots = SYM ? (int) rb.n_slots : 0;
+    double *tile = lds + n_slots;
+    for (int i = threadIdx.x; i < n_slots + n_rows; i += BLOCK_THREADS) lds[i] = 0.0;
     __syncthreads();
 
     // wave w takes passes w, w+4, ..., two at a time when they have the same
@@ -280,13 +343,21 @@ void csx_spmv_kernel(const SpxRowBlock *rbs_, const SpxPass *passes_, uint32_t n
     if (a.alpha == 123.0)
 #endif
     for (int t = wave; t < n_pass; t += 2 * WAVES_PER_BLOCK) {
-        if (t + WAVES_PER_BLOCK < n_pass) {
+        const bool two = t + WAVES_PER_BLOCK < n_pass;
+        if (SYM && p0.kind == SPX_PASS_SYMTILE) {
+            symtile_pass(a, rb, p0, lds, tile, lane);
+            if (two) {
+                if (p1.kind == SPX_PASS_SYMTILE) symtile_pass(a, rb, p1, lds, tile, lane);
+                else run_pass(a, rb, p1, tile, lane);
+            }
+        } else if (two) {
             if (p0.kind == p1.kind && p0.width == p1.width) {
                 if (p0.kind == SPX_PASS_GATHER) run_units<2, true>(a, rb, {p0, p1}, tile, lane);
                 else run_units<2, false>(a, rb, {p0, p1}, tile, lane);
             } else {
                 run_pass(a, rb, p0, tile, lane);
-                run_pass(a, rb, p1, tile, lane);
+                if (SYM && p1.kind == SPX_PASS_SYMTILE) symtile_pass(a, rb, p1, lds, tile, lane);
+                else run_pass(a, rb, p1, tile, lane);
             }
         } else {
             run_pass(a, rb, p0, tile, lane);
@@ -310,6 +381,72 @@ void csx_spmv_kernel(const SpxRowBlock *rbs_, const SpxPass *passes_, uint32_t n
             if (a.beta != 0.0) t += a.beta * a.y[g];
             a.y[g] = t;
         }
+    }
+    if (SYM)
+        for (int i = threadIdx.x; i < n_slots; i += BLOCK_THREADS) a.spill[rb.spill_off + i] = lds[i];
+}
+
+#define SPX_KERNEL_PARAMS                                                                        \
+    const SpxRowBlock *rbs_, const SpxPass *passes_, uint32_t n_rb_, uint32_t pass_stride_,      \
+    uint32_t blocks_per_xcd, uint32_t /*pad*/, const double *values_, const SpxUnitDesc *descs_, \
+    const uint8_t *cidx_, const uint16_t *segrows_, const double *x_, double *y_,               \
+    double *carry_, const double *dvalues_, double *spill_, double alpha_, double beta_
+#define SPX_KERNEL_ARGS(a)                                                                       \
+    KernelArgs a;                                                                                \
+    a.rbs = rbs_; a.passes = passes_; a.n_rb = n_rb_; a.pass_stride = pass_stride_;              \
+    a.values = values_; a.descs = descs_; a.cidx = cidx_; a.segrows = segrows_; a.x = x_;        \
+    a.y = y_; a.carry = carry_; a.dvalues = dvalues_; a.spill = spill_; a.alpha = alpha_;        \
+    a.beta = beta_
+
+// (Individual scalar arguments, most urgent first.  Preloading them into SGPRs
+// at wave launch -- hipcc -mllvm -amdgpu-kernarg-preload-count=16 -- was
+// measured: it removes the kernarg fetch in front of the first real load but
+// costs more at dispatch, cant 7.5 -> 8.0 us; not used.)
+__global__ __launch_bounds__(BLOCK_THREADS)
+void csx_spmv_kernel(SPX_KERNEL_PARAMS)
+{
+    SPX_KERNEL_ARGS(a);
+    __shared__ double tile[SPX_MAX_RB_ROWS];
+    spmv_body<false>(a, blocks_per_xcd, tile);
+}
+
+__global__ __launch_bounds__(BLOCK_THREADS)
+void csx_spmv_symtile_kernel(SPX_KERNEL_PARAMS)
+{
+    SPX_KERNEL_ARGS(a);
+    extern __shared__ double lds_dyn[];
+    spmv_body<true>(a, blocks_per_xcd, lds_dyn);
+}
+
+// symmetric tiles, second step: every row collects the transposed sums that
+// other row-blocks spilled for it (fixed order: deterministic).  A workgroup
+// takes eight consecutive rows and spreads each row's entries over 32 slices
+// (wave w, lanes (g, r) = (lane >> 3, lane & 7): row r, entries 8w+g, 8w+g+32,
+// ...), so that a typical row is one entry per lane: three dependent loads
+// deep instead of a loop.  The eight columns of a tile are eight consecutive
+// rows here with consecutive slots: the eight lanes of a slice read one line.
+__global__ __launch_bounds__(256)
+void csx_symfix_kernel(const uint32_t *fix_ptr, const uint32_t *fix_idx,
+                       const double *spill, double *y, double alpha, uint32_t nrows)
+{
+    __shared__ double part[4][8];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t r = lane & 7u;
+    const uint32_t row = blockIdx.x * 8u + r;
+    const uint32_t slice = wave * 8u + (lane >> 3);
+    double s = 0.0;
+    if (row < nrows) {
+        const uint32_t e = fix_ptr[row + 1];
+        for (uint32_t k = fix_ptr[row] + slice; k < e; k += 32u) s += spill[fix_idx[k]];
+    }
+    s += __shfl_xor(s, 8);
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if (lane < 8u) part[wave][lane] = s;
+    __syncthreads();
+    if (threadIdx.x < 8u && row < nrows) {
+        const double t = (part[0][r] + part[1][r]) + (part[2][r] + part[3][r]);
+        if (t != 0.0) y[row] += alpha * t;
     }
 }
 
@@ -362,6 +499,11 @@ struct DeviceMatrix {
     SpxSharedRow *shared = nullptr;
     double *carry = nullptr;
     double *dvalues = nullptr;
+    // symmetric tiles
+    uint32_t n_spill = 0, lds_doubles = SPX_MAX_RB_ROWS;
+    double *spill = nullptr;
+    uint32_t *fix_ptr = nullptr, *fix_idx = nullptr;
+    size_t n_fix_ptr = 0, n_fix_idx = 0;
     // staging vectors of the host-pointer path
     double *d_x = nullptr, *d_y = nullptr;
     double *p_x = nullptr, *p_y = nullptr;      // pinned
@@ -426,6 +568,20 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
         dv.resize(nrows, 0.0);
         m->dvalues = upload(dv);
     }
+    m->n_spill = s.n_spill;
+    m->lds_doubles = s.lds_doubles;
+    if (s.n_spill) {
+        std::vector<double> zero_spill(s.n_spill, 0.0);
+        m->spill = upload(zero_spill);
+        m->fix_ptr = upload(s.fix_ptr);
+        m->fix_idx = upload(s.fix_idx);
+        m->n_fix_ptr = s.fix_ptr.size();
+        m->n_fix_idx = s.fix_idx.size();
+        // (a row-block may need more than the 64 KB a kernel gets by default)
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(csx_spmv_symtile_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(m->lds_doubles * sizeof(double))));
+    }
     m->n_values = s.values.size(); m->n_descs = s.descs.size(); m->n_passes = s.passes.size();
     m->n_cidx = s.cidx.size(); m->n_segrows = s.segrows.size();
     m->value_bytes = s.values.size() * sizeof(double);
@@ -441,6 +597,9 @@ void device_free(DeviceMatrix *m)
     (void) hipFree(m->cidx); (void) hipFree(m->segrows); (void) hipFree(m->shared);
     (void) hipFree(m->carry);
     if (m->dvalues) (void) hipFree(m->dvalues);
+    if (m->spill) (void) hipFree(m->spill);
+    if (m->fix_ptr) (void) hipFree(m->fix_ptr);
+    if (m->fix_idx) (void) hipFree(m->fix_idx);
     if (m->d_x) (void) hipFree(m->d_x);
     if (m->d_y) (void) hipFree(m->d_y);
     if (m->p_x) (void) hipHostFree(m->p_x);
@@ -471,11 +630,22 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
                            m->own_lo, m->own_hi, alpha, beta);
         a.beta = beta = 1.0;
     }
-    if (blocks)
+    a.spill = m->spill;
+    if (blocks && m->n_spill) {
+        // symmetric tiles: slots + y tile in dynamic LDS, then the rows collect
+        // what other row-blocks spilled for them
+        hipLaunchKernelGGL(csx_spmv_symtile_kernel, dim3(blocks), dim3(BLOCK_THREADS),
+                           m->lds_doubles * sizeof(double), stream, a.rbs, a.passes, a.n_rb,
+                           a.pass_stride, blocks >> 3, 0u, a.values, a.descs, a.cidx, a.segrows,
+                           a.x, a.y, a.carry, a.dvalues, a.spill, a.alpha, a.beta);
+        hipLaunchKernelGGL(csx_symfix_kernel, dim3((unsigned)((m->nrows + 7) / 8)), dim3(256), 0,
+                           stream, m->fix_ptr, m->fix_idx, m->spill, d_y, alpha, (uint32_t) m->nrows);
+    } else if (blocks) {
         hipLaunchKernelGGL(csx_spmv_kernel, dim3(blocks), dim3(BLOCK_THREADS), 0, stream, a.rbs,
                            a.passes, a.n_rb, a.pass_stride, blocks >> 3, 0u, a.values, a.descs,
-                           a.cidx, a.segrows,
-                           a.x, a.y, a.carry, a.dvalues, a.alpha, a.beta);
+                           a.cidx, a.segrows, a.x, a.y, a.carry, a.dvalues, a.spill, a.alpha,
+                           a.beta);
+    }
     if (m->n_shared)
         hipLaunchKernelGGL(csx_fixup_kernel, dim3((m->n_shared + 63) / 64), dim3(64), 0,
                            stream, m->shared, m->n_shared, m->carry, d_y, alpha, beta,
@@ -534,6 +704,12 @@ void device_download(const DeviceMatrix *m, GpuStream &s)
     s.n_carry = m->n_carry;
     s.sym_fused = m->sym_fused;
     s.pass_stride = m->pass_stride;
+    s.n_spill = m->n_spill;
+    s.lds_doubles = m->lds_doubles;
+    if (m->n_spill) {
+        download(s.fix_ptr, m->fix_ptr, m->n_fix_ptr);
+        download(s.fix_idx, m->fix_idx, m->n_fix_idx);
+    }
     if (m->symmetric) download(s.dvalues, m->dvalues, m->nrows);
 }
 

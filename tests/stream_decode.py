@@ -9,8 +9,8 @@ import numpy as np
 
 RB = np.dtype([("val_off", "<u8"), ("pass_off", "<u4"), ("desc_off", "<u4"), ("cidx_off", "<u4"),
                ("seg_off", "<u4"), ("cbase", "<u4"), ("row0", "<u4"), ("n_rows", "<u2"),
-               ("n_pass", "<u2"), ("cidx_width", "u1"), ("flags", "u1"), ("pad", "<u2"),
-               ("carry_slot", "<u4"), ("pad2", "<u4")])
+               ("n_pass", "<u2"), ("cidx_width", "u1"), ("flags", "u1"), ("n_slots", "<u2"),
+               ("carry_slot", "<u4"), ("spill_off", "<u4")])
 PASS = np.dtype([("mask", "<u8"), ("val_off", "<u4"), ("rank0", "<u2"), ("seg0", "<u2"),
                  ("nseg", "u1"), ("width", "u1"), ("kind", "u1"), ("pad", "u1"), ("elem0", "<u4")])
 DESC = np.dtype([("col0", "<u4"), ("bits", "<u4")])
@@ -24,13 +24,14 @@ class Stream:
     def __init__(self, path):
         with open(path, "rb") as f:
             buf = f.read()
-        assert buf[:8] == b"SPXHIP05", buf[:8]
-        hdr = struct.unpack_from("<4i3Q2i4Q2I", buf, 8)
+        assert buf[:8] == b"SPXHIP06", buf[:8]
+        hdr = struct.unpack_from("<4i3Q2i4Q4I", buf, 8)
         (self.nrows, self.ncols, self.nnz, self.symmetric, self.nr_partitions, self.first_part,
          self.last_part, self.own_lo, self.own_hi, self.nnz_stored, self.n_unit_elems,
-         self.n_delta_elems, self.n_units, self.n_carry, flags) = hdr
+         self.n_delta_elems, self.n_units, self.n_carry, flags, self.n_spill, self.lds_doubles) = hdr
         self.sym_fused = bool(flags & 1)
-        self.off = 8 + struct.calcsize("<4i3Q2i4Q2I")
+        self.pass_stride = flags >> 1
+        self.off = 8 + struct.calcsize("<4i3Q2i4Q4I")
         self.buf = buf
 
         def vec(dt):
@@ -48,12 +49,15 @@ class Stream:
         self.shared = vec(SHARED)
         self.dvalues = vec("<f8")
         self.values = vec("<f8")
+        self.fix_ptr = vec("<u4")
+        self.fix_idx = vec("<u4")
         self.perm = vec("<i4")
         assert self.off == len(buf)
 
     def triplets(self):
         """(row, col, value, rowblock) of every stored nonzero, as the kernel's lanes see them."""
         R, Cc, V, B = [], [], [], []
+        self._tile_adds = []         # (row-block, slot of the column, value, global row) per tile nonzero
         for bi, rb in enumerate(self.rbs):
             vbase = int(rb["val_off"])
             for ps in self.passes[int(rb["pass_off"]):int(rb["pass_off"]) + int(rb["n_pass"])]:
@@ -103,6 +107,25 @@ class Stream:
                         off = sum(self.cidx[o + b].astype(np.int64) << (8 * b) for b in range(cw))
                         R.append(row + int(rb["row0"])); Cc.append(off + int(rb["cbase"]))
                         V.append(self.values[pv + idx]); B.append(np.full(nseg, bi))
+                elif ps["kind"] == 3:
+                    # symmetric tiles: lanes 8t..8t+7 = rows of tile t; every value counts twice
+                    nseg = int(ps["nseg"])
+                    assert nseg % 8 == 0 and 8 <= nseg <= 64 and int(ps["width"]) == 8 and self.sym_fused
+                    lanes = np.arange(nseg)
+                    d = self.descs[int(rb["desc_off"]) + int(ps["rank0"]) + (lanes >> 3)]
+                    bits = d["bits"].astype(np.int64)
+                    row = (bits & 511) + (lanes & 7)
+                    slot = bits >> 9
+                    assert (row < int(rb["n_rows"])).all()
+                    assert (slot + 8 <= int(rb["n_slots"]) + int(rb["n_rows"])).all()
+                    col0 = d["col0"].astype(np.int64)
+                    assert (col0 + 7 < row + int(rb["row0"])).all()          # strictly below the diagonal
+                    for w in range(8):
+                        idx = (w >> 1) * 2 * nseg + lanes * 2 + (w & 1)
+                        v = self.values[pv + idx]
+                        R.append(row + int(rb["row0"])); Cc.append(col0 + w); V.append(v); B.append(np.full(nseg, bi))
+                        R.append(col0 + w); Cc.append(row + int(rb["row0"])); V.append(v); B.append(np.full(nseg, -1 - bi))
+                        self._tile_adds.append((bi, slot + w, v, row + int(rb["row0"])))
                 else:
                     raise AssertionError("unknown pass kind %d" % int(ps["kind"]))
         if not R:
@@ -111,10 +134,28 @@ class Stream:
         return np.concatenate(R), np.concatenate(Cc), np.concatenate(V), np.concatenate(B)
 
     def matvec(self, x):
-        """y = A x as the stream defines it (symmetric: the diagonal comes from dvalues)."""
-        r, c, v, _ = self.triplets()
+        """y = A x the way the kernels compute it: nonzeros into the rows of their row-block,
+        the transposed contributions of the symmetric tiles through their slots -- own rows
+        directly, the others through spill[] and the per-row fix lists -- and the diagonal from
+        dvalues."""
+        r, c, v, b = self.triplets()
         y = np.zeros(self.nrows)
-        np.add.at(y, r, v * x[c])
+        direct = b >= 0                     # (mirrored tile entries are routed through the slots below)
+        np.add.at(y, r[direct], v[direct] * x[c[direct]])
+        spill = np.zeros(self.n_spill)
+        for bi, slot, val, grow in self._tile_adds:
+            rb = self.rbs[bi]
+            ns = int(rb["n_slots"])
+            contrib = val * x[grow]
+            own = slot >= ns
+            np.add.at(y, int(rb["row0"]) + slot[own] - ns, contrib[own])
+            np.add.at(spill, int(rb["spill_off"]) + slot[~own], contrib[~own])
+        if self.n_spill:
+            assert self.fix_ptr.size == self.nrows + 1 and self.fix_idx.size == self.n_spill
+            assert np.array_equal(np.sort(self.fix_idx), np.arange(self.n_spill))
+            sums = np.add.reduceat(np.append(spill[self.fix_idx], 0.0), self.fix_ptr[:-1].astype(np.int64))
+            sums[np.diff(self.fix_ptr.astype(np.int64)) == 0] = 0.0
+            y += sums
         if self.symmetric:
             y[self.own_lo:self.own_hi] += (self.dvalues * x[:self.dvalues.size])[self.own_lo:self.own_hi]
         return y

@@ -122,12 +122,17 @@ def test_every_nonzero_exactly_once_and_product_matches(gen, opts):
 def test_symmetric_partitions_and_product():
     csr = synth.syn_cant(0.04)
     rp, ci, va, n = csr
-    A = tune(csr, {"spx.preproc.sampling": "none", "spx.rt.nr_threads": "3"}, sym=True,
-             host_only=True)
+    lower = synth.lower_plus_diag_nnz(rp, ci) - n
+    # default: dense 8x8 tiles once, the rest and its mirror image (plus the odd explicit
+    # zero on the diagonal that joins two runs)
+    B = tune(csr, {"spx.preproc.sampling": "none", "spx.rt.nr_threads": "3"}, sym=True, host_only=True)
+    assert lower <= B.info().nnz_stored <= 2 * lower + n
+    A = tune(csr, {"spx.preproc.sampling": "none", "spx.rt.nr_threads": "3", "spx.gpu.sym_once": "false"},
+             sym=True, host_only=True)
     inf = A.info()
     assert inf.symmetric == 1
-    # HBM holds the strictly lower triangle and its mirror image
-    assert inf.nnz_stored == 2 * (synth.lower_plus_diag_nnz(rp, ci) - n)
+    # mirrored stream: HBM holds the strictly lower triangle and its mirror image
+    assert inf.nnz_stored == 2 * lower
     x = synth.random_x(n)
     yo, ex = oracle_y(A, x, 0.5)
     check_y(csr, x, yo, 0.5)
