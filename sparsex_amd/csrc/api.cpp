@@ -338,10 +338,9 @@ static void emit_and_upload(spx_matrix_t *A)
         // does not touch are zeroed by the init kernel) to be summed later.
         gs.sym_fused = A->own_lo == 0 && A->own_hi == A->nrows;
         std::vector<SymTile> tiles;
-        if (gs.sym_fused && gp.sym_once) {
-            // ... and it can read the dense 8x8 tiles of the lower triangle once
-            // and use them twice (SPX_PASS_SYMTILE); everything else is
-            // mirrored as below
+        if (gp.sym_once) {
+            // the dense 8x8 tiles of the lower triangle are read once and used
+            // twice (SPX_PASS_SYMTILE); everything else is mirrored as below
             build_sym_once(A->parts, full, tiles);
             gp.tiles = &tiles;
         } else {

@@ -419,35 +419,29 @@ void csx_spmv_symtile_kernel(SPX_KERNEL_PARAMS)
 }
 
 // symmetric tiles, second step: every row collects the transposed sums that
-// other row-blocks spilled for it (fixed order: deterministic).  A workgroup
-// takes eight consecutive rows and spreads each row's entries over 32 slices
-// (wave w, lanes (g, r) = (lane >> 3, lane & 7): row r, entries 8w+g, 8w+g+32,
-// ...), so that a typical row is one entry per lane: three dependent loads
-// deep instead of a loop.  The eight columns of a tile are eight consecutive
-// rows here with consecutive slots: the eight lanes of a slice read one line.
+// other row-blocks spilled for it (fixed order: deterministic).  A wavefront
+// takes eight consecutive rows, lanes (g, r) = (lane >> 3, lane & 7): row r's
+// entries g, g+8, ...  The eight columns of a tile are eight consecutive rows
+// here with consecutive slots, so the eight lanes of a g read one 64-byte line.
+// (Measured: one thread per row 16.4 us, this 9.1 us, a workgroup per eight
+// rows 9.6 us on syn-nd24k -- the kernel is bound by its ~300 k scattered
+// line requests, not by the depth of its loop.)
 __global__ __launch_bounds__(256)
 void csx_symfix_kernel(const uint32_t *fix_ptr, const uint32_t *fix_idx,
                        const double *spill, double *y, double alpha, uint32_t nrows)
 {
-    __shared__ double part[4][8];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t r = lane & 7u;
-    const uint32_t row = blockIdx.x * 8u + r;
-    const uint32_t slice = wave * 8u + (lane >> 3);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t row = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 8u + (lane & 7u);
+    const uint32_t g = lane >> 3;
     double s = 0.0;
     if (row < nrows) {
         const uint32_t e = fix_ptr[row + 1];
-        for (uint32_t k = fix_ptr[row] + slice; k < e; k += 32u) s += spill[fix_idx[k]];
+        for (uint32_t k = fix_ptr[row] + g; k < e; k += 8u) s += spill[fix_idx[k]];
     }
     s += __shfl_xor(s, 8);
     s += __shfl_xor(s, 16);
     s += __shfl_xor(s, 32);
-    if (lane < 8u) part[wave][lane] = s;
-    __syncthreads();
-    if (threadIdx.x < 8u && row < nrows) {
-        const double t = (part[0][r] + part[1][r]) + (part[2][r] + part[3][r]);
-        if (t != 0.0) y[row] += alpha * t;
-    }
+    if (g == 0 && row < nrows && s != 0.0) y[row] += alpha * s;
 }
 
 // rows split over several row-blocks: sum their partials
@@ -638,7 +632,7 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
                            m->lds_doubles * sizeof(double), stream, a.rbs, a.passes, a.n_rb,
                            a.pass_stride, blocks >> 3, 0u, a.values, a.descs, a.cidx, a.segrows,
                            a.x, a.y, a.carry, a.dvalues, a.spill, a.alpha, a.beta);
-        hipLaunchKernelGGL(csx_symfix_kernel, dim3((unsigned)((m->nrows + 7) / 8)), dim3(256), 0,
+        hipLaunchKernelGGL(csx_symfix_kernel, dim3((unsigned)((m->nrows + 31) / 32)), dim3(256), 0,
                            stream, m->fix_ptr, m->fix_idx, m->spill, d_y, alpha, (uint32_t) m->nrows);
     } else if (blocks) {
         hipLaunchKernelGGL(csx_spmv_kernel, dim3(blocks), dim3(BLOCK_THREADS), 0, stream, a.rbs,

@@ -110,7 +110,7 @@ class Stream:
                 elif ps["kind"] == 3:
                     # symmetric tiles: lanes 8t..8t+7 = rows of tile t; every value counts twice
                     nseg = int(ps["nseg"])
-                    assert nseg % 8 == 0 and 8 <= nseg <= 64 and int(ps["width"]) == 8 and self.sym_fused
+                    assert nseg % 8 == 0 and 8 <= nseg <= 64 and int(ps["width"]) == 8 and self.symmetric
                     lanes = np.arange(nseg)
                     d = self.descs[int(rb["desc_off"]) + int(ps["rank0"]) + (lanes >> 3)]
                     bits = d["bits"].astype(np.int64)

@@ -137,3 +137,26 @@ def test_long_rows_are_shared_and_complete(tmp_path):
     r, c, v, b, m = dense_of(s)
     assert abs(m.tocsr() - a).max() == 0
     s.check_ownership()
+
+
+@pytest.mark.parametrize("once", ["true", "false"])
+def test_symmetric_slices_sum_to_the_product(tmp_path, once):
+    """Two processes, each holding half of the partitions of a symmetric matrix: their streams
+    (tiles read once where there are any, the rest mirrored) give partial vectors that sum to A x."""
+    csr = synth.syn_nd24k(0.03)
+    rp, ci, va, n = csr
+    a = sp.csr_matrix((va, ci, rp), shape=(n, n))
+    x = synth.random_x(n)
+    y = np.zeros(n)
+    tiles = 0
+    for rank in range(2):
+        A = tune(csr, {"spx.preproc.sampling": "none", "spx.rt.nr_threads": "4", "spx.rt.gpu_world": "2",
+                       "spx.rt.gpu_rank": str(rank), "spx.gpu.sym_once": once}, sym=True, host_only=True)
+        f = str(tmp_path / ("m%d.spx" % rank))
+        A.save(f)
+        s = Stream(f)
+        assert not s.sym_fused
+        y += s.matvec(x)
+        tiles += int((s.passes["kind"] == 3).sum())
+    assert np.allclose(y, a @ x, rtol=1e-12, atol=1e-14)
+    assert (tiles > 0) == (once == "true")
