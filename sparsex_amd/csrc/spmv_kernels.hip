@@ -494,6 +494,7 @@ struct DeviceMatrix {
     double *carry = nullptr;
     double *dvalues = nullptr;
     // symmetric tiles
+    bool has_tiles = false;
     uint32_t n_spill = 0, lds_doubles = SPX_MAX_RB_ROWS;
     double *spill = nullptr;
     uint32_t *fix_ptr = nullptr, *fix_idx = nullptr;
@@ -564,6 +565,14 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
     }
     m->n_spill = s.n_spill;
     m->lds_doubles = s.lds_doubles;
+    for (const SpxRowBlock &rb : s.rbs)
+        for (uint32_t k = 0; k < rb.n_pass && !m->has_tiles; ++k)
+            m->has_tiles = s.passes[rb.pass_off + k].kind == SPX_PASS_SYMTILE;
+    if (m->has_tiles)
+        // (a row-block may need more than the 64 KB a kernel gets by default)
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(csx_spmv_symtile_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(m->lds_doubles * sizeof(double))));
     if (s.n_spill) {
         std::vector<double> zero_spill(s.n_spill, 0.0);
         m->spill = upload(zero_spill);
@@ -571,10 +580,6 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
         m->fix_idx = upload(s.fix_idx);
         m->n_fix_ptr = s.fix_ptr.size();
         m->n_fix_idx = s.fix_idx.size();
-        // (a row-block may need more than the 64 KB a kernel gets by default)
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(csx_spmv_symtile_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)(m->lds_doubles * sizeof(double))));
     }
     m->n_values = s.values.size(); m->n_descs = s.descs.size(); m->n_passes = s.passes.size();
     m->n_cidx = s.cidx.size(); m->n_segrows = s.segrows.size();
@@ -625,15 +630,17 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
         a.beta = beta = 1.0;
     }
     a.spill = m->spill;
-    if (blocks && m->n_spill) {
+    if (blocks && m->has_tiles) {
         // symmetric tiles: slots + y tile in dynamic LDS, then the rows collect
         // what other row-blocks spilled for them
         hipLaunchKernelGGL(csx_spmv_symtile_kernel, dim3(blocks), dim3(BLOCK_THREADS),
                            m->lds_doubles * sizeof(double), stream, a.rbs, a.passes, a.n_rb,
                            a.pass_stride, blocks >> 3, 0u, a.values, a.descs, a.cidx, a.segrows,
                            a.x, a.y, a.carry, a.dvalues, a.spill, a.alpha, a.beta);
-        hipLaunchKernelGGL(csx_symfix_kernel, dim3((unsigned)((m->nrows + 31) / 32)), dim3(256), 0,
-                           stream, m->fix_ptr, m->fix_idx, m->spill, d_y, alpha, (uint32_t) m->nrows);
+        if (m->n_spill)
+            hipLaunchKernelGGL(csx_symfix_kernel, dim3((unsigned)((m->nrows + 31) / 32)), dim3(256),
+                               0, stream, m->fix_ptr, m->fix_idx, m->spill, d_y, alpha,
+                               (uint32_t) m->nrows);
     } else if (blocks) {
         hipLaunchKernelGGL(csx_spmv_kernel, dim3(blocks), dim3(BLOCK_THREADS), 0, stream, a.rbs,
                            a.passes, a.n_rb, a.pass_stride, blocks >> 3, 0u, a.values, a.descs,

@@ -160,3 +160,51 @@ def test_symmetric_slices_sum_to_the_product(tmp_path, once):
         tiles += int((s.passes["kind"] == 3).sum())
     assert np.allclose(y, a @ x, rtol=1e-12, atol=1e-14)
     assert (tiles > 0) == (once == "true")
+
+
+def _one_rowblock_sym():
+    """12 x 12 blocks of 8 x 8, block (i, j) present for j in {i, i-1, i-3}: small enough for ONE row-block."""
+    nb = 12
+    rng = np.random.RandomState(17)
+    br = [i for i in range(nb) for d in (0, 1, 3) if i - d >= 0]
+    bc = [i - d for i in range(nb) for d in (0, 1, 3) if i - d >= 0]
+    a8, b8 = np.meshgrid(np.arange(8), np.arange(8), indexing="ij")
+    r = (np.array(br)[:, None] * 8 + a8.ravel()[None, :]).ravel()
+    c = (np.array(bc)[:, None] * 8 + b8.ravel()[None, :]).ravel()
+    low = sp.coo_matrix((rng.uniform(-1, 1, r.size), (r, c)), shape=(nb * 8, nb * 8)).tocsr()
+    low = sp.tril(low, k=-1)
+    m = (low + low.T + sp.diags(np.asarray(abs(low + low.T).sum(axis=1)).ravel() + 1.0)).tocsr()
+    m.sort_indices()
+    csr = (m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data.copy(), nb * 8)
+    opts = {"spx.preproc.sampling": "none", "spx.gpu.rowblock_elems": "8192", "spx.gpu.rowblock_rows": "512"}
+    return csr, opts
+
+
+def test_symmetric_tiles_inside_a_single_rowblock_need_no_spill(tmp_path):
+    csr, opts = _one_rowblock_sym()
+    rp, ci, va, n = csr
+    A = tune(csr, opts, sym=True, host_only=True)
+    f = str(tmp_path / "m.spx")
+    A.save(f)
+    s = Stream(f)
+    assert len(s.rbs) == 1 and (s.passes["kind"][:int(s.rbs[0]["n_pass"])] == 3).any()
+    assert s.n_spill == 0 and int(s.rbs[0]["n_slots"]) == 0       # every tile column is an own row
+    a = sp.csr_matrix((va, ci, rp), shape=(n, n))
+    x = synth.random_x(n)
+    assert np.allclose(s.matvec(x), a @ x, rtol=1e-12, atol=1e-14)
+
+
+@pytest.mark.gpu
+def test_symmetric_tiles_inside_a_single_rowblock_gpu():
+    from helpers import check_y
+    csr, opts = _one_rowblock_sym()
+    n = csr[3]
+    A = tune(csr, opts, sym=True)
+    x = synth.random_x(n)
+    y = np.full(n, np.nan)
+    A.matvec_mult(0.5, x, y)
+    check_y(csr, x, y, 0.5)
+    y0 = synth.random_x(n, seed=3)
+    y = y0.copy()
+    A.matvec_kernel(-1.5, x, 0.5, y)
+    check_y(csr, x, y, -1.5, 0.5, y0)
