@@ -491,6 +491,7 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     A->emit_params.max_rows = (size_t) std::max<long>(1, cfg.get_long("spx.gpu.rowblock_rows"));
     A->emit_params.sym_remine = cfg.get_bool("spx.gpu.sym_remine");
     A->emit_params.sym_once = cfg.get_bool("spx.gpu.sym_once");
+    A->emit_params.recut_linear = cfg.get_bool("spx.gpu.recut_linear");
     A->emit_params.stack_segments = cfg.get_bool("spx.gpu.stack_segments");
     {
         idx_t lo = nown ? A->bounds[first].row_start : 0;

@@ -17,6 +17,7 @@ struct Piece {
 };
 
 struct Single { idx_t row, col; val_t val; };   // 0-based row (partition), 0-based col
+struct RowSeg { idx_t row, col; uint8_t width; val_t v[SPX_MAX_SEG_WIDTH]; };   // same numbering
 
 struct Plan {
     idx_t row_lo, row_hi;   // rows [lo, hi) of the partition
@@ -47,7 +48,8 @@ public:
     // emits one row-block for rows [lo, hi) from the given pieces/singles
     void emit(idx_t lo, idx_t hi, const std::vector<Piece> &pieces,
               std::vector<Single> &singles, uint8_t flags, uint32_t carry_slot,
-              const std::vector<const SymTile *> *tiles = nullptr);
+              const std::vector<const SymTile *> *tiles = nullptr,
+              const std::vector<RowSeg> *rowsegs = nullptr);
 
 private:
     void add_group(idx_t row, idx_t col, size_t nseg, size_t width, unsigned kind, unsigned step)
@@ -415,7 +417,7 @@ void RbBuilder::emit_tile_passes(SpxRowBlock &rb, const std::vector<const SymTil
 
 void RbBuilder::emit(idx_t lo, idx_t hi, const std::vector<Piece> &pieces,
                      std::vector<Single> &singles, uint8_t flags, uint32_t carry_slot,
-                     const std::vector<const SymTile *> *tiles)
+                     const std::vector<const SymTile *> *tiles, const std::vector<RowSeg> *rowsegs)
 {
     SpxRowBlock rb;
     std::memset(&rb, 0, sizeof(rb));
@@ -432,6 +434,11 @@ void RbBuilder::emit(idx_t lo, idx_t hi, const std::vector<Piece> &pieces,
     groups_.clear();
     gvals_.clear();
     for (const Piece &pc : pieces) groups_from_piece(pc, lo);
+    if (rowsegs)
+        for (const RowSeg &sg : *rowsegs) {
+            add_group(sg.row - lo, sg.col, 1, sg.width, SPX_KIND_HORIZ, 0);
+            gvals_.insert(gvals_.end(), sg.v, sg.v + sg.width);
+        }
     const size_t n_unit = gvals_.size();
     if (stack_) stack_groups();
     emit_unit_passes(rb);
@@ -767,6 +774,7 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out)
 
     // 3. cut every unit at row-block borders
     std::vector<std::vector<Piece>> pieces(plans.size());
+    std::vector<std::vector<Piece>> lin_pieces(plans.size());   // of one-nonzero-per-lane units
     std::vector<std::vector<Single>> singles(plans.size());
     auto add_singles = [&](const Elem &u, size_t k0, size_t k1) {
         for (size_t k = k0; k < k1; ++k) {
@@ -819,9 +827,76 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out)
             }
             const bool wide_step = e.delta > SPX_MAX_STEP && !enc_is_block(e.type) &&
                                    !(e.type == ENC_H && e.delta == 1);
+            const bool one_wide = !enc_is_block(e.type) && !(e.type == ENC_H && e.delta == 1);
             if (plans[pl].split || k1 - k0 <= 2 || wide_step) add_singles(e, k0, k1);
+            else if (one_wide && prm.recut_linear)
+                lin_pieces[pl].push_back(Piece{(uint32_t) i, (uint16_t) k0, (uint16_t) k1});
             else pieces[pl].push_back(Piece{(uint32_t) i, (uint16_t) k0, (uint16_t) k1});
             k0 = k1;
+        }
+    }
+
+    // 3a. vertical, diagonal, anti-diagonal and strided units give one nonzero
+    // per lane.  Where the nonzeros of such units sit next to each other along
+    // their rows (a 27-point stencil mined as diagonals: six consecutive columns
+    // per row), the row-block takes them as row segments instead -- the units
+    // were right for a CPU that walks one unit at a time, the lanes want width.
+    std::vector<std::vector<RowSeg>> rowsegs(plans.size());
+    {
+        std::vector<Single> pts;
+        for (size_t pl = 0; prm.recut_linear && pl < plans.size(); ++pl) {
+            pts.clear();
+            for (const Piece &pc : lin_pieces[pl]) {
+                const Elem &u = p.elems[pc.elem];
+                for (size_t k = pc.a; k < pc.b; ++k) {
+                    idx_t r, c;
+                    unit_elem_coords(u, k, r, c);
+                    pts.push_back(Single{r - 1, c - 1, p.pool[u.voff + k]});
+                }
+            }
+            std::sort(pts.begin(), pts.end(), [](const Single &a, const Single &b) {
+                return a.row < b.row || (a.row == b.row && a.col < b.col);
+            });
+            size_t nseg = 0;
+            for (size_t a = 0; a < pts.size(); ++nseg) {
+                size_t b = a + 1;
+                while (b < pts.size() && b - a < SPX_MAX_SEG_WIDTH && pts[b].row == pts[a].row &&
+                       pts[b].col == pts[b - 1].col + 1)
+                    ++b;
+                a = b;
+            }
+            if (pts.size() * 4 < nseg * 7) {        // below 1.75 nonzeros per segment: keep the units
+                pieces[pl].insert(pieces[pl].end(), lin_pieces[pl].begin(), lin_pieces[pl].end());
+                pts.clear();
+            }
+            // the leftover nonzeros of the row-block join in: next to a segment
+            // they widen it, next to each other they form one
+            if (pts.empty() && singles[pl].size() < 2) continue;
+            if (plans[pl].split) continue;
+            pts.insert(pts.end(), singles[pl].begin(), singles[pl].end());
+            singles[pl].clear();
+            std::sort(pts.begin(), pts.end(), [](const Single &a, const Single &b) {
+                return a.row < b.row || (a.row == b.row && a.col < b.col);
+            });
+            for (size_t a = 0; a < pts.size();) {
+                size_t b = a + 1;
+                while (b < pts.size() && b - a < SPX_MAX_SEG_WIDTH && pts[b].row == pts[a].row &&
+                       pts[b].col == pts[b - 1].col + 1)
+                    ++b;
+                if (b - a < 3) {
+                    // (pairs stay leftovers: a width-2 unit pass of a few lanes per
+                    // row-block costs more than two gathered nonzeros)
+                    for (size_t k = a; k < b; ++k) singles[pl].push_back(pts[k]);
+                } else {
+                    RowSeg sg;
+                    sg.row = pts[a].row;
+                    sg.col = pts[a].col;
+                    sg.width = (uint8_t)(b - a);
+                    for (size_t k = a; k < b; ++k) sg.v[k - a] = pts[k].val;
+                    rowsegs[pl].push_back(sg);
+                }
+                a = b;
+            }
         }
     }
 
@@ -870,9 +945,11 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out)
     RbBuilder bld(p, out, prm.stack_segments);
     for (size_t i = 0; i < plans.size(); ++i) {
         const Plan &pl = plans[i];
-        if (prm.skip_empty && pieces[i].empty() && singles[i].empty() && rb_tiles[i].empty()) continue;
+        if (prm.skip_empty && pieces[i].empty() && singles[i].empty() && rb_tiles[i].empty() &&
+            rowsegs[i].empty())
+            continue;
         if (!pl.split) {
-            bld.emit(pl.row_lo, pl.row_hi, pieces[i], singles[i], 0, 0, &rb_tiles[i]);
+            bld.emit(pl.row_lo, pl.row_hi, pieces[i], singles[i], 0, 0, &rb_tiles[i], &rowsegs[i]);
             continue;
         }
         // an over-long row: everything is a single here; chunk it

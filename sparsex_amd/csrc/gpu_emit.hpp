@@ -70,6 +70,8 @@ struct GpuEmitParams {
     bool skip_empty = false;      // accumulate mode: rows without nonzeros need no write
     bool stack_segments = true;   // spx.gpu.stack_segments: equal row segments of consecutive
                                   // rows share one descriptor as a dense block
+    bool recut_linear = true;     // spx.gpu.recut_linear: nonzeros of vertical / diagonal /
+                                  // strided units that line up along their rows run as row segments
     bool sym_remine = true;       // spx.gpu.sym_remine (see append_sym_expanded)
     bool sym_once = true;         // spx.gpu.sym_once: dense 8x8 tiles of a symmetric matrix are
                                   // read once (one process holding the whole matrix only)
