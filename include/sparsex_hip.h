@@ -20,6 +20,8 @@
  *   spx.gpu.rowblock_rows   max rows per row-block (default and cap 512)
  *   spx.gpu.stack_segments  "false": one descriptor per CSX unit piece instead
  *                           of merging equal row segments of consecutive rows
+ *   spx.gpu.recut_linear    "false": vertical / diagonal / strided units always run one
+ *                           nonzero per lane, even where they line up along rows
  *   spx.gpu.sym_once        "false": symmetric path reads lower triangle and mirror
  *                           image (default: dense 8x8 tiles are read once)
  *   spx.gpu.sym_remine      "false": symmetric path mirrors unit by unit
