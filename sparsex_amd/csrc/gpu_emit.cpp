@@ -140,85 +140,127 @@ void RbBuilder::groups_from_piece(const Piece &pc, idx_t lo)
     gvals_.insert(gvals_.end(), src + pc.a, src + pc.b);
 }
 
-// Row segments that sit on top of each other (same columns, consecutive rows)
-// share one descriptor as a dense block, whatever units they came from: the
-// pieces of a cut block, horizontal units of neighbouring rows, chunks of wide
-// horizontal units.  Fewer descriptors, same lanes.
+// Equal row segments that follow a regular course share one descriptor,
+// whatever units they came from (the pieces of a cut block, horizontal units of
+// neighbouring rows, the chunks of a wide horizontal unit, re-cut stencil rows):
+//   * along a diagonal -- same width, rows and first columns advancing by the
+//     same step (a stencil; the 3x3 node blocks of an FE matrix, row by row);
+//     long chains (>= 8 segments) are taken first,
+//   * on top of each other -- same columns, consecutive rows: a dense block,
+//   * next to each other in one row (full chunks),
+//   * short diagonal chains among what is left.
+// Fewer descriptors, same lanes.
 void RbBuilder::stack_groups()
 {
-    struct Run { uint16_t row0, nrows; uint32_t col0; uint32_t voff; uint8_t width; };
+    struct Run { uint16_t row0; uint32_t col0; uint32_t voff; uint8_t width; };   // one row segment
     std::vector<Run> runs;
     std::vector<Group> kept;
     for (const Group &g : groups_) {
         if (g.kind == SPX_KIND_BLOCK || g.nseg == 1) {
-            runs.push_back(Run{g.row0, g.nseg, g.col0, g.voff, g.width});
+            for (uint32_t s = 0; s < g.nseg; ++s)
+                runs.push_back(Run{(uint16_t)(g.row0 + s), g.col0, g.voff + s * g.width, g.width});
         } else if (g.kind == SPX_KIND_HORIZ && g.step == SPX_HORIZ_CHUNK && g.width == SPX_HORIZ_CHUNK) {
             for (uint32_t s = 0; s < g.nseg; ++s)
-                runs.push_back(Run{g.row0, 1, g.col0 + s * SPX_HORIZ_CHUNK, g.voff + s * SPX_HORIZ_CHUNK,
-                                   g.width});
+                runs.push_back(Run{g.row0, g.col0 + s * SPX_HORIZ_CHUNK, g.voff + s * SPX_HORIZ_CHUNK, g.width});
         } else {
             kept.push_back(g);
         }
     }
     if (runs.empty()) return;
-    std::sort(runs.begin(), runs.end(), [](const Run &a, const Run &b) {
-        if (a.width != b.width) return a.width < b.width;
-        if (a.col0 != b.col0) return a.col0 < b.col0;
-        return a.row0 < b.row0;
-    });
     std::vector<val_t> vals;
     vals.reserve(gvals_.size());
-    auto copy_vals = [&](const Group &g) {
-        uint32_t off = (uint32_t) vals.size();
+    for (Group &g : kept) {
+        const uint32_t off = (uint32_t) vals.size();
         vals.insert(vals.end(), gvals_.begin() + g.voff, gvals_.begin() + g.voff + (size_t) g.nseg * g.width);
-        return off;
-    };
-    for (Group &g : kept) g.voff = copy_vals(g);
-    std::vector<Group> lone;     // width-8 segments left alone: chained along their row again
-    for (size_t i = 0; i < runs.size();) {
+        g.voff = off;
+    }
+    // emits runs[idx[i..j)] as one group
+    auto emit_chain = [&](const std::vector<uint32_t> &idx, size_t i, size_t j, unsigned kind, unsigned step) {
+        const Run &r0 = runs[idx[i]];
         Group g;
-        g.row0 = runs[i].row0;
-        g.col0 = runs[i].col0;
-        g.width = runs[i].width;
-        g.kind = SPX_KIND_BLOCK;
-        g.step = 0;
-        g.voff = (uint32_t) vals.size();
-        size_t rows = 0, j = i;
-        while (j < runs.size() && runs[j].width == g.width && runs[j].col0 == g.col0 &&
-               runs[j].row0 == g.row0 + rows) {
-            vals.insert(vals.end(), gvals_.begin() + runs[j].voff,
-                        gvals_.begin() + runs[j].voff + (size_t) runs[j].nrows * g.width);
-            rows += runs[j].nrows;
-            ++j;
-        }
-        g.nseg = (uint16_t) rows;
-        if (rows == 1 && g.width == SPX_HORIZ_CHUNK) lone.push_back(g);
-        else kept.push_back(g);
-        i = j;
-    }
-    std::sort(lone.begin(), lone.end(), [](const Group &a, const Group &b) {
-        return a.row0 != b.row0 ? a.row0 < b.row0 : a.col0 < b.col0;
-    });
-    for (size_t i = 0; i < lone.size();) {
-        Group g = lone[i];
-        g.kind = SPX_KIND_HORIZ;
-        g.step = SPX_HORIZ_CHUNK;
-        g.voff = (uint32_t) vals.size();
-        size_t j = i;
-        while (j < lone.size() && lone[j].row0 == g.row0 &&
-               lone[j].col0 == g.col0 + (uint32_t)((j - i) * SPX_HORIZ_CHUNK)) {
-            // values of lone[j] were appended to `vals` above; move them behind each other
-            ++j;
-        }
+        g.row0 = r0.row0;
+        g.col0 = r0.col0;
         g.nseg = (uint16_t)(j - i);
-        std::vector<val_t> tmp;
-        for (size_t k = i; k < j; ++k)
-            tmp.insert(tmp.end(), vals.begin() + lone[k].voff, vals.begin() + lone[k].voff + g.width);
+        g.width = r0.width;
+        g.kind = (uint8_t) kind;
+        g.step = (uint8_t) step;
         g.voff = (uint32_t) vals.size();
-        vals.insert(vals.end(), tmp.begin(), tmp.end());
+        for (size_t k = i; k < j; ++k)
+            vals.insert(vals.end(), gvals_.begin() + runs[idx[k]].voff,
+                        gvals_.begin() + runs[idx[k]].voff + g.width);
         kept.push_back(g);
+    };
+    auto diag_id = [&](uint32_t k) { return (int64_t) runs[k].col0 - (int64_t) runs[k].row0; };
+    // chains along diagonals; `min_len` segments at least; returns what is left
+    auto diagonal_chains = [&](std::vector<uint32_t> idx, size_t min_len) {
+        std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) {
+            if (runs[a].width != runs[b].width) return runs[a].width < runs[b].width;
+            if (diag_id(a) != diag_id(b)) return diag_id(a) < diag_id(b);
+            return runs[a].row0 < runs[b].row0;
+        });
+        std::vector<uint32_t> left;
+        for (size_t i = 0; i < idx.size();) {
+            size_t j = i + 1;
+            unsigned step = 0;
+            auto same = [&](size_t k) {
+                return runs[idx[k]].width == runs[idx[i]].width && diag_id(idx[k]) == diag_id(idx[i]);
+            };
+            if (j < idx.size() && same(j) &&
+                (unsigned)(runs[idx[j]].row0 - runs[idx[i]].row0) <= SPX_MAX_STEP) {
+                step = (unsigned)(runs[idx[j]].row0 - runs[idx[i]].row0);
+                while (j < idx.size() && same(j) &&
+                       runs[idx[j]].row0 == runs[idx[i]].row0 + (j - i) * step)
+                    ++j;
+            }
+            if (step && j - i >= min_len) {
+                emit_chain(idx, i, j, SPX_KIND_DIAG, step);
+                i = j;
+            } else {
+                left.push_back(idx[i]);
+                ++i;
+            }
+        }
+        return left;
+    };
+    std::vector<uint32_t> idx(runs.size());
+    for (uint32_t k = 0; k < idx.size(); ++k) idx[k] = k;
+    idx = diagonal_chains(idx, 8);
+    // dense blocks
+    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) {
+        if (runs[a].width != runs[b].width) return runs[a].width < runs[b].width;
+        if (runs[a].col0 != runs[b].col0) return runs[a].col0 < runs[b].col0;
+        return runs[a].row0 < runs[b].row0;
+    });
+    std::vector<uint32_t> lone;
+    for (size_t i = 0; i < idx.size();) {
+        size_t j = i + 1;
+        while (j < idx.size() && runs[idx[j]].width == runs[idx[i]].width &&
+               runs[idx[j]].col0 == runs[idx[i]].col0 &&
+               runs[idx[j]].row0 == runs[idx[i]].row0 + (j - i))
+            ++j;
+        if (j - i > 1) emit_chain(idx, i, j, SPX_KIND_BLOCK, 0);
+        else lone.push_back(idx[i]);
         i = j;
     }
+    // full chunks next to each other in one row
+    std::sort(lone.begin(), lone.end(), [&](uint32_t a, uint32_t b) {
+        return runs[a].row0 != runs[b].row0 ? runs[a].row0 < runs[b].row0 : runs[a].col0 < runs[b].col0;
+    });
+    std::vector<uint32_t> rest;
+    for (size_t i = 0; i < lone.size();) {
+        size_t j = i + 1;
+        if (runs[lone[i]].width == SPX_HORIZ_CHUNK)
+            while (j < lone.size() && runs[lone[j]].width == SPX_HORIZ_CHUNK &&
+                   runs[lone[j]].row0 == runs[lone[i]].row0 &&
+                   runs[lone[j]].col0 == runs[lone[i]].col0 + (uint32_t)((j - i) * SPX_HORIZ_CHUNK))
+                ++j;
+        if (j - i > 1) emit_chain(lone, i, j, SPX_KIND_HORIZ, SPX_HORIZ_CHUNK);
+        else rest.push_back(lone[i]);
+        i = j;
+    }
+    // short diagonal chains, then segments of their own
+    rest = diagonal_chains(rest, 2);
+    for (size_t i = 0; i < rest.size(); ++i) emit_chain(rest, i, i + 1, SPX_KIND_HORIZ, 0);
     groups_.swap(kept);
     gvals_.swap(vals);
 }
