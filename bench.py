@@ -432,7 +432,7 @@ def main():
                          "avg_launch_us": round(1e6 * launch_s, 3)},
             "format": {"nnz_stored": nnz_local, "unit_elems": int(info.n_unit_elems),
                        "delta_elems": int(info.n_delta_elems), "units": int(info.n_units),
-                       "rowblocks": int(info.n_rowblocks),
+                       "rowblocks": int(info.n_rowblocks), "waves_per_workgroup": int(info.waves),
                        "index_bytes_per_nnz": round(info.index_bytes / max(nnz_local, 1), 3),
                        "tune_seconds": round(info.tune_seconds, 3),
                        "emit_upload_seconds": round(info.emit_seconds, 3)},

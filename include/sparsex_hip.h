@@ -17,6 +17,9 @@
  *                           [rank*P/world, (rank+1)*P/world), P = spx.rt.nr_threads
  *   spx.gpu.rowblock_elems  target nonzeros per row-block (default 0 = auto:
  *                           nnz/1280 clamped to [1024, 4096]; 8192 beyond 64 M)
+ *   spx.gpu.waves           wavefronts per workgroup of the SpMV kernel: 2, 4 or 8;
+ *                           0 (default): spx_mat_tune() measures a few launch
+ *                           configurations on the device and keeps the fastest
  *   spx.gpu.rowblock_rows   max rows per row-block (default and cap 512)
  *   spx.gpu.stack_segments  "false": one descriptor per CSX unit piece instead
  *                           of merging equal row segments of consecutive rows
@@ -115,6 +118,8 @@ typedef struct {
     int32_t symmetric;
     int32_t on_device;       /* 0 for host-only matrices                        */
     int32_t device;
+    int32_t waves;           /* wavefronts per workgroup of the SpMV kernel      */
+    int32_t pad_;
     double  tune_seconds;    /* preprocessing (mining + encoding)               */
     double  emit_seconds;    /* descriptor stream + upload                      */
 } spx_hip_info_t;

@@ -64,6 +64,8 @@ struct matrix {
     idx_t own_lo, own_hi;
     GpuEmitParams emit_params;
     bool auto_rb;
+    double rb_scale = 1.0;      // chosen by the launch autotuner (multiplies the automatic row-block size)
+    int waves = 4;              // wavefronts per workgroup of the SpMV kernel
     bool host_only;
     int device_ordinal;
     bool dirty;                               // values changed since the last upload
@@ -318,6 +320,7 @@ static void emit_and_upload(spx_matrix_t *A)
         // with the largest row-blocks: syn-nd24k x4, 114 M nonzeros, 162 -> 159 us)
         gp.target_elems = std::min<size_t>(std::max<size_t>(local / 1280 + 1, 1024),
                                            local > ((size_t) 64 << 20) ? SPX_MAX_RB_ELEMS : 4096);
+        gp.target_elems = std::max<size_t>((size_t)(A->rb_scale * (double) gp.target_elems), 512);
     }
     GpuStream gs;
     if (sym) {
@@ -353,6 +356,7 @@ static void emit_and_upload(spx_matrix_t *A)
         for (size_t i = 0; i < nown; ++i) emit_gpu(A->parts[i], gp, gs);
     }
     finalize_stream(gs, (size_t) A->nrows);
+    gs.waves = (uint32_t) A->waves;
     A->nnz_stored = gs.nnz_stored;
     A->n_unit_elems = gs.n_unit_elems;
     A->n_delta_elems = gs.n_delta_elems;
@@ -371,6 +375,50 @@ static void emit_and_upload(spx_matrix_t *A)
     else
         A->host_stream.reset(new GpuStream(std::move(gs)));
     A->dirty = false;
+}
+
+// Launch parameters are measured, not guessed: small matrices (one round of
+// workgroups) like two wavefronts per workgroup and smaller row-blocks,
+// leftover-heavy ones eight wavefronts, the rest the default.  A handful of
+// candidates, a few hundred launches each; the fastest stays.
+static void autotune_launch(spx_matrix_t *A)
+{
+    const int W = 10, N = 100;
+    auto time_with = [&](int waves) {
+        device_set_waves(A->dev, waves);
+        double best = device_time_spmv(A->dev, W, N);
+        for (int rep = 0; rep < 3; ++rep) best = std::min(best, device_time_spmv(A->dev, 0, N));
+        return best;
+    };
+    // default row-blocks: 4 and 8 wavefronts
+    const double t4 = time_with(4), t8 = time_with(8);
+    int best_waves = t8 < 0.985 * t4 ? 8 : 4;
+    double best_t = std::min(t4, t8), best_scale = 1.0;
+    // smaller row-blocks with 2 wavefronts: only worth trying where the whole
+    // matrix is in flight at once anyway (needs a second emission + upload)
+    if (A->auto_rb && A->n_rowblocks <= 4096) {
+        for (double scale : {0.7, 0.52}) {
+            A->rb_scale = scale;
+            A->waves = 2;
+            emit_and_upload(A);
+            const double t2 = time_with(2);
+            if (t2 < 0.985 * best_t) {
+                best_t = t2;
+                best_waves = 2;
+                best_scale = scale;
+            }
+        }
+        if (A->rb_scale != best_scale) {
+            A->rb_scale = best_scale;
+            A->waves = best_waves;
+            emit_and_upload(A);
+        }
+    }
+    A->rb_scale = best_scale;
+    A->waves = best_waves;
+    device_set_waves(A->dev, best_waves);
+    log_msg(LOG_INFO, "launch autotune: %d wavefronts per workgroup, row-block scale %.2f (%.2f us per SpMV)\n",
+            best_waves, best_scale, 1e6 * best_t);
 }
 
 static spx_matrix_t *do_tune(spx_input_t *in)
@@ -500,7 +548,11 @@ static spx_matrix_t *do_tune(spx_input_t *in)
         A->own_lo = lo;
         A->own_hi = hi;
     }
+    A->waves = (int) cfg.get_long("spx.gpu.waves");
+    const bool autotune = A->waves == 0;
+    if (autotune) A->waves = 4;
     emit_and_upload(A.get());
+    if (autotune && A->dev && A->nnz_stored >= 100000) autotune_launch(A.get());
     if (!cfg.get_bool("spx.rt.keep_encoded")) {
         A->parts.clear();
         A->parts.shrink_to_fit();
@@ -744,7 +796,7 @@ spx_error_t spx_mat_set_entry(spx_matrix_t *A, spx_index_t row, spx_index_t colu
 
 namespace {
 
-const char kMagic[8] = {'S', 'P', 'X', 'H', 'I', 'P', '0', '6'};
+const char kMagic[8] = {'S', 'P', 'X', 'H', 'I', 'P', '0', '7'};
 
 template <typename T>
 bool put_vec(FILE *f, const std::vector<T> &v)
@@ -771,6 +823,7 @@ struct SavedHeader {
     uint64_t nnz_stored, n_unit_elems, n_delta_elems, n_units;
     uint32_t n_carry, pad;
     uint32_t n_spill, lds_doubles;
+    uint32_t waves, pad2;
 };
 
 }  // namespace
@@ -820,6 +873,7 @@ spx_error_t spx_mat_save(const spx_matrix_t *A, const char *filename)
     h.pad = (gs->sym_fused ? 1u : 0u) | (gs->pass_stride << 1);
     h.n_spill = gs->n_spill;
     h.lds_doubles = gs->lds_doubles;
+    h.waves = gs->waves;
     bool good = fwrite(kMagic, 1, 8, f) == 8 && fwrite(&h, sizeof(h), 1, f) == 1;
     std::vector<int32_t> bnd;
     for (const PartBounds &b : A->bounds) {
@@ -879,6 +933,7 @@ spx_matrix_t *spx_mat_restore(const char *filename)
     gs->pass_stride = h.pad >> 1;
     gs->n_spill = h.n_spill;
     gs->lds_doubles = h.lds_doubles;
+    gs->waves = h.waves;
     gs->nnz_stored = h.nnz_stored; gs->n_unit_elems = h.n_unit_elems;
     gs->n_delta_elems = h.n_delta_elems; gs->n_units = h.n_units;
     std::unique_ptr<matrix> A(new matrix);
@@ -893,6 +948,7 @@ spx_matrix_t *spx_mat_restore(const char *filename)
         A->bounds.push_back(PartBounds{bnd[3 * i], bnd[3 * i + 1], (size_t) bnd[3 * i + 2]});
     A->full_colind = false;
     A->dev = nullptr;
+    A->waves = (h.waves == 2 || h.waves == 8) ? (int) h.waves : 4;
     A->own_lo = h.own_lo; A->own_hi = h.own_hi;
     A->nnz_stored = h.nnz_stored; A->n_unit_elems = h.n_unit_elems;
     A->n_delta_elems = h.n_delta_elems; A->n_units = h.n_units;
@@ -1214,6 +1270,7 @@ spx_error_t spx_hip_mat_info(const spx_matrix_t *A, spx_hip_info_t *info)
         device_info(A->dev, di);
         info->device = di.device;
     }
+    info->waves = A->dev ? device_get_waves(A->dev) : A->waves;
     info->tune_seconds = A->tune_seconds;
     info->emit_seconds = A->emit_seconds;
     return SPX_SUCCESS;

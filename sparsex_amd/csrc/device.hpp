@@ -30,6 +30,15 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
 void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x,
                       double beta, double *h_y);
 
+// wavefronts per workgroup of the SpMV kernel: 2, 4 or 8
+void device_set_waves(DeviceMatrix *m, int waves);
+int device_get_waves(const DeviceMatrix *m);
+
+// seconds per SpMV (alpha = 1, beta = 0) over `launches` back-to-back launches
+// on a private stream with scratch vectors -- what spx_mat_tune() measures to
+// choose launch parameters
+double device_time_spmv(DeviceMatrix *m, int warmup, int launches);
+
 // copies the descriptor stream back from HBM (for spx_mat_save)
 void device_download(const DeviceMatrix *m, GpuStream &s);
 

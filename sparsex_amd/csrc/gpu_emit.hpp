@@ -44,6 +44,7 @@ struct GpuStream {
     // pass headers of row-block i start at passes[i * pass_stride] once
     // finalize_stream() ran (0: packed, as the emitter appends them)
     uint32_t pass_stride = 0;
+    uint32_t waves = 4;           // wavefronts per workgroup the kernel is launched with
     // accounting
     size_t nnz_stored = 0;        // nonzeros held in `values` (without padding)
     size_t n_unit_elems = 0;

@@ -55,11 +55,9 @@ struct KernelArgs {
     uint32_t pass_stride;    // pass headers of row-block i start at passes[i * pass_stride]
 };
 
-#ifndef SPX_WAVES
-#define SPX_WAVES 4
-#endif
-constexpr int WAVES_PER_BLOCK = SPX_WAVES;
-constexpr int BLOCK_THREADS = 64 * WAVES_PER_BLOCK;
+// wavefronts per workgroup: the kernels exist for 2, 4 and 8 (spx.gpu.waves, or
+// measured at tune time: small matrices like 2, leftover-heavy ones 8)
+constexpr int MAX_WAVES_PER_BLOCK = 8;
 
 // set bits of `mask` in lanes 1..lane (bit 0 is never set by the emitter)
 __device__ __forceinline__ uint32_t starts_upto(uint64_t mask, int lane)
@@ -309,10 +307,11 @@ __device__ __forceinline__ void run_pass(const KernelArgs &a, const SpxRowBlock 
 // SYM: the symmetric variant with tiles (dynamic LDS: the row-block's
 // transposed-sum slots in front of its y tile; the sums of columns owned by
 // other row-blocks are spilled for csx_symfix_kernel).
-template <bool SYM>
+template <bool SYM, int WAVES_PER_BLOCK>
 __device__ __forceinline__ void spmv_body(const KernelArgs &a, uint32_t blocks_per_xcd,
                                           double *lds)
 {
+    constexpr int BLOCK_THREADS = 64 * WAVES_PER_BLOCK;
 #ifdef SPX_ABL_EMPTY
     if (a.alpha != 123.0) return;
 #endif
@@ -402,20 +401,22 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, uint32_t blocks_p
 // at wave launch -- hipcc -mllvm -amdgpu-kernarg-preload-count=16 -- was
 // measured: it removes the kernarg fetch in front of the first real load but
 // costs more at dispatch, cant 7.5 -> 8.0 us; not used.)
-__global__ __launch_bounds__(BLOCK_THREADS)
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES)
 void csx_spmv_kernel(SPX_KERNEL_PARAMS)
 {
     SPX_KERNEL_ARGS(a);
     __shared__ double tile[SPX_MAX_RB_ROWS];
-    spmv_body<false>(a, blocks_per_xcd, tile);
+    spmv_body<false, WAVES>(a, blocks_per_xcd, tile);
 }
 
-__global__ __launch_bounds__(BLOCK_THREADS)
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES)
 void csx_spmv_symtile_kernel(SPX_KERNEL_PARAMS)
 {
     SPX_KERNEL_ARGS(a);
     extern __shared__ double lds_dyn[];
-    spmv_body<true>(a, blocks_per_xcd, lds_dyn);
+    spmv_body<true, WAVES>(a, blocks_per_xcd, lds_dyn);
 }
 
 // symmetric tiles, second step: every row collects the transposed sums that
@@ -495,6 +496,7 @@ struct DeviceMatrix {
     double *dvalues = nullptr;
     // symmetric tiles
     bool has_tiles = false;
+    int waves = 4;            // wavefronts per workgroup of the SpMV kernel (2, 4 or 8)
     uint32_t n_spill = 0, lds_doubles = SPX_MAX_RB_ROWS;
     double *spill = nullptr;
     uint32_t *fix_ptr = nullptr, *fix_idx = nullptr;
@@ -544,6 +546,7 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
     m->symmetric = symmetric;
     m->sym_fused = symmetric && s.sym_fused;
     m->pass_stride = s.pass_stride;
+    m->waves = (s.waves == 2 || s.waves == 8) ? (int) s.waves : 4;
     m->own_lo = (size_t) own_lo;
     m->own_hi = (size_t) own_hi;
     m->n_rb = (uint32_t) s.rbs.size();
@@ -552,7 +555,7 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
     m->rbs = upload(s.rbs);
     m->values = upload(s.values, 160);
     m->descs = upload(s.descs, 8);
-    m->passes = upload(s.passes, (size_t) s.pass_stride + 2 * WAVES_PER_BLOCK);
+    m->passes = upload(s.passes, (size_t) s.pass_stride + 2 * MAX_WAVES_PER_BLOCK);
     m->cidx = upload(s.cidx, 64);
     m->segrows = upload(s.segrows, 80);
     m->shared = upload(s.shared);
@@ -568,11 +571,7 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
     for (const SpxRowBlock &rb : s.rbs)
         for (uint32_t k = 0; k < rb.n_pass && !m->has_tiles; ++k)
             m->has_tiles = s.passes[rb.pass_off + k].kind == SPX_PASS_SYMTILE;
-    if (m->has_tiles)
-        // (a row-block may need more than the 64 KB a kernel gets by default)
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(csx_spmv_symtile_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)(m->lds_doubles * sizeof(double))));
+    // (n_slots + n_rows <= 3584 doubles = 28 KB: within the default dynamic LDS limit)
     if (s.n_spill) {
         std::vector<double> zero_spill(s.n_spill, 0.0);
         m->spill = upload(zero_spill);
@@ -630,28 +629,72 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
         a.beta = beta = 1.0;
     }
     a.spill = m->spill;
+#define SPX_LAUNCH(KERNEL, W, LDS)                                                               \
+    hipLaunchKernelGGL(KERNEL<W>, dim3(blocks), dim3(64 * W), LDS, stream, a.rbs, a.passes,      \
+                       a.n_rb, a.pass_stride, blocks >> 3, 0u, a.values, a.descs, a.cidx,        \
+                       a.segrows, a.x, a.y, a.carry, a.dvalues, a.spill, a.alpha, a.beta)
     if (blocks && m->has_tiles) {
         // symmetric tiles: slots + y tile in dynamic LDS, then the rows collect
         // what other row-blocks spilled for them
-        hipLaunchKernelGGL(csx_spmv_symtile_kernel, dim3(blocks), dim3(BLOCK_THREADS),
-                           m->lds_doubles * sizeof(double), stream, a.rbs, a.passes, a.n_rb,
-                           a.pass_stride, blocks >> 3, 0u, a.values, a.descs, a.cidx, a.segrows,
-                           a.x, a.y, a.carry, a.dvalues, a.spill, a.alpha, a.beta);
+        const size_t lds = m->lds_doubles * sizeof(double);
+        if (m->waves == 2) SPX_LAUNCH(csx_spmv_symtile_kernel, 2, lds);
+        else if (m->waves == 8) SPX_LAUNCH(csx_spmv_symtile_kernel, 8, lds);
+        else SPX_LAUNCH(csx_spmv_symtile_kernel, 4, lds);
         if (m->n_spill)
             hipLaunchKernelGGL(csx_symfix_kernel, dim3((unsigned)((m->nrows + 31) / 32)), dim3(256),
                                0, stream, m->fix_ptr, m->fix_idx, m->spill, d_y, alpha,
                                (uint32_t) m->nrows);
     } else if (blocks) {
-        hipLaunchKernelGGL(csx_spmv_kernel, dim3(blocks), dim3(BLOCK_THREADS), 0, stream, a.rbs,
-                           a.passes, a.n_rb, a.pass_stride, blocks >> 3, 0u, a.values, a.descs,
-                           a.cidx, a.segrows, a.x, a.y, a.carry, a.dvalues, a.spill, a.alpha,
-                           a.beta);
+        if (m->waves == 2) SPX_LAUNCH(csx_spmv_kernel, 2, 0);
+        else if (m->waves == 8) SPX_LAUNCH(csx_spmv_kernel, 8, 0);
+        else SPX_LAUNCH(csx_spmv_kernel, 4, 0);
     }
+#undef SPX_LAUNCH
     if (m->n_shared)
         hipLaunchKernelGGL(csx_fixup_kernel, dim3((m->n_shared + 63) / 64), dim3(64), 0,
                            stream, m->shared, m->n_shared, m->carry, d_y, alpha, beta,
                            a.dvalues, d_x);
     HIP_CHECK(hipGetLastError());
+}
+
+void device_set_waves(DeviceMatrix *m, int waves)
+{
+    m->waves = (waves == 2 || waves == 8) ? waves : 4;
+}
+
+int device_get_waves(const DeviceMatrix *m) { return m->waves; }
+
+static void ensure_staging(DeviceMatrix *m)
+{
+    if (m->d_x) return;
+    const size_t xb = m->ncols * sizeof(double), yb = m->nrows * sizeof(double);
+    HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&m->d_x), xb ? xb : 8));
+    HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&m->d_y), yb ? yb : 8));
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&m->p_x), xb ? xb : 8, hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&m->p_y), yb ? yb : 8, hipHostMallocDefault));
+    HIP_CHECK(hipStreamCreateWithFlags(&m->host_stream, hipStreamNonBlocking));
+}
+
+double device_time_spmv(DeviceMatrix *m, int warmup, int launches)
+{
+    HIP_CHECK(hipSetDevice(m->device));
+    ensure_staging(m);
+    hipStream_t st = m->host_stream;
+    HIP_CHECK(hipMemsetAsync(m->d_x, 0, m->ncols * sizeof(double), st));
+    HIP_CHECK(hipMemsetAsync(m->d_y, 0, m->nrows * sizeof(double), st));
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < warmup; ++i) device_spmv(m, 1.0, m->d_x, 0.0, m->d_y, st);
+    HIP_CHECK(hipEventRecord(e0, st));
+    for (int i = 0; i < launches; ++i) device_spmv(m, 1.0, m->d_x, 0.0, m->d_y, st);
+    HIP_CHECK(hipEventRecord(e1, st));
+    HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void) hipEventDestroy(e0);
+    (void) hipEventDestroy(e1);
+    return 1e-3 * ms / (launches > 0 ? launches : 1);
 }
 
 // Host-vector entry point: x (and y when it is read) go through pinned staging
@@ -662,13 +705,7 @@ void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x, double b
 {
     HIP_CHECK(hipSetDevice(m->device));
     const size_t xb = m->ncols * sizeof(double), yb = m->nrows * sizeof(double);
-    if (!m->d_x) {
-        HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&m->d_x), xb ? xb : 8));
-        HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&m->d_y), yb ? yb : 8));
-        HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&m->p_x), xb ? xb : 8, hipHostMallocDefault));
-        HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&m->p_y), yb ? yb : 8, hipHostMallocDefault));
-        HIP_CHECK(hipStreamCreateWithFlags(&m->host_stream, hipStreamNonBlocking));
-    }
+    ensure_staging(m);
     hipStream_t st = m->host_stream;
     std::memcpy(m->p_x, h_x, xb);
     HIP_CHECK(hipMemcpyAsync(m->d_x, m->p_x, xb, hipMemcpyHostToDevice, st));
@@ -705,6 +742,7 @@ void device_download(const DeviceMatrix *m, GpuStream &s)
     s.n_carry = m->n_carry;
     s.sym_fused = m->sym_fused;
     s.pass_stride = m->pass_stride;
+    s.waves = (uint32_t) m->waves;
     s.n_spill = m->n_spill;
     s.lds_doubles = m->lds_doubles;
     if (m->n_spill) {

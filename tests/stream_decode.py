@@ -24,14 +24,15 @@ class Stream:
     def __init__(self, path):
         with open(path, "rb") as f:
             buf = f.read()
-        assert buf[:8] == b"SPXHIP06", buf[:8]
-        hdr = struct.unpack_from("<4i3Q2i4Q4I", buf, 8)
+        assert buf[:8] == b"SPXHIP07", buf[:8]
+        hdr = struct.unpack_from("<4i3Q2i4Q6I", buf, 8)
         (self.nrows, self.ncols, self.nnz, self.symmetric, self.nr_partitions, self.first_part,
          self.last_part, self.own_lo, self.own_hi, self.nnz_stored, self.n_unit_elems,
-         self.n_delta_elems, self.n_units, self.n_carry, flags, self.n_spill, self.lds_doubles) = hdr
+         self.n_delta_elems, self.n_units, self.n_carry, flags, self.n_spill, self.lds_doubles,
+         self.waves, _) = hdr
         self.sym_fused = bool(flags & 1)
         self.pass_stride = flags >> 1
-        self.off = 8 + struct.calcsize("<4i3Q2i4Q4I")
+        self.off = 8 + struct.calcsize("<4i3Q2i4Q6I")
         self.buf = buf
 
         def vec(dt):
