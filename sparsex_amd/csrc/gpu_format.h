@@ -19,7 +19,7 @@
  * Segment s of a unit sits at row0 + s*drow, columns col0 + s*dcol ... +W-1.
  * One 8-byte SpxUnitDesc describes the whole run (strides come from a 3-bit
  * kind and a 7-bit step; linear units with a step above 127 are rare and go
- * to the delta passes instead).
+ * to the gather passes instead).
  *
  * Work is cut into *passes*: a pass is up to 64 row segments of the SAME
  * width W, one per lane of a wavefront.  Its values are stored interleaved
@@ -33,6 +33,14 @@
  * owns one piece -- W values, W u16/u32 column offsets (relative to cbase,
  * element-major [W][nseg]), one u16 row -- and adds one partial sum, exactly
  * like a unit pass whose columns are not consecutive.
+ *
+ * The emitter (gpu_emit.cpp) shapes the segments for the lanes: nonzeros of
+ * one-wide units that line up along their rows are re-cut into row segments,
+ * and equal segments that follow a regular course (a diagonal, a stack, a
+ * row) share one descriptor.  The pass headers of row-block i start at
+ * passes[i * pass_stride] (fixed stride: a workgroup fetches its first headers
+ * together with its row-block header).  Symmetric matrices: see
+ * SPX_PASS_SYMTILE below.
  */
 #ifndef SPX_GPU_FORMAT_H
 #define SPX_GPU_FORMAT_H
