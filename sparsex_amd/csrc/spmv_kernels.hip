@@ -432,7 +432,11 @@ void csx_symfix_kernel(const uint32_t *fix_ptr, const uint32_t *fix_idx,
                        const double *spill, double *y, double alpha, uint32_t nrows)
 {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t row = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 8u + (lane & 7u);
+    // XCD-aware: workgroup b runs on XCD b % 8; each XCD takes one contiguous
+    // eighth of the rows, so that the two halves of a 128-byte spill line (the
+    // slots of two neighbouring tile columns) are asked for by the same L2
+    const uint32_t blk = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const uint32_t row = (blk * 4u + (threadIdx.x >> 6)) * 8u + (lane & 7u);
     const uint32_t g = lane >> 3;
     double s = 0.0;
     if (row < nrows) {
@@ -641,7 +645,7 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
         else if (m->waves == 8) SPX_LAUNCH(csx_spmv_symtile_kernel, 8, lds);
         else SPX_LAUNCH(csx_spmv_symtile_kernel, 4, lds);
         if (m->n_spill)
-            hipLaunchKernelGGL(csx_symfix_kernel, dim3((unsigned)((m->nrows + 31) / 32)), dim3(256),
+            hipLaunchKernelGGL(csx_symfix_kernel, dim3((unsigned)((((m->nrows + 31) / 32) + 7) & ~(size_t) 7)), dim3(256),
                                0, stream, m->fix_ptr, m->fix_idx, m->spill, d_y, alpha,
                                (uint32_t) m->nrows);
     } else if (blocks) {
