@@ -30,7 +30,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (guides/MI355X_MICROARCH.md)
 ALPHA = 0.5
-REF_BASELINE_THREADS = [1, 2, 4, 8, 16, 24, 32, 48, 64, 96, 128, 192, 256]
+REF_BASELINE_THREADS = [8, 16, 32, 64, 128, 256]   # the counts cpu_baseline() may try
 
 
 def load_mtx(path):
@@ -185,7 +185,7 @@ def cpu_baseline(csr, symmetric, budget_s=20.0):
     cores = host_cores()
     nnz = int(rp[-1])
     x = synth.random_x(n)
-    cands = [t for t in (8, 16, 32, 64, 128, 256) if t <= cores] or [cores]
+    cands = [t for t in REF_BASELINE_THREADS if t <= cores] or [cores]
     cands = cands[-5:]
     best = None
     share = budget_s / max(len(cands), 1)
