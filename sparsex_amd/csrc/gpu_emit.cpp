@@ -337,7 +337,8 @@ void RbBuilder::emit_gather_passes(SpxRowBlock &rb, std::vector<Single> &singles
     const size_t n = singles.size();
     rb.seg_off = (uint32_t) out_.segrows.size();
     while (out_.cidx.size() % 16) out_.cidx.push_back(0);
-    rb.cidx_off = (uint32_t) out_.cidx.size();
+    const size_t cbytes = out_.cidx.size();           // 16-byte aligned
+    rb.cidx_off = (uint32_t)(cbytes / 16);
     rb.cidx_width = 2;
     if (!n) return;
     idx_t cmin = singles[0].col, cmax = singles[0].col;
@@ -361,12 +362,12 @@ void RbBuilder::emit_gather_passes(SpxRowBlock &rb, std::vector<Single> &singles
     auto put_off = [&](size_t at, uint32_t off) {
         if (rb.cidx_width == 2) {
             uint16_t o = (uint16_t) off;
-            std::memcpy(&out_.cidx[rb.cidx_off + at * 2], &o, 2);
+            std::memcpy(&out_.cidx[cbytes + at * 2], &o, 2);
         } else {
-            std::memcpy(&out_.cidx[rb.cidx_off + at * 4], &off, 4);
+            std::memcpy(&out_.cidx[cbytes + at * 4], &off, 4);
         }
     };
-    out_.cidx.resize(rb.cidx_off + n * rb.cidx_width, 0);
+    out_.cidx.resize(cbytes + n * rb.cidx_width, 0);
     size_t elems_before = 0, pieces_before = 0;
     for (size_t b = 0; b < pcs.size();) {
         const uint32_t W = pcs[b].width;

@@ -109,7 +109,8 @@ typedef struct {
     uint64_t val_off;     /* first value of the row-block in values[]          */
     uint32_t pass_off;    /* first SpxPass                                      */
     uint32_t desc_off;    /* first SpxUnitDesc                                  */
-    uint32_t cidx_off;    /* byte offset of the leftovers' column offsets       */
+    uint32_t cidx_off;    /* offset of the leftovers' column offsets, in units of
+                             16 bytes (up to 64 GB of them)                      */
     uint32_t seg_off;     /* first u16 row of the leftover row pieces           */
     uint32_t cbase;       /* column base of the leftovers                       */
     uint32_t row0;        /* first row owned (global)                           */

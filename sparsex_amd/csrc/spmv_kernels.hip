@@ -90,7 +90,7 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
         l[b] = active[b] ? (uint32_t) lane : 0u;         // idle lanes shadow lane 0
         if (G) {
             q[b].x = a.segrows[rb.seg_off + ps[b].seg0 + l[b]];
-            const uint8_t *cidx = a.cidx + rb.cidx_off;
+            const uint8_t *cidx = a.cidx + (size_t) rb.cidx_off * 16u;
             const uint32_t e0 = ps[b].elem0 + l[b];
             if (rb.cidx_width == 4) {
 #pragma unroll

@@ -24,7 +24,7 @@ class Stream:
     def __init__(self, path):
         with open(path, "rb") as f:
             buf = f.read()
-        assert buf[:8] == b"SPXHIP07", buf[:8]
+        assert buf[:8] == b"SPXHIP08", buf[:8]
         hdr = struct.unpack_from("<4i3Q2i4Q6I", buf, 8)
         (self.nrows, self.ncols, self.nnz, self.symmetric, self.nr_partitions, self.first_part,
          self.last_part, self.own_lo, self.own_hi, self.nnz_stored, self.n_unit_elems,
@@ -96,7 +96,6 @@ class Stream:
                     row = self.segrows[int(rb["seg_off"]) + int(ps["seg0"]) + lanes].astype(np.int64)
                     assert (row < int(rb["n_rows"])).all()
                     cw = int(rb["cidx_width"])
-                    assert int(rb["cidx_off"]) % 16 == 0
                     e0 = int(ps["elem0"])
                     for w in range(W):
                         pair = w >> 1
@@ -104,7 +103,7 @@ class Stream:
                             idx = pair * 2 * nseg + lanes
                         else:
                             idx = pair * 2 * nseg + lanes * 2 + (w & 1)
-                        o = int(rb["cidx_off"]) + (e0 + w * nseg + lanes) * cw
+                        o = int(rb["cidx_off"]) * 16 + (e0 + w * nseg + lanes) * cw
                         off = sum(self.cidx[o + b].astype(np.int64) << (8 * b) for b in range(cw))
                         R.append(row + int(rb["row0"])); Cc.append(off + int(rb["cbase"]))
                         V.append(self.values[pv + idx]); B.append(np.full(nseg, bi))
