@@ -1,6 +1,8 @@
 // input.cpp -- see input.hpp.
 #include "input.hpp"
 
+#include <cerrno>
+
 #include <algorithm>
 #include <cassert>
 #include <cstdlib>
@@ -198,12 +200,64 @@ void MmfInput::load_all()
     // Mmf.hpp:445-478: read everything, mirror the stored triangle of a
     // symmetric file, sort row-major
     matrix_.reserve(symmetric ? declared_nnz_ * 2 : declared_nnz_);
+    // The file is read in large chunks and parsed in place (one "row col value"
+    // line per entry, as read_line()/parse3() demand): a SuiteSparse file of
+    // a few hundred million entries is minutes through line-by-line iostreams.
+    const size_t CHUNK = (size_t) 64 << 20;
+    std::string buf;
+    size_t have = 0;              // valid bytes in buf
+    size_t pos = 0;               // parse position
+    bool eof = false;
+    auto refill = [&]() {         // keeps the unparsed tail, appends the next chunk
+        if (pos > 0) {
+            buf.erase(0, pos);
+            have -= pos;
+            pos = 0;
+        }
+        if (eof) return;
+        buf.resize(have + CHUNK);
+        in_.read(&buf[have], (std::streamsize) CHUNK);
+        const size_t got = (size_t) in_.gcount();
+        have += got;
+        buf.resize(have);
+        if (got < CHUNK) eof = true;
+    };
+    refill();
     for (size_t i = 0; i < declared_nnz_; ++i) {
-        Triplet t;
-        if (!next_from_file(t)) {
+        // a whole line must be in the buffer
+        size_t eol = buf.find('\n', pos);
+        if (eol == std::string::npos && !eof) {
+            refill();
+            eol = buf.find('\n', pos);
+        }
+        if (eol == std::string::npos) eol = have;
+        if (pos >= have) {
             log_msg(LOG_ERR, "Requesting dereference, but mmf ended.\n");
             throw FatalError("short MMF file");
         }
+        // (strto* stop at the string's terminating null at the latest)
+        char *b = &buf[pos], *e = nullptr;
+        const char *lim = &buf[0] + eol;
+        auto blank = [](char ch) { return ch == ' ' || ch == '\t' || ch == '\r'; };
+        errno = 0;
+        const long r0 = strtol(b, &e, 10);
+        bool ok = e != b && e <= lim;
+        b = e;
+        const long c0 = ok ? strtol(b, &e, 10) : 0;
+        ok = ok && e != b && e <= lim;
+        b = e;
+        const double v = ok ? strtod(b, &e) : 0.0;
+        ok = ok && e != b && e <= lim;
+        while (ok && e < lim && blank(*e)) ++e;
+        if (!ok || e != lim) {
+            log_msg(LOG_ERR, "bad input, less arguments in line of MMF file\n");
+            throw FatalError("bad entry line");
+        }
+        pos = eol < have ? eol + 1 : have;
+        Triplet t;
+        t.row = (idx_t)(zero_based ? r0 + 1 : r0);
+        t.col = (idx_t)(zero_based ? c0 + 1 : c0);
+        t.val = v;
         matrix_.push_back(t);
         if (symmetric && t.row != t.col) {
             Triplet m = t;
