@@ -106,3 +106,33 @@ def test_bad_banner_and_missing_file(tmp_path):
         sx.input_load_mmf(_write(tmp_path, "x.mtx", "%%NotMatrixMarket foo\n1 1 1\n1 1 1\n"))
     with pytest.raises(sx.SpxError):
         sx.input_load_mmf(str(tmp_path / "missing.mtx"))
+
+
+def test_standard_matrix_market_file_column_major_symmetric(tmp_path):
+    """What SuiteSparse ships: banner, comments, lower triangle in column-major order,
+    CRLF line ends tolerated; loaded whole, mirrored and sorted (Mmf.hpp:445-478)."""
+    import scipy.sparse as sp
+    from sparsex_amd import synth
+    from helpers import oracle_y, check_y
+    rp, ci, va, n = synth.syn_cant(0.02)
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    low = ci <= rows
+    r, c, v = rows[low], ci[low], va[low]
+    o = np.lexsort((r, c))
+    f = tmp_path / "std.mtx"
+    with open(f, "w", newline="") as fh:
+        fh.write("%%MatrixMarket matrix coordinate real symmetric\r\n% a comment\r\n%another\r\n")
+        fh.write("%d %d %d\r\n" % (n, n, r.size))
+        for k in o:
+            fh.write("%d %d %.17g\r\n" % (r[k] + 1, c[k] + 1, v[k]))
+    x = synth.random_x(n)
+    for sym in (False, True):
+        sx.options_reset()
+        sx.option_set("spx.rt.host_only", "true")
+        sx.option_set("spx.rt.nr_threads", "2")
+        if sym:
+            sx.option_set("spx.matrix.symmetric", "true")
+        A = sx.mat_tune(sx.input_load_mmf(str(f)))
+        assert (A.nrows, A.ncols, A.nnz) == (n, n, rp[-1])
+        yo, _ = oracle_y(A, x, 0.5)
+        check_y((rp, ci, va, n), x, yo, 0.5)
