@@ -169,3 +169,22 @@ def test_reference_examples_compile_and_link_unchanged(example, tmp_path):
            "-lsparsex", "-Wl,-rpath," + os.path.dirname(sx.lib_path()), "-o", exe]
     subprocess.check_call(cmd)
     assert os.path.exists(exe)
+
+
+def _build_cg_example(tmp_path):
+    exe = str(tmp_path / "cg_device")
+    subprocess.check_call(["gcc", "-std=gnu99", "-Wall", "-Werror", os.path.join(ROOT, "examples", "cg_device.c"),
+                           "-I" + os.path.join(ROOT, "include"), "-L" + os.path.dirname(sx.lib_path()),
+                           "-lsparsex", "-Wl,-rpath," + os.path.dirname(sx.lib_path()), "-lm", "-o", exe])
+    return exe
+
+
+def test_own_c_example_compiles_and_links(tmp_path):
+    """examples/cg_device.c: a plain C client of the device-resident extension (sparsex_hip.h)."""
+    assert os.path.exists(_build_cg_example(tmp_path))
+
+
+@pytest.mark.gpu
+def test_own_c_example_solves_on_the_gpu(tmp_path):
+    out = subprocess.check_output([_build_cg_example(tmp_path), "120"]).decode()
+    assert "CG iterations" in out
