@@ -187,3 +187,26 @@ class RefCsxMatrix(C.Structure):
 
 class RefCsxSymMatrix(C.Structure):
     _fields_ = [("lower_matrix", C.POINTER(RefCsxMatrix)), ("dvalues", C.POINTER(C.c_double))]
+
+
+def build_test_client():
+    """The reference's own test client (test/src/sparsex_test.c), compiled unmodified from where it
+    lies and linked against THIS repository's libsparsex.so -> oracle/_ref/sparsex_test.  Its one
+    non-API dependency, check_result(), comes from tests/ref_client/ (the reference's version sits on
+    its Boost-based internals).  The source is fed through stdin so that `#include "CsxCheck.hpp"`
+    resolves to tests/ref_client/CsxCheck.hpp, not to the file next to it."""
+    if not reference_available():
+        return None
+    root = os.path.dirname(HERE)
+    os.makedirs(REF_DIR, exist_ok=True)
+    exe = os.path.join(REF_DIR, "sparsex_test")
+    src = os.path.join(REF_ROOT, "test", "src", "sparsex_test.c")
+    client = os.path.join(root, "tests", "ref_client")
+    with open(src, "rb") as f:
+        text = f.read()
+    cmd = ["gcc", "-std=gnu99", "-O1", "-x", "c", "-", os.path.join(client, "check_result.c"),
+           "-I" + client, "-I" + os.path.join(root, "include"),
+           "-L" + os.path.join(root, "sparsex_amd", "lib"), "-lsparsex", "-lm",
+           "-Wl,-rpath,$ORIGIN/../../sparsex_amd/lib", "-o", exe]
+    subprocess.run(cmd, input=text, check=True)
+    return exe
