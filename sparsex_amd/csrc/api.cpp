@@ -81,7 +81,8 @@ struct matrix {
 
 namespace {
 
-enum { ALLOC_STD = 1, ALLOC_OTHER = 4 };       // Vector.cpp:36-41
+enum { ALLOC_STD = 1, ALLOC_OTHER = 4,          // Vector.cpp:36-41
+       ALLOC_PINNED = 8 };                      // this build: page-locked, copied to/from HBM directly
 enum { VEC_MODE_INVALID = 45 };                // Vector.cpp:43-47
 
 double now_sec()
@@ -1170,7 +1171,8 @@ static spx_error_t run_host(const spx_matrix_t *A, spx_value_t alpha, const spx_
         return SPX_FAILURE;
     }
     try {
-        device_spmv_host(A->dev, alpha, x->elements, beta, y->elements);
+        device_spmv_host(A->dev, alpha, x->elements, x->alloc_type == ALLOC_PINNED, beta,
+                         y->elements, y->alloc_type == ALLOC_PINNED);
     } catch (const FatalError &e) {
         SETERROR_1(SPX_ERR_TUNED_MAT, e.what.c_str());
         return SPX_FAILURE;
@@ -1377,10 +1379,18 @@ static spx_vector_t *vec_alloc(size_t size)
 {
     spx_vector_t *v = (spx_vector_t *) malloc(sizeof(spx_vector_t));
     if (!v) { log_msg(LOG_ERR, "malloc failed\n"); exit(1); }
-    v->elements = (spx_value_t *) calloc(size ? size : 1, sizeof(spx_value_t));
+    // page-locked where a HIP device is present: spx_matvec_* then copy the
+    // vector to and from HBM without a staging copy
+    v->alloc_type = ALLOC_PINNED;
+    v->elements = (spx_value_t *) device_host_alloc((size ? size : 1) * sizeof(spx_value_t));
+    if (v->elements) {
+        memset(v->elements, 0, (size ? size : 1) * sizeof(spx_value_t));
+    } else {
+        v->elements = (spx_value_t *) calloc(size ? size : 1, sizeof(spx_value_t));
+        v->alloc_type = ALLOC_STD;
+    }
     if (!v->elements) { log_msg(LOG_ERR, "malloc failed\n"); exit(1); }
     v->size = size;
-    v->alloc_type = ALLOC_STD;
     v->vec_mode = VEC_MODE_INVALID;
     return v;
 }
@@ -1584,6 +1594,7 @@ void spx_vec_destroy(spx_vector_t *v)
 {
     if (!v) return;
     if (v->alloc_type == ALLOC_STD) free(v->elements);
+    else if (v->alloc_type == ALLOC_PINNED) device_host_free(v->elements);
     free(v);
 }
 

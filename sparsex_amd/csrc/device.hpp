@@ -26,9 +26,16 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
                  double *d_y, void *stream);
 
 // host-vector convenience path used by spx_matvec_*: H2D x (and y when
-// beta != 0), kernel, D2H y; synchronous.
-void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x,
-                      double beta, double *h_y);
+// beta != 0), kernel, D2H y; synchronous.  Vectors the library allocated itself
+// are pinned (device_host_alloc) and are copied from / to directly; user
+// buffers go through pinned staging copies.
+void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x, bool x_pinned,
+                      double beta, double *h_y, bool y_pinned);
+
+// page-locked host memory for the library's own vectors; nullptr when there is
+// no HIP device (the caller falls back to malloc)
+void *device_host_alloc(size_t bytes);
+void device_host_free(void *p);
 
 // wavefronts per workgroup of the SpMV kernel: 2, 4 or 8
 void device_set_waves(DeviceMatrix *m, int waves);

@@ -704,26 +704,50 @@ double device_time_spmv(DeviceMatrix *m, int warmup, int launches)
 // Host-vector entry point: x (and y when it is read) go through pinned staging
 // buffers and asynchronous copies on one private stream -- a pageable
 // hipMemcpy stages internally as well, but synchronously and chunk by chunk.
-void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x, double beta,
-                      double *h_y)
+void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x, bool x_pinned,
+                      double beta, double *h_y, bool y_pinned)
 {
     HIP_CHECK(hipSetDevice(m->device));
     const size_t xb = m->ncols * sizeof(double), yb = m->nrows * sizeof(double);
     ensure_staging(m);
     hipStream_t st = m->host_stream;
-    std::memcpy(m->p_x, h_x, xb);
-    HIP_CHECK(hipMemcpyAsync(m->d_x, m->p_x, xb, hipMemcpyHostToDevice, st));
+    const double *src_x = h_x;
+    if (!x_pinned) {
+        std::memcpy(m->p_x, h_x, xb);
+        src_x = m->p_x;
+    }
+    HIP_CHECK(hipMemcpyAsync(m->d_x, src_x, xb, hipMemcpyHostToDevice, st));
     // y travels to the device only when it is read: beta != 0, or this process
     // owns a slice of the rows and the others must keep the caller's values
     const bool whole = m->own_lo == 0 && m->own_hi == m->nrows && (!m->symmetric || m->sym_fused);
     if (beta != 0.0 || !whole) {
-        std::memcpy(m->p_y, h_y, yb);
-        HIP_CHECK(hipMemcpyAsync(m->d_y, m->p_y, yb, hipMemcpyHostToDevice, st));
+        const double *src_y = h_y;
+        if (!y_pinned) {
+            std::memcpy(m->p_y, h_y, yb);
+            src_y = m->p_y;
+        }
+        HIP_CHECK(hipMemcpyAsync(m->d_y, src_y, yb, hipMemcpyHostToDevice, st));
     }
     device_spmv(m, alpha, m->d_x, beta, m->d_y, st);
-    HIP_CHECK(hipMemcpyAsync(m->p_y, m->d_y, yb, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(y_pinned ? h_y : m->p_y, m->d_y, yb, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    std::memcpy(h_y, m->p_y, yb);
+    if (!y_pinned) std::memcpy(h_y, m->p_y, yb);
+}
+
+void *device_host_alloc(size_t bytes)
+{
+    if (device_count() <= 0) return nullptr;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 8, hipHostMallocPortable) != hipSuccess) {
+        (void) hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+void device_host_free(void *p)
+{
+    if (p) (void) hipHostFree(p);
 }
 
 template <typename T>
