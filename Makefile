@@ -10,9 +10,10 @@ CSRC      := sparsex_amd/csrc
 LIBDIR    := sparsex_amd/lib
 OBJDIR    := build/obj
 LIB       := $(LIBDIR)/libsparsex.so
+SYNLIB    := $(LIBDIR)/libspxsynth.so
 
 HOST_SRCS := common.cpp config.cpp partition.cpp stats.cpp encoder.cpp input.cpp reorder.cpp \
-             csx_emit.cpp gpu_emit.cpp api.cpp
+             csx_emit.cpp gpu_emit.cpp stream_index.cpp api.cpp
 HOST_OBJS := $(HOST_SRCS:%.cpp=$(OBJDIR)/%.o)
 HIP_OBJ   := $(OBJDIR)/spmv_kernels.o $(OBJDIR)/vec_kernels.o
 
@@ -23,7 +24,12 @@ HIPFLAGS  := --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -munsafe-fp-atomics \
 .PHONY: all lib oracle clean
 all: lib oracle
 
-lib: $(LIB)
+lib: $(LIB) $(SYNLIB)
+
+# input generator of the nlpkkt stand-in (bench/test data only, no SpMV code)
+$(SYNLIB): tools/synth/nlpkkt_gen.c
+	@mkdir -p $(LIBDIR)
+	$(CC) -O3 -shared -fPIC -o $@ $< -lm
 
 $(OBJDIR)/%.o: $(CSRC)/%.cpp $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.h) \
                $(wildcard include/sparsex/*.h) include/sparsex_hip.h

@@ -16,6 +16,8 @@
 #include "gpu_emit.hpp"
 #include "input.hpp"
 #include "reorder.hpp"
+#include "stream_index.hpp"
+#include "threads.hpp"
 
 #include <chrono>
 #include <cmath>
@@ -47,34 +49,34 @@ struct partition {
 };
 
 struct matrix {
-    spx_index_t nrows, ncols, nnz;
-    int symmetric;
-    spx_perm_t *permutation;
+    spx_index_t nrows = 0, ncols = 0, nnz = 0;
+    int symmetric = 0;
+    spx_perm_t *permutation = SPX_INVALID_PERM;
     // tuned representation
-    size_t nr_partitions;              // P, over all processes
-    size_t first_part, last_part;      // owned partitions [first, last)
+    size_t nr_partitions = 0;          // P, over all processes
+    size_t first_part = 0, last_part = 0;   // owned partitions [first, last)
     std::vector<PartBounds> bounds;    // all P partitions
     std::vector<Partition> parts;      // encoded, horizontal order (owned ones)
     std::vector<std::vector<val_t>> diag;   // symmetric: per owned partition
     std::vector<std::unique_ptr<CsxStream>> exported;
     std::vector<std::vector<spx_index_t>> exported_rows_info;
-    bool full_colind;
-    DeviceMatrix *dev;
+    bool full_colind = false;
+    DeviceMatrix *dev = nullptr;
     std::unique_ptr<GpuStream> host_stream;   // kept for host-only matrices (save/restore)
-    idx_t own_lo, own_hi;
+    idx_t own_lo = 0, own_hi = 0;
     GpuEmitParams emit_params;
-    bool auto_rb;
+    bool auto_rb = false;
     double rb_scale = 1.0;      // chosen by the launch autotuner (multiplies the automatic row-block size)
     int waves = 4;              // wavefronts per workgroup of the SpMV kernel
-    bool host_only;
-    int device_ordinal;
-    bool dirty;                               // values changed since the last upload
+    bool host_only = false;
+    int device_ordinal = -1;
+    bool dirty = false;                       // values changed since the last upload
     std::vector<std::vector<idx_t>> spans;    // per partition and row: reach of its units
     std::vector<idx_t> max_span;              // per partition
     // accounting
-    size_t nnz_stored, n_unit_elems, n_delta_elems, n_units;
-    size_t value_bytes, index_bytes, n_rowblocks, n_shared;
-    double tune_seconds, emit_seconds;
+    size_t nnz_stored = 0, n_unit_elems = 0, n_delta_elems = 0, n_units = 0;
+    size_t value_bytes = 0, index_bytes = 0, n_rowblocks = 0, n_shared = 0;
+    double tune_seconds = 0.0, emit_seconds = 0.0;
     std::string log;
     std::mutex mtx;
 };
@@ -324,13 +326,26 @@ static void emit_and_upload(spx_matrix_t *A)
         gp.target_elems = std::max<size_t>((size_t)(A->rb_scale * (double) gp.target_elems), 512);
     }
     GpuStream gs;
+    const unsigned hw = host_threads();
+    // pieces (partitions, row ranges) are emitted concurrently into streams of
+    // their own and joined in order; threads left over work inside a piece
+    auto emit_pieces = [&](std::vector<Partition> &pieces, const std::vector<std::vector<SymTile>> *tl) {
+        const size_t n = pieces.size();
+        std::vector<GpuStream> locs(n);
+        const unsigned inner = (unsigned) std::max<size_t>(1, hw / std::max<size_t>(1, std::min<size_t>(n, hw)));
+        parallel_for(n, hw, [&](size_t i) {
+            GpuEmitParams g = gp;
+            if (tl) g.tiles = &(*tl)[i];
+            emit_gpu(pieces[i], g, locs[i], inner);
+        });
+        for (GpuStream &l : locs) append_stream(gs, std::move(l));
+    };
     if (sym) {
         // The GPU stream holds the stored lower triangle and its mirror image
         // as one general matrix over rows [0, last owned row): every row is
         // then owned by exactly one row-block of this process and no atomics
         // are needed; the diagonal goes through csx_sym_init_kernel.
         gs.dvalues.assign((size_t) A->nrows, 0.0);
-        Partition full;
         for (size_t i = 0; i < nown; ++i) {
             const PartBounds &b = A->bounds[first + i];
             for (size_t r = 0; r < A->diag[i].size() && r < (size_t) b.nr_rows; ++r)
@@ -341,20 +356,39 @@ static void emit_and_upload(spx_matrix_t *A)
         // process with a slice produces a partial vector instead (rows it
         // does not touch are zeroed by the init kernel) to be summed later.
         gs.sym_fused = A->own_lo == 0 && A->own_hi == A->nrows;
-        std::vector<SymTile> tiles;
+        gp.skip_empty = !gs.sym_fused;
         if (gp.sym_once) {
             // the dense 8x8 tiles of the lower triangle are read once and used
-            // twice (SPX_PASS_SYMTILE); everything else is mirrored as below
-            build_sym_once(A->parts, full, tiles);
-            gp.tiles = &tiles;
+            // twice (SPX_PASS_SYMTILE); everything else is held with its mirror
+            // image.  One piece per owned partition, plus -- for a process with
+            // a slice -- pieces for the rows in front of it that its mirror
+            // image reaches.
+            std::vector<SymRange> ranges;
+            if (A->own_lo > 0) {
+                const idx_t k = (idx_t) std::max<size_t>(1, std::min<size_t>(hw, (size_t) A->own_lo / 8192));
+                for (idx_t q = 0; q < k; ++q) {
+                    const idx_t lo = (idx_t)((int64_t) A->own_lo * q / k) & ~7;
+                    const idx_t hi = q + 1 == k ? A->own_lo : ((idx_t)((int64_t) A->own_lo * (q + 1) / k) & ~7);
+                    if (hi > lo) ranges.push_back(SymRange{lo, hi});
+                }
+            }
+            for (size_t i = 0; i < nown; ++i) {
+                const PartBounds &b = A->bounds[first + i];
+                const idx_t hi = i + 1 == nown ? A->own_hi : A->bounds[first + i + 1].row_start;
+                ranges.push_back(SymRange{b.row_start, hi});
+            }
+            std::vector<Partition> fulls;
+            std::vector<std::vector<SymTile>> tiles;
+            build_sym_ranges(A->parts, ranges, gp.max_rows >= 8, fulls, tiles, hw);
+            emit_pieces(fulls, &tiles);
         } else {
+            Partition full;
             for (size_t i = 0; i < nown; ++i) append_sym_expanded(A->parts[i], full, gp.sym_remine);
+            if (gs.sym_fused) full.nr_rows = (size_t) A->nrows;
+            emit_gpu(full, gp, gs, hw);
         }
-        if (gs.sym_fused) full.nr_rows = (size_t) A->nrows;
-        gp.skip_empty = !gs.sym_fused;
-        emit_gpu(full, gp, gs);
     } else {
-        for (size_t i = 0; i < nown; ++i) emit_gpu(A->parts[i], gp, gs);
+        emit_pieces(A->parts, nullptr);
     }
     finalize_stream(gs, (size_t) A->nrows);
     gs.waves = (uint32_t) A->waves;

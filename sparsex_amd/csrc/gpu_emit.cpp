@@ -1,5 +1,6 @@
 // gpu_emit.cpp -- see gpu_emit.hpp and gpu_format.h.
 #include "gpu_emit.hpp"
+#include "threads.hpp"
 
 #include <algorithm>
 #include <cassert>
@@ -661,7 +662,12 @@ static void extract_tiles(std::vector<Single> &pts, std::vector<SymTile> &tiles,
                segs[j].row == segs[j - 1].row + 1)
             ++j;
         size_t k = i;
-        if (segs[i].width == 8)
+        if (segs[i].width == 8) {
+            // tiles start on rows that are multiples of eight (0-based, global): a
+            // row-block border then never has to cut one (see emit_gpu, step 2)
+            while (k < j && (segs[k].row - 1) % 8 != 0) ++k;
+            for (size_t q = i; q < k && q < j; ++q)
+                for (uint32_t w = 0; w < segs[q].width; ++w) rest.push_back(pts[segs[q].first + w]);
             for (; k + 8 <= j; k += 8) {
                 SymTile t;
                 t.row0 = segs[k].row - 1;          // points are 1-based
@@ -670,6 +676,7 @@ static void extract_tiles(std::vector<Single> &pts, std::vector<SymTile> &tiles,
                     for (size_t w = 0; w < 8; ++w) t.v[r * 8 + w] = pts[segs[k + r].first + w].val;
                 tiles.push_back(t);
             }
+        }
         for (; k < j; ++k)
             for (uint32_t w = 0; w < segs[k].width; ++w) rest.push_back(pts[segs[k].first + w]);
         i = j;
@@ -679,18 +686,97 @@ static void extract_tiles(std::vector<Single> &pts, std::vector<SymTile> &tiles,
     });
 }
 
-void build_sym_once(const std::vector<Partition> &lowers, Partition &out,
-                    std::vector<SymTile> &tiles)
+// Joins `src` to the end of `dst` (both packed, i.e. not finalized): offsets
+// of the appended row-blocks are shifted behind what `dst` already holds.
+void append_stream(GpuStream &dst, GpuStream &&src)
 {
-    std::vector<Single> pts, rest;
-    out.type = ENC_H;
-    out.row_start = 0;
-    for (const Partition &lower : lowers) {
+    assert(!dst.pass_stride && !src.pass_stride);
+    if (src.rbs.empty() && src.shared.empty()) {
+        dst.lds_doubles = std::max(dst.lds_doubles, src.lds_doubles);
+        return;
+    }
+    pad_to(dst.values, 2);
+    while (dst.cidx.size() % 16) dst.cidx.push_back(0);
+    const uint64_t v0 = dst.values.size();
+    const uint32_t p0 = (uint32_t) dst.passes.size(), d0 = (uint32_t) dst.descs.size();
+    const uint32_t c0 = (uint32_t)(dst.cidx.size() / 16), s0 = (uint32_t) dst.segrows.size();
+    const uint32_t k0 = dst.n_carry, sp0 = (uint32_t) dst.spill_col.size();
+    if (dst.rbs.empty() && dst.values.empty()) {
+        // (first piece: take the arrays as they are)
+        dst.values.swap(src.values);
+        dst.descs.swap(src.descs);
+        dst.passes.swap(src.passes);
+        dst.cidx.swap(src.cidx);
+        dst.segrows.swap(src.segrows);
+        dst.spill_col.swap(src.spill_col);
+        dst.rbs.swap(src.rbs);
+        dst.shared.swap(src.shared);
+    } else {
+        for (SpxRowBlock &rb : src.rbs) {
+            rb.val_off += v0;
+            rb.pass_off += p0;
+            rb.desc_off += d0;
+            rb.cidx_off += c0;
+            rb.seg_off += s0;
+            rb.spill_off += sp0;
+            if (rb.flags & SPX_RB_SHARED) rb.carry_slot += k0;
+        }
+        for (SpxSharedRow &sr : src.shared) sr.first_slot += k0;
+        dst.values.insert(dst.values.end(), src.values.begin(), src.values.end());
+        dst.descs.insert(dst.descs.end(), src.descs.begin(), src.descs.end());
+        dst.passes.insert(dst.passes.end(), src.passes.begin(), src.passes.end());
+        dst.cidx.insert(dst.cidx.end(), src.cidx.begin(), src.cidx.end());
+        dst.segrows.insert(dst.segrows.end(), src.segrows.begin(), src.segrows.end());
+        dst.spill_col.insert(dst.spill_col.end(), src.spill_col.begin(), src.spill_col.end());
+        dst.rbs.insert(dst.rbs.end(), src.rbs.begin(), src.rbs.end());
+        dst.shared.insert(dst.shared.end(), src.shared.begin(), src.shared.end());
+    }
+    dst.n_carry += src.n_carry;
+    dst.lds_doubles = std::max(dst.lds_doubles, src.lds_doubles);
+    dst.nnz_stored += src.nnz_stored;
+    dst.n_unit_elems += src.n_unit_elems;
+    dst.n_delta_elems += src.n_delta_elems;
+    dst.n_units += src.n_units;
+    GpuStream().values.swap(src.values);      // release the piece's memory now
+}
+
+void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<SymRange> &ranges,
+                      bool want_tiles, std::vector<Partition> &outs,
+                      std::vector<std::vector<SymTile>> &tiles, unsigned nthreads)
+{
+    const size_t P = lowers.size(), R = ranges.size();
+    outs.assign(R, Partition());
+    tiles.assign(R, std::vector<SymTile>());
+    if (!R) return;
+    const idx_t nrows = ranges.back().hi;
+    const size_t nr_cols = P ? lowers[0].nr_cols : (size_t) nrows;
+    // range of a (0-based) row
+    auto range_of = [&](idx_t row) {
+        size_t lo = 0, hi = R;
+        while (hi - lo > 1) {
+            const size_t mid = (lo + hi) / 2;
+            if (ranges[mid].lo <= row) lo = mid;
+            else hi = mid;
+        }
+        return lo;
+    };
+    // the range that IS partition i (its rows), or R
+    std::vector<size_t> own_range(P, R);
+    for (size_t i = 0; i < P; ++i)
+        for (size_t j = 0; j < R; ++j)
+            if (ranges[j].lo == lowers[i].row_start) own_range[i] = j;
+
+    // 1. every partition: its strictly lower points (1-based global), dense
+    // aligned 8x8 tiles apart
+    std::vector<std::vector<Single>> rest(P);
+    std::vector<std::vector<SymTile>> ptiles(P);
+    parallel_for(P, nthreads, [&](size_t i) {
+        const Partition &lower = lowers[i];
         const idx_t rs = lower.row_start;
-        out.nr_cols = lower.nr_cols;
-        out.nr_rows = std::max<size_t>(out.nr_rows, (size_t) rs + lower.nr_rows);
-        for (size_t i = 0; i < lower.elems_size; ++i) {
-            const Elem &e = lower.elems[i];
+        std::vector<Single> pts;
+        pts.reserve(lower.nnz);
+        for (size_t k = 0; k < lower.elems_size; ++k) {
+            const Elem &e = lower.elems[k];
             if (!e.is_unit()) {
                 pts.push_back(Single{e.row + rs, e.col, e.val});
                 continue;
@@ -698,34 +784,103 @@ void build_sym_once(const std::vector<Partition> &lowers, Partition &out,
             const val_t *src = &lower.pool[e.voff];
             Elem g = e;
             g.row += rs;
-            for (size_t k = 0; k < e.size; ++k) {
+            for (size_t q = 0; q < e.size; ++q) {
                 idx_t r, c;
-                unit_elem_coords(g, k, r, c);
-                pts.push_back(Single{r, c, src[k]});
+                unit_elem_coords(g, q, r, c);
+                pts.push_back(Single{r, c, src[q]});
             }
         }
+        if (want_tiles) {
+            extract_tiles(pts, ptiles[i], rest[i]);
+        } else {
+            rest[i].swap(pts);
+        }
+    });
+
+    // 2. a group of eight rows that holds tiles must fit one row-block: count
+    // the nonzeros of the full rows (lower + mirror image) where there are tiles
+    size_t n_tiles = 0;
+    for (size_t i = 0; i < P; ++i) n_tiles += ptiles[i].size();
+    if (n_tiles) {
+        std::vector<std::atomic<uint32_t>> cnt((size_t) nrows);
+        for (auto &c : cnt) c.store(0, std::memory_order_relaxed);
+        parallel_for(P, nthreads, [&](size_t i) {
+            for (const Single &s : rest[i]) {
+                cnt[(size_t) s.row - 1].fetch_add(1, std::memory_order_relaxed);
+                cnt[(size_t) s.col - 1].fetch_add(1, std::memory_order_relaxed);
+            }
+            for (const SymTile &t : ptiles[i])
+                for (idx_t k = 0; k < 8; ++k) {
+                    cnt[(size_t)(t.row0 + k)].fetch_add(8, std::memory_order_relaxed);
+                    cnt[(size_t)(t.col0 + k)].fetch_add(8, std::memory_order_relaxed);
+                }
+        });
+        parallel_for(P, nthreads, [&](size_t i) {
+            std::vector<SymTile> keep;
+            for (const SymTile &t : ptiles[i]) {
+                size_t need = 0;
+                for (idx_t k = 0; k < 8; ++k) need += cnt[(size_t)(t.row0 + k)].load(std::memory_order_relaxed);
+                if (need <= SPX_MAX_RB_ELEMS) {
+                    keep.push_back(t);
+                    continue;
+                }
+                for (idx_t r = 0; r < 8; ++r)
+                    for (idx_t w = 0; w < 8; ++w)
+                        rest[i].push_back(Single{t.row0 + r + 1, t.col0 + w + 1, t.v[r * 8 + w]});
+            }
+            ptiles[i].swap(keep);
+        });
     }
-    const size_t n_lower = pts.size();
-    extract_tiles(pts, tiles, rest);
-    // what is not in a tile: lower triangle and mirror image, both as row segments
-    const size_t n_rest = rest.size();
-    rest.reserve(2 * n_rest);
-    for (size_t i = 0; i < n_rest; ++i) rest.push_back(Single{rest[i].col, rest[i].row, rest[i].val});
-    // The diagonal itself is held apart (dvalues), which splits every row's run
-    // around it in two.  Where a(r,r-1) exists (and so does its mirror image
-    // a(r-1,r)), an explicit zero at (r,r) joins the runs of row r again: the
-    // triangular blocks along the diagonal become dense blocks of one width
-    // instead of eight ragged ones.
-    {
-        std::vector<char> has_sub(out.nr_rows + 2, 0);
-        for (size_t i = 0; i < n_rest; ++i)
-            if (rest[i].col + 1 == rest[i].row) has_sub[(size_t) rest[i].row] = 1;
-        for (size_t r = 2; r + 1 <= out.nr_rows; ++r)
-            if (has_sub[r] && has_sub[r + 1]) rest.push_back(Single{(idx_t) r, (idx_t) r, 0.0});
-    }
-    append_upper_segments(rest, out);
-    out.elems_size = out.elems.size();
-    out.nnz += 2 * n_lower;
+
+    // 3. mirror image of what is not in a tile, dealt to the range of its row
+    std::vector<std::vector<std::vector<Single>>> bucket(P, std::vector<std::vector<Single>>(R));
+    parallel_for(P, nthreads, [&](size_t i) {
+        size_t j = 0;
+        for (const Single &s : rest[i]) {
+            const idx_t row = s.col - 1;                  // 0-based row of the mirrored point
+            if (!(ranges[j].lo <= row && row < ranges[j].hi)) j = range_of(row);
+            bucket[i][j].push_back(Single{s.col, s.row, s.val});
+        }
+    });
+
+    // 4. every range: its points as row segments and blocks, rows relative to
+    // the range
+    parallel_for(R, nthreads, [&](size_t j) {
+        std::vector<Single> pts;
+        size_t total = 0;
+        for (size_t i = 0; i < P; ++i) total += bucket[i][j].size() + (own_range[i] == j ? rest[i].size() : 0);
+        pts.reserve(total + total / 8);
+        for (size_t i = 0; i < P; ++i) {
+            if (own_range[i] == j) {
+                pts.insert(pts.end(), rest[i].begin(), rest[i].end());
+                std::vector<Single>().swap(rest[i]);
+                tiles[j].swap(ptiles[i]);
+            }
+            pts.insert(pts.end(), bucket[i][j].begin(), bucket[i][j].end());
+            std::vector<Single>().swap(bucket[i][j]);
+        }
+        const size_t n_pts = pts.size();
+        std::sort(pts.begin(), pts.end(), [](const Single &a, const Single &b) {
+            return a.row < b.row || (a.row == b.row && a.col < b.col);
+        });
+        // The diagonal itself is held apart (dvalues), which splits every row's run
+        // around it in two.  Where a(r,r-1) and a(r,r+1) both exist, an explicit
+        // zero at (r,r) joins the runs of row r again: the triangular blocks along
+        // the diagonal become dense blocks of one width instead of eight ragged ones.
+        for (size_t k = 0; k + 1 < n_pts; ++k)
+            if (pts[k].row == pts[k + 1].row && pts[k].col + 1 == pts[k].row &&
+                pts[k + 1].col == pts[k].row + 1)
+                pts.push_back(Single{pts[k].row, pts[k].row, 0.0});
+        Partition &out = outs[j];
+        out.type = ENC_H;
+        out.row_start = ranges[j].lo;
+        out.nr_rows = (size_t)(ranges[j].hi - ranges[j].lo);
+        out.nr_cols = nr_cols;
+        for (Single &s : pts) s.row -= ranges[j].lo;
+        append_upper_segments(pts, out);
+        out.elems_size = out.elems.size();
+        out.nnz = n_pts;
+    });
 }
 
 void finalize_stream(GpuStream &s, size_t nrows)
@@ -755,7 +910,7 @@ void finalize_stream(GpuStream &s, size_t nrows)
     s.pass_stride = stride;
 }
 
-void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out)
+void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsigned nthreads)
 {
     assert(p.type == ENC_H);
     const idx_t nrows = (idx_t) p.nr_rows;
@@ -781,10 +936,13 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out)
     for (const SymTile &t : tiles)
         for (idx_t r = 0; r < 8; ++r) cnt[(size_t)(t.row0 - p.row_start + r)] += 8;
 
-    // 2. row ranges of the row-blocks
-    std::vector<char> inside_tile((size_t) nrows + 1, 0);   // a border in front of row r cuts a tile
-    for (const SymTile &t : tiles)
-        for (idx_t r = 1; r < 8; ++r) inside_tile[(size_t)(t.row0 - p.row_start + r)] = 1;
+    // 2. row ranges of the row-blocks.  Symmetric tiles sit on rows that are
+    // multiples of eight (global numbering); such a group of eight rows is never
+    // cut: the row-block is closed in front of it when it would not fit.
+    std::vector<char> tile_group((size_t) nrows / 8 + 2, 0);   // by (global row) / 8 - first group
+    const idx_t g0 = p.row_start / 8;
+    for (const SymTile &t : tiles) tile_group[(size_t)(t.row0 / 8 - g0)] = 1;
+    auto in_group = [&](idx_t r) { return tile_group[(size_t)((p.row_start + r) / 8 - g0)] != 0; };
     std::vector<Plan> plans;
     {
         idx_t start = 0;
@@ -792,16 +950,31 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out)
         for (idx_t r = 0; r < nrows; ++r) {
             size_t c = cnt[(size_t) r];
             if (c > SPX_MAX_RB_ELEMS) {
+                if (in_group(r)) throw FatalError("symmetric tile on an over-long row");
                 if (r > start) plans.push_back(Plan{start, r, false});
                 plans.push_back(Plan{r, r + 1, true});
                 start = r + 1;
                 acc = 0;
                 continue;
             }
-            // (a border inside a symmetric tile would cost the tile: such rows
-            // only close a row-block when a hard limit says so)
-            const bool hard = acc + c > SPX_MAX_RB_ELEMS || (size_t)(r - start) >= max_rows;
-            if (hard || (acc > 0 && acc + c > target && !inside_tile[(size_t) r])) {
+            const bool grouped = in_group(r);
+            const bool head = grouped && (p.row_start + r) % 8 == 0;
+            bool close;
+            if (grouped && !head) {
+                close = false;                    // inside a tile group
+            } else if (head) {
+                size_t need = 0;
+                for (idx_t k = r; k < r + 8 && k < nrows; ++k) need += cnt[(size_t) k];
+                if (need > SPX_MAX_RB_ELEMS || max_rows < 8)
+                    throw FatalError("symmetric tile group exceeds a row-block");
+                close = acc > 0 && (acc + need > std::max<size_t>(target, need) ||
+                                    (size_t)(r - start) + 8 > max_rows);
+                if (acc + need > SPX_MAX_RB_ELEMS) close = true;
+            } else {
+                const bool hard = acc + c > SPX_MAX_RB_ELEMS || (size_t)(r - start) >= max_rows;
+                close = hard || (acc > 0 && acc + c > target);
+            }
+            if (close && r > start) {
                 plans.push_back(Plan{start, r, false});
                 start = r;
                 acc = 0;
@@ -879,121 +1052,92 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out)
         }
     }
 
-    // 3a. vertical, diagonal, anti-diagonal and strided units give one nonzero
-    // per lane.  Where the nonzeros of such units sit next to each other along
-    // their rows (a 27-point stencil mined as diagonals: six consecutive columns
-    // per row), the row-block takes them as row segments instead -- the units
-    // were right for a CPU that walks one unit at a time, the lanes want width.
-    std::vector<std::vector<RowSeg>> rowsegs(plans.size());
-    {
+    // 3a. (per row-block, see recut_plan) vertical, diagonal, anti-diagonal and
+    // strided units give one nonzero per lane.  Where the nonzeros of such units
+    // sit next to each other along their rows (a 27-point stencil mined as
+    // diagonals: six consecutive columns per row), the row-block takes them as
+    // row segments instead -- the units were right for a CPU that walks one unit
+    // at a time, the lanes want width.
+    auto recut_plan = [&](size_t pl, std::vector<RowSeg> &rowsegs) {
+        if (!prm.recut_linear) return;
         std::vector<Single> pts;
-        for (size_t pl = 0; prm.recut_linear && pl < plans.size(); ++pl) {
-            pts.clear();
-            for (const Piece &pc : lin_pieces[pl]) {
-                const Elem &u = p.elems[pc.elem];
-                for (size_t k = pc.a; k < pc.b; ++k) {
-                    idx_t r, c;
-                    unit_elem_coords(u, k, r, c);
-                    pts.push_back(Single{r - 1, c - 1, p.pool[u.voff + k]});
-                }
-            }
-            std::sort(pts.begin(), pts.end(), [](const Single &a, const Single &b) {
-                return a.row < b.row || (a.row == b.row && a.col < b.col);
-            });
-            size_t nseg = 0;
-            for (size_t a = 0; a < pts.size(); ++nseg) {
-                size_t b = a + 1;
-                while (b < pts.size() && b - a < SPX_MAX_SEG_WIDTH && pts[b].row == pts[a].row &&
-                       pts[b].col == pts[b - 1].col + 1)
-                    ++b;
-                a = b;
-            }
-            if (pts.size() * 4 < nseg * 7) {        // below 1.75 nonzeros per segment: keep the units
-                pieces[pl].insert(pieces[pl].end(), lin_pieces[pl].begin(), lin_pieces[pl].end());
-                pts.clear();
-            }
-            // the leftover nonzeros of the row-block join in: next to a segment
-            // they widen it, next to each other they form one
-            if (pts.empty() && singles[pl].size() < 2) continue;
-            if (plans[pl].split) continue;
-            pts.insert(pts.end(), singles[pl].begin(), singles[pl].end());
-            singles[pl].clear();
-            std::sort(pts.begin(), pts.end(), [](const Single &a, const Single &b) {
-                return a.row < b.row || (a.row == b.row && a.col < b.col);
-            });
-            for (size_t a = 0; a < pts.size();) {
-                size_t b = a + 1;
-                while (b < pts.size() && b - a < SPX_MAX_SEG_WIDTH && pts[b].row == pts[a].row &&
-                       pts[b].col == pts[b - 1].col + 1)
-                    ++b;
-                if (b - a < 3) {
-                    // (pairs stay leftovers: a width-2 unit pass of a few lanes per
-                    // row-block costs more than two gathered nonzeros)
-                    for (size_t k = a; k < b; ++k) singles[pl].push_back(pts[k]);
-                } else {
-                    RowSeg sg;
-                    sg.row = pts[a].row;
-                    sg.col = pts[a].col;
-                    sg.width = (uint8_t)(b - a);
-                    for (size_t k = a; k < b; ++k) sg.v[k - a] = pts[k].val;
-                    rowsegs[pl].push_back(sg);
-                }
-                a = b;
+        for (const Piece &pc : lin_pieces[pl]) {
+            const Elem &u = p.elems[pc.elem];
+            for (size_t k = pc.a; k < pc.b; ++k) {
+                idx_t r, c;
+                unit_elem_coords(u, k, r, c);
+                pts.push_back(Single{r - 1, c - 1, p.pool[u.voff + k]});
             }
         }
-    }
-
-    // 3b. symmetric tiles: a tile lives in the row-block of its eight rows; one
-    // that a row-block border cuts (or that would overflow the slots of its
-    // row-block) is given up and goes, with its mirror image, to the leftovers
-    std::vector<std::vector<const SymTile *>> rb_tiles(plans.size());
-    {
-        std::vector<std::vector<idx_t>> touched(plans.size());
-        auto demote = [&](const SymTile &t) {
-            for (idx_t i = 0; i < 8; ++i)
-                for (idx_t w = 0; w < 8; ++w) {
-                    const idx_t r = t.row0 - p.row_start + i, c = t.col0 + w;   // 0-based
-                    const val_t v = t.v[i * 8 + w];
-                    singles[plan_of_row[(size_t) r]].push_back(Single{r, c, v});
-                    singles[plan_of_row[(size_t)(c - p.row_start)]].push_back(
-                        Single{c - p.row_start, r + p.row_start, v});
-                }
+        auto by_row_col = [](const Single &a, const Single &b) {
+            return a.row < b.row || (a.row == b.row && a.col < b.col);
         };
-        for (const SymTile &t : tiles) {
-            const size_t r = (size_t)(t.row0 - p.row_start);
-            const uint32_t pl = plan_of_row[r];
-            if (plan_of_row[r + 7] != pl || plans[pl].split) {
-                demote(t);
-                continue;
-            }
-            // distinct columns in front of the row-block so far (upper bound: 8 more)
-            std::vector<idx_t> &tc = touched[pl];
-            const idx_t lo_g = p.row_start + plans[pl].row_lo;
-            size_t add = 0;
-            for (idx_t c = t.col0; c < t.col0 + 8 && c < lo_g; ++c)
-                if (!std::binary_search(tc.begin(), tc.end(), c)) ++add;
-            if (tc.size() + add > SPX_MAX_TILE_SLOTS) {
-                demote(t);
-                continue;
-            }
-            for (idx_t c = t.col0; c < t.col0 + 8 && c < lo_g; ++c) {
-                auto it = std::lower_bound(tc.begin(), tc.end(), c);
-                if (it == tc.end() || *it != c) tc.insert(it, c);
-            }
-            rb_tiles[pl].push_back(&t);
+        std::sort(pts.begin(), pts.end(), by_row_col);
+        size_t nseg = 0;
+        for (size_t a = 0; a < pts.size(); ++nseg) {
+            size_t b = a + 1;
+            while (b < pts.size() && b - a < SPX_MAX_SEG_WIDTH && pts[b].row == pts[a].row &&
+                   pts[b].col == pts[b - 1].col + 1)
+                ++b;
+            a = b;
         }
+        if (pts.size() * 4 < nseg * 7) {        // below 1.75 nonzeros per segment: keep the units
+            pieces[pl].insert(pieces[pl].end(), lin_pieces[pl].begin(), lin_pieces[pl].end());
+            pts.clear();
+        }
+        // the leftover nonzeros of the row-block join in: next to a segment
+        // they widen it, next to each other they form one
+        if (pts.empty() && singles[pl].size() < 2) return;
+        if (plans[pl].split) return;
+        pts.insert(pts.end(), singles[pl].begin(), singles[pl].end());
+        singles[pl].clear();
+        std::sort(pts.begin(), pts.end(), by_row_col);
+        for (size_t a = 0; a < pts.size();) {
+            size_t b = a + 1;
+            while (b < pts.size() && b - a < SPX_MAX_SEG_WIDTH && pts[b].row == pts[a].row &&
+                   pts[b].col == pts[b - 1].col + 1)
+                ++b;
+            if (b - a < 3) {
+                // (pairs stay leftovers: a width-2 unit pass of a few lanes per
+                // row-block costs more than two gathered nonzeros)
+                for (size_t k = a; k < b; ++k) singles[pl].push_back(pts[k]);
+            } else {
+                RowSeg sg;
+                sg.row = pts[a].row;
+                sg.col = pts[a].col;
+                sg.width = (uint8_t)(b - a);
+                for (size_t k = a; k < b; ++k) sg.v[k - a] = pts[k].val;
+                rowsegs.push_back(sg);
+            }
+            a = b;
+        }
+    };
+
+    // 3b. symmetric tiles: a tile lives in the row-block of its eight rows (the
+    // planner never cuts a tile group, and 8192 nonzeros per row-block bound the
+    // distinct tile columns far below the slot limit)
+    std::vector<std::vector<const SymTile *>> rb_tiles(plans.size());
+    for (const SymTile &t : tiles) {
+        const size_t r = (size_t)(t.row0 - p.row_start);
+        const uint32_t pl = plan_of_row[r];
+        if (plan_of_row[r + 7] != pl || plans[pl].split)
+            throw FatalError("symmetric tile cut by a row-block border");
+        rb_tiles[pl].push_back(&t);
     }
 
-    // 4. emit
-    RbBuilder bld(p, out, prm.stack_segments);
-    for (size_t i = 0; i < plans.size(); ++i) {
+    // 4. emit: the row-blocks are independent of each other, so contiguous runs
+    // of them are built by several threads into streams of their own and joined
+    // in order
+    auto emit_plan = [&](size_t i, RbBuilder &bld, GpuStream &dst) {
         const Plan &pl = plans[i];
+        std::vector<RowSeg> rowsegs;
+        recut_plan(i, rowsegs);
         if (prm.skip_empty && pieces[i].empty() && singles[i].empty() && rb_tiles[i].empty() &&
-            rowsegs[i].empty())
-            continue;
+            rowsegs.empty())
+            return;
         if (!pl.split) {
-            bld.emit(pl.row_lo, pl.row_hi, pieces[i], singles[i], 0, 0, &rb_tiles[i], &rowsegs[i]);
-            continue;
+            bld.emit(pl.row_lo, pl.row_hi, pieces[i], singles[i], 0, 0, &rb_tiles[i], &rowsegs);
+            return;
         }
         // an over-long row: everything is a single here; chunk it
         std::vector<Single> &all = singles[i];
@@ -1002,18 +1146,31 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out)
         const size_t chunk = SPX_MAX_RB_ELEMS / 2;
         SpxSharedRow sr;
         sr.row = (uint32_t)(p.row_start + pl.row_lo);
-        sr.first_slot = out.n_carry;
+        sr.first_slot = dst.n_carry;
         sr.n_slots = 0;
         std::vector<Piece> none;
         for (size_t b = 0; b < all.size(); b += chunk) {
             size_t e2 = std::min(all.size(), b + chunk);
             std::vector<Single> part(all.begin() + b, all.begin() + e2);
-            bld.emit(pl.row_lo, pl.row_hi, none, part, SPX_RB_SHARED, out.n_carry);
-            ++out.n_carry;
+            bld.emit(pl.row_lo, pl.row_hi, none, part, SPX_RB_SHARED, dst.n_carry);
+            ++dst.n_carry;
             ++sr.n_slots;
         }
-        out.shared.push_back(sr);
+        dst.shared.push_back(sr);
+    };
+    if (nthreads <= 1 || plans.size() < 64) {
+        RbBuilder bld(p, out, prm.stack_segments);
+        for (size_t i = 0; i < plans.size(); ++i) emit_plan(i, bld, out);
+        return;
     }
+    const size_t n_chunks = std::min<size_t>(plans.size() / 16, (size_t) nthreads * 4);
+    std::vector<GpuStream> locs(n_chunks);
+    parallel_for(n_chunks, nthreads, [&](size_t c) {
+        const size_t lo = plans.size() * c / n_chunks, hi = plans.size() * (c + 1) / n_chunks;
+        RbBuilder bld(p, locs[c], prm.stack_segments);
+        for (size_t i = lo; i < hi; ++i) emit_plan(i, bld, locs[c]);
+    });
+    for (GpuStream &l : locs) append_stream(out, std::move(l));
 }
 
 }  // namespace spx

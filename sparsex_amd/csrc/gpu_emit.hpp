@@ -80,8 +80,13 @@ struct GpuEmitParams {
 };
 
 // Appends the row-blocks of partition `p` (horizontal order) to `out`.
-// Rows are numbered globally (p.row_start + local row).
-void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out);
+// Rows are numbered globally (p.row_start + local row).  With nthreads > 1
+// runs of row-blocks are built concurrently and joined in order (same stream).
+void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsigned nthreads = 1);
+
+// Joins `src` to the end of `dst` (neither finalized yet): what per-partition /
+// per-range emitter threads produced becomes one stream.
+void append_stream(GpuStream &dst, GpuStream &&src);
 
 // Lays the pass headers out at a fixed stride per row-block (the largest pass
 // count), so that a workgroup can fetch its first headers without waiting for
@@ -98,12 +103,21 @@ void finalize_stream(GpuStream &s, size_t nrows);
 // R x c <-> block-col c x R).
 void append_sym_expanded(const Partition &lower, Partition &out, bool remine_upper = true);
 
-// Symmetric path, whole matrix in one process, values read once where it pays:
-// the strictly lower triangle held by `lowers` (global numbering) is split into
-// dense 8x8 tiles (-> `tiles`, sorted by row) and the rest, which goes to `out`
-// together with its mirror image, both re-cut into row segments and blocks.
-void build_sym_once(const std::vector<Partition> &lowers, Partition &out,
-                    std::vector<SymTile> &tiles);
+// Symmetric path, values read once where it pays.  The strictly lower triangle
+// held by `lowers` (rows local to each partition) is turned into one general
+// partition per row range of `ranges` (ascending, contiguous, 0-based global
+// [lo, hi); the rows of every partition of `lowers` must be one of the ranges,
+// further ranges in front take the mirror image that lands on rows of other
+// processes): dense 8x8 tiles on rows that are multiples of eight go to
+// `tiles[range]` (sorted by row), everything else goes to `outs[range]` together
+// with the mirror image that falls into the range, both re-cut into row
+// segments and blocks; rows of outs[j] are relative to ranges[j].lo.  Ranges
+// are independent of each other, so they are built -- and can then be emitted
+// -- concurrently.
+struct SymRange { idx_t lo, hi; };
+void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<SymRange> &ranges,
+                      bool want_tiles, std::vector<Partition> &outs,
+                      std::vector<std::vector<SymTile>> &tiles, unsigned nthreads);
 
 // coordinates (1-based, horizontal order) of element k of a unit
 inline void unit_elem_coords(const Elem &u, size_t k, idx_t &r, idx_t &c)

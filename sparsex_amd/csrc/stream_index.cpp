@@ -1,0 +1,189 @@
+// stream_index.cpp -- see stream_index.hpp.
+#include "stream_index.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace spx {
+
+namespace {
+
+inline uint32_t popcount_upto(uint64_t mask, uint32_t lane)
+{
+    // set bits in lanes 1..lane (bit 0 is never set)
+    const uint64_t m = lane >= 63 ? mask : (mask & ((2ull << lane) - 1ull));
+    return (uint32_t) __builtin_popcountll(m);
+}
+
+struct LaneSeg { int64_t row; int64_t col0; int64_t dcol_elem; bool ok; };
+
+// row (relative to the row-block) and first column of lane l of a unit pass
+inline void unit_lane(const GpuStream &s, const SpxRowBlock &rb, const SpxPass &ps, uint32_t l,
+                      int64_t &row, int64_t &col)
+{
+    const uint32_t rank = (uint32_t) ps.rank0 + popcount_upto(ps.mask, l);
+    const SpxUnitDesc &d = s.descs[(size_t) rb.desc_off + rank];
+    const uint32_t bits = d.bits;
+    const int sidx = (int) ((ps.seg0 + l - ((bits >> 9) & 8191u)) & 0xffffu);
+    const uint32_t kind = (bits >> 22) & 7u;
+    const int step = (int) (bits >> 25);
+    const int drow = kind == SPX_KIND_BLOCK ? 1 : (kind >= SPX_KIND_VERT ? step : 0);
+    const int dcol = (kind == SPX_KIND_HORIZ || kind == SPX_KIND_DIAG)
+                         ? step : (kind == SPX_KIND_ADIAG ? -step : 0);
+    row = (int64_t) (bits & 511u) + (int64_t) sidx * drow;
+    col = (int64_t) d.col0 + (int64_t) sidx * dcol;
+}
+
+inline uint32_t gather_off(const GpuStream &s, const SpxRowBlock &rb, size_t e)
+{
+    const uint8_t *c = s.cidx.data() + (size_t) rb.cidx_off * 16u;
+    if (rb.cidx_width == 4) {
+        uint32_t v;
+        std::memcpy(&v, c + e * 4, 4);
+        return v;
+    }
+    uint16_t v;
+    std::memcpy(&v, c + e * 2, 2);
+    return v;
+}
+
+}  // namespace
+
+void stream_locate(const GpuStream &s, idx_t row, idx_t col, std::vector<size_t> &out)
+{
+    // row-blocks are emitted in ascending row order: first one that ends behind `row`
+    size_t lo = 0, hi = s.rbs.size();
+    while (lo < hi) {
+        const size_t mid = (lo + hi) / 2;
+        if ((int64_t) s.rbs[mid].row0 + s.rbs[mid].n_rows <= (int64_t) row) lo = mid + 1;
+        else hi = mid;
+    }
+    for (size_t i = lo; i < s.rbs.size() && (int64_t) s.rbs[i].row0 <= (int64_t) row; ++i) {
+        const SpxRowBlock &rb = s.rbs[i];
+        if ((int64_t) row >= (int64_t) rb.row0 + rb.n_rows) continue;
+        const int64_t rrel = (int64_t) row - rb.row0;
+        for (uint32_t t = 0; t < rb.n_pass; ++t) {
+            const SpxPass &ps = s.passes[(size_t) rb.pass_off + t];
+            const uint32_t nseg = ps.nseg, W = ps.width;
+            const size_t vbase = (size_t) rb.val_off + ps.val_off;
+            if (ps.kind == SPX_PASS_GATHER) {
+                for (uint32_t l = 0; l < nseg; ++l) {
+                    if ((int64_t) s.segrows[(size_t) rb.seg_off + ps.seg0 + l] != rrel) continue;
+                    for (uint32_t w = 0; w < W; ++w) {
+                        const int64_t c = (int64_t) rb.cbase +
+                                          gather_off(s, rb, (size_t) ps.elem0 + l + (size_t) w * nseg);
+                        if (c == (int64_t) col) out.push_back(vbase + spx_pass_value_index(l, w, nseg, W));
+                    }
+                }
+            } else if (ps.kind == SPX_PASS_SYMTILE) {
+                for (uint32_t l = 0; l < nseg; ++l) {
+                    const SpxUnitDesc &d = s.descs[(size_t) rb.desc_off + ps.rank0 + (l >> 3)];
+                    const int64_t r = (int64_t) (d.bits & 511u) + (l & 7u);
+                    if (r != rrel) continue;
+                    const int64_t w = (int64_t) col - (int64_t) d.col0;
+                    if (w >= 0 && w < 8) out.push_back(vbase + spx_pass_value_index(l, (uint32_t) w, nseg, 8));
+                }
+            } else {
+                for (uint32_t l = 0; l < nseg; ++l) {
+                    int64_t r, c0;
+                    unit_lane(s, rb, ps, l, r, c0);
+                    if (r != rrel) continue;
+                    const int64_t w = (int64_t) col - c0;
+                    if (w >= 0 && w < (int64_t) W)
+                        out.push_back(vbase + spx_pass_value_index(l, (uint32_t) w, nseg, W));
+                }
+            }
+        }
+    }
+}
+
+bool stream_validate(const GpuStream &s, size_t nrows, size_t ncols, size_t n_values,
+                     std::string &why)
+{
+#define SPX_REQUIRE(cond, msg)                                                                   \
+    do {                                                                                         \
+        if (!(cond)) {                                                                           \
+            why = msg;                                                                           \
+            return false;                                                                        \
+        }                                                                                        \
+    } while (0)
+    SPX_REQUIRE(s.rbs.empty() || s.pass_stride >= 1, "pass stride missing");
+    SPX_REQUIRE(s.passes.size() == s.rbs.size() * (size_t) s.pass_stride, "pass table size");
+    SPX_REQUIRE(s.waves == 2 || s.waves == 4 || s.waves == 8, "wavefronts per workgroup");
+    SPX_REQUIRE(s.lds_doubles <= SPX_MAX_TILE_SLOTS + SPX_MAX_RB_ROWS, "LDS budget");
+    SPX_REQUIRE(s.n_spill == 0 || (s.fix_ptr.size() == nrows + 1 && s.fix_idx.size() == s.n_spill),
+                "spill lists");
+    for (size_t i = 0; i + 1 < s.fix_ptr.size(); ++i)
+        SPX_REQUIRE(s.fix_ptr[i] <= s.fix_ptr[i + 1], "spill list order");
+    SPX_REQUIRE(s.fix_ptr.empty() || s.fix_ptr.back() == s.fix_idx.size(), "spill list end");
+    for (uint32_t k : s.fix_idx) SPX_REQUIRE(k < s.n_spill, "spill index");
+    SPX_REQUIRE(s.dvalues.empty() || s.dvalues.size() == nrows, "diagonal length");
+    bool tiles = false;
+    for (size_t i = 0; i < s.rbs.size(); ++i) {
+        const SpxRowBlock &rb = s.rbs[i];
+        SPX_REQUIRE(rb.n_rows >= 1 && rb.n_rows <= SPX_MAX_RB_ROWS, "row-block rows");
+        SPX_REQUIRE((size_t) rb.row0 + rb.n_rows <= nrows, "row-block row range");
+        SPX_REQUIRE(rb.pass_off == i * (size_t) s.pass_stride && rb.n_pass <= s.pass_stride,
+                    "row-block pass range");
+        SPX_REQUIRE(rb.val_off <= n_values && rb.val_off % 2 == 0, "row-block value offset");
+        SPX_REQUIRE(rb.desc_off <= s.descs.size(), "row-block descriptor offset");
+        SPX_REQUIRE((size_t) rb.cidx_off * 16u <= s.cidx.size(), "row-block column-offset position");
+        SPX_REQUIRE(rb.cidx_width == 2 || rb.cidx_width == 4, "column-offset width");
+        SPX_REQUIRE(rb.seg_off <= s.segrows.size(), "row-block row-piece offset");
+        SPX_REQUIRE((size_t) rb.n_slots + rb.n_rows <= s.lds_doubles, "row-block LDS use");
+        SPX_REQUIRE(rb.n_slots == 0 || (size_t) rb.spill_off + rb.n_slots <= s.n_spill, "spill range");
+        if (rb.flags & SPX_RB_SHARED)
+            SPX_REQUIRE(rb.carry_slot < s.n_carry && rb.n_rows == 1, "carry slot");
+        for (uint32_t t = 0; t < rb.n_pass; ++t) {
+            const SpxPass &ps = s.passes[(size_t) rb.pass_off + t];
+            const uint32_t nseg = ps.nseg, W = ps.width;
+            SPX_REQUIRE(nseg >= 1 && nseg <= SPX_PASS_SEGS && W >= 1 && W <= SPX_MAX_SEG_WIDTH,
+                        "pass shape");
+            SPX_REQUIRE(ps.val_off % 2 == 0 &&
+                        (size_t) rb.val_off + ps.val_off + (size_t) nseg * W <= n_values,
+                        "pass value range");
+            if (ps.kind == SPX_PASS_GATHER) {
+                SPX_REQUIRE((size_t) rb.seg_off + ps.seg0 + nseg <= s.segrows.size(), "row-piece range");
+                SPX_REQUIRE((size_t) rb.cidx_off * 16u +
+                            ((size_t) ps.elem0 + (size_t) nseg * W) * rb.cidx_width <= s.cidx.size(),
+                            "column-offset range");
+                for (uint32_t l = 0; l < nseg; ++l) {
+                    SPX_REQUIRE(s.segrows[(size_t) rb.seg_off + ps.seg0 + l] < rb.n_rows, "row piece row");
+                    for (uint32_t w = 0; w < W; ++w)
+                        SPX_REQUIRE((size_t) rb.cbase + gather_off(s, rb, (size_t) ps.elem0 + l +
+                                                                            (size_t) w * nseg) < ncols,
+                                    "gathered column");
+                }
+            } else if (ps.kind == SPX_PASS_SYMTILE) {
+                tiles = true;
+                SPX_REQUIRE(W == 8 && nseg % 8 == 0, "tile pass shape");
+                SPX_REQUIRE((size_t) rb.desc_off + ps.rank0 + nseg / 8 <= s.descs.size(),
+                            "tile descriptor range");
+                for (uint32_t k = 0; k < nseg / 8; ++k) {
+                    const SpxUnitDesc &d = s.descs[(size_t) rb.desc_off + ps.rank0 + k];
+                    SPX_REQUIRE((d.bits & 511u) + 8u <= rb.n_rows, "tile rows");
+                    SPX_REQUIRE((size_t) d.col0 + 8u <= ncols, "tile columns");
+                    SPX_REQUIRE((size_t) (d.bits >> 9) + 8u <= (size_t) rb.n_slots + rb.n_rows, "tile slots");
+                }
+            } else {
+                SPX_REQUIRE(ps.kind == SPX_PASS_UNIT, "pass kind");
+                SPX_REQUIRE((ps.mask & 1ull) == 0, "segment-start mask");
+                const uint32_t last = (uint32_t) ps.rank0 + popcount_upto(ps.mask, nseg - 1);
+                SPX_REQUIRE((size_t) rb.desc_off + last < s.descs.size(), "descriptor range");
+                for (uint32_t l = 0; l < nseg; ++l) {
+                    int64_t r, c;
+                    unit_lane(s, rb, ps, l, r, c);
+                    SPX_REQUIRE(r >= 0 && r < (int64_t) rb.n_rows, "segment row");
+                    SPX_REQUIRE(c >= 0 && (size_t) c + W <= ncols, "segment columns");
+                }
+            }
+        }
+    }
+    SPX_REQUIRE(!tiles || s.lds_doubles >= 1, "tile LDS");
+    for (const SpxSharedRow &sr : s.shared)
+        SPX_REQUIRE(sr.row < nrows && (size_t) sr.first_slot + sr.n_slots <= s.n_carry, "shared row");
+#undef SPX_REQUIRE
+    return true;
+}
+
+}  // namespace spx

@@ -1,0 +1,30 @@
+// stream_index.hpp -- host-side walk of the row-block descriptor stream
+// (gpu_format.h): where in `values` does nonzero (row, col) live, and is a
+// stream read from a file safe to hand to the kernels.
+//
+// Counterpart of the reference's random access into a tuned matrix
+// (include/sparsex/internals/CsxGetSet.hpp:195-320 walks the ctl stream of a
+// row and of the rows above it); here a row-block holds every nonzero of its
+// rows, so one row-block (a few for an over-long row) is decoded per lookup.
+#pragma once
+
+#include "gpu_emit.hpp"
+
+#include <string>
+#include <vector>
+
+namespace spx {
+
+// Appends the positions in GpuStream::values of every stored copy of nonzero
+// (row, col), 0-based global coordinates.  `s.values` itself is not read (the
+// index arrays are enough), so `s` may be the index-only copy a matrix keeps
+// on the host while its values live in HBM.
+void stream_locate(const GpuStream &s, idx_t row, idx_t col, std::vector<size_t> &out);
+
+// Structural checks of a finalized stream (array-size relations, offsets of
+// every row-block and pass inside their arrays, rows and columns inside the
+// matrix, LDS budget).  Returns false and a reason on the first violation.
+bool stream_validate(const GpuStream &s, size_t nrows, size_t ncols, size_t n_values,
+                     std::string &why);
+
+}  // namespace spx

@@ -146,6 +146,66 @@ def random_x(ncols, seed=42):
     return np.random.RandomState(seed).uniform(-0.1, 0.1, ncols)
 
 
+_SYNLIB = None
+
+
+def _synlib():
+    """libspxsynth.so (tools/synth/nlpkkt_gen.c, built by `make lib`): the
+    row-sliced generator of the nlpkkt stand-in."""
+    global _SYNLIB
+    if _SYNLIB is None:
+        import ctypes as C
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libspxsynth.so")
+        L = C.CDLL(path)
+        L.spx_syn_nlpkkt_nrows.restype = C.c_int64
+        L.spx_syn_nlpkkt_nrows.argtypes = [C.c_int]
+        L.spx_syn_nlpkkt_counts.restype = None
+        L.spx_syn_nlpkkt_counts.argtypes = [C.c_int, C.c_void_p]
+        L.spx_syn_nlpkkt_rows.restype = C.c_int64
+        L.spx_syn_nlpkkt_rows.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_uint64, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]
+        _SYNLIB = L
+    return _SYNLIB
+
+
+def nlpkkt_nrows(N):
+    return int(_synlib().spx_syn_nlpkkt_nrows(int(N)))
+
+
+def nlpkkt_row_counts(N):
+    """Nonzeros of every row of syn_nlpkkt_rows(N) (int32, all rows)."""
+    cnt = np.empty(nlpkkt_nrows(N), dtype=np.int32)
+    _synlib().spx_syn_nlpkkt_counts(int(N), cnt.ctypes.data)
+    return cnt
+
+
+def syn_nlpkkt_rows(N, lo=0, hi=None, counts=None, seed=SEED_BASE + 4):
+    """Rows [lo, hi) of the nlpkkt stand-in as a CSR slice: the pattern of
+    syn_nlpkkt(N), generated row by row in C so that a process can hold only
+    the rows it owns (values: symmetric hash of the coordinate pair, diagonal
+    dominant).  Returns (rowptr int32 relative to the slice, colind int32,
+    values float64, n) with n the order of the WHOLE matrix."""
+    n = nlpkkt_nrows(N)
+    hi = n if hi is None else hi
+    if counts is None:
+        counts = nlpkkt_row_counts(N)
+    nnz = int(counts[lo:hi].sum(dtype=np.int64))
+    assert nnz < 2 ** 31, "slice too large for 32-bit row pointers"
+    rp = np.zeros(hi - lo + 1, dtype=np.int64)
+    ci = np.zeros(nnz, dtype=np.int32)
+    va = np.zeros(nnz, dtype=np.float64)
+    got = _synlib().spx_syn_nlpkkt_rows(int(N), int(lo), int(hi), int(seed), rp.ctypes.data,
+                                        ci.ctypes.data, va.ctypes.data)
+    assert got == nnz
+    return rp.astype(np.int32), ci, va, n
+
+
+def nlpkkt_edge(scale):
+    """Grid edge for a size factor: scale 1 is nlpkkt240's order (N = 240)."""
+    return max(3, int(round(240.0 * scale ** (1.0 / 3.0))))
+
+
 def syn_nlpkkt_scaled(scale=1.0):
     """syn_nlpkkt with the grid edge derived from a size factor: scale 1 is
     nlpkkt240 itself (N = 240, ~760 M nonzeros); the default single-GPU stand-in

@@ -52,6 +52,9 @@ CASES = [
     ("webbase-tiny-rb", lambda: synth.syn_webbase(0.01), {"spx.gpu.rowblock_elems": "100", "spx.gpu.rowblock_rows": "11"}),
     ("nlpkkt", lambda: synth.syn_nlpkkt(7), {"spx.preproc.sampling": "none", "spx.rt.nr_threads": "2"}),
     ("all-types", lambda: synth.syn_nlpkkt(6), {"spx.preproc.xform": "all", "spx.preproc.sampling": "none"}),
+    # enough row-blocks for the emitter to build runs of them on several threads and join the pieces
+    ("cant-threaded", lambda: synth.syn_cant(0.25), {"spx.gpu.rowblock_elems": "400"}),
+    ("webbase-threaded", lambda: synth.syn_webbase(0.1), {"spx.gpu.rowblock_elems": "300", "spx.rt.nr_threads": "3"}),
 ]
 
 
@@ -84,7 +87,9 @@ def test_general_stream_holds_the_matrix_exactly(tmp_path, name, gen, opts):
     ("cant", lambda: synth.syn_cant(0.04), {"spx.preproc.sampling": "none", "spx.rt.nr_threads": "2"}),
     ("nd24k", lambda: synth.syn_nd24k(0.02), {"spx.preproc.sampling": "none"}),
     ("nlpkkt-all", lambda: synth.syn_nlpkkt(6), {"spx.preproc.xform": "all", "spx.preproc.sampling": "none"}),
-], ids=["cant", "nd24k", "nlpkkt-all"])
+    ("nd24k-threaded", lambda: synth.syn_nd24k(0.08), {"spx.gpu.rowblock_elems": "1500", "spx.rt.nr_threads": "3"}),
+    ("nlpkkt-threaded", lambda: synth.syn_nlpkkt(14), {"spx.gpu.rowblock_elems": "600", "spx.rt.nr_threads": "2"}),
+], ids=["cant", "nd24k", "nlpkkt-all", "nd24k-threaded", "nlpkkt-threaded"])
 def test_symmetric_stream_is_lower_plus_mirror(tmp_path, name, gen, opts, remine):
     csr = gen()
     rp, ci, va, n = csr
