@@ -63,6 +63,8 @@ struct matrix {
     bool full_colind = false;
     DeviceMatrix *dev = nullptr;
     std::unique_ptr<GpuStream> host_stream;   // kept for host-only matrices (save/restore)
+    std::unique_ptr<GpuStream> index;         // matrix in HBM: host copy of the stream's index arrays (no values),
+                                              // walked by get/set entry
     idx_t own_lo = 0, own_hi = 0;
     GpuEmitParams emit_params;
     bool auto_rb = false;
@@ -306,6 +308,18 @@ static void encode_partition(Partition &p, const EncoderParams &prm, const Xform
     }
 }
 
+// The values live in HBM; the host keeps the index arrays of the stream so that
+// single entries can be found (spx_mat_get_entry / spx_mat_set_entry).
+static void keep_index(spx_matrix_t *A, GpuStream &&gs)
+{
+    std::vector<val_t>().swap(gs.values);
+    std::vector<val_t>().swap(gs.dvalues);
+    std::vector<uint32_t>().swap(gs.fix_idx);
+    std::vector<uint32_t>().swap(gs.fix_ptr);
+    std::vector<uint32_t>().swap(gs.spill_col);
+    A->index.reset(new GpuStream(std::move(gs)));
+}
+
 // Builds the row-block descriptor stream from the encoded partitions and puts
 // it into HBM (or keeps it on the host for host-only matrices).
 static void emit_and_upload(spx_matrix_t *A)
@@ -404,11 +418,13 @@ static void emit_and_upload(spx_matrix_t *A)
         device_free(A->dev);
         A->dev = nullptr;
     }
-    if (!A->host_only)
+    if (!A->host_only) {
         A->dev = device_upload(gs, (size_t) A->nrows, (size_t) A->ncols, sym, A->own_lo, A->own_hi,
                                A->device_ordinal);
-    else
+        keep_index(A, std::move(gs));
+    } else {
         A->host_stream.reset(new GpuStream(std::move(gs)));
+    }
     A->dirty = false;
 }
 
@@ -669,10 +685,13 @@ spx_error_t spx_mat_destroy(spx_matrix_t *A)
 // ---- get / set entry ------------------------------------------------------------------
 // Random access into the tuned matrix (reference: src/api/matvec.c:324-407,
 // include/sparsex/internals/CsxGetSet.hpp:195-320).  The reference walks the
-// ctl stream of the row and of the rows above it within `span`; here the
-// encoded partitions are searched the same way: the units anchored in row i
-// can reach down to row i + span[i].  A changed value is written to the host
-// copy and the descriptor stream is rebuilt before the next multiplication.
+// ctl stream of the row and of the rows above it within `span`.  Here the
+// row-block that owns the row is decoded on the host from the stream's index
+// arrays (stream_index.cpp) and the value is read or written where it lives:
+// in HBM, or in the host copy of a host-only matrix.  A restored matrix works
+// like a freshly tuned one.  Where the encoded partitions are still held
+// (spx.rt.keep_encoded, the default) they are kept in step, so that an export
+// in the reference's CSX layout shows the change.
 
 }  // extern "C"
 
@@ -705,8 +724,9 @@ void build_spans(spx_matrix_t *A)
     }
 }
 
-// pointer to the stored value of (row, col), 1-based global; NULL if absent
-val_t *locate(spx_matrix_t *A, idx_t row, idx_t col)
+// pointer to the stored value of (row, col) in the encoded partitions,
+// 1-based global; NULL if absent
+val_t *locate_encoded(spx_matrix_t *A, idx_t row, idx_t col)
 {
     if (A->symmetric) {
         if (col > row) std::swap(row, col);
@@ -744,6 +764,33 @@ val_t *locate(spx_matrix_t *A, idx_t row, idx_t col)
         return nullptr;
     }
     return nullptr;
+}
+
+// Where the descriptor stream holds (row, col), 1-based global: positions in
+// its values (a symmetric matrix holds an off-diagonal entry once in a tile, or
+// twice -- lower triangle and mirror image), or the diagonal entry.
+struct EntryRef {
+    bool diagonal = false;
+    size_t diag_row = 0;
+    std::vector<size_t> pos;
+    bool found() const { return diagonal || !pos.empty(); }
+};
+
+EntryRef locate_stream(const spx_matrix_t *A, idx_t row, idx_t col)
+{
+    EntryRef ref;
+    const GpuStream *s = A->host_stream ? A->host_stream.get() : A->index.get();
+    if (!s) return ref;
+    if (A->symmetric && row == col) {
+        if (row - 1 >= A->own_lo && row - 1 < A->own_hi) {
+            ref.diagonal = true;
+            ref.diag_row = (size_t) row - 1;
+        }
+        return ref;
+    }
+    stream_locate(*s, row - 1, col - 1, ref.pos);
+    if (A->symmetric) stream_locate(*s, col - 1, row - 1, ref.pos);
+    return ref;
 }
 
 bool entry_args(const spx_matrix_t *A, spx_option_t indexing, spx_index_t &row, spx_index_t &col)
@@ -785,19 +832,22 @@ spx_error_t spx_mat_get_entry(const spx_matrix_t *A_, spx_index_t row, spx_index
         return SPX_FAILURE;
     }
     if (!entry_args(A, indexing, row, column)) return SPX_FAILURE;
-    if (A->parts.empty() && A->nnz) {
-        SETERROR_1(SPX_ERR_ENTRY_NOT_FOUND,
-                   "the encoded partitions were dropped (spx.rt.keep_encoded=false or a restored matrix)");
-        return SPX_FAILURE;
-    }
     std::lock_guard<std::mutex> lk(A->mtx);
-    build_spans(A);
-    const val_t *v = locate(A, row, column);
-    if (!v) {
+    const EntryRef ref = locate_stream(A, row, column);
+    if (!ref.found()) {
         SETERROR_0(SPX_ERR_ENTRY_NOT_FOUND);
         return SPX_FAILURE;
     }
-    *value = *v;
+    try {
+        if (A->host_stream)
+            *value = ref.diagonal ? A->host_stream->dvalues[ref.diag_row] : A->host_stream->values[ref.pos[0]];
+        else
+            *value = ref.diagonal ? device_peek(A->dev, true, ref.diag_row)
+                                  : device_peek(A->dev, false, ref.pos[0]);
+    } catch (const FatalError &e) {
+        SETERROR_1(SPX_ERR_TUNED_MAT, e.what.c_str());
+        return SPX_FAILURE;
+    }
     return SPX_SUCCESS;
 }
 
@@ -816,22 +866,32 @@ spx_error_t spx_mat_set_entry(spx_matrix_t *A, spx_index_t row, spx_index_t colu
         SETWARNING(SPX_WARN_ENTRY_NOT_SET);
         return SPX_FAILURE;
     }
-    if (A->parts.empty() && A->nnz) {
-        SETERROR_1(SPX_ERR_ENTRY_NOT_FOUND,
-                   "the encoded partitions were dropped (spx.rt.keep_encoded=false or a restored matrix)");
-        return SPX_FAILURE;
-    }
     std::lock_guard<std::mutex> lk(A->mtx);
-    build_spans(A);
-    val_t *v = locate(A, row, column);
-    if (!v) {
+    const EntryRef ref = locate_stream(A, row, column);
+    if (!ref.found()) {
         SETERROR_0(SPX_ERR_ENTRY_NOT_FOUND);
         return SPX_FAILURE;
     }
-    *v = value;
-    A->dirty = true;           // the HBM copy is refreshed before the next SpMV
-    A->exported.clear();
-    A->exported_rows_info.clear();
+    try {
+        if (A->host_stream) {
+            if (ref.diagonal) A->host_stream->dvalues[ref.diag_row] = value;
+            for (size_t p : ref.pos) A->host_stream->values[p] = value;
+        } else {
+            if (ref.diagonal) device_poke(A->dev, true, ref.diag_row, value);
+            for (size_t p : ref.pos) device_poke(A->dev, false, p, value);
+        }
+    } catch (const FatalError &e) {
+        SETERROR_1(SPX_ERR_TUNED_MAT, e.what.c_str());
+        return SPX_FAILURE;
+    }
+    if (!A->parts.empty()) {
+        // the encoded partitions follow (export in the reference's layout)
+        build_spans(A);
+        val_t *v = locate_encoded(A, row, column);
+        if (v) *v = value;
+        A->exported.clear();
+        A->exported_rows_info.clear();
+    }
     return SPX_SUCCESS;
 }
 
@@ -846,7 +906,7 @@ spx_error_t spx_mat_set_entry(spx_matrix_t *A, spx_index_t row, spx_index_t colu
 
 namespace {
 
-const char kMagic[8] = {'S', 'P', 'X', 'H', 'I', 'P', '0', '8'};
+const char kMagic[8] = {'S', 'P', 'X', 'H', 'I', 'P', '0', '9'};
 
 template <typename T>
 bool put_vec(FILE *f, const std::vector<T> &v)
@@ -862,6 +922,15 @@ bool get_vec(FILE *f, std::vector<T> &v)
     uint64_t n = 0;
     if (fread(&n, sizeof(n), 1, f) != 1) return false;
     if (n > (uint64_t) 1 << 40) return false;
+    // (a count that the rest of the file cannot hold is a damaged file, not a
+    // reason to allocate terabytes)
+    const long here = ftell(f);
+    if (here >= 0 && fseek(f, 0, SEEK_END) == 0) {
+        const long end = ftell(f);
+        if (fseek(f, here, SEEK_SET) != 0 || end < here ||
+            n > (uint64_t)(end - here) / sizeof(T))
+            return false;
+    }
     v.resize(n);
     return n == 0 || fread(v.data(), sizeof(T), n, f) == n;
 }
@@ -873,12 +942,72 @@ struct SavedHeader {
     uint64_t nnz_stored, n_unit_elems, n_delta_elems, n_units;
     uint32_t n_carry, pad;
     uint32_t n_spill, lds_doubles;
-    uint32_t waves, pad2;
+    uint32_t waves, n_encoded;          // n_encoded: encoded partitions that follow the stream
+    uint64_t checksum;                  // FNV-1a over the index arrays
 };
+
+// a cheap guard against damaged or stale files: the kernels trust the index
+// arrays, so they are summed (the values are not: a flipped value bit gives a
+// wrong product, not an out-of-bounds access)
+template <typename T>
+void fnv(uint64_t &h, const std::vector<T> &v)
+{
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(v.data());
+    for (size_t i = 0, n = v.size() * sizeof(T); i < n; ++i) h = (h ^ p[i]) * 0x100000001B3ull;
+}
+
+uint64_t stream_checksum(const GpuStream &s)
+{
+    uint64_t h = 0xCBF29CE484222325ull;
+    fnv(h, s.rbs); fnv(h, s.passes); fnv(h, s.descs); fnv(h, s.cidx); fnv(h, s.segrows);
+    fnv(h, s.shared); fnv(h, s.fix_ptr); fnv(h, s.fix_idx);
+    return h;
+}
+
+struct SavedPartition {
+    uint64_t nr_rows, nr_cols, nnz, elems_size;
+    int32_t type, row_start;
+};
+
+bool put_partition(FILE *f, const Partition &p, const std::vector<val_t> *diag)
+{
+    SavedPartition h;
+    memset(&h, 0, sizeof(h));
+    h.nr_rows = p.nr_rows; h.nr_cols = p.nr_cols; h.nnz = p.nnz; h.elems_size = p.elems_size;
+    h.type = p.type; h.row_start = p.row_start;
+    std::vector<Elem> live(p.elems.begin(), p.elems.begin() + p.elems_size);
+    static const std::vector<val_t> none;
+    return fwrite(&h, sizeof(h), 1, f) == 1 && put_vec(f, live) && put_vec(f, p.rowptr) &&
+           put_vec(f, p.pool) && put_vec(f, diag ? *diag : none);
+}
+
+bool get_partition(FILE *f, Partition &p, std::vector<val_t> &diag)
+{
+    SavedPartition h;
+    if (fread(&h, sizeof(h), 1, f) != 1) return false;
+    p.nr_rows = h.nr_rows; p.nr_cols = h.nr_cols; p.nnz = h.nnz; p.elems_size = h.elems_size;
+    p.type = h.type; p.row_start = h.row_start;
+    if (!(get_vec(f, p.elems) && get_vec(f, p.rowptr) && get_vec(f, p.pool) && get_vec(f, diag)))
+        return false;
+    if (p.elems.size() != p.elems_size || p.rowptr.empty() || p.rowptr.size() > p.nr_rows + 1)
+        return false;
+    for (size_t i = 0; i + 1 < p.rowptr.size(); ++i)
+        if (p.rowptr[i] > p.rowptr[i + 1]) return false;
+    if ((size_t) p.rowptr.back() != p.elems_size || p.rowptr[0] != 0) return false;
+    for (const Elem &e : p.elems) {
+        if (e.size == 0 || e.row < 1 || (size_t) e.row > p.nr_rows || e.col < 1 || (size_t) e.col > p.nr_cols)
+            return false;
+        if (e.is_unit() && ((size_t) e.voff + e.size > p.pool.size() || e.type <= ENC_NONE || e.type >= ENC_MAX))
+            return false;
+    }
+    return true;
+}
 
 }  // namespace
 
 extern "C" {
+
+static bool refresh_if_dirty(const spx_matrix_t *A_);
 
 spx_error_t spx_mat_save(const spx_matrix_t *A, const char *filename)
 {
@@ -890,6 +1019,9 @@ spx_error_t spx_mat_save(const spx_matrix_t *A, const char *filename)
         SETWARNING(SPX_WARN_CSXFILE);
         filename = "csx_file";
     }
+    // the file must show what the matrix holds now (the reference writes
+    // set_entry straight into the arrays it archives, src/api/matvec.c:409-425)
+    if (!refresh_if_dirty(A)) return SPX_FAILURE;
     GpuStream tmp;
     const GpuStream *gs = A->host_stream.get();
     if (!gs) {
@@ -924,6 +1056,8 @@ spx_error_t spx_mat_save(const spx_matrix_t *A, const char *filename)
     h.n_spill = gs->n_spill;
     h.lds_doubles = gs->lds_doubles;
     h.waves = gs->waves;
+    h.n_encoded = (uint32_t) A->parts.size();
+    h.checksum = stream_checksum(*gs);
     bool good = fwrite(kMagic, 1, 8, f) == 8 && fwrite(&h, sizeof(h), 1, f) == 1;
     std::vector<int32_t> bnd;
     for (const PartBounds &b : A->bounds) {
@@ -938,6 +1072,10 @@ spx_error_t spx_mat_save(const spx_matrix_t *A, const char *filename)
     std::vector<int32_t> perm;
     if (A->permutation) perm.assign(A->permutation, A->permutation + A->nrows);
     good = good && put_vec(f, perm);
+    // the encoded partitions, where they are still held: a restored matrix can
+    // then be exported in the reference's CSX layout like the one that was saved
+    for (size_t i = 0; good && i < A->parts.size(); ++i)
+        good = put_partition(f, A->parts[i], A->symmetric ? &A->diag[i] : nullptr);
     good = (fclose(f) == 0) && good;
     if (!good) {
         SETERROR_1(SPX_ERR_FILE, "writing the tuned matrix failed");
@@ -973,20 +1111,44 @@ spx_matrix_t *spx_mat_restore(const char *filename)
                 get_vec(f, gs->fix_idx);
     std::vector<int32_t> perm;
     good = good && get_vec(f, perm);
+    std::unique_ptr<matrix> A(new matrix);
+    if (good && h.n_encoded) {
+        good = h.n_encoded == h.last_part - h.first_part && h.n_encoded <= (1u << 20);
+        if (good) {
+            A->parts.resize(h.n_encoded);
+            if (h.symmetric) A->diag.resize(h.n_encoded);
+        }
+        std::vector<val_t> nodiag;
+        for (uint32_t i = 0; good && i < h.n_encoded; ++i)
+            good = get_partition(f, A->parts[i], h.symmetric ? A->diag[i] : nodiag);
+    }
     fclose(f);
-    if (!good || bnd.size() != 3 * h.nr_partitions || (!perm.empty() && perm.size() != (size_t) h.nrows)) {
-        SETERROR_1(SPX_ERR_FILE, "not a tuned-matrix file of this build");
+    std::string why = "not a tuned-matrix file of this build";
+    if (good) {
+        good = h.nrows >= 0 && h.ncols >= 0 && bnd.size() == 3 * h.nr_partitions &&
+               h.first_part <= h.last_part && h.last_part <= h.nr_partitions &&
+               (perm.empty() || perm.size() == (size_t) h.nrows) && h.own_lo >= 0 &&
+               h.own_lo <= h.own_hi && h.own_hi <= h.nrows &&
+               (!h.symmetric || gs->dvalues.size() == (size_t) h.nrows);
+        for (int32_t v : perm) good = good && v >= 0 && v < h.nrows;
+    }
+    if (good) {
+        gs->n_carry = h.n_carry;
+        gs->sym_fused = (h.pad & 1u) != 0;
+        gs->pass_stride = h.pad >> 1;
+        gs->n_spill = h.n_spill;
+        gs->lds_doubles = h.lds_doubles;
+        gs->waves = h.waves;
+        gs->nnz_stored = h.nnz_stored; gs->n_unit_elems = h.n_unit_elems;
+        gs->n_delta_elems = h.n_delta_elems; gs->n_units = h.n_units;
+        good = stream_checksum(*gs) == h.checksum;
+        if (!good) why = "tuned-matrix file is damaged (checksum of the index arrays)";
+        else good = stream_validate(*gs, (size_t) h.nrows, (size_t) h.ncols, gs->values.size(), why);
+    }
+    if (!good) {
+        SETERROR_1(SPX_ERR_FILE, why.c_str());
         return SPX_INVALID_MAT;
     }
-    gs->n_carry = h.n_carry;
-    gs->sym_fused = (h.pad & 1u) != 0;
-    gs->pass_stride = h.pad >> 1;
-    gs->n_spill = h.n_spill;
-    gs->lds_doubles = h.lds_doubles;
-    gs->waves = h.waves;
-    gs->nnz_stored = h.nnz_stored; gs->n_unit_elems = h.n_unit_elems;
-    gs->n_delta_elems = h.n_delta_elems; gs->n_units = h.n_units;
-    std::unique_ptr<matrix> A(new matrix);
     A->nrows = h.nrows; A->ncols = h.ncols; A->nnz = h.nnz; A->symmetric = h.symmetric;
     A->permutation = SPX_INVALID_PERM;
     if (!perm.empty()) {
@@ -1007,14 +1169,21 @@ spx_matrix_t *spx_mat_restore(const char *filename)
     A->n_rowblocks = gs->rbs.size();
     A->n_shared = gs->shared.size();
     A->tune_seconds = 0.0;
+    A->dirty = false;
+    A->auto_rb = false;
     const double t0 = now_sec();
     Config &cfg = Config::instance();
+    A->host_only = cfg.get_bool("spx.rt.host_only");
+    A->device_ordinal = (int) cfg.get_long("spx.rt.device");
+    A->full_colind = cfg.get_bool("spx.matrix.full_colind");
     try {
-        if (!cfg.get_bool("spx.rt.host_only"))
+        if (!A->host_only) {
             A->dev = device_upload(*gs, (size_t) A->nrows, (size_t) A->ncols, A->symmetric != 0,
-                                   A->own_lo, A->own_hi, (int) cfg.get_long("spx.rt.device"));
-        else
+                                   A->own_lo, A->own_hi, A->device_ordinal);
+            keep_index(A.get(), std::move(*gs));
+        } else {
             A->host_stream = std::move(gs);
+        }
     } catch (const FatalError &) {
         SETERROR_0(SPX_ERR_TUNED_MAT);
         return SPX_INVALID_MAT;
@@ -1186,6 +1355,10 @@ static bool refresh_if_dirty(const spx_matrix_t *A_)
     if (!A->dirty) return true;
     std::lock_guard<std::mutex> lk(A->mtx);
     if (!A->dirty) return true;
+    if (A->parts.empty()) {
+        SETERROR_1(SPX_ERR_TUNED_MAT, "matrix is marked changed but holds no encoded partitions to rebuild from");
+        return false;
+    }
     try {
         emit_and_upload(A);
     } catch (const FatalError &e) {

@@ -49,6 +49,12 @@ double device_time_spmv(DeviceMatrix *m, int warmup, int launches);
 // copies the descriptor stream back from HBM (for spx_mat_save)
 void device_download(const DeviceMatrix *m, GpuStream &s);
 
+// one stored value (diagonal: of the symmetric path's diagonal array) read from /
+// written to HBM where it lies (spx_mat_get_entry / spx_mat_set_entry);
+// synchronous
+double device_peek(const DeviceMatrix *m, bool diagonal, size_t index);
+void device_poke(DeviceMatrix *m, bool diagonal, size_t index, double value);
+
 struct DeviceMatrixInfo {
     size_t n_rowblocks, n_shared_rows;
     size_t value_bytes, index_bytes;

@@ -780,6 +780,25 @@ void device_download(const DeviceMatrix *m, GpuStream &s)
     if (m->symmetric) download(s.dvalues, m->dvalues, m->nrows);
 }
 
+double device_peek(const DeviceMatrix *m, bool diagonal, size_t index)
+{
+    if (diagonal ? (!m->dvalues || index >= m->nrows) : index >= m->n_values)
+        throw FatalError("value index outside the stream");
+    HIP_CHECK(hipSetDevice(m->device));
+    double v = 0.0;
+    HIP_CHECK(hipMemcpy(&v, (diagonal ? m->dvalues : m->values) + index, sizeof(v), hipMemcpyDeviceToHost));
+    return v;
+}
+
+void device_poke(DeviceMatrix *m, bool diagonal, size_t index, double value)
+{
+    if (diagonal ? (!m->dvalues || index >= m->nrows) : index >= m->n_values)
+        throw FatalError("value index outside the stream");
+    HIP_CHECK(hipSetDevice(m->device));
+    HIP_CHECK(hipMemcpy((diagonal ? m->dvalues : m->values) + index, &value, sizeof(value),
+                        hipMemcpyHostToDevice));
+}
+
 void device_info(const DeviceMatrix *m, DeviceMatrixInfo &info)
 {
     info.n_rowblocks = m->n_rb;

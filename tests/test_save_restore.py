@@ -60,3 +60,30 @@ def test_round_trip_gpu(tmp_path, sym):
     y3 = y0.copy()
     B.matvec_kernel(1.0, x, 2.0, y3)
     check_y(csr, x, y3, 1.0, 2.0, y0)
+
+
+def test_restore_rejects_damaged_files(tmp_path):
+    """A file that still carries the magic but whose index arrays were cut or
+    changed must not reach the kernels (they trust every offset)."""
+    csr = synth.syn_webbase(0.004)
+    A = tune(csr, {"spx.rt.keep_encoded": "false"}, host_only=True)
+    f = tmp_path / "m.csx"
+    A.save(str(f))
+    good = f.read_bytes()
+    sx.option_set("spx.rt.host_only", "true")
+    sx.mat_restore(str(f)).destroy()
+    sx.lib().spx_log_disable_all()
+    bad = tmp_path / "bad.csx"
+    bad.write_bytes(good[:len(good) * 2 // 3])                      # truncated
+    with pytest.raises(sx.SpxError):
+        sx.mat_restore(str(bad))
+    rng = np.random.RandomState(2)
+    hdr = 8 + 112
+    for _ in range(20):                                             # one byte of the index flipped
+        b = bytearray(good)
+        # (stay inside the row-block / pass / descriptor arrays that follow the header)
+        pos = hdr + 8 + int(rng.randint(0, 4000))
+        b[pos] ^= 0x5A
+        bad.write_bytes(bytes(b))
+        with pytest.raises(sx.SpxError):
+            sx.mat_restore(str(bad))
