@@ -13,9 +13,9 @@ LIB       := $(LIBDIR)/libsparsex.so
 SYNLIB    := $(LIBDIR)/libspxsynth.so
 
 HOST_SRCS := common.cpp config.cpp partition.cpp stats.cpp encoder.cpp input.cpp reorder.cpp \
-             csx_emit.cpp gpu_emit.cpp stream_index.cpp api.cpp
+             csx_emit.cpp gpu_emit.cpp stream_index.cpp dist.cpp api.cpp
 HOST_OBJS := $(HOST_SRCS:%.cpp=$(OBJDIR)/%.o)
-HIP_OBJ   := $(OBJDIR)/spmv_kernels.o $(OBJDIR)/vec_kernels.o
+HIP_OBJ   := $(OBJDIR)/spmv_kernels.o $(OBJDIR)/vec_kernels.o $(OBJDIR)/dist_kernels.o
 
 CXXFLAGS  := -std=c++17 -O2 -g -fPIC -Wall -Iinclude -I$(CSRC) -pthread
 HIPFLAGS  := --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -munsafe-fp-atomics \
@@ -43,7 +43,7 @@ $(OBJDIR)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.h) \
 
 $(LIB): $(HOST_OBJS) $(HIP_OBJ)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -pthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -pthread -ldl
 
 oracle:
 	$(MAKE) -C oracle

@@ -15,6 +15,8 @@
  *   spx.rt.device           HIP device ordinal (default: current device)
  *   spx.rt.gpu_rank/world   this process owns partitions
  *                           [rank*P/world, (rank+1)*P/world), P = spx.rt.nr_threads
+ *   spx.rt.row_offset,      the input holds rows [offset, offset + its rows) of a
+ *   spx.rt.global_rows      matrix with global_rows rows (0: the input is the matrix)
  *   spx.gpu.rowblock_elems  target nonzeros per row-block (default 0 = auto:
  *                           nnz/1280 clamped to [1024, 4096]; 8192 beyond 64 M)
  *   spx.gpu.waves           wavefronts per workgroup of the SpMV kernel: 2, 4 or 8;
@@ -100,6 +102,89 @@ spx_error_t spx_hip_vec_copy(const spx_hip_vec_t *v1, spx_hip_vec_t *v2, void *s
 spx_error_t spx_hip_matvec_kernel_vec(spx_value_t alpha, const spx_matrix_t *A,
                                       const spx_hip_vec_t *x, spx_value_t beta,
                                       spx_hip_vec_t *y, void *stream);
+
+/* ---- one process per GPU: row-partitioned matrices -------------------------------
+ * The reference partitions the rows over the threads of one process
+ * (include/sparsex/internals/SparseInternal.hpp:117-152); its symmetric kernel
+ * lets every thread add into rows of the threads in front of it through local
+ * buffers, and a conflict map says which entries have to be summed afterwards
+ * (src/api/matvec.c:302-318, include/sparsex/internals/CsxBuild.hpp:400-451,
+ * src/internals/Vector.cpp:291-299).  Here the "threads" are processes, one per
+ * MI355X, and the map drives a point-to-point exchange over xGMI:
+ *
+ *   - every process tunes the rows it owns, either as a slice of the
+ *     partitions of a matrix it was given in full (spx.rt.gpu_rank/gpu_world)
+ *     or from just those rows (spx.rt.row_offset / spx.rt.global_rows: the
+ *     input of spx_input_load_csr holds rows [offset, offset + nrows) of a
+ *     matrix with global_rows rows; symmetric: the full rows, of which the part
+ *     on and below the diagonal is kept);
+ *   - spx_hip_mat_dist_attach() (collective) learns every process' row range,
+ *     hands each process' conflict rows to their owners and builds the lists
+ *     for the exchange;
+ *   - spx_hip_matvec_dist() multiplies and completes the rows this process
+ *     owns: general matrices need nothing from the others; symmetric ones send
+ *     the sums they formed for rows in front of their own -- only those entries,
+ *     packed -- to the owners, which add them in a fixed order.  With
+ *     SPX_DIST_GATHER_Y the finished slices are then handed round so that every
+ *     process holds all of y (what a solver needs as the next x).
+ *
+ * The exchange itself goes through a transport: RCCL over xGMI (built in;
+ * librccl is loaded when the transport is created, so single-GPU users never
+ * pay for it), or two callbacks of the caller's (the CPU tests run the same
+ * plan over gloo).  Vectors are full length (ncols / global rows) on every
+ * process, as in the reference, where every thread sees all of x.
+ */
+typedef struct spx_hip_transport {
+    void *ctx;
+    int rank, world;
+    /* Per-peer exchange of 8-byte words in HOST memory; blocking; every
+     * process calls it with matching counts (send_cnt[p] here = recv_cnt[me]
+     * on p).  Offsets and counts are in words; entries for `rank` itself are
+     * ignored.  Returns 0 on success. */
+    int (*exchange_host)(void *ctx, const uint64_t *send, const size_t *send_off,
+                         const size_t *send_cnt, uint64_t *recv, const size_t *recv_off,
+                         const size_t *recv_cnt);
+    /* The same for doubles in DEVICE memory, enqueued on `stream` (hipStream_t). */
+    int (*exchange_device)(void *ctx, const spx_value_t *send, const size_t *send_off,
+                           const size_t *send_cnt, spx_value_t *recv, const size_t *recv_off,
+                           const size_t *recv_cnt, void *stream);
+} spx_hip_transport_t;
+
+#define SPX_RCCL_ID_BYTES 128
+/* rank 0 creates the id and hands it to the others by whatever means the job
+ * has (MPI, a file, torch.distributed); then every process creates its
+ * transport -- collective, on the current HIP device. */
+spx_error_t spx_hip_rccl_unique_id(void *id);
+spx_hip_transport_t *spx_hip_transport_rccl(const void *id, int rank, int world);
+void spx_hip_transport_destroy(spx_hip_transport_t *t);
+
+/* Collective over the transport's processes; the matrix keeps a copy of *t
+ * (the transport must outlive the matrix). */
+spx_error_t spx_hip_mat_dist_attach(spx_matrix_t *A, const spx_hip_transport_t *t);
+
+#define SPX_DIST_OWNED_ROWS 0   /* y[row_lo, row_hi) complete on return, the rest unspecified */
+#define SPX_DIST_GATHER_Y   1   /* all of y complete on every process */
+/* y <- alpha*A*x + beta*y over all processes; device pointers of full length,
+ * everything enqueued on `stream`.  Collective. */
+spx_error_t spx_hip_matvec_dist(spx_value_t alpha, const spx_matrix_t *A,
+                                const spx_value_t *x_dev, spx_value_t beta,
+                                spx_value_t *y_dev, int flags, void *stream);
+
+/* What the exchange of an attached matrix looks like (arrays owned by the matrix). */
+typedef struct {
+    int32_t rank, world;
+    const spx_index_t *row_lo, *row_hi;     /* [world] rows of every process          */
+    int64_t n_send;                         /* conflict rows of this process          */
+    const spx_index_t *send_rows;           /* ascending, i.e. grouped by owner       */
+    const size_t *send_off, *send_cnt;      /* [world] segment of every owner         */
+    int64_t n_recv;                         /* entries this process receives          */
+    const size_t *recv_off, *recv_cnt;      /* [world] segment of every sender        */
+    int64_t n_fix_rows;                     /* own rows that receive something        */
+    const spx_index_t *fix_rows;            /* [n_fix_rows] ascending                 */
+    const uint32_t *fix_ptr, *fix_pos;      /* per such row: positions in the receive buffer */
+    int32_t any_exchange;                   /* some process sends something           */
+} spx_hip_dist_plan_t;
+spx_error_t spx_hip_mat_dist_plan(const spx_matrix_t *A, spx_hip_dist_plan_t *plan);
 
 /* ---- introspection ---------------------------------------------------------- */
 typedef struct {

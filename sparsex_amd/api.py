@@ -454,3 +454,150 @@ def mat_tune(inp, reorder=False):
     if not h:
         raise SpxError("spx_mat_tune failed (see stderr)")
     return Matrix(h)
+
+
+# ---- one process per GPU (include/sparsex_hip.h, "row-partitioned matrices") -----------
+
+_XCHG_HOST = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_size_t),
+                         C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.POINTER(C.c_size_t),
+                         C.POINTER(C.c_size_t))
+_XCHG_DEV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t),
+                        C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t),
+                        C.POINTER(C.c_size_t), C.c_void_p)
+
+
+class TransportStruct(C.Structure):
+    """``spx_hip_transport_t``."""
+    _fields_ = [("ctx", C.c_void_p), ("rank", C.c_int), ("world", C.c_int),
+                ("exchange_host", _XCHG_HOST), ("exchange_device", _XCHG_DEV)]
+
+
+class DistPlanStruct(C.Structure):
+    """``spx_hip_dist_plan_t``."""
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32),
+                ("row_lo", C.POINTER(C.c_int)), ("row_hi", C.POINTER(C.c_int)),
+                ("n_send", C.c_int64), ("send_rows", C.POINTER(C.c_int)),
+                ("send_off", C.POINTER(C.c_size_t)), ("send_cnt", C.POINTER(C.c_size_t)),
+                ("n_recv", C.c_int64),
+                ("recv_off", C.POINTER(C.c_size_t)), ("recv_cnt", C.POINTER(C.c_size_t)),
+                ("n_fix_rows", C.c_int64), ("fix_rows", C.POINTER(C.c_int)),
+                ("fix_ptr", C.POINTER(C.c_uint32)), ("fix_pos", C.POINTER(C.c_uint32)),
+                ("any_exchange", C.c_int32)]
+
+
+SPX_DIST_OWNED_ROWS = 0
+SPX_DIST_GATHER_Y = 1
+SPX_RCCL_ID_BYTES = 128
+
+
+def rccl_unique_id():
+    """``spx_hip_rccl_unique_id``: 128 bytes for rank 0 to hand to the others."""
+    buf = C.create_string_buffer(SPX_RCCL_ID_BYTES)
+    if lib().spx_hip_rccl_unique_id(buf) != SPX_SUCCESS:
+        raise SpxError("spx_hip_rccl_unique_id failed (see stderr)")
+    return buf.raw
+
+
+class RcclTransport:
+    """The built-in transport: RCCL point-to-point over xGMI (collective to create)."""
+
+    def __init__(self, unique_id, rank, world):
+        L = lib()
+        L.spx_hip_transport_rccl.restype = C.POINTER(TransportStruct)
+        L.spx_hip_transport_rccl.argtypes = [C.c_char_p, C.c_int, C.c_int]
+        L.spx_hip_transport_destroy.argtypes = [C.POINTER(TransportStruct)]
+        L.spx_hip_transport_destroy.restype = None
+        self.ptr = L.spx_hip_transport_rccl(unique_id, rank, world)
+        if not self.ptr:
+            raise SpxError("spx_hip_transport_rccl failed (see stderr)")
+        self.rank, self.world = rank, world
+
+    def destroy(self):
+        if self.ptr:
+            lib().spx_hip_transport_destroy(self.ptr)
+            self.ptr = None
+
+
+class CallbackTransport:
+    """A transport made of two Python callables (tests: torch.distributed/gloo).
+
+    ``host(send, send_off, send_cnt, recv, recv_off, recv_cnt)`` gets numpy uint64 views;
+    ``device(send_ptr, send_off, send_cnt, recv_ptr, recv_off, recv_cnt, stream)`` gets raw
+    device addresses.  Offsets/counts are numpy arrays of length ``world``."""
+
+    def __init__(self, rank, world, host, device):
+        self.rank, self.world = rank, world
+
+        def _arr(p):
+            return np.ctypeslib.as_array(p, shape=(world,)).astype(np.int64)
+
+        def _host(ctx, send, soff, scnt, recv, roff, rcnt):
+            try:
+                so, sc, ro, rc = _arr(soff), _arr(scnt), _arr(roff), _arr(rcnt)
+                ns = int(max([so[q] + sc[q] for q in range(world) if q != rank] + [1]))
+                nr = int(max([ro[q] + rc[q] for q in range(world) if q != rank] + [1]))
+                host(np.ctypeslib.as_array(send, shape=(ns,)), so, sc,
+                     np.ctypeslib.as_array(recv, shape=(nr,)), ro, rc)
+                return 0
+            except Exception as e:       # never unwind through C
+                print("transport host exchange failed: %r" % (e,))
+                return -1
+
+        def _dev(ctx, send, soff, scnt, recv, roff, rcnt, stream):
+            try:
+                device(send or 0, _arr(soff), _arr(scnt), recv or 0, _arr(roff), _arr(rcnt), stream or 0)
+                return 0
+            except Exception as e:
+                print("transport device exchange failed: %r" % (e,))
+                return -1
+
+        self._cb = (_XCHG_HOST(_host), _XCHG_DEV(_dev))      # keep the thunks alive
+        self.struct = TransportStruct(None, rank, world, self._cb[0], self._cb[1])
+        self.ptr = C.pointer(self.struct)
+
+    def destroy(self):
+        pass
+
+
+def _dist_attach(self, transport):
+    """``spx_hip_mat_dist_attach`` (collective)."""
+    L = lib()
+    L.spx_hip_mat_dist_attach.argtypes = [C.c_void_p, C.POINTER(TransportStruct)]
+    if L.spx_hip_mat_dist_attach(self.handle, transport.ptr) != SPX_SUCCESS:
+        raise SpxError("spx_hip_mat_dist_attach failed (see stderr)")
+    self._transport = transport
+
+
+def _dist_plan(self):
+    """``spx_hip_mat_dist_plan`` as a dict of numpy copies."""
+    L = lib()
+    L.spx_hip_mat_dist_plan.argtypes = [C.c_void_p, C.POINTER(DistPlanStruct)]
+    p = DistPlanStruct()
+    if L.spx_hip_mat_dist_plan(self.handle, C.byref(p)) != SPX_SUCCESS:
+        raise SpxError("spx_hip_mat_dist_plan failed (see stderr)")
+    W = p.world
+
+    def arr(ptr, n, dt):
+        return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt) if n else np.zeros(0, dtype=dt)
+    return {"rank": p.rank, "world": W, "row_lo": arr(p.row_lo, W, np.int64), "row_hi": arr(p.row_hi, W, np.int64),
+            "send_rows": arr(p.send_rows, p.n_send, np.int64),
+            "send_off": arr(p.send_off, W, np.int64), "send_cnt": arr(p.send_cnt, W, np.int64),
+            "n_recv": int(p.n_recv),
+            "recv_off": arr(p.recv_off, W, np.int64), "recv_cnt": arr(p.recv_cnt, W, np.int64),
+            "fix_rows": arr(p.fix_rows, p.n_fix_rows, np.int64),
+            "fix_ptr": arr(p.fix_ptr, p.n_fix_rows + 1 if p.n_fix_rows else 1, np.int64),
+            "fix_pos": arr(p.fix_pos, p.n_recv, np.int64), "any_exchange": bool(p.any_exchange)}
+
+
+def _hip_matvec_dist(self, alpha, x_ptr, beta, y_ptr, flags=SPX_DIST_OWNED_ROWS, stream=0):
+    """``spx_hip_matvec_dist`` (collective)."""
+    L = lib()
+    L.spx_hip_matvec_dist.argtypes = [C.c_double, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
+                                      C.c_int, C.c_void_p]
+    if L.spx_hip_matvec_dist(alpha, self.handle, x_ptr, beta, y_ptr, flags, stream) != SPX_SUCCESS:
+        raise SpxError("spx_hip_matvec_dist failed (see stderr)")
+
+
+Matrix.dist_attach = _dist_attach
+Matrix.dist_plan = _dist_plan
+Matrix.hip_matvec_dist = _hip_matvec_dist

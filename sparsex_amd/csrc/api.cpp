@@ -12,6 +12,7 @@
 #include "config.hpp"
 #include "csx_emit.hpp"
 #include "device.hpp"
+#include "dist.hpp"
 #include "encoder.hpp"
 #include "gpu_emit.hpp"
 #include "input.hpp"
@@ -31,57 +32,7 @@
 
 using namespace spx;
 
-// ---- handle types (opaque to clients) ----------------------------------------------
-
-struct input {
-    spx_index_t nrows, ncols, nnz;
-    char type;                         // 'C' (CSR) or 'M' (MMF)
-    MatrixInput *mat;
-};
-
-struct partition {
-    size_t nr_partitions;
-    size_t *parts;
-    int *nodes;
-    int *affinity;
-    spx_index_t *row_start;
-    spx_index_t *row_end;
-};
-
-struct matrix {
-    spx_index_t nrows = 0, ncols = 0, nnz = 0;
-    int symmetric = 0;
-    spx_perm_t *permutation = SPX_INVALID_PERM;
-    // tuned representation
-    size_t nr_partitions = 0;          // P, over all processes
-    size_t first_part = 0, last_part = 0;   // owned partitions [first, last)
-    std::vector<PartBounds> bounds;    // all P partitions
-    std::vector<Partition> parts;      // encoded, horizontal order (owned ones)
-    std::vector<std::vector<val_t>> diag;   // symmetric: per owned partition
-    std::vector<std::unique_ptr<CsxStream>> exported;
-    std::vector<std::vector<spx_index_t>> exported_rows_info;
-    bool full_colind = false;
-    DeviceMatrix *dev = nullptr;
-    std::unique_ptr<GpuStream> host_stream;   // kept for host-only matrices (save/restore)
-    std::unique_ptr<GpuStream> index;         // matrix in HBM: host copy of the stream's index arrays (no values),
-                                              // walked by get/set entry
-    idx_t own_lo = 0, own_hi = 0;
-    GpuEmitParams emit_params;
-    bool auto_rb = false;
-    double rb_scale = 1.0;      // chosen by the launch autotuner (multiplies the automatic row-block size)
-    int waves = 4;              // wavefronts per workgroup of the SpMV kernel
-    bool host_only = false;
-    int device_ordinal = -1;
-    bool dirty = false;                       // values changed since the last upload
-    std::vector<std::vector<idx_t>> spans;    // per partition and row: reach of its units
-    std::vector<idx_t> max_span;              // per partition
-    // accounting
-    size_t nnz_stored = 0, n_unit_elems = 0, n_delta_elems = 0, n_units = 0;
-    size_t value_bytes = 0, index_bytes = 0, n_rowblocks = 0, n_shared = 0;
-    double tune_seconds = 0.0, emit_seconds = 0.0;
-    std::string log;
-    std::mutex mtx;
-};
+#include "handles.hpp"
 
 namespace {
 
@@ -404,6 +355,8 @@ static void emit_and_upload(spx_matrix_t *A)
     } else {
         emit_pieces(A->parts, nullptr);
     }
+    A->conflict_rows.clear();
+    if (sym && !gs.sym_fused) stream_touched_rows(gs, A->own_lo, A->conflict_rows);
     finalize_stream(gs, (size_t) A->nrows);
     gs.waves = (uint32_t) A->waves;
     A->nnz_stored = gs.nnz_stored;
@@ -501,6 +454,20 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     }
     const size_t first = (size_t) rank * (P / (size_t) world);
     const size_t last = first + P / (size_t) world;
+    // A process may hand over just the rows it owns of a larger matrix
+    // (spx.rt.row_offset / spx.rt.global_rows): partitions, row-blocks and the
+    // vectors of spx_matvec_* are then numbered globally, exactly as when it
+    // holds a slice of the partitions of a matrix given in full.
+    const long slice_rows = cfg.get_long("spx.rt.global_rows");
+    const long slice_off = slice_rows > 0 ? cfg.get_long("spx.rt.row_offset") : 0;
+    if (slice_rows > 0 && (world != 1 || slice_off < 0 || slice_off + (long) in->nrows > slice_rows)) {
+        log_msg(LOG_ERR, "spx.rt.row_offset/global_rows (%ld/%ld) do not hold the %ld input rows "
+                "(and exclude spx.rt.gpu_world > 1)\n", slice_off, slice_rows, (long) in->nrows);
+        throw FatalError("bad row slice");
+    }
+    in->mat->row_base = (size_t) slice_off;
+    in->mat->global_rows = slice_rows > 0 ? (size_t) slice_rows : 0;
+    const idx_t rows_end = slice_rows > 0 ? (idx_t)(slice_off + in->nrows) : in->nrows;   // last input row + 1, global
     const bool sym = cfg.get_bool("spx.matrix.symmetric");
     const bool host_only = cfg.get_bool("spx.rt.host_only");
     EncoderParams prm = EncoderParams::from_config(cfg);
@@ -514,7 +481,7 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     }
 
     std::unique_ptr<matrix> A(new matrix);
-    A->nrows = in->nrows;
+    A->nrows = slice_rows > 0 ? (spx_index_t) slice_rows : in->nrows;
     A->ncols = in->ncols;
     A->nnz = in->nnz;
     A->symmetric = sym ? 1 : 0;
@@ -557,7 +524,7 @@ static spx_matrix_t *do_tune(spx_input_t *in)
                 } else {
                     e1.remove_ignore(seq);
                     e2.remove_ignore(seq);
-                    if (first + i) e1.encode_all(lg);
+                    if (ps.lower.row_start > 0) e1.encode_all(lg);
                     e2.encode_all(lg);
                 }
                 ps.merge();
@@ -588,8 +555,8 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     // them to the caller-side VecInit (CsxKernels.cpp:93).
     if (last == P && nown) {
         PartBounds &b = A->bounds[P - 1];
-        if (b.row_start + b.nr_rows < A->nrows) {
-            b.nr_rows = A->nrows - b.row_start;
+        if (b.row_start + b.nr_rows < rows_end) {
+            b.nr_rows = rows_end - b.row_start;
             A->parts[nown - 1].nr_rows = (size_t) b.nr_rows;
         }
     }
@@ -610,7 +577,7 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     {
         idx_t lo = nown ? A->bounds[first].row_start : 0;
         idx_t hi = nown ? A->bounds[last - 1].row_start + A->bounds[last - 1].nr_rows : 0;
-        if (last == P) hi = A->nrows;     // trailing empty rows belong to the last slice
+        if (last == P) hi = rows_end;     // trailing empty rows belong to the last slice
         A->own_lo = lo;
         A->own_hi = hi;
     }
@@ -641,6 +608,10 @@ spx_matrix_t *spx_mat_tune(spx_input_t *in, ...)
     // (src/api/matvec.c:280-288: input->mat = ReorderCSR/ReorderMMF(...)); a
     // matrix that cannot be reordered is tuned in its given order.
     std::vector<idx_t> perm;
+    if (option == SPX_MAT_REORDER && Config::instance().get_long("spx.rt.global_rows") > 0) {
+        SETWARNING(SPX_WARN_REORDER);      // a row slice cannot be reordered on its own
+        option = 0;
+    }
     if (option == SPX_MAT_REORDER) {
         TripletInput *re = nullptr;
         try {
@@ -677,6 +648,7 @@ spx_error_t spx_mat_destroy(spx_matrix_t *A)
         return SPX_FAILURE;
     }
     try { device_free(A->dev); } catch (...) {}
+    try { dist_free_plan(A->dist); } catch (...) {}
     if (A->permutation) free(A->permutation);
     delete A;
     return SPX_SUCCESS;
@@ -1176,6 +1148,7 @@ spx_matrix_t *spx_mat_restore(const char *filename)
     A->host_only = cfg.get_bool("spx.rt.host_only");
     A->device_ordinal = (int) cfg.get_long("spx.rt.device");
     A->full_colind = cfg.get_bool("spx.matrix.full_colind");
+    if (A->symmetric && !gs->sym_fused) stream_touched_rows(*gs, A->own_lo, A->conflict_rows);
     try {
         if (!A->host_only) {
             A->dev = device_upload(*gs, (size_t) A->nrows, (size_t) A->ncols, A->symmetric != 0,
@@ -1378,8 +1351,12 @@ static spx_error_t run_host(const spx_matrix_t *A, spx_value_t alpha, const spx_
         return SPX_FAILURE;
     }
     try {
+        // a row-partitioned matrix with an exchange plan: every process ends up
+        // with all of y in host memory, as the reference's caller expects
+        std::function<void(double *, void *)> after;
+        if (A->dist) after = [A](double *d_y, void *st) { dist_complete(A->dist, d_y, true, st); };
         device_spmv_host(A->dev, alpha, x->elements, x->alloc_type == ALLOC_PINNED, beta,
-                         y->elements, y->alloc_type == ALLOC_PINNED);
+                         y->elements, y->alloc_type == ALLOC_PINNED, after);
     } catch (const FatalError &e) {
         SETERROR_1(SPX_ERR_TUNED_MAT, e.what.c_str());
         return SPX_FAILURE;
@@ -1461,6 +1438,26 @@ spx_error_t spx_hip_matvec_kernel(spx_value_t alpha, const spx_matrix_t *A,
     return SPX_SUCCESS;
 }
 
+spx_error_t spx_hip_matvec_dist(spx_value_t alpha, const spx_matrix_t *A,
+                                const spx_value_t *x_dev, spx_value_t beta,
+                                spx_value_t *y_dev, int flags, void *stream)
+{
+    if (check_dev(A, x_dev, y_dev) != SPX_SUCCESS) return SPX_FAILURE;
+    if (!A->dist) {
+        SETERROR_1(SPX_ERR_TUNED_MAT, "matrix has no exchange plan (spx_hip_mat_dist_attach)");
+        return SPX_FAILURE;
+    }
+    if (!refresh_if_dirty(A)) return SPX_FAILURE;
+    try {
+        device_spmv(A->dev, alpha, x_dev, beta, y_dev, stream);
+        dist_complete(A->dist, y_dev, (flags & SPX_DIST_GATHER_Y) != 0, stream);
+    } catch (const FatalError &e) {
+        SETERROR_1(SPX_ERR_TUNED_MAT, e.what.c_str());
+        return SPX_FAILURE;
+    }
+    return SPX_SUCCESS;
+}
+
 // ======================================================================================
 //  extensions: info / export
 // ======================================================================================
@@ -1481,12 +1478,8 @@ spx_error_t spx_hip_mat_info(const spx_matrix_t *A, spx_hip_info_t *info)
     info->nr_partitions = (int32_t) A->nr_partitions;
     info->first_partition = (int32_t) A->first_part;
     info->last_partition = (int32_t) A->last_part;
-    if (A->last_part > A->first_part) {
-        info->row_lo = A->bounds[A->first_part].row_start;
-        const PartBounds &b = A->bounds[A->last_part - 1];
-        info->row_hi = (A->last_part == A->nr_partitions) ? A->nrows
-                                                           : b.row_start + b.nr_rows;
-    }
+    info->row_lo = A->own_lo;
+    info->row_hi = A->own_hi;
     info->symmetric = A->symmetric;
     info->on_device = A->dev ? 1 : 0;
     if (A->dev) {

@@ -7,6 +7,7 @@
 
 #include "gpu_emit.hpp"
 
+#include <functional>
 #include <string>
 
 namespace spx {
@@ -29,13 +30,20 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
 // beta != 0), kernel, D2H y; synchronous.  Vectors the library allocated itself
 // are pinned (device_host_alloc) and are copied from / to directly; user
 // buffers go through pinned staging copies.
+// `after(d_y, stream)`, if given, runs between the kernel and the copy back (the
+// exchange of a row-partitioned matrix).
 void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x, bool x_pinned,
-                      double beta, double *h_y, bool y_pinned);
+                      double beta, double *h_y, bool y_pinned,
+                      const std::function<void(double *, void *)> &after = nullptr);
 
 // page-locked host memory for the library's own vectors; nullptr when there is
 // no HIP device (the caller falls back to malloc)
 void *device_host_alloc(size_t bytes);
 void device_host_free(void *p);
+
+// symmetric slice: the first kernel clears y on rows [first_row, own rows) only
+// (default 0: the whole partial vector is defined, for a caller-side all-reduce)
+void device_set_init_rows(DeviceMatrix *m, size_t first_row);
 
 // wavefronts per workgroup of the SpMV kernel: 2, 4 or 8
 void device_set_waves(DeviceMatrix *m, int waves);

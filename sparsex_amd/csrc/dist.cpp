@@ -1,0 +1,230 @@
+// dist.cpp -- see dist.hpp.
+#include "dist.hpp"
+#include "handles.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace spx {
+
+namespace {
+
+void host_exchange(const spx_hip_transport_t &t, const std::vector<uint64_t> &send,
+                   const std::vector<size_t> &soff, const std::vector<size_t> &scnt,
+                   std::vector<uint64_t> &recv, const std::vector<size_t> &roff,
+                   const std::vector<size_t> &rcnt)
+{
+    if (t.world <= 1) return;
+    if (!t.exchange_host) throw FatalError("transport without exchange_host");
+    static const uint64_t dummy = 0;
+    uint64_t rdummy = 0;
+    if (t.exchange_host(t.ctx, send.empty() ? &dummy : send.data(), soff.data(), scnt.data(),
+                        recv.empty() ? &rdummy : recv.data(), roff.data(), rcnt.data()) != 0)
+        throw FatalError("transport: host exchange failed");
+}
+
+}  // namespace
+
+DistPlan *dist_build_plan(const spx_hip_transport_t &t, idx_t own_lo, idx_t own_hi, idx_t nrows,
+                          const std::vector<idx_t> &conflict_rows, bool on_device)
+{
+    if (t.world < 1 || t.rank < 0 || t.rank >= t.world) throw FatalError("transport: bad rank/world");
+    std::unique_ptr<DistPlan> p(new DistPlan);
+    p->transport = t;
+    p->rank = t.rank;
+    p->world = t.world;
+    const size_t W = (size_t) t.world, me = (size_t) t.rank;
+
+    // 1. everybody's rows
+    {
+        std::vector<uint64_t> send = {(uint64_t) own_lo, (uint64_t) own_hi}, recv(2 * W, 0);
+        std::vector<size_t> soff(W, 0), scnt(W, 2), roff(W), rcnt(W, 2);
+        for (size_t q = 0; q < W; ++q) roff[q] = 2 * q;
+        scnt[me] = rcnt[me] = 0;
+        host_exchange(t, send, soff, scnt, recv, roff, rcnt);
+        recv[2 * me] = (uint64_t) own_lo;
+        recv[2 * me + 1] = (uint64_t) own_hi;
+        p->row_lo.resize(W);
+        p->row_hi.resize(W);
+        for (size_t q = 0; q < W; ++q) {
+            p->row_lo[q] = (idx_t) recv[2 * q];
+            p->row_hi[q] = (idx_t) recv[2 * q + 1];
+        }
+        // the ranges must tile [0, nrows) in rank order
+        idx_t at = 0;
+        for (size_t q = 0; q < W; ++q) {
+            if (p->row_lo[q] != at || p->row_hi[q] < at) throw FatalError("row ranges of the processes do not tile the matrix");
+            at = p->row_hi[q];
+        }
+        if (at != nrows) throw FatalError("row ranges of the processes do not cover the matrix");
+    }
+
+    // 2. this process' conflict rows, by owner (they are ascending)
+    p->send_rows = conflict_rows;
+    p->send_off.assign(W, 0);
+    p->send_cnt.assign(W, 0);
+    {
+        size_t k = 0;
+        for (size_t q = 0; q < W; ++q) {
+            p->send_off[q] = k;
+            while (k < conflict_rows.size() && conflict_rows[k] < p->row_hi[q]) {
+                if (q >= me) throw FatalError("conflict row not in front of the own rows");
+                ++k;
+            }
+            p->send_cnt[q] = k - p->send_off[q];
+        }
+        if (k != conflict_rows.size()) throw FatalError("conflict row outside the matrix");
+    }
+
+    // 3. counts, then the row lists themselves
+    p->recv_off.assign(W, 0);
+    p->recv_cnt.assign(W, 0);
+    {
+        std::vector<uint64_t> send(W), recv(W, 0);
+        std::vector<size_t> off(W), one(W, 1);
+        for (size_t q = 0; q < W; ++q) {
+            send[q] = p->send_cnt[q];
+            off[q] = q;
+        }
+        one[me] = 0;
+        host_exchange(t, send, off, one, recv, off, one);
+        size_t k = 0;
+        for (size_t q = 0; q < W; ++q) {
+            p->recv_off[q] = k;
+            p->recv_cnt[q] = q == me ? 0 : (size_t) recv[q];
+            k += p->recv_cnt[q];
+        }
+        p->n_recv = k;
+    }
+    std::vector<uint64_t> recv_rows(p->n_recv, 0);
+    {
+        std::vector<uint64_t> send(conflict_rows.begin(), conflict_rows.end());
+        host_exchange(t, send, p->send_off, p->send_cnt, recv_rows, p->recv_off, p->recv_cnt);
+    }
+    // 4. does anybody exchange anything?  (a general matrix: nobody)
+    {
+        std::vector<uint64_t> send(W, conflict_rows.empty() ? 0 : 1), recv(W, 0);
+        std::vector<size_t> off(W), one(W, 1);
+        for (size_t q = 0; q < W; ++q) off[q] = q;
+        one[me] = 0;
+        host_exchange(t, send, off, one, recv, off, one);
+        p->any_exchange = !conflict_rows.empty();
+        for (size_t q = 0; q < W; ++q) p->any_exchange = p->any_exchange || (q != me && recv[q]);
+    }
+
+    // 5. per own row: where in the receive buffer its sums arrive (fixed order)
+    {
+        std::vector<std::pair<idx_t, uint32_t>> pr(p->n_recv);
+        for (size_t k = 0; k < p->n_recv; ++k) {
+            const idx_t r = (idx_t) recv_rows[k];
+            if (r < own_lo || r >= own_hi) throw FatalError("received a conflict row that is not owned here");
+            pr[k] = std::make_pair(r, (uint32_t) k);
+        }
+        std::sort(pr.begin(), pr.end());
+        p->fix_ptr.push_back(0);
+        for (size_t k = 0; k < pr.size(); ++k) {
+            if (k == 0 || pr[k].first != pr[k - 1].first) {
+                if (k) p->fix_ptr.push_back((uint32_t) k);
+                p->fix_rows.push_back(pr[k].first);
+            }
+            p->fix_pos.push_back(pr[k].second);
+        }
+        if (!pr.empty()) p->fix_ptr.push_back((uint32_t) pr.size());
+    }
+
+    // 6. the slices of y, in place
+    p->gat_send_off.assign(W, (size_t) own_lo);
+    p->gat_send_cnt.assign(W, (size_t)(own_hi - own_lo));
+    p->gat_recv_off.resize(W);
+    p->gat_recv_cnt.resize(W);
+    for (size_t q = 0; q < W; ++q) {
+        p->gat_recv_off[q] = (size_t) p->row_lo[q];
+        p->gat_recv_cnt[q] = (size_t)(p->row_hi[q] - p->row_lo[q]);
+    }
+    p->gat_send_cnt[me] = p->gat_recv_cnt[me] = 0;
+
+    if (on_device) p->dev = dist_device_create(*p);
+    return p.release();
+}
+
+void dist_free_plan(DistPlan *p)
+{
+    if (!p) return;
+    dist_device_free(p->dev);
+    delete p;
+}
+
+void dist_complete(DistPlan *p, double *d_y, bool gather, void *stream)
+{
+    if (p->world <= 1) return;
+    const spx_hip_transport_t &t = p->transport;
+    if (!t.exchange_device) throw FatalError("transport without exchange_device");
+    if (p->any_exchange) {
+        const double *sendbuf = dist_device_pack(p->dev, d_y, stream);
+        if (t.exchange_device(t.ctx, sendbuf, p->send_off.data(), p->send_cnt.data(),
+                              dist_device_recvbuf(p->dev), p->recv_off.data(), p->recv_cnt.data(),
+                              stream) != 0)
+            throw FatalError("transport: device exchange failed");
+        dist_device_unpack(p->dev, d_y, stream);
+    }
+    if (gather &&
+        t.exchange_device(t.ctx, d_y, p->gat_send_off.data(), p->gat_send_cnt.data(), d_y,
+                          p->gat_recv_off.data(), p->gat_recv_cnt.data(), stream) != 0)
+        throw FatalError("transport: gathering y failed");
+}
+
+}  // namespace spx
+
+// ---- C API -------------------------------------------------------------------------------------
+
+extern "C" {
+
+spx_error_t spx_hip_mat_dist_attach(spx_matrix_t *A, const spx_hip_transport_t *t)
+{
+    if (!A || !t) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid argument"); return SPX_FAILURE; }
+    try {
+        if (A->dist) {
+            dist_free_plan(A->dist);
+            A->dist = nullptr;
+        }
+        A->dist = dist_build_plan(*t, A->own_lo, A->own_hi, A->nrows, A->conflict_rows,
+                                  A->dev != nullptr);
+        // the exchange takes over what the caller-side all-reduce needed: rows this
+        // process neither owns nor adds to are nobody's business any more
+        if (A->dev && A->symmetric)
+            device_set_init_rows(A->dev, A->conflict_rows.empty() ? A->own_lo : A->conflict_rows.front());
+    } catch (const FatalError &e) {
+        SETERROR_1(SPX_ERR_TUNED_MAT, e.what.c_str());
+        return SPX_FAILURE;
+    }
+    return SPX_SUCCESS;
+}
+
+spx_error_t spx_hip_mat_dist_plan(const spx_matrix_t *A, spx_hip_dist_plan_t *plan)
+{
+    if (!A || !plan || !A->dist) {
+        SETERROR_1(SPX_ERR_ARG_INVALID, "matrix has no exchange plan (spx_hip_mat_dist_attach)");
+        return SPX_FAILURE;
+    }
+    const DistPlan &p = *A->dist;
+    memset(plan, 0, sizeof(*plan));
+    plan->rank = p.rank;
+    plan->world = p.world;
+    plan->row_lo = p.row_lo.data();
+    plan->row_hi = p.row_hi.data();
+    plan->n_send = (int64_t) p.send_rows.size();
+    plan->send_rows = p.send_rows.data();
+    plan->send_off = p.send_off.data();
+    plan->send_cnt = p.send_cnt.data();
+    plan->n_recv = (int64_t) p.n_recv;
+    plan->recv_off = p.recv_off.data();
+    plan->recv_cnt = p.recv_cnt.data();
+    plan->n_fix_rows = (int64_t) p.fix_rows.size();
+    plan->fix_rows = p.fix_rows.data();
+    plan->fix_ptr = p.fix_ptr.data();
+    plan->fix_pos = p.fix_pos.data();
+    plan->any_exchange = p.any_exchange ? 1 : 0;
+    return SPX_SUCCESS;
+}
+
+}  // extern "C"

@@ -1,0 +1,50 @@
+// dist.hpp -- row-partitioned matrices, one process per GPU: the exchange plan
+// that completes y and its device side (see include/sparsex_hip.h, "one process
+// per GPU").  Counterpart of the reference's conflict map and its reduction
+// (include/sparsex/internals/CsxBuild.hpp:400-581, Map.hpp:23-27,
+// src/internals/Vector.cpp:291-299, src/internals/CsxSpmv.cpp:37-50).
+#pragma once
+
+#include <sparsex_hip.h>
+
+#include "common.hpp"
+
+#include <vector>
+
+namespace spx {
+
+struct DistDevice;     // device arrays of a plan (dist_kernels.hip)
+
+struct DistPlan {
+    spx_hip_transport_t transport;
+    int rank = 0, world = 1;
+    std::vector<idx_t> row_lo, row_hi;            // every process' rows
+    std::vector<idx_t> send_rows;                 // this process' conflict rows (ascending)
+    std::vector<size_t> send_off, send_cnt;       // per owner
+    std::vector<size_t> recv_off, recv_cnt;       // per sender
+    size_t n_recv = 0;
+    std::vector<idx_t> fix_rows;                  // own rows that receive something
+    std::vector<uint32_t> fix_ptr, fix_pos;       // per such row: positions in the receive buffer
+    bool any_exchange = false;                    // some process sends something
+    std::vector<size_t> gat_send_off, gat_send_cnt, gat_recv_off, gat_recv_cnt;   // slices of y, in place
+    DistDevice *dev = nullptr;
+};
+
+// Collective.  `conflict_rows`: rows in front of own_lo this process adds to.
+// Throws FatalError.
+DistPlan *dist_build_plan(const spx_hip_transport_t &t, idx_t own_lo, idx_t own_hi, idx_t nrows,
+                          const std::vector<idx_t> &conflict_rows, bool on_device);
+void dist_free_plan(DistPlan *p);
+
+// after the local SpMV on `stream`: hand the sums for other processes' rows to
+// their owners and add what arrives; then (gather) pass the finished slices round
+void dist_complete(DistPlan *p, double *d_y, bool gather, void *stream);
+
+// device side (dist_kernels.hip)
+DistDevice *dist_device_create(const DistPlan &p);
+void dist_device_free(DistDevice *d);
+const double *dist_device_pack(DistDevice *d, const double *d_y, void *stream);
+double *dist_device_recvbuf(DistDevice *d);
+void dist_device_unpack(DistDevice *d, double *d_y, void *stream);
+
+}  // namespace spx

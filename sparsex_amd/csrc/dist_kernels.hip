@@ -1,0 +1,276 @@
+// dist_kernels.hip -- device side of the exchange plan of a row-partitioned
+// matrix (dist.hpp) and the built-in transport: RCCL point-to-point over xGMI.
+//
+// A symmetric process adds into rows in front of its own (the reference's local
+// buffers, src/api/matvec.c:302-318); only those entries travel, packed, to
+// their owners, which add them in a fixed order (the reference's map reduction,
+// src/internals/Vector.cpp:291-299).  xGMI is point-to-point: every pair of
+// GPUs has its own link, so the direct pairwise exchange below is the collective
+// that fits it -- a ring would push every byte over up to seven links.
+#include "dist.hpp"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+
+namespace spx {
+
+#define HIP_CHECK(expr)                                                         \
+    do {                                                                        \
+        hipError_t e_ = (expr);                                                 \
+        if (e_ != hipSuccess) {                                                 \
+            std::string m_ = std::string("HIP failure: ") + #expr + ": " +      \
+                             hipGetErrorString(e_);                             \
+            log_msg(LOG_ERR, "%s\n", m_.c_str());                               \
+            throw FatalError(m_);                                               \
+        }                                                                       \
+    } while (0)
+
+struct DistDevice {
+    int device = 0;
+    size_t n_send = 0, n_recv = 0, n_fix = 0;
+    idx_t *send_rows = nullptr;
+    double *sendbuf = nullptr, *recvbuf = nullptr;
+    idx_t *fix_rows = nullptr;
+    uint32_t *fix_ptr = nullptr, *fix_pos = nullptr;
+};
+
+// sendbuf[k] = y[send_rows[k]]: the sums this process formed for rows of others
+__global__ void dist_pack_kernel(const idx_t *rows, const double *y, double *buf, size_t n)
+{
+    const size_t k = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) buf[k] = y[rows[k]];
+}
+
+// y[row] += what the other processes sent for it, in the order of the senders
+__global__ void dist_unpack_kernel(const idx_t *rows, const uint32_t *ptr, const uint32_t *pos,
+                                   const double *buf, double *y, size_t n)
+{
+    const size_t t = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    double s = 0.0;
+    for (uint32_t k = ptr[t]; k < ptr[t + 1]; ++k) s += buf[pos[k]];
+    y[rows[t]] += s;
+}
+
+template <typename T>
+static T *to_device(const std::vector<T> &v, size_t min_elems = 1)
+{
+    T *d = nullptr;
+    const size_t n = std::max(v.size(), min_elems);
+    HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d), n * sizeof(T)));
+    if (!v.empty()) HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return d;
+}
+
+DistDevice *dist_device_create(const DistPlan &p)
+{
+    DistDevice *d = new DistDevice;
+    HIP_CHECK(hipGetDevice(&d->device));
+    d->n_send = p.send_rows.size();
+    d->n_recv = p.n_recv;
+    d->n_fix = p.fix_rows.size();
+    d->send_rows = to_device(p.send_rows);
+    d->fix_rows = to_device(p.fix_rows);
+    d->fix_ptr = to_device(p.fix_ptr, 2);
+    d->fix_pos = to_device(p.fix_pos);
+    HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d->sendbuf), std::max<size_t>(d->n_send, 1) * sizeof(double)));
+    HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d->recvbuf), std::max<size_t>(d->n_recv, 1) * sizeof(double)));
+    return d;
+}
+
+void dist_device_free(DistDevice *d)
+{
+    if (!d) return;
+    (void) hipFree(d->send_rows); (void) hipFree(d->fix_rows); (void) hipFree(d->fix_ptr);
+    (void) hipFree(d->fix_pos); (void) hipFree(d->sendbuf); (void) hipFree(d->recvbuf);
+    delete d;
+}
+
+const double *dist_device_pack(DistDevice *d, const double *d_y, void *stream)
+{
+    if (d->n_send)
+        hipLaunchKernelGGL(dist_pack_kernel, dim3((unsigned) ((d->n_send + 255) / 256)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), d->send_rows, d_y, d->sendbuf, d->n_send);
+    return d->sendbuf;
+}
+
+double *dist_device_recvbuf(DistDevice *d) { return d->recvbuf; }
+
+void dist_device_unpack(DistDevice *d, double *d_y, void *stream)
+{
+    if (d->n_fix)
+        hipLaunchKernelGGL(dist_unpack_kernel, dim3((unsigned) ((d->n_fix + 255) / 256)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), d->fix_rows, d->fix_ptr, d->fix_pos,
+                           d->recvbuf, d_y, d->n_fix);
+}
+
+// ---- RCCL transport --------------------------------------------------------------------------
+
+namespace {
+
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+Rccl &rccl()
+{
+    static Rccl r;
+    if (r.lib) return r;
+    // loaded on demand: a single-GPU user of this library never maps librccl
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) throw FatalError(std::string("cannot load librccl: ") + dlerror());
+#define SPX_SYM(field, sym)                                                                      \
+    r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, sym));                            \
+    if (!r.field) throw FatalError(std::string("librccl lacks ") + sym)
+    SPX_SYM(GetUniqueId, "ncclGetUniqueId");
+    SPX_SYM(CommInitRank, "ncclCommInitRank");
+    SPX_SYM(CommDestroy, "ncclCommDestroy");
+    SPX_SYM(GroupStart, "ncclGroupStart");
+    SPX_SYM(GroupEnd, "ncclGroupEnd");
+    SPX_SYM(Send, "ncclSend");
+    SPX_SYM(Recv, "ncclRecv");
+    SPX_SYM(GetErrorString, "ncclGetErrorString");
+#undef SPX_SYM
+    return r;
+}
+
+struct RcclCtx {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    hipStream_t setup_stream = nullptr;
+};
+
+int rccl_exchange_device(void *ctx_, const double *send, const size_t *soff, const size_t *scnt,
+                         double *recv, const size_t *roff, const size_t *rcnt, void *stream)
+{
+    RcclCtx *c = static_cast<RcclCtx *>(ctx_);
+    Rccl &r = rccl();
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ncclResult_t rc = r.GroupStart();
+    for (int q = 0; q < c->world && rc == ncclSuccess; ++q) {
+        if (q == c->rank) continue;
+        if (scnt[q]) rc = r.Send(send + soff[q], scnt[q], ncclDouble, q, c->comm, st);
+        if (rc == ncclSuccess && rcnt[q]) rc = r.Recv(recv + roff[q], rcnt[q], ncclDouble, q, c->comm, st);
+    }
+    const ncclResult_t rc2 = r.GroupEnd();
+    if (rc == ncclSuccess) rc = rc2;
+    if (rc != ncclSuccess) {
+        log_msg(LOG_ERR, "RCCL: %s\n", r.GetErrorString(rc));
+        return -1;
+    }
+    return 0;
+}
+
+int rccl_exchange_host(void *ctx_, const uint64_t *send, const size_t *soff, const size_t *scnt,
+                       uint64_t *recv, const size_t *roff, const size_t *rcnt)
+{
+    // set-up time only: staged through device buffers (8-byte words travel as doubles,
+    // nothing looks at the bits)
+    RcclCtx *c = static_cast<RcclCtx *>(ctx_);
+    size_t ns = 0, nr = 0;
+    for (int q = 0; q < c->world; ++q) {
+        if (q == c->rank) continue;
+        ns = std::max(ns, soff[q] + scnt[q]);
+        nr = std::max(nr, roff[q] + rcnt[q]);
+    }
+    double *ds = nullptr, *dr = nullptr;
+    int ret = -1;
+    if (hipMalloc(reinterpret_cast<void **>(&ds), std::max<size_t>(ns, 1) * 8) == hipSuccess &&
+        hipMalloc(reinterpret_cast<void **>(&dr), std::max<size_t>(nr, 1) * 8) == hipSuccess &&
+        (ns == 0 || hipMemcpyAsync(ds, send, ns * 8, hipMemcpyHostToDevice, c->setup_stream) == hipSuccess) &&
+        rccl_exchange_device(c, ds, soff, scnt, dr, roff, rcnt, c->setup_stream) == 0 &&
+        hipStreamSynchronize(c->setup_stream) == hipSuccess) {
+        // only the segments that were received are defined
+        ret = 0;
+        for (int q = 0; q < c->world && ret == 0; ++q)
+            if (q != c->rank && rcnt[q] &&
+                hipMemcpy(recv + roff[q], dr + roff[q], rcnt[q] * 8, hipMemcpyDeviceToHost) != hipSuccess)
+                ret = -1;
+    }
+    (void) hipFree(ds);
+    (void) hipFree(dr);
+    return ret;
+}
+
+}  // namespace
+
+}  // namespace spx
+
+extern "C" {
+
+spx_error_t spx_hip_rccl_unique_id(void *id)
+{
+    static_assert(sizeof(ncclUniqueId) == SPX_RCCL_ID_BYTES, "RCCL id size");
+    try {
+        ncclUniqueId u;
+        if (!id || spx::rccl().GetUniqueId(&u) != ncclSuccess) return SPX_FAILURE;
+        memcpy(id, &u, sizeof(u));
+    } catch (const spx::FatalError &e) {
+        spx::log_msg(spx::LOG_ERR, "%s\n", e.what.c_str());
+        return SPX_FAILURE;
+    }
+    return SPX_SUCCESS;
+}
+
+spx_hip_transport_t *spx_hip_transport_rccl(const void *id, int rank, int world)
+{
+    if (!id || world < 1 || rank < 0 || rank >= world) return NULL;
+    try {
+        spx::Rccl &r = spx::rccl();
+        std::unique_ptr<spx::RcclCtx> c(new spx::RcclCtx);
+        c->rank = rank;
+        c->world = world;
+        ncclUniqueId u;
+        memcpy(&u, id, sizeof(u));
+        const ncclResult_t rc = r.CommInitRank(&c->comm, world, u, rank);
+        if (rc != ncclSuccess) {
+            spx::log_msg(spx::LOG_ERR, "RCCL communicator: %s\n", r.GetErrorString(rc));
+            return NULL;
+        }
+        if (hipStreamCreateWithFlags(&c->setup_stream, hipStreamNonBlocking) != hipSuccess) return NULL;
+        spx_hip_transport_t *t = new spx_hip_transport_t;
+        t->ctx = c.release();
+        t->rank = rank;
+        t->world = world;
+        t->exchange_host = spx::rccl_exchange_host;
+        t->exchange_device = spx::rccl_exchange_device;
+        return t;
+    } catch (const spx::FatalError &e) {
+        spx::log_msg(spx::LOG_ERR, "%s\n", e.what.c_str());
+        return NULL;
+    }
+}
+
+void spx_hip_transport_destroy(spx_hip_transport_t *t)
+{
+    // (only transports made by spx_hip_transport_rccl)
+    if (!t) return;
+    spx::RcclCtx *c = static_cast<spx::RcclCtx *>(t->ctx);
+    if (c) {
+        if (c->comm) (void) spx::rccl().CommDestroy(c->comm);
+        if (c->setup_stream) (void) hipStreamDestroy(c->setup_stream);
+        delete c;
+    }
+    delete t;
+}
+
+}  // extern "C"

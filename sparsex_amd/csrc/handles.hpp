@@ -1,0 +1,75 @@
+// handles.hpp -- what the opaque handles of <sparsex/sparsex.h> point to
+// (reference: the structs at the top of src/api/matvec.c:30-62).
+#pragma once
+
+#include <sparsex/sparsex.h>
+#include <sparsex_hip.h>
+
+#include "csx_emit.hpp"
+#include "device.hpp"
+#include "gpu_emit.hpp"
+#include "input.hpp"
+
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace spx { struct DistPlan; }
+
+using namespace spx;
+
+struct input {
+    spx_index_t nrows, ncols, nnz;
+    char type;                         // 'C' (CSR) or 'M' (MMF)
+    MatrixInput *mat;
+};
+
+struct partition {
+    size_t nr_partitions;
+    size_t *parts;
+    int *nodes;
+    int *affinity;
+    spx_index_t *row_start;
+    spx_index_t *row_end;
+};
+
+struct matrix {
+    spx_index_t nrows = 0, ncols = 0, nnz = 0;
+    int symmetric = 0;
+    spx_perm_t *permutation = SPX_INVALID_PERM;
+    // tuned representation
+    size_t nr_partitions = 0;          // P, over all processes
+    size_t first_part = 0, last_part = 0;   // owned partitions [first, last)
+    std::vector<PartBounds> bounds;    // all P partitions
+    std::vector<Partition> parts;      // encoded, horizontal order (owned ones)
+    std::vector<std::vector<val_t>> diag;   // symmetric: per owned partition
+    std::vector<std::unique_ptr<CsxStream>> exported;
+    std::vector<std::vector<spx_index_t>> exported_rows_info;
+    bool full_colind = false;
+    DeviceMatrix *dev = nullptr;
+    std::unique_ptr<GpuStream> host_stream;   // kept for host-only matrices (save/restore)
+    std::unique_ptr<GpuStream> index;         // matrix in HBM: host copy of the stream's index arrays (no values),
+                                              // walked by get/set entry
+    idx_t own_lo = 0, own_hi = 0;
+    // symmetric matrix of which this process holds a slice: the rows in front of
+    // its own that it adds to (the reference's conflict map, CsxBuild.hpp:400-451)
+    std::vector<idx_t> conflict_rows;
+    spx::DistPlan *dist = nullptr;            // set by spx_hip_mat_dist_attach
+    GpuEmitParams emit_params;
+    bool auto_rb = false;
+    double rb_scale = 1.0;      // chosen by the launch autotuner (multiplies the automatic row-block size)
+    int waves = 4;              // wavefronts per workgroup of the SpMV kernel
+    bool host_only = false;
+    int device_ordinal = -1;
+    bool dirty = false;                       // values changed since the last upload
+    std::vector<std::vector<idx_t>> spans;    // per partition and row: reach of its units
+    std::vector<idx_t> max_span;              // per partition
+    // accounting
+    size_t nnz_stored = 0, n_unit_elems = 0, n_delta_elems = 0, n_units = 0;
+    size_t value_bytes = 0, index_bytes = 0, n_rowblocks = 0, n_shared = 0;
+    double tune_seconds = 0.0, emit_seconds = 0.0;
+    std::string log;
+    std::mutex mtx;
+};
+

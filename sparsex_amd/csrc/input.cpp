@@ -331,7 +331,7 @@ size_t take_partition(MatrixInput &in, idx_t row_start, size_t limit,
     Triplet t;
     if (dst) dst->elems.clear();
     while (in.peek(t)) {
-        idx_t row = t.row - row_start;     // 1-based inside the partition
+        idx_t row = t.row + (idx_t) in.row_base - row_start;     // 1-based inside the partition
         if (row != row_prev) {
             if (limit && cnt >= limit) break;
             row_prev = row;
@@ -355,7 +355,7 @@ size_t take_partition_sym(MatrixInput &in, idx_t row_start, size_t limit,
     bool any_lower = false;
     Triplet t;
     while (in.peek(t)) {
-        idx_t row = t.row - row_start;
+        idx_t row = t.row + (idx_t) in.row_base - row_start;
         idx_t col = t.col;
         if (row_start + row > col) {           // strictly lower
             if (row != row_prev) {
@@ -386,7 +386,7 @@ void build_partitions(MatrixInput &in, size_t nr, size_t first, size_t last,
     bounds.clear();
     const size_t total = in.nnz;
     size_t cnt = 0;
-    idx_t row_start = 0;
+    idx_t row_start = (idx_t) in.row_base;
     for (size_t i = 0; i < nr; ++i) {
         size_t limit = (total - cnt) / (nr - i);
         Partition *p = (i >= first && i < last) ? &parts[i - first] : nullptr;
@@ -420,7 +420,7 @@ void build_partitions_sym(MatrixInput &in, size_t nr, size_t first, size_t last,
                           std::vector<PartitionSym> &parts,
                           std::vector<PartBounds> &bounds)
 {
-    if (in.nr_rows != in.nr_cols) {
+    if ((in.global_rows ? in.global_rows : in.nr_rows) != in.nr_cols) {
         log_msg(LOG_ERR, "symmetric format requested for a non-square matrix\n");
         throw FatalError("non-square symmetric");
     }
@@ -430,9 +430,19 @@ void build_partitions_sym(MatrixInput &in, size_t nr, size_t first, size_t last,
     bounds.clear();
     // lower triangle + diagonal of a matrix given in full; presumes a full
     // diagonal (SparseInternal.hpp:83-96)
-    const size_t total = (in.nnz + in.nr_cols) / 2;
+    size_t total = (in.nnz + in.nr_cols) / 2;
+    if (in.global_rows) {
+        // a row slice: count what it holds on and below the diagonal
+        total = 0;
+        Triplet t;
+        while (in.peek(t)) {
+            if ((idx_t)(t.row + (idx_t) in.row_base) >= t.col) ++total;
+            in.advance();
+        }
+        in.rewind();
+    }
     size_t cnt = 0;
-    idx_t row_start = 0;
+    idx_t row_start = (idx_t) in.row_base;
     for (size_t i = 0; i < nr; ++i) {
         size_t limit = (total - cnt) / (nr - i);
         PartitionSym *p = (i >= first && i < last) ? &parts[i - first] : nullptr;

@@ -24,6 +24,10 @@ class MatrixInput {
 public:
     virtual ~MatrixInput() {}
     size_t nr_rows = 0, nr_cols = 0, nnz = 0;
+    // The input may be a row slice of a larger matrix (one process per GPU, each
+    // holding the rows it owns): its rows are [row_base, row_base + nr_rows) of
+    // a matrix with global_rows rows.  0 / 0: the input is the whole matrix.
+    size_t row_base = 0, global_rows = 0;
     virtual void rewind() = 0;
     // false at the end of the stream; does not advance
     virtual bool peek(Triplet &t) = 0;
@@ -82,7 +86,8 @@ private:
 // Splits the stream into `nr` row partitions of (roughly) equal nonzero
 // count and materialises those in [first, last).  Partitions outside that
 // range are walked but not stored (their boundaries still matter).
-// Returns row_start/nr_rows of every partition through `bounds`.
+// Returns row_start/nr_rows of every partition through `bounds` (global row
+// numbers when the input is a slice: the first partition starts at row_base).
 struct PartBounds { idx_t row_start; idx_t nr_rows; size_t nnz; };
 
 void build_partitions(MatrixInput &in, size_t nr, size_t first, size_t last,

@@ -466,10 +466,10 @@ __global__ void csx_fixup_kernel(const SpxSharedRow *shared, uint32_t n_shared,
 // rows, 0 elsewhere (the main kernel then accumulates; on several GPUs the
 // per-GPU vectors are summed afterwards)
 __global__ void csx_sym_init_kernel(double *y, const double *x, const double *dvalues,
-                                    size_t nrows, size_t own_lo, size_t own_hi,
+                                    size_t first, size_t nrows, size_t own_lo, size_t own_hi,
                                     double alpha, double beta)
 {
-    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = first + (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nrows) return;
     double v = 0.0;
     if (i >= own_lo && i < own_hi) {
@@ -488,6 +488,7 @@ struct DeviceMatrix {
     bool sym_fused = false;
     uint32_t pass_stride = 1;
     size_t own_lo = 0, own_hi = 0;
+    size_t init_lo = 0;       // symmetric slice with an exchange plan: first row to clear
     uint32_t n_rb = 0, n_shared = 0, n_carry = 0;
     SpxRowBlock *rbs = nullptr;
     double *values = nullptr;
@@ -614,6 +615,10 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
                  double *d_y, void *stream_)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != m->device)
+        throw FatalError("the matrix lives on HIP device " + std::to_string(m->device) +
+                         ", the calling thread's current device is " + std::to_string(cur));
     KernelArgs a;
     a.rbs = m->rbs; a.values = m->values; a.descs = m->descs; a.passes = m->passes;
     a.cidx = m->cidx; a.segrows = m->segrows; a.x = d_x; a.y = d_y;
@@ -626,10 +631,14 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
         // y <- beta*y + alpha*diag*x on the owned rows, 0 elsewhere; the
         // row-blocks (stored lower triangle and its mirror image) then
         // accumulate on top of that
+        // (attached to an exchange plan: only [init_lo, own_hi) -- the rows this
+        // process owns or adds to -- are anybody's business)
         const int t = 256;
-        hipLaunchKernelGGL(csx_sym_init_kernel, dim3((unsigned)((m->nrows + t - 1) / t)),
-                           dim3(t), 0, stream, d_y, d_x, m->dvalues, m->nrows,
-                           m->own_lo, m->own_hi, alpha, beta);
+        const size_t first = m->init_lo, last = m->init_lo ? m->own_hi : m->nrows;
+        if (last > first)
+            hipLaunchKernelGGL(csx_sym_init_kernel, dim3((unsigned)((last - first + t - 1) / t)),
+                               dim3(t), 0, stream, d_y, d_x, m->dvalues, first, last,
+                               m->own_lo, m->own_hi, alpha, beta);
         a.beta = beta = 1.0;
     }
     a.spill = m->spill;
@@ -660,6 +669,8 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
                            a.dvalues, d_x);
     HIP_CHECK(hipGetLastError());
 }
+
+void device_set_init_rows(DeviceMatrix *m, size_t first_row) { m->init_lo = first_row; }
 
 void device_set_waves(DeviceMatrix *m, int waves)
 {
@@ -705,7 +716,8 @@ double device_time_spmv(DeviceMatrix *m, int warmup, int launches)
 // buffers and asynchronous copies on one private stream -- a pageable
 // hipMemcpy stages internally as well, but synchronously and chunk by chunk.
 void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x, bool x_pinned,
-                      double beta, double *h_y, bool y_pinned)
+                      double beta, double *h_y, bool y_pinned,
+                      const std::function<void(double *, void *)> &after)
 {
     HIP_CHECK(hipSetDevice(m->device));
     const size_t xb = m->ncols * sizeof(double), yb = m->nrows * sizeof(double);
@@ -729,6 +741,7 @@ void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x, bool x_p
         HIP_CHECK(hipMemcpyAsync(m->d_y, src_y, yb, hipMemcpyHostToDevice, st));
     }
     device_spmv(m, alpha, m->d_x, beta, m->d_y, st);
+    if (after) after(m->d_y, st);
     HIP_CHECK(hipMemcpyAsync(y_pinned ? h_y : m->p_y, m->d_y, yb, hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     if (!y_pinned) std::memcpy(h_y, m->p_y, yb);

@@ -97,6 +97,39 @@ void stream_locate(const GpuStream &s, idx_t row, idx_t col, std::vector<size_t>
     }
 }
 
+void stream_touched_rows(const GpuStream &s, idx_t below, std::vector<idx_t> &rows)
+{
+    rows.clear();
+    if (below <= 0) return;
+    std::vector<char> mark((size_t) below, 0);
+    for (const SpxRowBlock &rb : s.rbs) {
+        if ((int64_t) rb.row0 >= (int64_t) below) continue;
+        for (uint32_t t = 0; t < rb.n_pass; ++t) {
+            const SpxPass &ps = s.passes[(size_t) rb.pass_off + t];
+            for (uint32_t l = 0; l < ps.nseg; ++l) {
+                int64_t r;
+                if (ps.kind == SPX_PASS_GATHER) {
+                    r = s.segrows[(size_t) rb.seg_off + ps.seg0 + l];
+                } else if (ps.kind == SPX_PASS_SYMTILE) {
+                    r = (int64_t) (s.descs[(size_t) rb.desc_off + ps.rank0 + (l >> 3)].bits & 511u) + (l & 7u);
+                } else {
+                    int64_t c;
+                    unit_lane(s, rb, ps, l, r, c);
+                }
+                r += rb.row0;
+                if (r < (int64_t) below) mark[(size_t) r] = 1;
+            }
+        }
+    }
+    for (uint32_t c : s.spill_col)
+        if ((int64_t) c < (int64_t) below) mark[c] = 1;
+    // (a restored stream: the per-row lists of the spilled sums are what is left)
+    for (size_t r = 0; r + 1 < s.fix_ptr.size() && r < (size_t) below; ++r)
+        if (s.fix_ptr[r + 1] > s.fix_ptr[r]) mark[r] = 1;
+    for (idx_t r = 0; r < below; ++r)
+        if (mark[(size_t) r]) rows.push_back(r);
+}
+
 bool stream_validate(const GpuStream &s, size_t nrows, size_t ncols, size_t n_values,
                      std::string &why)
 {

@@ -21,6 +21,14 @@ namespace spx {
 // on the host while its values live in HBM.
 void stream_locate(const GpuStream &s, idx_t row, idx_t col, std::vector<size_t> &out);
 
+// Rows in front of `below` that the stream adds to: rows of lanes of row-blocks
+// that start in front of it, and the columns of symmetric tiles' spilled sums
+// (s.spill_col, host side, still present).  Ascending, unique.  For a process
+// that holds a slice of a symmetric matrix these are the rows of OTHER processes
+// it contributes to -- the counterpart of the reference's conflict map
+// (include/sparsex/internals/CsxBuild.hpp:400-451).
+void stream_touched_rows(const GpuStream &s, idx_t below, std::vector<idx_t> &rows);
+
 // Structural checks of a finalized stream (array-size relations, offsets of
 // every row-block and pass inside their arrays, rows and columns inside the
 // matrix, LDS budget).  Returns false and a reason on the first violation.

@@ -67,3 +67,82 @@ def test_two_ranks_gloo(symmetric):
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, symmetric, ret), nprocs=world, join=True)
     assert all(ret.get(r) for r in range(world))
+
+
+# ---- the exchange plan of row-sliced matrices (BASELINE config 4's layout) --------------
+
+def _slice_worker(rank, world, port, symmetric, gen, tmpdir, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import scipy.sparse as sp
+    import sparsex_amd as sx
+    from sparsex_amd import synth
+    from sparsex_amd.dist_torch import torch_transport
+    from stream_decode import Stream
+    from test_row_slices import nnz_balanced_bounds
+    try:
+        if gen == "nlpkkt":
+            rp, ci, va, n = synth.syn_nlpkkt_rows(9)
+        else:
+            rp, ci, va, n = synth.syn_nd24k(0.02)
+        a = sp.csr_matrix((va, ci, rp), shape=(n, n))
+        cuts = nnz_balanced_bounds(np.diff(rp), world)
+        lo, hi = cuts[rank], cuts[rank + 1]
+        # every rank holds ONLY its rows (the whole matrix above is the checker's)
+        rl = (rp[lo:hi + 1] - rp[lo]).astype(np.int32)
+        cl, vl = ci[rp[lo]:rp[hi]].copy(), va[rp[lo]:rp[hi]].copy()
+        sx.options_reset()
+        for k, v in {"spx.rt.host_only": "true", "spx.preproc.sampling": "none",
+                     "spx.rt.nr_threads": "2", "spx.rt.row_offset": lo, "spx.rt.global_rows": n,
+                     "spx.matrix.symmetric": "true" if symmetric else "false"}.items():
+            sx.option_set(k, str(v))
+        A = sx.mat_tune(sx.input_load_csr(rl, cl, vl, hi - lo, n))
+        A.dist_attach(torch_transport(rank, world))
+        plan = A.dist_plan()
+        assert plan["rank"] == rank and plan["world"] == world
+        assert list(plan["row_lo"]) == cuts[:-1] and list(plan["row_hi"]) == cuts[1:]
+        # the conflict rows are exactly the columns in front of the slice that its
+        # lower triangle touches (the reference's map, CsxBuild.hpp:432-451)
+        if symmetric:
+            sl = a[lo:hi].tocoo()
+            want = np.unique(sl.col[sl.col < lo])
+        else:
+            want = np.zeros(0, dtype=np.int64)
+        assert np.array_equal(plan["send_rows"], want), (plan["send_rows"][:10], want[:10])
+        assert plan["any_exchange"] == (symmetric and world > 1)
+        # the local product, lane by lane from the saved stream (numpy decoder)
+        f = os.path.join(tmpdir, "r%d.spx" % rank)
+        A.save(f)
+        x = synth.random_x(n)
+        y = Stream(f).matvec(x)
+        # pack -> pairwise exchange -> add in the plan's fixed order
+        send = torch.from_numpy(y[plan["send_rows"]].copy())
+        recv = torch.empty(plan["n_recv"], dtype=torch.float64)
+        dist.all_to_all_single(recv, send, [int(v) for v in plan["recv_cnt"]],
+                               [int(v) for v in plan["send_cnt"]])
+        recv = recv.numpy()
+        for t, r in enumerate(plan["fix_rows"]):
+            y[r] += recv[plan["fix_pos"][plan["fix_ptr"][t]:plan["fix_ptr"][t + 1]]].sum()
+        want_y = (a @ x)[lo:hi]
+        ok = np.allclose(y[lo:hi], want_y, rtol=1e-12, atol=1e-14)
+        # bytes that travel: the conflict entries, not n doubles
+        ret[rank] = (bool(ok), int(plan["send_rows"].size), n)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("gen", ["nlpkkt", "nd24k"])
+@pytest.mark.parametrize("symmetric", [False, True])
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_slices_exchange_plan_gloo(tmp_path, world, symmetric, gen):
+    port = 29850 + (os.getpid() % 100) + 7 * world + (3 if symmetric else 0) + (40 if gen == "nd24k" else 0)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_slice_worker, args=(world, port, symmetric, gen, str(tmp_path), ret), nprocs=world, join=True)
+    assert all(ret[r][0] for r in range(world))
+    if symmetric:
+        # rank 0 sends nothing; the others send far less than an n-long all-reduce would move
+        assert ret[0][1] == 0 and all(0 < ret[r][1] < ret[r][2] // 2 for r in range(1, world))
