@@ -3,18 +3,28 @@
 
 A "step" is one y <- alpha*A*x (spx_matvec_mult semantics, alpha = 0.5 as in
 the reference's test/src/sparsex_test.c:70) through the C ABI's
-device-resident entry point, x and y resident in HBM.  Metric: GFLOP/s =
+device-resident entry points, x and y resident in HBM.  Metric: GFLOP/s =
 2*nnz/t (reference convention, src/bench/SparsexModule.cpp:80) plus the
 roofline object (algorithmic bytes per launch / average launch duration).
 
-N = 1: the workload is BASELINE.json configs[1] -- SuiteSparse `cant` -- via
-its deterministic synthetic stand-in `syn-cant` (no network for the file).
-N > 1: weak scaling -- the global matrix is the N-fold block-diagonal
-repetition of the workload, row-partitioned by nonzeros over the ranks exactly
-as the reference partitions threads; every rank holds the full x and writes
-its own rows of y.  The general path has no exchange step, so no collective is
-issued; with --symmetric every rank produces a partial y that is summed with
-an RCCL all-reduce (the reference's local-buffer reduction).
+Protocol (reference harness, src/bench/Bench.cpp:29-30 and
+src/bench/SparsexModule.cpp:65-79): after the warm-up, 5 batches of --steps
+SpMVs each; every batch is bracketed by a barrier + device synchronisation on
+both sides and timed on the host and with HIP events on the launch stream; the
+time of a batch is the maximum over the ranks; the MEDIAN batch is reported.
+
+Workload: ONE fixed global matrix -- `syn-nlpkkt`, the stand-in for SuiteSparse
+nlpkkt240 (BASELINE.json configs[4]) at a grid edge that fits one GPU and lies
+far beyond the 256 MB Infinity Cache -- row-partitioned by nonzeros over the
+--gpus ranks exactly as the reference partitions threads (strong scaling; at
+N = 1 the same matrix on one GPU).  Every rank generates and tunes only the rows
+it owns (spx.rt.row_offset / spx.rt.global_rows), holds the full x and completes
+its own rows of y: the general path needs nothing from the other ranks, the
+symmetric path (--symmetric) hands the sums it formed for rows in front of its
+own -- the reference's conflict map -- to their owners through RCCL
+point-to-point inside the library (spx_hip_matvec_dist).  At N = 1 the line also
+carries a "configs" object with the other BASELINE configurations (cant, nd24k on
+the symmetric path, webbase-1M; synthetic stand-ins) measured the same way.
 """
 import argparse
 import json
@@ -29,9 +39,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (guides/MI355X_MICROARCH.md)
+MALL_BYTES = 256 << 20  # Infinity Cache
 ALPHA = 0.5
-REF_BASELINE_THREADS = [8, 16, 32, 64, 128, 256]   # the counts cpu_baseline() may try
+BATCHES = 5             # OUTER_LOOPS of the reference harness
+REF_BASELINE_THREADS = [8, 16, 32, 64]   # the counts cpu_baseline() may try
+DEFAULT_EDGE = 120      # syn-nlpkkt grid edge: 3.5 M rows, 184 M nonzeros, 1.5 GB of values
+SAMPLE_EDGE = 60        # its CPU-baseline sample: the same generator at 1/8 of the nonzeros
 
+
+# ---- workloads -----------------------------------------------------------------------------
 
 def load_mtx(path):
     """A real Matrix Market file (e.g. SuiteSparse cant.mtx) as zero-based CSR;
@@ -49,6 +65,8 @@ def load_mtx(path):
 
 
 def make_workload(name, scale, copies=1, mtx=None):
+    """The whole matrix of a (small) workload as CSR.  (`copies`: block-diagonal
+    repetition, kept for the gpu_rank/gpu_world tests.)"""
     from sparsex_amd import synth
     rp, ci, va, n = load_mtx(mtx) if mtx else synth.WORKLOADS[name](scale)
     if copies > 1:
@@ -61,13 +79,62 @@ def make_workload(name, scale, copies=1, mtx=None):
     return rp, ci, va, n
 
 
-def tune(csr, opts):
+def nnz_balanced_cuts(counts, world):
+    """Row ranges of `world` ranks with (roughly) equal nonzero counts: rank i
+    takes rows until it holds (nnz - taken)/(world - i) of them, the rule of the
+    reference's thread partitioning (SparseInternal.hpp:131-144)."""
+    cum = np.concatenate([[0], np.cumsum(counts, dtype=np.int64)])
+    cuts, taken = [0], 0
+    for i in range(world - 1):
+        limit = (int(cum[-1]) - taken) // (world - i)
+        r = int(np.searchsorted(cum, taken + limit, side="left"))
+        r = min(max(r, cuts[-1]), counts.size)
+        cuts.append(r)
+        taken = int(cum[r])
+    return cuts + [int(counts.size)]
+
+
+class Workload:
+    """The rows [lo, hi) this rank owns of the global n x n matrix."""
+
+    def __init__(self, args, rank, world):
+        from sparsex_amd import synth
+        self.name = args.workload
+        if args.mtx or args.workload != "syn-nlpkkt":
+            rp, ci, va, n = make_workload(args.workload, args.scale, mtx=args.mtx)
+            counts = np.diff(rp)
+            cuts = nnz_balanced_cuts(counts, world)
+            lo, hi = cuts[rank], cuts[rank + 1]
+            self.rp = (rp[lo:hi + 1] - rp[lo]).astype(np.int32)
+            self.ci, self.va = ci[rp[lo]:rp[hi]], va[rp[lo]:rp[hi]]
+            self.label = (os.path.basename(args.mtx) if args.mtx else
+                          "%s (stand-in for SuiteSparse %s)" % (args.workload, args.workload.replace("syn-", "")))
+        else:
+            # every rank generates only its rows (tools/synth/nlpkkt_gen.c)
+            self.edge = args.edge
+            counts = synth.nlpkkt_row_counts(args.edge)
+            n = counts.size
+            cuts = nnz_balanced_cuts(counts, world)
+            lo, hi = cuts[rank], cuts[rank + 1]
+            self.rp, self.ci, self.va, _ = synth.syn_nlpkkt_rows(args.edge, lo, hi, counts=counts)
+            self.label = ("syn-nlpkkt, grid edge %d (stand-in for SuiteSparse nlpkkt240, which is edge 240: "
+                          "same KKT stencil structure, %.1f M rows)" % (args.edge, n / 1e6))
+        self.n, self.lo, self.hi, self.cuts = int(n), int(lo), int(hi), cuts
+        self.nnz = int(counts.sum(dtype=np.int64))
+        self.nnz_local = int(self.rp[-1])
+
+    def local_csr(self):
+        import scipy.sparse as sp
+        return sp.csr_matrix((self.va, self.ci, self.rp), shape=(self.hi - self.lo, self.n))
+
+
+def tune(csr, opts, nrows=None):
     import sparsex_amd as sx
     rp, ci, va, n = csr
     sx.options_reset()
     for k, v in opts.items():
         sx.option_set(k, str(v))
-    inp = sx.input_load_csr(rp, ci, va, n, n)
+    inp = sx.input_load_csr(rp, ci, va, n if nrows is None else nrows, n)
     A = sx.mat_tune(inp)
     A._input = inp
     return A
@@ -80,6 +147,8 @@ def host_cores():
         return os.cpu_count() or 1
 
 
+# ---- CPU baseline (the only place that touches oracle/) -----------------------------------
+
 def baseline_partitions(csr, threads, symmetric):
     """Tunes on the host only, with one partition per CPU thread, and exports
     the partitions in the reference's CSX format."""
@@ -90,53 +159,72 @@ def baseline_partitions(csr, threads, symmetric):
     return ex
 
 
-def prebuild_reference_baseline(name="syn-cant", scale=1.0):
-    """build(): instantiate the reference's templates for the bench workload at
-    the thread counts bench.py may pick on the GPU box."""
+def _ref_key(e):
+    return (tuple(i for i in e["id_map"] if i >= 0), bool(e["row_jumps"]), bool(e["full_colind"]))
+
+
+def baseline_workloads():
+    """(name, csr factory, symmetric) of every CPU baseline bench.py may time."""
+    from sparsex_amd import synth
+    return [("syn-nlpkkt", lambda: synth.syn_nlpkkt_rows(SAMPLE_EDGE), False),
+            ("syn-nlpkkt", lambda: synth.syn_nlpkkt_rows(SAMPLE_EDGE), True),
+            ("syn-cant", lambda: synth.syn_cant(1.0), False),
+            ("syn-nd24k", lambda: synth.syn_nd24k(1.0), True),
+            ("syn-nd24k", lambda: synth.syn_nd24k(1.0), False),
+            ("syn-webbase", lambda: synth.syn_webbase(1.0), False)]
+
+
+def prebuild_reference_baseline(only=None):
+    """build(): instantiate the reference's templates (oracle/_ref) for the pattern
+    sets the baselines meet at the thread counts bench.py may pick on the GPU box."""
     from oracle import build_ref
-    csr = make_workload(name, scale)
     done = set()
-    for t in REF_BASELINE_THREADS:
-        for e in baseline_partitions(csr, t, False):
-            key = (tuple(i for i in e["id_map"] if i >= 0), bool(e["row_jumps"]),
-                   bool(e["full_colind"]))
-            if key[0] and key not in done:
-                build_ref.build(key[0], False, key[1], key[2], opt="-O3")
-                done.add(key)
+    for name, gen, sym in baseline_workloads():
+        if only and name not in only:
+            continue
+        csr = gen()
+        for t in REF_BASELINE_THREADS:
+            for e in baseline_partitions(csr, t, sym):
+                key = _ref_key(e) + (sym,)
+                if key[0] and key not in done:
+                    build_ref.build(key[0], sym, key[1], key[2], opt="-O3")
+                    done.add(key)
     return len(done)
 
 
-def _time_baseline(ex, x, n, threads, symmetric, loops, batches=5):
+def _time_baseline(ex, csr, x, n, threads, symmetric, loops, batches=5):
     """One (thread count) point of the CPU baseline through oracle/cpu_baseline.c.
-    Returns (seconds per SpMV, kind)."""
+    Returns (seconds per SpMV, kind, the last product)."""
     import ctypes as C
     from oracle import pyoracle, build_ref
     L = pyoracle.lib()
+    vp = C.c_void_p
     L.oracle_time_threads.restype = C.c_double
-    L.oracle_time_threads.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_double,
-                                      C.c_int, C.c_int, C.c_void_p]
+    L.oracle_time_threads.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_long, C.c_double,
+                                      C.c_int, C.c_int, vp]
+    L.oracle_time_threads_sym.restype = C.c_double
+    L.oracle_time_threads_sym.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_long,
+                                          C.c_double, C.c_int, C.c_int, vp, vp, vp]
     y = np.zeros(n)
     cpus = (C.c_int * threads)(*sorted(os.sched_getaffinity(0))[:threads])
+    # the reference's own template code, one specialised routine per partition, where
+    # oracle/_ref holds a build for every partition's pattern set
     sos = []
-    if not symmetric:
-        for e in ex:
-            ids = [i for i in e["id_map"] if i >= 0]
-            so = build_ref.lookup(ids, False, bool(e["row_jumps"]), bool(e["full_colind"]),
-                                  opt="-O3") if ids else ""
-            if so is None:
-                sos = None
-                break
-            sos.append(so)
-    else:
-        sos = None
+    for e in ex:
+        ids = [i for i in e["id_map"] if i >= 0]
+        so = build_ref.lookup(ids, symmetric, bool(e["row_jumps"]), bool(e["full_colind"]),
+                              opt="-O3") if ids else ""
+        if so is None:
+            sos = None
+            break
+        sos.append(so)
+    keep = []
+    fns = spms = xin = yout = None
     if sos is not None:
-        # the reference's own template code, one specialised routine per partition
         xin = build_ref.RefVector(x.ctypes.data_as(C.POINTER(C.c_double)), n, 1, 45)
         yout = build_ref.RefVector(y.ctypes.data_as(C.POINTER(C.c_double)), n, 1, 45)
-        fns = (C.c_void_p * threads)()
-        spms = (C.c_void_p * threads)()
-        keep = []
+        fns = (vp * threads)()
+        spms = (vp * threads)()
         for i, (e, so) in enumerate(zip(ex, sos)):
             if not so:
                 continue
@@ -151,34 +239,61 @@ def _time_baseline(ex, x, n, threads, symmetric, loops, batches=5):
                 m.id_map[k] = e["id_map"][k]
             lib = C.CDLL(so)
             keep += [vals, ctl, m, lib]
-            fns[i] = C.cast(lib.spm_csx_multiply, C.c_void_p)
-            spms[i] = C.cast(C.pointer(m), C.c_void_p)
-        t = L.oracle_time_threads(threads, None, fns, spms, C.byref(xin), C.byref(yout),
-                                  x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p),
-                                  n, ALPHA, loops, batches, cpus)
-        return t, "reference"
-    if symmetric:
-        P = pyoracle.Partitions(ex, True)
-        t0 = time.perf_counter()
-        for _ in range(max(loops // 4, 1)):
-            pyoracle.csx_matvec(P, x, n, ALPHA, nthreads=threads)
-        return (time.perf_counter() - t0) / max(loops // 4, 1), "port"
-    P = pyoracle.Partitions(ex, False)
-    t = L.oracle_time_threads(threads, P.arr, None, None, None, None,
-                              x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p),
-                              n, ALPHA, loops, batches, cpus)
-    return t, "port"
+            if symmetric:
+                dv = np.ascontiguousarray(e["dvalues"])
+                sm = build_ref.RefCsxSymMatrix(C.pointer(m), dv.ctypes.data_as(C.POINTER(C.c_double)))
+                keep += [dv, sm]
+                fns[i] = C.cast(lib.spm_csx_sym_multiply, vp)
+                spms[i] = C.cast(C.pointer(sm), vp)
+            else:
+                fns[i] = C.cast(lib.spm_csx_multiply, vp)
+                spms[i] = C.cast(C.pointer(m), vp)
+    P = None if sos is not None else pyoracle.Partitions(ex, symmetric)
+    kind = "reference" if sos is not None else "port"
+    xp, yp = x.ctypes.data_as(vp), y.ctypes.data_as(vp)
+    if not symmetric:
+        t = L.oracle_time_threads(threads, P.arr if P else None, fns, spms,
+                                  C.byref(xin) if xin else None, C.byref(yout) if yout else None,
+                                  xp, yp, n, ALPHA, loops, batches, cpus)
+        return t, kind, y
+    # symmetric: local buffers + the conflict map (MatVecMult_sym); per partition the
+    # columns in front of its first row that its lower triangle touches
+    rp, ci, _, _ = csr
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(rp))
+    conf, ptr = [], [0]
+    for e in ex:
+        r0, r1 = e["row_start"], e["row_start"] + e["nrows"]
+        cols = ci[rp[r0]:rp[min(r1, n)]]
+        cols = np.unique(cols[cols < r0]).astype(np.int32)
+        conf.append(cols)
+        ptr.append(ptr[-1] + cols.size)
+    del rows
+    conf_cols = np.ascontiguousarray(np.concatenate(conf) if conf else np.zeros(0, dtype=np.int32))
+    conf_ptr = np.ascontiguousarray(np.array(ptr, dtype=np.int64))
+    bufs = [y] + [np.zeros(n) for _ in range(threads - 1)]
+    locals_ = (vp * threads)(*[b.ctypes.data_as(vp) for b in bufs])
+    ref_locals = (vp * threads)()
+    for i, b in enumerate(bufs):
+        v = build_ref.RefVector(b.ctypes.data_as(C.POINTER(C.c_double)), n, 1, 45)
+        keep.append(v)
+        ref_locals[i] = C.cast(C.pointer(v), vp)
+    t = L.oracle_time_threads_sym(threads, P.arr if P else None, fns, spms,
+                                  C.byref(xin) if xin else None, C.byref(yout) if yout else None,
+                                  ref_locals, locals_, xp, yp, n, ALPHA, loops, batches, cpus,
+                                  conf_ptr.ctypes.data_as(vp), conf_cols.ctypes.data_as(vp))
+    return t, kind, y
 
 
-def cpu_baseline(csr, symmetric, budget_s=20.0):
+def cpu_baseline(csr, symmetric, budget_s=20.0, sample=""):
     """The reference's CPU CSX path timed on this box's host cores.
 
-    One partition per thread, persistent pinned threads and a spin barrier per
-    SpMV as in the reference (oracle/cpu_baseline.c).  The per-partition
+    One partition per thread, persistent pinned threads and spin barriers around
+    every SpMV as in the reference (oracle/cpu_baseline.c; symmetric: local
+    buffers and the conflict-map reduction of MatVecMult_sym).  The per-partition
     routine is the reference's own template code when oracle/_ref holds a build
     for the partition's pattern set (kind "reference"), else the C port of
-    oracle/csx_oracle.c (kind "port").  Several thread counts are tried and
-    the fastest is reported together with the count used.
+    oracle/csx_oracle.c (kind "port").  Several thread counts are tried within
+    the time budget and the fastest is reported together with the count used.
     """
     from sparsex_amd import synth
     rp, ci, va, n = csr
@@ -186,29 +301,33 @@ def cpu_baseline(csr, symmetric, budget_s=20.0):
     nnz = int(rp[-1])
     x = synth.random_x(n)
     cands = [t for t in REF_BASELINE_THREADS if t <= cores] or [cores]
-    cands = cands[-5:]
     best = None
-    share = budget_s / max(len(cands), 1)
     tried = {}
-    for t in cands:
+    t_start = time.perf_counter()
+    share = budget_s / max(len(cands), 1)
+    for t in cands[::-1] if cores >= 64 else cands:
+        # (many-core hosts: start at the larger counts, where the best has been)
+        if tried and time.perf_counter() - t_start > budget_s:
+            break
         ex = baseline_partitions(csr, t, symmetric)
-        sec, kind = _time_baseline(ex, x, n, t, symmetric, loops=4, batches=1)
-        loops = int(min(max(share / max(sec, 1e-6) / 5, 4), 256))
-        sec, kind = _time_baseline(ex, x, n, t, symmetric, loops=loops, batches=5)
+        sec, kind, _ = _time_baseline(ex, csr, x, n, t, symmetric, loops=2, batches=1)
+        loops = int(min(max(0.5 * share / max(sec, 1e-6) / 5, 2), 256))
+        sec, kind, _ = _time_baseline(ex, csr, x, n, t, symmetric, loops=loops, batches=5)
         tried[t] = round(2.0 * nnz / sec / 1e9, 3)
         if best is None or sec < best[0]:
             best = (sec, kind, t, loops)
         elif sec > 2.0 * best[0]:
-            # well past the knee (spinning threads sharing cores, or a CPU quota
-            # below the core count): larger counts only burn the time budget
-            break
+            break       # well past the knee: further counts only burn the time budget
     sec, kind, t, loops = best
     return {"value": round(2.0 * nnz / sec / 1e9, 3), "unit": "GFLOP/s", "cores": t,
             "kind": kind,
-            "sample": "median of 5 batches x %d SpMVs (alpha=0.5) of the same matrix, one "
-                      "partition per pinned thread; thread counts tried (GFLOP/s): %s; "
-                      "host has %d cores" % (loops, json.dumps(tried), cores)}
+            "sample": "%smedian of 5 batches x %d SpMVs (alpha=0.5), one partition per pinned thread, "
+                      "%s; thread counts tried (GFLOP/s): %s; host has %d cores" % (
+                          sample, loops, "local buffers + conflict-map reduction" if symmetric
+                          else "spin barriers", json.dumps(tried), cores)}
 
+
+# ---- measurement helpers ------------------------------------------------------------------
 
 def measured_read_peak(sx, torch, elems=1 << 27, reps=10):
     """Practical HBM read roof on this box: the library's own dot-product kernel
@@ -229,11 +348,11 @@ def measured_read_peak(sx, torch, elems=1 << 27, reps=10):
     return 2.0 * 8.0 * elems / sec / 1e9
 
 
-def host_api_rate(A, xh, n, nnz, calls=50):
+def host_api_rate(A, xh, n, nnz, calls=20):
     """API-visible rate of the unchanged reference entry point: spx_matvec_mult on
     HOST vectors (x up, kernel, y down, synchronous) -- PCIe inclusive."""
     yh = np.zeros(n)
-    for _ in range(5):
+    for _ in range(3):
         A.matvec_mult(ALPHA, xh, yh)
     t0 = time.perf_counter()
     for _ in range(calls):
@@ -243,35 +362,155 @@ def host_api_rate(A, xh, n, nnz, calls=50):
             "us_per_call": round(sec * 1e6, 1), "gflops": round(2.0 * nnz / sec / 1e9, 1)}
 
 
-def measured_traffic(workload):
-    """HBM bytes per launch from the committed PMC passes (profiles/traffic.json,
-    produced by tools/profile.sh: FETCH_SIZE and WRITE_SIZE in separate
-    rocprofv3 --pmc runs, FETCH_SIZE doubled per the gfx950 note of the
-    microarchitecture guide); None when this workload was not profiled."""
+def measured_traffic(key):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/traffic.json, produced by tools/profile.sh + tools/collect_profiles.py:
+    FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs of this very
+    command, FETCH_SIZE doubled per the gfx950 note of the microarchitecture
+    guide); None when this configuration was not profiled."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return json.load(f)[workload]["hbm_bytes_per_launch"]
+            return json.load(f)[key]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         return None
+
+
+def kernel_name(info, symmetric, world):
+    w = int(info.waves)
+    if symmetric and world == 1:
+        return "csx_spmv_symtile_kernel<%d> (+ csx_symfix_kernel)" % w if info.sym_tiles else \
+            "csx_spmv_kernel<%d> (symmetric stream: lower triangle + mirror image)" % w
+    if symmetric:
+        return "csx_sym_init_kernel + csx_spmv_%skernel<%d> (+ pack / unpack of the exchange)" % (
+            "symtile_" if info.sym_tiles else "", w)
+    return "csx_spmv_kernel<%d>" % w
+
+
+def parity_gate(torch, y, a_local, xh, lo, hi, ablation):
+    """This rank's rows against the CSR product (the reference's own criterion)."""
+    yc = ALPHA * (a_local @ xh)
+    yg = y[lo:hi].cpu().numpy()
+    rel = np.abs(yg - yc) / np.maximum(np.abs(yc), 1e-300)
+    # the stated fp64 tolerance (SURVEY.md section 8d): summation-order independent
+    bound = 64.0 * 2.0 ** -53 * abs(ALPHA) * (abs(a_local) @ np.abs(xh))
+    bound_ratio = float(np.max(np.abs(yg - yc) / np.maximum(bound, 1e-300))) if yc.size else 0.0
+    assert ablation or np.all((rel <= 1e-6) | (np.abs(yg - yc) < 1e-18)), "parity gate failed before timing"
+    assert ablation or bound_ratio <= 1.0, "fp64 bound exceeded before timing"
+    return {"max_rel_err_vs_csr": float(rel[np.abs(yg - yc) >= 1e-18].max(initial=0.0)),
+            "max_err_over_fp64_bound": round(bound_ratio, 4),
+            "criterion": "rel <= 1e-6 (reference Vector.cpp:51-57) and |err| <= 64*2^-53*sum|a||x|"}
+
+
+def time_batches(torch, step, steps, barrier, reduce_max, use_graph):
+    """BATCHES batches of `steps` steps -> (median wall seconds per batch over the
+    ranks' maxima, median HIP-event seconds per batch, graph used, all wall times)."""
+    graph = None
+    if use_graph:
+        # the library only enqueues kernels on the stream it is handed, so a
+        # whole solver loop can be captured; here: the K SpMVs of a batch
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                cap = torch.cuda.current_stream().cuda_stream
+                for _ in range(steps):
+                    step(cap)
+            graph.replay()                  # instantiate + upload outside the timed region
+        except Exception as e:              # no capture on this stack: plain launches
+            print("hipGraph capture failed (%s); timing stream launches" % e, file=sys.stderr)
+            graph = None
+    stream = torch.cuda.current_stream().cuda_stream
+    walls, devs = [], []
+    for _ in range(BATCHES):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        t0 = time.perf_counter()
+        ev0.record()
+        if graph is not None:
+            graph.replay()
+        else:
+            for _ in range(steps):
+                step(stream)
+        ev1.record()
+        barrier()
+        walls.append(reduce_max(time.perf_counter() - t0))
+        devs.append(1e-3 * ev0.elapsed_time(ev1))       # HIP events on the launch stream
+    return float(np.median(walls)), float(np.median(devs)), graph is not None, walls
+
+
+def algorithmic_bytes(symmetric, nnz_local_full, rows_local, n, lower_local=None):
+    """every stored value once, x once, the owned rows of
+    y once; symmetric storage holds the strictly lower values and the diagonal."""
+    if symmetric:
+        return 8.0 * (lower_local + rows_local) + 8.0 * n + 8.0 * rows_local
+    return 8.0 * nnz_local_full + 8.0 * n + 8.0 * rows_local
+
+
+def run_config(torch, sx, name, symmetric, steps, warmup, cpu_budget, T):
+    """One of the small BASELINE configurations on this GPU, measured like the main line."""
+    from sparsex_amd import synth
+    import scipy.sparse as sp
+    csr = make_workload(name, 1.0)
+    rp, ci, va, n = csr
+    nnz = int(rp[-1])
+    A = tune(csr, {"spx.rt.nr_threads": T, "spx.rt.device": torch.cuda.current_device(),
+                   "spx.matrix.symmetric": "true" if symmetric else "false",
+                   "spx.rt.keep_encoded": "false"})
+    info = A.info()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    xh = synth.random_x(n)
+    x = torch.from_numpy(xh).to(dev)
+    y = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
+
+    def step(stream):
+        A.hip_matvec_mult(ALPHA, x.data_ptr(), y.data_ptr(), stream)
+    step(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    a = sp.csr_matrix((va, ci, rp), shape=(n, n))
+    parity = parity_gate(torch, y, a, xh, 0, n, os.environ.get("SPX_BENCH_ABLATION") == "1")
+    for _ in range(warmup):
+        step(torch.cuda.current_stream().cuda_stream)
+    wall, devs, graphed, _ = time_batches(torch, step, steps, torch.cuda.synchronize, lambda v: v, True)
+    lower = synth.lower_plus_diag_nnz(rp, ci) - n if symmetric else None
+    b_alg = algorithmic_bytes(symmetric, nnz, n, n, lower)
+    launch_s = devs / steps
+    out = {"gflops": round(2.0 * nnz * steps / wall / 1e9, 2), "us_per_spmv": round(1e6 * wall / steps, 3),
+           "nnz": nnz, "nrows": n, "symmetric_path": symmetric,
+           "roofline": {"bound": "hbm", "achieved": round(b_alg / launch_s / 1e9, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(b_alg / launch_s / 1e9 / HBM_PEAK_GBS, 4),
+                        "kernel": kernel_name(info, symmetric, 1), "avg_launch_us": round(1e6 * launch_s, 3),
+                        "algorithmic_bytes_per_launch": int(b_alg),
+                        "traffic": measured_traffic(name + ("-sym" if symmetric else ""))},
+           "cache_resident": bool(info.value_bytes + info.index_bytes < MALL_BYTES),
+           "index_bytes_per_nnz": round(info.index_bytes / max(int(info.nnz_stored), 1), 3),
+           "tune_seconds": round(info.tune_seconds, 3), "emit_upload_seconds": round(info.emit_seconds, 3),
+           "parity": parity}
+    if cpu_budget > 0:
+        out["cpu_baseline"] = cpu_baseline(csr, symmetric, cpu_budget)
+    A.destroy()
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1280)
-    ap.add_argument("--warmup", type=int, default=128)
-    ap.add_argument("--workload", default="syn-cant", choices=["syn-cant", "syn-nd24k", "syn-webbase", "syn-nlpkkt"],
-                    help="syn-nlpkkt: --scale 1 is nlpkkt240 (760 M nonzeros); use e.g. --scale 0.0156 (N = 60) on one GPU")
-    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--steps", type=int, default=128, help="SpMVs per batch (LOOPS); %d batches are timed" % BATCHES)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--workload", default="syn-nlpkkt", choices=["syn-cant", "syn-nd24k", "syn-webbase", "syn-nlpkkt"])
+    ap.add_argument("--edge", type=int, default=DEFAULT_EDGE,
+                    help="syn-nlpkkt: grid edge (240 = the order of nlpkkt240; the default %d gives 184 M "
+                         "nonzeros, 1.5 GB of values)" % DEFAULT_EDGE)
+    ap.add_argument("--scale", type=float, default=1.0, help="size factor of the other synthetic workloads")
     ap.add_argument("--mtx", default=None,
                     help="Matrix Market file to use instead of the synthetic stand-in")
     ap.add_argument("--symmetric", action="store_true")
     ap.add_argument("--host-threads", type=int, default=0,
-                    help="host preprocessing partitions per GPU (default: min(cores, 8))")
+                    help="host preprocessing partitions per GPU (default: min(cores / ranks, 32))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="N = 1: skip the other BASELINE configurations (cant, nd24k symmetric, webbase)")
     ap.add_argument("--no-graph", dest="graph", action="store_false",
-                    help="launch the K timed steps one by one instead of replaying them as one hipGraph "
-                         "(stream capture; the default wherever a step is kernels only)")
+                    help="launch the steps of a batch one by one instead of replaying them as one hipGraph "
+                         "(stream capture; the default on one GPU, where a step is kernels only)")
     ap.add_argument("--opt", action="append", default=[], help="extra option=value")
     args = ap.parse_args()
 
@@ -284,7 +523,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # SPX_BENCH_BACKEND=gloo lets the multi-rank path be exercised on a box with
-    # fewer GPUs than ranks (ranks then share devices); the default is RCCL
+    # fewer GPUs than ranks (ranks then share devices and the exchange is staged
+    # through the host); the default is RCCL
     backend = os.environ.get("SPX_BENCH_BACKEND", "nccl")
     if args.gpus > 1 or world > 1:
         assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
@@ -298,163 +538,203 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
 
-    def all_reduce(t, op=dist.ReduceOp.SUM):
-        if backend == "nccl":
-            dist.all_reduce(t, op=op)
-        else:                               # test-only path: gloo reduces on the host
-            h = t.cpu()
-            dist.all_reduce(h, op=op)
-            t.copy_(h)
-
-    csr = make_workload(args.workload, args.scale, copies=world, mtx=args.mtx)
-    rp, ci, va, n = csr
-    nnz = int(rp[-1])
-    T = args.host_threads or min(host_cores() // max(world, 1), 8) or 1
-    opts = {"spx.rt.nr_threads": T * world, "spx.rt.gpu_rank": rank, "spx.rt.gpu_world": world,
-            "spx.rt.device": torch.cuda.current_device(),
-            "spx.matrix.symmetric": "true" if args.symmetric else "false",
-            "spx.rt.keep_encoded": "false"}
-    for o in args.opt:
-        k, v = o.split("=", 1)
-        opts[k] = v
-    A = tune(csr, opts)
-    info = A.info()
-
-    x = torch.from_numpy(synth.random_x(n)).to(dev)
-    y = torch.zeros(n, dtype=torch.float64, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def step():
-        A.hip_matvec_mult(ALPHA, x.data_ptr(), y.data_ptr(), stream)
-        if args.symmetric and world > 1:
-            all_reduce(y)
+    def reduce_max(v):
+        if world == 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    t_gen = time.perf_counter()
+    wl = Workload(args, rank, world)
+    t_gen = time.perf_counter() - t_gen
+    n, lo, hi = wl.n, wl.lo, wl.hi
+    T = args.host_threads or max(1, min(host_cores() // max(world, 1), 32))
+    opts = {"spx.rt.nr_threads": T, "spx.rt.device": torch.cuda.current_device(),
+            "spx.matrix.symmetric": "true" if args.symmetric else "false",
+            "spx.rt.keep_encoded": "false"}
+    if world > 1:
+        opts.update({"spx.rt.row_offset": lo, "spx.rt.global_rows": n})
+    for o in args.opt:
+        k, v = o.split("=", 1)
+        opts[k] = v
+    A = tune((wl.rp, wl.ci, wl.va, n), opts, nrows=hi - lo)
+    info = A.info()
+    assert (info.row_lo, info.row_hi) == (lo, hi)
+
+    # several ranks: the exchange that completes y lives in the library (RCCL
+    # point-to-point over xGMI); torch.distributed only carries the 128-byte id
+    transport_name = "none"
+    if world > 1:
+        if backend == "nccl":
+            ids = [sx.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            transport = sx.RcclTransport(ids[0], rank, world)
+            transport_name = "RCCL point-to-point inside libsparsex (spx_hip_transport_rccl)"
+        else:
+            from sparsex_amd.dist_torch import torch_transport
+            transport = torch_transport(rank, world)
+            transport_name = "torch.distributed/%s staged through the host (test path)" % backend
+        A.dist_attach(transport)
+        plan = A.dist_plan()
+
+    xh = synth.random_x(n)
+    x = torch.from_numpy(xh).to(dev)
+    y = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
+
+    def step(stream, flags=sx.SPX_DIST_OWNED_ROWS):
+        if world > 1:
+            A.hip_matvec_dist(ALPHA, x.data_ptr(), 0.0, y.data_ptr(), flags, stream)
+        else:
+            A.hip_matvec_mult(ALPHA, x.data_ptr(), y.data_ptr(), stream)
+
+    def step_local(stream):                  # the kernels alone, no exchange
+        A.hip_matvec_mult(ALPHA, x.data_ptr(), y.data_ptr(), stream)
+
     # correctness gate before timing: this rank's rows against the CSR product
-    step()
-    torch.cuda.synchronize()
-    import scipy.sparse as sp
-    lo, hi = (0, n) if (args.symmetric and world > 1) else (info.row_lo, info.row_hi)
-    a_csr = sp.csr_matrix((va, ci, rp), shape=(n, n))[lo:hi]
-    xh = x.cpu().numpy()
-    yc = ALPHA * (a_csr @ xh)
-    yg = y.cpu().numpy()[lo:hi]
-    rel = np.abs(yg - yc) / np.maximum(np.abs(yc), 1e-300)
-    # the stated fp64 tolerance: summation-order independent
-    bound = 64.0 * 2.0 ** -53 * abs(ALPHA) * (abs(a_csr) @ np.abs(xh))
-    bound_ratio = float(np.max(np.abs(yg - yc) / np.maximum(bound, 1e-300))) if yc.size else 0.0
     # (kernel ablations built by tools/build_variant.sh compute wrong results on
     # purpose; their lines are marked and never a bench result)
     ablation = os.environ.get("SPX_BENCH_ABLATION") == "1"
-    assert ablation or np.all((rel <= 1e-6) | (np.abs(yg - yc) < 1e-18)), "parity gate failed before timing"
-    assert ablation or bound_ratio <= 1.0, "fp64 bound exceeded before timing"
-    parity = {"max_rel_err_vs_csr": float(rel[np.abs(yg - yc) >= 1e-18].max(initial=0.0)),
-              "max_err_over_fp64_bound": round(bound_ratio, 4),
-              "criterion": "rel <= 1e-6 (reference Vector.cpp:51-57) and |err| <= 64*2^-53*sum|a||x|"}
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    graph = None
-    if args.graph and not (args.symmetric and world > 1):
-        # the library only enqueues kernels on the stream it is handed, so a
-        # whole solver loop can be captured; here: the K timed SpMVs
-        try:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                cap = torch.cuda.current_stream().cuda_stream
-                for _ in range(args.steps):
-                    A.hip_matvec_mult(ALPHA, x.data_ptr(), y.data_ptr(), cap)
-            graph.replay()                  # instantiate + upload outside the timed region
-        except Exception as e:              # no capture on this stack: plain launches
-            print("hipGraph capture failed (%s); timing stream launches" % e, file=sys.stderr)
-            graph = None
-        barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    if graph is not None:
-        graph.replay()
-    else:
-        for _ in range(args.steps):
-            step()
-    ev1.record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)          # HIP events on the launch stream
-
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    step(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    a_local = wl.local_csr()
+    parity = parity_gate(torch, y, a_local, xh, lo, hi, ablation)
     if world > 1:
-        all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+        # ... and, with the slices handed round, all of y on every rank
+        step(torch.cuda.current_stream().cuda_stream, sx.SPX_DIST_GATHER_Y)
+        torch.cuda.synchronize()
+        chk = torch.tensor([float(torch.nan_to_num(y, nan=1e300).abs().sum())], dtype=torch.float64,
+                           device=dev if backend == "nccl" else "cpu")
+        sums = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(sums, chk)
+        assert all(abs(float(s) - float(sums[0])) <= 1e-9 * abs(float(sums[0])) for s in sums), \
+            "gathered y differs between the ranks"
+        parity_gate(torch, y, a_local, xh, lo, hi, ablation)
+    lower_local = None
+    if args.symmetric:
+        rows = np.repeat(np.arange(lo, hi, dtype=np.int64), np.diff(wl.rp))
+        lower_local = int((wl.ci < rows).sum())
+        del rows
+    del a_local
+
+    cur = torch.cuda.current_stream().cuda_stream
+    for _ in range(args.warmup):
+        step(cur)
+    barrier()
+    use_graph = args.graph and world == 1
+    wall, devs, graphed, walls = time_batches(torch, step, args.steps, barrier, reduce_max, use_graph)
+    extra = {}
+    if world > 1:
+        w2, _, _, _ = time_batches(torch, step_local, args.steps, barrier, reduce_max, False)
+        w3, _, _, _ = time_batches(torch, lambda s: step(s, sx.SPX_DIST_GATHER_Y), args.steps, barrier,
+                                   reduce_max, False)
+        extra = {"kernels_only_gflops": round(2.0 * wl.nnz * args.steps / w2 / 1e9, 2),
+                 "with_y_allgather_gflops": round(2.0 * wl.nnz * args.steps / w3 / 1e9, 2)}
+
+    # per-rank facts the line reports for every rank
+    mine = {"rank": rank, "rows": [lo, hi], "nnz": wl.nnz_local, "rowblocks": int(info.n_rowblocks),
+            "tune_seconds": round(info.tune_seconds, 2), "emit_upload_seconds": round(info.emit_seconds, 2),
+            "avg_launch_us": round(1e6 * devs / args.steps, 2),
+            "conflict_rows_sent": int(plan["send_rows"].size) if world > 1 else 0,
+            "conflict_entries_received": int(plan["n_recv"]) if world > 1 else 0}
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
-        gflops = 2.0 * nnz * args.steps / elapsed / 1e9
-        # algorithmic bytes of one launch on this GPU: every stored value once,
-        # x once, the owned rows of y once
-        nnz_local = int(info.nnz_stored)
-        rows_local = info.row_hi - info.row_lo
-        if args.symmetric:
-            # symmetric storage: strictly lower values + diagonal, once each
-            # (the GPU stream mirrors the lower triangle, which is overhead)
-            # (one process: from the matrix itself -- the stream may hold tiles once
-            # and the rest twice; several processes: half of the mirrored stream)
-            nnz_alg = (nnz - n) // 2 + n if world == 1 else nnz_local // 2 + rows_local
-            b_alg = 8.0 * nnz_alg + 8.0 * n + 8.0 * (n if world > 1 else rows_local)
-        else:
-            b_alg = 8.0 * nnz_local + 8.0 * n + 8.0 * rows_local
-        launch_s = 1e-3 * dev_ms / args.steps
+        ms_per_step = 1e3 * wall / args.steps
+        gflops = 2.0 * wl.nnz * args.steps / wall / 1e9
+        rows_local = hi - lo
+        b_alg = algorithmic_bytes(args.symmetric, wl.nnz_local, rows_local, n, lower_local)
+        launch_s = devs / args.steps
         achieved = b_alg / launch_s / 1e9
+        tkey = "%s%s%s" % (args.workload, "-e%d" % args.edge if args.workload == "syn-nlpkkt" else "",
+                           "-sym" if args.symmetric else "")
+        std = world == 1 and args.scale == 1.0 and not args.opt and not args.mtx
+        if not args.symmetric:
+            par = "rows partitioned by nonzeros over %d rank%s; x replicated; no collective: every rank " \
+                  "completes its own rows of y" % (world, "s" if world > 1 else "")
+        else:
+            par = "rows partitioned by nonzeros over %d rank%s; x replicated; symmetric storage: each rank " \
+                  "sends the sums for its conflict rows (rows in front of its own that its lower triangle " \
+                  "touches) to their owners, packed, pairwise (no n-long all-reduce)" % (
+                      world, "s" if world > 1 else "")
         out = {
             "metric": "SpMV GFLOP/s (2*nnz/t, alpha=0.5, x/y resident in HBM)",
             "value": round(gflops, 3), "unit": "GFLOP/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 6), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "file" if args.mtx else "synthetic",
-            "config": {"workload": (os.path.basename(args.mtx) if args.mtx else
-                                    "%s (stand-in for SuiteSparse %s)" % (
-                                        args.workload, args.workload.replace("syn-", ""))) +
-                                   (" x%d block-diagonal" % world if world > 1 else ""),
-                       "nrows": n, "nnz": nnz, "symmetric_path": bool(args.symmetric),
-                       "partitions_per_gpu": T,
-                       "launch": "one hipGraph of %d captured launches" % args.steps if graph is not None
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "file" if args.mtx else "synthetic",
+            "protocol": {"batches": BATCHES, "steps_per_batch": args.steps, "reported": "median batch "
+                         "(max over ranks per batch)", "batch_ms": [round(1e3 * w, 4) for w in walls],
+                         "reference": "src/bench/Bench.cpp:29-30, SparsexModule.cpp:65-79"},
+            "config": {"workload": wl.label, "nrows": n, "nnz": wl.nnz,
+                       "symmetric_path": bool(args.symmetric), "partitions_per_gpu": T,
+                       "launch": "one hipGraph of %d captured launches per batch" % args.steps if graphed
                                  else "stream launches",
-                       "parallelism": "row-partitioned x%d, %s" % (
-                           world, "RCCL all-reduce of y" if args.symmetric and world > 1
-                           else "no collective")},
+                       "parallelism": par, "transport": transport_name,
+                       "collective_in_value": ("included: pack, pairwise exchange and ordered add complete the "
+                                               "owned rows inside every step" if args.symmetric and world > 1
+                                               else "none needed"),
+                       "generate_seconds": round(t_gen, 2)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": (measured_traffic(args.workload)
-                                     if world == 1 and not args.symmetric and args.scale == 1.0
-                                     and not args.opt and not args.mtx else None),
-                         "kernel": "csx_spmv_kernel",
+                         "traffic": measured_traffic(tkey) if std else None,
+                         "kernel": kernel_name(info, args.symmetric, world),
                          "algorithmic_bytes_per_launch": int(b_alg),
-                         "avg_launch_us": round(1e6 * launch_s, 3)},
-            "format": {"nnz_stored": nnz_local, "unit_elems": int(info.n_unit_elems),
+                         "avg_launch_us": round(1e6 * launch_s, 3),
+                         "cache_resident": bool(info.value_bytes + info.index_bytes < MALL_BYTES),
+                         "scope": "rank 0's GPU: its stored values, x and its rows of y once per launch"},
+            "format": {"nnz_stored": int(info.nnz_stored), "unit_elems": int(info.n_unit_elems),
                        "delta_elems": int(info.n_delta_elems), "units": int(info.n_units),
                        "rowblocks": int(info.n_rowblocks), "waves_per_workgroup": int(info.waves),
-                       "index_bytes_per_nnz": round(info.index_bytes / max(nnz_local, 1), 3),
+                       "index_bytes_per_nnz": round(info.index_bytes / max(int(info.nnz_stored), 1), 3),
+                       "index_bytes": int(info.index_bytes), "value_bytes": int(info.value_bytes),
+                       "csr_equivalent_bytes": int(12 * wl.nnz_local + 4 * (rows_local + 1) + 8 * n + 8 * rows_local),
                        "tune_seconds": round(info.tune_seconds, 3),
                        "emit_upload_seconds": round(info.emit_seconds, 3)},
+            "ranks": per_rank,
+            "parity": parity,
         }
-        out["parity"] = parity
-        nrows_local = info.row_hi - info.row_lo
-        out["format"]["index_bytes"] = int(info.index_bytes)
-        out["format"]["csr_equivalent_bytes"] = int(12 * nnz_local + 4 * (nrows_local + 1) + 8 * n + 8 * nrows_local)
+        if extra:
+            out["collective"] = extra
         if world == 1 and not args.symmetric:
             peak = measured_read_peak(sx, torch)
             out["roofline"]["measured_stream_read_peak"] = round(peak, 1)
             out["roofline"]["frac_of_measured_read_peak"] = round(achieved / peak, 4)
-            out["host_api"] = host_api_rate(A, xh, n, nnz)
+        if world == 1:
+            out["host_api"] = host_api_rate(A, xh, n, wl.nnz)
         if ablation:
             out["INVALID_ablation_build"] = os.environ.get("SPX_LIB_PATH", "")
+    A.destroy()
+    del x, y
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(csr, args.symmetric)
+            if args.workload == "syn-nlpkkt" and not args.mtx and args.edge > SAMPLE_EDGE:
+                csr_s = synth.syn_nlpkkt_rows(SAMPLE_EDGE)
+                note = "sample: syn-nlpkkt at grid edge %d (%.1f M nonzeros; the bench matrix's generator at " \
+                       "1/%d of its nonzeros); " % (SAMPLE_EDGE, csr_s[0][-1] / 1e6,
+                                                    round(wl.nnz / max(int(csr_s[0][-1]), 1)))
+            else:
+                csr_s = (wl.rp, wl.ci, wl.va, n)
+                note = "sample: the whole bench matrix; "
+            out["cpu_baseline"] = cpu_baseline(csr_s, args.symmetric, 20.0, note)
+            del csr_s
+        if world == 1 and not args.no_configs and args.workload == "syn-nlpkkt" and not args.mtx:
+            del wl
+            cfgs = {}
+            for name, sym in (("syn-cant", False), ("syn-nd24k", True), ("syn-webbase", False)):
+                cfgs[name + (" --symmetric" if sym else "")] = run_config(
+                    torch, sx, name, sym, max(args.steps, 256), max(args.warmup, 32),
+                    0.0 if args.no_cpu_baseline else 8.0, T)
+            out["configs"] = cfgs
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -204,7 +204,8 @@ typedef struct {
     int32_t on_device;       /* 0 for host-only matrices                        */
     int32_t device;
     int32_t waves;           /* wavefronts per workgroup of the SpMV kernel      */
-    int32_t pad_;
+    int32_t sym_tiles;       /* symmetric path: the stream holds dense 8x8 tiles
+                                that are read once (SPX_PASS_SYMTILE)            */
     double  tune_seconds;    /* preprocessing (mining + encoding)               */
     double  emit_seconds;    /* descriptor stream + upload                      */
 } spx_hip_info_t;

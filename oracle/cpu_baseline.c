@@ -10,6 +10,15 @@
  * zeroes y first, CsxKernels.cpp:93).  The per-partition multiply routine is
  * either the reference's own template code (a function pointer obtained from
  * an oracle/_ref build, kind "reference") or oracle_csx_multiply (kind "port").
+ *
+ * Symmetric matrices (oracle_time_threads_sym) follow MatVecMult_sym /
+ * do_mv_sym_thread (src/internals/CsxKernels.cpp:105-129,
+ * src/internals/CsxSpmv.cpp:37-50): every thread but the first multiplies into
+ * a full-length local buffer for the rows in front of its own, and a conflict
+ * map -- split over the threads by column ranges of equal entry count, as
+ * MakeMap does (include/sparsex/internals/CsxBuild.hpp:400-581) -- says which
+ * entries are zeroed before and summed into y after the multiply
+ * (src/internals/Vector.cpp:213-221, 291-299): four barrier crossings per SpMV.
  */
 #define _GNU_SOURCE
 #include "csx_oracle.h"
@@ -35,12 +44,22 @@ typedef struct {
     int cpu;
 } slot_t;
 
+typedef struct {              /* map_t, include/sparsex/internals/Map.hpp:23-27 */
+    long length;
+    unsigned *cpus, *pos;
+} cmap_t;
+
 typedef struct {
     int nthreads;
     slot_t *slots;
     atomic_int count;
     atomic_int sense;
     atomic_int stop;
+    /* symmetric */
+    int symmetric;
+    double **locals;          /* [nthreads] raw buffers, locals[0] = y            */
+    void **ref_locals;        /* [nthreads] the same as the reference's vector_t  */
+    cmap_t *maps;             /* [nthreads]                                       */
 } pool_t;
 
 static void barrier_wait(pool_t *p, int *local_sense)
@@ -61,6 +80,19 @@ static void run_slot(slot_t *s)
     else if (s->m) oracle_csx_multiply(s->m, s->x, s->y, s->alpha);
 }
 
+/* do_mv_sym_thread */
+static void run_slot_sym(pool_t *p, int id, int *sense)
+{
+    slot_t *s = &p->slots[id];
+    const cmap_t *map = &p->maps[id];
+    for (long i = 0; i < map->length; i++) p->locals[map->cpus[i]][map->pos[i]] = 0.0;
+    barrier_wait(p, sense);
+    if (s->fn) s->fn(s->ref_spm, s->ref_in, s->ref_out, s->alpha, p->ref_locals[id]);
+    else if (s->m) oracle_csx_sym_multiply(s->m, s->x, s->y, p->locals[id], s->alpha);
+    barrier_wait(p, sense);
+    for (long i = 0; i < map->length; i++) s->y[map->pos[i]] += p->locals[map->cpus[i]][map->pos[i]];
+}
+
 typedef struct { pool_t *p; int id; } warg_t;
 
 static void *worker(void *arg)
@@ -78,7 +110,8 @@ static void *worker(void *arg)
     for (;;) {
         barrier_wait(p, &sense);           /* released by the caller */
         if (atomic_load(&p->stop)) break;
-        run_slot(s);
+        if (p->symmetric) run_slot_sym(p, w->id, &sense);
+        else run_slot(s);
         barrier_wait(p, &sense);           /* joined by the caller */
     }
     return NULL;
@@ -87,12 +120,12 @@ static void *worker(void *arg)
 /* Runs `loops` SpMVs per batch, `batches` batches; returns the median batch
    time in seconds per SpMV.  y (nrows doubles) is zeroed by the caller thread
    before every product, as MatVecMult does. */
-double oracle_time_threads(int nthreads, const oracle_csx_t *parts, void **ref_fns,
+static double time_threads(pool_t *preset, int nthreads, const oracle_csx_t *parts, void **ref_fns,
                            void **ref_spms, void *ref_in, void *ref_out, const double *x,
                            double *y, long nrows, double alpha, int loops, int batches,
                            const int *cpus)
 {
-    pool_t pool;
+    pool_t pool = *preset;
     pool.nthreads = nthreads;
     pool.slots = (slot_t *) calloc((size_t) nthreads, sizeof(slot_t));
     atomic_init(&pool.count, nthreads);
@@ -131,7 +164,8 @@ double oracle_time_threads(int nthreads, const oracle_csx_t *parts, void **ref_f
         for (int l = 0; l < loops; l++) {
             memset(y, 0, sizeof(double) * (size_t) nrows);
             barrier_wait(&pool, &sense);
-            run_slot(&pool.slots[0]);
+            if (pool.symmetric) run_slot_sym(&pool, 0, &sense);
+            else run_slot(&pool.slots[0]);
             barrier_wait(&pool, &sense);
         }
         clock_gettime(CLOCK_MONOTONIC, &t1);
@@ -156,4 +190,71 @@ double oracle_time_threads(int nthreads, const oracle_csx_t *parts, void **ref_f
     }
     free(times); free(wa); free(th); free(pool.slots);
     return med;
+}
+
+double oracle_time_threads(int nthreads, const oracle_csx_t *parts, void **ref_fns,
+                           void **ref_spms, void *ref_in, void *ref_out, const double *x,
+                           double *y, long nrows, double alpha, int loops, int batches,
+                           const int *cpus)
+{
+    pool_t preset;
+    memset(&preset, 0, sizeof(preset));
+    return time_threads(&preset, nthreads, parts, ref_fns, ref_spms, ref_in, ref_out, x, y, nrows,
+                        alpha, loops, batches, cpus);
+}
+
+/* Symmetric matrices.  conf_ptr/conf_cols: for every partition k the (ascending)
+   columns in front of its first row that it writes (its row of MakeMap's
+   initial_map); locals[k] / ref_locals[k]: partition k's full-length buffer
+   (k = 0: y itself, as temp[0] = y in MatVecMult_sym). */
+double oracle_time_threads_sym(int nthreads, const oracle_csx_t *parts, void **ref_fns,
+                               void **ref_spms, void *ref_in, void *ref_out, void **ref_locals,
+                               double **locals, const double *x, double *y, long nrows,
+                               double alpha, int loops, int batches, const int *cpus,
+                               const long *conf_ptr, const int *conf_cols)
+{
+    pool_t preset;
+    memset(&preset, 0, sizeof(preset));
+    preset.symmetric = 1;
+    preset.locals = locals;
+    preset.ref_locals = ref_locals;
+    /* MakeMap: count[j] = partitions that write column j; thread i takes the next
+       columns until it holds total/(threads left) entries */
+    unsigned *count = (unsigned *) calloc((size_t) nrows + 1, sizeof(unsigned));
+    long total = 0;
+    for (int k = 0; k < nthreads; k++)
+        for (long e = conf_ptr[k]; e < conf_ptr[k + 1]; e++) { count[conf_cols[e]]++; total++; }
+    long *cursor = (long *) calloc((size_t) nthreads, sizeof(long));
+    for (int k = 0; k < nthreads; k++) cursor[k] = conf_ptr[k];
+    preset.maps = (cmap_t *) calloc((size_t) nthreads, sizeof(cmap_t));
+    long end = 0, left = total;
+    for (int i = 0; i < nthreads; i++) {
+        const long start = end;
+        long take = 0;
+        if (i < nthreads - 1) {
+            const long limit = left / (nthreads - i);
+            while (take < limit && end < nrows) take += count[end++];
+        } else {
+            end = nrows;
+            take = left;
+        }
+        left -= take;
+        cmap_t *m = &preset.maps[i];
+        m->length = take;
+        m->cpus = (unsigned *) malloc(sizeof(unsigned) * (size_t) (take ? take : 1));
+        m->pos = (unsigned *) malloc(sizeof(unsigned) * (size_t) (take ? take : 1));
+        long t = 0;
+        for (long j = start; j < end; j++)
+            for (int k = 0; k < nthreads && count[j]; k++)
+                if (cursor[k] < conf_ptr[k + 1] && conf_cols[cursor[k]] == j) {
+                    m->cpus[t] = (unsigned) k;
+                    m->pos[t++] = (unsigned) j;
+                    cursor[k]++;
+                }
+    }
+    const double r = time_threads(&preset, nthreads, parts, ref_fns, ref_spms, ref_in, ref_out, x, y,
+                                  nrows, alpha, loops, batches, cpus);
+    for (int i = 0; i < nthreads; i++) { free(preset.maps[i].cpus); free(preset.maps[i].pos); }
+    free(preset.maps); free(cursor); free(count);
+    return r;
 }

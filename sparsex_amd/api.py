@@ -46,7 +46,7 @@ class HipInfo(C.Structure):
                 ("first_partition", C.c_int32), ("last_partition", C.c_int32),
                 ("row_lo", C.c_int32), ("row_hi", C.c_int32),
                 ("symmetric", C.c_int32), ("on_device", C.c_int32),
-                ("device", C.c_int32), ("waves", C.c_int32), ("pad_", C.c_int32),
+                ("device", C.c_int32), ("waves", C.c_int32), ("sym_tiles", C.c_int32),
                 ("tune_seconds", C.c_double),
                 ("emit_seconds", C.c_double)]
 

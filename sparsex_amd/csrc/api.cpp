@@ -259,6 +259,14 @@ static void encode_partition(Partition &p, const EncoderParams &prm, const Xform
     }
 }
 
+static bool stream_has_tiles(const GpuStream &s)
+{
+    for (const SpxRowBlock &rb : s.rbs)
+        for (uint32_t k = 0; k < rb.n_pass; ++k)
+            if (s.passes[(size_t) rb.pass_off + k].kind == SPX_PASS_SYMTILE) return true;
+    return false;
+}
+
 // The values live in HBM; the host keeps the index arrays of the stream so that
 // single entries can be found (spx_mat_get_entry / spx_mat_set_entry).
 static void keep_index(spx_matrix_t *A, GpuStream &&gs)
@@ -367,6 +375,7 @@ static void emit_and_upload(spx_matrix_t *A)
     A->index_bytes = gs.index_bytes();
     A->n_rowblocks = gs.rbs.size();
     A->n_shared = gs.shared.size();
+    A->has_tiles = stream_has_tiles(gs);
     if (A->dev) {
         device_free(A->dev);
         A->dev = nullptr;
@@ -1140,6 +1149,7 @@ spx_matrix_t *spx_mat_restore(const char *filename)
     A->index_bytes = gs->index_bytes();
     A->n_rowblocks = gs->rbs.size();
     A->n_shared = gs->shared.size();
+    A->has_tiles = stream_has_tiles(*gs);
     A->tune_seconds = 0.0;
     A->dirty = false;
     A->auto_rb = false;
@@ -1488,6 +1498,7 @@ spx_error_t spx_hip_mat_info(const spx_matrix_t *A, spx_hip_info_t *info)
         info->device = di.device;
     }
     info->waves = A->dev ? device_get_waves(A->dev) : A->waves;
+    info->sym_tiles = A->has_tiles ? 1 : 0;
     info->tune_seconds = A->tune_seconds;
     info->emit_seconds = A->emit_seconds;
     return SPX_SUCCESS;

@@ -61,6 +61,7 @@ struct matrix {
     double rb_scale = 1.0;      // chosen by the launch autotuner (multiplies the automatic row-block size)
     int waves = 4;              // wavefronts per workgroup of the SpMV kernel
     bool host_only = false;
+    bool has_tiles = false;     // the stream holds SPX_PASS_SYMTILE passes
     int device_ordinal = -1;
     bool dirty = false;                       // values changed since the last upload
     std::vector<std::vector<idx_t>> spans;    // per partition and row: reach of its units

@@ -1,0 +1,74 @@
+"""Several ranks on the GPU box (which has ONE MI355X): fresh child processes
+share device 0 and talk over gloo (SPX_BENCH_BACKEND=gloo), so everything of
+the row-partitioned path runs on the GPU except the transport -- row-slice
+inputs, per-rank tuning, the symmetric init / tile / mirror kernels of a slice,
+pack -> pairwise exchange -> ordered add, the y hand-round -- with bench.py's
+per-rank parity gate against the CSR product of the rank's own rows.  The rank
+boundaries cut through coupled rows (a 27-point stencil, dense 8x8 blocks), so
+the symmetric exchange carries real sums.  The children are started before they
+touch the GPU; nothing is re-exec'ed."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(world, extra, port):
+    env = dict(os.environ)
+    env.update({"SPX_BENCH_BACKEND": "gloo", "MASTER_ADDR": "127.0.0.1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", str(world), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--host-threads", "2"] + extra
+    if world == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+               "--no-cpu-baseline", "--no-configs", "--host-threads", "2"] + extra
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("name,extra,tiles", [
+    ("nlpkkt", ["--edge", "28"], False),
+    ("nlpkkt-sym", ["--edge", "28", "--symmetric"], False),
+    ("nd24k-sym", ["--workload", "syn-nd24k", "--scale", "0.15", "--symmetric"], True),
+    ("webbase", ["--workload", "syn-webbase", "--scale", "0.1"], False),
+], ids=["nlpkkt", "nlpkkt-sym", "nd24k-sym", "webbase"])
+def test_ranks_share_one_gpu(world, name, extra, tiles):
+    out = run_bench(world, extra, 29700 + 10 * world + len(name))
+    assert out["n_gpus"] == world and out["scaling"] == "strong" and out["value"] > 0
+    assert out["parity"]["max_err_over_fp64_bound"] <= 1.0
+    ranks = out["ranks"]
+    assert [r["rank"] for r in ranks] == list(range(world))
+    # the ranks' rows tile the matrix in order, with comparable nonzero counts
+    assert ranks[0]["rows"][0] == 0 and ranks[-1]["rows"][1] == out["config"]["nrows"]
+    assert all(ranks[i]["rows"][1] == ranks[i + 1]["rows"][0] for i in range(world - 1))
+    assert sum(r["nnz"] for r in ranks) == out["config"]["nnz"]
+    assert max(r["nnz"] for r in ranks) < 1.5 * min(r["nnz"] for r in ranks)
+    sym = out["config"]["symmetric_path"]
+    sent = [r["conflict_rows_sent"] for r in ranks]
+    if sym:
+        # real cross-rank coupling: every rank but the first adds into rows of the ranks in
+        # front of it, and what travels is far less than an n-long all-reduce would move
+        assert sent[0] == 0 and all(0 < s < out["config"]["nrows"] // 2 for s in sent[1:])
+        assert sum(r["conflict_entries_received"] for r in ranks) == sum(sent)
+        assert "collective" in out and out["collective"]["kernels_only_gflops"] > 0
+    else:
+        assert sent == [0] * world
+
+
+@pytest.mark.gpu
+def test_one_rank_runs_the_same_workload():
+    """N = 1 is the same matrix on one GPU (what makes the N-axis a strong-scaling curve)."""
+    one = run_bench(1, ["--edge", "28"], 29790)
+    two = run_bench(2, ["--edge", "28"], 29791)
+    assert one["config"]["nnz"] == two["config"]["nnz"] and one["config"]["nrows"] == two["config"]["nrows"]
+    assert one["config"]["workload"] == two["config"]["workload"]
+    assert one["scaling"] == two["scaling"] == "strong"
