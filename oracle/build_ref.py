@@ -210,3 +210,25 @@ def build_test_client():
            "-Wl,-rpath,$ORIGIN/../../sparsex_amd/lib", "-o", exe]
     subprocess.run(cmd, input=text, check=True)
     return exe
+
+
+EXAMPLES = ["csr_example", "mmf_example", "advanced_example", "matrix_caching_example_p1",
+            "matrix_caching_example_p2", "reordering_example"]
+
+
+def build_examples():
+    """The reference's six example clients (src/examples/*.c), compiled unmodified from where
+    they lie against THIS repository's headers and libsparsex.so -> oracle/_ref/examples/.
+    tests/test_gpu_reference_client.py runs them on the GPU."""
+    if not reference_available():
+        return None
+    root = os.path.dirname(HERE)
+    out = os.path.join(REF_DIR, "examples")
+    os.makedirs(out, exist_ok=True)
+    for name in EXAMPLES:
+        cmd = ["gcc", "-std=gnu99", "-O1", "-w", os.path.join(REF_ROOT, "src", "examples", name + ".c"),
+               "-I" + os.path.join(root, "include"), "-L" + os.path.join(root, "sparsex_amd", "lib"),
+               "-lsparsex", "-lm", "-Wl,-rpath,$ORIGIN/../../../sparsex_amd/lib",
+               "-o", os.path.join(out, name)]
+        subprocess.check_call(cmd)
+    return out

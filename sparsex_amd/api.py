@@ -448,6 +448,44 @@ def vec_inv_reorder(v, perm):
     return _vec_permute("spx_vec_inv_reorder", v, perm)
 
 
+def matvec_kernel_csr(A, rowptr, colind, values, nrows, ncols, alpha, x, beta, y):
+    """``spx_matvec_kernel_csr(&A, nrows, ncols, rowptr, colind, values, alpha, x, beta, y)``
+    (reference src/api/matvec.c:622-673): with ``A`` None the CSR arrays (zero-based) are
+    tuned first and the new :class:`Matrix` is returned; later calls pass it back and
+    only multiply."""
+    L = lib()
+    rp = np.ascontiguousarray(rowptr, dtype=np.int32) if rowptr is not None else None
+    ci = np.ascontiguousarray(colind, dtype=np.int32) if colind is not None else None
+    va = np.ascontiguousarray(values, dtype=np.float64) if values is not None else None
+    h = C.c_void_p(A.handle if A is not None else None)
+    L.spx_matvec_kernel_csr.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_double, C.POINTER(VectorStruct), C.c_double,
+                                        C.POINTER(VectorStruct)]
+
+    def view(v):
+        if v is None:
+            return None
+        return L.spx_vec_create_from_buff(v.ctypes.data_as(C.POINTER(C.c_double)), None, v.size, None,
+                                          SPX_VEC_AS_IS)
+
+    def ptr(a):
+        return a.ctypes.data_as(C.c_void_p) if a is not None else None
+    xv, yv = view(x), view(y)
+    try:
+        rc = L.spx_matvec_kernel_csr(C.byref(h), nrows, ncols, ptr(rp), ptr(ci), ptr(va), alpha, xv, beta, yv)
+    finally:
+        for v in (xv, yv):
+            if v:
+                L.spx_vec_destroy(v)
+    if rc != SPX_SUCCESS:
+        raise SpxError("spx_matvec_kernel_csr failed (see stderr)")
+    if A is not None:
+        return A
+    M = Matrix(h.value)
+    M._keep = (rp, ci, va)
+    return M
+
+
 def mat_tune(inp, reorder=False):
     """``spx_mat_tune(input[, SPX_MAT_REORDER])``."""
     h = lib().spx_mat_tune(C.c_void_p(inp.handle), C.c_int(SPX_MAT_REORDER if reorder else 0))

@@ -245,6 +245,16 @@ __device__ __forceinline__ void symtile_pass(const KernelArgs &a, const SpxRowBl
     const int i = (int) (l & 7u);
     const int row = (int) (q.y & 511u) + i;
     const uint32_t slot = q.y >> 9;
+#ifdef SPX_ABL_SYM_VALSONLY
+    {
+        // (ablation: the stream of the pass alone -- descriptor and values)
+        double t = (double) q.x;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) t += v2[p].x + v2[p].y;
+        if (t == 1.2345) tile[0] = t;
+        return;
+    }
+#endif
     const double xr = a.x[rb.row0 + (uint32_t) row];
     const double *xp = a.x + q.x;
     double v[8], t = 0.0, p8[8];
@@ -258,6 +268,11 @@ __device__ __forceinline__ void symtile_pass(const KernelArgs &a, const SpxRowBl
         t = fma(v[w], xp[w], t);
         p8[w] = active ? v[w] * xr : 0.0;
     }
+#ifdef SPX_ABL_SYM_NOSHFL
+    double cs = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) cs += p8[w];
+#else
     // exchange with lane^4: lanes 0-3 collect columns 0-3, lanes 4-7 columns 4-7
     double p4[4];
     {
@@ -288,10 +303,15 @@ __device__ __forceinline__ void symtile_pass(const KernelArgs &a, const SpxRowBl
         const double keep = hi ? p2[1] : p2[0];
         cs = keep + __shfl_xor(send, 1);
     }
+#endif
+#ifdef SPX_ABL_SYM_NOATOMIC
+    if (active && t + cs == 1.2345) tile[row] = t;
+#else
     if (active) {
         atomicAdd(&tile[row], t);
         atomicAdd(&slots[slot + (uint32_t) i], cs);
     }
+#endif
 }
 
 __device__ __forceinline__ void run_pass(const KernelArgs &a, const SpxRowBlock &rb,
@@ -381,8 +401,10 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, uint32_t blocks_p
             a.y[g] = t;
         }
     }
+#ifndef SPX_ABL_SYM_NOSPILL
     if (SYM)
         for (int i = threadIdx.x; i < n_slots; i += BLOCK_THREADS) a.spill[rb.spill_off + i] = lds[i];
+#endif
 }
 
 #define SPX_KERNEL_PARAMS                                                                        \

@@ -56,3 +56,13 @@ def check_y(csr, x, y, alpha=1.0, beta=0.0, y0=None):
     assert pyoracle.vec_compare(yc, y) == 0, "relative 1e-6 criterion failed"
     err = np.abs(y - yc)
     assert np.all(err <= bound), "fp64 bound exceeded: max ratio %g" % (err / bound).max()
+
+
+def check_vs_oracle(csr, x, y, yo, alpha=1.0):
+    """The HIP product against the oracle's product of the SAME tuned matrix, directly:
+    both lie within the fp64 bound of the exact product, so they differ by at most
+    twice that bound; and the reference's own relative 1e-6 criterion."""
+    assert pyoracle.vec_compare(yo, y) == 0, "HIP vs oracle: relative 1e-6 criterion failed"
+    err = np.abs(y - yo)
+    bound = 2.0 * abs_bound(csr, x, alpha)
+    assert np.all(err <= bound), "HIP vs oracle: max ratio %g" % (err / bound).max()

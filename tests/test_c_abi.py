@@ -159,7 +159,9 @@ REF = os.environ.get("SPX_REFERENCE_ROOT", "/root/reference")
 
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src", "examples")),
                     reason="reference tree not mounted")
-@pytest.mark.parametrize("example", ["csr_example.c", "mmf_example.c", "advanced_example.c"])
+@pytest.mark.parametrize("example", ["csr_example.c", "mmf_example.c", "advanced_example.c",
+                                     "matrix_caching_example_p1.c", "matrix_caching_example_p2.c",
+                                     "reordering_example.c"])
 def test_reference_examples_compile_and_link_unchanged(example, tmp_path):
     """Drop-in proof: the reference's example clients build against this
     repository's headers and library without modification."""

@@ -10,7 +10,7 @@ import pytest
 
 import sparsex_amd as sx
 from sparsex_amd import synth
-from helpers import tune, oracle_y, check_y
+from helpers import tune, oracle_y, check_y, check_vs_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -40,8 +40,10 @@ def test_mult_general(name, gen, opts):
     y = np.full(n, np.nan)          # mult must overwrite, never read, y
     A.matvec_mult(0.5, x, y)
     yo, _ = oracle_y(A, x, 0.5)
+    check_vs_oracle(csr, x, y, yo, 0.5)
     check_y(csr, x, y, 0.5)
     check_y(csr, x, yo, 0.5)
+    check_vs_oracle(csr, x, y, yo, 0.5)
     # repeated calls agree to rounding (the wavefronts of a row-block add into
     # its LDS tile in no fixed order) and never depend on y's previous contents
     y2 = np.zeros(n)
@@ -72,6 +74,7 @@ def test_mult_symmetric(name, gen, opts):
     y = np.full(n, np.nan)
     A.matvec_mult(0.5, x, y)
     yo, _ = oracle_y(A, x, 0.5)
+    check_vs_oracle(csr, x, y, yo, 0.5)
     check_y(csr, x, y, 0.5)
     check_y(csr, x, yo, 0.5)
     y0 = synth.random_x(n, seed=9)

@@ -65,3 +65,32 @@ def test_reference_client_scenario(tmp_path, name, args):
     assert "Check Passed" in out
     if "-t" in args:
         assert "MFLOPS" in out
+
+
+EXAMPLES = os.path.join(ROOT, "oracle", "_ref", "examples")
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(EXAMPLES, "csr_example")),
+                    reason="oracle/_ref/examples not built (needs the reference tree at build time)")
+def test_reference_examples_run_unchanged(tmp_path):
+    """All six example programs of the reference (src/examples/*.c), compiled unmodified
+    against this library by oracle/build_ref.py::build_examples(), run on the GPU: CSR input,
+    MMF input, the alpha/beta kernel on tuned buffers, save in one process and restore in
+    another (matrix_caching_example_p1/p2), and RCM reordering with vector (inverse)
+    reordering.  Each runs its 128 SpMV loops and prints its timing lines."""
+    with open(os.path.join(GOLDEN, "reference_matrices.json")) as f:
+        mats = json.load(f)
+    mtx = str(tmp_path / "demopatt.mtx.sorted")
+    write_sorted_mtx(mtx, mats["demopatt"])
+    binfile = str(tmp_path / "csx_file.bin")
+    runs = [("csr_example", []), ("mmf_example", [mtx]), ("advanced_example", [mtx]),
+            ("matrix_caching_example_p1", [mtx, binfile]), ("matrix_caching_example_p2", [binfile]),
+            ("reordering_example", [mtx])]
+    for name, args in runs:
+        p = subprocess.run([os.path.join(EXAMPLES, name)] + args, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, timeout=300, cwd=str(tmp_path))
+        out = p.stdout.decode(errors="replace")
+        assert p.returncode == 0, name + ": " + out[-2000:]
+        assert "SPMV time:" in out and "MFLOPS:" in out, name + ": " + out[-2000:]
+        if name == "matrix_caching_example_p1":
+            assert os.path.getsize(binfile) > 0

@@ -11,5 +11,5 @@ mkdir -p build/var sparsex_amd/lib/variants
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O3 -fPIC -munsafe-fp-atomics -Iinclude -Isparsex_amd/csrc \
     $FLAGS -c sparsex_amd/csrc/spmv_kernels.hip -o build/var/spmv_$NAME.o
 OBJS=$(ls build/obj/*.o | grep -v spmv_kernels.o)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o sparsex_amd/lib/variants/libsparsex_$NAME.so $OBJS build/var/spmv_$NAME.o -pthread
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o sparsex_amd/lib/variants/libsparsex_$NAME.so $OBJS build/var/spmv_$NAME.o -pthread -ldl
 echo sparsex_amd/lib/variants/libsparsex_$NAME.so
