@@ -279,6 +279,21 @@ static void keep_index(spx_matrix_t *A, GpuStream &&gs)
     A->index.reset(new GpuStream(std::move(gs)));
 }
 
+// Automatic row-block size: about five row-blocks per compute unit, so that a
+// small matrix runs as a single round of workgroups; `scale` is what the launch
+// autotuner multiplies it with.
+static size_t auto_target_elems(const spx_matrix_t *A, double scale)
+{
+    size_t local = 0;
+    for (const Partition &p : A->parts) local += p.nnz * (A->symmetric ? 2 : 1);
+    // (matrices far beyond the 256 MB Infinity Cache stream a little better
+    // with the largest row-blocks: syn-nd24k x4, 114 M nonzeros, 162 -> 159 us)
+    size_t t = std::min<size_t>(std::max<size_t>(local / 1280 + 1, 1024),
+                                local > ((size_t) 64 << 20) ? SPX_MAX_RB_ELEMS : 4096);
+    t = std::max<size_t>((size_t)(scale * (double) t), 512);
+    return std::min<size_t>(t, SPX_MAX_RB_ELEMS);
+}
+
 // Builds the row-block descriptor stream from the encoded partitions and puts
 // it into HBM (or keeps it on the host for host-only matrices).
 static void emit_and_upload(spx_matrix_t *A)
@@ -287,17 +302,7 @@ static void emit_and_upload(spx_matrix_t *A)
     const size_t first = A->first_part;
     const bool sym = A->symmetric != 0;
     GpuEmitParams gp = A->emit_params;
-    if (A->auto_rb) {
-        // auto: about five row-blocks per compute unit, so that a small matrix
-        // runs as a single round of workgroups
-        size_t local = 0;
-        for (size_t i = 0; i < nown; ++i) local += A->parts[i].nnz * (sym ? 2 : 1);
-        // (matrices far beyond the 256 MB Infinity Cache stream a little better
-        // with the largest row-blocks: syn-nd24k x4, 114 M nonzeros, 162 -> 159 us)
-        gp.target_elems = std::min<size_t>(std::max<size_t>(local / 1280 + 1, 1024),
-                                           local > ((size_t) 64 << 20) ? SPX_MAX_RB_ELEMS : 4096);
-        gp.target_elems = std::max<size_t>((size_t)(A->rb_scale * (double) gp.target_elems), 512);
-    }
+    if (A->auto_rb) gp.target_elems = auto_target_elems(A, A->rb_scale);
     GpuStream gs;
     const unsigned hw = host_threads();
     // pieces (partitions, row ranges) are emitted concurrently into streams of
@@ -367,6 +372,7 @@ static void emit_and_upload(spx_matrix_t *A)
     if (sym && !gs.sym_fused) stream_touched_rows(gs, A->own_lo, A->conflict_rows);
     finalize_stream(gs, (size_t) A->nrows);
     gs.waves = (uint32_t) A->waves;
+    gs.sym_atomic = A->sym_atomic;
     A->nnz_stored = gs.nnz_stored;
     A->n_unit_elems = gs.n_unit_elems;
     A->n_delta_elems = gs.n_delta_elems;
@@ -394,9 +400,23 @@ static void emit_and_upload(spx_matrix_t *A)
 // workgroups) like two wavefronts per workgroup and smaller row-blocks,
 // leftover-heavy ones eight wavefronts, the rest the default.  A handful of
 // candidates, a few hundred launches each; the fastest stays.
-static void autotune_launch(spx_matrix_t *A)
+static void autotune_launch(spx_matrix_t *A, bool tune_waves, bool tune_spill)
 {
     const int W = 10, N = 100;
+    if (!tune_waves) {
+        // (the wavefront count is pinned: only the hand-over of the tiles' sums is measured)
+        if (!tune_spill || !device_has_spill(A->dev)) return;
+        auto t_of = [&](bool atomic) {
+            device_set_sym_atomic(A->dev, atomic);
+            double best = device_time_spmv(A->dev, W, N);
+            for (int rep = 0; rep < 3; ++rep) best = std::min(best, device_time_spmv(A->dev, 0, N));
+            return best;
+        };
+        const double tl = t_of(false), ta = t_of(true);
+        A->sym_atomic = ta < 0.985 * tl;
+        device_set_sym_atomic(A->dev, A->sym_atomic);
+        return;
+    }
     auto time_with = [&](int waves) {
         device_set_waves(A->dev, waves);
         double best = device_time_spmv(A->dev, W, N);
@@ -407,6 +427,18 @@ static void autotune_launch(spx_matrix_t *A)
     const double t4 = time_with(4), t8 = time_with(8);
     int best_waves = t8 < 0.985 * t4 ? 8 : 4;
     double best_t = std::min(t4, t8), best_scale = 1.0;
+    // symmetric tiles: the transposed sums through the spill array and a second
+    // kernel, or straight into y with global atomics
+    if (tune_spill && device_has_spill(A->dev)) {
+        device_set_sym_atomic(A->dev, !A->sym_atomic);
+        const double ta = time_with(best_waves);
+        if (ta < 0.985 * best_t) {
+            best_t = ta;
+            A->sym_atomic = !A->sym_atomic;
+        } else {
+            device_set_sym_atomic(A->dev, A->sym_atomic);
+        }
+    }
     // smaller row-blocks with 2 wavefronts: only worth trying where the whole
     // matrix is in flight at once anyway (needs a second emission + upload)
     if (A->auto_rb && A->n_rowblocks <= 4096) {
@@ -429,7 +461,10 @@ static void autotune_launch(spx_matrix_t *A)
     }
     // many row-blocks (several rounds of workgroups): twice the size halves the
     // per-row-block overhead (syn-nlpkkt N = 60: 33.0 -> 30.4 us)
-    if (A->auto_rb && A->n_rowblocks > 4096) {
+    // (not where the row-blocks already have the largest size: the second
+    // emission would produce the same stream)
+    if (A->auto_rb && A->n_rowblocks > 4096 &&
+        auto_target_elems(A, 2.0) != auto_target_elems(A, best_scale)) {
         A->rb_scale = 2.0;
         A->waves = best_waves;
         emit_and_upload(A);
@@ -593,8 +628,15 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     A->waves = (int) cfg.get_long("spx.gpu.waves");
     const bool autotune = A->waves == 0;
     if (autotune) A->waves = 4;
+    const std::string spill_mode = cfg.get_str("spx.gpu.sym_spill");
+    if (spill_mode != "auto" && spill_mode != "lists" && spill_mode != "atomic") {
+        log_msg(LOG_ERR, "spx.gpu.sym_spill: lists, atomic or auto\n");
+        throw FatalError("bad spx.gpu.sym_spill");
+    }
+    A->sym_atomic = spill_mode == "atomic";
     emit_and_upload(A.get());
-    if (autotune && A->dev && A->nnz_stored >= 100000) autotune_launch(A.get());
+    if (A->dev && A->nnz_stored >= 100000 && (autotune || spill_mode == "auto"))
+        autotune_launch(A.get(), autotune, spill_mode == "auto");
     if (!cfg.get_bool("spx.rt.keep_encoded")) {
         A->parts.clear();
         A->parts.shrink_to_fit();
@@ -887,7 +929,7 @@ spx_error_t spx_mat_set_entry(spx_matrix_t *A, spx_index_t row, spx_index_t colu
 
 namespace {
 
-const char kMagic[8] = {'S', 'P', 'X', 'H', 'I', 'P', '0', '9'};
+const char kMagic[8] = {'S', 'P', 'X', 'H', 'I', 'P', '1', '0'};
 
 template <typename T>
 bool put_vec(FILE *f, const std::vector<T> &v)
@@ -924,6 +966,7 @@ struct SavedHeader {
     uint32_t n_carry, pad;
     uint32_t n_spill, lds_doubles;
     uint32_t waves, n_encoded;          // n_encoded: encoded partitions that follow the stream
+    uint32_t sym_atomic, pad3;          // symmetric tiles: sums handed over with global atomics
     uint64_t checksum;                  // FNV-1a over the index arrays
 };
 
@@ -941,7 +984,7 @@ uint64_t stream_checksum(const GpuStream &s)
 {
     uint64_t h = 0xCBF29CE484222325ull;
     fnv(h, s.rbs); fnv(h, s.passes); fnv(h, s.descs); fnv(h, s.cidx); fnv(h, s.segrows);
-    fnv(h, s.shared); fnv(h, s.fix_ptr); fnv(h, s.fix_idx);
+    fnv(h, s.shared); fnv(h, s.fix_ptr); fnv(h, s.fix_idx); fnv(h, s.slot_group_col);
     return h;
 }
 
@@ -1038,6 +1081,7 @@ spx_error_t spx_mat_save(const spx_matrix_t *A, const char *filename)
     h.lds_doubles = gs->lds_doubles;
     h.waves = gs->waves;
     h.n_encoded = (uint32_t) A->parts.size();
+    h.sym_atomic = gs->sym_atomic ? 1u : 0u;
     h.checksum = stream_checksum(*gs);
     bool good = fwrite(kMagic, 1, 8, f) == 8 && fwrite(&h, sizeof(h), 1, f) == 1;
     std::vector<int32_t> bnd;
@@ -1049,7 +1093,8 @@ spx_error_t spx_mat_save(const spx_matrix_t *A, const char *filename)
     good = good && put_vec(f, bnd) && put_vec(f, gs->rbs) && put_vec(f, gs->passes) &&
            put_vec(f, gs->descs) && put_vec(f, gs->cidx) &&
            put_vec(f, gs->segrows) && put_vec(f, gs->shared) && put_vec(f, gs->dvalues) &&
-           put_vec(f, gs->values) && put_vec(f, gs->fix_ptr) && put_vec(f, gs->fix_idx);
+           put_vec(f, gs->values) && put_vec(f, gs->fix_ptr) && put_vec(f, gs->fix_idx) &&
+           put_vec(f, gs->slot_group_col);
     std::vector<int32_t> perm;
     if (A->permutation) perm.assign(A->permutation, A->permutation + A->nrows);
     good = good && put_vec(f, perm);
@@ -1089,7 +1134,7 @@ spx_matrix_t *spx_mat_restore(const char *filename)
                 get_vec(f, gs->passes) && get_vec(f, gs->descs) &&
                 get_vec(f, gs->cidx) && get_vec(f, gs->segrows) && get_vec(f, gs->shared) &&
                 get_vec(f, gs->dvalues) && get_vec(f, gs->values) && get_vec(f, gs->fix_ptr) &&
-                get_vec(f, gs->fix_idx);
+                get_vec(f, gs->fix_idx) && get_vec(f, gs->slot_group_col);
     std::vector<int32_t> perm;
     good = good && get_vec(f, perm);
     std::unique_ptr<matrix> A(new matrix);
@@ -1120,6 +1165,7 @@ spx_matrix_t *spx_mat_restore(const char *filename)
         gs->n_spill = h.n_spill;
         gs->lds_doubles = h.lds_doubles;
         gs->waves = h.waves;
+        gs->sym_atomic = h.sym_atomic != 0;
         gs->nnz_stored = h.nnz_stored; gs->n_unit_elems = h.n_unit_elems;
         gs->n_delta_elems = h.n_delta_elems; gs->n_units = h.n_units;
         good = stream_checksum(*gs) == h.checksum;
@@ -1150,6 +1196,7 @@ spx_matrix_t *spx_mat_restore(const char *filename)
     A->n_rowblocks = gs->rbs.size();
     A->n_shared = gs->shared.size();
     A->has_tiles = stream_has_tiles(*gs);
+    A->sym_atomic = gs->sym_atomic;
     A->tune_seconds = 0.0;
     A->dirty = false;
     A->auto_rb = false;

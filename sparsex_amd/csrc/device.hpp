@@ -45,6 +45,12 @@ void device_host_free(void *p);
 // (default 0: the whole partial vector is defined, for a caller-side all-reduce)
 void device_set_init_rows(DeviceMatrix *m, size_t first_row);
 
+// symmetric tiles: hand the transposed sums over with global atomics (true) or
+// through the spill array and a second kernel (false)
+void device_set_sym_atomic(DeviceMatrix *m, bool on);
+bool device_get_sym_atomic(const DeviceMatrix *m);
+bool device_has_spill(const DeviceMatrix *m);
+
 // wavefronts per workgroup of the SpMV kernel: 2, 4 or 8
 void device_set_waves(DeviceMatrix *m, int waves);
 int device_get_waves(const DeviceMatrix *m);

@@ -644,9 +644,12 @@ static void extract_tiles(std::vector<Single> &pts, std::vector<SymTile> &tiles,
     struct Seg { idx_t row, col; uint32_t first; uint32_t width; };
     std::vector<Seg> segs;
     for (size_t i = 0; i < pts.size();) {
+        // (segments end where the column number reaches a multiple of eight, so that a
+        // full one starts on such a column: the eight column sums of a tile then are
+        // one aligned 64-byte piece of y)
         size_t j = i + 1;
         while (j < pts.size() && j - i < 8 && pts[j].row == pts[i].row &&
-               pts[j].col == pts[j - 1].col + 1)
+               pts[j].col == pts[j - 1].col + 1 && (pts[j].col - 1) % 8 != 0)
             ++j;
         segs.push_back(Seg{pts[i].row, pts[i].col, (uint32_t) i, (uint32_t)(j - i)});
         i = j;
@@ -887,6 +890,13 @@ void finalize_stream(GpuStream &s, size_t nrows)
 {
     if (s.pass_stride) return;
     s.n_spill = (uint32_t) s.spill_col.size();
+    // tiles start on columns that are multiples of eight: the slots come in groups
+    // of eight consecutive columns, one first column per group
+    s.slot_group_col.clear();
+    for (size_t k = 0; k < s.spill_col.size(); k += 8) {
+        assert(s.spill_col[k] % 8 == 0 && k + 8 <= s.spill_col.size() && s.spill_col[k + 7] == s.spill_col[k] + 7);
+        s.slot_group_col.push_back(s.spill_col[k]);
+    }
     if (!s.spill_col.empty()) {
         // per row: the spill slots whose sums belong to it (counting sort by column)
         s.fix_ptr.assign(nrows + 1, 0);

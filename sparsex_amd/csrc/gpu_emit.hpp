@@ -39,6 +39,14 @@ struct GpuStream {
     // (host side only) and, per row, the slots whose sums belong to it
     std::vector<uint32_t> spill_col;
     std::vector<uint32_t> fix_ptr, fix_idx;
+    // first column of every group of eight slots (tiles start on columns that are
+    // multiples of eight); slot i of the stream belongs to column
+    // slot_group_col[i / 8] + i % 8
+    std::vector<uint32_t> slot_group_col;
+    // symmetric tiles: how the transposed sums reach their rows -- false: spilled
+    // and collected per row by a second kernel in a fixed order; true: added
+    // straight into y with 64-byte groups of global_atomic_add_f64
+    bool sym_atomic = false;
     uint32_t n_spill = 0;                      // spill slots (= spill_col.size() after emission)
     uint32_t lds_doubles = SPX_MAX_RB_ROWS;    // largest n_slots + n_rows
     // pass headers of row-block i start at passes[i * pass_stride] once
@@ -60,7 +68,7 @@ struct GpuStream {
     size_t index_bytes() const
     {
         return descs.size() * sizeof(SpxUnitDesc) + n_pass_used() * sizeof(SpxPass) + cidx.size() +
-               (fix_ptr.size() + fix_idx.size()) * 4 +
+               (sym_atomic ? slot_group_col.size() : fix_ptr.size() + fix_idx.size()) * 4 +
                segrows.size() * 2 + rbs.size() * sizeof(SpxRowBlock);
     }
 };

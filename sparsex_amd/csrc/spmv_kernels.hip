@@ -50,6 +50,7 @@ struct KernelArgs {
     double *carry;
     const double *dvalues;   // symmetric, fused: diagonal added at the write-out (else null)
     double *spill;           // symmetric tiles: transposed sums of columns owned by other row-blocks
+    const uint32_t *slot_col;  // ... or (atomic hand-over) the first column of every group of eight slots
     double alpha, beta;
     uint32_t n_rb;
     uint32_t pass_stride;    // pass headers of row-block i start at passes[i * pass_stride]
@@ -327,7 +328,11 @@ __device__ __forceinline__ void run_pass(const KernelArgs &a, const SpxRowBlock 
 // SYM: the symmetric variant with tiles (dynamic LDS: the row-block's
 // transposed-sum slots in front of its y tile; the sums of columns owned by
 // other row-blocks are spilled for csx_symfix_kernel).
-template <bool SYM, int WAVES_PER_BLOCK>
+// ATOMIC (symmetric tiles only): the row-block hands everything over with
+// global_atomic_add_f64 -- its own rows (csx_sym_init_kernel has put beta*y and the
+// diagonal term there) and, in aligned groups of eight, the transposed sums of
+// the columns in front of it -- instead of spilling them for a second kernel.
+template <bool SYM, bool ATOMIC, int WAVES_PER_BLOCK>
 __device__ __forceinline__ void spmv_body(const KernelArgs &a, uint32_t blocks_per_xcd,
                                           double *lds)
 {
@@ -391,6 +396,12 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, uint32_t blocks_p
     // ---------------- write the owned rows ------------------------------------------------
     if (rb.flags & SPX_RB_SHARED) {
         if (threadIdx.x == 0) a.carry[rb.carry_slot] = tile[0];
+    } else if (ATOMIC) {
+        for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS)
+            atomicAdd(&a.y[(size_t) rb.row0 + i], a.alpha * tile[i]);
+        const uint32_t *gcol = a.slot_col + (rb.spill_off >> 3);
+        for (int i = threadIdx.x; i < n_slots; i += BLOCK_THREADS)
+            atomicAdd(&a.y[(size_t) gcol[i >> 3] + (i & 7)], a.alpha * lds[i]);
     } else {
         for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS) {
             const size_t g = (size_t) rb.row0 + i;
@@ -402,7 +413,7 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, uint32_t blocks_p
         }
     }
 #ifndef SPX_ABL_SYM_NOSPILL
-    if (SYM)
+    if (SYM && !ATOMIC)
         for (int i = threadIdx.x; i < n_slots; i += BLOCK_THREADS) a.spill[rb.spill_off + i] = lds[i];
 #endif
 }
@@ -411,12 +422,14 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, uint32_t blocks_p
     const SpxRowBlock *rbs_, const SpxPass *passes_, uint32_t n_rb_, uint32_t pass_stride_,      \
     uint32_t blocks_per_xcd, uint32_t /*pad*/, const double *values_, const SpxUnitDesc *descs_, \
     const uint8_t *cidx_, const uint16_t *segrows_, const double *x_, double *y_,               \
-    double *carry_, const double *dvalues_, double *spill_, double alpha_, double beta_
+    double *carry_, const double *dvalues_, double *spill_, const uint32_t *slot_col_,         \
+    double alpha_, double beta_
 #define SPX_KERNEL_ARGS(a)                                                                       \
     KernelArgs a;                                                                                \
     a.rbs = rbs_; a.passes = passes_; a.n_rb = n_rb_; a.pass_stride = pass_stride_;              \
     a.values = values_; a.descs = descs_; a.cidx = cidx_; a.segrows = segrows_; a.x = x_;        \
-    a.y = y_; a.carry = carry_; a.dvalues = dvalues_; a.spill = spill_; a.alpha = alpha_;        \
+    a.y = y_; a.carry = carry_; a.dvalues = dvalues_; a.spill = spill_; a.slot_col = slot_col_;  \
+    a.alpha = alpha_;                                                                            \
     a.beta = beta_
 
 // (Individual scalar arguments, most urgent first.  Preloading them into SGPRs
@@ -429,7 +442,7 @@ void csx_spmv_kernel(SPX_KERNEL_PARAMS)
 {
     SPX_KERNEL_ARGS(a);
     __shared__ double tile[SPX_MAX_RB_ROWS];
-    spmv_body<false, WAVES>(a, blocks_per_xcd, tile);
+    spmv_body<false, false, WAVES>(a, blocks_per_xcd, tile);
 }
 
 template <int WAVES>
@@ -438,7 +451,16 @@ void csx_spmv_symtile_kernel(SPX_KERNEL_PARAMS)
 {
     SPX_KERNEL_ARGS(a);
     extern __shared__ double lds_dyn[];
-    spmv_body<true, WAVES>(a, blocks_per_xcd, lds_dyn);
+    spmv_body<true, false, WAVES>(a, blocks_per_xcd, lds_dyn);
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES)
+void csx_spmv_symtile_atomic_kernel(SPX_KERNEL_PARAMS)
+{
+    SPX_KERNEL_ARGS(a);
+    extern __shared__ double lds_dyn[];
+    spmv_body<true, true, WAVES>(a, blocks_per_xcd, lds_dyn);
 }
 
 // symmetric tiles, second step: every row collects the transposed sums that
@@ -528,6 +550,9 @@ struct DeviceMatrix {
     double *spill = nullptr;
     uint32_t *fix_ptr = nullptr, *fix_idx = nullptr;
     size_t n_fix_ptr = 0, n_fix_idx = 0;
+    bool sym_atomic = false;   // transposed sums go straight into y (global atomics), no second kernel
+    uint32_t *slot_col = nullptr;
+    size_t n_slot_col = 0;
     // staging vectors of the host-pointer path
     double *d_x = nullptr, *d_y = nullptr;
     double *p_x = nullptr, *p_y = nullptr;      // pinned
@@ -606,7 +631,10 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
         m->fix_idx = upload(s.fix_idx);
         m->n_fix_ptr = s.fix_ptr.size();
         m->n_fix_idx = s.fix_idx.size();
+        m->slot_col = upload(s.slot_group_col);
+        m->n_slot_col = s.slot_group_col.size();
     }
+    m->sym_atomic = s.sym_atomic && m->has_tiles;
     m->n_values = s.values.size(); m->n_descs = s.descs.size(); m->n_passes = s.passes.size();
     m->n_cidx = s.cidx.size(); m->n_segrows = s.segrows.size();
     m->value_bytes = s.values.size() * sizeof(double);
@@ -625,6 +653,7 @@ void device_free(DeviceMatrix *m)
     if (m->spill) (void) hipFree(m->spill);
     if (m->fix_ptr) (void) hipFree(m->fix_ptr);
     if (m->fix_idx) (void) hipFree(m->fix_idx);
+    if (m->slot_col) (void) hipFree(m->slot_col);
     if (m->d_x) (void) hipFree(m->d_x);
     if (m->d_y) (void) hipFree(m->d_y);
     if (m->p_x) (void) hipHostFree(m->p_x);
@@ -645,11 +674,16 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
     a.rbs = m->rbs; a.values = m->values; a.descs = m->descs; a.passes = m->passes;
     a.cidx = m->cidx; a.segrows = m->segrows; a.x = d_x; a.y = d_y;
     a.carry = m->carry; a.alpha = alpha; a.beta = beta; a.n_rb = m->n_rb;
-    a.dvalues = m->sym_fused ? m->dvalues : nullptr;
+    // (atomic hand-over of the tiles' sums: every row may be added to by several
+    // workgroups, so beta*y and the diagonal term are put there first, as for a
+    // process that holds a slice)
+    const bool fused = m->sym_fused && !m->sym_atomic;
+    a.dvalues = fused ? m->dvalues : nullptr;
     a.pass_stride = m->pass_stride;
+    a.slot_col = m->slot_col;
 
     uint32_t blocks = (m->n_rb + 7u) & ~7u;
-    if (m->symmetric && !m->sym_fused) {
+    if (m->symmetric && !fused) {
         // y <- beta*y + alpha*diag*x on the owned rows, 0 elsewhere; the
         // row-blocks (stored lower triangle and its mirror image) then
         // accumulate on top of that
@@ -667,15 +701,19 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
 #define SPX_LAUNCH(KERNEL, W, LDS)                                                               \
     hipLaunchKernelGGL(KERNEL<W>, dim3(blocks), dim3(64 * W), LDS, stream, a.rbs, a.passes,      \
                        a.n_rb, a.pass_stride, blocks >> 3, 0u, a.values, a.descs, a.cidx,        \
-                       a.segrows, a.x, a.y, a.carry, a.dvalues, a.spill, a.alpha, a.beta)
+                       a.segrows, a.x, a.y, a.carry, a.dvalues, a.spill, a.slot_col, a.alpha, a.beta)
     if (blocks && m->has_tiles) {
         // symmetric tiles: slots + y tile in dynamic LDS, then the rows collect
         // what other row-blocks spilled for them
         const size_t lds = m->lds_doubles * sizeof(double);
-        if (m->waves == 2) SPX_LAUNCH(csx_spmv_symtile_kernel, 2, lds);
+        if (m->sym_atomic) {
+            if (m->waves == 2) SPX_LAUNCH(csx_spmv_symtile_atomic_kernel, 2, lds);
+            else if (m->waves == 8) SPX_LAUNCH(csx_spmv_symtile_atomic_kernel, 8, lds);
+            else SPX_LAUNCH(csx_spmv_symtile_atomic_kernel, 4, lds);
+        } else if (m->waves == 2) SPX_LAUNCH(csx_spmv_symtile_kernel, 2, lds);
         else if (m->waves == 8) SPX_LAUNCH(csx_spmv_symtile_kernel, 8, lds);
         else SPX_LAUNCH(csx_spmv_symtile_kernel, 4, lds);
-        if (m->n_spill)
+        if (m->n_spill && !m->sym_atomic)
             hipLaunchKernelGGL(csx_symfix_kernel, dim3((unsigned)((((m->nrows + 31) / 32) + 7) & ~(size_t) 7)), dim3(256),
                                0, stream, m->fix_ptr, m->fix_idx, m->spill, d_y, alpha,
                                (uint32_t) m->nrows);
@@ -693,6 +731,10 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
 }
 
 void device_set_init_rows(DeviceMatrix *m, size_t first_row) { m->init_lo = first_row; }
+
+void device_set_sym_atomic(DeviceMatrix *m, bool on) { m->sym_atomic = on && m->has_tiles && m->n_spill; }
+bool device_get_sym_atomic(const DeviceMatrix *m) { return m->sym_atomic; }
+bool device_has_spill(const DeviceMatrix *m) { return m->has_tiles && m->n_spill; }
 
 void device_set_waves(DeviceMatrix *m, int waves)
 {
@@ -754,6 +796,7 @@ void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x, bool x_p
     // y travels to the device only when it is read: beta != 0, or this process
     // owns a slice of the rows and the others must keep the caller's values
     const bool whole = m->own_lo == 0 && m->own_hi == m->nrows && (!m->symmetric || m->sym_fused);
+    // (atomic hand-over reads y only through the init kernel's beta*y: nothing to upload when beta == 0)
     if (beta != 0.0 || !whole) {
         const double *src_y = h_y;
         if (!y_pinned) {
@@ -808,6 +851,8 @@ void device_download(const DeviceMatrix *m, GpuStream &s)
     s.waves = (uint32_t) m->waves;
     s.n_spill = m->n_spill;
     s.lds_doubles = m->lds_doubles;
+    s.sym_atomic = m->sym_atomic;
+    if (m->n_spill) download(s.slot_group_col, m->slot_col, m->n_slot_col);
     if (m->n_spill) {
         download(s.fix_ptr, m->fix_ptr, m->n_fix_ptr);
         download(s.fix_idx, m->fix_idx, m->n_fix_idx);

@@ -150,6 +150,8 @@ bool stream_validate(const GpuStream &s, size_t nrows, size_t ncols, size_t n_va
         SPX_REQUIRE(s.fix_ptr[i] <= s.fix_ptr[i + 1], "spill list order");
     SPX_REQUIRE(s.fix_ptr.empty() || s.fix_ptr.back() == s.fix_idx.size(), "spill list end");
     for (uint32_t k : s.fix_idx) SPX_REQUIRE(k < s.n_spill, "spill index");
+    SPX_REQUIRE(s.slot_group_col.size() * 8 == s.n_spill, "slot groups");
+    for (uint32_t c : s.slot_group_col) SPX_REQUIRE(c % 8 == 0 && (size_t) c + 8 <= nrows, "slot group column");
     SPX_REQUIRE(s.dvalues.empty() || s.dvalues.size() == nrows, "diagonal length");
     bool tiles = false;
     for (size_t i = 0; i < s.rbs.size(); ++i) {
@@ -164,7 +166,8 @@ bool stream_validate(const GpuStream &s, size_t nrows, size_t ncols, size_t n_va
         SPX_REQUIRE(rb.cidx_width == 2 || rb.cidx_width == 4, "column-offset width");
         SPX_REQUIRE(rb.seg_off <= s.segrows.size(), "row-block row-piece offset");
         SPX_REQUIRE((size_t) rb.n_slots + rb.n_rows <= s.lds_doubles, "row-block LDS use");
-        SPX_REQUIRE(rb.n_slots == 0 || (size_t) rb.spill_off + rb.n_slots <= s.n_spill, "spill range");
+        SPX_REQUIRE(rb.n_slots == 0 || ((size_t) rb.spill_off + rb.n_slots <= s.n_spill &&
+                                        rb.spill_off % 8 == 0 && rb.n_slots % 8 == 0), "spill range");
         if (rb.flags & SPX_RB_SHARED)
             SPX_REQUIRE(rb.carry_slot < s.n_carry && rb.n_rows == 1, "carry slot");
         for (uint32_t t = 0; t < rb.n_pass; ++t) {

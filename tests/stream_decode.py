@@ -24,15 +24,15 @@ class Stream:
     def __init__(self, path):
         with open(path, "rb") as f:
             buf = f.read()
-        assert buf[:8] == b"SPXHIP09", buf[:8]
-        hdr = struct.unpack_from("<4i3Q2i4Q6IQ", buf, 8)
+        assert buf[:8] == b"SPXHIP10", buf[:8]
+        hdr = struct.unpack_from("<4i3Q2i4Q8IQ", buf, 8)
         (self.nrows, self.ncols, self.nnz, self.symmetric, self.nr_partitions, self.first_part,
          self.last_part, self.own_lo, self.own_hi, self.nnz_stored, self.n_unit_elems,
          self.n_delta_elems, self.n_units, self.n_carry, flags, self.n_spill, self.lds_doubles,
-         self.waves, self.n_encoded, self.checksum) = hdr
+         self.waves, self.n_encoded, self.sym_atomic, _, self.checksum) = hdr
         self.sym_fused = bool(flags & 1)
         self.pass_stride = flags >> 1
-        self.off = 8 + struct.calcsize("<4i3Q2i4Q6IQ")
+        self.off = 8 + struct.calcsize("<4i3Q2i4Q8IQ")
         self.buf = buf
 
         def vec(dt):
@@ -52,6 +52,7 @@ class Stream:
         self.values = vec("<f8")
         self.fix_ptr = vec("<u4")
         self.fix_idx = vec("<u4")
+        self.slot_group_col = vec("<u4")
         self.perm = vec("<i4")
         # the encoded partitions (kept for exports of a restored matrix) follow
         self.encoded = []

@@ -139,3 +139,25 @@ def test_demopatt_reference_scenarios():
         for _ in range(128):
             A.matvec_mult(0.5, x, y)
         check_y(csr, x, y, 0.5)
+
+
+@pytest.mark.parametrize("mode", ["lists", "atomic", "auto"])
+@pytest.mark.parametrize("threads", ["1", "3"])
+def test_symmetric_tiles_hand_over_modes(mode, threads):
+    """The transposed sums of the symmetric tiles reach their rows through the spill array
+    and a second kernel (fixed order) or straight through global atomics
+    (spx.gpu.sym_spill); same product either way, with and without beta."""
+    csr = synth.syn_nd24k(0.05)
+    n = csr[3]
+    A = tune(csr, {"spx.gpu.sym_spill": mode, "spx.rt.nr_threads": threads}, sym=True)
+    assert A.info().sym_tiles == 1
+    x = synth.random_x(n)
+    y = np.full(n, np.nan)
+    A.matvec_mult(0.5, x, y)
+    check_y(csr, x, y, 0.5)
+    yo, _ = oracle_y(A, x, 0.5)
+    check_vs_oracle(csr, x, y, yo, 0.5)
+    y0 = synth.random_x(n, seed=3)
+    y1 = y0.copy()
+    A.matvec_kernel(1.5, x, -0.25, y1)
+    check_y(csr, x, y1, 1.5, -0.25, y0)

@@ -78,7 +78,7 @@ def test_restore_rejects_damaged_files(tmp_path):
     with pytest.raises(sx.SpxError):
         sx.mat_restore(str(bad))
     rng = np.random.RandomState(2)
-    hdr = 8 + 112
+    hdr = 8 + 120
     for _ in range(20):                                             # one byte of the index flipped
         b = bytearray(good)
         # (stay inside the row-block / pass / descriptor arrays that follow the header)

@@ -15,6 +15,12 @@ for v in ${VARIANTS:-FULL SYM_VALSONLY SYM_NOSHFL SYM_NOATOMIC SYM_NOSPILL}; do
     rm -rf $OUT; mkdir -p $OUT
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o run -- python3 $ROOT/bench.py --no-cpu-baseline --no-configs --steps 100 --warmup 10 --workload ${WORKLOAD:-syn-nd24k} --symmetric "$@" > $OUT/log 2>&1
     echo "== $v"
-    find $OUT -name '*kernel_stats.csv' -exec grep -E "csx_|Name" {} \; | cut -d, -f1-4,6-7 | cut -c1-150
+    python3 - $OUT <<'PY'
+import csv, glob, sys
+for f in glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "csx_" in r["Name"]:
+            print("  %-70s calls %6s avg %9.1f ns  min %8s" % (r["Name"].split("(")[0][-70:], r["Calls"], float(r["AverageNs"]), r["MinNs"]))
+PY
     rm -rf $OUT
 done
