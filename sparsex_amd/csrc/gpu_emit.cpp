@@ -412,9 +412,13 @@ void RbBuilder::emit_tile_passes(SpxRowBlock &rb, const std::vector<const SymTil
 {
     if (tiles.empty()) return;
     const idx_t row0 = (idx_t) rb.row0;
+    // (tiles start on columns that are multiples of eight; a group of eight columns
+    // that begins in front of the row-block is taken whole, also where the
+    // row-block -- whose first row need not be a multiple of eight -- begins inside it)
     std::vector<idx_t> cols;
     for (const SymTile *t : tiles)
-        for (idx_t c = t->col0; c < t->col0 + 8 && c < row0; ++c) cols.push_back(c);
+        if (t->col0 < row0)
+            for (idx_t c = t->col0; c < t->col0 + 8; ++c) cols.push_back(c);
     std::sort(cols.begin(), cols.end());
     cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
     assert(cols.size() <= SPX_MAX_TILE_SLOTS);
