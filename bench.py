@@ -528,7 +528,9 @@ def main():
     backend = os.environ.get("SPX_BENCH_BACKEND", "nccl")
     if args.gpus > 1 or world > 1:
         assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-        dev_id = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+        # (SPX_BENCH_SHARE_GPU=1: experiment -- several RCCL ranks on one device, where RCCL allows it)
+        share = backend != "nccl" or os.environ.get("SPX_BENCH_SHARE_GPU") == "1"
+        dev_id = local_rank % torch.cuda.device_count() if share else local_rank
         torch.cuda.set_device(dev_id)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_id))

@@ -133,8 +133,13 @@ Rccl &rccl()
     static Rccl r;
     if (r.lib) return r;
     // loaded on demand: a single-GPU user of this library never maps librccl
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    // (a copy the process has mapped already -- e.g. the one PyTorch ships -- is
+    // taken first, so that there is one RCCL per process)
+    for (int flags : {RTLD_NOW | RTLD_NOLOAD, RTLD_NOW | RTLD_GLOBAL}) {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.lib = dlopen(name, flags);
+            if (r.lib) break;
+        }
         if (r.lib) break;
     }
     if (!r.lib) throw FatalError(std::string("cannot load librccl: ") + dlerror());

@@ -222,6 +222,41 @@ __device__ __forceinline__ void run_units(const KernelArgs &a, const SpxRowBlock
     }
 }
 
+// lane ^ 1, ^ 2, ^ 4 inside groups of eight lanes as DPP moves (VALU) instead of
+// ds_bpermute (__shfl_xor goes through the LDS crossbar): quad_perm for 1 and 2,
+// row_half_mirror followed by a reversed quad for 4 (lane i <- 7-i <- (7-i)^3 = i^4).
+template <int DPP_CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), DPP_CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), DPP_CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double xchg1(double v)
+{
+#ifdef SPX_SYM_BPERMUTE
+    return __shfl_xor(v, 1);
+#else
+    return dpp_mov_f64<0xB1>(v);                       // quad_perm [1,0,3,2]
+#endif
+}
+__device__ __forceinline__ double xchg2(double v)
+{
+#ifdef SPX_SYM_BPERMUTE
+    return __shfl_xor(v, 2);
+#else
+    return dpp_mov_f64<0x4E>(v);                       // quad_perm [2,3,0,1]
+#endif
+}
+__device__ __forceinline__ double xchg4(double v)
+{
+#ifdef SPX_SYM_BPERMUTE
+    return __shfl_xor(v, 4);
+#else
+    return dpp_mov_f64<0x1B>(dpp_mov_f64<0x141>(v));   // row_half_mirror, then quad_perm [3,2,1,0]
+#endif
+}
+
 // A pass of symmetric tiles (SPX_PASS_SYMTILE): lanes 8t..8t+7 hold the rows of
 // the dense 8x8 tile t of the stored lower triangle.  Each value is read once
 // and used twice: a(r,c)*x[c] summed along the lane's row goes to the y tile,
@@ -282,7 +317,7 @@ __device__ __forceinline__ void symtile_pass(const KernelArgs &a, const SpxRowBl
         for (int w = 0; w < 4; ++w) {
             const double send = hi ? p8[w] : p8[w + 4];
             const double keep = hi ? p8[w + 4] : p8[w];
-            p4[w] = keep + __shfl_xor(send, 4);
+            p4[w] = keep + xchg4(send);
         }
     }
     // lane^2: lanes with bit 1 clear keep the lower two of their four columns
@@ -293,7 +328,7 @@ __device__ __forceinline__ void symtile_pass(const KernelArgs &a, const SpxRowBl
         for (int w = 0; w < 2; ++w) {
             const double send = hi ? p4[w] : p4[w + 2];
             const double keep = hi ? p4[w + 2] : p4[w];
-            p2[w] = keep + __shfl_xor(send, 2);
+            p2[w] = keep + xchg2(send);
         }
     }
     // lane^1: one column each -- lane i of the tile holds column i
@@ -302,7 +337,7 @@ __device__ __forceinline__ void symtile_pass(const KernelArgs &a, const SpxRowBl
         const bool hi = (i & 1) != 0;
         const double send = hi ? p2[0] : p2[1];
         const double keep = hi ? p2[1] : p2[0];
-        cs = keep + __shfl_xor(send, 1);
+        cs = keep + xchg1(send);
     }
 #endif
 #ifdef SPX_ABL_SYM_NOATOMIC

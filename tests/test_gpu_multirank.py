@@ -74,3 +74,36 @@ def test_one_rank_runs_the_same_workload():
     assert one["config"]["nnz"] == two["config"]["nnz"] and one["config"]["nrows"] == two["config"]["nrows"]
     assert one["config"]["workload"] == two["config"]["workload"]
     assert one["scaling"] == two["scaling"] == "strong"
+
+
+@pytest.mark.gpu
+def test_rccl_transport_single_rank():
+    """The built-in transport on the one GPU of this box: librccl is loaded on demand, a
+    communicator of one rank is created from a unique id, a matrix attaches to it and
+    spx_hip_matvec_dist runs (nothing to exchange with one rank).  The pairwise exchange
+    itself needs several GPUs (RCCL refuses two ranks on one device)."""
+    import numpy as np
+    import torch
+    import sparsex_amd as sx
+    from sparsex_amd import synth
+    from helpers import tune, check_y
+    uid = sx.rccl_unique_id()
+    assert len(uid) == 128
+    t = sx.RcclTransport(uid, 0, 1)
+    for sym in (False, True):
+        csr = synth.syn_nd24k(0.03)
+        n = csr[3]
+        A = tune(csr, {}, sym=sym)
+        A.dist_attach(t)
+        plan = A.dist_plan()
+        assert plan["world"] == 1 and list(plan["row_lo"]) == [0] and list(plan["row_hi"]) == [n]
+        assert not plan["any_exchange"] and plan["send_rows"].size == 0
+        xh = synth.random_x(n)
+        x = torch.from_numpy(xh).cuda()
+        y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+        A.hip_matvec_dist(0.5, x.data_ptr(), 0.0, y.data_ptr(), sx.SPX_DIST_GATHER_Y,
+                          torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        check_y(csr, xh, y.cpu().numpy(), 0.5)
+        A.destroy()
+    t.destroy()
