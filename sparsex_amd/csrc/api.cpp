@@ -617,6 +617,7 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     A->emit_params.sym_remine = cfg.get_bool("spx.gpu.sym_remine");
     A->emit_params.sym_once = cfg.get_bool("spx.gpu.sym_once");
     A->emit_params.recut_linear = cfg.get_bool("spx.gpu.recut_linear");
+    A->emit_params.x_window = cfg.get_bool("spx.gpu.x_window");
     A->emit_params.stack_segments = cfg.get_bool("spx.gpu.stack_segments");
     {
         idx_t lo = nown ? A->bounds[first].row_start : 0;
@@ -929,7 +930,7 @@ spx_error_t spx_mat_set_entry(spx_matrix_t *A, spx_index_t row, spx_index_t colu
 
 namespace {
 
-const char kMagic[8] = {'S', 'P', 'X', 'H', 'I', 'P', '1', '0'};
+const char kMagic[8] = {'S', 'P', 'X', 'H', 'I', 'P', '1', '1'};
 
 template <typename T>
 bool put_vec(FILE *f, const std::vector<T> &v)

@@ -43,8 +43,8 @@ struct Group {
 
 class RbBuilder {
 public:
-    RbBuilder(const Partition &p, GpuStream &out, bool stack = true)
-        : p_(p), out_(out), stack_(stack) {}
+    RbBuilder(const Partition &p, GpuStream &out, bool stack = true, bool x_window = true)
+        : p_(p), out_(out), stack_(stack), x_window_(x_window) {}
 
     // emits one row-block for rows [lo, hi) from the given pieces/singles
     void emit(idx_t lo, idx_t hi, const std::vector<Piece> &pieces,
@@ -74,6 +74,7 @@ private:
     const Partition &p_;
     GpuStream &out_;
     bool stack_;
+    bool x_window_;
     std::vector<Group> groups_;
     std::vector<val_t> gvals_;
 };
@@ -330,6 +331,12 @@ void RbBuilder::emit_unit_passes(SpxRowBlock &rb)
 // reduction, and lanes of a pass mostly hit different rows (same-address LDS
 // adds are serialised at ~3 clocks each).  Pieces are grouped by size so that a
 // pass is uniform, like the unit passes.
+//
+// Where many of the row-block's leftovers have their columns close together (a
+// web graph's links inside a site, the couplings of a band), those columns
+// become the row-block's x window: the workgroup stages x[window] in LDS with
+// coalesced loads and these leftovers gather from LDS (SPX_PASS_GATHER_LDS, u16
+// offsets); the others gather through L2 as before.
 void RbBuilder::emit_gather_passes(SpxRowBlock &rb, std::vector<Single> &singles, idx_t lo)
 {
     std::sort(singles.begin(), singles.end(), [](const Single &x, const Single &y) {
@@ -342,64 +349,135 @@ void RbBuilder::emit_gather_passes(SpxRowBlock &rb, std::vector<Single> &singles
     rb.cidx_off = (uint32_t)(cbytes / 16);
     rb.cidx_width = 2;
     if (!n) return;
-    idx_t cmin = singles[0].col, cmax = singles[0].col;
-    for (const Single &s : singles) {
-        cmin = std::min(cmin, s.col);
-        cmax = std::max(cmax, s.col);
-    }
-    rb.cbase = (uint32_t) cmin;
-    rb.cidx_width = ((size_t)(cmax - cmin) < 65536) ? 2 : 4;
-    struct Piece2 { uint32_t first; uint8_t width; };
-    std::vector<Piece2> pcs;
-    for (size_t i = 0; i < n;) {
-        size_t j = i;
-        while (j < n && singles[j].row == singles[i].row) ++j;
-        for (size_t k = i; k < j; k += SPX_MAX_SEG_WIDTH)
-            pcs.push_back(Piece2{(uint32_t) k, (uint8_t) std::min<size_t>(SPX_MAX_SEG_WIDTH, j - k)});
-        i = j;
-    }
-    std::stable_sort(pcs.begin(), pcs.end(),
-                     [](const Piece2 &a, const Piece2 &b) { return a.width < b.width; });
-    auto put_off = [&](size_t at, uint32_t off) {
-        if (rb.cidx_width == 2) {
-            uint16_t o = (uint16_t) off;
-            std::memcpy(&out_.cidx[cbytes + at * 2], &o, 2);
-        } else {
-            std::memcpy(&out_.cidx[cbytes + at * 4], &off, 4);
-        }
-    };
-    out_.cidx.resize(cbytes + n * rb.cidx_width, 0);
-    size_t elems_before = 0, pieces_before = 0;
-    for (size_t b = 0; b < pcs.size();) {
-        const uint32_t W = pcs[b].width;
-        size_t e = b;
-        while (e < pcs.size() && e - b < SPX_PASS_SEGS && pcs[e].width == W) ++e;
-        const size_t nseg = e - b;
-        SpxPass ps;
-        std::memset(&ps, 0, sizeof(ps));
-        if (out_.values.size() % 2) out_.values.push_back(0.0);
-        ps.val_off = (uint32_t)(out_.values.size() - rb.val_off);
-        ps.seg0 = (uint16_t) pieces_before;
-        ps.nseg = (uint8_t) nseg;
-        ps.width = (uint8_t) W;
-        ps.kind = SPX_PASS_GATHER;
-        ps.elem0 = (uint32_t) elems_before;
-        const size_t base = out_.values.size();
-        out_.values.resize(base + nseg * W, 0.0);
-        for (size_t l = 0; l < nseg; ++l) {
-            const Piece2 &pc = pcs[b + l];
-            out_.segrows.push_back((uint16_t)(singles[pc.first].row - lo));
-            for (uint32_t w = 0; w < W; ++w) {
-                const Single &s = singles[pc.first + w];
-                out_.values[base + spx_pass_value_index((uint32_t) l, w, (uint32_t) nseg, W)] = s.val;
-                put_off(elems_before + (size_t) w * nseg + l, (uint32_t)(s.col - cmin));
+
+    // The x window: the run of columns (at most SPX_MAX_XWIN wide) whose staging
+    // pays best -- every leftover inside saves a scattered 64-byte request, every
+    // double staged costs 8 coalesced bytes: maximise 8 * count - span.
+    idx_t wlo = 0, whi = -1;
+    if (x_window_ && n >= 64) {
+        std::vector<idx_t> cols(n);
+        for (size_t i = 0; i < n; ++i) cols[i] = singles[i].col;
+        std::sort(cols.begin(), cols.end());
+        // for the right end b the best left end a maximises cols[a] - 8a among the
+        // a with cols[b] - cols[a] < SPX_MAX_XWIN - 1 (a monotonic queue)
+        std::vector<size_t> dq;
+        size_t head = 0;
+        int64_t best = 0;
+        auto key = [&](size_t a) { return (int64_t) cols[a] - 8 * (int64_t) a; };
+        for (size_t b = 0; b < n; ++b) {
+            while (dq.size() > head && key(dq.back()) <= key(b)) dq.pop_back();
+            dq.push_back(b);
+            while (cols[b] - cols[dq[head]] >= (idx_t) SPX_MAX_XWIN - 1) ++head;
+            const size_t a = dq[head];
+            const int64_t gain = 8 * (int64_t)(b - a + 1) - (int64_t)(cols[b] - cols[a] + 1);
+            if (gain > best) {
+                best = gain;
+                wlo = cols[a];
+                whi = cols[b];
             }
         }
-        out_.passes.push_back(ps);
-        ++rb.n_pass;
-        elems_before += nseg * W;
-        pieces_before += nseg;
-        b = e;
+        wlo &= ~(idx_t) 1;
+        size_t inside = 0;
+        for (idx_t c : cols) inside += c >= wlo && c <= whi;
+        if (inside < 64 || best <= 0) whi = wlo - 1;     // too few to be worth a pass of their own
+    }
+    std::vector<Single> near;
+    if (whi >= wlo) {
+        std::vector<Single> far;
+        for (const Single &s : singles) (s.col >= wlo && s.col <= whi ? near : far).push_back(s);
+        singles.swap(far);
+        rb.xwin_base = (uint32_t) wlo;
+        rb.xwin_len = (uint16_t)(whi - wlo + 1);
+        out_.lds_doubles = std::max<uint32_t>(out_.lds_doubles,
+                                              (uint32_t) rb.n_slots + rb.n_rows + rb.xwin_len);
+    }
+
+    struct Piece2 { uint32_t first; uint8_t width; };
+    size_t pieces_before = 0;
+    // one set of passes: `set` sorted by (row, col); offsets of `width` bytes relative
+    // to `base`, appended to the row-block's offset area.  Pieces are taken in order
+    // of their size, 64 to a pass; a pass is as wide as its longest piece and the
+    // shorter ones are padded (zero value, offset 0; the piece's length travels with
+    // its row in `segrows`, the lanes skip what is not there).  A pass is closed
+    // early when the padding would pass 30 % of it.
+    auto emit_set = [&](const std::vector<Single> &set, uint8_t kind, idx_t base, unsigned width,
+                        size_t area) {
+        const size_t m = set.size();
+        std::vector<Piece2> pcs;
+        for (size_t i = 0; i < m;) {
+            size_t j = i;
+            while (j < m && set[j].row == set[i].row) ++j;
+            for (size_t k = i; k < j; k += SPX_MAX_SEG_WIDTH)
+                pcs.push_back(Piece2{(uint32_t) k, (uint8_t) std::min<size_t>(SPX_MAX_SEG_WIDTH, j - k)});
+            i = j;
+        }
+        std::stable_sort(pcs.begin(), pcs.end(),
+                         [](const Piece2 &a, const Piece2 &b) { return a.width < b.width; });
+        auto put_off = [&](size_t at, uint32_t off) {
+            if (width == 2) {
+                uint16_t o = (uint16_t) off;
+                std::memcpy(&out_.cidx[area + at * 2], &o, 2);
+            } else {
+                std::memcpy(&out_.cidx[area + at * 4], &off, 4);
+            }
+        };
+        size_t elems_before = 0;
+        for (size_t b = 0; b < pcs.size();) {
+            size_t e = b, real = 0;
+            while (e < pcs.size() && e - b < SPX_PASS_SEGS) {
+                const size_t w = pcs[e].width, lanes = e - b + 1;
+                if (e - b >= 16 && (lanes * w - (real + w)) * 10 > lanes * w * 3) break;
+                real += w;
+                ++e;
+            }
+            const uint32_t W = pcs[e - 1].width;
+            const size_t nseg = e - b;
+            SpxPass ps;
+            std::memset(&ps, 0, sizeof(ps));
+            if (out_.values.size() % 2) out_.values.push_back(0.0);
+            ps.val_off = (uint32_t)(out_.values.size() - rb.val_off);
+            ps.seg0 = (uint16_t) pieces_before;
+            ps.nseg = (uint8_t) nseg;
+            ps.width = (uint8_t) W;
+            ps.kind = kind;
+            ps.elem0 = (uint32_t) elems_before;
+            const size_t vbase = out_.values.size();
+            out_.values.resize(vbase + nseg * W, 0.0);
+            out_.cidx.resize(area + (elems_before + nseg * W) * width, 0);
+            for (size_t l = 0; l < nseg; ++l) {
+                const Piece2 &pc = pcs[b + l];
+                out_.segrows.push_back((uint16_t)((set[pc.first].row - lo) | ((pc.width - 1u) << 9)));
+                for (uint32_t w = 0; w < pc.width; ++w) {
+                    const Single &s = set[pc.first + w];
+                    out_.values[vbase + spx_pass_value_index((uint32_t) l, w, (uint32_t) nseg, W)] = s.val;
+                    put_off(elems_before + (size_t) w * nseg + l, (uint32_t)(s.col - base));
+                }
+            }
+            out_.passes.push_back(ps);
+            ++rb.n_pass;
+            elems_before += nseg * W;
+            pieces_before += nseg;
+            b = e;
+        }
+    };
+    if (!singles.empty()) {
+        idx_t cmin = singles[0].col, cmax = singles[0].col;
+        for (const Single &s : singles) {
+            cmin = std::min(cmin, s.col);
+            cmax = std::max(cmax, s.col);
+        }
+        rb.cbase = (uint32_t) cmin;
+        rb.cidx_width = ((size_t)(cmax - cmin) < 65536) ? 2 : 4;
+        emit_set(singles, SPX_PASS_GATHER, cmin, rb.cidx_width, cbytes);
+    }
+    if (!near.empty()) {
+        while (out_.cidx.size() % 16) out_.cidx.push_back(0);
+        const size_t nbytes = out_.cidx.size();
+        if ((nbytes - cbytes) / 16 > 0xffff) throw FatalError("offset area of a row-block too large");
+        rb.near_off = (uint16_t)((nbytes - cbytes) / 16);
+        emit_set(near, SPX_PASS_GATHER_LDS, wlo, 2, nbytes);
+        // (the caller accounts for the leftovers through `singles`)
+        singles.insert(singles.end(), near.begin(), near.end());
     }
 }
 
@@ -1173,7 +1251,7 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsi
         dst.shared.push_back(sr);
     };
     if (nthreads <= 1 || plans.size() < 64) {
-        RbBuilder bld(p, out, prm.stack_segments);
+        RbBuilder bld(p, out, prm.stack_segments, prm.x_window);
         for (size_t i = 0; i < plans.size(); ++i) emit_plan(i, bld, out);
         return;
     }
@@ -1181,7 +1259,7 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsi
     std::vector<GpuStream> locs(n_chunks);
     parallel_for(n_chunks, nthreads, [&](size_t c) {
         const size_t lo = plans.size() * c / n_chunks, hi = plans.size() * (c + 1) / n_chunks;
-        RbBuilder bld(p, locs[c], prm.stack_segments);
+        RbBuilder bld(p, locs[c], prm.stack_segments, prm.x_window);
         for (size_t i = lo; i < hi; ++i) emit_plan(i, bld, locs[c]);
     });
     for (GpuStream &l : locs) append_stream(out, std::move(l));

@@ -82,6 +82,8 @@ struct GpuEmitParams {
     bool recut_linear = true;     // spx.gpu.recut_linear: nonzeros of vertical / diagonal /
                                   // strided units that line up along their rows run as row segments
     bool sym_remine = true;       // spx.gpu.sym_remine (see append_sym_expanded)
+    bool x_window = true;         // spx.gpu.x_window: stage a window of x in LDS for leftovers
+                                  // whose columns lie close together
     bool sym_once = true;         // spx.gpu.sym_once: dense 8x8 tiles of a symmetric matrix are
                                   // read once (one process holding the whole matrix only)
     const std::vector<SymTile> *tiles = nullptr;   // symmetric, fused: tiles read once (sorted by row0)

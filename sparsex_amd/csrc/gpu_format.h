@@ -32,7 +32,10 @@
  * leftovers are cut into pieces of at most SPX_MAX_SEG_WIDTH nonzeros; a lane
  * owns one piece -- W values, W u16/u32 column offsets (relative to cbase,
  * element-major [W][nseg]), one u16 row -- and adds one partial sum, exactly
- * like a unit pass whose columns are not consecutive.
+ * like a unit pass whose columns are not consecutive.  Where enough of a
+ * row-block's leftovers have their columns close together, the workgroup stages
+ * that window of x in LDS (coalesced loads) and those leftovers gather from LDS
+ * (SPX_PASS_GATHER_LDS); far columns keep gathering through L2.
  *
  * The emitter (gpu_emit.cpp) shapes the segments for the lanes: nonzeros of
  * one-wide units that line up along their rows are re-cut into row segments,
@@ -67,7 +70,17 @@
 #define SPX_PASS_GATHER 2    /* leftover nonzeros as row pieces: lane l owns up to
                                 SPX_MAX_SEG_WIDTH nonzeros of ONE row with explicit
                                 column offsets; values interleaved like a unit
-                                pass, offsets element-major [W][nseg]             */
+                                pass, offsets element-major [W][nseg].  The row-
+                                block's u16 `segrows` entry of a piece holds its row
+                                (bits 0-8) and its length - 1 (bits 9-11): a pass is
+                                as wide as its longest piece, shorter ones are padded */
+
+#define SPX_PASS_GATHER_LDS 4 /* the same, for leftovers whose columns fall into the
+                                row-block's x window: the workgroup stages
+                                x[xwin_base, xwin_base + xwin_len) in LDS once,
+                                coalesced, and the lanes gather from there; u16
+                                offsets relative to xwin_base                      */
+#define SPX_MAX_XWIN    4096  /* doubles of x a row-block may stage in LDS (32 KB)  */
 
 #define SPX_KIND_BLOCK  0u   /* rows of a dense block: drow 1, dcol 0             */
 #define SPX_KIND_HORIZ  1u   /* same row, column step `step`                      */
@@ -99,7 +112,7 @@ typedef struct {
                             row-block's u16 rows at seg_off)                     */
     uint8_t  nseg;       /* active lanes, 1..64                                  */
     uint8_t  width;      /* W: nonzeros per lane                                 */
-    uint8_t  kind;       /* SPX_PASS_UNIT / SPX_PASS_GATHER                      */
+    uint8_t  kind;       /* SPX_PASS_UNIT / _GATHER / _GATHER_LDS / _SYMTILE      */
     uint8_t  pad_;
     uint32_t elem0;      /* gather pass: leftover nonzeros of the row-block in
                             front of this pass (index of its first column offset) */
@@ -125,7 +138,11 @@ typedef struct {
     uint32_t carry_slot;  /* SPX_RB_SHARED: slot of the partial sum             */
     uint32_t spill_off;   /* the n_slots sums go to spill[spill_off ...]; a second
                              kernel adds them to the rows they belong to          */
-} SpxRowBlock;            /* 48 bytes */
+    uint32_t xwin_base;   /* first column of the x window staged in LDS          */
+    uint16_t xwin_len;    /* its length in doubles (0: none), <= SPX_MAX_XWIN    */
+    uint16_t near_off;    /* u16 offsets of the SPX_PASS_GATHER_LDS passes start
+                             at cidx_off * 16 + near_off * 16 bytes               */
+} SpxRowBlock;            /* 56 bytes */
 
 #define SPX_RB_SHARED 1u  /* owns one chunk of an over-long row; the partial
                              goes to carry[carry_slot] and a fix-up kernel sums */

@@ -76,9 +76,13 @@ __device__ __forceinline__ uint32_t starts_upto(uint64_t mask, int lane)
 // G (gather pass): the lane's segment is a piece of one row's leftover
 // nonzeros; its row comes from the row-block's u16 rows and every nonzero has
 // its own column offset (element-major [W][nseg]) instead of a descriptor.
-template <int W, int B, bool G>
+//
+// G == 2 (SPX_PASS_GATHER_LDS): the same, but the columns lie in the row-block's
+// x window, which the workgroup has staged in LDS (`win`): u16 offsets, ds_read.
+template <int W, int B, int G>
 __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlock &rb,
-                                            const SpxPass (&ps)[B], double *tile, int lane)
+                                            const SpxPass (&ps)[B], double *tile,
+                                            const double *win, int lane)
 {
     bool active[B];
     uint32_t l[B], nseg[B];
@@ -91,9 +95,9 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
         l[b] = active[b] ? (uint32_t) lane : 0u;         // idle lanes shadow lane 0
         if (G) {
             q[b].x = a.segrows[rb.seg_off + ps[b].seg0 + l[b]];
-            const uint8_t *cidx = a.cidx + (size_t) rb.cidx_off * 16u;
+            const uint8_t *cidx = a.cidx + ((size_t) rb.cidx_off + (G == 2 ? rb.near_off : 0u)) * 16u;
             const uint32_t e0 = ps[b].elem0 + l[b];
-            if (rb.cidx_width == 4) {
+            if (G == 1 && rb.cidx_width == 4) {
 #pragma unroll
                 for (int w = 0; w < W; ++w)
                     goff[b][w] = reinterpret_cast<const uint32_t *>(cidx)[e0 + (uint32_t) w * nseg[b]];
@@ -136,15 +140,26 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
 #pragma unroll
     for (int b = 0; b < B; ++b) {
         double x[W];
-        if (G) {
-            row[b] = (int) q[b].x;
+        if (G == 2) {
+            // (a piece shorter than the pass is padded: nothing is multiplied there)
+            row[b] = (int) (q[b].x & 511u);
+            const int len = (int) (q[b].x >> 9) + 1;
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const double xv = win[goff[b][w]];
+                x[w] = w < len ? xv : 0.0;
+            }
+        } else if (G) {
+            row[b] = (int) (q[b].x & 511u);
+            const int len = (int) (q[b].x >> 9) + 1;
             const double *xp = a.x + rb.cbase;
 #pragma unroll
             for (int w = 0; w < W; ++w) {
 #ifdef SPX_ABL_NOX
                 x[w] = (double) goff[b][w];
 #else
-                x[w] = xp[goff[b][w]];
+                const double xv = xp[goff[b][w]];
+                x[w] = w < len ? xv : 0.0;
 #endif
             }
         } else {
@@ -182,7 +197,7 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
     for (int b = 0; b < B; ++b)
         if (active[b] && acc[b] == 1.2345) tile[row[b]] = acc[b];
 #else
-    if (G && rb.n_rows == 1) {
+    if (G == 1 && rb.n_rows == 1) {
         // a chunk of one over-long row: every lane targets tile[0]
         double t = 0.0;
 #pragma unroll
@@ -198,26 +213,27 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
 #endif
 }
 
-template <int B, bool G>
+template <int B, int G>
 __device__ __forceinline__ void run_units(const KernelArgs &a, const SpxRowBlock &rb,
-                                          const SpxPass (&ps)[B], double *tile, int lane)
+                                          const SpxPass (&ps)[B], double *tile, const double *win,
+                                          int lane)
 {
     switch (ps[0].width) {         // wave-uniform
-    case 1: unit_passes<1, B, G>(a, rb, ps, tile, lane); break;
-    case 2: unit_passes<2, B, G>(a, rb, ps, tile, lane); break;
-    case 3: unit_passes<3, B, G>(a, rb, ps, tile, lane); break;
-    case 4: unit_passes<4, B, G>(a, rb, ps, tile, lane); break;
-    case 5: unit_passes<5, 1, G>(a, rb, {ps[0]}, tile, lane);
-            if (B > 1) unit_passes<5, 1, G>(a, rb, {ps[B - 1]}, tile, lane);
+    case 1: unit_passes<1, B, G>(a, rb, ps, tile, win, lane); break;
+    case 2: unit_passes<2, B, G>(a, rb, ps, tile, win, lane); break;
+    case 3: unit_passes<3, B, G>(a, rb, ps, tile, win, lane); break;
+    case 4: unit_passes<4, B, G>(a, rb, ps, tile, win, lane); break;
+    case 5: unit_passes<5, 1, G>(a, rb, {ps[0]}, tile, win, lane);
+            if (B > 1) unit_passes<5, 1, G>(a, rb, {ps[B - 1]}, tile, win, lane);
             break;
-    case 6: unit_passes<6, 1, G>(a, rb, {ps[0]}, tile, lane);
-            if (B > 1) unit_passes<6, 1, G>(a, rb, {ps[B - 1]}, tile, lane);
+    case 6: unit_passes<6, 1, G>(a, rb, {ps[0]}, tile, win, lane);
+            if (B > 1) unit_passes<6, 1, G>(a, rb, {ps[B - 1]}, tile, win, lane);
             break;
-    case 7: unit_passes<7, 1, G>(a, rb, {ps[0]}, tile, lane);
-            if (B > 1) unit_passes<7, 1, G>(a, rb, {ps[B - 1]}, tile, lane);
+    case 7: unit_passes<7, 1, G>(a, rb, {ps[0]}, tile, win, lane);
+            if (B > 1) unit_passes<7, 1, G>(a, rb, {ps[B - 1]}, tile, win, lane);
             break;
-    default: unit_passes<8, 1, G>(a, rb, {ps[0]}, tile, lane);
-            if (B > 1) unit_passes<8, 1, G>(a, rb, {ps[B - 1]}, tile, lane);
+    default: unit_passes<8, 1, G>(a, rb, {ps[0]}, tile, win, lane);
+            if (B > 1) unit_passes<8, 1, G>(a, rb, {ps[B - 1]}, tile, win, lane);
             break;
     }
 }
@@ -351,10 +367,11 @@ __device__ __forceinline__ void symtile_pass(const KernelArgs &a, const SpxRowBl
 }
 
 __device__ __forceinline__ void run_pass(const KernelArgs &a, const SpxRowBlock &rb,
-                                         const SpxPass &ps, double *tile, int lane)
+                                         const SpxPass &ps, double *tile, const double *win, int lane)
 {
-    if (ps.kind == SPX_PASS_GATHER) run_units<1, true>(a, rb, {ps}, tile, lane);
-    else run_units<1, false>(a, rb, {ps}, tile, lane);
+    if (ps.kind == SPX_PASS_GATHER) run_units<1, 1>(a, rb, {ps}, tile, win, lane);
+    else if (ps.kind == SPX_PASS_GATHER_LDS) run_units<1, 2>(a, rb, {ps}, tile, win, lane);
+    else run_units<1, 0>(a, rb, {ps}, tile, win, lane);
 }
 
 // One workgroup owns one row-block; its wavefronts take the passes in turn
@@ -392,6 +409,14 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, uint32_t blocks_p
     const int n_slots = SYM ? (int) rb.n_slots : 0;
     double *tile = lds + n_slots;
     for (int i = threadIdx.x; i < n_slots + n_rows; i += BLOCK_THREADS) lds[i] = 0.0;
+    // the row-block's x window (leftovers whose columns lie close together gather
+    // from LDS): staged once, coalesced
+    double *win = tile + n_rows;
+    {
+        const int xw = rb.xwin_len;
+        const double *xs = a.x + rb.xwin_base;
+        for (int i = threadIdx.x; i < xw; i += BLOCK_THREADS) win[i] = xs[i];
+    }
     __syncthreads();
 
     // wave w takes passes w, w+4, ..., two at a time when they have the same
@@ -407,19 +432,20 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, uint32_t blocks_p
             symtile_pass(a, rb, p0, lds, tile, lane);
             if (two) {
                 if (p1.kind == SPX_PASS_SYMTILE) symtile_pass(a, rb, p1, lds, tile, lane);
-                else run_pass(a, rb, p1, tile, lane);
+                else run_pass(a, rb, p1, tile, win, lane);
             }
         } else if (two) {
             if (p0.kind == p1.kind && p0.width == p1.width) {
-                if (p0.kind == SPX_PASS_GATHER) run_units<2, true>(a, rb, {p0, p1}, tile, lane);
-                else run_units<2, false>(a, rb, {p0, p1}, tile, lane);
+                if (p0.kind == SPX_PASS_GATHER) run_units<2, 1>(a, rb, {p0, p1}, tile, win, lane);
+                else if (p0.kind == SPX_PASS_GATHER_LDS) run_units<2, 2>(a, rb, {p0, p1}, tile, win, lane);
+                else run_units<2, 0>(a, rb, {p0, p1}, tile, win, lane);
             } else {
-                run_pass(a, rb, p0, tile, lane);
+                run_pass(a, rb, p0, tile, win, lane);
                 if (SYM && p1.kind == SPX_PASS_SYMTILE) symtile_pass(a, rb, p1, lds, tile, lane);
-                else run_pass(a, rb, p1, tile, lane);
+                else run_pass(a, rb, p1, tile, win, lane);
             }
         } else {
-            run_pass(a, rb, p0, tile, lane);
+            run_pass(a, rb, p0, tile, win, lane);
         }
         if (t + 2 * WAVES_PER_BLOCK < n_pass) {
             p0 = passes[t + 2 * WAVES_PER_BLOCK];
@@ -476,8 +502,8 @@ __global__ __launch_bounds__(64 * WAVES)
 void csx_spmv_kernel(SPX_KERNEL_PARAMS)
 {
     SPX_KERNEL_ARGS(a);
-    __shared__ double tile[SPX_MAX_RB_ROWS];
-    spmv_body<false, false, WAVES>(a, blocks_per_xcd, tile);
+    extern __shared__ double lds_dyn[];      // y tile, then the x window
+    spmv_body<false, false, WAVES>(a, blocks_per_xcd, lds_dyn);
 }
 
 template <int WAVES>
@@ -753,9 +779,10 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
                                0, stream, m->fix_ptr, m->fix_idx, m->spill, d_y, alpha,
                                (uint32_t) m->nrows);
     } else if (blocks) {
-        if (m->waves == 2) SPX_LAUNCH(csx_spmv_kernel, 2, 0);
-        else if (m->waves == 8) SPX_LAUNCH(csx_spmv_kernel, 8, 0);
-        else SPX_LAUNCH(csx_spmv_kernel, 4, 0);
+        const size_t lds = m->lds_doubles * sizeof(double);
+        if (m->waves == 2) SPX_LAUNCH(csx_spmv_kernel, 2, lds);
+        else if (m->waves == 8) SPX_LAUNCH(csx_spmv_kernel, 8, lds);
+        else SPX_LAUNCH(csx_spmv_kernel, 4, lds);
     }
 #undef SPX_LAUNCH
     if (m->n_shared)

@@ -34,17 +34,28 @@ inline void unit_lane(const GpuStream &s, const SpxRowBlock &rb, const SpxPass &
     col = (int64_t) d.col0 + (int64_t) sidx * dcol;
 }
 
-inline uint32_t gather_off(const GpuStream &s, const SpxRowBlock &rb, size_t e)
+// column of leftover e of a gather pass (through L2, or from the x window)
+inline int64_t gather_col(const GpuStream &s, const SpxRowBlock &rb, const SpxPass &ps, size_t e)
 {
+    if (ps.kind == SPX_PASS_GATHER_LDS) {
+        uint16_t v;
+        std::memcpy(&v, s.cidx.data() + ((size_t) rb.cidx_off + rb.near_off) * 16u + e * 2, 2);
+        return (int64_t) rb.xwin_base + v;
+    }
     const uint8_t *c = s.cidx.data() + (size_t) rb.cidx_off * 16u;
     if (rb.cidx_width == 4) {
         uint32_t v;
         std::memcpy(&v, c + e * 4, 4);
-        return v;
+        return (int64_t) rb.cbase + v;
     }
     uint16_t v;
     std::memcpy(&v, c + e * 2, 2);
-    return v;
+    return (int64_t) rb.cbase + v;
+}
+
+inline bool is_gather(const SpxPass &ps)
+{
+    return ps.kind == SPX_PASS_GATHER || ps.kind == SPX_PASS_GATHER_LDS;
 }
 
 }  // namespace
@@ -66,12 +77,12 @@ void stream_locate(const GpuStream &s, idx_t row, idx_t col, std::vector<size_t>
             const SpxPass &ps = s.passes[(size_t) rb.pass_off + t];
             const uint32_t nseg = ps.nseg, W = ps.width;
             const size_t vbase = (size_t) rb.val_off + ps.val_off;
-            if (ps.kind == SPX_PASS_GATHER) {
+            if (is_gather(ps)) {
                 for (uint32_t l = 0; l < nseg; ++l) {
-                    if ((int64_t) s.segrows[(size_t) rb.seg_off + ps.seg0 + l] != rrel) continue;
-                    for (uint32_t w = 0; w < W; ++w) {
-                        const int64_t c = (int64_t) rb.cbase +
-                                          gather_off(s, rb, (size_t) ps.elem0 + l + (size_t) w * nseg);
+                    const uint32_t sr = s.segrows[(size_t) rb.seg_off + ps.seg0 + l];
+                    if ((int64_t) (sr & 511u) != rrel) continue;
+                    for (uint32_t w = 0; w < W && w <= (sr >> 9); ++w) {
+                        const int64_t c = gather_col(s, rb, ps, (size_t) ps.elem0 + l + (size_t) w * nseg);
                         if (c == (int64_t) col) out.push_back(vbase + spx_pass_value_index(l, w, nseg, W));
                     }
                 }
@@ -108,8 +119,8 @@ void stream_touched_rows(const GpuStream &s, idx_t below, std::vector<idx_t> &ro
             const SpxPass &ps = s.passes[(size_t) rb.pass_off + t];
             for (uint32_t l = 0; l < ps.nseg; ++l) {
                 int64_t r;
-                if (ps.kind == SPX_PASS_GATHER) {
-                    r = s.segrows[(size_t) rb.seg_off + ps.seg0 + l];
+                if (is_gather(ps)) {
+                    r = s.segrows[(size_t) rb.seg_off + ps.seg0 + l] & 511u;
                 } else if (ps.kind == SPX_PASS_SYMTILE) {
                     r = (int64_t) (s.descs[(size_t) rb.desc_off + ps.rank0 + (l >> 3)].bits & 511u) + (l & 7u);
                 } else {
@@ -143,7 +154,7 @@ bool stream_validate(const GpuStream &s, size_t nrows, size_t ncols, size_t n_va
     SPX_REQUIRE(s.rbs.empty() || s.pass_stride >= 1, "pass stride missing");
     SPX_REQUIRE(s.passes.size() == s.rbs.size() * (size_t) s.pass_stride, "pass table size");
     SPX_REQUIRE(s.waves == 2 || s.waves == 4 || s.waves == 8, "wavefronts per workgroup");
-    SPX_REQUIRE(s.lds_doubles <= SPX_MAX_TILE_SLOTS + SPX_MAX_RB_ROWS, "LDS budget");
+    SPX_REQUIRE(s.lds_doubles <= SPX_MAX_TILE_SLOTS + SPX_MAX_RB_ROWS + SPX_MAX_XWIN, "LDS budget");
     SPX_REQUIRE(s.n_spill == 0 || (s.fix_ptr.size() == nrows + 1 && s.fix_idx.size() == s.n_spill),
                 "spill lists");
     for (size_t i = 0; i + 1 < s.fix_ptr.size(); ++i)
@@ -165,7 +176,8 @@ bool stream_validate(const GpuStream &s, size_t nrows, size_t ncols, size_t n_va
         SPX_REQUIRE((size_t) rb.cidx_off * 16u <= s.cidx.size(), "row-block column-offset position");
         SPX_REQUIRE(rb.cidx_width == 2 || rb.cidx_width == 4, "column-offset width");
         SPX_REQUIRE(rb.seg_off <= s.segrows.size(), "row-block row-piece offset");
-        SPX_REQUIRE((size_t) rb.n_slots + rb.n_rows <= s.lds_doubles, "row-block LDS use");
+        SPX_REQUIRE((size_t) rb.n_slots + rb.n_rows + rb.xwin_len <= s.lds_doubles, "row-block LDS use");
+        SPX_REQUIRE(rb.xwin_len <= SPX_MAX_XWIN && (size_t) rb.xwin_base + rb.xwin_len <= ncols, "x window");
         SPX_REQUIRE(rb.n_slots == 0 || ((size_t) rb.spill_off + rb.n_slots <= s.n_spill &&
                                         rb.spill_off % 8 == 0 && rb.n_slots % 8 == 0), "spill range");
         if (rb.flags & SPX_RB_SHARED)
@@ -178,17 +190,20 @@ bool stream_validate(const GpuStream &s, size_t nrows, size_t ncols, size_t n_va
             SPX_REQUIRE(ps.val_off % 2 == 0 &&
                         (size_t) rb.val_off + ps.val_off + (size_t) nseg * W <= n_values,
                         "pass value range");
-            if (ps.kind == SPX_PASS_GATHER) {
+            if (is_gather(ps)) {
+                const bool lds = ps.kind == SPX_PASS_GATHER_LDS;
                 SPX_REQUIRE((size_t) rb.seg_off + ps.seg0 + nseg <= s.segrows.size(), "row-piece range");
-                SPX_REQUIRE((size_t) rb.cidx_off * 16u +
-                            ((size_t) ps.elem0 + (size_t) nseg * W) * rb.cidx_width <= s.cidx.size(),
+                SPX_REQUIRE(((size_t) rb.cidx_off + (lds ? rb.near_off : 0u)) * 16u +
+                            ((size_t) ps.elem0 + (size_t) nseg * W) * (lds ? 2u : rb.cidx_width) <= s.cidx.size(),
                             "column-offset range");
                 for (uint32_t l = 0; l < nseg; ++l) {
-                    SPX_REQUIRE(s.segrows[(size_t) rb.seg_off + ps.seg0 + l] < rb.n_rows, "row piece row");
-                    for (uint32_t w = 0; w < W; ++w)
-                        SPX_REQUIRE((size_t) rb.cbase + gather_off(s, rb, (size_t) ps.elem0 + l +
-                                                                            (size_t) w * nseg) < ncols,
-                                    "gathered column");
+                    const uint32_t sr = s.segrows[(size_t) rb.seg_off + ps.seg0 + l];
+                    SPX_REQUIRE((sr & 511u) < rb.n_rows && (sr >> 9) < W, "row piece row");
+                    for (uint32_t w = 0; w < W; ++w) {
+                        const int64_t c = gather_col(s, rb, ps, (size_t) ps.elem0 + l + (size_t) w * nseg);
+                        SPX_REQUIRE(c >= 0 && (size_t) c < ncols, "gathered column");
+                        SPX_REQUIRE(!lds || c < (int64_t) rb.xwin_base + rb.xwin_len, "column outside the x window");
+                    }
                 }
             } else if (ps.kind == SPX_PASS_SYMTILE) {
                 tiles = true;

@@ -10,12 +10,13 @@ import numpy as np
 RB = np.dtype([("val_off", "<u8"), ("pass_off", "<u4"), ("desc_off", "<u4"), ("cidx_off", "<u4"),
                ("seg_off", "<u4"), ("cbase", "<u4"), ("row0", "<u4"), ("n_rows", "<u2"),
                ("n_pass", "<u2"), ("cidx_width", "u1"), ("flags", "u1"), ("n_slots", "<u2"),
-               ("carry_slot", "<u4"), ("spill_off", "<u4")])
+               ("carry_slot", "<u4"), ("spill_off", "<u4"), ("xwin_base", "<u4"), ("xwin_len", "<u2"),
+               ("near_off", "<u2")])
 PASS = np.dtype([("mask", "<u8"), ("val_off", "<u4"), ("rank0", "<u2"), ("seg0", "<u2"),
                  ("nseg", "u1"), ("width", "u1"), ("kind", "u1"), ("pad", "u1"), ("elem0", "<u4")])
 DESC = np.dtype([("col0", "<u4"), ("bits", "<u4")])
 SHARED = np.dtype([("row", "<u4"), ("first_slot", "<u4"), ("n_slots", "<u4")])
-assert RB.itemsize == 48 and PASS.itemsize == 24 and DESC.itemsize == 8
+assert RB.itemsize == 56 and PASS.itemsize == 24 and DESC.itemsize == 8
 
 KIND_BLOCK, KIND_HORIZ, KIND_VERT, KIND_DIAG, KIND_ADIAG = range(5)
 
@@ -24,7 +25,7 @@ class Stream:
     def __init__(self, path):
         with open(path, "rb") as f:
             buf = f.read()
-        assert buf[:8] == b"SPXHIP10", buf[:8]
+        assert buf[:8] == b"SPXHIP11", buf[:8]
         hdr = struct.unpack_from("<4i3Q2i4Q8IQ", buf, 8)
         (self.nrows, self.ncols, self.nnz, self.symmetric, self.nr_partitions, self.first_part,
          self.last_part, self.own_lo, self.own_hi, self.nnz_stored, self.n_unit_elems,
@@ -97,14 +98,19 @@ class Stream:
                             idx = pair * 2 * nseg + lanes * 2 + (w & 1)
                         R.append(row + int(rb["row0"])); Cc.append(col + w)
                         V.append(self.values[pv + idx]); B.append(np.full(nseg, bi))
-                elif ps["kind"] == 2:
-                    # gather pass: lane l owns W leftover nonzeros of one row
+                elif ps["kind"] in (2, 4):
+                    # gather pass: lane l owns W leftover nonzeros of one row; kind 4: their
+                    # columns lie in the row-block's x window (u16 offsets from xwin_base)
                     nseg, W = int(ps["nseg"]), int(ps["width"])
                     assert 1 <= nseg <= 64 and 1 <= W <= 8
                     lanes = np.arange(nseg)
-                    row = self.segrows[int(rb["seg_off"]) + int(ps["seg0"]) + lanes].astype(np.int64)
-                    assert (row < int(rb["n_rows"])).all()
-                    cw = int(rb["cidx_width"])
+                    sr = self.segrows[int(rb["seg_off"]) + int(ps["seg0"]) + lanes].astype(np.int64)
+                    row, plen = sr & 511, (sr >> 9) + 1        # a pass is as wide as its longest piece
+                    assert (row < int(rb["n_rows"])).all() and (plen <= W).all() and plen.max() == W
+                    near = ps["kind"] == 4
+                    cw = 2 if near else int(rb["cidx_width"])
+                    cbase = int(rb["xwin_base"]) if near else int(rb["cbase"])
+                    area = (int(rb["cidx_off"]) + (int(rb["near_off"]) if near else 0)) * 16
                     e0 = int(ps["elem0"])
                     for w in range(W):
                         pair = w >> 1
@@ -112,10 +118,14 @@ class Stream:
                             idx = pair * 2 * nseg + lanes
                         else:
                             idx = pair * 2 * nseg + lanes * 2 + (w & 1)
-                        o = int(rb["cidx_off"]) * 16 + (e0 + w * nseg + lanes) * cw
+                        o = area + (e0 + w * nseg + lanes) * cw
                         off = sum(self.cidx[o + b].astype(np.int64) << (8 * b) for b in range(cw))
-                        R.append(row + int(rb["row0"])); Cc.append(off + int(rb["cbase"]))
-                        V.append(self.values[pv + idx]); B.append(np.full(nseg, bi))
+                        if near:
+                            assert (off < int(rb["xwin_len"])).all() and int(rb["xwin_len"]) <= 4096
+                        have = plen > w                            # (padding: zero value, offset 0)
+                        assert (self.values[pv + idx][~have] == 0).all() and (off[~have] == 0).all()
+                        R.append((row + int(rb["row0"]))[have]); Cc.append((off + cbase)[have])
+                        V.append(self.values[pv + idx][have]); B.append(np.full(int(have.sum()), bi))
                 elif ps["kind"] == 3:
                     # symmetric tiles: lanes 8t..8t+7 = rows of tile t; every value counts twice
                     nseg = int(ps["nseg"])
