@@ -43,7 +43,7 @@ MALL_BYTES = 256 << 20  # Infinity Cache
 ALPHA = 0.5
 BATCHES = 5             # OUTER_LOOPS of the reference harness
 REF_BASELINE_THREADS = [8, 16, 32, 64]   # the counts cpu_baseline() may try
-DEFAULT_EDGE = 120      # syn-nlpkkt grid edge: 3.5 M rows, 184 M nonzeros, 1.5 GB of values
+DEFAULT_EDGE = 190      # syn-nlpkkt grid edge: 13.9 M rows, 734 M nonzeros (nlpkkt240: 760 M), 5.9 GB of values
 SAMPLE_EDGE = 60        # its CPU-baseline sample: the same generator at 1/8 of the nonzeros
 
 
@@ -495,10 +495,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128, help="SpMVs per batch (LOOPS); %d batches are timed" % BATCHES)
     ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--workload", default="syn-nlpkkt", choices=["syn-cant", "syn-nd24k", "syn-webbase", "syn-nlpkkt"])
+    ap.add_argument("--workload", default="syn-nlpkkt", choices=["syn-cant", "syn-nd24k", "syn-webbase", "syn-nlpkkt", "syn-bandrandom"])
     ap.add_argument("--edge", type=int, default=DEFAULT_EDGE,
-                    help="syn-nlpkkt: grid edge (240 = the order of nlpkkt240; the default %d gives 184 M "
-                         "nonzeros, 1.5 GB of values)" % DEFAULT_EDGE)
+                    help="syn-nlpkkt: grid edge (240 = the order of nlpkkt240; the default %d gives 734 M "
+                         "nonzeros, 5.9 GB of values)" % DEFAULT_EDGE)
     ap.add_argument("--scale", type=float, default=1.0, help="size factor of the other synthetic workloads")
     ap.add_argument("--mtx", default=None,
                     help="Matrix Market file to use instead of the synthetic stand-in")

@@ -351,25 +351,27 @@ void RbBuilder::emit_gather_passes(SpxRowBlock &rb, std::vector<Single> &singles
     if (!n) return;
 
     // The x window: the run of columns (at most SPX_MAX_XWIN wide) whose staging
-    // pays best -- every leftover inside saves a scattered 64-byte request, every
-    // double staged costs 8 coalesced bytes: maximise 8 * count - span.
+    // pays best.  Measured on syn-webbase (profiles/r02/ablation.md): leftovers near
+    // the diagonal already hit L2, so a sparse window (one leftover per four
+    // doubles staged) only adds passes, 39.2 -> 39.9 us; staging pays where the
+    // window is dense -- a band that CSX left unencoded.  Maximise 2 * count - span.
     idx_t wlo = 0, whi = -1;
     if (x_window_ && n >= 64) {
         std::vector<idx_t> cols(n);
         for (size_t i = 0; i < n; ++i) cols[i] = singles[i].col;
         std::sort(cols.begin(), cols.end());
-        // for the right end b the best left end a maximises cols[a] - 8a among the
+        // for the right end b the best left end a maximises cols[a] - 2a among the
         // a with cols[b] - cols[a] < SPX_MAX_XWIN - 1 (a monotonic queue)
         std::vector<size_t> dq;
         size_t head = 0;
         int64_t best = 0;
-        auto key = [&](size_t a) { return (int64_t) cols[a] - 8 * (int64_t) a; };
+        auto key = [&](size_t a) { return (int64_t) cols[a] - 2 * (int64_t) a; };
         for (size_t b = 0; b < n; ++b) {
             while (dq.size() > head && key(dq.back()) <= key(b)) dq.pop_back();
             dq.push_back(b);
             while (cols[b] - cols[dq[head]] >= (idx_t) SPX_MAX_XWIN - 1) ++head;
             const size_t a = dq[head];
-            const int64_t gain = 8 * (int64_t)(b - a + 1) - (int64_t)(cols[b] - cols[a] + 1);
+            const int64_t gain = 2 * (int64_t)(b - a + 1) - (int64_t)(cols[b] - cols[a] + 1);
             if (gain > best) {
                 best = gain;
                 wlo = cols[a];

@@ -133,6 +133,16 @@ def syn_nlpkkt(N=12, seed=SEED_BASE + 4):
     return _finish(r, c, n, rng, symmetric=True)
 
 
+def syn_bandrandom(n=200000, band=300, per_row=40, seed=SEED_BASE + 9):
+    """Random nonzeros inside a narrow band: no substructure for CSX to find (everything
+    stays a leftover), but every row-block's columns fit a small window of x -- the case
+    the LDS-staged x window is for.  Not a BASELINE configuration."""
+    rng = np.random.RandomState(seed & 0x7FFFFFFF)
+    rows = np.repeat(np.arange(n), per_row)
+    cols = np.clip(rows + rng.randint(-band, band + 1, rows.size), 0, n - 1)
+    return _finish(rows, cols, n, rng, symmetric=False)
+
+
 def lower_plus_diag_nnz(rowptr, colind):
     """nnz_lower + n for a symmetric matrix given in full."""
     n = rowptr.size - 1
@@ -218,4 +228,5 @@ WORKLOADS = {
     "syn-nd24k": syn_nd24k,
     "syn-webbase": syn_webbase,
     "syn-nlpkkt": syn_nlpkkt_scaled,
+    "syn-bandrandom": lambda scale=1.0: syn_bandrandom(max(2000, int(200000 * scale))),
 }

@@ -19,6 +19,7 @@ CASES = [
     ("web", lambda: synth.syn_webbase(0.02)),
     ("nd24k", lambda: synth.syn_nd24k(0.02)),
     ("kkt", lambda: synth.syn_nlpkkt(8)),
+    ("band", lambda: synth.syn_bandrandom(20000)),        # leftovers gather from the LDS x window
 ]
 OPTS = [
     {},
@@ -63,7 +64,7 @@ def test_kernel_beta(name, gen):
     check_y(csr, x, y, 1.5, -0.25, y0)
 
 
-@pytest.mark.parametrize("name,gen", [c for c in CASES if c[0] != "web"])
+@pytest.mark.parametrize("name,gen", [c for c in CASES if c[0] not in ("web", "band")])
 @pytest.mark.parametrize("opts", [{}, {"spx.preproc.sampling": "none"},
                                   {"spx.preproc.sampling": "none", "spx.rt.nr_threads": "4"}])
 def test_mult_symmetric(name, gen, opts):
@@ -161,3 +162,18 @@ def test_symmetric_tiles_hand_over_modes(mode, threads):
     y1 = y0.copy()
     A.matvec_kernel(1.5, x, -0.25, y1)
     check_y(csr, x, y1, 1.5, -0.25, y0)
+
+
+@pytest.mark.parametrize("window", ["true", "false"])
+def test_x_window_on_and_off(window):
+    """Leftovers whose columns lie close together gather from a window of x staged in LDS
+    (SPX_PASS_GATHER_LDS), the others through L2: same product with the window switched off."""
+    csr = synth.syn_bandrandom(30000, band=200, per_row=30)
+    n = csr[3]
+    A = tune(csr, {"spx.gpu.x_window": window, "spx.rt.nr_threads": "2"})
+    x = synth.random_x(n)
+    y = np.full(n, np.nan)
+    A.matvec_mult(0.5, x, y)
+    check_y(csr, x, y, 0.5)
+    yo, _ = oracle_y(A, x, 0.5)
+    check_vs_oracle(csr, x, y, yo, 0.5)

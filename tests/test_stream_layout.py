@@ -55,6 +55,9 @@ CASES = [
     # enough row-blocks for the emitter to build runs of them on several threads and join the pieces
     ("cant-threaded", lambda: synth.syn_cant(0.25), {"spx.gpu.rowblock_elems": "400"}),
     ("webbase-threaded", lambda: synth.syn_webbase(0.1), {"spx.gpu.rowblock_elems": "300", "spx.rt.nr_threads": "3"}),
+    # leftovers inside a narrow band: row-blocks stage an x window in LDS, u16 offsets from its base
+    ("band-window", lambda: synth.syn_bandrandom(8000), {}),
+    ("band-no-window", lambda: synth.syn_bandrandom(8000), {"spx.gpu.x_window": "false"}),
 ]
 
 
@@ -80,6 +83,10 @@ def test_general_stream_holds_the_matrix_exactly(tmp_path, name, gen, opts):
     s.check_ownership()
     row0 = s.rbs["row0"].astype(np.int64)[b]
     assert ((r >= row0) & (r < row0 + s.rbs["n_rows"].astype(np.int64)[b])).all()
+    if name.startswith("band"):
+        windows = int((s.rbs["xwin_len"] > 0).sum())
+        assert (windows > len(s.rbs) // 2) == (name == "band-window")
+        assert bool((s.passes["kind"] == 4).any()) == (name == "band-window")
 
 
 @pytest.mark.parametrize("remine", ["true", "false"])
