@@ -377,13 +377,18 @@ def measured_traffic(key):
 
 def kernel_name(info, symmetric, world):
     w = int(info.waves)
-    if symmetric and world == 1:
-        return "csx_spmv_symtile_kernel<%d> (+ csx_symfix_kernel)" % w if info.sym_tiles else \
+    tiles = int(info.sym_tiles)
+    if not symmetric:
+        return "csx_spmv_kernel<%d>" % w
+    if tiles == 2:
+        main = "csx_sym_init_kernel + csx_spmv_symtile_atomic_kernel<%d>" % w
+    elif tiles == 1:
+        main = ("csx_sym_init_kernel + " if world > 1 else "") + \
+            "csx_spmv_symtile_kernel<%d> + csx_symfix_kernel" % w
+    else:
+        main = ("csx_sym_init_kernel + " if world > 1 else "") + \
             "csx_spmv_kernel<%d> (symmetric stream: lower triangle + mirror image)" % w
-    if symmetric:
-        return "csx_sym_init_kernel + csx_spmv_%skernel<%d> (+ pack / unpack of the exchange)" % (
-            "symtile_" if info.sym_tiles else "", w)
-    return "csx_spmv_kernel<%d>" % w
+    return main + (" (+ pack / unpack of the exchange)" if world > 1 else "")
 
 
 def parity_gate(torch, y, a_local, xh, lo, hi, ablation):

@@ -205,7 +205,9 @@ typedef struct {
     int32_t device;
     int32_t waves;           /* wavefronts per workgroup of the SpMV kernel      */
     int32_t sym_tiles;       /* symmetric path: the stream holds dense 8x8 tiles
-                                that are read once (SPX_PASS_SYMTILE)            */
+                                that are read once (SPX_PASS_SYMTILE): 1 = their
+                                transposed sums go through the spill lists and a
+                                second kernel, 2 = straight into y (global atomics) */
     double  tune_seconds;    /* preprocessing (mining + encoding)               */
     double  emit_seconds;    /* descriptor stream + upload                      */
 } spx_hip_info_t;

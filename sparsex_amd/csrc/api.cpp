@@ -1546,7 +1546,7 @@ spx_error_t spx_hip_mat_info(const spx_matrix_t *A, spx_hip_info_t *info)
         info->device = di.device;
     }
     info->waves = A->dev ? device_get_waves(A->dev) : A->waves;
-    info->sym_tiles = A->has_tiles ? 1 : 0;
+    info->sym_tiles = A->has_tiles ? ((A->dev ? device_get_sym_atomic(A->dev) : A->sym_atomic) ? 2 : 1) : 0;
     info->tune_seconds = A->tune_seconds;
     info->emit_seconds = A->emit_seconds;
     return SPX_SUCCESS;

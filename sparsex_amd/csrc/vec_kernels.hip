@@ -83,30 +83,12 @@ __global__ __launch_bounds__(VEC_BLOCK) void vec_dot_kernel(const double *__rest
     const size_t n2 = n / 2;
     const size_t stride = (size_t) gridDim.x * VEC_BLOCK;
     double acc = 0.0;
-    size_t i = (size_t) blockIdx.x * VEC_BLOCK + threadIdx.x;
-    // four steps at a time: eight 16-byte loads per lane in flight (a reduction has
-    // nothing else to hide the HBM latency with), four independent sums
-    double acc4[4] = {0.0, 0.0, 0.0, 0.0};
-    for (; i + 3 * stride < n2; i += 4 * stride) {
-        double2 va[4], vb[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            va[k] = reinterpret_cast<const double2 *>(a)[i + k * stride];
-            vb[k] = reinterpret_cast<const double2 *>(b)[i + k * stride];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            acc4[k] = fma(va[k].x, vb[k].x, acc4[k]);
-            acc4[k] = fma(va[k].y, vb[k].y, acc4[k]);
-        }
-    }
-    for (; i < n2; i += stride) {
+    for (size_t i = (size_t) blockIdx.x * VEC_BLOCK + threadIdx.x; i < n2; i += stride) {
         const double2 va = reinterpret_cast<const double2 *>(a)[i];
         const double2 vb = reinterpret_cast<const double2 *>(b)[i];
         acc = fma(va.x, vb.x, acc);
         acc = fma(va.y, vb.y, acc);
     }
-    acc += (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) acc = fma(a[n - 1], b[n - 1], acc);
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;

@@ -1,20 +1,21 @@
 #!/bin/bash
 # Runs, on the GPU box, the whole set of measurements profiles/<round>/ holds:
-# rocprofv3 kernel stats + FETCH_SIZE/WRITE_SIZE passes for the three synthetic
-# workloads, then the plain bench lines (with the CPU baseline).
-# usage: tools/refresh_profiles.sh <round-tag>       e.g. r01
+# rocprofv3 kernel stats + FETCH_SIZE/WRITE_SIZE passes (separate runs) of the
+# default bench command (syn-nlpkkt, general path) and of the three BASELINE
+# configurations of the "configs" object, then the plain bench lines (with the
+# CPU baselines).
+# usage: tools/refresh_profiles.sh <round-tag>       e.g. r02
 set -u
-R=${1:-r01}
+R=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-for W in cant nd24k webbase; do
-    bash "$ROOT/tools/profile.sh" ${R}_$W --workload syn-$W > /dev/null 2>&1
-done
+bash "$ROOT/tools/profile.sh" ${R}_nlpkkt > /dev/null 2>&1
+bash "$ROOT/tools/profile.sh" ${R}_cant --workload syn-cant > /dev/null 2>&1
+bash "$ROOT/tools/profile.sh" ${R}_nd24k_sym --workload syn-nd24k --symmetric > /dev/null 2>&1
+bash "$ROOT/tools/profile.sh" ${R}_webbase --workload syn-webbase > /dev/null 2>&1
 cd "$ROOT"
-for W in cant nd24k webbase; do
-    python3 bench.py --workload syn-$W 2> gpurun_out/${R}_$W/bench_plain.err | tail -1 > gpurun_out/${R}_$W/bench_plain.json
-done
-python3 bench.py --workload syn-nd24k --symmetric 2>/dev/null | tail -1 > gpurun_out/${R}_nd24k/bench_plain_sym.json
-python3 bench.py --workload syn-cant --symmetric 2>/dev/null | tail -1 > gpurun_out/${R}_cant/bench_plain_sym.json
-for W in cant nd24k webbase; do
-    echo "== $W"; cat gpurun_out/${R}_$W/bench_plain.json; head -4 gpurun_out/${R}_$W/kernel_stats.csv; cat gpurun_out/${R}_$W/pmc_*.txt | grep csx_spmv
+python3 bench.py 2> gpurun_out/${R}_nlpkkt/bench_plain.err | tail -1 > gpurun_out/${R}_nlpkkt/bench_plain.json
+python3 bench.py --symmetric --no-configs 2>/dev/null | tail -1 > gpurun_out/${R}_nlpkkt/bench_plain_sym.json
+python3 bench.py --workload syn-nd24k --no-configs 2>/dev/null | tail -1 > gpurun_out/${R}_nd24k_sym/bench_plain_general.json
+for W in nlpkkt cant nd24k_sym webbase; do
+    echo "== $W"; head -c 600 gpurun_out/${R}_$W/bench_line.json; echo; head -6 gpurun_out/${R}_$W/kernel_stats.csv | cut -c1-200; grep csx_ gpurun_out/${R}_$W/pmc_*.txt | cut -c1-200
 done
