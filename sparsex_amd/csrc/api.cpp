@@ -26,9 +26,11 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <atomic>
 #include <sstream>
 #include <thread>
 #include <unistd.h>
+#include <unordered_map>
 
 using namespace spx;
 
@@ -39,6 +41,42 @@ namespace {
 enum { ALLOC_STD = 1, ALLOC_OTHER = 4,          // Vector.cpp:36-41
        ALLOC_PINNED = 8 };                      // this build: page-locked, copied to/from HBM directly
 enum { VEC_MODE_INVALID = 45 };                // Vector.cpp:43-47
+
+// spx.vec.device: vectors the library created carry a version that every
+// spx_vec_* mutator advances; spx_matvec_* reuse x's copy in HBM while it stands
+// (a relinked reference client's 128-loop, test/src/sparsex_test.c:161-163,
+// uploads x once).  Opt-in: a caller that writes through v->elements directly
+// must not use it.
+std::mutex g_vec_mtx;
+std::unordered_map<const spx_vector_t *, uint64_t> g_vec_version;
+std::atomic<uint64_t> g_version_clock(1);
+
+void vec_track(const spx_vector_t *v)
+{
+    if (!Config::instance().get_bool("spx.vec.device")) return;
+    std::lock_guard<std::mutex> lk(g_vec_mtx);
+    g_vec_version[v] = g_version_clock++;
+}
+
+void vec_touch(const spx_vector_t *v)
+{
+    std::lock_guard<std::mutex> lk(g_vec_mtx);
+    auto it = g_vec_version.find(v);
+    if (it != g_vec_version.end()) it->second = g_version_clock++;
+}
+
+void vec_forget(const spx_vector_t *v)
+{
+    std::lock_guard<std::mutex> lk(g_vec_mtx);
+    g_vec_version.erase(v);
+}
+
+uint64_t vec_version(const spx_vector_t *v)
+{
+    std::lock_guard<std::mutex> lk(g_vec_mtx);
+    auto it = g_vec_version.find(v);
+    return it == g_vec_version.end() ? 0 : it->second;
+}
 
 double now_sec()
 {
@@ -1414,7 +1452,8 @@ static spx_error_t run_host(const spx_matrix_t *A, spx_value_t alpha, const spx_
         std::function<void(double *, void *)> after;
         if (A->dist) after = [A](double *d_y, void *st) { dist_complete(A->dist, d_y, true, st); };
         device_spmv_host(A->dev, alpha, x->elements, x->alloc_type == ALLOC_PINNED, beta,
-                         y->elements, y->alloc_type == ALLOC_PINNED, after);
+                         y->elements, y->alloc_type == ALLOC_PINNED, after, vec_version(x));
+        vec_touch(y);
     } catch (const FatalError &e) {
         SETERROR_1(SPX_ERR_TUNED_MAT, e.what.c_str());
         return SPX_FAILURE;
@@ -1651,6 +1690,7 @@ static spx_vector_t *vec_alloc(size_t size)
     if (!v->elements) { log_msg(LOG_ERR, "malloc failed\n"); exit(1); }
     v->size = size;
     v->vec_mode = VEC_MODE_INVALID;
+    vec_track(v);
     return v;
 }
 
@@ -1688,6 +1728,7 @@ spx_vector_t *spx_vec_create_from_buff(spx_value_t *buff, spx_value_t **tuned, s
 
 void spx_vec_init_rand_range(spx_vector_t *v, spx_value_t max, spx_value_t min)
 {
+    vec_touch(v);
     for (size_t i = 0; i < v->size; i++) {
         spx_value_t val = ((spx_value_t)(rand() + i) / ((spx_value_t) RAND_MAX + 1));
         v->elements[i] = min + val * (max - min);
@@ -1708,11 +1749,13 @@ spx_vector_t *spx_vec_create_random(size_t size, const spx_partition_t *p)
 
 void spx_vec_init(spx_vector_t *v, spx_value_t val)
 {
+    vec_touch(v);
     for (size_t i = 0; i < v->size; i++) v->elements[i] = val;
 }
 
 void spx_vec_init_part(spx_vector_t *v, spx_value_t val, spx_index_t start, spx_index_t end)
 {
+    vec_touch(v);
     for (spx_index_t i = start; i < end; i++) v->elements[i] = val;
 }
 
@@ -1730,16 +1773,19 @@ spx_error_t spx_vec_set_entry(spx_vector_t *v, spx_index_t idx, spx_value_t val,
         return SPX_FAILURE;
     }
     v->elements[pos] = val;
+    vec_touch(v);
     return SPX_SUCCESS;
 }
 
 void spx_vec_scale(spx_vector_t *v1, spx_vector_t *v2, spx_value_t num)
 {
+    vec_touch(v2);
     for (size_t i = 0; i < v1->size; i++) v2->elements[i] = num * v1->elements[i];
 }
 
 void spx_vec_scale_add(spx_vector_t *v1, spx_vector_t *v2, spx_vector_t *v3, spx_value_t num)
 {
+    vec_touch(v3);
     for (size_t i = 0; i < v1->size; i++)
         v3->elements[i] = v1->elements[i] + num * v2->elements[i];
 }
@@ -1747,12 +1793,14 @@ void spx_vec_scale_add(spx_vector_t *v1, spx_vector_t *v2, spx_vector_t *v3, spx
 void spx_vec_scale_add_part(spx_vector_t *v1, spx_vector_t *v2, spx_vector_t *v3,
                             spx_value_t num, spx_index_t start, spx_index_t end)
 {
+    vec_touch(v3);
     for (spx_index_t i = start; i < end; i++)
         v3->elements[i] = v1->elements[i] + num * v2->elements[i];
 }
 
 void spx_vec_add(spx_vector_t *v1, spx_vector_t *v2, spx_vector_t *v3)
 {
+    vec_touch(v3);
     if (v1->size != v2->size || v1->size != v3->size) {
         fprintf(stderr, "v1->size=%lu v2->size=%lu v3->size=%lu differ\n",
                 (unsigned long) v1->size, (unsigned long) v2->size, (unsigned long) v3->size);
@@ -1764,18 +1812,21 @@ void spx_vec_add(spx_vector_t *v1, spx_vector_t *v2, spx_vector_t *v3)
 void spx_vec_add_part(spx_vector_t *v1, spx_vector_t *v2, spx_vector_t *v3,
                       spx_index_t start, spx_index_t end)
 {
+    vec_touch(v3);
     for (spx_index_t i = start; i < end; i++)
         v3->elements[i] = v1->elements[i] + v2->elements[i];
 }
 
 void spx_vec_sub(spx_vector_t *v1, spx_vector_t *v2, spx_vector_t *v3)
 {
+    vec_touch(v3);
     for (size_t i = 0; i < v1->size; i++) v3->elements[i] = v1->elements[i] - v2->elements[i];
 }
 
 void spx_vec_sub_part(spx_vector_t *v1, spx_vector_t *v2, spx_vector_t *v3,
                       spx_index_t start, spx_index_t end)
 {
+    vec_touch(v3);
     for (spx_index_t i = start; i < end; i++)
         v3->elements[i] = v1->elements[i] - v2->elements[i];
 }
@@ -1804,6 +1855,7 @@ spx_error_t spx_vec_reorder(spx_vector_t *v, spx_perm_t *p)
     std::vector<spx_value_t> tmp(v->size);
     for (size_t i = 0; i < v->size; i++) tmp[(size_t) p[i]] = v->elements[i];
     memcpy(v->elements, tmp.data(), v->size * sizeof(spx_value_t));
+    vec_touch(v);
     return SPX_SUCCESS;
 }
 
@@ -1816,11 +1868,13 @@ spx_error_t spx_vec_inv_reorder(spx_vector_t *v, spx_perm_t *p)
     std::vector<spx_value_t> tmp(v->size);
     for (size_t i = 0; i < v->size; i++) tmp[i] = v->elements[(size_t) p[i]];
     memcpy(v->elements, tmp.data(), v->size * sizeof(spx_value_t));
+    vec_touch(v);
     return SPX_SUCCESS;
 }
 
 void spx_vec_copy(const spx_vector_t *v1, spx_vector_t *v2)
 {
+    vec_touch(v2);
     memcpy(v2->elements, v1->elements, v1->size * sizeof(spx_value_t));
 }
 
@@ -1852,6 +1906,7 @@ void spx_vec_print(const spx_vector_t *v)
 void spx_vec_destroy(spx_vector_t *v)
 {
     if (!v) return;
+    vec_forget(v);
     if (v->alloc_type == ALLOC_STD) free(v->elements);
     else if (v->alloc_type == ALLOC_PINNED) device_host_free(v->elements);
     free(v);

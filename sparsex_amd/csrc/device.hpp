@@ -32,9 +32,13 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
 // buffers go through pinned staging copies.
 // `after(d_y, stream)`, if given, runs between the kernel and the copy back (the
 // exchange of a row-partitioned matrix).
+// `x_version` != 0 names the contents of h_x (spx.vec.device: library-created
+// vectors carry a version that every spx_vec_* mutator advances): the copy of x in
+// HBM is reused while the version stays the same.
 void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x, bool x_pinned,
                       double beta, double *h_y, bool y_pinned,
-                      const std::function<void(double *, void *)> &after = nullptr);
+                      const std::function<void(double *, void *)> &after = nullptr,
+                      uint64_t x_version = 0);
 
 // page-locked host memory for the library's own vectors; nullptr when there is
 // no HIP device (the caller falls back to malloc)

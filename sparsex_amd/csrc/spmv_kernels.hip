@@ -617,6 +617,7 @@ struct DeviceMatrix {
     // staging vectors of the host-pointer path
     double *d_x = nullptr, *d_y = nullptr;
     double *p_x = nullptr, *p_y = nullptr;      // pinned
+    uint64_t x_version = 0;                      // contents of d_x (0: unknown)
     hipStream_t host_stream = nullptr;
     size_t value_bytes = 0, index_bytes = 0;
     size_t n_values = 0, n_descs = 0, n_passes = 0, n_cidx = 0, n_segrows = 0;
@@ -823,6 +824,7 @@ double device_time_spmv(DeviceMatrix *m, int warmup, int launches)
     hipStream_t st = m->host_stream;
     HIP_CHECK(hipMemsetAsync(m->d_x, 0, m->ncols * sizeof(double), st));
     HIP_CHECK(hipMemsetAsync(m->d_y, 0, m->nrows * sizeof(double), st));
+    m->x_version = 0;
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0));
     HIP_CHECK(hipEventCreate(&e1));
@@ -843,18 +845,21 @@ double device_time_spmv(DeviceMatrix *m, int warmup, int launches)
 // hipMemcpy stages internally as well, but synchronously and chunk by chunk.
 void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x, bool x_pinned,
                       double beta, double *h_y, bool y_pinned,
-                      const std::function<void(double *, void *)> &after)
+                      const std::function<void(double *, void *)> &after, uint64_t x_version)
 {
     HIP_CHECK(hipSetDevice(m->device));
     const size_t xb = m->ncols * sizeof(double), yb = m->nrows * sizeof(double);
     ensure_staging(m);
     hipStream_t st = m->host_stream;
-    const double *src_x = h_x;
-    if (!x_pinned) {
-        std::memcpy(m->p_x, h_x, xb);
-        src_x = m->p_x;
+    if (!x_version || x_version != m->x_version) {
+        const double *src_x = h_x;
+        if (!x_pinned) {
+            std::memcpy(m->p_x, h_x, xb);
+            src_x = m->p_x;
+        }
+        HIP_CHECK(hipMemcpyAsync(m->d_x, src_x, xb, hipMemcpyHostToDevice, st));
+        m->x_version = x_version;
     }
-    HIP_CHECK(hipMemcpyAsync(m->d_x, src_x, xb, hipMemcpyHostToDevice, st));
     // y travels to the device only when it is read: beta != 0, or this process
     // owns a slice of the rows and the others must keep the caller's values
     const bool whole = m->own_lo == 0 && m->own_hi == m->nrows && (!m->symmetric || m->sym_fused);
