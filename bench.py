@@ -579,10 +579,32 @@ def main():
     transport_name = "none"
     if world > 1:
         if backend == "nccl":
-            ids = [sx.rccl_unique_id() if rank == 0 else None]
+            transport = None
+            try:
+                ids = [sx.rccl_unique_id() if rank == 0 else None]
+            except sx.SpxError:
+                ids = [None]
             dist.broadcast_object_list(ids, src=0)
-            transport = sx.RcclTransport(ids[0], rank, world)
-            transport_name = "RCCL point-to-point inside libsparsex (spx_hip_transport_rccl)"
+            if ids[0] is not None:
+                try:
+                    transport = sx.RcclTransport(ids[0], rank, world)
+                except sx.SpxError:
+                    transport = None
+            # every rank must hold the same kind of transport
+            ok = torch.tensor([1 if transport is not None else 0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()):
+                transport_name = "RCCL point-to-point inside libsparsex (spx_hip_transport_rccl)"
+            else:
+                # stand-by, reported as such: the same plan over torch.distributed's RCCL group,
+                # staged through device buffers (sparsex_amd/dist_torch.py)
+                print("bench.py: the library's RCCL transport could not be created on every rank; "
+                      "falling back to torch.distributed all_to_all", file=sys.stderr)
+                if transport is not None:
+                    transport.destroy()
+                from sparsex_amd.dist_torch import torch_transport
+                transport = torch_transport(rank, world, staging_device=dev)
+                transport_name = "STAND-BY: torch.distributed all_to_all_single (RCCL) staged through device buffers"
         else:
             from sparsex_amd.dist_torch import torch_transport
             transport = torch_transport(rank, world)

@@ -44,7 +44,7 @@ def torch_transport(rank, world, staging_device="cpu"):
         sc, rc = counts(scnt), counts(rcnt)
         parts = [send[int(soff[q]):int(soff[q]) + sc[q]].astype(np.int64) for q in range(world)]
         send_t = torch.from_numpy(np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64))
-        if staging_device != "cpu":
+        if str(staging_device) != "cpu":
             send_t = send_t.to(staging_device)
         got = a2a(send_t, sc, rc).cpu().numpy().astype(np.uint64)
         k = 0
@@ -55,9 +55,8 @@ def torch_transport(rank, world, staging_device="cpu"):
     def device(send_ptr, soff, scnt, recv_ptr, roff, rcnt, stream):
         hip = _hiprt()
         sc, rc = counts(scnt), counts(rcnt)
-        on_host = staging_device == "cpu"
-        send_t = torch.empty(sum(sc), dtype=torch.float64, device=staging_device,
-                             pin_memory=False)
+        on_host = str(staging_device) == "cpu"
+        send_t = torch.empty(sum(sc), dtype=torch.float64, device=staging_device)
         kind_out = 2 if on_host else 3          # hipMemcpyDeviceToHost / DeviceToDevice
         kind_in = 1 if on_host else 3           # hipMemcpyHostToDevice / DeviceToDevice
         k = 0
