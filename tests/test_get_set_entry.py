@@ -15,6 +15,7 @@ from helpers import tune, oracle_y, check_y
     (lambda: synth.syn_nlpkkt(6), {"spx.preproc.sampling": "none", "spx.rt.nr_threads": "3"}, False),
     (lambda: synth.syn_nd24k(0.012), {"spx.preproc.sampling": "none"}, False),
     (lambda: synth.syn_webbase(0.004), {}, False),
+    (lambda: synth.syn_bandrandom(5000), {}, False),       # leftovers addressed through the x window
     (lambda: synth.syn_cant(0.02), {"spx.preproc.sampling": "none", "spx.rt.nr_threads": "2"}, True),
 ])
 def test_get_every_entry_and_set_some_host(gen, opts, sym):
