@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void valu_kernel(const double *vals, const uin
 // ---- MFMA: a pass = 8 tiles = 4 pairs; per pair the 128 values are stored in operand order:
 // mvals[pair][step s][lane l] = T_{l%16 < 8 ? a : b}[(l%16)%8][4s + l/16]  (A operand: m = l%16, k = l/16).
 // SYM additionally reads tvals[pair][s][l] = T_{..}[4s + l/16][(l%16)%8] (the transposed tile) for c = T^T xr.
-template <bool SYM>
+template <bool SYM, int MAP>
 __global__ __launch_bounds__(256) void mfma_kernel(const double *mvals, const double *tvals, const uint32_t *tcol,
                                                    const uint32_t *trow, const double *x, double *y, size_t npass)
 {
@@ -87,10 +87,12 @@ __global__ __launch_bounds__(256) void mfma_kernel(const double *mvals, const do
             double4_t d = {0.0, 0.0, 0.0, 0.0};
             d = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, d, 0, 0, 0);
             d = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, d, 0, 0, 0);
-            // D[m = 4*(lane/16) + r][n = lane%16]: column 0 rows 0-7 = tile a, column 1 rows 8-15 = tile b
-            if ((j == 0 && k < 2) || (j == 1 && k >= 2)) {
+            // D[m][n = lane%16] with m = 4*(lane/16) + r (MAP 0) or (lane/16) + 4*r (MAP 1; what gfx950
+            // does for f64, established by this very check): column 0 rows 0-7 = tile a, column 1 rows 8-15 = tile b
 #pragma unroll
-                for (int r = 0; r < 4; ++r) atomicAdd(&y[r0 + ((4 * k + r) & 7)], d[r]);
+            for (int r = 0; r < 4; ++r) {
+                const int m = MAP ? k + 4 * r : 4 * k + r;
+                if (j < 2 && (m >> 3) == j) atomicAdd(&y[r0 + (m & 7)], d[r]);
             }
             if (SYM) {
                 const double *tv = tvals + (p * 4 + pr) * 128;
@@ -99,9 +101,10 @@ __global__ __launch_bounds__(256) void mfma_kernel(const double *mvals, const do
                 double4_t c = {0.0, 0.0, 0.0, 0.0};
                 c = __builtin_amdgcn_mfma_f64_16x16x4f64(t0, e0, c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f64_16x16x4f64(t1, e1, c, 0, 0, 0);
-                if ((j == 0 && k < 2) || (j == 1 && k >= 2)) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) atomicAdd(&y[NX + c0 + ((4 * k + r) & 7)], c[r]);
+                for (int r = 0; r < 4; ++r) {
+                    const int m = MAP ? k + 4 * r : 4 * k + r;
+                    if (j < 2 && (m >> 3) == j) atomicAdd(&y[NX + c0 + (m & 7)], c[r]);
                 }
             }
         }
@@ -149,13 +152,15 @@ int main(int argc, char **argv)
     CK(hipMemcpy(dt, ht.data(), ht.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dx, hx.data(), NX * 8, hipMemcpyHostToDevice));
     CK(hipMemcpy(dc, hc.data(), hc.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dr, hr.data(), hr.size() * 4, hipMemcpyHostToDevice));
     const unsigned blocks = 4096;
-    for (int variant = 0; variant < 4; ++variant) {
-        const char *names[] = {"valu_row", "mfma_row", "valu_sym", "mfma_sym"};
+    for (int variant = 0; variant < 6; ++variant) {
+        const char *names[] = {"valu_row", "mfma_row", "valu_sym", "mfma_sym", "mfma_row(map1)", "mfma_sym(map1)"};
         auto launch = [&]() {
             if (variant == 0) valu_kernel<false><<<blocks, 256>>>(dv, dc, dr, dx, dy, npass);
-            if (variant == 1) mfma_kernel<false><<<blocks, 256>>>(dm, dt, dc, dr, dx, dy, npass);
+            if (variant == 1) mfma_kernel<false, 0><<<blocks, 256>>>(dm, dt, dc, dr, dx, dy, npass);
             if (variant == 2) valu_kernel<true><<<blocks, 256>>>(dv, dc, dr, dx, dy, npass);
-            if (variant == 3) mfma_kernel<true><<<blocks, 256>>>(dm, dt, dc, dr, dx, dy, npass);
+            if (variant == 3) mfma_kernel<true, 0><<<blocks, 256>>>(dm, dt, dc, dr, dx, dy, npass);
+            if (variant == 4) mfma_kernel<false, 1><<<blocks, 256>>>(dm, dt, dc, dr, dx, dy, npass);
+            if (variant == 5) mfma_kernel<true, 1><<<blocks, 256>>>(dm, dt, dc, dr, dx, dy, npass);
         };
         CK(hipMemset(dy, 0, 2 * NX * 8));
         launch();
@@ -163,7 +168,7 @@ int main(int argc, char **argv)
         std::vector<double> got(2 * NX);
         CK(hipMemcpy(got.data(), dy, 2 * NX * 8, hipMemcpyDeviceToHost));
         double err = 0.0;
-        const size_t upto = (variant & 2) ? 2 * NX : NX;
+        const size_t upto = (variant == 2 || variant == 3 || variant == 5) ? 2 * NX : NX;
         for (size_t q = 0; q < upto; ++q) err = fmax(err, fabs(got[q] - ref[q]) / (1.0 + fabs(ref[q])));
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
