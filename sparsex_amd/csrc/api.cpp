@@ -410,7 +410,8 @@ static void emit_and_upload(spx_matrix_t *A)
     if (sym && !gs.sym_fused) stream_touched_rows(gs, A->own_lo, A->conflict_rows);
     finalize_stream(gs, (size_t) A->nrows);
     gs.waves = (uint32_t) A->waves;
-    gs.sym_atomic = A->sym_atomic;
+    gs.sym_atomic = A->sym_atomic && !A->deterministic;
+    gs.deterministic = A->deterministic;
     A->nnz_stored = gs.nnz_stored;
     A->n_unit_elems = gs.n_unit_elems;
     A->n_delta_elems = gs.n_delta_elems;
@@ -672,10 +673,11 @@ static spx_matrix_t *do_tune(spx_input_t *in)
         log_msg(LOG_ERR, "spx.gpu.sym_spill: lists, atomic or auto\n");
         throw FatalError("bad spx.gpu.sym_spill");
     }
-    A->sym_atomic = spill_mode == "atomic";
+    A->deterministic = cfg.get_bool("spx.gpu.deterministic");
+    A->sym_atomic = spill_mode == "atomic" && !A->deterministic;
     emit_and_upload(A.get());
-    if (A->dev && A->nnz_stored >= 100000 && (autotune || spill_mode == "auto"))
-        autotune_launch(A.get(), autotune, spill_mode == "auto");
+    if (A->dev && A->nnz_stored >= 100000 && (autotune || (spill_mode == "auto" && !A->deterministic)))
+        autotune_launch(A.get(), autotune, spill_mode == "auto" && !A->deterministic);
     if (!cfg.get_bool("spx.rt.keep_encoded")) {
         A->parts.clear();
         A->parts.shrink_to_fit();
@@ -1121,6 +1123,7 @@ spx_error_t spx_mat_save(const spx_matrix_t *A, const char *filename)
     h.waves = gs->waves;
     h.n_encoded = (uint32_t) A->parts.size();
     h.sym_atomic = gs->sym_atomic ? 1u : 0u;
+    h.pad3 = gs->deterministic ? 1u : 0u;
     h.checksum = stream_checksum(*gs);
     bool good = fwrite(kMagic, 1, 8, f) == 8 && fwrite(&h, sizeof(h), 1, f) == 1;
     std::vector<int32_t> bnd;
@@ -1205,6 +1208,7 @@ spx_matrix_t *spx_mat_restore(const char *filename)
         gs->lds_doubles = h.lds_doubles;
         gs->waves = h.waves;
         gs->sym_atomic = h.sym_atomic != 0;
+        gs->deterministic = (h.pad3 & 1u) != 0;
         gs->nnz_stored = h.nnz_stored; gs->n_unit_elems = h.n_unit_elems;
         gs->n_delta_elems = h.n_delta_elems; gs->n_units = h.n_units;
         good = stream_checksum(*gs) == h.checksum;
@@ -1236,6 +1240,7 @@ spx_matrix_t *spx_mat_restore(const char *filename)
     A->n_shared = gs->shared.size();
     A->has_tiles = stream_has_tiles(*gs);
     A->sym_atomic = gs->sym_atomic;
+    A->deterministic = gs->deterministic;
     A->tune_seconds = 0.0;
     A->dirty = false;
     A->auto_rb = false;

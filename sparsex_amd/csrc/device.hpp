@@ -55,6 +55,11 @@ void device_set_sym_atomic(DeviceMatrix *m, bool on);
 bool device_get_sym_atomic(const DeviceMatrix *m);
 bool device_has_spill(const DeviceMatrix *m);
 
+// spx.gpu.deterministic: every wavefront of a workgroup adds into a y tile of its own, the
+// copies are summed in wavefront order -- repeated products are bit-identical
+void device_set_deterministic(DeviceMatrix *m, bool on);
+bool device_get_deterministic(const DeviceMatrix *m);
+
 // wavefronts per workgroup of the SpMV kernel: 2, 4 or 8
 void device_set_waves(DeviceMatrix *m, int waves);
 int device_get_waves(const DeviceMatrix *m);

@@ -413,7 +413,12 @@ __device__ __forceinline__ void run_pass(const KernelArgs &a, const SpxRowBlock 
 // global_atomic_add_f64 -- its own rows (csx_sym_init_kernel has put beta*y and the
 // diagonal term there) and, in aligned groups of eight, the transposed sums of
 // the columns in front of it -- instead of spilling them for a second kernel.
-template <bool SYM, bool ATOMIC, int WAVES_PER_BLOCK>
+//
+// DET (spx.gpu.deterministic): every wavefront adds into a y tile (and slots) of its
+// own, and the copies are summed in wavefront order before the write-out -- the
+// only thing in this library whose order of additions is not fixed is the LDS adds
+// of different wavefronts of a workgroup into the shared tile.
+template <bool SYM, bool ATOMIC, int WAVES_PER_BLOCK, bool DET = false>
 __device__ __forceinline__ void spmv_body(const KernelArgs &a, uint32_t blocks_per_xcd,
                                           double *lds)
 {
@@ -436,11 +441,14 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, uint32_t blocks_p
     SpxPass p1 = passes[wave + WAVES_PER_BLOCK];         // (the table is padded by one stride)
     const int n_rows = rb.n_rows;
     const int n_slots = SYM ? (int) rb.n_slots : 0;
-    double *tile = lds + n_slots;
-    for (int i = threadIdx.x; i < n_slots + n_rows; i += BLOCK_THREADS) lds[i] = 0.0;
+    const int core = n_slots + n_rows;                       // doubles per copy of slots + y tile
+    constexpr int COPIES = DET ? WAVES_PER_BLOCK : 1;
+    double *mine = lds + (DET ? wave * core : 0);            // this wavefront's slots, then its y tile
+    double *tile = mine + n_slots;
+    for (int i = threadIdx.x; i < COPIES * core; i += BLOCK_THREADS) lds[i] = 0.0;
     // the row-block's x window (leftovers whose columns lie close together gather
     // from LDS): staged once, coalesced
-    double *win = tile + n_rows;
+    double *win = lds + COPIES * core;
     {
         const int xw = rb.xwin_len;
         const double *xs = a.x + rb.xwin_base;
@@ -458,9 +466,9 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, uint32_t blocks_p
     for (int t = wave; t < n_pass; t += 2 * WAVES_PER_BLOCK) {
         const bool two = t + WAVES_PER_BLOCK < n_pass;
         if (SYM && p0.kind == SPX_PASS_SYMTILE) {
-            symtile_pass(a, rb, p0, lds, tile, lane);
+            symtile_pass(a, rb, p0, mine, tile, lane);
             if (two) {
-                if (p1.kind == SPX_PASS_SYMTILE) symtile_pass(a, rb, p1, lds, tile, lane);
+                if (p1.kind == SPX_PASS_SYMTILE) symtile_pass(a, rb, p1, mine, tile, lane);
                 else run_pass(a, rb, p1, tile, win, lane);
             }
         } else if (two) {
@@ -470,7 +478,7 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, uint32_t blocks_p
                 else run_units<2, 0>(a, rb, {p0, p1}, tile, win, lane);
             } else {
                 run_pass(a, rb, p0, tile, win, lane);
-                if (SYM && p1.kind == SPX_PASS_SYMTILE) symtile_pass(a, rb, p1, lds, tile, lane);
+                if (SYM && p1.kind == SPX_PASS_SYMTILE) symtile_pass(a, rb, p1, mine, tile, lane);
                 else run_pass(a, rb, p1, tile, win, lane);
             }
         } else {
@@ -482,6 +490,17 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, uint32_t blocks_p
         }
     }
     __syncthreads();
+    if (DET) {
+        // the wavefronts' copies, summed in wavefront order into the first one
+        for (int i = threadIdx.x; i < core; i += BLOCK_THREADS) {
+            double t = lds[i];
+#pragma unroll
+            for (int w = 1; w < COPIES; ++w) t += lds[w * core + i];
+            lds[i] = t;
+        }
+        __syncthreads();
+        tile = lds + n_slots;
+    }
 
     // ---------------- write the owned rows ------------------------------------------------
     if (rb.flags & SPX_RB_SHARED) {
@@ -542,6 +561,24 @@ void csx_spmv_symtile_kernel(SPX_KERNEL_PARAMS)
     SPX_KERNEL_ARGS(a);
     extern __shared__ double lds_dyn[];
     spmv_body<true, false, WAVES>(a, blocks_per_xcd, lds_dyn);
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES)
+void csx_spmv_det_kernel(SPX_KERNEL_PARAMS)
+{
+    SPX_KERNEL_ARGS(a);
+    extern __shared__ double lds_dyn[];      // a y tile per wavefront, then the x window
+    spmv_body<false, false, WAVES, true>(a, blocks_per_xcd, lds_dyn);
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES)
+void csx_spmv_symtile_det_kernel(SPX_KERNEL_PARAMS)
+{
+    SPX_KERNEL_ARGS(a);
+    extern __shared__ double lds_dyn[];
+    spmv_body<true, false, WAVES, true>(a, blocks_per_xcd, lds_dyn);
 }
 
 template <int WAVES>
@@ -641,6 +678,7 @@ struct DeviceMatrix {
     uint32_t *fix_ptr = nullptr, *fix_idx = nullptr;
     size_t n_fix_ptr = 0, n_fix_idx = 0;
     bool sym_atomic = false;   // transposed sums go straight into y (global atomics), no second kernel
+    bool deterministic = false;   // per-wavefront y tiles summed in order (spx.gpu.deterministic)
     uint32_t *slot_col = nullptr;
     size_t n_slot_col = 0;
     // staging vectors of the host-pointer path
@@ -726,6 +764,7 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
         m->n_slot_col = s.slot_group_col.size();
     }
     m->sym_atomic = s.sym_atomic && m->has_tiles;
+    if (s.deterministic) device_set_deterministic(m, true);
     m->n_values = s.values.size(); m->n_descs = s.descs.size(); m->n_passes = s.passes.size();
     m->n_cidx = s.cidx.size(); m->n_segrows = s.segrows.size();
     m->value_bytes = s.values.size() * sizeof(double);
@@ -793,7 +832,24 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
     hipLaunchKernelGGL(KERNEL<W>, dim3(blocks), dim3(64 * W), LDS, stream, a.rbs, a.passes,      \
                        a.n_rb, a.pass_stride, blocks >> 3, 0u, a.values, a.descs, a.cidx,        \
                        a.segrows, a.x, a.y, a.carry, a.dvalues, a.spill, a.slot_col, a.alpha, a.beta)
-    if (blocks && m->has_tiles) {
+    if (blocks && m->deterministic) {
+        // a copy of slots + y tile per wavefront: as many wavefronts as fit the LDS
+        const int w = m->waves;
+        const size_t lds = (size_t) w * m->lds_doubles * sizeof(double);
+        if (m->has_tiles) {
+            if (w == 2) SPX_LAUNCH(csx_spmv_symtile_det_kernel, 2, lds);
+            else if (w == 8) SPX_LAUNCH(csx_spmv_symtile_det_kernel, 8, lds);
+            else SPX_LAUNCH(csx_spmv_symtile_det_kernel, 4, lds);
+            if (m->n_spill)
+                hipLaunchKernelGGL(csx_symfix_kernel, dim3((unsigned)((((m->nrows + 31) / 32) + 7) & ~(size_t) 7)), dim3(256),
+                                   0, stream, m->fix_ptr, m->fix_idx, m->spill, d_y, alpha,
+                                   (uint32_t) m->nrows);
+        } else {
+            if (w == 2) SPX_LAUNCH(csx_spmv_det_kernel, 2, lds);
+            else if (w == 8) SPX_LAUNCH(csx_spmv_det_kernel, 8, lds);
+            else SPX_LAUNCH(csx_spmv_det_kernel, 4, lds);
+        }
+    } else if (blocks && m->has_tiles) {
         // symmetric tiles: slots + y tile in dynamic LDS, then the rows collect
         // what other row-blocks spilled for them
         const size_t lds = m->lds_doubles * sizeof(double);
@@ -824,13 +880,38 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
 
 void device_set_init_rows(DeviceMatrix *m, size_t first_row) { m->init_lo = first_row; }
 
-void device_set_sym_atomic(DeviceMatrix *m, bool on) { m->sym_atomic = on && m->has_tiles && m->n_spill; }
+void device_set_sym_atomic(DeviceMatrix *m, bool on)
+{
+    m->sym_atomic = on && m->has_tiles && m->n_spill && !m->deterministic;
+}
+
+// per-wavefront tiles need waves x the LDS: pick the largest wavefront count that fits
+// (the kernels may use up to 160 KB once told so)
+void device_set_deterministic(DeviceMatrix *m, bool on)
+{
+    m->deterministic = on;
+    if (!on) return;
+    m->sym_atomic = false;
+    const size_t per_copy = (size_t) m->lds_doubles * sizeof(double);
+    int w = m->waves;
+    while (w > 2 && (size_t) w * per_copy > 160u * 1024u) w /= 2;
+    if ((size_t) w * per_copy > 160u * 1024u) throw FatalError("row-blocks too large for per-wavefront tiles");
+    m->waves = w;
+    const int bytes = 160 * 1024;
+#define SPX_ATTR(K) (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
+    SPX_ATTR(csx_spmv_det_kernel<2>); SPX_ATTR(csx_spmv_det_kernel<4>); SPX_ATTR(csx_spmv_det_kernel<8>);
+    SPX_ATTR(csx_spmv_symtile_det_kernel<2>); SPX_ATTR(csx_spmv_symtile_det_kernel<4>);
+    SPX_ATTR(csx_spmv_symtile_det_kernel<8>);
+#undef SPX_ATTR
+}
+bool device_get_deterministic(const DeviceMatrix *m) { return m->deterministic; }
 bool device_get_sym_atomic(const DeviceMatrix *m) { return m->sym_atomic; }
 bool device_has_spill(const DeviceMatrix *m) { return m->has_tiles && m->n_spill; }
 
 void device_set_waves(DeviceMatrix *m, int waves)
 {
     m->waves = (waves == 2 || waves == 8) ? waves : 4;
+    if (m->deterministic) device_set_deterministic(m, true);     // (re-checks the LDS budget)
 }
 
 int device_get_waves(const DeviceMatrix *m) { return m->waves; }
@@ -948,6 +1029,7 @@ void device_download(const DeviceMatrix *m, GpuStream &s)
     s.n_spill = m->n_spill;
     s.lds_doubles = m->lds_doubles;
     s.sym_atomic = m->sym_atomic;
+    s.deterministic = m->deterministic;
     if (m->n_spill) download(s.slot_group_col, m->slot_col, m->n_slot_col);
     if (m->n_spill) {
         download(s.fix_ptr, m->fix_ptr, m->n_fix_ptr);

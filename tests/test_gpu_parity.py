@@ -177,3 +177,35 @@ def test_x_window_on_and_off(window):
     check_y(csr, x, y, 0.5)
     yo, _ = oracle_y(A, x, 0.5)
     check_vs_oracle(csr, x, y, yo, 0.5)
+
+
+@pytest.mark.parametrize("name,gen,sym", [
+    ("cant", lambda: synth.syn_cant(0.3), False),
+    ("web", lambda: synth.syn_webbase(0.2), False),
+    ("nd24k-sym", lambda: synth.syn_nd24k(0.1), True),
+    ("cant-sym", lambda: synth.syn_cant(0.2), True),
+    ("band", lambda: synth.syn_bandrandom(40000), False),
+], ids=["cant", "web", "nd24k-sym", "cant-sym", "band"])
+def test_deterministic_mode_is_bitwise_repeatable(name, gen, sym):
+    """spx.gpu.deterministic: every wavefront adds into a y tile of its own and the copies are
+    summed in wavefront order; the symmetric tiles' sums travel through the fixed-order lists.
+    Repeated products are then bit-identical (the reference's CPU kernels are deterministic too)."""
+    csr = gen()
+    n = csr[3]
+    A = tune(csr, {"spx.gpu.deterministic": "true", "spx.rt.nr_threads": "2"}, sym=sym)
+    x = synth.random_x(n)
+    y0 = np.full(n, np.nan)
+    A.matvec_mult(0.5, x, y0)
+    check_y(csr, x, y0, 0.5)
+    for _ in range(8):
+        y = np.full(n, np.nan)
+        A.matvec_mult(0.5, x, y)
+        assert np.array_equal(y, y0)
+    yb = synth.random_x(n, seed=9)
+    y1 = yb.copy()
+    A.matvec_kernel(1.5, x, -0.5, y1)
+    check_y(csr, x, y1, 1.5, -0.5, yb)
+    for _ in range(4):
+        y2 = yb.copy()
+        A.matvec_kernel(1.5, x, -0.5, y2)
+        assert np.array_equal(y1, y2)
