@@ -378,16 +378,17 @@ def measured_traffic(key):
 def kernel_name(info, symmetric, world):
     w = int(info.waves)
     tiles = int(info.sym_tiles)
+    gen = "csx_spmv_det_kernel<%d> (a y tile per wavefront)" % w if int(info.wave_tiles) else "csx_spmv_kernel<%d>" % w
     if not symmetric:
-        return "csx_spmv_kernel<%d>" % w
+        return gen
     if tiles == 2:
         main = "csx_sym_init_kernel + csx_spmv_symtile_atomic_kernel<%d>" % w
     elif tiles == 1:
         main = ("csx_sym_init_kernel + " if world > 1 else "") + \
-            "csx_spmv_symtile_kernel<%d> + csx_symfix_kernel" % w
+            "csx_spmv_symtile_%skernel<%d> + csx_symfix_kernel" % ("det_" if int(info.wave_tiles) else "", w)
     else:
         main = ("csx_sym_init_kernel + " if world > 1 else "") + \
-            "csx_spmv_kernel<%d> (symmetric stream: lower triangle + mirror image)" % w
+            gen + " (symmetric stream: lower triangle + mirror image)"
     return main + (" (+ pack / unpack of the exchange)" if world > 1 else "")
 
 

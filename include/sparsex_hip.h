@@ -27,6 +27,15 @@
  *                           of merging equal row segments of consecutive rows
  *   spx.gpu.recut_linear    "false": vertical / diagonal / strided units always run one
  *                           nonzero per lane, even where they line up along rows
+ *   spx.gpu.wave_tiles      a y tile per wavefront instead of one per workgroup: "true",
+ *                           "false", "auto" (default: spx_mat_tune() measures it)
+ *   spx.gpu.deterministic   "true": bit-identical repeated products (wave tiles, the
+ *                           symmetric tiles' sums through the fixed-order lists)
+ *   spx.gpu.sym_spill       symmetric tiles' transposed sums: "lists" (second kernel,
+ *                           fixed order), "atomic" (global atomics), "auto" (measured)
+ *   spx.gpu.x_window        "false": leftovers never gather from an LDS window of x
+ *   spx.vec.device          "true": vectors the library creates keep x's HBM copy
+ *                           between spx_matvec_* calls
  *   spx.gpu.sym_once        "false": symmetric path reads lower triangle and mirror
  *                           image (default: dense 8x8 tiles are read once)
  *   spx.gpu.sym_remine      "false": symmetric path mirrors unit by unit
@@ -210,6 +219,9 @@ typedef struct {
                                 second kernel, 2 = straight into y (global atomics) */
     double  tune_seconds;    /* preprocessing (mining + encoding)               */
     double  emit_seconds;    /* descriptor stream + upload                      */
+    int32_t wave_tiles;      /* 1: every wavefront of a workgroup adds into a y tile
+                                of its own (summed in wavefront order)          */
+    int32_t pad2_;
 } spx_hip_info_t;
 
 spx_error_t spx_hip_mat_info(const spx_matrix_t *A, spx_hip_info_t *info);

@@ -412,6 +412,7 @@ static void emit_and_upload(spx_matrix_t *A)
     gs.waves = (uint32_t) A->waves;
     gs.sym_atomic = A->sym_atomic && !A->deterministic;
     gs.deterministic = A->deterministic;
+    gs.wave_tiles = A->deterministic || A->wave_tiles == 1;
     A->nnz_stored = gs.nnz_stored;
     A->n_unit_elems = gs.n_unit_elems;
     A->n_delta_elems = gs.n_delta_elems;
@@ -439,11 +440,22 @@ static void emit_and_upload(spx_matrix_t *A)
 // workgroups) like two wavefronts per workgroup and smaller row-blocks,
 // leftover-heavy ones eight wavefronts, the rest the default.  A handful of
 // candidates, a few hundred launches each; the fastest stays.
-static void autotune_launch(spx_matrix_t *A, bool tune_waves, bool tune_spill)
+static void autotune_launch(spx_matrix_t *A, bool tune_waves, bool tune_spill, bool tune_wave_tiles)
 {
     const int W = 10, N = 100;
     if (!tune_waves) {
         // (the wavefront count is pinned: only the hand-over of the tiles' sums is measured)
+        if (tune_wave_tiles && !device_has_tiles(A->dev)) {
+            auto t_of = [&](bool on) {
+                device_set_wave_tiles(A->dev, on);
+                double best = device_time_spmv(A->dev, W, N);
+                for (int rep = 0; rep < 3; ++rep) best = std::min(best, device_time_spmv(A->dev, 0, N));
+                return best;
+            };
+            const double t0 = t_of(false), t1 = t_of(true);
+            A->wave_tiles = t1 < 0.985 * t0 ? 1 : 0;
+            device_set_wave_tiles(A->dev, A->wave_tiles == 1);
+        }
         if (!tune_spill || !device_has_spill(A->dev)) return;
         auto t_of = [&](bool atomic) {
             device_set_sym_atomic(A->dev, atomic);
@@ -466,6 +478,20 @@ static void autotune_launch(spx_matrix_t *A, bool tune_waves, bool tune_spill)
     const double t4 = time_with(4), t8 = time_with(8);
     int best_waves = t8 < 0.985 * t4 ? 8 : 4;
     double best_t = std::min(t4, t8), best_scale = 1.0;
+    // a y tile per wavefront (no two wavefronts add to the same LDS address; more LDS,
+    // a reduction before the write-out): pays where rows are spread over many passes
+    // (syn-nlpkkt 291 -> 274 us), costs where the kernel is launch-bound (syn-cant 7.2 -> 7.9)
+    if (tune_wave_tiles && !device_has_tiles(A->dev)) {
+        device_set_wave_tiles(A->dev, true);
+        const double tw = time_with(best_waves);
+        if (tw < 0.985 * best_t) {
+            best_t = tw;
+            A->wave_tiles = 1;
+        } else {
+            device_set_wave_tiles(A->dev, false);
+            A->wave_tiles = 0;
+        }
+    }
     // symmetric tiles: the transposed sums through the spill array and a second
     // kernel, or straight into y with global atomics
     if (tune_spill && device_has_spill(A->dev)) {
@@ -675,9 +701,17 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     }
     A->deterministic = cfg.get_bool("spx.gpu.deterministic");
     A->sym_atomic = spill_mode == "atomic" && !A->deterministic;
+    const std::string wt_mode = cfg.get_str("spx.gpu.wave_tiles");
+    if (wt_mode != "auto" && wt_mode != "true" && wt_mode != "false") {
+        log_msg(LOG_ERR, "spx.gpu.wave_tiles: true, false or auto\n");
+        throw FatalError("bad spx.gpu.wave_tiles");
+    }
+    A->wave_tiles = wt_mode == "true" ? 1 : 0;          // (auto: off until measured)
     emit_and_upload(A.get());
-    if (A->dev && A->nnz_stored >= 100000 && (autotune || (spill_mode == "auto" && !A->deterministic)))
-        autotune_launch(A.get(), autotune, spill_mode == "auto" && !A->deterministic);
+    const bool tune_spill = spill_mode == "auto" && !A->deterministic;
+    const bool tune_wt = wt_mode == "auto" && !A->deterministic;
+    if (A->dev && A->nnz_stored >= 100000 && (autotune || tune_spill || tune_wt))
+        autotune_launch(A.get(), autotune, tune_spill, tune_wt);
     if (!cfg.get_bool("spx.rt.keep_encoded")) {
         A->parts.clear();
         A->parts.shrink_to_fit();
@@ -1123,7 +1157,7 @@ spx_error_t spx_mat_save(const spx_matrix_t *A, const char *filename)
     h.waves = gs->waves;
     h.n_encoded = (uint32_t) A->parts.size();
     h.sym_atomic = gs->sym_atomic ? 1u : 0u;
-    h.pad3 = gs->deterministic ? 1u : 0u;
+    h.pad3 = (gs->deterministic ? 1u : 0u) | (gs->wave_tiles ? 2u : 0u);
     h.checksum = stream_checksum(*gs);
     bool good = fwrite(kMagic, 1, 8, f) == 8 && fwrite(&h, sizeof(h), 1, f) == 1;
     std::vector<int32_t> bnd;
@@ -1209,6 +1243,7 @@ spx_matrix_t *spx_mat_restore(const char *filename)
         gs->waves = h.waves;
         gs->sym_atomic = h.sym_atomic != 0;
         gs->deterministic = (h.pad3 & 1u) != 0;
+        gs->wave_tiles = (h.pad3 & 2u) != 0;
         gs->nnz_stored = h.nnz_stored; gs->n_unit_elems = h.n_unit_elems;
         gs->n_delta_elems = h.n_delta_elems; gs->n_units = h.n_units;
         good = stream_checksum(*gs) == h.checksum;
@@ -1241,6 +1276,7 @@ spx_matrix_t *spx_mat_restore(const char *filename)
     A->has_tiles = stream_has_tiles(*gs);
     A->sym_atomic = gs->sym_atomic;
     A->deterministic = gs->deterministic;
+    A->wave_tiles = gs->wave_tiles ? 1 : 0;
     A->tune_seconds = 0.0;
     A->dirty = false;
     A->auto_rb = false;
@@ -1591,6 +1627,7 @@ spx_error_t spx_hip_mat_info(const spx_matrix_t *A, spx_hip_info_t *info)
     }
     info->waves = A->dev ? device_get_waves(A->dev) : A->waves;
     info->sym_tiles = A->has_tiles ? ((A->dev ? device_get_sym_atomic(A->dev) : A->sym_atomic) ? 2 : 1) : 0;
+    info->wave_tiles = A->dev ? (device_get_wave_tiles(A->dev) ? 1 : 0) : (A->wave_tiles == 1 || A->deterministic ? 1 : 0);
     info->tune_seconds = A->tune_seconds;
     info->emit_seconds = A->emit_seconds;
     return SPX_SUCCESS;

@@ -59,6 +59,11 @@ bool device_has_spill(const DeviceMatrix *m);
 // copies are summed in wavefront order -- repeated products are bit-identical
 void device_set_deterministic(DeviceMatrix *m, bool on);
 bool device_get_deterministic(const DeviceMatrix *m);
+// the per-wavefront tiles alone (also a speed option: no two wavefronts add to the same LDS
+// address; spx_mat_tune measures it on matrices without symmetric tiles)
+void device_set_wave_tiles(DeviceMatrix *m, bool on);
+bool device_get_wave_tiles(const DeviceMatrix *m);
+bool device_has_tiles(const DeviceMatrix *m);
 
 // wavefronts per workgroup of the SpMV kernel: 2, 4 or 8
 void device_set_waves(DeviceMatrix *m, int waves);

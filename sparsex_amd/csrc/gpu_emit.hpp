@@ -48,6 +48,7 @@ struct GpuStream {
     // straight into y with 64-byte groups of global_atomic_add_f64
     bool sym_atomic = false;
     bool deterministic = false;   // spx.gpu.deterministic: per-wavefront y tiles, summed in order
+    bool wave_tiles = false;      // per-wavefront y tiles (chosen by the launch autotuner or forced)
     uint32_t n_spill = 0;                      // spill slots (= spill_col.size() after emission)
     uint32_t lds_doubles = SPX_MAX_RB_ROWS;    // largest n_slots + n_rows
     // pass headers of row-block i start at passes[i * pass_stride] once

@@ -64,6 +64,7 @@ struct matrix {
     bool has_tiles = false;     // the stream holds SPX_PASS_SYMTILE passes
     bool sym_atomic = false;    // their transposed sums go straight into y (global atomics)
     bool deterministic = false; // spx.gpu.deterministic
+    int wave_tiles = -1;        // per-wavefront y tiles: 1 / 0, -1 = measured at tune time (spx.gpu.wave_tiles)
     int device_ordinal = -1;
     bool dirty = false;                       // values changed since the last upload
     std::vector<std::vector<idx_t>> spans;    // per partition and row: reach of its units

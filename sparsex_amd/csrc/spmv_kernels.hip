@@ -678,7 +678,8 @@ struct DeviceMatrix {
     uint32_t *fix_ptr = nullptr, *fix_idx = nullptr;
     size_t n_fix_ptr = 0, n_fix_idx = 0;
     bool sym_atomic = false;   // transposed sums go straight into y (global atomics), no second kernel
-    bool deterministic = false;   // per-wavefront y tiles summed in order (spx.gpu.deterministic)
+    bool wave_tiles = false;      // a y tile per wavefront, summed in wavefront order before the write-out
+    bool deterministic = false;   // spx.gpu.deterministic: wave tiles + fixed-order hand-overs, pinned
     uint32_t *slot_col = nullptr;
     size_t n_slot_col = 0;
     // staging vectors of the host-pointer path
@@ -765,6 +766,7 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
     }
     m->sym_atomic = s.sym_atomic && m->has_tiles;
     if (s.deterministic) device_set_deterministic(m, true);
+    else if (s.wave_tiles) device_set_wave_tiles(m, true);
     m->n_values = s.values.size(); m->n_descs = s.descs.size(); m->n_passes = s.passes.size();
     m->n_cidx = s.cidx.size(); m->n_segrows = s.segrows.size();
     m->value_bytes = s.values.size() * sizeof(double);
@@ -832,7 +834,7 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
     hipLaunchKernelGGL(KERNEL<W>, dim3(blocks), dim3(64 * W), LDS, stream, a.rbs, a.passes,      \
                        a.n_rb, a.pass_stride, blocks >> 3, 0u, a.values, a.descs, a.cidx,        \
                        a.segrows, a.x, a.y, a.carry, a.dvalues, a.spill, a.slot_col, a.alpha, a.beta)
-    if (blocks && m->deterministic) {
+    if (blocks && m->wave_tiles) {
         // a copy of slots + y tile per wavefront: as many wavefronts as fit the LDS
         const int w = m->waves;
         const size_t lds = (size_t) w * m->lds_doubles * sizeof(double);
@@ -882,14 +884,14 @@ void device_set_init_rows(DeviceMatrix *m, size_t first_row) { m->init_lo = firs
 
 void device_set_sym_atomic(DeviceMatrix *m, bool on)
 {
-    m->sym_atomic = on && m->has_tiles && m->n_spill && !m->deterministic;
+    m->sym_atomic = on && m->has_tiles && m->n_spill && !m->wave_tiles;
 }
 
 // per-wavefront tiles need waves x the LDS: pick the largest wavefront count that fits
 // (the kernels may use up to 160 KB once told so)
-void device_set_deterministic(DeviceMatrix *m, bool on)
+void device_set_wave_tiles(DeviceMatrix *m, bool on)
 {
-    m->deterministic = on;
+    m->wave_tiles = on;
     if (!on) return;
     m->sym_atomic = false;
     const size_t per_copy = (size_t) m->lds_doubles * sizeof(double);
@@ -904,6 +906,14 @@ void device_set_deterministic(DeviceMatrix *m, bool on)
     SPX_ATTR(csx_spmv_symtile_det_kernel<8>);
 #undef SPX_ATTR
 }
+bool device_get_wave_tiles(const DeviceMatrix *m) { return m->wave_tiles; }
+bool device_has_tiles(const DeviceMatrix *m) { return m->has_tiles; }
+
+void device_set_deterministic(DeviceMatrix *m, bool on)
+{
+    m->deterministic = on;
+    if (on) device_set_wave_tiles(m, true);
+}
 bool device_get_deterministic(const DeviceMatrix *m) { return m->deterministic; }
 bool device_get_sym_atomic(const DeviceMatrix *m) { return m->sym_atomic; }
 bool device_has_spill(const DeviceMatrix *m) { return m->has_tiles && m->n_spill; }
@@ -911,7 +921,7 @@ bool device_has_spill(const DeviceMatrix *m) { return m->has_tiles && m->n_spill
 void device_set_waves(DeviceMatrix *m, int waves)
 {
     m->waves = (waves == 2 || waves == 8) ? waves : 4;
-    if (m->deterministic) device_set_deterministic(m, true);     // (re-checks the LDS budget)
+    if (m->wave_tiles) device_set_wave_tiles(m, true);     // (re-checks the LDS budget)
 }
 
 int device_get_waves(const DeviceMatrix *m) { return m->waves; }
@@ -1030,6 +1040,7 @@ void device_download(const DeviceMatrix *m, GpuStream &s)
     s.lds_doubles = m->lds_doubles;
     s.sym_atomic = m->sym_atomic;
     s.deterministic = m->deterministic;
+    s.wave_tiles = m->wave_tiles;
     if (m->n_spill) download(s.slot_group_col, m->slot_col, m->n_slot_col);
     if (m->n_spill) {
         download(s.fix_ptr, m->fix_ptr, m->n_fix_ptr);
