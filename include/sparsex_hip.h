@@ -64,7 +64,13 @@ extern "C" {
  * hipGraph by stream capture).  With several processes (spx.rt.gpu_world > 1)
  * only the rows of this process' partitions are written on the general path;
  * on the symmetric path y_dev receives this process' partial vector, to be
- * summed over processes by the caller (RCCL all-reduce).
+ * summed over processes by the caller (RCCL all-reduce) -- or use the exchange plan
+ * of spx_hip_mat_dist_attach / spx_hip_matvec_dist below, which moves only the
+ * entries that have to travel.
+ * A matrix handle is single-stream: products of the SAME matrix must not overlap in
+ * time (they share its scratch: the partial sums of over-long rows, the spill array
+ * of the symmetric tiles, the exchange buffers); different matrices are independent.
+ * The calling thread's current HIP device must be the matrix's device (checked).
  */
 spx_error_t spx_hip_matvec_mult(spx_value_t alpha, const spx_matrix_t *A,
                                 const spx_value_t *x_dev, spx_value_t *y_dev,
