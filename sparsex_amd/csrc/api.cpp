@@ -311,6 +311,7 @@ static void keep_index(spx_matrix_t *A, GpuStream &&gs)
 {
     std::vector<val_t>().swap(gs.values);
     std::vector<val_t>().swap(gs.dvalues);
+    std::vector<val_t>().swap(gs.mirror_val);
     std::vector<uint32_t>().swap(gs.fix_idx);
     std::vector<uint32_t>().swap(gs.fix_ptr);
     std::vector<uint32_t>().swap(gs.spill_col);
@@ -395,8 +396,22 @@ static void emit_and_upload(spx_matrix_t *A)
             }
             std::vector<Partition> fulls;
             std::vector<std::vector<SymTile>> tiles;
-            build_sym_ranges(A->parts, ranges, gp.max_rows >= 8, fulls, tiles, hw);
+            std::vector<MirrorPoint> thin;
+            build_sym_ranges(A->parts, ranges, gp.max_rows >= 8, fulls, tiles, hw,
+                             gs.sym_fused ? nullptr : &thin);
             emit_pieces(fulls, &tiles);
+            // thinly spread mirror image on rows of other processes: a CSR over those rows
+            for (size_t k = 0; k < thin.size(); ++k) {
+                if (k == 0 || thin[k].row != thin[k - 1].row) {
+                    gs.mirror_rows.push_back((uint32_t) thin[k].row);
+                    gs.mirror_ptr.push_back((uint32_t) k);
+                }
+                gs.mirror_col.push_back((uint32_t) thin[k].col);
+                gs.mirror_val.push_back(thin[k].val);
+            }
+            gs.mirror_ptr.push_back((uint32_t) thin.size());
+            gs.nnz_stored += thin.size();
+            gs.n_delta_elems += thin.size();
         } else {
             Partition full;
             for (size_t i = 0; i < nown; ++i) append_sym_expanded(A->parts[i], full, gp.sym_remine);
@@ -871,6 +886,7 @@ struct EntryRef {
     bool diagonal = false;
     size_t diag_row = 0;
     std::vector<size_t> pos;
+    std::vector<size_t> mirror_pos;     // symmetric slice: copies in the thin mirror list
     bool found() const { return diagonal || !pos.empty(); }
 };
 
@@ -887,7 +903,11 @@ EntryRef locate_stream(const spx_matrix_t *A, idx_t row, idx_t col)
         return ref;
     }
     stream_locate(*s, row - 1, col - 1, ref.pos);
-    if (A->symmetric) stream_locate(*s, col - 1, row - 1, ref.pos);
+    if (A->symmetric) {
+        stream_locate(*s, col - 1, row - 1, ref.pos);
+        // (the stored entry is the lower one; its mirror image may sit in the thin list)
+        stream_locate_mirror(*s, std::min(row, col) - 1, std::max(row, col) - 1, ref.mirror_pos);
+    }
     return ref;
 }
 
@@ -974,9 +994,11 @@ spx_error_t spx_mat_set_entry(spx_matrix_t *A, spx_index_t row, spx_index_t colu
         if (A->host_stream) {
             if (ref.diagonal) A->host_stream->dvalues[ref.diag_row] = value;
             for (size_t p : ref.pos) A->host_stream->values[p] = value;
+            for (size_t p : ref.mirror_pos) A->host_stream->mirror_val[p] = value;
         } else {
             if (ref.diagonal) device_poke(A->dev, true, ref.diag_row, value);
             for (size_t p : ref.pos) device_poke(A->dev, false, p, value);
+            for (size_t p : ref.mirror_pos) device_poke_mirror(A->dev, p, value);
         }
     } catch (const FatalError &e) {
         SETERROR_1(SPX_ERR_TUNED_MAT, e.what.c_str());
@@ -1004,7 +1026,7 @@ spx_error_t spx_mat_set_entry(spx_matrix_t *A, spx_index_t row, spx_index_t colu
 
 namespace {
 
-const char kMagic[8] = {'S', 'P', 'X', 'H', 'I', 'P', '1', '1'};
+const char kMagic[8] = {'S', 'P', 'X', 'H', 'I', 'P', '1', '2'};
 
 template <typename T>
 bool put_vec(FILE *f, const std::vector<T> &v)
@@ -1060,6 +1082,7 @@ uint64_t stream_checksum(const GpuStream &s)
     uint64_t h = 0xCBF29CE484222325ull;
     fnv(h, s.rbs); fnv(h, s.passes); fnv(h, s.descs); fnv(h, s.cidx); fnv(h, s.segrows);
     fnv(h, s.shared); fnv(h, s.fix_ptr); fnv(h, s.fix_idx); fnv(h, s.slot_group_col);
+    fnv(h, s.mirror_rows); fnv(h, s.mirror_ptr); fnv(h, s.mirror_col);
     return h;
 }
 
@@ -1170,7 +1193,8 @@ spx_error_t spx_mat_save(const spx_matrix_t *A, const char *filename)
            put_vec(f, gs->descs) && put_vec(f, gs->cidx) &&
            put_vec(f, gs->segrows) && put_vec(f, gs->shared) && put_vec(f, gs->dvalues) &&
            put_vec(f, gs->values) && put_vec(f, gs->fix_ptr) && put_vec(f, gs->fix_idx) &&
-           put_vec(f, gs->slot_group_col);
+           put_vec(f, gs->slot_group_col) && put_vec(f, gs->mirror_rows) && put_vec(f, gs->mirror_ptr) &&
+           put_vec(f, gs->mirror_col) && put_vec(f, gs->mirror_val);
     std::vector<int32_t> perm;
     if (A->permutation) perm.assign(A->permutation, A->permutation + A->nrows);
     good = good && put_vec(f, perm);
@@ -1210,7 +1234,8 @@ spx_matrix_t *spx_mat_restore(const char *filename)
                 get_vec(f, gs->passes) && get_vec(f, gs->descs) &&
                 get_vec(f, gs->cidx) && get_vec(f, gs->segrows) && get_vec(f, gs->shared) &&
                 get_vec(f, gs->dvalues) && get_vec(f, gs->values) && get_vec(f, gs->fix_ptr) &&
-                get_vec(f, gs->fix_idx) && get_vec(f, gs->slot_group_col);
+                get_vec(f, gs->fix_idx) && get_vec(f, gs->slot_group_col) && get_vec(f, gs->mirror_rows) &&
+                get_vec(f, gs->mirror_ptr) && get_vec(f, gs->mirror_col) && get_vec(f, gs->mirror_val);
     std::vector<int32_t> perm;
     good = good && get_vec(f, perm);
     std::unique_ptr<matrix> A(new matrix);

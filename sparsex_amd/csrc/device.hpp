@@ -82,6 +82,7 @@ void device_download(const DeviceMatrix *m, GpuStream &s);
 // synchronous
 double device_peek(const DeviceMatrix *m, bool diagonal, size_t index);
 void device_poke(DeviceMatrix *m, bool diagonal, size_t index, double value);
+void device_poke_mirror(DeviceMatrix *m, size_t index, double value);   // GpuStream::mirror_val
 
 struct DeviceMatrixInfo {
     size_t n_rowblocks, n_shared_rows;

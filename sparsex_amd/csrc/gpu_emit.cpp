@@ -829,7 +829,8 @@ void append_stream(GpuStream &dst, GpuStream &&src)
 
 void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<SymRange> &ranges,
                       bool want_tiles, std::vector<Partition> &outs,
-                      std::vector<std::vector<SymTile>> &tiles, unsigned nthreads)
+                      std::vector<std::vector<SymTile>> &tiles, unsigned nthreads,
+                      std::vector<MirrorPoint> *sparse_mirror)
 {
     const size_t P = lowers.size(), R = ranges.size();
     outs.assign(R, Partition());
@@ -932,6 +933,7 @@ void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<Sy
 
     // 4. every range: its points as row segments and blocks, rows relative to
     // the range
+    std::vector<std::vector<MirrorPoint>> thin(R);
     parallel_for(R, nthreads, [&](size_t j) {
         std::vector<Single> pts;
         size_t total = 0;
@@ -946,10 +948,31 @@ void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<Sy
             pts.insert(pts.end(), bucket[i][j].begin(), bucket[i][j].end());
             std::vector<Single>().swap(bucket[i][j]);
         }
-        const size_t n_pts = pts.size();
         std::sort(pts.begin(), pts.end(), [](const Single &a, const Single &b) {
             return a.row < b.row || (a.row == b.row && a.col < b.col);
         });
+        // A range that holds only mirror image (rows of other processes): stretches of
+        // 512 rows with fewer than 128 nonzeros are not worth a workgroup each -- they
+        // leave the row-block stream for the per-row list
+        bool mirror_only = true;
+        for (size_t i = 0; i < P; ++i) mirror_only = mirror_only && own_range[i] != j;
+        if (sparse_mirror && mirror_only && !pts.empty()) {
+            std::vector<Single> keep;
+            for (size_t a = 0; a < pts.size();) {
+                const idx_t chunk = (pts[a].row - 1 - ranges[j].lo) / 512;
+                size_t b = a;
+                while (b < pts.size() && (pts[b].row - 1 - ranges[j].lo) / 512 == chunk) ++b;
+                if (b - a < 128) {
+                    for (size_t k = a; k < b; ++k)
+                        thin[j].push_back(MirrorPoint{pts[k].row - 1, pts[k].col - 1, pts[k].val});
+                } else {
+                    keep.insert(keep.end(), pts.begin() + a, pts.begin() + b);
+                }
+                a = b;
+            }
+            pts.swap(keep);
+        }
+        const size_t n_pts = pts.size();
         // The diagonal itself is held apart (dvalues), which splits every row's run
         // around it in two.  Where a(r,r-1) and a(r,r+1) both exist, an explicit
         // zero at (r,r) joins the runs of row r again: the triangular blocks along
@@ -968,6 +991,9 @@ void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<Sy
         out.elems_size = out.elems.size();
         out.nnz = n_pts;
     });
+    if (sparse_mirror)
+        for (size_t j = 0; j < R; ++j)       // (ranges ascend, points inside are sorted: ascending rows)
+            sparse_mirror->insert(sparse_mirror->end(), thin[j].begin(), thin[j].end());
 }
 
 void finalize_stream(GpuStream &s, size_t nrows)

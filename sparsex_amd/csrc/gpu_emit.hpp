@@ -43,6 +43,14 @@ struct GpuStream {
     // multiples of eight); slot i of the stream belongs to column
     // slot_group_col[i / 8] + i % 8
     std::vector<uint32_t> slot_group_col;
+    // symmetric slice: mirror-image nonzeros that land, thinly spread, on rows in front of
+    // the own rows (a stencil matrix's constraint couplings seen from the last process) are
+    // not worth row-blocks of their own (a workgroup per handful of nonzeros): they are kept
+    // as a small CSR over those rows, one thread per row adds them (csx_sym_mirror_rows_kernel)
+    std::vector<uint32_t> mirror_rows;     // global row of every such row, ascending
+    std::vector<uint32_t> mirror_ptr;      // mirror_rows.size() + 1
+    std::vector<uint32_t> mirror_col;      // column = own row the value multiplies x of
+    std::vector<val_t> mirror_val;
     // symmetric tiles: how the transposed sums reach their rows -- false: spilled
     // and collected per row by a second kernel in a fixed order; true: added
     // straight into y with 64-byte groups of global_atomic_add_f64
@@ -71,6 +79,7 @@ struct GpuStream {
     {
         return descs.size() * sizeof(SpxUnitDesc) + n_pass_used() * sizeof(SpxPass) + cidx.size() +
                (sym_atomic ? slot_group_col.size() : fix_ptr.size() + fix_idx.size()) * 4 +
+               (mirror_rows.size() + mirror_ptr.size() + mirror_col.size()) * 4 +
                segrows.size() * 2 + rbs.size() * sizeof(SpxRowBlock);
     }
 };
@@ -120,16 +129,19 @@ void append_sym_expanded(const Partition &lower, Partition &out, bool remine_upp
 // partition per row range of `ranges` (ascending, contiguous, 0-based global
 // [lo, hi); the rows of every partition of `lowers` must be one of the ranges,
 // further ranges in front take the mirror image that lands on rows of other
-// processes): dense 8x8 tiles on rows that are multiples of eight go to
+// processes; where that image is thin -- fewer than 128 nonzeros in a stretch of 512 rows --
+// it goes to `sparse_mirror` instead, if given): dense 8x8 tiles on rows that are multiples of eight go to
 // `tiles[range]` (sorted by row), everything else goes to `outs[range]` together
 // with the mirror image that falls into the range, both re-cut into row
 // segments and blocks; rows of outs[j] are relative to ranges[j].lo.  Ranges
 // are independent of each other, so they are built -- and can then be emitted
 // -- concurrently.
 struct SymRange { idx_t lo, hi; };
+struct MirrorPoint { idx_t row, col; val_t val; };      // 0-based global; row < every own row
 void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<SymRange> &ranges,
                       bool want_tiles, std::vector<Partition> &outs,
-                      std::vector<std::vector<SymTile>> &tiles, unsigned nthreads);
+                      std::vector<std::vector<SymTile>> &tiles, unsigned nthreads,
+                      std::vector<MirrorPoint> *sparse_mirror = nullptr);
 
 // coordinates (1-based, horizontal order) of element k of a unit
 inline void unit_elem_coords(const Elem &u, size_t k, idx_t &r, idx_t &c)

@@ -650,6 +650,20 @@ __global__ void csx_sym_init_kernel(double *y, const double *x, const double *dv
     y[i] = v;
 }
 
+// symmetric slice: the thinly spread part of the mirror image on rows of other
+// processes (GpuStream::mirror_*): one thread per such row, its few nonzeros in
+// fixed order.  The rows are distinct and no row-block touches them.
+__global__ void csx_sym_mirror_rows_kernel(const uint32_t *rows, const uint32_t *ptr, const uint32_t *col,
+                                           const double *val, const double *x, double *y, double alpha,
+                                           uint32_t n)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    double s = 0.0;
+    for (uint32_t k = ptr[t]; k < ptr[t + 1]; ++k) s = fma(val[k], x[col[k]], s);
+    y[rows[t]] += alpha * s;
+}
+
 // ---- host side ------------------------------------------------------------------------------
 
 struct DeviceMatrix {
@@ -682,6 +696,11 @@ struct DeviceMatrix {
     bool deterministic = false;   // spx.gpu.deterministic: wave tiles + fixed-order hand-overs, pinned
     uint32_t *slot_col = nullptr;
     size_t n_slot_col = 0;
+    // symmetric slice: thin mirror image as a CSR over rows of other processes
+    uint32_t n_mirror_rows = 0;
+    size_t n_mirror_nnz = 0;
+    uint32_t *mirror_rows = nullptr, *mirror_ptr = nullptr, *mirror_col = nullptr;
+    double *mirror_val = nullptr;
     // staging vectors of the host-pointer path
     double *d_x = nullptr, *d_y = nullptr;
     double *p_x = nullptr, *p_y = nullptr;      // pinned
@@ -764,6 +783,14 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
         m->slot_col = upload(s.slot_group_col);
         m->n_slot_col = s.slot_group_col.size();
     }
+    if (!s.mirror_rows.empty()) {
+        m->n_mirror_rows = (uint32_t) s.mirror_rows.size();
+        m->n_mirror_nnz = s.mirror_col.size();
+        m->mirror_rows = upload(s.mirror_rows);
+        m->mirror_ptr = upload(s.mirror_ptr);
+        m->mirror_col = upload(s.mirror_col);
+        m->mirror_val = upload(s.mirror_val);
+    }
     m->sym_atomic = s.sym_atomic && m->has_tiles;
     if (s.deterministic) device_set_deterministic(m, true);
     else if (s.wave_tiles) device_set_wave_tiles(m, true);
@@ -786,6 +813,10 @@ void device_free(DeviceMatrix *m)
     if (m->fix_ptr) (void) hipFree(m->fix_ptr);
     if (m->fix_idx) (void) hipFree(m->fix_idx);
     if (m->slot_col) (void) hipFree(m->slot_col);
+    if (m->mirror_rows) (void) hipFree(m->mirror_rows);
+    if (m->mirror_ptr) (void) hipFree(m->mirror_ptr);
+    if (m->mirror_col) (void) hipFree(m->mirror_col);
+    if (m->mirror_val) (void) hipFree(m->mirror_val);
     if (m->d_x) (void) hipFree(m->d_x);
     if (m->d_y) (void) hipFree(m->d_y);
     if (m->p_x) (void) hipHostFree(m->p_x);
@@ -873,6 +904,10 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
         else SPX_LAUNCH(csx_spmv_kernel, 4, lds);
     }
 #undef SPX_LAUNCH
+    if (m->n_mirror_rows)
+        hipLaunchKernelGGL(csx_sym_mirror_rows_kernel, dim3((m->n_mirror_rows + 255) / 256), dim3(256), 0, stream,
+                           m->mirror_rows, m->mirror_ptr, m->mirror_col, m->mirror_val, d_x, d_y, alpha,
+                           m->n_mirror_rows);
     if (m->n_shared)
         hipLaunchKernelGGL(csx_fixup_kernel, dim3((m->n_shared + 63) / 64), dim3(64), 0,
                            stream, m->shared, m->n_shared, m->carry, d_y, alpha, beta,
@@ -1038,6 +1073,12 @@ void device_download(const DeviceMatrix *m, GpuStream &s)
     s.waves = (uint32_t) m->waves;
     s.n_spill = m->n_spill;
     s.lds_doubles = m->lds_doubles;
+    if (m->n_mirror_rows) {
+        download(s.mirror_rows, m->mirror_rows, m->n_mirror_rows);
+        download(s.mirror_ptr, m->mirror_ptr, (size_t) m->n_mirror_rows + 1);
+        download(s.mirror_col, m->mirror_col, m->n_mirror_nnz);
+        download(s.mirror_val, m->mirror_val, m->n_mirror_nnz);
+    }
     s.sym_atomic = m->sym_atomic;
     s.deterministic = m->deterministic;
     s.wave_tiles = m->wave_tiles;
@@ -1047,6 +1088,13 @@ void device_download(const DeviceMatrix *m, GpuStream &s)
         download(s.fix_idx, m->fix_idx, m->n_fix_idx);
     }
     if (m->symmetric) download(s.dvalues, m->dvalues, m->nrows);
+}
+
+void device_poke_mirror(DeviceMatrix *m, size_t index, double value)
+{
+    if (index >= m->n_mirror_nnz) throw FatalError("value index outside the mirror list");
+    HIP_CHECK(hipSetDevice(m->device));
+    HIP_CHECK(hipMemcpy(m->mirror_val + index, &value, sizeof(value), hipMemcpyHostToDevice));
 }
 
 double device_peek(const DeviceMatrix *m, bool diagonal, size_t index)

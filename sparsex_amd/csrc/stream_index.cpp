@@ -134,11 +134,22 @@ void stream_touched_rows(const GpuStream &s, idx_t below, std::vector<idx_t> &ro
     }
     for (uint32_t c : s.spill_col)
         if ((int64_t) c < (int64_t) below) mark[c] = 1;
+    for (uint32_t r : s.mirror_rows)
+        if ((int64_t) r < (int64_t) below) mark[r] = 1;
     // (a restored stream: the per-row lists of the spilled sums are what is left)
     for (size_t r = 0; r + 1 < s.fix_ptr.size() && r < (size_t) below; ++r)
         if (s.fix_ptr[r + 1] > s.fix_ptr[r]) mark[r] = 1;
     for (idx_t r = 0; r < below; ++r)
         if (mark[(size_t) r]) rows.push_back(r);
+}
+
+void stream_locate_mirror(const GpuStream &s, idx_t row, idx_t col, std::vector<size_t> &out)
+{
+    auto it = std::lower_bound(s.mirror_rows.begin(), s.mirror_rows.end(), (uint32_t) row);
+    if (it == s.mirror_rows.end() || *it != (uint32_t) row) return;
+    const size_t t = (size_t) (it - s.mirror_rows.begin());
+    for (uint32_t k = s.mirror_ptr[t]; k < s.mirror_ptr[t + 1]; ++k)
+        if (s.mirror_col[k] == (uint32_t) col) out.push_back(k);
 }
 
 bool stream_validate(const GpuStream &s, size_t nrows, size_t ncols, size_t n_values,
@@ -161,6 +172,14 @@ bool stream_validate(const GpuStream &s, size_t nrows, size_t ncols, size_t n_va
         SPX_REQUIRE(s.fix_ptr[i] <= s.fix_ptr[i + 1], "spill list order");
     SPX_REQUIRE(s.fix_ptr.empty() || s.fix_ptr.back() == s.fix_idx.size(), "spill list end");
     for (uint32_t k : s.fix_idx) SPX_REQUIRE(k < s.n_spill, "spill index");
+    SPX_REQUIRE(s.mirror_rows.empty() ? s.mirror_ptr.size() <= 1 && s.mirror_col.empty()
+                                      : s.mirror_ptr.size() == s.mirror_rows.size() + 1 &&
+                                        s.mirror_ptr.back() == s.mirror_col.size(), "mirror list sizes");
+    SPX_REQUIRE(s.mirror_val.empty() || s.mirror_val.size() == s.mirror_col.size(), "mirror list values");
+    for (size_t i = 0; i < s.mirror_rows.size(); ++i)
+        SPX_REQUIRE(s.mirror_rows[i] < nrows && s.mirror_ptr[i] <= s.mirror_ptr[i + 1] &&
+                    (i == 0 || s.mirror_rows[i] > s.mirror_rows[i - 1]), "mirror list rows");
+    for (uint32_t c : s.mirror_col) SPX_REQUIRE(c < ncols, "mirror list column");
     SPX_REQUIRE(s.slot_group_col.size() * 8 == s.n_spill, "slot groups");
     for (uint32_t c : s.slot_group_col) SPX_REQUIRE(c % 8 == 0 && (size_t) c + 8 <= nrows, "slot group column");
     SPX_REQUIRE(s.dvalues.empty() || s.dvalues.size() == nrows, "diagonal length");

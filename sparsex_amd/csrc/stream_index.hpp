@@ -21,6 +21,10 @@ namespace spx {
 // on the host while its values live in HBM.
 void stream_locate(const GpuStream &s, idx_t row, idx_t col, std::vector<size_t> &out);
 
+// The same for the thin mirror image of a symmetric slice (GpuStream::mirror_*):
+// positions in mirror_val of (row, col).
+void stream_locate_mirror(const GpuStream &s, idx_t row, idx_t col, std::vector<size_t> &out);
+
 // Rows in front of `below` that the stream adds to: rows of lanes of row-blocks
 // that start in front of it, and the columns of symmetric tiles' spilled sums
 // (s.spill_col, host side, still present).  Ascending, unique.  For a process

@@ -25,7 +25,7 @@ class Stream:
     def __init__(self, path):
         with open(path, "rb") as f:
             buf = f.read()
-        assert buf[:8] == b"SPXHIP11", buf[:8]
+        assert buf[:8] == b"SPXHIP12", buf[:8]
         hdr = struct.unpack_from("<4i3Q2i4Q8IQ", buf, 8)
         (self.nrows, self.ncols, self.nnz, self.symmetric, self.nr_partitions, self.first_part,
          self.last_part, self.own_lo, self.own_hi, self.nnz_stored, self.n_unit_elems,
@@ -54,6 +54,8 @@ class Stream:
         self.fix_ptr = vec("<u4")
         self.fix_idx = vec("<u4")
         self.slot_group_col = vec("<u4")
+        self.mirror_rows, self.mirror_ptr = vec("<u4"), vec("<u4")     # symmetric slice: thin mirror image, per row
+        self.mirror_col, self.mirror_val = vec("<u4"), vec("<f8")
         self.perm = vec("<i4")
         # the encoded partitions (kept for exports of a restored matrix) follow
         self.encoded = []
@@ -147,6 +149,12 @@ class Stream:
                         self._tile_adds.append((bi, slot + w, v, row + int(rb["row0"])))
                 else:
                     raise AssertionError("unknown pass kind %d" % int(ps["kind"]))
+        if len(self.mirror_rows):
+            assert self.mirror_ptr.size == self.mirror_rows.size + 1 and int(self.mirror_ptr[-1]) == self.mirror_col.size
+            assert (np.diff(self.mirror_rows.astype(np.int64)) > 0).all() and self.mirror_rows.max() < self.own_lo
+            cnt = np.diff(self.mirror_ptr.astype(np.int64))
+            R.append(np.repeat(self.mirror_rows.astype(np.int64), cnt)); Cc.append(self.mirror_col.astype(np.int64))
+            V.append(self.mirror_val); B.append(np.full(self.mirror_col.size, len(self.rbs)))
         if not R:
             z = np.zeros(0, dtype=np.int64)
             return z, z, np.zeros(0), z

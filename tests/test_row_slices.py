@@ -108,3 +108,50 @@ def test_symmetric_slices_sum_to_the_product(tmp_path, world, gen):
         assert A.get_entry(lo, lo) == a[lo, lo]
     assert np.allclose(y, a @ x, rtol=1e-12, atol=1e-14)
     assert (tiles > 0) == (gen == "nd24k")
+
+
+def test_thin_mirror_image_is_kept_per_row(tmp_path):
+    """The last slice of the KKT stand-in couples, through its constraint rows, into rows all over
+    the grid: a handful of mirrored nonzeros per 512 rows.  They do not become row-blocks of
+    their own (a workgroup per handful of nonzeros doubled that rank's SpMV time) but a small
+    per-row list; entries in it can be read and set like any other."""
+    N, world = 40, 3
+    rp, ci, va, n = synth.syn_nlpkkt_rows(N)
+    va = va.copy()
+    cuts = nnz_balanced_bounds(np.diff(rp), world)
+    lo, hi = cuts[-2], cuts[-1]
+    rl = (rp[lo:hi + 1] - rp[lo]).astype(np.int32)
+    cl, vl = ci[rp[lo]:rp[hi]].copy(), va[rp[lo]:rp[hi]].copy()
+    sx.options_reset()
+    o = slice_opts(lo, n, {"spx.rt.host_only": "true", "spx.matrix.symmetric": "true"})
+    del o["spx.preproc.sampling"]
+    for k, v in o.items():
+        sx.option_set(k, v)
+    A = sx.mat_tune(sx.input_load_csr(rl, cl, vl, hi - lo, n))
+    f = str(tmp_path / "last.spx")
+    A.save(f)
+    s = Stream(f)
+    assert s.mirror_rows.size > 1000 and s.mirror_rows.max() < lo
+    # the row-blocks in front of the slice cover the band only, the list took the thin part
+    front = s.rbs[s.rbs["row0"] < lo]
+    assert int(front["row0"].min()) > lo - 3 * (N * N + N + 1)
+    # an entry whose mirror image lives in the list: (constraint row, coupled grid row)
+    listed = set(s.mirror_rows.tolist())
+    r = next(q for q in range(n - 1, lo, -1) if int(ci[rp[q]]) in listed)
+    k = int(rp[r])
+    c = int(ci[k])                          # its first column: a grid row far in front of the slice
+    assert c < lo
+    assert A.get_entry(r, c) == va[k] and A.get_entry(c, r) == va[k]
+    A.set_entry(r, c, 4.5)
+    assert A.get_entry(c, r) == 4.5
+    A.save(f)
+    s2 = Stream(f)
+    va[k] = 4.5
+    va[rp[c] + int(np.searchsorted(ci[rp[c]:rp[c + 1]], r))] = 4.5
+    full = sp.csr_matrix((va, ci, rp), shape=(n, n))
+    x = synth.random_x(n)
+    lower = sp.tril(full, k=-1).tocsr()[lo:hi]               # strictly lower part of the slice's rows
+    want = np.zeros(n)
+    want[lo:hi] = lower @ x + full.diagonal()[lo:hi] * x[lo:hi]
+    want += lower.T @ x[lo:hi]
+    assert np.allclose(s2.matvec(x), want, rtol=1e-12, atol=1e-14)
