@@ -423,6 +423,8 @@ static void emit_and_upload(spx_matrix_t *A)
     }
     A->conflict_rows.clear();
     if (sym && !gs.sym_fused) stream_touched_rows(gs, A->own_lo, A->conflict_rows);
+    A->first_block_row = A->own_lo;
+    for (const SpxRowBlock &rb : gs.rbs) A->first_block_row = std::min<idx_t>(A->first_block_row, (idx_t) rb.row0);
     finalize_stream(gs, (size_t) A->nrows);
     gs.waves = (uint32_t) A->waves;
     gs.sym_atomic = A->sym_atomic && !A->deterministic;
@@ -1311,6 +1313,8 @@ spx_matrix_t *spx_mat_restore(const char *filename)
     A->device_ordinal = (int) cfg.get_long("spx.rt.device");
     A->full_colind = cfg.get_bool("spx.matrix.full_colind");
     if (A->symmetric && !gs->sym_fused) stream_touched_rows(*gs, A->own_lo, A->conflict_rows);
+    A->first_block_row = A->own_lo;
+    for (const SpxRowBlock &rb : gs->rbs) A->first_block_row = std::min<idx_t>(A->first_block_row, (idx_t) rb.row0);
     try {
         if (!A->host_only) {
             A->dev = device_upload(*gs, (size_t) A->nrows, (size_t) A->ncols, A->symmetric != 0,

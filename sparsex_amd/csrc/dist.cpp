@@ -191,8 +191,13 @@ spx_error_t spx_hip_mat_dist_attach(spx_matrix_t *A, const spx_hip_transport_t *
                                   A->dev != nullptr);
         // the exchange takes over what the caller-side all-reduce needed: rows this
         // process neither owns nor adds to are nobody's business any more
-        if (A->dev && A->symmetric)
-            device_set_init_rows(A->dev, A->conflict_rows.empty() ? A->own_lo : A->conflict_rows.front());
+        // (the thin mirror list stores its rows, it needs no cleared y; spilled tile sums in
+        // front of the row-blocks do)
+        if (A->dev && A->symmetric) {
+            idx_t first = A->first_block_row;
+            if (A->has_tiles && !A->conflict_rows.empty()) first = std::min(first, A->conflict_rows.front());
+            device_set_init_rows(A->dev, (size_t) first);
+        }
     } catch (const FatalError &e) {
         SETERROR_1(SPX_ERR_TUNED_MAT, e.what.c_str());
         return SPX_FAILURE;

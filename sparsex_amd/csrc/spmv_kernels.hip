@@ -661,7 +661,7 @@ __global__ void csx_sym_mirror_rows_kernel(const uint32_t *rows, const uint32_t 
     if (t >= n) return;
     double s = 0.0;
     for (uint32_t k = ptr[t]; k < ptr[t + 1]; ++k) s = fma(val[k], x[col[k]], s);
-    y[rows[t]] += alpha * s;
+    y[rows[t]] = alpha * s;          // (nothing else adds to these rows: no need to clear them first)
 }
 
 // ---- host side ------------------------------------------------------------------------------
@@ -858,6 +858,12 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
             hipLaunchKernelGGL(csx_sym_init_kernel, dim3((unsigned)((last - first + t - 1) / t)),
                                dim3(t), 0, stream, d_y, d_x, m->dvalues, first, last,
                                m->own_lo, m->own_hi, alpha, beta);
+        // the thin mirror list stores its rows; whatever else lands on them (spilled tile
+        // sums) is added afterwards
+        if (m->n_mirror_rows)
+            hipLaunchKernelGGL(csx_sym_mirror_rows_kernel, dim3((m->n_mirror_rows + 255) / 256), dim3(256), 0,
+                               stream, m->mirror_rows, m->mirror_ptr, m->mirror_col, m->mirror_val, d_x, d_y,
+                               alpha, m->n_mirror_rows);
         a.beta = beta = 1.0;
     }
     a.spill = m->spill;
@@ -904,10 +910,6 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
         else SPX_LAUNCH(csx_spmv_kernel, 4, lds);
     }
 #undef SPX_LAUNCH
-    if (m->n_mirror_rows)
-        hipLaunchKernelGGL(csx_sym_mirror_rows_kernel, dim3((m->n_mirror_rows + 255) / 256), dim3(256), 0, stream,
-                           m->mirror_rows, m->mirror_ptr, m->mirror_col, m->mirror_val, d_x, d_y, alpha,
-                           m->n_mirror_rows);
     if (m->n_shared)
         hipLaunchKernelGGL(csx_fixup_kernel, dim3((m->n_shared + 63) / 64), dim3(64), 0,
                            stream, m->shared, m->n_shared, m->carry, d_y, alpha, beta,
