@@ -1595,6 +1595,11 @@ spx_error_t spx_hip_matvec_kernel(spx_value_t alpha, const spx_matrix_t *A,
                                   spx_value_t *y_dev, void *stream)
 {
     if (check_dev(A, x_dev, y_dev) != SPX_SUCCESS) return SPX_FAILURE;
+    if (A->dirty && device_stream_is_capturing(stream)) {
+        // (rebuilding the stream allocates and copies synchronously: not inside a capture)
+        SETERROR_1(SPX_ERR_TUNED_MAT, "the matrix has pending changes: multiply once outside the stream capture first");
+        return SPX_FAILURE;
+    }
     if (!refresh_if_dirty(A)) return SPX_FAILURE;
     try {
         device_spmv(A->dev, alpha, x_dev, beta, y_dev, stream);

@@ -40,6 +40,9 @@ void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x, bool x_p
                       const std::function<void(double *, void *)> &after = nullptr,
                       uint64_t x_version = 0);
 
+// true while `stream` (a hipStream_t) is being captured into a hipGraph
+bool device_stream_is_capturing(void *stream);
+
 // page-locked host memory for the library's own vectors; nullptr when there is
 // no HIP device (the caller falls back to malloc)
 void *device_host_alloc(size_t bytes);

@@ -1036,6 +1036,16 @@ void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x, bool x_p
     if (!y_pinned) std::memcpy(h_y, m->p_y, yb);
 }
 
+bool device_stream_is_capturing(void *stream)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(static_cast<hipStream_t>(stream), &st) != hipSuccess) {
+        (void) hipGetLastError();
+        return false;
+    }
+    return st != hipStreamCaptureStatusNone;
+}
+
 void *device_host_alloc(size_t bytes)
 {
     if (device_count() <= 0) return nullptr;
