@@ -1028,7 +1028,7 @@ spx_error_t spx_mat_set_entry(spx_matrix_t *A, spx_index_t row, spx_index_t colu
 
 namespace {
 
-const char kMagic[8] = {'S', 'P', 'X', 'H', 'I', 'P', '1', '2'};
+const char kMagic[8] = {'S', 'P', 'X', 'H', 'I', 'P', '1', '3'};
 
 template <typename T>
 bool put_vec(FILE *f, const std::vector<T> &v)

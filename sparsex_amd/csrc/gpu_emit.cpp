@@ -415,16 +415,9 @@ void RbBuilder::emit_gather_passes(SpxRowBlock &rb, std::vector<Single> &singles
         }
         std::stable_sort(pcs.begin(), pcs.end(),
                          [](const Piece2 &a, const Piece2 &b) { return a.width < b.width; });
-        auto put_off = [&](size_t at, uint32_t off) {
-            if (width == 2) {
-                uint16_t o = (uint16_t) off;
-                std::memcpy(&out_.cidx[area + at * 2], &o, 2);
-            } else {
-                std::memcpy(&out_.cidx[area + at * 4], &off, 4);
-            }
-        };
-        size_t elems_before = 0;
-        for (size_t b = 0; b < pcs.size();) {
+        // where one pass ends (the same rule below): needed up front for 3-byte offsets,
+        // whose high bytes form an array of their own behind all the low halves
+        auto pass_end = [&](size_t b) {
             size_t e = b, real = 0;
             while (e < pcs.size() && e - b < SPX_PASS_SEGS) {
                 const size_t w = pcs[e].width, lanes = e - b + 1;
@@ -432,6 +425,35 @@ void RbBuilder::emit_gather_passes(SpxRowBlock &rb, std::vector<Single> &singles
                 real += w;
                 ++e;
             }
+            return e;
+        };
+        size_t slots_total = 0;
+        for (size_t b = 0; b < pcs.size();) {
+            const size_t e = pass_end(b);
+            slots_total += (e - b) * pcs[e - 1].width;
+            b = e;
+        }
+        size_t hi_area = 0;
+        if (width == 3) {
+            hi_area = (area + slots_total * 2 + 15) / 16 * 16;
+            rb.hi_off = (uint32_t)((hi_area - cbytes) / 16);
+            out_.cidx.resize(hi_area + slots_total, 0);
+        }
+        auto put_off = [&](size_t at, uint32_t off) {
+            if (width == 2) {
+                uint16_t o = (uint16_t) off;
+                std::memcpy(&out_.cidx[area + at * 2], &o, 2);
+            } else if (width == 3) {
+                uint16_t o = (uint16_t) off;
+                std::memcpy(&out_.cidx[area + at * 2], &o, 2);
+                out_.cidx[hi_area + at] = (uint8_t)(off >> 16);
+            } else {
+                std::memcpy(&out_.cidx[area + at * 4], &off, 4);
+            }
+        };
+        size_t elems_before = 0;
+        for (size_t b = 0; b < pcs.size();) {
+            const size_t e = pass_end(b);
             const uint32_t W = pcs[e - 1].width;
             const size_t nseg = e - b;
             SpxPass ps;
@@ -445,7 +467,7 @@ void RbBuilder::emit_gather_passes(SpxRowBlock &rb, std::vector<Single> &singles
             ps.elem0 = (uint32_t) elems_before;
             const size_t vbase = out_.values.size();
             out_.values.resize(vbase + nseg * W, 0.0);
-            out_.cidx.resize(area + (elems_before + nseg * W) * width, 0);
+            if (width != 3) out_.cidx.resize(area + (elems_before + nseg * W) * width, 0);
             for (size_t l = 0; l < nseg; ++l) {
                 const Piece2 &pc = pcs[b + l];
                 out_.segrows.push_back((uint16_t)((set[pc.first].row - lo) | ((pc.width - 1u) << 9)));
@@ -469,7 +491,7 @@ void RbBuilder::emit_gather_passes(SpxRowBlock &rb, std::vector<Single> &singles
             cmax = std::max(cmax, s.col);
         }
         rb.cbase = (uint32_t) cmin;
-        rb.cidx_width = ((size_t)(cmax - cmin) < 65536) ? 2 : 4;
+        rb.cidx_width = ((size_t)(cmax - cmin) < 65536) ? 2 : ((size_t)(cmax - cmin) < (1u << 24) ? 3 : 4);
         emit_set(singles, SPX_PASS_GATHER, cmin, rb.cidx_width, cbytes);
     }
     if (!near.empty()) {

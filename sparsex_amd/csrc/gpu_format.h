@@ -129,7 +129,8 @@ typedef struct {
     uint32_t row0;        /* first row owned (global)                           */
     uint16_t n_rows;      /* rows owned                                         */
     uint16_t n_pass;
-    uint8_t  cidx_width;  /* 2 or 4 bytes per column offset                     */
+    uint8_t  cidx_width;  /* bytes per column offset: 2, 4, or 3 = a u16 array (low
+                             halves) followed, at hi_off, by a u8 array (bits 16-23) */
     uint8_t  flags;       /* SPX_RB_* */
     uint16_t n_slots;     /* transposed-sum slots (SPX_PASS_SYMTILE): one per
                              distinct column in front of row0 that a tile of this
@@ -142,7 +143,10 @@ typedef struct {
     uint16_t xwin_len;    /* its length in doubles (0: none), <= SPX_MAX_XWIN    */
     uint16_t near_off;    /* u16 offsets of the SPX_PASS_GATHER_LDS passes start
                              at cidx_off * 16 + near_off * 16 bytes               */
-} SpxRowBlock;            /* 56 bytes */
+    uint32_t hi_off;      /* cidx_width 3: the u8 array starts at
+                             cidx_off * 16 + hi_off * 16 bytes                    */
+    uint32_t pad2_;
+} SpxRowBlock;            /* 64 bytes */
 
 #define SPX_RB_SHARED 1u  /* owns one chunk of an over-long row; the partial
                              goes to carry[carry_slot] and a fix-up kernel sums */

@@ -101,6 +101,14 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
 #pragma unroll
                 for (int w = 0; w < W; ++w)
                     goff[b][w] = reinterpret_cast<const uint32_t *>(cidx)[e0 + (uint32_t) w * nseg[b]];
+            } else if (G == 1 && rb.cidx_width == 3) {
+                // 24-bit offsets: the low halves, then (array of its own) the high bytes
+                const uint8_t *hi = cidx + (size_t) rb.hi_off * 16u;
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    const uint32_t e = e0 + (uint32_t) w * nseg[b];
+                    goff[b][w] = (uint32_t) reinterpret_cast<const uint16_t *>(cidx)[e] | ((uint32_t) hi[e] << 16);
+                }
             } else {
 #pragma unroll
                 for (int w = 0; w < W; ++w)

@@ -50,6 +50,7 @@ inline int64_t gather_col(const GpuStream &s, const SpxRowBlock &rb, const SpxPa
     }
     uint16_t v;
     std::memcpy(&v, c + e * 2, 2);
+    if (rb.cidx_width == 3) return (int64_t) rb.cbase + (v | ((uint32_t) c[(size_t) rb.hi_off * 16u + e] << 16));
     return (int64_t) rb.cbase + v;
 }
 
@@ -193,7 +194,7 @@ bool stream_validate(const GpuStream &s, size_t nrows, size_t ncols, size_t n_va
         SPX_REQUIRE(rb.val_off <= n_values && rb.val_off % 2 == 0, "row-block value offset");
         SPX_REQUIRE(rb.desc_off <= s.descs.size(), "row-block descriptor offset");
         SPX_REQUIRE((size_t) rb.cidx_off * 16u <= s.cidx.size(), "row-block column-offset position");
-        SPX_REQUIRE(rb.cidx_width == 2 || rb.cidx_width == 4, "column-offset width");
+        SPX_REQUIRE(rb.cidx_width >= 2 && rb.cidx_width <= 4, "column-offset width");
         SPX_REQUIRE(rb.seg_off <= s.segrows.size(), "row-block row-piece offset");
         SPX_REQUIRE((size_t) rb.n_slots + rb.n_rows + rb.xwin_len <= s.lds_doubles, "row-block LDS use");
         SPX_REQUIRE(rb.xwin_len <= SPX_MAX_XWIN && (size_t) rb.xwin_base + rb.xwin_len <= ncols, "x window");
@@ -213,8 +214,11 @@ bool stream_validate(const GpuStream &s, size_t nrows, size_t ncols, size_t n_va
                 const bool lds = ps.kind == SPX_PASS_GATHER_LDS;
                 SPX_REQUIRE((size_t) rb.seg_off + ps.seg0 + nseg <= s.segrows.size(), "row-piece range");
                 SPX_REQUIRE(((size_t) rb.cidx_off + (lds ? rb.near_off : 0u)) * 16u +
-                            ((size_t) ps.elem0 + (size_t) nseg * W) * (lds ? 2u : rb.cidx_width) <= s.cidx.size(),
-                            "column-offset range");
+                            ((size_t) ps.elem0 + (size_t) nseg * W) * (lds || rb.cidx_width == 3 ? 2u : rb.cidx_width)
+                                <= s.cidx.size(), "column-offset range");
+                SPX_REQUIRE(lds || rb.cidx_width != 3 ||
+                            ((size_t) rb.cidx_off + rb.hi_off) * 16u + (size_t) ps.elem0 + (size_t) nseg * W <= s.cidx.size(),
+                            "column-offset high bytes");
                 for (uint32_t l = 0; l < nseg; ++l) {
                     const uint32_t sr = s.segrows[(size_t) rb.seg_off + ps.seg0 + l];
                     SPX_REQUIRE((sr & 511u) < rb.n_rows && (sr >> 9) < W, "row piece row");

@@ -11,12 +11,12 @@ RB = np.dtype([("val_off", "<u8"), ("pass_off", "<u4"), ("desc_off", "<u4"), ("c
                ("seg_off", "<u4"), ("cbase", "<u4"), ("row0", "<u4"), ("n_rows", "<u2"),
                ("n_pass", "<u2"), ("cidx_width", "u1"), ("flags", "u1"), ("n_slots", "<u2"),
                ("carry_slot", "<u4"), ("spill_off", "<u4"), ("xwin_base", "<u4"), ("xwin_len", "<u2"),
-               ("near_off", "<u2")])
+               ("near_off", "<u2"), ("hi_off", "<u4"), ("pad2", "<u4")])
 PASS = np.dtype([("mask", "<u8"), ("val_off", "<u4"), ("rank0", "<u2"), ("seg0", "<u2"),
                  ("nseg", "u1"), ("width", "u1"), ("kind", "u1"), ("pad", "u1"), ("elem0", "<u4")])
 DESC = np.dtype([("col0", "<u4"), ("bits", "<u4")])
 SHARED = np.dtype([("row", "<u4"), ("first_slot", "<u4"), ("n_slots", "<u4")])
-assert RB.itemsize == 56 and PASS.itemsize == 24 and DESC.itemsize == 8
+assert RB.itemsize == 64 and PASS.itemsize == 24 and DESC.itemsize == 8
 
 KIND_BLOCK, KIND_HORIZ, KIND_VERT, KIND_DIAG, KIND_ADIAG = range(5)
 
@@ -25,7 +25,7 @@ class Stream:
     def __init__(self, path):
         with open(path, "rb") as f:
             buf = f.read()
-        assert buf[:8] == b"SPXHIP12", buf[:8]
+        assert buf[:8] == b"SPXHIP13", buf[:8]
         hdr = struct.unpack_from("<4i3Q2i4Q8IQ", buf, 8)
         (self.nrows, self.ncols, self.nnz, self.symmetric, self.nr_partitions, self.first_part,
          self.last_part, self.own_lo, self.own_hi, self.nnz_stored, self.n_unit_elems,
@@ -120,8 +120,13 @@ class Stream:
                             idx = pair * 2 * nseg + lanes
                         else:
                             idx = pair * 2 * nseg + lanes * 2 + (w & 1)
-                        o = area + (e0 + w * nseg + lanes) * cw
-                        off = sum(self.cidx[o + b].astype(np.int64) << (8 * b) for b in range(cw))
+                        if cw == 3:         # u16 low halves, then (at hi_off) a u8 array of bits 16-23
+                            o = area + (e0 + w * nseg + lanes) * 2
+                            off = self.cidx[o].astype(np.int64) | (self.cidx[o + 1].astype(np.int64) << 8)
+                            off |= self.cidx[area + int(rb["hi_off"]) * 16 + e0 + w * nseg + lanes].astype(np.int64) << 16
+                        else:
+                            o = area + (e0 + w * nseg + lanes) * cw
+                            off = sum(self.cidx[o + b].astype(np.int64) << (8 * b) for b in range(cw))
                         if near:
                             assert (off < int(rb["xwin_len"])).all() and int(rb["xwin_len"]) <= 4096
                         have = plen > w                            # (padding: zero value, offset 0)
