@@ -190,3 +190,23 @@ def test_own_c_example_compiles_and_links(tmp_path):
 def test_own_c_example_solves_on_the_gpu(tmp_path):
     out = subprocess.check_output([_build_cg_example(tmp_path), "120"]).decode()
     assert "CG iterations" in out
+
+
+def _build_dist_example(tmp_path):
+    exe = str(tmp_path / "dist_spmv")
+    subprocess.check_call(["gcc", "-std=gnu99", "-Wall", "-Werror", os.path.join(ROOT, "examples", "dist_spmv.c"),
+                           "-I" + os.path.join(ROOT, "include"), "-L" + os.path.dirname(sx.lib_path()),
+                           "-lsparsex", "-Wl,-rpath," + os.path.dirname(sx.lib_path()), "-lm", "-o", exe])
+    return exe
+
+
+def test_dist_c_example_compiles_and_links(tmp_path):
+    """examples/dist_spmv.c: the row-partitioned symmetric SpMV (row-slice input, RCCL transport,
+    exchange plan) from plain C."""
+    assert os.path.exists(_build_dist_example(tmp_path))
+
+
+@pytest.mark.gpu
+def test_dist_c_example_runs_as_one_rank(tmp_path):
+    out = subprocess.check_output([_build_dist_example(tmp_path), "1", "0", str(tmp_path / "id"), "50000"]).decode()
+    assert "rank 0 of 1" in out and "max |y - exact|" in out
