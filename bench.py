@@ -381,7 +381,9 @@ def kernel_name(info, symmetric, world):
     gen = "csx_spmv_det_kernel<%d> (a y tile per wavefront)" % w if int(info.wave_tiles) else "csx_spmv_kernel<%d>" % w
     if not symmetric:
         return gen
-    if tiles == 2:
+    if tiles == 2 and int(info.sym_segments):
+        main = "csx_sym_init_kernel + csx_spmv_symseg_kernel<%d>" % w
+    elif tiles == 2:
         main = "csx_sym_init_kernel + csx_spmv_symtile_atomic_kernel<%d>" % w
     elif tiles == 1:
         main = ("csx_sym_init_kernel + " if world > 1 else "") + \

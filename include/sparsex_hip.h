@@ -33,6 +33,14 @@
  *                           symmetric tiles' sums through the fixed-order lists)
  *   spx.gpu.sym_spill       symmetric tiles' transposed sums: "lists" (second kernel,
  *                           fixed order), "atomic" (global atomics), "auto" (measured)
+ *   spx.gpu.sym_segments    symmetric path: runs of three or more consecutive columns of the
+ *                           lower triangle are read once and used for both triangles
+ *                           ("true"), their mirror image is stored instead ("false"), or
+ *                           "auto" (default): read once where at least half of the triangle
+ *                           lies in such runs and the triangle has 16 M nonzeros or more (a
+ *                           smaller matrix stays in the Infinity Cache, where reading it
+ *                           twice is cheaper than the extra atomics); implies the atomic
+ *                           hand-over
  *   spx.gpu.x_window        "false": leftovers never gather from an LDS window of x
  *   spx.vec.device          "true": vectors the library creates keep x's HBM copy
  *                           between spx_matvec_* calls
@@ -227,7 +235,8 @@ typedef struct {
     double  emit_seconds;    /* descriptor stream + upload                      */
     int32_t wave_tiles;      /* 1: every wavefront of a workgroup adds into a y tile
                                 of its own (summed in wavefront order)          */
-    int32_t pad2_;
+    int32_t sym_segments;    /* 1: the stream holds row segments of the lower triangle
+                                that are read once and used twice (SPX_PASS_SYMSEG) */
 } spx_hip_info_t;
 
 spx_error_t spx_hip_mat_info(const spx_matrix_t *A, spx_hip_info_t *info);

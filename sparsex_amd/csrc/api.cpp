@@ -297,11 +297,21 @@ static void encode_partition(Partition &p, const EncoderParams &prm, const Xform
     }
 }
 
-static bool stream_has_tiles(const GpuStream &s)
+static bool stream_has_symsegs(const GpuStream &s)
 {
     for (const SpxRowBlock &rb : s.rbs)
         for (uint32_t k = 0; k < rb.n_pass; ++k)
-            if (s.passes[(size_t) rb.pass_off + k].kind == SPX_PASS_SYMTILE) return true;
+            if (s.passes[(size_t) rb.pass_off + k].kind == SPX_PASS_SYMSEG) return true;
+    return false;
+}
+
+static bool stream_has_tiles(const GpuStream &s)
+{
+    for (const SpxRowBlock &rb : s.rbs)
+        for (uint32_t k = 0; k < rb.n_pass; ++k) {
+            const uint8_t kind = s.passes[(size_t) rb.pass_off + k].kind;
+            if (kind == SPX_PASS_SYMTILE || kind == SPX_PASS_SYMSEG) return true;
+        }
     return false;
 }
 
@@ -346,13 +356,15 @@ static void emit_and_upload(spx_matrix_t *A)
     const unsigned hw = host_threads();
     // pieces (partitions, row ranges) are emitted concurrently into streams of
     // their own and joined in order; threads left over work inside a piece
-    auto emit_pieces = [&](std::vector<Partition> &pieces, const std::vector<std::vector<SymTile>> *tl) {
+    auto emit_pieces = [&](std::vector<Partition> &pieces, const std::vector<std::vector<SymTile>> *tl,
+                           const std::vector<std::vector<SymSeg>> *sl = nullptr) {
         const size_t n = pieces.size();
         std::vector<GpuStream> locs(n);
         const unsigned inner = (unsigned) std::max<size_t>(1, hw / std::max<size_t>(1, std::min<size_t>(n, hw)));
         parallel_for(n, hw, [&](size_t i) {
             GpuEmitParams g = gp;
             if (tl) g.tiles = &(*tl)[i];
+            if (sl) g.symsegs = &(*sl)[i];
             emit_gpu(pieces[i], g, locs[i], inner);
         });
         for (GpuStream &l : locs) append_stream(gs, std::move(l));
@@ -397,9 +409,36 @@ static void emit_and_upload(spx_matrix_t *A)
             std::vector<Partition> fulls;
             std::vector<std::vector<SymTile>> tiles;
             std::vector<MirrorPoint> thin;
+            // read-once row segments need the atomic hand-over (their fall-back adds straight
+            // to y) and so exclude the deterministic mode
+            std::vector<std::vector<SymSeg>> segs;
+            size_t n_seg_elems = 0, n_lower = 0;
+            for (const Partition &pt : A->parts) n_lower += pt.nnz;
+            const size_t min_lower = (size_t) 16 << 20;       // (auto: see below)
+            const bool want_segs = gp.sym_segments != 0 && !A->deterministic && A->spill_mode != 0 && !A->wave_tiles &&
+                                   (gp.sym_segments == 1 || n_lower >= min_lower);
             build_sym_ranges(A->parts, ranges, gp.max_rows >= 8, fulls, tiles, hw,
-                             gs.sym_fused ? nullptr : &thin);
-            emit_pieces(fulls, &tiles);
+                             gs.sym_fused ? nullptr : &thin, want_segs ? &segs : nullptr);
+            for (const auto &v : segs)
+                for (const SymSeg &sg : v) n_seg_elems += sg.width;
+            // (auto: worth it where most of the stored triangle lies in such runs and the
+            // matrix does not stay in the Infinity Cache anyway -- measured on syn-nlpkkt: 181 MB
+            // of values 6 % slower, 433 MB 24 % faster, 5.9 GB 15 % faster than with the mirror
+            // image stored; syn-cant, 30 MB, 25 % slower)
+            const bool use_segs = want_segs && n_seg_elems > 0 &&
+                                  (gp.sym_segments == 1 || 2 * n_seg_elems >= n_lower);
+            if (want_segs && !use_segs) {
+                // not worth it: the segments go back to the mirrored path
+                segs.clear();
+                fulls.clear();
+                tiles.clear();
+                thin.clear();
+                build_sym_ranges(A->parts, ranges, gp.max_rows >= 8, fulls, tiles, hw,
+                                 gs.sym_fused ? nullptr : &thin, nullptr);
+            }
+            A->has_symsegs = use_segs;
+            if (use_segs) A->sym_atomic = true;
+            emit_pieces(fulls, &tiles, use_segs ? &segs : nullptr);
             // thinly spread mirror image on rows of other processes: a CSR over those rows
             for (size_t k = 0; k < thin.size(); ++k) {
                 if (k == 0 || thin[k].row != thin[k - 1].row) {
@@ -700,6 +739,14 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     A->emit_params.sym_once = cfg.get_bool("spx.gpu.sym_once");
     A->emit_params.recut_linear = cfg.get_bool("spx.gpu.recut_linear");
     A->emit_params.x_window = cfg.get_bool("spx.gpu.x_window");
+    {
+        const std::string m = cfg.get_str("spx.gpu.sym_segments");
+        if (m != "auto" && m != "true" && m != "false") {
+            log_msg(LOG_ERR, "spx.gpu.sym_segments: true, false or auto\n");
+            throw FatalError("bad spx.gpu.sym_segments");
+        }
+        A->emit_params.sym_segments = m == "auto" ? -1 : (m == "true" ? 1 : 0);
+    }
     A->emit_params.stack_segments = cfg.get_bool("spx.gpu.stack_segments");
     {
         idx_t lo = nown ? A->bounds[first].row_start : 0;
@@ -718,6 +765,7 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     }
     A->deterministic = cfg.get_bool("spx.gpu.deterministic");
     A->sym_atomic = spill_mode == "atomic" && !A->deterministic;
+    A->spill_mode = spill_mode == "lists" ? 0 : (spill_mode == "atomic" ? 1 : -1);
     const std::string wt_mode = cfg.get_str("spx.gpu.wave_tiles");
     if (wt_mode != "auto" && wt_mode != "true" && wt_mode != "false") {
         log_msg(LOG_ERR, "spx.gpu.wave_tiles: true, false or auto\n");
@@ -725,8 +773,8 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     }
     A->wave_tiles = wt_mode == "true" ? 1 : 0;          // (auto: off until measured)
     emit_and_upload(A.get());
-    const bool tune_spill = spill_mode == "auto" && !A->deterministic;
-    const bool tune_wt = wt_mode == "auto" && !A->deterministic;
+    const bool tune_spill = spill_mode == "auto" && !A->deterministic && !A->has_symsegs;
+    const bool tune_wt = wt_mode == "auto" && !A->deterministic && !A->has_symsegs;
     if (A->dev && A->nnz_stored >= 100000 && (autotune || tune_spill || tune_wt))
         autotune_launch(A.get(), autotune, tune_spill, tune_wt);
     if (!cfg.get_bool("spx.rt.keep_encoded")) {
@@ -1301,6 +1349,7 @@ spx_matrix_t *spx_mat_restore(const char *filename)
     A->n_rowblocks = gs->rbs.size();
     A->n_shared = gs->shared.size();
     A->has_tiles = stream_has_tiles(*gs);
+    A->has_symsegs = stream_has_symsegs(*gs);
     A->sym_atomic = gs->sym_atomic;
     A->deterministic = gs->deterministic;
     A->wave_tiles = gs->wave_tiles ? 1 : 0;
@@ -1662,6 +1711,7 @@ spx_error_t spx_hip_mat_info(const spx_matrix_t *A, spx_hip_info_t *info)
     info->waves = A->dev ? device_get_waves(A->dev) : A->waves;
     info->sym_tiles = A->has_tiles ? ((A->dev ? device_get_sym_atomic(A->dev) : A->sym_atomic) ? 2 : 1) : 0;
     info->wave_tiles = A->dev ? (device_get_wave_tiles(A->dev) ? 1 : 0) : (A->wave_tiles == 1 || A->deterministic ? 1 : 0);
+    info->sym_segments = A->has_symsegs ? 1 : 0;
     info->tune_seconds = A->tune_seconds;
     info->emit_seconds = A->emit_seconds;
     return SPX_SUCCESS;

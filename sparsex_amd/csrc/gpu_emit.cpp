@@ -39,6 +39,7 @@ struct Group {
     uint8_t kind;        // SPX_KIND_*
     uint8_t step;
     uint32_t voff;       // into RbBuilder::gvals_
+    uint32_t slot0 = SPX_NO_SLOT;   // SPX_PASS_SYMSEG: slot of segment 0's first column
 };
 
 class RbBuilder {
@@ -50,7 +51,8 @@ public:
     void emit(idx_t lo, idx_t hi, const std::vector<Piece> &pieces,
               std::vector<Single> &singles, uint8_t flags, uint32_t carry_slot,
               const std::vector<const SymTile *> *tiles = nullptr,
-              const std::vector<RowSeg> *rowsegs = nullptr);
+              const std::vector<RowSeg> *rowsegs = nullptr,
+              const std::vector<const SymSeg *> *symsegs = nullptr);
 
 private:
     void add_group(idx_t row, idx_t col, size_t nseg, size_t width, unsigned kind, unsigned step)
@@ -67,7 +69,19 @@ private:
     }
     void groups_from_piece(const Piece &pc, idx_t lo);
     void stack_groups();
-    void emit_unit_passes(SpxRowBlock &rb);
+    void emit_unit_passes(SpxRowBlock &rb, bool sym = false);
+    void assign_slots(SpxRowBlock &rb, const std::vector<const SymTile *> *tiles,
+                      const std::vector<const SymSeg *> *symsegs);
+    void slot_symseg_groups(const SpxRowBlock &rb);
+    // slot of global column c in the current row-block (SPX_NO_SLOT: none)
+    uint32_t slot_of(const SpxRowBlock &rb, idx_t c) const
+    {
+        if (c >= (idx_t) rb.row0) return (uint32_t) rb.n_slots + (uint32_t)(c - (idx_t) rb.row0);
+        const idx_t g = c & ~(idx_t) 7;
+        auto it = std::lower_bound(slot_groups_.begin(), slot_groups_.end(), g);
+        if (it == slot_groups_.end() || *it != g) return SPX_NO_SLOT;
+        return (uint32_t)(it - slot_groups_.begin()) * 8u + (uint32_t)(c & 7);
+    }
     void emit_gather_passes(SpxRowBlock &rb, std::vector<Single> &singles, idx_t lo);
     void emit_tile_passes(SpxRowBlock &rb, const std::vector<const SymTile *> &tiles);
 
@@ -77,6 +91,7 @@ private:
     bool x_window_;
     std::vector<Group> groups_;
     std::vector<val_t> gvals_;
+    std::vector<idx_t> slot_groups_;   // first columns of the row-block's slot groups (ascending)
 };
 
 void RbBuilder::groups_from_piece(const Piece &pc, idx_t lo)
@@ -267,7 +282,7 @@ void RbBuilder::stack_groups()
     gvals_.swap(vals);
 }
 
-void RbBuilder::emit_unit_passes(SpxRowBlock &rb)
+void RbBuilder::emit_unit_passes(SpxRowBlock &rb, bool sym)
 {
     // passes hold segments of one width: order the groups by width
     std::vector<uint32_t> order(groups_.size());
@@ -288,7 +303,7 @@ void RbBuilder::emit_unit_passes(SpxRowBlock &rb)
         ps.seg0 = (uint16_t)(seg_counter - lanes.size());
         ps.nseg = (uint8_t) lanes.size();
         ps.width = width;
-        ps.kind = SPX_PASS_UNIT;
+        ps.kind = sym ? SPX_PASS_SYMSEG : SPX_PASS_UNIT;
         const size_t nseg = lanes.size();
         size_t base = out_.values.size();
         out_.values.resize(base + nseg * width, 0.0);
@@ -315,6 +330,12 @@ void RbBuilder::emit_unit_passes(SpxRowBlock &rb)
         d.bits = spx_desc_bits(g.row0, seg_counter, g.kind, g.step);
         uint32_t di = (uint32_t)(out_.descs.size() - rb.desc_off);
         out_.descs.push_back(d);
+        if (sym) {
+            SpxUnitDesc d2;        // second half of a symmetric unit's descriptor: its slot
+            d2.col0 = g.slot0;
+            d2.bits = 0;
+            out_.descs.push_back(d2);
+        }
         ++out_.n_units;
         for (uint16_t s = 0; s < g.nseg; ++s) {
             lanes.push_back(Slot{di, gi, s});
@@ -505,6 +526,84 @@ void RbBuilder::emit_gather_passes(SpxRowBlock &rb, std::vector<Single> &singles
     }
 }
 
+// The transposed-sum slots of a row-block: one group of eight per aligned group of eight
+// columns in front of its first row that a tile or a read-once row segment touches (tiles
+// first: they cannot do without), as many as the LDS holds.
+void RbBuilder::assign_slots(SpxRowBlock &rb, const std::vector<const SymTile *> *tiles,
+                             const std::vector<const SymSeg *> *symsegs)
+{
+    const idx_t row0 = (idx_t) rb.row0;
+    slot_groups_.clear();
+    if (tiles)
+        for (const SymTile *t : *tiles)
+            if (t->col0 < row0) slot_groups_.push_back(t->col0 & ~(idx_t) 7);
+    std::sort(slot_groups_.begin(), slot_groups_.end());
+    slot_groups_.erase(std::unique(slot_groups_.begin(), slot_groups_.end()), slot_groups_.end());
+    assert(slot_groups_.size() * 8 <= SPX_MAX_TILE_SLOTS);
+    if (symsegs && !symsegs->empty()) {
+        std::vector<idx_t> more;
+        for (const SymSeg *sg : *symsegs)
+            for (idx_t c = sg->col & ~(idx_t) 7; c < sg->col + sg->width && c < row0; c += 8) more.push_back(c);
+        std::sort(more.begin(), more.end());
+        more.erase(std::unique(more.begin(), more.end()), more.end());
+        // (nearest to the row-block first, should they not all fit: the others add to y directly)
+        for (size_t k = more.size(); k-- > 0;) {
+            if ((slot_groups_.size() + 1) * 8 > SPX_MAX_TILE_SLOTS) break;
+            if (!std::binary_search(slot_groups_.begin(), slot_groups_.end(), more[k])) slot_groups_.push_back(more[k]);
+        }
+        std::sort(slot_groups_.begin(), slot_groups_.end());
+        slot_groups_.erase(std::unique(slot_groups_.begin(), slot_groups_.end()), slot_groups_.end());
+    }
+    rb.n_slots = (uint16_t)(slot_groups_.size() * 8);
+    rb.spill_off = (uint32_t) out_.spill_col.size();
+    for (idx_t g : slot_groups_)
+        for (idx_t c = g; c < g + 8; ++c) out_.spill_col.push_back((uint32_t) c);
+    out_.lds_doubles = std::max<uint32_t>(out_.lds_doubles, (uint32_t) rb.n_slots + rb.n_rows);
+}
+
+// Gives every group of read-once segments (groups_, after stacking) its slot: segment s of a
+// group uses slot0 + s * dcol, so the slots of all its segments must lie in one run of
+// consecutive slots; a group whose segments do not (they leave a window of touched columns,
+// or cross the row-block's first row where the slots do not continue into the y tile) is
+// broken into its segments, and a segment that still has no run of slots of its own gets none.
+void RbBuilder::slot_symseg_groups(const SpxRowBlock &rb)
+{
+    auto seg_slot = [&](idx_t col, unsigned width) -> uint32_t {
+        const uint32_t s0 = slot_of(rb, col);
+        if (s0 == SPX_NO_SLOT) return SPX_NO_SLOT;
+        for (unsigned w = 1; w < width; ++w)
+            if (slot_of(rb, col + (idx_t) w) != s0 + w) return SPX_NO_SLOT;
+        return s0;
+    };
+    std::vector<Group> out;
+    for (Group g : groups_) {
+        const int dcol = (g.kind == SPX_KIND_HORIZ || g.kind == SPX_KIND_DIAG) ? (int) g.step
+                         : (g.kind == SPX_KIND_ADIAG ? -(int) g.step : 0);
+        const int drow = g.kind == SPX_KIND_BLOCK ? 1 : (g.kind >= SPX_KIND_VERT ? (int) g.step : 0);
+        const uint32_t s0 = seg_slot((idx_t) g.col0, g.width);
+        bool ok = s0 != SPX_NO_SLOT;
+        for (uint32_t sidx = 1; ok && sidx < g.nseg; ++sidx)
+            ok = seg_slot((idx_t) g.col0 + (idx_t) sidx * dcol, g.width) == s0 + (uint32_t)((int) sidx * dcol);
+        if (ok || g.nseg == 1) {
+            g.slot0 = s0;
+            out.push_back(g);
+            continue;
+        }
+        for (uint32_t sidx = 0; sidx < g.nseg; ++sidx) {
+            Group one = g;
+            one.row0 = (uint16_t)(g.row0 + sidx * drow);
+            one.col0 = (uint32_t)((int64_t) g.col0 + (int64_t) sidx * dcol);
+            one.nseg = 1;
+            one.kind = SPX_KIND_HORIZ;
+            one.step = 0;
+            one.voff = g.voff + sidx * g.width;
+            one.slot0 = seg_slot((idx_t) one.col0, g.width);
+            out.push_back(one);
+        }
+    }
+    groups_.swap(out);
+}
+
 // Symmetric tiles of this row-block: eight tiles per pass, lanes 8t..8t+7 the
 // rows of tile t.  The transposed sums of a tile's eight columns go to
 // consecutive slots: columns in front of the row-block's first row are ranked
@@ -514,20 +613,8 @@ void RbBuilder::emit_tile_passes(SpxRowBlock &rb, const std::vector<const SymTil
 {
     if (tiles.empty()) return;
     const idx_t row0 = (idx_t) rb.row0;
-    // (tiles start on columns that are multiples of eight; a group of eight columns
-    // that begins in front of the row-block is taken whole, also where the
-    // row-block -- whose first row need not be a multiple of eight -- begins inside it)
-    std::vector<idx_t> cols;
-    for (const SymTile *t : tiles)
-        if (t->col0 < row0)
-            for (idx_t c = t->col0; c < t->col0 + 8; ++c) cols.push_back(c);
-    std::sort(cols.begin(), cols.end());
-    cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
-    assert(cols.size() <= SPX_MAX_TILE_SLOTS);
-    rb.n_slots = (uint16_t) cols.size();
-    rb.spill_off = (uint32_t) out_.spill_col.size();
-    for (idx_t c : cols) out_.spill_col.push_back((uint32_t) c);
-    out_.lds_doubles = std::max<uint32_t>(out_.lds_doubles, (uint32_t) rb.n_slots + rb.n_rows);
+    // (the slots were laid out by assign_slots: tiles start on columns that are multiples of
+    // eight, a group of eight columns that begins in front of the row-block is taken whole)
     for (size_t b = 0; b < tiles.size(); b += 8) {
         const size_t nt = std::min<size_t>(8, tiles.size() - b);
         const uint32_t nseg = (uint32_t)(8 * nt);
@@ -543,11 +630,8 @@ void RbBuilder::emit_tile_passes(SpxRowBlock &rb, const std::vector<const SymTil
         out_.values.resize(base + (size_t) nseg * 8, 0.0);
         for (size_t k = 0; k < nt; ++k) {
             const SymTile &t = *tiles[b + k];
-            uint32_t slot;
-            if (t.col0 < row0)
-                slot = (uint32_t)(std::lower_bound(cols.begin(), cols.end(), t.col0) - cols.begin());
-            else
-                slot = (uint32_t) rb.n_slots + (uint32_t)(t.col0 - row0);
+            const uint32_t slot = slot_of(rb, t.col0);
+            assert(slot != SPX_NO_SLOT);
             SpxUnitDesc d;
             d.col0 = (uint32_t) t.col0;
             d.bits = (uint32_t)(t.row0 - row0) | (slot << 9);
@@ -567,7 +651,8 @@ void RbBuilder::emit_tile_passes(SpxRowBlock &rb, const std::vector<const SymTil
 
 void RbBuilder::emit(idx_t lo, idx_t hi, const std::vector<Piece> &pieces,
                      std::vector<Single> &singles, uint8_t flags, uint32_t carry_slot,
-                     const std::vector<const SymTile *> *tiles, const std::vector<RowSeg> *rowsegs)
+                     const std::vector<const SymTile *> *tiles, const std::vector<RowSeg> *rowsegs,
+                     const std::vector<const SymSeg *> *symsegs)
 {
     SpxRowBlock rb;
     std::memset(&rb, 0, sizeof(rb));
@@ -580,7 +665,23 @@ void RbBuilder::emit(idx_t lo, idx_t hi, const std::vector<Piece> &pieces,
     rb.flags = flags;
     rb.carry_slot = carry_slot;
 
+    if ((tiles && !tiles->empty()) || (symsegs && !symsegs->empty())) assign_slots(rb, tiles, symsegs);
     if (tiles) emit_tile_passes(rb, *tiles);      // the bulk of the work first
+    size_t n_sym = 0;
+    if (symsegs && !symsegs->empty()) {
+        // row segments of the lower triangle that are read once: grouped like any others,
+        // then given their slots
+        groups_.clear();
+        gvals_.clear();
+        for (const SymSeg *sg : *symsegs) {
+            add_group(sg->row - p_.row_start - lo, sg->col, 1, sg->width, SPX_KIND_HORIZ, 0);
+            gvals_.insert(gvals_.end(), sg->v, sg->v + sg->width);
+        }
+        n_sym = gvals_.size();
+        if (stack_) stack_groups();
+        slot_symseg_groups(rb);
+        emit_unit_passes(rb, true);
+    }
     groups_.clear();
     gvals_.clear();
     for (const Piece &pc : pieces) groups_from_piece(pc, lo);
@@ -599,9 +700,9 @@ void RbBuilder::emit(idx_t lo, idx_t hi, const std::vector<Piece> &pieces,
     pad_to(out_.values, 2);
     assert(n_unit + n_delta <= 2 * SPX_MAX_RB_ELEMS);
 
-    out_.n_unit_elems += n_unit;
+    out_.n_unit_elems += n_unit + n_sym;
     out_.n_delta_elems += n_delta;
-    out_.nnz_stored += n_unit + n_delta;
+    out_.nnz_stored += n_unit + n_delta + n_sym;
     out_.rbs.push_back(rb);
 }
 
@@ -852,7 +953,8 @@ void append_stream(GpuStream &dst, GpuStream &&src)
 void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<SymRange> &ranges,
                       bool want_tiles, std::vector<Partition> &outs,
                       std::vector<std::vector<SymTile>> &tiles, unsigned nthreads,
-                      std::vector<MirrorPoint> *sparse_mirror)
+                      std::vector<MirrorPoint> *sparse_mirror,
+                      std::vector<std::vector<SymSeg>> *symsegs)
 {
     const size_t P = lowers.size(), R = ranges.size();
     outs.assign(R, Partition());
@@ -911,7 +1013,8 @@ void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<Sy
     // the nonzeros of the full rows (lower + mirror image) where there are tiles
     size_t n_tiles = 0;
     for (size_t i = 0; i < P; ++i) n_tiles += ptiles[i].size();
-    if (n_tiles) {
+    std::vector<char> long_row;          // rows that an over-long row-block chunking could hit
+    if (n_tiles || symsegs) {
         std::vector<std::atomic<uint32_t>> cnt((size_t) nrows);
         for (auto &c : cnt) c.store(0, std::memory_order_relaxed);
         parallel_for(P, nthreads, [&](size_t i) {
@@ -940,6 +1043,59 @@ void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<Sy
             }
             ptiles[i].swap(keep);
         });
+        if (symsegs) {
+            long_row.assign((size_t) nrows, 0);
+            for (size_t r = 0; r < (size_t) nrows; ++r)
+                long_row[r] = cnt[r].load(std::memory_order_relaxed) > SPX_MAX_RB_ELEMS;
+        }
+    }
+
+    // 2b. read-once row segments: of what is not in a tile, the runs of three and more
+    // consecutive columns of a row (cut into pieces of at most eight) are neither mirrored:
+    // a lane will add their transposed products to the slots of its row-block
+    std::vector<std::vector<SymSeg>> psegs(P);
+    if (symsegs) {
+        symsegs->assign(R, std::vector<SymSeg>());
+        parallel_for(P, nthreads, [&](size_t i) {
+            std::vector<Single> &pts = rest[i];
+            std::sort(pts.begin(), pts.end(), [](const Single &a, const Single &b) {
+                return a.row < b.row || (a.row == b.row && a.col < b.col);
+            });
+            std::vector<Single> loose;
+            for (size_t a = 0; a < pts.size();) {
+                size_t b = a + 1;
+                while (b < pts.size() && pts[b].row == pts[a].row && pts[b].col == pts[b - 1].col + 1) ++b;
+                // a run of b - a consecutive columns: pieces of eight, the remainder if >= 3
+                // (not on rows so long that they are chunked over several row-blocks)
+                size_t k = a;
+                const bool take = !long_row[(size_t) pts[a].row - 1];
+                for (; take && b - k >= 3; k += std::min<size_t>(8, b - k)) {
+                    const size_t w = std::min<size_t>(8, b - k);
+                    if (b - k - w > 0 && b - k - w < 3 && w == 8 && b - k < 11) {
+                        // (do not leave a tail of one or two: split 9 and 10 as 5+4 / 5+5)
+                        const size_t w1 = (b - k + 1) / 2;
+                        SymSeg sg;
+                        sg.row = pts[k].row - 1; sg.col = pts[k].col - 1; sg.width = (uint8_t) w1;
+                        for (size_t q = 0; q < w1; ++q) sg.v[q] = pts[k + q].val;
+                        psegs[i].push_back(sg);
+                        k += w1;
+                        const size_t w2 = b - k;
+                        sg.row = pts[k].row - 1; sg.col = pts[k].col - 1; sg.width = (uint8_t) w2;
+                        for (size_t q = 0; q < w2; ++q) sg.v[q] = pts[k + q].val;
+                        psegs[i].push_back(sg);
+                        k = b;
+                        break;
+                    }
+                    SymSeg sg;
+                    sg.row = pts[k].row - 1; sg.col = pts[k].col - 1; sg.width = (uint8_t) w;
+                    for (size_t q = 0; q < w; ++q) sg.v[q] = pts[k + q].val;
+                    psegs[i].push_back(sg);
+                }
+                for (; k < b; ++k) loose.push_back(pts[k]);
+                a = b;
+            }
+            pts.swap(loose);
+        });
     }
 
     // 3. mirror image of what is not in a tile, dealt to the range of its row
@@ -966,6 +1122,7 @@ void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<Sy
                 pts.insert(pts.end(), rest[i].begin(), rest[i].end());
                 std::vector<Single>().swap(rest[i]);
                 tiles[j].swap(ptiles[i]);
+                if (symsegs) (*symsegs)[j].swap(psegs[i]);
             }
             pts.insert(pts.end(), bucket[i][j].begin(), bucket[i][j].end());
             std::vector<Single>().swap(bucket[i][j]);
@@ -1077,6 +1234,9 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsi
     const std::vector<SymTile> &tiles = prm.tiles ? *prm.tiles : no_tiles;
     for (const SymTile &t : tiles)
         for (idx_t r = 0; r < 8; ++r) cnt[(size_t)(t.row0 - p.row_start + r)] += 8;
+    static const std::vector<SymSeg> no_segs;
+    const std::vector<SymSeg> &symsegs = prm.symsegs ? *prm.symsegs : no_segs;
+    for (const SymSeg &sg : symsegs) cnt[(size_t)(sg.row - p.row_start)] += sg.width;
 
     // 2. row ranges of the row-blocks.  Symmetric tiles sit on rows that are
     // multiples of eight (global numbering); such a group of eight rows is never
@@ -1267,6 +1427,15 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsi
         rb_tiles[pl].push_back(&t);
     }
 
+    // 3c. read-once row segments: to the row-block of their row (an over-long row has none:
+    // build_sym_ranges leaves such rows to the mirrored path -- checked here)
+    std::vector<std::vector<const SymSeg *>> rb_segs(plans.size());
+    for (const SymSeg &sg : symsegs) {
+        const uint32_t pl = plan_of_row[(size_t)(sg.row - p.row_start)];
+        if (plans[pl].split) throw FatalError("read-once segment on an over-long row");
+        rb_segs[pl].push_back(&sg);
+    }
+
     // 4. emit: the row-blocks are independent of each other, so contiguous runs
     // of them are built by several threads into streams of their own and joined
     // in order
@@ -1275,10 +1444,10 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsi
         std::vector<RowSeg> rowsegs;
         recut_plan(i, rowsegs);
         if (prm.skip_empty && pieces[i].empty() && singles[i].empty() && rb_tiles[i].empty() &&
-            rowsegs.empty())
+            rowsegs.empty() && rb_segs[i].empty())
             return;
         if (!pl.split) {
-            bld.emit(pl.row_lo, pl.row_hi, pieces[i], singles[i], 0, 0, &rb_tiles[i], &rowsegs);
+            bld.emit(pl.row_lo, pl.row_hi, pieces[i], singles[i], 0, 0, &rb_tiles[i], &rowsegs, &rb_segs[i]);
             return;
         }
         // an over-long row: everything is a single here; chunk it

@@ -20,6 +20,13 @@ struct SymTile {
     val_t v[64];           // row-major
 };
 
+// A row segment of the strictly lower triangle that is read once (SPX_PASS_SYMSEG).
+struct SymSeg {
+    idx_t row, col;        // 0-based, global
+    uint8_t width;         // 3..8
+    val_t v[8];
+};
+
 struct GpuStream {
     std::vector<val_t> values;
     std::vector<SpxUnitDesc> descs;
@@ -95,9 +102,12 @@ struct GpuEmitParams {
     bool sym_remine = true;       // spx.gpu.sym_remine (see append_sym_expanded)
     bool x_window = true;         // spx.gpu.x_window: stage a window of x in LDS for leftovers
                                   // whose columns lie close together
+    int sym_segments = -1;        // spx.gpu.sym_segments: 1 / 0, -1 = where most of the lower triangle
+                                  // lies in runs of three and more columns
     bool sym_once = true;         // spx.gpu.sym_once: dense 8x8 tiles of a symmetric matrix are
                                   // read once (one process holding the whole matrix only)
     const std::vector<SymTile> *tiles = nullptr;   // symmetric, fused: tiles read once (sorted by row0)
+    const std::vector<SymSeg> *symsegs = nullptr;  // symmetric: lower row segments read once (sorted by row)
 };
 
 // Appends the row-blocks of partition `p` (horizontal order) to `out`.
@@ -133,7 +143,9 @@ void append_sym_expanded(const Partition &lower, Partition &out, bool remine_upp
 // it goes to `sparse_mirror` instead, if given): dense 8x8 tiles on rows that are multiples of eight go to
 // `tiles[range]` (sorted by row), everything else goes to `outs[range]` together
 // with the mirror image that falls into the range, both re-cut into row
-// segments and blocks; rows of outs[j] are relative to ranges[j].lo.  Ranges
+// segments and blocks; rows of outs[j] are relative to ranges[j].lo.  With `symsegs`, runs of three
+// and more consecutive columns of a row of what is not in a tile are not mirrored either: they go to
+// symsegs[range] (sorted by row) and are read once as well (SPX_PASS_SYMSEG).  Ranges
 // are independent of each other, so they are built -- and can then be emitted
 // -- concurrently.
 struct SymRange { idx_t lo, hi; };
@@ -141,7 +153,8 @@ struct MirrorPoint { idx_t row, col; val_t val; };      // 0-based global; row <
 void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<SymRange> &ranges,
                       bool want_tiles, std::vector<Partition> &outs,
                       std::vector<std::vector<SymTile>> &tiles, unsigned nthreads,
-                      std::vector<MirrorPoint> *sparse_mirror = nullptr);
+                      std::vector<MirrorPoint> *sparse_mirror = nullptr,
+                      std::vector<std::vector<SymSeg>> *symsegs = nullptr);
 
 // coordinates (1-based, horizontal order) of element k of a unit
 inline void unit_elem_coords(const Elem &u, size_t k, idx_t &r, idx_t &c)

@@ -82,6 +82,20 @@
                                 offsets relative to xwin_base                      */
 #define SPX_MAX_XWIN    4096  /* doubles of x a row-block may stage in LDS (32 KB)  */
 
+#define SPX_PASS_SYMSEG 5     /* symmetric path, values read ONCE: row segments of the
+                                stored lower triangle, one per lane as in a unit pass;
+                                besides its row sum a(r,c..c+W-1) . x[c..] the lane adds
+                                the W transposed products a(r,c+w) * x[r] to the
+                                row-block's transposed-sum slots (the same slots the
+                                tiles use).  Two SpxUnitDesc entries per unit: the unit
+                                descriptor, then {slot of segment 0's first column, 0};
+                                segment s uses slot + s * dcol.  Slot 0xFFFFFFFF: no slot
+                                (window full, or the segment straddles the row-block's
+                                first row): the lane adds straight to y with global
+                                atomics.  Only in streams whose sums are handed over
+                                atomically (sym_atomic)                              */
+#define SPX_NO_SLOT 0xFFFFFFFFu
+
 #define SPX_KIND_BLOCK  0u   /* rows of a dense block: drow 1, dcol 0             */
 #define SPX_KIND_HORIZ  1u   /* same row, column step `step`                      */
 #define SPX_KIND_VERT   2u   /* same column, row step `step`                      */

@@ -403,6 +403,77 @@ __device__ __forceinline__ void symtile_pass(const KernelArgs &a, const SpxRowBl
 #endif
 }
 
+// A pass of read-once row segments of a symmetric matrix (SPX_PASS_SYMSEG): a unit pass
+// whose lanes, besides the row sum a(r, c..c+W-1) . x[c..], add the W transposed products
+// a(r, c+w) * x[r] to the slots of their columns (consecutive slots, consecutive LDS
+// addresses; lanes of neighbouring rows mostly hit different ones) -- every value is read
+// once and used twice.  A segment without slots adds straight to y (global atomics; the
+// kernel's hand-over is atomic anyway).
+template <int W>
+__device__ __forceinline__ void symseg_pass(const KernelArgs &a, const SpxRowBlock &rb,
+                                            const SpxPass &ps, double *slots, double *tile, int lane)
+{
+    const uint32_t nseg = ps.nseg;
+    const bool active = (uint32_t) lane < nseg;
+    const uint32_t l = active ? (uint32_t) lane : 0u;
+    const uint32_t rank = (uint32_t) ps.rank0 + 2u * (active ? starts_upto(ps.mask, lane) : 0u);
+    const uint2 q = *reinterpret_cast<const uint2 *>(a.descs + rb.desc_off + rank);
+    const uint32_t slot0 = a.descs[rb.desc_off + rank + 1u].col0;
+    const double *vals = a.values + rb.val_off + ps.val_off;
+    double v[W];
+#pragma unroll
+    for (int p = 0; p < W / 2; ++p) {
+        const double2 vv = *reinterpret_cast<const double2 *>(vals + (uint32_t) p * 2u * nseg + l * 2u);
+        v[2 * p] = vv.x;
+        v[2 * p + 1] = vv.y;
+    }
+    if (W & 1) v[W - 1] = vals[(uint32_t) (W / 2) * 2u * nseg + l];
+    const uint32_t bits = q.y;
+    const int s = (int) ((ps.seg0 + l - ((bits >> 9) & 8191u)) & 0xffffu);
+    const uint32_t kind = (bits >> 22) & 7u;
+    const int step = (int) (bits >> 25);
+    const int drow = kind == SPX_KIND_BLOCK ? 1 : (kind >= SPX_KIND_VERT ? step : 0);
+    const int dcol = (kind == SPX_KIND_HORIZ || kind == SPX_KIND_DIAG) ? step : (kind == SPX_KIND_ADIAG ? -step : 0);
+    const int row = (int) (bits & 511u) + s * drow;
+    const uint32_t col = q.x + (uint32_t) (s * dcol);
+    const double *xp = a.x + col;
+    const double xr = a.x[rb.row0 + (uint32_t) row];
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) t = fma(v[w], xp[w], t);
+    if (!active) return;
+    atomicAdd(&tile[row], t);
+    if (slot0 != SPX_NO_SLOT) {
+        double *sl = slots + slot0 + (uint32_t) (s * dcol);
+#ifdef SPX_ABL_SEG_NOSLOTADD
+        double u = 0.0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) u += v[w] * xr;
+        if (u == 1.2345) sl[0] = u;
+#else
+#pragma unroll
+        for (int w = 0; w < W; ++w) atomicAdd(&sl[w], v[w] * xr);
+#endif
+    } else {
+        double *yp = a.y + col;
+#pragma unroll
+        for (int w = 0; w < W; ++w) atomicAdd(&yp[w], a.alpha * (v[w] * xr));
+    }
+}
+
+__device__ __forceinline__ void run_symseg(const KernelArgs &a, const SpxRowBlock &rb, const SpxPass &ps,
+                                           double *slots, double *tile, int lane)
+{
+    switch (ps.width) {            // wave-uniform
+    case 3: symseg_pass<3>(a, rb, ps, slots, tile, lane); break;
+    case 4: symseg_pass<4>(a, rb, ps, slots, tile, lane); break;
+    case 5: symseg_pass<5>(a, rb, ps, slots, tile, lane); break;
+    case 6: symseg_pass<6>(a, rb, ps, slots, tile, lane); break;
+    case 7: symseg_pass<7>(a, rb, ps, slots, tile, lane); break;
+    default: symseg_pass<8>(a, rb, ps, slots, tile, lane); break;
+    }
+}
+
 __device__ __forceinline__ void run_pass(const KernelArgs &a, const SpxRowBlock &rb,
                                          const SpxPass &ps, double *tile, const double *win, int lane)
 {
@@ -426,7 +497,7 @@ __device__ __forceinline__ void run_pass(const KernelArgs &a, const SpxRowBlock 
 // own, and the copies are summed in wavefront order before the write-out -- the
 // only thing in this library whose order of additions is not fixed is the LDS adds
 // of different wavefronts of a workgroup into the shared tile.
-template <bool SYM, bool ATOMIC, int WAVES_PER_BLOCK, bool DET = false>
+template <bool SYM, bool ATOMIC, int WAVES_PER_BLOCK, bool DET = false, bool SEGS = false>
 __device__ __forceinline__ void spmv_body(const KernelArgs &a, uint32_t blocks_per_xcd,
                                           double *lds)
 {
@@ -473,7 +544,17 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, uint32_t blocks_p
 #endif
     for (int t = wave; t < n_pass; t += 2 * WAVES_PER_BLOCK) {
         const bool two = t + WAVES_PER_BLOCK < n_pass;
-        if (SYM && p0.kind == SPX_PASS_SYMTILE) {
+        if (SEGS && (p0.kind == SPX_PASS_SYMSEG || (two && p1.kind == SPX_PASS_SYMSEG))) {
+            // read-once row segments (atomic hand-over only); whatever shares the round runs on its own
+            if (p0.kind == SPX_PASS_SYMSEG) run_symseg(a, rb, p0, mine, tile, lane);
+            else if (p0.kind == SPX_PASS_SYMTILE) symtile_pass(a, rb, p0, mine, tile, lane);
+            else run_pass(a, rb, p0, tile, win, lane);
+            if (two) {
+                if (p1.kind == SPX_PASS_SYMSEG) run_symseg(a, rb, p1, mine, tile, lane);
+                else if (p1.kind == SPX_PASS_SYMTILE) symtile_pass(a, rb, p1, mine, tile, lane);
+                else run_pass(a, rb, p1, tile, win, lane);
+            }
+        } else if (SYM && p0.kind == SPX_PASS_SYMTILE) {
             symtile_pass(a, rb, p0, mine, tile, lane);
             if (two) {
                 if (p1.kind == SPX_PASS_SYMTILE) symtile_pass(a, rb, p1, mine, tile, lane);
@@ -516,9 +597,11 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, uint32_t blocks_p
     } else if (ATOMIC) {
         for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS)
             atomicAdd(&a.y[(size_t) rb.row0 + i], a.alpha * tile[i]);
+#ifndef SPX_ABL_SEG_NOFLUSH
         const uint32_t *gcol = a.slot_col + (rb.spill_off >> 3);
         for (int i = threadIdx.x; i < n_slots; i += BLOCK_THREADS)
             atomicAdd(&a.y[(size_t) gcol[i >> 3] + (i & 7)], a.alpha * lds[i]);
+#endif
     } else {
         for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS) {
             const size_t g = (size_t) rb.row0 + i;
@@ -569,6 +652,17 @@ void csx_spmv_symtile_kernel(SPX_KERNEL_PARAMS)
     SPX_KERNEL_ARGS(a);
     extern __shared__ double lds_dyn[];
     spmv_body<true, false, WAVES>(a, blocks_per_xcd, lds_dyn);
+}
+
+// the atomic hand-over kernel for streams that also hold read-once row segments
+// (SPX_PASS_SYMSEG): a kernel of its own so that the tile-only one keeps its registers
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES)
+void csx_spmv_symseg_kernel(SPX_KERNEL_PARAMS)
+{
+    SPX_KERNEL_ARGS(a);
+    extern __shared__ double lds_dyn[];
+    spmv_body<true, true, WAVES, false, true>(a, blocks_per_xcd, lds_dyn);
 }
 
 template <int WAVES>
@@ -700,6 +794,7 @@ struct DeviceMatrix {
     uint32_t *fix_ptr = nullptr, *fix_idx = nullptr;
     size_t n_fix_ptr = 0, n_fix_idx = 0;
     bool sym_atomic = false;   // transposed sums go straight into y (global atomics), no second kernel
+    bool has_symsegs = false;     // the stream holds SPX_PASS_SYMSEG passes
     bool wave_tiles = false;      // a y tile per wavefront, summed in wavefront order before the write-out
     bool deterministic = false;   // spx.gpu.deterministic: wave tiles + fixed-order hand-overs, pinned
     uint32_t *slot_col = nullptr;
@@ -779,7 +874,11 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
     m->lds_doubles = s.lds_doubles;
     for (const SpxRowBlock &rb : s.rbs)
         for (uint32_t k = 0; k < rb.n_pass && !m->has_tiles; ++k)
-            m->has_tiles = s.passes[rb.pass_off + k].kind == SPX_PASS_SYMTILE;
+            m->has_tiles = s.passes[rb.pass_off + k].kind == SPX_PASS_SYMTILE ||
+                           s.passes[rb.pass_off + k].kind == SPX_PASS_SYMSEG;
+    for (const SpxRowBlock &rb : s.rbs)
+        for (uint32_t k = 0; k < rb.n_pass && !m->has_symsegs; ++k)
+            m->has_symsegs = s.passes[rb.pass_off + k].kind == SPX_PASS_SYMSEG;
     // (n_slots + n_rows <= 3584 doubles = 28 KB: within the default dynamic LDS limit)
     if (s.n_spill) {
         std::vector<double> zero_spill(s.n_spill, 0.0);
@@ -799,7 +898,7 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
         m->mirror_col = upload(s.mirror_col);
         m->mirror_val = upload(s.mirror_val);
     }
-    m->sym_atomic = s.sym_atomic && m->has_tiles;
+    m->sym_atomic = (s.sym_atomic || m->has_symsegs) && m->has_tiles;
     if (s.deterministic) device_set_deterministic(m, true);
     else if (s.wave_tiles) device_set_wave_tiles(m, true);
     m->n_values = s.values.size(); m->n_descs = s.descs.size(); m->n_passes = s.passes.size();
@@ -900,7 +999,11 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
         // symmetric tiles: slots + y tile in dynamic LDS, then the rows collect
         // what other row-blocks spilled for them
         const size_t lds = m->lds_doubles * sizeof(double);
-        if (m->sym_atomic) {
+        if (m->sym_atomic && m->has_symsegs) {
+            if (m->waves == 2) SPX_LAUNCH(csx_spmv_symseg_kernel, 2, lds);
+            else if (m->waves == 8) SPX_LAUNCH(csx_spmv_symseg_kernel, 8, lds);
+            else SPX_LAUNCH(csx_spmv_symseg_kernel, 4, lds);
+        } else if (m->sym_atomic) {
             if (m->waves == 2) SPX_LAUNCH(csx_spmv_symtile_atomic_kernel, 2, lds);
             else if (m->waves == 8) SPX_LAUNCH(csx_spmv_symtile_atomic_kernel, 8, lds);
             else SPX_LAUNCH(csx_spmv_symtile_atomic_kernel, 4, lds);
@@ -929,7 +1032,7 @@ void device_set_init_rows(DeviceMatrix *m, size_t first_row) { m->init_lo = firs
 
 void device_set_sym_atomic(DeviceMatrix *m, bool on)
 {
-    m->sym_atomic = on && m->has_tiles && m->n_spill && !m->wave_tiles;
+    m->sym_atomic = (on || m->has_symsegs) && m->has_tiles && !m->wave_tiles;
 }
 
 // per-wavefront tiles need waves x the LDS: pick the largest wavefront count that fits

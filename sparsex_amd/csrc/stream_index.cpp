@@ -19,10 +19,13 @@ struct LaneSeg { int64_t row; int64_t col0; int64_t dcol_elem; bool ok; };
 
 // row (relative to the row-block) and first column of lane l of a unit pass
 inline void unit_lane(const GpuStream &s, const SpxRowBlock &rb, const SpxPass &ps, uint32_t l,
-                      int64_t &row, int64_t &col)
+                      int64_t &row, int64_t &col, uint32_t *slot = nullptr)
 {
-    const uint32_t rank = (uint32_t) ps.rank0 + popcount_upto(ps.mask, l);
+    // (read-once symmetric segments: two entries per unit, the second holds the slot)
+    const uint32_t stride = ps.kind == SPX_PASS_SYMSEG ? 2u : 1u;
+    const uint32_t rank = (uint32_t) ps.rank0 + stride * popcount_upto(ps.mask, l);
     const SpxUnitDesc &d = s.descs[(size_t) rb.desc_off + rank];
+    if (slot) *slot = stride == 2 ? s.descs[(size_t) rb.desc_off + rank + 1].col0 : SPX_NO_SLOT;
     const uint32_t bits = d.bits;
     const int sidx = (int) ((ps.seg0 + l - ((bits >> 9) & 8191u)) & 0xffffu);
     const uint32_t kind = (bits >> 22) & 7u;
@@ -32,6 +35,7 @@ inline void unit_lane(const GpuStream &s, const SpxRowBlock &rb, const SpxPass &
                          ? step : (kind == SPX_KIND_ADIAG ? -step : 0);
     row = (int64_t) (bits & 511u) + (int64_t) sidx * drow;
     col = (int64_t) d.col0 + (int64_t) sidx * dcol;
+    if (slot && *slot != SPX_NO_SLOT) *slot = (uint32_t)((int64_t) *slot + (int64_t) sidx * dcol);
 }
 
 // column of leftover e of a gather pass (through L2, or from the x window)
@@ -115,26 +119,31 @@ void stream_touched_rows(const GpuStream &s, idx_t below, std::vector<idx_t> &ro
     if (below <= 0) return;
     std::vector<char> mark((size_t) below, 0);
     for (const SpxRowBlock &rb : s.rbs) {
-        if ((int64_t) rb.row0 >= (int64_t) below) continue;
         for (uint32_t t = 0; t < rb.n_pass; ++t) {
             const SpxPass &ps = s.passes[(size_t) rb.pass_off + t];
+            // (row-blocks of own rows matter through what they hand to rows in front of them)
+            if ((int64_t) rb.row0 >= (int64_t) below && ps.kind != SPX_PASS_SYMSEG && ps.kind != SPX_PASS_SYMTILE) continue;
             for (uint32_t l = 0; l < ps.nseg; ++l) {
                 int64_t r;
                 if (is_gather(ps)) {
                     r = s.segrows[(size_t) rb.seg_off + ps.seg0 + l] & 511u;
                 } else if (ps.kind == SPX_PASS_SYMTILE) {
-                    r = (int64_t) (s.descs[(size_t) rb.desc_off + ps.rank0 + (l >> 3)].bits & 511u) + (l & 7u);
+                    const SpxUnitDesc &d = s.descs[(size_t) rb.desc_off + ps.rank0 + (l >> 3)];
+                    r = (int64_t) (d.bits & 511u) + (l & 7u);
+                    const int64_t c = (int64_t) d.col0 + (l & 7u);   // the transposed tile's row
+                    if (c < (int64_t) below) mark[(size_t) c] = 1;
                 } else {
                     int64_t c;
                     unit_lane(s, rb, ps, l, r, c);
+                    if (ps.kind == SPX_PASS_SYMSEG)                  // through a slot or straight into y
+                        for (uint32_t w = 0; w < ps.width; ++w)
+                            if (c + w < (int64_t) below) mark[(size_t)(c + w)] = 1;
                 }
                 r += rb.row0;
                 if (r < (int64_t) below) mark[(size_t) r] = 1;
             }
         }
     }
-    for (uint32_t c : s.spill_col)
-        if ((int64_t) c < (int64_t) below) mark[c] = 1;
     for (uint32_t r : s.mirror_rows)
         if ((int64_t) r < (int64_t) below) mark[r] = 1;
     // (a restored stream: the per-row lists of the spilled sums are what is left)
@@ -240,15 +249,23 @@ bool stream_validate(const GpuStream &s, size_t nrows, size_t ncols, size_t n_va
                     SPX_REQUIRE((size_t) (d.bits >> 9) + 8u <= (size_t) rb.n_slots + rb.n_rows, "tile slots");
                 }
             } else {
-                SPX_REQUIRE(ps.kind == SPX_PASS_UNIT, "pass kind");
+                const bool sym = ps.kind == SPX_PASS_SYMSEG;
+                SPX_REQUIRE(ps.kind == SPX_PASS_UNIT || sym, "pass kind");
+                SPX_REQUIRE(!sym || s.sym_atomic, "read-once segments without the atomic hand-over");
                 SPX_REQUIRE((ps.mask & 1ull) == 0, "segment-start mask");
-                const uint32_t last = (uint32_t) ps.rank0 + popcount_upto(ps.mask, nseg - 1);
+                const uint32_t last = (uint32_t) ps.rank0 + (sym ? 2u : 1u) * popcount_upto(ps.mask, nseg - 1) + (sym ? 1u : 0u);
                 SPX_REQUIRE((size_t) rb.desc_off + last < s.descs.size(), "descriptor range");
                 for (uint32_t l = 0; l < nseg; ++l) {
                     int64_t r, c;
-                    unit_lane(s, rb, ps, l, r, c);
+                    uint32_t slot;
+                    unit_lane(s, rb, ps, l, r, c, &slot);
                     SPX_REQUIRE(r >= 0 && r < (int64_t) rb.n_rows, "segment row");
                     SPX_REQUIRE(c >= 0 && (size_t) c + W <= ncols, "segment columns");
+                    if (sym) {
+                        SPX_REQUIRE(c + (int64_t) W <= (int64_t) rb.row0 + r, "read-once segment above the diagonal");
+                        SPX_REQUIRE(slot == SPX_NO_SLOT || (size_t) slot + W <= (size_t) rb.n_slots + rb.n_rows,
+                                    "segment slots");
+                    }
                 }
             }
         }

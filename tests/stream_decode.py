@@ -76,12 +76,15 @@ class Stream:
             for ps in self.passes[int(rb["pass_off"]):int(rb["pass_off"]) + int(rb["n_pass"])]:
                 pv = vbase + int(ps["val_off"])
                 assert pv % 2 == 0                    # 16-byte aligned lane loads
-                if ps["kind"] == 0:
+                if ps["kind"] in (0, 5):
+                    # unit pass; kind 5: read-once row segments of a symmetric matrix (two descriptor
+                    # entries per unit, the second holds the slot; every value counts twice)
+                    sym = ps["kind"] == 5
                     nseg, W, mask = int(ps["nseg"]), int(ps["width"]), int(ps["mask"])
                     assert 1 <= nseg <= 64 and 1 <= W <= 8 and not (mask & 1)
                     lanes = np.arange(nseg)
                     starts = np.array([(mask >> l) & 1 for l in range(nseg)])
-                    rank = int(ps["rank0"]) + np.cumsum(starts)
+                    rank = int(ps["rank0"]) + (2 if sym else 1) * np.cumsum(starts)
                     d = self.descs[int(rb["desc_off"]) + rank]
                     bits = d["bits"].astype(np.int64)
                     s = (int(ps["seg0"]) + lanes - ((bits >> 9) & 8191)) & 0xffff
@@ -92,6 +95,13 @@ class Stream:
                     row = (bits & 511) + s * drow
                     col = d["col0"].astype(np.int64) + s * dcol
                     assert (row < int(rb["n_rows"])).all(), "segment leaves its row-block"
+                    if sym:
+                        assert self.symmetric and self.sym_atomic
+                        slot0 = self.descs[int(rb["desc_off"]) + rank + 1]["col0"].astype(np.int64)
+                        has = slot0 != 0xFFFFFFFF
+                        slot = np.where(has, slot0 + s * dcol, -1)
+                        assert (col + W - 1 < row + int(rb["row0"])).all()       # strictly below the diagonal
+                        assert (slot[has] + W <= int(rb["n_slots"]) + int(rb["n_rows"])).all()
                     for w in range(W):
                         pair = w >> 1
                         if (W & 1) and w == W - 1:
@@ -100,6 +110,13 @@ class Stream:
                             idx = pair * 2 * nseg + lanes * 2 + (w & 1)
                         R.append(row + int(rb["row0"])); Cc.append(col + w)
                         V.append(self.values[pv + idx]); B.append(np.full(nseg, bi))
+                        if sym:
+                            v = self.values[pv + idx]
+                            grow = row + int(rb["row0"])
+                            # slotted lanes hand their transposed products to the slots, the others add to y
+                            R.append((col + w)[has]); Cc.append(grow[has]); V.append(v[has]); B.append(np.full(int(has.sum()), -1 - bi))
+                            self._tile_adds.append((bi, (slot + w)[has], v[has], grow[has]))
+                            R.append((col + w)[~has]); Cc.append(grow[~has]); V.append(v[~has]); B.append(np.full(int((~has).sum()), bi))
                 elif ps["kind"] in (2, 4):
                     # gather pass: lane l owns W leftover nonzeros of one row; kind 4: their
                     # columns lie in the row-block's x window (u16 offsets from xwin_base)

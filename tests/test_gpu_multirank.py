@@ -38,11 +38,12 @@ def run_bench(world, extra, port):
 @pytest.mark.parametrize("name,extra,tiles", [
     ("nlpkkt", ["--edge", "28"], False),
     ("nlpkkt-sym", ["--edge", "28", "--symmetric"], False),
+    ("nlpkkt-sym-segments", ["--edge", "28", "--symmetric", "--opt", "spx.gpu.sym_segments=true"], False),
     ("nd24k-sym", ["--workload", "syn-nd24k", "--scale", "0.15", "--symmetric"], True),
     ("nd24k-sym-atomic", ["--workload", "syn-nd24k", "--scale", "0.15", "--symmetric",
                           "--opt", "spx.gpu.sym_spill=atomic"], True),
     ("webbase", ["--workload", "syn-webbase", "--scale", "0.1"], False),
-], ids=["nlpkkt", "nlpkkt-sym", "nd24k-sym", "nd24k-sym-atomic", "webbase"])
+], ids=["nlpkkt", "nlpkkt-sym", "nlpkkt-sym-segments", "nd24k-sym", "nd24k-sym-atomic", "webbase"])
 def test_ranks_share_one_gpu(world, name, extra, tiles):
     out = run_bench(world, extra, 29700 + 10 * world + len(name))
     assert out["n_gpus"] == world and out["scaling"] == "strong" and out["value"] > 0

@@ -142,6 +142,37 @@ def test_demopatt_reference_scenarios():
         check_y(csr, x, y, 0.5)
 
 
+@pytest.mark.parametrize("segs", ["true", "false"])
+@pytest.mark.parametrize("threads", ["1", "3"])
+@pytest.mark.parametrize("name,gen", [
+    ("cant", lambda: synth.syn_cant(0.1)),
+    ("nd24k", lambda: synth.syn_nd24k(0.05)),
+    ("kkt", lambda: synth.syn_nlpkkt_rows(20)),
+], ids=["cant", "nd24k", "kkt"])
+def test_symmetric_read_once_segments(name, gen, threads, segs):
+    """spx.gpu.sym_segments: runs of consecutive columns of the lower triangle are read once --
+    the lane adds its row sum to the y tile and value * x[row] to the columns' rows (LDS slots
+    or global atomics); same product as with the mirror image stored."""
+    csr = gen()
+    n = csr[3]
+    A = tune(csr, {"spx.gpu.sym_segments": segs, "spx.rt.nr_threads": threads}, sym=True)
+    assert A.info().sym_segments == int(segs == "true")
+    x = synth.random_x(n)
+    y = np.full(n, np.nan)
+    A.matvec_mult(0.5, x, y)
+    check_y(csr, x, y, 0.5)
+    yo, _ = oracle_y(A, x, 0.5)
+    check_vs_oracle(csr, x, y, yo, 0.5)
+    y0 = synth.random_x(n, seed=3)
+    y1 = y0.copy()
+    A.matvec_kernel(1.5, x, -0.25, y1)
+    check_y(csr, x, y1, 1.5, -0.25, y0)
+    # repeated products agree to rounding (the hand-over order varies)
+    y2 = np.empty(n)
+    A.matvec_mult(0.5, x, y2)
+    check_y(csr, x, y2, 0.5)
+
+
 @pytest.mark.parametrize("mode", ["lists", "atomic", "auto"])
 @pytest.mark.parametrize("threads", ["1", "3"])
 def test_symmetric_tiles_hand_over_modes(mode, threads):

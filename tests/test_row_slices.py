@@ -133,8 +133,9 @@ def test_thin_mirror_image_is_kept_per_row(tmp_path):
     s = Stream(f)
     assert s.mirror_rows.size > 1000 and s.mirror_rows.max() < lo
     # the row-blocks in front of the slice cover the band only, the list took the thin part
+    # (none at all where the band went into read-once row segments, which add into y themselves)
     front = s.rbs[s.rbs["row0"] < lo]
-    assert int(front["row0"].min()) > lo - 3 * (N * N + N + 1)
+    assert front.size == 0 or int(front["row0"].min()) > lo - 3 * (N * N + N + 1)
     # an entry whose mirror image lives in the list: (constraint row, coupled grid row)
     listed = set(s.mirror_rows.tolist())
     r = next(q for q in range(n - 1, lo, -1) if int(ci[rp[q]]) in listed)

@@ -174,6 +174,79 @@ def test_symmetric_slices_sum_to_the_product(tmp_path, once):
     assert (tiles > 0) == (once == "true")
 
 
+def _scattered_sym(n=6000, per_row=9, seed=23):
+    """Random symmetric pattern with a few planted runs of 3..12 consecutive columns."""
+    rng = np.random.RandomState(seed)
+    r = np.repeat(np.arange(n), per_row)
+    c = rng.randint(0, n, r.size)
+    rr = rng.randint(20, n, 300)
+    ln = rng.randint(3, 13, 300)
+    c0 = (rng.uniform(0, 1, 300) * (rr - ln)).astype(np.int64)
+    r = np.concatenate([r] + [np.full(l, q) for q, l in zip(rr, ln)])
+    c = np.concatenate([c] + [np.arange(a, a + l) for a, l in zip(c0, ln)])
+    keep = c < r
+    low = sp.coo_matrix((rng.uniform(-1, 1, int(keep.sum())), (r[keep], c[keep])), shape=(n, n)).tocsr()
+    low.sum_duplicates()
+    m = (low + low.T + sp.diags(np.asarray(abs(low + low.T).sum(axis=1)).ravel() + 1.0)).tocsr()
+    m.sort_indices()
+    return m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data.copy(), n
+
+
+@pytest.mark.parametrize("threads", ["1", "3"])
+@pytest.mark.parametrize("mode", ["true", "false", "auto"])
+@pytest.mark.parametrize("name,gen,auto_on", [
+    # (auto: only beyond 16 M nonzeros in the triangle -- tests/test_gpu_fullsize.py has such a case)
+    ("nlpkkt", lambda: synth.syn_nlpkkt_rows(10), False),     # stencil rows: runs of four and six columns
+    ("cant", lambda: synth.syn_cant(0.05), False),
+    ("nd24k", lambda: synth.syn_nd24k(0.02), False),          # dense tiles take the triangle first
+    ("scattered", lambda: _scattered_sym(), False),           # hardly any runs
+], ids=["nlpkkt", "cant", "nd24k", "scattered"])
+def test_symmetric_row_segments_are_stored_once(tmp_path, name, gen, auto_on, mode, threads):
+    """spx.gpu.sym_segments: runs of >= 3 consecutive columns of the lower triangle become
+    SPX_PASS_SYMSEG passes -- stored once, the lane forms the row sum AND hands value * x[row]
+    to the columns' rows (through a slot of the row-block or straight into y)."""
+    csr = gen()
+    rp, ci, va, n = csr
+    A = tune(csr, {"spx.gpu.sym_segments": mode, "spx.rt.nr_threads": threads, "spx.preproc.sampling": "none"},
+             sym=True, host_only=True)
+    f = str(tmp_path / "m.spx")
+    A.save(f)
+    s = Stream(f)
+    used = np.zeros(len(s.passes), bool)
+    for rb in s.rbs:
+        used[int(rb["pass_off"]):int(rb["pass_off"]) + int(rb["n_pass"])] = True
+    has = bool((s.passes["kind"][used] == 5).any())
+    assert A.info().sym_segments == int(has)
+    if mode == "false":
+        assert not has
+    elif mode == "true":
+        assert has
+    elif auto_on is not None:
+        assert has == auto_on
+    if has:
+        assert s.sym_atomic and A.info().sym_tiles == 2
+        # what was a mirrored copy is gone: about the lower triangle is stored, not twice that
+        lower = synth.lower_plus_diag_nnz(rp, ci) - n
+        assert s.nnz_stored < (2.0 if name == "scattered" else 1.35) * lower + n
+    r, c, v, b, m = dense_of(s)
+    a = sp.csr_matrix((va, ci, rp), shape=(n, n))
+    off = a - sp.diags(a.diagonal())
+    assert abs(m.tocsr() - off.tocsr()).max() == 0
+    s.check_ownership()
+    x = synth.random_x(n)
+    assert np.allclose(s.matvec(x), a @ x, rtol=1e-12, atol=1e-14)
+    # a restored matrix keeps them, and its entries can still be read and set from either triangle
+    B = sx.mat_restore(f)
+    assert B.info().sym_segments == int(has)
+    k = int(rp[n // 2]) if ci[rp[n // 2]] < n // 2 else int(rp[n // 2 + 1])
+    row = int(np.searchsorted(rp, k, side="right") - 1)
+    col = int(ci[k])
+    if col < row:
+        assert B.get_entry(row, col) == va[k] == B.get_entry(col, row)
+        B.set_entry(col, row, 2.5)
+        assert B.get_entry(row, col) == 2.5
+
+
 def _one_rowblock_sym():
     """12 x 12 blocks of 8 x 8, block (i, j) present for j in {i, i-1, i-3}: small enough for ONE row-block."""
     nb = 12
