@@ -583,10 +583,15 @@ def main():
     if world > 1:
         if backend == "nccl":
             transport = None
+            # (every rank first shows that its library can reach librccl at all: a rank that
+            # cannot would leave the others waiting inside the communicator's initialisation)
             try:
-                ids = [sx.rccl_unique_id() if rank == 0 else None]
+                mine_id = sx.rccl_unique_id()
             except sx.SpxError:
-                ids = [None]
+                mine_id = None
+            can = torch.tensor([1 if mine_id is not None else 0], device=dev)
+            dist.all_reduce(can, op=dist.ReduceOp.MIN)
+            ids = [mine_id if rank == 0 and int(can.item()) else None]
             dist.broadcast_object_list(ids, src=0)
             if ids[0] is not None:
                 try:
