@@ -382,7 +382,7 @@ def kernel_name(info, symmetric, world):
     if not symmetric:
         return gen
     if tiles == 2 and int(info.sym_segments):
-        main = "csx_sym_init_kernel + csx_spmv_symseg_kernel<%d>" % w
+        main = "csx_sym_init_kernel + csx_spmv_symseg_%skernel<%d>" % ("notile_" if int(info.sym_segments) == 2 else "", w)
     elif tiles == 2:
         main = "csx_sym_init_kernel + csx_spmv_symtile_atomic_kernel<%d>" % w
     elif tiles == 1:

@@ -41,6 +41,11 @@
  *                           smaller matrix stays in the Infinity Cache, where reading it
  *                           twice is cheaper than the extra atomics); implies the atomic
  *                           hand-over
+ *   spx.gpu.sym_wide_rows   rows of a row-block that holds such segments: consecutive row-blocks
+ *                           (512 rows at most each) go side by side into one with a common y
+ *                           tile and common slots, so that a column several of them reach is
+ *                           handed to y once (default 1024, at most 2048; measured on syn-nlpkkt,
+ *                           734 M nonzeros: 512 0.842 ms, 1024 0.826 ms, 2048 0.92 ms)
  *   spx.gpu.x_window        "false": leftovers never gather from an LDS window of x
  *   spx.vec.device          "true": vectors the library creates keep x's HBM copy
  *                           between spx_matvec_* calls
@@ -235,8 +240,9 @@ typedef struct {
     double  emit_seconds;    /* descriptor stream + upload                      */
     int32_t wave_tiles;      /* 1: every wavefront of a workgroup adds into a y tile
                                 of its own (summed in wavefront order)          */
-    int32_t sym_segments;    /* 1: the stream holds row segments of the lower triangle
-                                that are read once and used twice (SPX_PASS_SYMSEG) */
+    int32_t sym_segments;    /* the stream holds row segments of the lower triangle
+                                that are read once and used twice (SPX_PASS_SYMSEG):
+                                1 = next to dense tiles, 2 = and no tiles           */
 } spx_hip_info_t;
 
 spx_error_t spx_hip_mat_info(const spx_matrix_t *A, spx_hip_info_t *info);

@@ -297,13 +297,14 @@ static void encode_partition(Partition &p, const EncoderParams &prm, const Xform
     }
 }
 
-static bool stream_has_symsegs(const GpuStream &s)
+static bool stream_has_pass(const GpuStream &s, uint8_t kind)
 {
     for (const SpxRowBlock &rb : s.rbs)
         for (uint32_t k = 0; k < rb.n_pass; ++k)
-            if (s.passes[(size_t) rb.pass_off + k].kind == SPX_PASS_SYMSEG) return true;
+            if (s.passes[(size_t) rb.pass_off + k].kind == kind) return true;
     return false;
 }
+static bool stream_has_symsegs(const GpuStream &s) { return stream_has_pass(s, SPX_PASS_SYMSEG); }
 
 static bool stream_has_tiles(const GpuStream &s)
 {
@@ -478,6 +479,7 @@ static void emit_and_upload(spx_matrix_t *A)
     A->n_rowblocks = gs.rbs.size();
     A->n_shared = gs.shared.size();
     A->has_tiles = stream_has_tiles(gs);
+    A->has_symtiles = stream_has_pass(gs, SPX_PASS_SYMTILE);
     if (A->dev) {
         device_free(A->dev);
         A->dev = nullptr;
@@ -746,6 +748,12 @@ static spx_matrix_t *do_tune(spx_input_t *in)
             throw FatalError("bad spx.gpu.sym_segments");
         }
         A->emit_params.sym_segments = m == "auto" ? -1 : (m == "true" ? 1 : 0);
+        const long wide = cfg.get_long("spx.gpu.sym_wide_rows");
+        if (wide < 1 || wide > SPX_MAX_WIDE_ROWS) {
+            log_msg(LOG_ERR, "spx.gpu.sym_wide_rows: 1 .. %d\n", SPX_MAX_WIDE_ROWS);
+            throw FatalError("bad spx.gpu.sym_wide_rows");
+        }
+        A->emit_params.wide_rows = (size_t) wide;
     }
     A->emit_params.stack_segments = cfg.get_bool("spx.gpu.stack_segments");
     {
@@ -1076,7 +1084,7 @@ spx_error_t spx_mat_set_entry(spx_matrix_t *A, spx_index_t row, spx_index_t colu
 
 namespace {
 
-const char kMagic[8] = {'S', 'P', 'X', 'H', 'I', 'P', '1', '3'};
+const char kMagic[8] = {'S', 'P', 'X', 'H', 'I', 'P', '1', '4'};
 
 template <typename T>
 bool put_vec(FILE *f, const std::vector<T> &v)
@@ -1349,6 +1357,7 @@ spx_matrix_t *spx_mat_restore(const char *filename)
     A->n_rowblocks = gs->rbs.size();
     A->n_shared = gs->shared.size();
     A->has_tiles = stream_has_tiles(*gs);
+    A->has_symtiles = stream_has_pass(*gs, SPX_PASS_SYMTILE);
     A->has_symsegs = stream_has_symsegs(*gs);
     A->sym_atomic = gs->sym_atomic;
     A->deterministic = gs->deterministic;
@@ -1711,7 +1720,7 @@ spx_error_t spx_hip_mat_info(const spx_matrix_t *A, spx_hip_info_t *info)
     info->waves = A->dev ? device_get_waves(A->dev) : A->waves;
     info->sym_tiles = A->has_tiles ? ((A->dev ? device_get_sym_atomic(A->dev) : A->sym_atomic) ? 2 : 1) : 0;
     info->wave_tiles = A->dev ? (device_get_wave_tiles(A->dev) ? 1 : 0) : (A->wave_tiles == 1 || A->deterministic ? 1 : 0);
-    info->sym_segments = A->has_symsegs ? 1 : 0;
+    info->sym_segments = A->has_symsegs ? (A->has_symtiles ? 1 : 2) : 0;
     info->tune_seconds = A->tune_seconds;
     info->emit_seconds = A->emit_seconds;
     return SPX_SUCCESS;

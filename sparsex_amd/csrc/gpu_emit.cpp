@@ -47,12 +47,28 @@ public:
     RbBuilder(const Partition &p, GpuStream &out, bool stack = true, bool x_window = true)
         : p_(p), out_(out), stack_(stack), x_window_(x_window) {}
 
+    // rows [lo, hi) of the partition with what the planner cut out for them
+    struct Part {
+        idx_t lo, hi;
+        const std::vector<Piece> *pieces;
+        std::vector<Single> *singles;
+        const std::vector<const SymTile *> *tiles;
+        const std::vector<RowSeg> *rowsegs;
+        const std::vector<const SymSeg *> *symsegs;
+    };
     // emits one row-block for rows [lo, hi) from the given pieces/singles
     void emit(idx_t lo, idx_t hi, const std::vector<Piece> &pieces,
               std::vector<Single> &singles, uint8_t flags, uint32_t carry_slot,
               const std::vector<const SymTile *> *tiles = nullptr,
               const std::vector<RowSeg> *rowsegs = nullptr,
-              const std::vector<const SymSeg *> *symsegs = nullptr);
+              const std::vector<const SymSeg *> *symsegs = nullptr)
+    {
+        std::vector<Part> one{Part{lo, hi, &pieces, &singles, tiles, rowsegs, symsegs}};
+        emit(one, flags, carry_slot);
+    }
+    // ... or one wide row-block from consecutive parts (each at most SPX_MAX_RB_ROWS rows,
+    // SPX_MAX_WIDE_ROWS together): one y tile, one set of transposed-sum slots
+    void emit(std::vector<Part> &parts, uint8_t flags, uint32_t carry_slot);
 
 private:
     void add_group(idx_t row, idx_t col, size_t nseg, size_t width, unsigned kind, unsigned step)
@@ -69,7 +85,7 @@ private:
     }
     void groups_from_piece(const Piece &pc, idx_t lo);
     void stack_groups();
-    void emit_unit_passes(SpxRowBlock &rb, bool sym = false);
+    void emit_unit_passes(SpxRowBlock &rb, bool sym = false, uint32_t row_base = 0);
     void assign_slots(SpxRowBlock &rb, const std::vector<const SymTile *> *tiles,
                       const std::vector<const SymSeg *> *symsegs);
     void slot_symseg_groups(const SpxRowBlock &rb);
@@ -83,7 +99,7 @@ private:
         return (uint32_t)(it - slot_groups_.begin()) * 8u + (uint32_t)(c & 7);
     }
     void emit_gather_passes(SpxRowBlock &rb, std::vector<Single> &singles, idx_t lo);
-    void emit_tile_passes(SpxRowBlock &rb, const std::vector<const SymTile *> &tiles);
+    void emit_tile_passes(SpxRowBlock &rb, const std::vector<const SymTile *> &tiles, uint32_t row_base = 0);
 
     const Partition &p_;
     GpuStream &out_;
@@ -282,7 +298,7 @@ void RbBuilder::stack_groups()
     gvals_.swap(vals);
 }
 
-void RbBuilder::emit_unit_passes(SpxRowBlock &rb, bool sym)
+void RbBuilder::emit_unit_passes(SpxRowBlock &rb, bool sym, uint32_t row_base)
 {
     // passes hold segments of one width: order the groups by width
     std::vector<uint32_t> order(groups_.size());
@@ -304,6 +320,7 @@ void RbBuilder::emit_unit_passes(SpxRowBlock &rb, bool sym)
         ps.nseg = (uint8_t) lanes.size();
         ps.width = width;
         ps.kind = sym ? SPX_PASS_SYMSEG : SPX_PASS_UNIT;
+        ps.elem0 = row_base;
         const size_t nseg = lanes.size();
         size_t base = out_.values.size();
         out_.values.resize(base + nseg * width, 0.0);
@@ -491,7 +508,7 @@ void RbBuilder::emit_gather_passes(SpxRowBlock &rb, std::vector<Single> &singles
             if (width != 3) out_.cidx.resize(area + (elems_before + nseg * W) * width, 0);
             for (size_t l = 0; l < nseg; ++l) {
                 const Piece2 &pc = pcs[b + l];
-                out_.segrows.push_back((uint16_t)((set[pc.first].row - lo) | ((pc.width - 1u) << 9)));
+                out_.segrows.push_back(SPX_SEGROW((uint32_t)(set[pc.first].row - lo), (uint32_t) pc.width));
                 for (uint32_t w = 0; w < pc.width; ++w) {
                     const Single &s = set[pc.first + w];
                     out_.values[vbase + spx_pass_value_index((uint32_t) l, w, (uint32_t) nseg, W)] = s.val;
@@ -540,6 +557,7 @@ void RbBuilder::assign_slots(SpxRowBlock &rb, const std::vector<const SymTile *>
     std::sort(slot_groups_.begin(), slot_groups_.end());
     slot_groups_.erase(std::unique(slot_groups_.begin(), slot_groups_.end()), slot_groups_.end());
     assert(slot_groups_.size() * 8 <= SPX_MAX_TILE_SLOTS);
+    const size_t max_slots = rb.n_rows > SPX_MAX_RB_ROWS ? SPX_MAX_WIDE_SLOTS : SPX_MAX_TILE_SLOTS;
     if (symsegs && !symsegs->empty()) {
         std::vector<idx_t> more;
         for (const SymSeg *sg : *symsegs)
@@ -548,7 +566,7 @@ void RbBuilder::assign_slots(SpxRowBlock &rb, const std::vector<const SymTile *>
         more.erase(std::unique(more.begin(), more.end()), more.end());
         // (nearest to the row-block first, should they not all fit: the others add to y directly)
         for (size_t k = more.size(); k-- > 0;) {
-            if ((slot_groups_.size() + 1) * 8 > SPX_MAX_TILE_SLOTS) break;
+            if ((slot_groups_.size() + 1) * 8 > max_slots) break;
             if (!std::binary_search(slot_groups_.begin(), slot_groups_.end(), more[k])) slot_groups_.push_back(more[k]);
         }
         std::sort(slot_groups_.begin(), slot_groups_.end());
@@ -609,10 +627,10 @@ void RbBuilder::slot_symseg_groups(const SpxRowBlock &rb)
 // consecutive slots: columns in front of the row-block's first row are ranked
 // (slot = number of touched columns in front), columns inside the row-block
 // continue behind them at n_slots + (column - row0), i.e. in the y tile itself.
-void RbBuilder::emit_tile_passes(SpxRowBlock &rb, const std::vector<const SymTile *> &tiles)
+void RbBuilder::emit_tile_passes(SpxRowBlock &rb, const std::vector<const SymTile *> &tiles, uint32_t row_base)
 {
     if (tiles.empty()) return;
-    const idx_t row0 = (idx_t) rb.row0;
+    const idx_t row0 = (idx_t) rb.row0 + (idx_t) row_base;     // first row of this part
     // (the slots were laid out by assign_slots: tiles start on columns that are multiples of
     // eight, a group of eight columns that begins in front of the row-block is taken whole)
     for (size_t b = 0; b < tiles.size(); b += 8) {
@@ -626,6 +644,7 @@ void RbBuilder::emit_tile_passes(SpxRowBlock &rb, const std::vector<const SymTil
         ps.nseg = (uint8_t) nseg;
         ps.width = 8;
         ps.kind = SPX_PASS_SYMTILE;
+        ps.elem0 = row_base;
         const size_t base = out_.values.size();
         out_.values.resize(base + (size_t) nseg * 8, 0.0);
         for (size_t k = 0; k < nt; ++k) {
@@ -649,11 +668,10 @@ void RbBuilder::emit_tile_passes(SpxRowBlock &rb, const std::vector<const SymTil
     out_.nnz_stored += 64 * tiles.size();
 }
 
-void RbBuilder::emit(idx_t lo, idx_t hi, const std::vector<Piece> &pieces,
-                     std::vector<Single> &singles, uint8_t flags, uint32_t carry_slot,
-                     const std::vector<const SymTile *> *tiles, const std::vector<RowSeg> *rowsegs,
-                     const std::vector<const SymSeg *> *symsegs)
+void RbBuilder::emit(std::vector<Part> &parts, uint8_t flags, uint32_t carry_slot)
 {
+    const idx_t lo = parts.front().lo, hi = parts.back().hi;
+    assert(parts.size() == 1 ? hi - lo <= (idx_t) SPX_MAX_RB_ROWS : hi - lo <= (idx_t) SPX_MAX_WIDE_ROWS);
     SpxRowBlock rb;
     std::memset(&rb, 0, sizeof(rb));
     pad_to(out_.values, 2);
@@ -663,42 +681,63 @@ void RbBuilder::emit(idx_t lo, idx_t hi, const std::vector<Piece> &pieces,
     rb.row0 = (uint32_t)(p_.row_start + lo);
     rb.n_rows = (uint16_t)(hi - lo);
     rb.flags = flags;
+    rb.cbase = 0;
     rb.carry_slot = carry_slot;
 
-    if ((tiles && !tiles->empty()) || (symsegs && !symsegs->empty())) assign_slots(rb, tiles, symsegs);
-    if (tiles) emit_tile_passes(rb, *tiles);      // the bulk of the work first
-    size_t n_sym = 0;
-    if (symsegs && !symsegs->empty()) {
+    // the transposed-sum slots belong to the row-block as a whole
+    {
+        std::vector<const SymTile *> all_tiles;
+        std::vector<const SymSeg *> all_segs;
+        for (const Part &pt : parts) {
+            if (pt.tiles) all_tiles.insert(all_tiles.end(), pt.tiles->begin(), pt.tiles->end());
+            if (pt.symsegs) all_segs.insert(all_segs.end(), pt.symsegs->begin(), pt.symsegs->end());
+        }
+        if (!all_tiles.empty() || !all_segs.empty()) assign_slots(rb, &all_tiles, &all_segs);
+    }
+    out_.lds_doubles = std::max<uint32_t>(out_.lds_doubles, (uint32_t) rb.n_slots + rb.n_rows);
+    // the bulk of the work first
+    for (const Part &pt : parts)
+        if (pt.tiles) emit_tile_passes(rb, *pt.tiles, (uint32_t)(pt.lo - lo));
+    size_t n_sym = 0, n_unit = 0;
+    for (const Part &pt : parts) {
+        if (!pt.symsegs || pt.symsegs->empty()) continue;
         // row segments of the lower triangle that are read once: grouped like any others,
         // then given their slots
         groups_.clear();
         gvals_.clear();
-        for (const SymSeg *sg : *symsegs) {
-            add_group(sg->row - p_.row_start - lo, sg->col, 1, sg->width, SPX_KIND_HORIZ, 0);
+        for (const SymSeg *sg : *pt.symsegs) {
+            add_group(sg->row - p_.row_start - pt.lo, sg->col, 1, sg->width, SPX_KIND_HORIZ, 0);
             gvals_.insert(gvals_.end(), sg->v, sg->v + sg->width);
         }
-        n_sym = gvals_.size();
+        n_sym += gvals_.size();
         if (stack_) stack_groups();
         slot_symseg_groups(rb);
-        emit_unit_passes(rb, true);
+        emit_unit_passes(rb, true, (uint32_t)(pt.lo - lo));
     }
-    groups_.clear();
-    gvals_.clear();
-    for (const Piece &pc : pieces) groups_from_piece(pc, lo);
-    if (rowsegs)
-        for (const RowSeg &sg : *rowsegs) {
-            add_group(sg.row - lo, sg.col, 1, sg.width, SPX_KIND_HORIZ, 0);
-            gvals_.insert(gvals_.end(), sg.v, sg.v + sg.width);
-        }
-    const size_t n_unit = gvals_.size();
-    if (stack_) stack_groups();
-    emit_unit_passes(rb);
+    for (const Part &pt : parts) {
+        groups_.clear();
+        gvals_.clear();
+        for (const Piece &pc : *pt.pieces) groups_from_piece(pc, pt.lo);
+        if (pt.rowsegs)
+            for (const RowSeg &sg : *pt.rowsegs) {
+                add_group(sg.row - pt.lo, sg.col, 1, sg.width, SPX_KIND_HORIZ, 0);
+                gvals_.insert(gvals_.end(), sg.v, sg.v + sg.width);
+            }
+        n_unit += gvals_.size();
+        if (stack_) stack_groups();
+        emit_unit_passes(rb, false, (uint32_t)(pt.lo - lo));
+    }
+    // the leftovers of all parts together (their rows count from the row-block's first)
+    std::vector<Single> merged;
+    if (parts.size() > 1)
+        for (const Part &pt : parts) merged.insert(merged.end(), pt.singles->begin(), pt.singles->end());
+    std::vector<Single> &singles = parts.size() > 1 ? merged : *parts.front().singles;
     const size_t n_delta = singles.size();
     emit_gather_passes(rb, singles, lo);
     // keep whole-lane over-reads of the last pass inside the arrays
     for (size_t i = 0; i < 16; ++i) out_.cidx.push_back(0);
     pad_to(out_.values, 2);
-    assert(n_unit + n_delta <= 2 * SPX_MAX_RB_ELEMS);
+    assert(n_unit + n_delta <= 2 * SPX_MAX_RB_ELEMS * parts.size());
 
     out_.n_unit_elems += n_unit + n_sym;
     out_.n_delta_elems += n_delta;
@@ -1439,6 +1478,36 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsi
     // 4. emit: the row-blocks are independent of each other, so contiguous runs
     // of them are built by several threads into streams of their own and joined
     // in order
+    // (4a. wide row-blocks: consecutive plans that hold read-once segments and no tiles go
+    // side by side into one row-block of up to prm.wide_rows rows -- one y tile, one set of
+    // transposed-sum slots, so that a column which several of them reach is handed to y
+    // once, not once per plan)
+    std::vector<std::pair<size_t, size_t>> jobs;          // plans [first, last)
+    {
+        const size_t wide = std::min<size_t>(prm.wide_rows, SPX_MAX_WIDE_ROWS);
+        auto joinable = [&](size_t i) {
+            return wide > SPX_MAX_RB_ROWS && !plans[i].split && rb_tiles[i].empty() && !rb_segs[i].empty();
+        };
+        for (size_t i = 0; i < plans.size();) {
+            size_t j = i + 1;
+            if (joinable(i))
+                while (j < plans.size() && joinable(j) &&
+                       (size_t)(plans[j].row_hi - plans[i].row_lo) <= wide)
+                    ++j;
+            jobs.emplace_back(i, j);
+            i = j;
+        }
+    }
+    auto emit_wide = [&](size_t first, size_t last, RbBuilder &bld) {
+        std::vector<std::vector<RowSeg>> rowsegs(last - first);
+        std::vector<RbBuilder::Part> parts;
+        for (size_t i = first; i < last; ++i) {
+            recut_plan(i, rowsegs[i - first]);
+            parts.push_back(RbBuilder::Part{plans[i].row_lo, plans[i].row_hi, &pieces[i], &singles[i],
+                                            &rb_tiles[i], &rowsegs[i - first], &rb_segs[i]});
+        }
+        bld.emit(parts, 0, 0);
+    };
     auto emit_plan = [&](size_t i, RbBuilder &bld, GpuStream &dst) {
         const Plan &pl = plans[i];
         std::vector<RowSeg> rowsegs;
@@ -1469,17 +1538,21 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsi
         }
         dst.shared.push_back(sr);
     };
-    if (nthreads <= 1 || plans.size() < 64) {
+    auto emit_job = [&](size_t k, RbBuilder &bld, GpuStream &dst) {
+        if (jobs[k].second - jobs[k].first > 1) emit_wide(jobs[k].first, jobs[k].second, bld);
+        else emit_plan(jobs[k].first, bld, dst);
+    };
+    if (nthreads <= 1 || jobs.size() < 64) {
         RbBuilder bld(p, out, prm.stack_segments, prm.x_window);
-        for (size_t i = 0; i < plans.size(); ++i) emit_plan(i, bld, out);
+        for (size_t k = 0; k < jobs.size(); ++k) emit_job(k, bld, out);
         return;
     }
-    const size_t n_chunks = std::min<size_t>(plans.size() / 16, (size_t) nthreads * 4);
+    const size_t n_chunks = std::min<size_t>(jobs.size() / 16, (size_t) nthreads * 4);
     std::vector<GpuStream> locs(n_chunks);
     parallel_for(n_chunks, nthreads, [&](size_t c) {
-        const size_t lo = plans.size() * c / n_chunks, hi = plans.size() * (c + 1) / n_chunks;
+        const size_t lo = jobs.size() * c / n_chunks, hi = jobs.size() * (c + 1) / n_chunks;
         RbBuilder bld(p, locs[c], prm.stack_segments, prm.x_window);
-        for (size_t i = lo; i < hi; ++i) emit_plan(i, bld, locs[c]);
+        for (size_t k = lo; k < hi; ++k) emit_job(k, bld, locs[c]);
     });
     for (GpuStream &l : locs) append_stream(out, std::move(l));
 }

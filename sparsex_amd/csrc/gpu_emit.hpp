@@ -94,6 +94,8 @@ struct GpuStream {
 struct GpuEmitParams {
     size_t target_elems = 2048;   // spx.gpu.rowblock_elems
     size_t max_rows = SPX_MAX_RB_ROWS;   // spx.gpu.rowblock_rows (<= SPX_MAX_RB_ROWS)
+    size_t wide_rows = SPX_MAX_RB_ROWS;  // spx.gpu.sym_wide_rows: rows of a row-block made of several
+                                         // planned ones (read-once segments only; <= SPX_MAX_WIDE_ROWS)
     bool skip_empty = false;      // accumulate mode: rows without nonzeros need no write
     bool stack_segments = true;   // spx.gpu.stack_segments: equal row segments of consecutive
                                   // rows share one descriptor as a dense block

@@ -52,6 +52,12 @@
 
 #define SPX_MAX_TILE_SLOTS 3072   /* transposed-sum slots per row-block (LDS)          */
 #define SPX_MAX_RB_ROWS    512    /* y tile of a row-block in LDS (doubles)      */
+#define SPX_MAX_WIDE_ROWS  2048   /* ... of a wide row-block: up to four ordinary ones
+                                     side by side that share their transposed-sum slots
+                                     (streams with SPX_PASS_SYMSEG only).  A descriptor
+                                     still holds a 9-bit row; its pass adds the first row
+                                     of its part of the row-block (SpxPass::elem0)      */
+#define SPX_MAX_WIDE_SLOTS 4096   /* transposed-sum slots of such a row-block           */
 #define SPX_MAX_RB_ELEMS   8192   /* nonzeros per row-block (16-bit counters)    */
 #define SPX_MAX_SEG_WIDTH  8      /* columns per row segment                      */
 #define SPX_HORIZ_CHUNK    8      /* horizontal units are cut into such chunks   */
@@ -72,8 +78,11 @@
                                 column offsets; values interleaved like a unit
                                 pass, offsets element-major [W][nseg].  The row-
                                 block's u16 `segrows` entry of a piece holds its row
-                                (bits 0-8) and its length - 1 (bits 9-11): a pass is
+                                (bits 0-10) and its length - 1 (bits 11-13): a pass is
                                 as wide as its longest piece, shorter ones are padded */
+#define SPX_SEGROW(row, len) ((uint16_t)((row) | (((len) - 1u) << 11)))
+#define SPX_SEGROW_ROW(sr)   ((uint32_t)(sr) & 2047u)
+#define SPX_SEGROW_LEN(sr)   ((((uint32_t)(sr) >> 11) & 7u) + 1u)
 
 #define SPX_PASS_GATHER_LDS 4 /* the same, for leftovers whose columns fall into the
                                 row-block's x window: the workgroup stages
@@ -129,7 +138,9 @@ typedef struct {
     uint8_t  kind;       /* SPX_PASS_UNIT / _GATHER / _GATHER_LDS / _SYMTILE      */
     uint8_t  pad_;
     uint32_t elem0;      /* gather pass: leftover nonzeros of the row-block in
-                            front of this pass (index of its first column offset) */
+                            front of this pass (index of its first column offset)
+                            other passes: added to the rows of their descriptors
+                            (0 but in wide row-blocks, SPX_MAX_WIDE_ROWS)           */
 } SpxPass;               /* 24 bytes */
 
 typedef struct {

@@ -65,6 +65,7 @@ struct matrix {
     bool has_tiles = false;     // the stream holds SPX_PASS_SYMTILE passes
     bool sym_atomic = false;    // their transposed sums go straight into y (global atomics)
     bool deterministic = false; // spx.gpu.deterministic
+    bool has_symtiles = false;  // the stream holds dense 8x8 tiles (SPX_PASS_SYMTILE)
     bool has_symsegs = false;   // the stream holds read-once row segments (SPX_PASS_SYMSEG): atomic hand-over only
     int spill_mode = -1;        // spx.gpu.sym_spill as asked for: 0 lists, 1 atomic, -1 auto
     int wave_tiles = -1;        // per-wavefront y tiles: 1 / 0, -1 = measured at tune time (spx.gpu.wave_tiles)

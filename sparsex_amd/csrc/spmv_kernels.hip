@@ -150,16 +150,16 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
         double x[W];
         if (G == 2) {
             // (a piece shorter than the pass is padded: nothing is multiplied there)
-            row[b] = (int) (q[b].x & 511u);
-            const int len = (int) (q[b].x >> 9) + 1;
+            row[b] = (int) SPX_SEGROW_ROW(q[b].x);
+            const int len = (int) SPX_SEGROW_LEN(q[b].x);
 #pragma unroll
             for (int w = 0; w < W; ++w) {
                 const double xv = win[goff[b][w]];
                 x[w] = w < len ? xv : 0.0;
             }
         } else if (G) {
-            row[b] = (int) (q[b].x & 511u);
-            const int len = (int) (q[b].x >> 9) + 1;
+            row[b] = (int) SPX_SEGROW_ROW(q[b].x);
+            const int len = (int) SPX_SEGROW_LEN(q[b].x);
             const double *xp = a.x + rb.cbase;
 #pragma unroll
             for (int w = 0; w < W; ++w) {
@@ -179,7 +179,7 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
             const int drow = kind == SPX_KIND_BLOCK ? 1 : (kind >= SPX_KIND_VERT ? step : 0);
             const int dcol = (kind == SPX_KIND_HORIZ || kind == SPX_KIND_DIAG)
                                  ? step : (kind == SPX_KIND_ADIAG ? -step : 0);
-            row[b] = (int) (bits & 511u) + s * drow;
+            row[b] = (int) (ps[b].elem0 + (bits & 511u)) + s * drow;
             const uint32_t col = q[b].x + (uint32_t) (s * dcol);
             const double *xp = a.x + col;
 #ifdef SPX_ABL_NOX
@@ -317,7 +317,7 @@ __device__ __forceinline__ void symtile_pass(const KernelArgs &a, const SpxRowBl
     for (int p = 0; p < 4; ++p)
         v2[p] = *reinterpret_cast<const double2 *>(vals + (uint32_t) p * 2u * nseg + l * 2u);
     const int i = (int) (l & 7u);
-    const int row = (int) (q.y & 511u) + i;
+    const int row = (int) (ps.elem0 + (q.y & 511u)) + i;
     const uint32_t slot = q.y >> 9;
 #ifdef SPX_ABL_SYM_VALSONLY
     {
@@ -434,7 +434,7 @@ __device__ __forceinline__ void symseg_pass(const KernelArgs &a, const SpxRowBlo
     const int step = (int) (bits >> 25);
     const int drow = kind == SPX_KIND_BLOCK ? 1 : (kind >= SPX_KIND_VERT ? step : 0);
     const int dcol = (kind == SPX_KIND_HORIZ || kind == SPX_KIND_DIAG) ? step : (kind == SPX_KIND_ADIAG ? -step : 0);
-    const int row = (int) (bits & 511u) + s * drow;
+    const int row = (int) (ps.elem0 + (bits & 511u)) + s * drow;
     const uint32_t col = q.x + (uint32_t) (s * dcol);
     const double *xp = a.x + col;
     const double xr = a.x[rb.row0 + (uint32_t) row];
@@ -497,7 +497,7 @@ __device__ __forceinline__ void run_pass(const KernelArgs &a, const SpxRowBlock 
 // own, and the copies are summed in wavefront order before the write-out -- the
 // only thing in this library whose order of additions is not fixed is the LDS adds
 // of different wavefronts of a workgroup into the shared tile.
-template <bool SYM, bool ATOMIC, int WAVES_PER_BLOCK, bool DET = false, bool SEGS = false>
+template <bool SYM, bool ATOMIC, int WAVES_PER_BLOCK, bool DET = false, bool SEGS = false, bool TILES = true>
 __device__ __forceinline__ void spmv_body(const KernelArgs &a, uint32_t blocks_per_xcd,
                                           double *lds)
 {
@@ -533,6 +533,15 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, uint32_t blocks_p
         const double *xs = a.x + rb.xwin_base;
         for (int i = threadIdx.x; i < xw; i += BLOCK_THREADS) win[i] = xs[i];
     }
+    // atomic hand-over: the first columns of the slot groups are fetched now, into LDS behind
+    // the window, so that the hand-over at the end does not start with a load from memory
+    // (a dependent L2/HBM round trip per 256 slots, at a point where the workgroup has
+    // nothing else in flight)
+    uint32_t *gcol_lds = reinterpret_cast<uint32_t *>(win + rb.xwin_len);
+    if (ATOMIC) {
+        const uint32_t *gcol = a.slot_col + (rb.spill_off >> 3);
+        for (int i = threadIdx.x; i < (n_slots >> 3); i += BLOCK_THREADS) gcol_lds[i] = gcol[i];
+    }
     __syncthreads();
 
     // wave w takes passes w, w+4, ..., two at a time when they have the same
@@ -546,15 +555,17 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, uint32_t blocks_p
         const bool two = t + WAVES_PER_BLOCK < n_pass;
         if (SEGS && (p0.kind == SPX_PASS_SYMSEG || (two && p1.kind == SPX_PASS_SYMSEG))) {
             // read-once row segments (atomic hand-over only); whatever shares the round runs on its own
+            // (one at a time: two side by side, as the unit passes run, need 100 VGPRs instead of 62,
+            // four wavefronts per SIMD instead of eight; measured 0.84 -> 0.97 ms on syn-nlpkkt)
             if (p0.kind == SPX_PASS_SYMSEG) run_symseg(a, rb, p0, mine, tile, lane);
-            else if (p0.kind == SPX_PASS_SYMTILE) symtile_pass(a, rb, p0, mine, tile, lane);
+            else if (TILES && p0.kind == SPX_PASS_SYMTILE) symtile_pass(a, rb, p0, mine, tile, lane);
             else run_pass(a, rb, p0, tile, win, lane);
             if (two) {
                 if (p1.kind == SPX_PASS_SYMSEG) run_symseg(a, rb, p1, mine, tile, lane);
-                else if (p1.kind == SPX_PASS_SYMTILE) symtile_pass(a, rb, p1, mine, tile, lane);
+                else if (TILES && p1.kind == SPX_PASS_SYMTILE) symtile_pass(a, rb, p1, mine, tile, lane);
                 else run_pass(a, rb, p1, tile, win, lane);
             }
-        } else if (SYM && p0.kind == SPX_PASS_SYMTILE) {
+        } else if (SYM && TILES && p0.kind == SPX_PASS_SYMTILE) {
             symtile_pass(a, rb, p0, mine, tile, lane);
             if (two) {
                 if (p1.kind == SPX_PASS_SYMTILE) symtile_pass(a, rb, p1, mine, tile, lane);
@@ -567,7 +578,7 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, uint32_t blocks_p
                 else run_units<2, 0>(a, rb, {p0, p1}, tile, win, lane);
             } else {
                 run_pass(a, rb, p0, tile, win, lane);
-                if (SYM && p1.kind == SPX_PASS_SYMTILE) symtile_pass(a, rb, p1, mine, tile, lane);
+                if (SYM && TILES && p1.kind == SPX_PASS_SYMTILE) symtile_pass(a, rb, p1, mine, tile, lane);
                 else run_pass(a, rb, p1, tile, win, lane);
             }
         } else {
@@ -598,9 +609,8 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, uint32_t blocks_p
         for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS)
             atomicAdd(&a.y[(size_t) rb.row0 + i], a.alpha * tile[i]);
 #ifndef SPX_ABL_SEG_NOFLUSH
-        const uint32_t *gcol = a.slot_col + (rb.spill_off >> 3);
         for (int i = threadIdx.x; i < n_slots; i += BLOCK_THREADS)
-            atomicAdd(&a.y[(size_t) gcol[i >> 3] + (i & 7)], a.alpha * lds[i]);
+            atomicAdd(&a.y[(size_t) gcol_lds[i >> 3] + (i & 7)], a.alpha * lds[i]);
 #endif
     } else {
         for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS) {
@@ -665,6 +675,16 @@ void csx_spmv_symseg_kernel(SPX_KERNEL_PARAMS)
     spmv_body<true, true, WAVES, false, true>(a, blocks_per_xcd, lds_dyn);
 }
 
+// ... and the same for streams with such segments and no tiles at all (a stencil matrix)
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES)
+void csx_spmv_symseg_notile_kernel(SPX_KERNEL_PARAMS)
+{
+    SPX_KERNEL_ARGS(a);
+    extern __shared__ double lds_dyn[];
+    spmv_body<true, true, WAVES, false, true, false>(a, blocks_per_xcd, lds_dyn);
+}
+
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES)
 void csx_spmv_det_kernel(SPX_KERNEL_PARAMS)
@@ -683,6 +703,8 @@ void csx_spmv_symtile_det_kernel(SPX_KERNEL_PARAMS)
     spmv_body<true, false, WAVES, true>(a, blocks_per_xcd, lds_dyn);
 }
 
+// (forcing eight wavefronts per SIMD on this kernel -- amdgpu_waves_per_eu(8, 8): 64 VGPRs and
+// 32 B of scratch instead of 70 -- was measured on syn-nd24k: 25.5 -> 30.5 us; not used)
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES)
 void csx_spmv_symtile_atomic_kernel(SPX_KERNEL_PARAMS)
@@ -795,6 +817,7 @@ struct DeviceMatrix {
     size_t n_fix_ptr = 0, n_fix_idx = 0;
     bool sym_atomic = false;   // transposed sums go straight into y (global atomics), no second kernel
     bool has_symsegs = false;     // the stream holds SPX_PASS_SYMSEG passes
+    bool has_symtiles = false;    // ... SPX_PASS_SYMTILE passes
     bool wave_tiles = false;      // a y tile per wavefront, summed in wavefront order before the write-out
     bool deterministic = false;   // spx.gpu.deterministic: wave tiles + fixed-order hand-overs, pinned
     uint32_t *slot_col = nullptr;
@@ -879,6 +902,9 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
     for (const SpxRowBlock &rb : s.rbs)
         for (uint32_t k = 0; k < rb.n_pass && !m->has_symsegs; ++k)
             m->has_symsegs = s.passes[rb.pass_off + k].kind == SPX_PASS_SYMSEG;
+    for (const SpxRowBlock &rb : s.rbs)
+        for (uint32_t k = 0; k < rb.n_pass && !m->has_symtiles; ++k)
+            m->has_symtiles = s.passes[rb.pass_off + k].kind == SPX_PASS_SYMTILE;
     // (n_slots + n_rows <= 3584 doubles = 28 KB: within the default dynamic LDS limit)
     if (s.n_spill) {
         std::vector<double> zero_spill(s.n_spill, 0.0);
@@ -899,6 +925,16 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
         m->mirror_val = upload(s.mirror_val);
     }
     m->sym_atomic = (s.sym_atomic || m->has_symsegs) && m->has_tiles;
+    if (m->has_symsegs && (size_t) m->lds_doubles * sizeof(double) + 2048u > 64u * 1024u) {
+        // wide row-blocks with an x window on top: beyond the default dynamic LDS limit
+        const int bytes = 160 * 1024;
+        (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&csx_spmv_symseg_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&csx_spmv_symseg_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&csx_spmv_symseg_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&csx_spmv_symseg_notile_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&csx_spmv_symseg_notile_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&csx_spmv_symseg_notile_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    }
     if (s.deterministic) device_set_deterministic(m, true);
     else if (s.wave_tiles) device_set_wave_tiles(m, true);
     m->n_values = s.values.size(); m->n_descs = s.descs.size(); m->n_passes = s.passes.size();
@@ -999,14 +1035,19 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
         // symmetric tiles: slots + y tile in dynamic LDS, then the rows collect
         // what other row-blocks spilled for them
         const size_t lds = m->lds_doubles * sizeof(double);
-        if (m->sym_atomic && m->has_symsegs) {
-            if (m->waves == 2) SPX_LAUNCH(csx_spmv_symseg_kernel, 2, lds);
-            else if (m->waves == 8) SPX_LAUNCH(csx_spmv_symseg_kernel, 8, lds);
-            else SPX_LAUNCH(csx_spmv_symseg_kernel, 4, lds);
+        const size_t lds_a = lds + SPX_MAX_WIDE_SLOTS / 8 * sizeof(uint32_t);   // + the slot groups' columns
+        if (m->sym_atomic && m->has_symsegs && !m->has_symtiles) {
+            if (m->waves == 2) SPX_LAUNCH(csx_spmv_symseg_notile_kernel, 2, lds_a);
+            else if (m->waves == 8) SPX_LAUNCH(csx_spmv_symseg_notile_kernel, 8, lds_a);
+            else SPX_LAUNCH(csx_spmv_symseg_notile_kernel, 4, lds_a);
+        } else if (m->sym_atomic && m->has_symsegs) {
+            if (m->waves == 2) SPX_LAUNCH(csx_spmv_symseg_kernel, 2, lds_a);
+            else if (m->waves == 8) SPX_LAUNCH(csx_spmv_symseg_kernel, 8, lds_a);
+            else SPX_LAUNCH(csx_spmv_symseg_kernel, 4, lds_a);
         } else if (m->sym_atomic) {
-            if (m->waves == 2) SPX_LAUNCH(csx_spmv_symtile_atomic_kernel, 2, lds);
-            else if (m->waves == 8) SPX_LAUNCH(csx_spmv_symtile_atomic_kernel, 8, lds);
-            else SPX_LAUNCH(csx_spmv_symtile_atomic_kernel, 4, lds);
+            if (m->waves == 2) SPX_LAUNCH(csx_spmv_symtile_atomic_kernel, 2, lds_a);
+            else if (m->waves == 8) SPX_LAUNCH(csx_spmv_symtile_atomic_kernel, 8, lds_a);
+            else SPX_LAUNCH(csx_spmv_symtile_atomic_kernel, 4, lds_a);
         } else if (m->waves == 2) SPX_LAUNCH(csx_spmv_symtile_kernel, 2, lds);
         else if (m->waves == 8) SPX_LAUNCH(csx_spmv_symtile_kernel, 8, lds);
         else SPX_LAUNCH(csx_spmv_symtile_kernel, 4, lds);

@@ -33,7 +33,7 @@ inline void unit_lane(const GpuStream &s, const SpxRowBlock &rb, const SpxPass &
     const int drow = kind == SPX_KIND_BLOCK ? 1 : (kind >= SPX_KIND_VERT ? step : 0);
     const int dcol = (kind == SPX_KIND_HORIZ || kind == SPX_KIND_DIAG)
                          ? step : (kind == SPX_KIND_ADIAG ? -step : 0);
-    row = (int64_t) (bits & 511u) + (int64_t) sidx * drow;
+    row = (int64_t) ps.elem0 + (int64_t) (bits & 511u) + (int64_t) sidx * drow;
     col = (int64_t) d.col0 + (int64_t) sidx * dcol;
     if (slot && *slot != SPX_NO_SLOT) *slot = (uint32_t)((int64_t) *slot + (int64_t) sidx * dcol);
 }
@@ -85,8 +85,8 @@ void stream_locate(const GpuStream &s, idx_t row, idx_t col, std::vector<size_t>
             if (is_gather(ps)) {
                 for (uint32_t l = 0; l < nseg; ++l) {
                     const uint32_t sr = s.segrows[(size_t) rb.seg_off + ps.seg0 + l];
-                    if ((int64_t) (sr & 511u) != rrel) continue;
-                    for (uint32_t w = 0; w < W && w <= (sr >> 9); ++w) {
+                    if ((int64_t) SPX_SEGROW_ROW(sr) != rrel) continue;
+                    for (uint32_t w = 0; w < W && w < SPX_SEGROW_LEN(sr); ++w) {
                         const int64_t c = gather_col(s, rb, ps, (size_t) ps.elem0 + l + (size_t) w * nseg);
                         if (c == (int64_t) col) out.push_back(vbase + spx_pass_value_index(l, w, nseg, W));
                     }
@@ -94,7 +94,7 @@ void stream_locate(const GpuStream &s, idx_t row, idx_t col, std::vector<size_t>
             } else if (ps.kind == SPX_PASS_SYMTILE) {
                 for (uint32_t l = 0; l < nseg; ++l) {
                     const SpxUnitDesc &d = s.descs[(size_t) rb.desc_off + ps.rank0 + (l >> 3)];
-                    const int64_t r = (int64_t) (d.bits & 511u) + (l & 7u);
+                    const int64_t r = (int64_t) ps.elem0 + (int64_t) (d.bits & 511u) + (l & 7u);
                     if (r != rrel) continue;
                     const int64_t w = (int64_t) col - (int64_t) d.col0;
                     if (w >= 0 && w < 8) out.push_back(vbase + spx_pass_value_index(l, (uint32_t) w, nseg, 8));
@@ -126,10 +126,10 @@ void stream_touched_rows(const GpuStream &s, idx_t below, std::vector<idx_t> &ro
             for (uint32_t l = 0; l < ps.nseg; ++l) {
                 int64_t r;
                 if (is_gather(ps)) {
-                    r = s.segrows[(size_t) rb.seg_off + ps.seg0 + l] & 511u;
+                    r = SPX_SEGROW_ROW(s.segrows[(size_t) rb.seg_off + ps.seg0 + l]);
                 } else if (ps.kind == SPX_PASS_SYMTILE) {
                     const SpxUnitDesc &d = s.descs[(size_t) rb.desc_off + ps.rank0 + (l >> 3)];
-                    r = (int64_t) (d.bits & 511u) + (l & 7u);
+                    r = (int64_t) ps.elem0 + (int64_t) (d.bits & 511u) + (l & 7u);
                     const int64_t c = (int64_t) d.col0 + (l & 7u);   // the transposed tile's row
                     if (c < (int64_t) below) mark[(size_t) c] = 1;
                 } else {
@@ -175,7 +175,7 @@ bool stream_validate(const GpuStream &s, size_t nrows, size_t ncols, size_t n_va
     SPX_REQUIRE(s.rbs.empty() || s.pass_stride >= 1, "pass stride missing");
     SPX_REQUIRE(s.passes.size() == s.rbs.size() * (size_t) s.pass_stride, "pass table size");
     SPX_REQUIRE(s.waves == 2 || s.waves == 4 || s.waves == 8, "wavefronts per workgroup");
-    SPX_REQUIRE(s.lds_doubles <= SPX_MAX_TILE_SLOTS + SPX_MAX_RB_ROWS + SPX_MAX_XWIN, "LDS budget");
+    SPX_REQUIRE(s.lds_doubles <= SPX_MAX_WIDE_SLOTS + SPX_MAX_WIDE_ROWS + SPX_MAX_XWIN, "LDS budget");
     SPX_REQUIRE(s.n_spill == 0 || (s.fix_ptr.size() == nrows + 1 && s.fix_idx.size() == s.n_spill),
                 "spill lists");
     for (size_t i = 0; i + 1 < s.fix_ptr.size(); ++i)
@@ -196,7 +196,7 @@ bool stream_validate(const GpuStream &s, size_t nrows, size_t ncols, size_t n_va
     bool tiles = false;
     for (size_t i = 0; i < s.rbs.size(); ++i) {
         const SpxRowBlock &rb = s.rbs[i];
-        SPX_REQUIRE(rb.n_rows >= 1 && rb.n_rows <= SPX_MAX_RB_ROWS, "row-block rows");
+        SPX_REQUIRE(rb.n_rows >= 1 && rb.n_rows <= SPX_MAX_WIDE_ROWS, "row-block rows");
         SPX_REQUIRE((size_t) rb.row0 + rb.n_rows <= nrows, "row-block row range");
         SPX_REQUIRE(rb.pass_off == i * (size_t) s.pass_stride && rb.n_pass <= s.pass_stride,
                     "row-block pass range");
@@ -230,7 +230,7 @@ bool stream_validate(const GpuStream &s, size_t nrows, size_t ncols, size_t n_va
                             "column-offset high bytes");
                 for (uint32_t l = 0; l < nseg; ++l) {
                     const uint32_t sr = s.segrows[(size_t) rb.seg_off + ps.seg0 + l];
-                    SPX_REQUIRE((sr & 511u) < rb.n_rows && (sr >> 9) < W, "row piece row");
+                    SPX_REQUIRE(SPX_SEGROW_ROW(sr) < rb.n_rows && SPX_SEGROW_LEN(sr) <= W && (sr >> 14) == 0, "row piece row");
                     for (uint32_t w = 0; w < W; ++w) {
                         const int64_t c = gather_col(s, rb, ps, (size_t) ps.elem0 + l + (size_t) w * nseg);
                         SPX_REQUIRE(c >= 0 && (size_t) c < ncols, "gathered column");
@@ -244,7 +244,7 @@ bool stream_validate(const GpuStream &s, size_t nrows, size_t ncols, size_t n_va
                             "tile descriptor range");
                 for (uint32_t k = 0; k < nseg / 8; ++k) {
                     const SpxUnitDesc &d = s.descs[(size_t) rb.desc_off + ps.rank0 + k];
-                    SPX_REQUIRE((d.bits & 511u) + 8u <= rb.n_rows, "tile rows");
+                    SPX_REQUIRE(ps.elem0 + (d.bits & 511u) + 8u <= rb.n_rows, "tile rows");
                     SPX_REQUIRE((size_t) d.col0 + 8u <= ncols, "tile columns");
                     SPX_REQUIRE((size_t) (d.bits >> 9) + 8u <= (size_t) rb.n_slots + rb.n_rows, "tile slots");
                 }

@@ -25,7 +25,7 @@ class Stream:
     def __init__(self, path):
         with open(path, "rb") as f:
             buf = f.read()
-        assert buf[:8] == b"SPXHIP13", buf[:8]
+        assert buf[:8] == b"SPXHIP14", buf[:8]
         hdr = struct.unpack_from("<4i3Q2i4Q8IQ", buf, 8)
         (self.nrows, self.ncols, self.nnz, self.symmetric, self.nr_partitions, self.first_part,
          self.last_part, self.own_lo, self.own_hi, self.nnz_stored, self.n_unit_elems,
@@ -92,7 +92,7 @@ class Stream:
                     drow = np.where(kind == KIND_BLOCK, 1, np.where(kind >= KIND_VERT, step, 0))
                     dcol = np.where((kind == KIND_HORIZ) | (kind == KIND_DIAG), step,
                                     np.where(kind == KIND_ADIAG, -step, 0))
-                    row = (bits & 511) + s * drow
+                    row = int(ps["elem0"]) + (bits & 511) + s * drow       # (elem0: first row of the pass's part)
                     col = d["col0"].astype(np.int64) + s * dcol
                     assert (row < int(rb["n_rows"])).all(), "segment leaves its row-block"
                     if sym:
@@ -124,7 +124,7 @@ class Stream:
                     assert 1 <= nseg <= 64 and 1 <= W <= 8
                     lanes = np.arange(nseg)
                     sr = self.segrows[int(rb["seg_off"]) + int(ps["seg0"]) + lanes].astype(np.int64)
-                    row, plen = sr & 511, (sr >> 9) + 1        # a pass is as wide as its longest piece
+                    row, plen = sr & 2047, ((sr >> 11) & 7) + 1        # a pass is as wide as its longest piece
                     assert (row < int(rb["n_rows"])).all() and (plen <= W).all() and plen.max() == W
                     near = ps["kind"] == 4
                     cw = 2 if near else int(rb["cidx_width"])
@@ -157,7 +157,7 @@ class Stream:
                     lanes = np.arange(nseg)
                     d = self.descs[int(rb["desc_off"]) + int(ps["rank0"]) + (lanes >> 3)]
                     bits = d["bits"].astype(np.int64)
-                    row = (bits & 511) + (lanes & 7)
+                    row = int(ps["elem0"]) + (bits & 511) + (lanes & 7)
                     slot = bits >> 9
                     assert (row < int(rb["n_rows"])).all()
                     assert (slot + 8 <= int(rb["n_slots"]) + int(rb["n_rows"])).all()

@@ -76,7 +76,7 @@ def test_full_size_symmetric_path_agrees_with_general(case):
     n = csr[3]
     S = tune(csr, {"spx.rt.nr_threads": "8", "spx.rt.keep_encoded": "false"}, sym=True)
     # beyond 16 M nonzeros in the triangle, runs of consecutive columns are read once
-    assert S.info().sym_segments == int(name == "syn-nlpkkt-e90")
+    assert (S.info().sym_segments > 0) == (name == "syn-nlpkkt-e90")
     x, z = synth.random_x(n), synth.random_x(n, seed=23)
     yg, ys = mult(A, 0.5, x), mult(S, 0.5, x)
     check_y(csr, x, ys, 0.5)

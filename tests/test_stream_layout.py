@@ -216,7 +216,8 @@ def test_symmetric_row_segments_are_stored_once(tmp_path, name, gen, auto_on, mo
     for rb in s.rbs:
         used[int(rb["pass_off"]):int(rb["pass_off"]) + int(rb["n_pass"])] = True
     has = bool((s.passes["kind"][used] == 5).any())
-    assert A.info().sym_segments == int(has)
+    assert (A.info().sym_segments > 0) == has
+    assert A.info().sym_segments != 1 or bool((s.passes["kind"][used] == 3).any())
     if mode == "false":
         assert not has
     elif mode == "true":
@@ -237,7 +238,7 @@ def test_symmetric_row_segments_are_stored_once(tmp_path, name, gen, auto_on, mo
     assert np.allclose(s.matvec(x), a @ x, rtol=1e-12, atol=1e-14)
     # a restored matrix keeps them, and its entries can still be read and set from either triangle
     B = sx.mat_restore(f)
-    assert B.info().sym_segments == int(has)
+    assert B.info().sym_segments == A.info().sym_segments
     k = int(rp[n // 2]) if ci[rp[n // 2]] < n // 2 else int(rp[n // 2 + 1])
     row = int(np.searchsorted(rp, k, side="right") - 1)
     col = int(ci[k])
@@ -245,6 +246,46 @@ def test_symmetric_row_segments_are_stored_once(tmp_path, name, gen, auto_on, mo
         assert B.get_entry(row, col) == va[k] == B.get_entry(col, row)
         B.set_entry(col, row, 2.5)
         assert B.get_entry(row, col) == 2.5
+
+
+@pytest.mark.parametrize("wide", ["512", "1024", "2048"])
+def test_wide_rowblocks_share_their_slots(tmp_path, wide):
+    """spx.gpu.sym_wide_rows: consecutive row-blocks with read-once segments go side by side into
+    one (one y tile, one set of slots); their passes carry the first row of their part."""
+    csr = synth.syn_nlpkkt_rows(24)
+    rp, ci, va, n = csr
+    va = va.copy()
+    A = tune((rp, ci, va, n), {"spx.gpu.sym_segments": "true", "spx.gpu.sym_wide_rows": wide, "spx.rt.nr_threads": "2"},
+             sym=True, host_only=True)
+    f = str(tmp_path / "m.spx")
+    A.save(f)
+    s = Stream(f)
+    rows = s.rbs["n_rows"].astype(np.int64)
+    assert rows.max() <= int(wide) and (rows.max() > 512) == (wide != "512")
+    if wide != "512":
+        # fewer slots in total: a column that two neighbouring row-blocks reached is one slot now
+        assert int(s.rbs["n_slots"].astype(np.int64).sum()) < 0.8 * 2 * n
+        wide_rb = s.rbs[rows > 512][0]
+        bases = {int(s.passes[int(wide_rb["pass_off"]) + t]["elem0"]) for t in range(int(wide_rb["n_pass"]))
+                 if int(s.passes[int(wide_rb["pass_off"]) + t]["kind"]) in (0, 5)}
+        assert len(bases) >= 2 and 0 in bases and max(bases) < int(wide_rb["n_rows"])
+    a = sp.csr_matrix((va, ci, rp), shape=(n, n))
+    r, c, v, b, m = dense_of(s)
+    off = a - sp.diags(a.diagonal())
+    assert abs(m.tocsr() - off.tocsr()).max() == 0
+    s.check_ownership()
+    x = synth.random_x(n)
+    assert np.allclose(s.matvec(x), a @ x, rtol=1e-12, atol=1e-14)
+    # entries of a part that is not the first of its row-block: found, set, and kept by a restore
+    big = s.rbs[np.argmax(rows)]
+    row = int(big["row0"]) + int(big["n_rows"]) - 3
+    k = int(rp[row])
+    col = int(ci[k])
+    assert col < row and A.get_entry(row, col) == va[k] == A.get_entry(col, row)
+    A.set_entry(row, col, -7.25)
+    A.save(f)
+    B = sx.mat_restore(f)
+    assert B.get_entry(col, row) == -7.25 and B.info().n_rowblocks == len(s.rbs)
 
 
 def _one_rowblock_sym():
