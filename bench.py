@@ -453,11 +453,13 @@ def algorithmic_bytes(symmetric, nnz_local_full, rows_local, n, lower_local=None
     return 8.0 * nnz_local_full + 8.0 * n + 8.0 * rows_local
 
 
-def run_config(torch, sx, name, symmetric, steps, warmup, cpu_budget, T):
-    """One of the small BASELINE configurations on this GPU, measured like the main line."""
+def run_config(torch, sx, name, symmetric, steps, warmup, cpu_budget, T, csr=None, traffic_key=None):
+    """One of the other BASELINE configurations on this GPU (or the bench matrix itself on the
+    other path), measured like the main line."""
     from sparsex_amd import synth
     import scipy.sparse as sp
-    csr = make_workload(name, 1.0)
+    if csr is None:
+        csr = make_workload(name, 1.0)
     rp, ci, va, n = csr
     nnz = int(rp[-1])
     A = tune(csr, {"spx.rt.nr_threads": T, "spx.rt.device": torch.cuda.current_device(),
@@ -478,7 +480,14 @@ def run_config(torch, sx, name, symmetric, steps, warmup, cpu_budget, T):
     for _ in range(warmup):
         step(torch.cuda.current_stream().cuda_stream)
     wall, devs, graphed, _ = time_batches(torch, step, steps, torch.cuda.synchronize, lambda v: v, True)
-    lower = synth.lower_plus_diag_nnz(rp, ci) - n if symmetric else None
+    lower = None
+    if symmetric:
+        # strictly lower nonzeros, row by row in chunks (no nnz-long temporaries)
+        lower = 0
+        for r0 in range(0, n, 1 << 20):
+            r1 = min(n, r0 + (1 << 20))
+            rows = np.repeat(np.arange(r0, r1, dtype=np.int64), np.diff(rp[r0:r1 + 1]))
+            lower += int((ci[rp[r0]:rp[r1]] < rows).sum())
     b_alg = algorithmic_bytes(symmetric, nnz, n, n, lower)
     launch_s = devs / steps
     out = {"gflops": round(2.0 * nnz * steps / wall / 1e9, 2), "us_per_spmv": round(1e6 * wall / steps, 3),
@@ -487,7 +496,7 @@ def run_config(torch, sx, name, symmetric, steps, warmup, cpu_budget, T):
                         "unit": "GB/s", "frac": round(b_alg / launch_s / 1e9 / HBM_PEAK_GBS, 4),
                         "kernel": kernel_name(info, symmetric, 1), "avg_launch_us": round(1e6 * launch_s, 3),
                         "algorithmic_bytes_per_launch": int(b_alg),
-                        "traffic": measured_traffic(name + ("-sym" if symmetric else ""))},
+                        "traffic": measured_traffic(traffic_key or (name + ("-sym" if symmetric else "")))},
            "cache_resident": bool(info.value_bytes + info.index_bytes < MALL_BYTES),
            "index_bytes_per_nnz": round(info.index_bytes / max(int(info.nnz_stored), 1), 3),
            "tune_seconds": round(info.tune_seconds, 3), "emit_upload_seconds": round(info.emit_seconds, 3),
@@ -767,8 +776,14 @@ def main():
             out["cpu_baseline"] = cpu_baseline(csr_s, args.symmetric, 20.0, note)
             del csr_s
         if world == 1 and not args.no_configs and args.workload == "syn-nlpkkt" and not args.mtx:
-            del wl
             cfgs = {}
+            if not args.symmetric and not args.opt:
+                # the bench matrix itself through the symmetric path (BASELINE config 4's path:
+                # lower triangle + diagonal stored, every value read once)
+                cfgs["syn-nlpkkt --symmetric (the bench matrix)"] = run_config(
+                    torch, sx, "syn-nlpkkt", True, args.steps, args.warmup, 0.0, T,
+                    csr=(wl.rp, wl.ci, wl.va, n), traffic_key="syn-nlpkkt-e%d-sym" % args.edge)
+            del wl
             for name, sym in (("syn-cant", False), ("syn-nd24k", True), ("syn-webbase", False)):
                 cfgs[name + (" --symmetric" if sym else "")] = run_config(
                     torch, sx, name, sym, max(args.steps, 256), max(args.warmup, 32),

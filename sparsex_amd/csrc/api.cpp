@@ -419,7 +419,7 @@ static void emit_and_upload(spx_matrix_t *A)
             const bool want_segs = gp.sym_segments != 0 && !A->deterministic && A->spill_mode != 0 && !A->wave_tiles &&
                                    (gp.sym_segments == 1 || n_lower >= min_lower);
             build_sym_ranges(A->parts, ranges, gp.max_rows >= 8, fulls, tiles, hw,
-                             gs.sym_fused ? nullptr : &thin, want_segs ? &segs : nullptr);
+                             gs.sym_fused ? nullptr : &thin, want_segs ? &segs : nullptr, gp.sym_min_run);
             for (const auto &v : segs)
                 for (const SymSeg &sg : v) n_seg_elems += sg.width;
             // (auto: worth it where most of the stored triangle lies in such runs and the
@@ -754,6 +754,12 @@ static spx_matrix_t *do_tune(spx_input_t *in)
             throw FatalError("bad spx.gpu.sym_wide_rows");
         }
         A->emit_params.wide_rows = (size_t) wide;
+        const long mr = cfg.get_long("spx.gpu.sym_segment_min");
+        if (mr < 2 || mr > 8) {
+            log_msg(LOG_ERR, "spx.gpu.sym_segment_min: 2 .. 8\n");
+            throw FatalError("bad spx.gpu.sym_segment_min");
+        }
+        A->emit_params.sym_min_run = (size_t) mr;
     }
     A->emit_params.stack_segments = cfg.get_bool("spx.gpu.stack_segments");
     {

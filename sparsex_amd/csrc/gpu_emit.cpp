@@ -993,7 +993,7 @@ void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<Sy
                       bool want_tiles, std::vector<Partition> &outs,
                       std::vector<std::vector<SymTile>> &tiles, unsigned nthreads,
                       std::vector<MirrorPoint> *sparse_mirror,
-                      std::vector<std::vector<SymSeg>> *symsegs)
+                      std::vector<std::vector<SymSeg>> *symsegs, size_t min_run)
 {
     const size_t P = lowers.size(), R = ranges.size();
     outs.assign(R, Partition());
@@ -1104,14 +1104,14 @@ void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<Sy
             for (size_t a = 0; a < pts.size();) {
                 size_t b = a + 1;
                 while (b < pts.size() && pts[b].row == pts[a].row && pts[b].col == pts[b - 1].col + 1) ++b;
-                // a run of b - a consecutive columns: pieces of eight, the remainder if >= 3
+                // a run of b - a consecutive columns: pieces of eight, the remainder if >= min_run
                 // (not on rows so long that they are chunked over several row-blocks)
                 size_t k = a;
                 const bool take = !long_row[(size_t) pts[a].row - 1];
-                for (; take && b - k >= 3; k += std::min<size_t>(8, b - k)) {
+                for (; take && b - k >= min_run; k += std::min<size_t>(8, b - k)) {
                     const size_t w = std::min<size_t>(8, b - k);
-                    if (b - k - w > 0 && b - k - w < 3 && w == 8 && b - k < 11) {
-                        // (do not leave a tail of one or two: split 9 and 10 as 5+4 / 5+5)
+                    if (b - k - w > 0 && b - k - w < min_run && w == 8 && b - k < 8 + min_run) {
+                        // (do not leave a tail shorter than that: split 9 and 10 as 5+4 / 5+5)
                         const size_t w1 = (b - k + 1) / 2;
                         SymSeg sg;
                         sg.row = pts[k].row - 1; sg.col = pts[k].col - 1; sg.width = (uint8_t) w1;

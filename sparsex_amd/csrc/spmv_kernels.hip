@@ -465,6 +465,7 @@ __device__ __forceinline__ void run_symseg(const KernelArgs &a, const SpxRowBloc
                                            double *slots, double *tile, int lane)
 {
     switch (ps.width) {            // wave-uniform
+    case 2: symseg_pass<2>(a, rb, ps, slots, tile, lane); break;
     case 3: symseg_pass<3>(a, rb, ps, slots, tile, lane); break;
     case 4: symseg_pass<4>(a, rb, ps, slots, tile, lane); break;
     case 5: symseg_pass<5>(a, rb, ps, slots, tile, lane); break;

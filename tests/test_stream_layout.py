@@ -248,6 +248,28 @@ def test_symmetric_row_segments_are_stored_once(tmp_path, name, gen, auto_on, mo
         assert B.get_entry(row, col) == 2.5
 
 
+@pytest.mark.parametrize("min_run", ["2", "3", "5"])
+def test_shortest_read_once_run(tmp_path, min_run):
+    """spx.gpu.sym_segment_min: shorter runs of the lower triangle stay on the mirrored path."""
+    csr = synth.syn_nlpkkt_rows(12)
+    rp, ci, va, n = csr
+    A = tune(csr, {"spx.gpu.sym_segments": "true", "spx.gpu.sym_segment_min": min_run, "spx.rt.nr_threads": "2"},
+             sym=True, host_only=True)
+    f = str(tmp_path / "m.spx")
+    A.save(f)
+    s = Stream(f)
+    used = np.zeros(len(s.passes), bool)
+    for rb in s.rbs:
+        used[int(rb["pass_off"]):int(rb["pass_off"]) + int(rb["n_pass"])] = True
+    seg = s.passes[used & (s.passes["kind"] == 5)]
+    assert len(seg) and int(seg["width"].min()) >= int(min_run) and (int(seg["width"].min()) == 2) == (min_run == "2")
+    a = sp.csr_matrix((va, ci, rp), shape=(n, n))
+    x = synth.random_x(n)
+    assert np.allclose(s.matvec(x), a @ x, rtol=1e-12, atol=1e-14)
+    r, c, v, b, m = dense_of(s)
+    assert abs(m.tocsr() - (a - sp.diags(a.diagonal())).tocsr()).max() == 0
+
+
 @pytest.mark.parametrize("wide", ["512", "1024", "2048"])
 def test_wide_rowblocks_share_their_slots(tmp_path, wide):
     """spx.gpu.sym_wide_rows: consecutive row-blocks with read-once segments go side by side into

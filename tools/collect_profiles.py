@@ -10,7 +10,7 @@ dst = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 traffic = {}
 # gpurun_out tag -> key bench.py looks up (workload[-e<edge>][-sym])
-KEYS = {"nlpkkt": None, "cant": "syn-cant", "nd24k_sym": "syn-nd24k-sym", "webbase": "syn-webbase"}
+KEYS = {"nlpkkt": None, "nlpkkt_sym": None, "cant": "syn-cant", "nd24k_sym": "syn-nd24k-sym", "webbase": "syn-webbase"}
 for w, key in KEYS.items():
     src = os.path.join(ROOT, "gpurun_out", "%s_%s" % (rnd, w))
     if not os.path.isdir(src):
@@ -26,7 +26,7 @@ for w, key in KEYS.items():
         try:
             line = json.load(open(os.path.join(src, "bench_line.json")))
             edge = re.search(r"grid edge (\d+)", line["config"]["workload"]).group(1)
-            key = "syn-nlpkkt-e%s" % edge
+            key = "syn-nlpkkt-e%s%s" % (edge, "-sym" if w.endswith("_sym") else "")
         except Exception:
             continue
     # The launch autotuner inside spx_mat_tune runs every variant (2/4/8 wavefronts, both
@@ -36,7 +36,8 @@ for w, key in KEYS.items():
     want = None
     try:
         plain = json.load(open(os.path.join(ROOT, "gpurun_out", "%s_nlpkkt" % rnd, "bench_plain.json")))
-        cfg = {"cant": "syn-cant", "nd24k_sym": "syn-nd24k --symmetric", "webbase": "syn-webbase"}.get(w)
+        cfg = {"cant": "syn-cant", "nd24k_sym": "syn-nd24k --symmetric", "webbase": "syn-webbase",
+               "nlpkkt_sym": "syn-nlpkkt --symmetric (the bench matrix)"}.get(w)
         name = plain["configs"][cfg]["roofline"]["kernel"] if cfg else plain["roofline"]["kernel"]
         want = re.search(r"csx_spmv[a-z_]*kernel<\d>", name).group(0)
     except Exception:
