@@ -5,7 +5,7 @@ import pytest
 
 from sparsex_amd import synth
 from helpers import tune, check_y
-from test_stream_random import random_matrix, random_options
+from test_stream_random import random_matrix, random_options, random_sym_options
 
 pytestmark = pytest.mark.gpu
 
@@ -27,15 +27,11 @@ def test_general_random_gpu(seed):
     check_y(csr, x, y, -1.0, 0.25, y0)
 
 
-@pytest.mark.parametrize("seed", range(40, 70))
+@pytest.mark.parametrize("seed", range(40, 90))
 def test_symmetric_random_gpu(seed):
     csr, m = random_matrix(seed, symmetric=True)
     n = csr[3]
-    o = random_options(seed)
-    rng = np.random.RandomState(seed)
-    for k in ("spx.gpu.sym_once", "spx.gpu.sym_remine"):
-        if rng.rand() < 0.3:
-            o[k] = "false"
+    o = random_sym_options(seed, random_options(seed))
     o["spx.gpu.waves"] = str([0, 2, 4, 8][seed % 4])
     A = tune(csr, o, sym=True)
     x = synth.random_x(n)

@@ -76,6 +76,19 @@ def random_options(seed):
     return o
 
 
+def random_sym_options(seed, o):
+    """... plus the choices of the symmetric path: mirrored / tiles / read-once segments."""
+    rng = np.random.RandomState(seed)
+    for k in ("spx.gpu.sym_once", "spx.gpu.sym_remine"):
+        if rng.rand() < 0.3:
+            o[k] = "false"
+    if rng.rand() < 0.6:
+        o["spx.gpu.sym_segments"] = "true"
+        o["spx.gpu.sym_wide_rows"] = str(rng.choice([512, 700, 1024, 2048]))
+        o["spx.gpu.sym_segment_min"] = str(rng.choice([2, 3, 4]))
+    return o
+
+
 @pytest.mark.parametrize("seed", range(40))
 def test_general_stream_random(tmp_path, seed):
     csr, m = random_matrix(seed, symmetric=False)
@@ -93,15 +106,11 @@ def test_general_stream_random(tmp_path, seed):
     assert np.allclose(s.matvec(x), m @ x, rtol=1e-12, atol=1e-13)
 
 
-@pytest.mark.parametrize("seed", range(40, 70))
+@pytest.mark.parametrize("seed", range(40, 90))
 def test_symmetric_stream_random(tmp_path, seed):
     csr, m = random_matrix(seed, symmetric=True)
     rp, ci, va, n = csr
-    o = random_options(seed)
-    rng = np.random.RandomState(seed)
-    for k in ("spx.gpu.sym_once", "spx.gpu.sym_remine"):
-        if rng.rand() < 0.3:
-            o[k] = "false"
+    o = random_sym_options(seed, random_options(seed))
     A = tune(csr, o, sym=True, host_only=True)
     f = str(tmp_path / "m.spx")
     A.save(f)
