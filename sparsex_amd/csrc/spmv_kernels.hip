@@ -1038,6 +1038,8 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
         const size_t lds = m->lds_doubles * sizeof(double);
         const size_t lds_a = lds + SPX_MAX_WIDE_SLOTS / 8 * sizeof(uint32_t);   // + the slot groups' columns
         if (m->sym_atomic && m->has_symsegs && !m->has_symtiles) {
+            // (16 wavefronts per workgroup, so that 2048-row row-blocks keep the SIMDs full, were
+            // measured: 0.90 ms against 0.835 with 8, syn-nlpkkt; not built)
             if (m->waves == 2) SPX_LAUNCH(csx_spmv_symseg_notile_kernel, 2, lds_a);
             else if (m->waves == 8) SPX_LAUNCH(csx_spmv_symseg_notile_kernel, 8, lds_a);
             else SPX_LAUNCH(csx_spmv_symseg_notile_kernel, 4, lds_a);
