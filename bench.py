@@ -453,7 +453,8 @@ def algorithmic_bytes(symmetric, nnz_local_full, rows_local, n, lower_local=None
     return 8.0 * nnz_local_full + 8.0 * n + 8.0 * rows_local
 
 
-def run_config(torch, sx, name, symmetric, steps, warmup, cpu_budget, T, csr=None, traffic_key=None):
+def run_config(torch, sx, name, symmetric, steps, warmup, cpu_budget, T, csr=None, traffic_key=None,
+               cpu_sample=None, cpu_note=""):
     """One of the other BASELINE configurations on this GPU (or the bench matrix itself on the
     other path), measured like the main line."""
     from sparsex_amd import synth
@@ -501,9 +502,11 @@ def run_config(torch, sx, name, symmetric, steps, warmup, cpu_budget, T, csr=Non
            "index_bytes_per_nnz": round(info.index_bytes / max(int(info.nnz_stored), 1), 3),
            "tune_seconds": round(info.tune_seconds, 3), "emit_upload_seconds": round(info.emit_seconds, 3),
            "parity": parity}
-    if cpu_budget > 0:
-        out["cpu_baseline"] = cpu_baseline(csr, symmetric, cpu_budget)
     A.destroy()
+    del A, x, y
+    if cpu_budget > 0:
+        out["cpu_baseline"] = (cpu_baseline(cpu_sample, symmetric, cpu_budget, cpu_note) if cpu_sample is not None
+                               else cpu_baseline(csr, symmetric, cpu_budget))
     return out
 
 
@@ -626,7 +629,24 @@ def main():
             from sparsex_amd.dist_torch import torch_transport
             transport = torch_transport(rank, world)
             transport_name = "torch.distributed/%s staged through the host (test path)" % backend
-        A.dist_attach(transport)
+        try:
+            A.dist_attach(transport)
+            attached = 1
+        except sx.SpxError as e:
+            print("bench.py: rank %d could not attach the exchange plan (%s)" % (rank, e), file=sys.stderr)
+            attached = 0
+        if backend == "nccl":
+            ok = torch.tensor([attached], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if not int(ok.item()) and not transport_name.startswith("STAND-BY"):
+                # (as above: everybody changes to the stand-by transport together)
+                transport.destroy()
+                from sparsex_amd.dist_torch import torch_transport
+                transport = torch_transport(rank, world, staging_device=dev)
+                transport_name = "STAND-BY: torch.distributed all_to_all_single (RCCL) staged through device buffers"
+                A.dist_attach(transport)
+                attached = 1
+        assert attached, "no exchange plan"
         plan = A.dist_plan()
 
     xh = synth.random_x(n)
@@ -780,9 +800,15 @@ def main():
             if not args.symmetric and not args.opt:
                 # the bench matrix itself through the symmetric path (BASELINE config 4's path:
                 # lower triangle + diagonal stored, every value read once)
+                sample, snote = None, ""
+                if not args.no_cpu_baseline and args.edge > SAMPLE_EDGE:
+                    sample = synth.syn_nlpkkt_rows(SAMPLE_EDGE)
+                    snote = "sample: syn-nlpkkt at grid edge %d (%.1f M nonzeros); " % (SAMPLE_EDGE, sample[0][-1] / 1e6)
                 cfgs["syn-nlpkkt --symmetric (the bench matrix)"] = run_config(
-                    torch, sx, "syn-nlpkkt", True, args.steps, args.warmup, 0.0, T,
-                    csr=(wl.rp, wl.ci, wl.va, n), traffic_key="syn-nlpkkt-e%d-sym" % args.edge)
+                    torch, sx, "syn-nlpkkt", True, args.steps, args.warmup,
+                    8.0 if sample is not None else 0.0, T,
+                    csr=(wl.rp, wl.ci, wl.va, n), traffic_key="syn-nlpkkt-e%d-sym" % args.edge,
+                    cpu_sample=sample, cpu_note=snote)
             del wl
             for name, sym in (("syn-cant", False), ("syn-nd24k", True), ("syn-webbase", False)):
                 cfgs[name + (" --symmetric" if sym else "")] = run_config(
