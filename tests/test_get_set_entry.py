@@ -54,11 +54,17 @@ def test_get_every_entry_and_set_some_host(gen, opts, sym):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sym", [False, True])
+@pytest.mark.parametrize("sym", [False, True, "segments"])
 def test_set_entry_reaches_the_gpu(sym):
+    """(sym == "segments": the lower triangle in read-once row segments -- one stored value
+    serves both triangles, so one poke must change both)"""
     csr = synth.syn_cant(0.03)
     rp, ci, va, n = csr
-    A = tune(csr, {"spx.preproc.sampling": "none"}, sym=sym)
+    o = {"spx.preproc.sampling": "none"}
+    if sym == "segments":
+        o.update({"spx.gpu.sym_segments": "true", "spx.gpu.sym_wide_rows": "2048"})
+    A = tune(csr, o, sym=bool(sym))
+    assert (A.info().sym_segments > 0) == (sym == "segments")
     x = synth.random_x(n)
     y = np.zeros(n)
     A.matvec_mult(1.0, x, y)

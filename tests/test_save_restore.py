@@ -39,11 +39,14 @@ def test_restore_rejects_garbage(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sym", [False, True])
+@pytest.mark.parametrize("sym", [False, True, "segments"])
 def test_round_trip_gpu(tmp_path, sym):
     csr = synth.syn_cant(0.05)
     n = csr[3]
-    A = tune(csr, {"spx.preproc.sampling": "none"}, sym=sym)
+    o = {"spx.preproc.sampling": "none"}
+    if sym == "segments":                       # read-once row segments in row-blocks of up to 2048 rows
+        o.update({"spx.gpu.sym_segments": "true", "spx.gpu.sym_wide_rows": "2048"})
+    A = tune(csr, o, sym=bool(sym))
     x = synth.random_x(n)
     y1 = np.zeros(n)
     A.matvec_mult(0.5, x, y1)
@@ -52,6 +55,7 @@ def test_round_trip_gpu(tmp_path, sym):
     A.destroy()
     sx.options_reset()
     B = sx.mat_restore(f)
+    assert (B.info().sym_segments > 0) == (sym == "segments")
     y2 = np.full(n, np.nan)
     B.matvec_mult(0.5, x, y2)
     check_y(csr, x, y2, 0.5)
