@@ -22,7 +22,10 @@
  *   spx.gpu.waves           wavefronts per workgroup of the SpMV kernel: 2, 4 or 8;
  *                           0 (default): spx_mat_tune() measures a few launch
  *                           configurations on the device and keeps the fastest
- *   spx.gpu.rowblock_rows   max rows per row-block (default and cap 512)
+ *   spx.gpu.rowblock_rows   max rows per row-block (default 512; up to 2048: planned row-blocks of
+ *                           at most 512 rows are then joined up to the target size -- for matrices
+ *                           with a few nonzeros per row; measured on syn-webbase: 38.8 us with 512,
+ *                           40.9 with 1024, so not the default)
  *   spx.gpu.stack_segments  "false": one descriptor per CSX unit piece instead
  *                           of merging equal row segments of consecutive rows
  *   spx.gpu.recut_linear    "false": vertical / diagonal / strided units always run one

@@ -736,7 +736,7 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     long rbe = cfg.get_long("spx.gpu.rowblock_elems");
     A->auto_rb = rbe <= 0;
     A->emit_params.target_elems = (size_t) std::max<long>(64, rbe);
-    A->emit_params.max_rows = (size_t) std::max<long>(1, cfg.get_long("spx.gpu.rowblock_rows"));
+    A->emit_params.max_rows = (size_t) std::min<long>(SPX_MAX_WIDE_ROWS, std::max<long>(1, cfg.get_long("spx.gpu.rowblock_rows")));
     A->emit_params.sym_remine = cfg.get_bool("spx.gpu.sym_remine");
     A->emit_params.sym_once = cfg.get_bool("spx.gpu.sym_once");
     A->emit_params.recut_linear = cfg.get_bool("spx.gpu.recut_linear");

@@ -1484,16 +1484,36 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsi
     // once, not once per plan)
     std::vector<std::pair<size_t, size_t>> jobs;          // plans [first, last)
     {
-        const size_t wide = std::min<size_t>(prm.wide_rows, SPX_MAX_WIDE_ROWS);
-        auto joinable = [&](size_t i) {
-            return wide > SPX_MAX_RB_ROWS && !plans[i].split && rb_tiles[i].empty() && !rb_segs[i].empty();
+        // (the same for any row-block when spx.gpu.rowblock_rows allows more than 512 rows: a
+        // matrix with a few nonzeros per row fills its row-blocks by rows long before it fills
+        // them by nonzeros; there the planned row-blocks are joined up to the target size)
+        const size_t wide_seg = std::min<size_t>(prm.wide_rows, SPX_MAX_WIDE_ROWS);
+        const size_t wide_any = std::min<size_t>(prm.max_rows, SPX_MAX_WIDE_ROWS);
+        auto elems_of = [&](size_t i) {
+            size_t e = 0;
+            for (idx_t r = plans[i].row_lo; r < plans[i].row_hi; ++r) e += cnt[(size_t) r];
+            return e;
+        };
+        auto joinable = [&](size_t i, bool seg) {
+            if (plans[i].split || !rb_tiles[i].empty()) return false;
+            return seg ? wide_seg > SPX_MAX_RB_ROWS && !rb_segs[i].empty()
+                       : wide_any > SPX_MAX_RB_ROWS && rb_segs[i].empty();
         };
         for (size_t i = 0; i < plans.size();) {
             size_t j = i + 1;
-            if (joinable(i))
-                while (j < plans.size() && joinable(j) &&
-                       (size_t)(plans[j].row_hi - plans[i].row_lo) <= wide)
+            if (joinable(i, true)) {
+                while (j < plans.size() && joinable(j, true) &&
+                       (size_t)(plans[j].row_hi - plans[i].row_lo) <= wide_seg)
                     ++j;
+            } else if (joinable(i, false)) {
+                size_t e = elems_of(i);
+                while (j < plans.size() && joinable(j, false) &&
+                       (size_t)(plans[j].row_hi - plans[i].row_lo) <= wide_any &&
+                       e + elems_of(j) <= target + elems_of(j) / 2) {      // (overshoot by half a part at most)
+                    e += elems_of(j);
+                    ++j;
+                }
+            }
             jobs.emplace_back(i, j);
             i = j;
         }

@@ -28,6 +28,7 @@ OPTS = [
     {"spx.preproc.sampling": "none", "spx.rt.nr_threads": "3"},
     {"spx.preproc.sampling": "none", "spx.gpu.rowblock_elems": "300",
      "spx.gpu.rowblock_rows": "7"},
+    {"spx.gpu.rowblock_elems": "8000", "spx.gpu.rowblock_rows": "2048"},     # row-blocks joined from planned ones
 ]
 
 

@@ -58,6 +58,9 @@ CASES = [
     # leftovers inside a narrow band: row-blocks stage an x window in LDS, u16 offsets from its base
     ("band-window", lambda: synth.syn_bandrandom(8000), {}),
     ("band-no-window", lambda: synth.syn_bandrandom(8000), {"spx.gpu.x_window": "false"}),
+    # few nonzeros per row: row-blocks of up to 2048 rows, joined from planned ones of <= 512
+    ("web-wide-rows", lambda: synth.syn_webbase(0.1), {"spx.gpu.rowblock_rows": "2048", "spx.gpu.rowblock_elems": "6000",
+                                                        "spx.rt.nr_threads": "2"}),
 ]
 
 
@@ -83,6 +86,8 @@ def test_general_stream_holds_the_matrix_exactly(tmp_path, name, gen, opts):
     s.check_ownership()
     row0 = s.rbs["row0"].astype(np.int64)[b]
     assert ((r >= row0) & (r < row0 + s.rbs["n_rows"].astype(np.int64)[b])).all()
+    if name == "web-wide-rows":
+        assert int(s.rbs["n_rows"].max()) > 1024
     if name.startswith("band"):
         windows = int((s.rbs["xwin_len"] > 0).sum())
         assert (windows > len(s.rbs) // 2) == (name == "band-window")
