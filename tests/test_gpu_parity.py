@@ -109,6 +109,25 @@ def test_long_rows_shared():
     check_y(csr, x, y, 0.5, 2.0, y0)
 
 
+@pytest.mark.parametrize("segs", ["true", "false"])
+def test_symmetric_long_rows(segs):
+    """Symmetric storage with rows beyond a row-block (shared rows, fix-up kernel after the atomic
+    hand-over), with and without read-once segments in the other rows."""
+    from test_stream_layout import long_row_sym
+    csr, m = long_row_sym()
+    n = csr[3]
+    A = tune(csr, {"spx.gpu.sym_segments": segs, "spx.rt.nr_threads": "3"}, sym=True)
+    assert A.info().n_shared_rows >= 2
+    x = synth.random_x(n)
+    y = np.full(n, np.nan)
+    A.matvec_mult(1.0, x, y)
+    check_y(csr, x, y, 1.0)
+    y0 = synth.random_x(n, seed=5)
+    y = y0.copy()
+    A.matvec_kernel(0.5, x, 2.0, y)
+    check_y(csr, x, y, 0.5, 2.0, y0)
+
+
 def test_demopatt_reference_scenarios():
     """The reference's own scenario list on its fixtures, 128 loops, alpha 0.5
     (test/scripts/test-sparsex.sh.in:55-244, test/src/sparsex_test.c:57-191)."""

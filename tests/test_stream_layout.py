@@ -156,6 +156,42 @@ def test_long_rows_are_shared_and_complete(tmp_path):
     s.check_ownership()
 
 
+def long_row_sym(n=30000, seed=8):
+    """Symmetric, with two rows near the end whose lower parts (20000 and 9000 nonzeros, long dense
+    runs among them) exceed a row-block, on top of a band with runs of four."""
+    rng = np.random.RandomState(seed)
+    r1 = np.full(20000, n - 7); c1 = np.arange(100, 20100)                       # one dense run
+    r2 = np.full(9000, n - 3); c2 = np.sort(rng.choice(n - 10, 9000, replace=False))
+    rb = np.repeat(np.arange(8, n), 4); cb = rb - np.tile(np.arange(5, 1, -1), n - 8)
+    r, c = np.concatenate([r1, r2, rb]), np.concatenate([c1, c2, cb])
+    low = sp.coo_matrix((rng.uniform(0.5, 1.5, r.size), (r, c)), shape=(n, n)).tocsr()
+    low.sum_duplicates()
+    low = sp.tril(low, k=-1)
+    m = (low + low.T + sp.diags(rng.uniform(1.0, 2.0, n))).tocsr()
+    m.sort_indices()
+    return (m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data.copy(), n), m
+
+
+@pytest.mark.parametrize("segs", ["true", "false"])
+def test_symmetric_long_rows_stay_on_the_mirrored_path(tmp_path, segs):
+    """Rows too long for one row-block are chunked over several (shared rows); read-once segments
+    leave them alone, whatever runs they hold."""
+    csr, m = long_row_sym()
+    rp, ci, va, n = csr
+    A = tune(csr, {"spx.gpu.sym_segments": segs, "spx.rt.nr_threads": "3"}, sym=True, host_only=True)
+    f = str(tmp_path / "m.spx")
+    A.save(f)
+    s = Stream(f)
+    assert len(s.shared) >= 2
+    assert (A.info().sym_segments > 0) == (segs == "true")
+    r, c, v, b, got = dense_of(s)
+    off = (m - sp.diags(m.diagonal())).tocsr()
+    assert abs(got.tocsr() - off).max() == 0
+    s.check_ownership()
+    x = synth.random_x(n)
+    assert np.allclose(s.matvec(x), m @ x, rtol=1e-12, atol=1e-13)
+
+
 @pytest.mark.parametrize("once", ["true", "false"])
 def test_symmetric_slices_sum_to_the_product(tmp_path, once):
     """Two processes, each holding half of the partitions of a symmetric matrix: their streams
