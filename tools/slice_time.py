@@ -2,7 +2,8 @@ import sys, time, numpy as np, torch
 sys.path.insert(0, ".")
 import sparsex_amd as sx, bench
 from sparsex_amd import synth
-N, W = 120, int(sys.argv[1])
+# usage: tools/slice_time.py <world> [grid edge, default 120]
+W = int(sys.argv[1]); N = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 counts = synth.nlpkkt_row_counts(N); n = counts.size
 cuts = bench.nnz_balanced_cuts(counts, W)
 x = torch.from_numpy(synth.random_x(n)).cuda(); y = torch.zeros(n, dtype=torch.float64, device="cuda")
@@ -19,5 +20,5 @@ for sym in (False, True):
         for _ in range(50): A.hip_matvec_mult(0.5, x.data_ptr(), y.data_ptr(), st)
         e1.record(); torch.cuda.synchronize()
         i = A.info()
-        print("world %d sym %d rank %d: %.1f us per local SpMV, %d row-blocks, %d nnz stored" % (W, sym, r, e0.elapsed_time(e1) * 1e3 / 50, i.n_rowblocks, i.nnz_stored), flush=True)
+        print("edge %d world %d sym %d rank %d: %.1f us per local SpMV, %d row-blocks, %d nnz stored, segments %d" % (N, W, sym, r, e0.elapsed_time(e1) * 1e3 / 50, i.n_rowblocks, i.nnz_stored, i.sym_segments), flush=True)
         A.destroy()
