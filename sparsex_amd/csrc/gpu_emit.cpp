@@ -560,8 +560,13 @@ void RbBuilder::assign_slots(SpxRowBlock &rb, const std::vector<const SymTile *>
     const size_t max_slots = rb.n_rows > SPX_MAX_RB_ROWS ? SPX_MAX_WIDE_SLOTS : SPX_MAX_TILE_SLOTS;
     if (symsegs && !symsegs->empty()) {
         std::vector<idx_t> more;
+        // (a group is handed to y whole, eight doubles: one that would reach past the last row of
+        // this range -- possible only in front of a row-block of its last seven rows -- is left
+        // out; its segments add to y themselves)
+        const idx_t end = p_.row_start + (idx_t) p_.nr_rows;
         for (const SymSeg *sg : *symsegs)
-            for (idx_t c = sg->col & ~(idx_t) 7; c < sg->col + sg->width && c < row0; c += 8) more.push_back(c);
+            for (idx_t c = sg->col & ~(idx_t) 7; c < sg->col + sg->width && c < row0; c += 8)
+                if (c + 8 <= end) more.push_back(c);
         std::sort(more.begin(), more.end());
         more.erase(std::unique(more.begin(), more.end()), more.end());
         // (nearest to the row-block first, should they not all fit: the others add to y directly)
@@ -1228,7 +1233,10 @@ void finalize_stream(GpuStream &s, size_t nrows)
     if (!s.spill_col.empty()) {
         // per row: the spill slots whose sums belong to it (counting sort by column)
         s.fix_ptr.assign(nrows + 1, 0);
-        for (uint32_t c : s.spill_col) ++s.fix_ptr[(size_t) c + 1];
+        for (uint32_t c : s.spill_col) {
+            if ((size_t) c >= nrows) throw FatalError("transposed-sum slot beyond the last row");
+            ++s.fix_ptr[(size_t) c + 1];
+        }
         for (size_t i = 0; i < nrows; ++i) s.fix_ptr[i + 1] += s.fix_ptr[i];
         s.fix_idx.resize(s.spill_col.size());
         std::vector<uint32_t> fill(s.fix_ptr.begin(), s.fix_ptr.end() - 1);

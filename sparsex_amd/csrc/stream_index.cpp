@@ -182,6 +182,7 @@ bool stream_validate(const GpuStream &s, size_t nrows, size_t ncols, size_t n_va
         SPX_REQUIRE(s.fix_ptr[i] <= s.fix_ptr[i + 1], "spill list order");
     SPX_REQUIRE(s.fix_ptr.empty() || s.fix_ptr.back() == s.fix_idx.size(), "spill list end");
     for (uint32_t k : s.fix_idx) SPX_REQUIRE(k < s.n_spill, "spill index");
+    for (uint32_t c : s.spill_col) SPX_REQUIRE(c < nrows, "spill columns");
     SPX_REQUIRE(s.mirror_rows.empty() ? s.mirror_ptr.size() <= 1 && s.mirror_col.empty()
                                       : s.mirror_ptr.size() == s.mirror_rows.size() + 1 &&
                                         s.mirror_ptr.back() == s.mirror_col.size(), "mirror list sizes");

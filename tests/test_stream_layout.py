@@ -311,6 +311,32 @@ def test_shortest_read_once_run(tmp_path, min_run):
     assert abs(m.tocsr() - (a - sp.diags(a.diagonal())).tocsr()).max() == 0
 
 
+def test_slot_groups_stay_inside_the_matrix(tmp_path):
+    """Slots come in aligned groups of eight columns that are handed to y whole.  In front of a
+    row-block of the last rows of a matrix whose order is not a multiple of eight, such a group
+    would reach past the last row (found by tools/soak_random.py: heap corruption at tune time,
+    out-of-bounds atomics at run time): those columns get no slots, their segments add to y
+    themselves."""
+    n = 700 + 3
+    r = np.repeat(np.arange(6, n), 5)
+    c = r - np.tile(np.arange(6, 1, -1), n - 6)                  # every row: a run of five columns in front of it
+    rng = np.random.RandomState(4)
+    low = sp.coo_matrix((rng.uniform(0.5, 1.5, r.size), (r, c)), shape=(n, n)).tocsr()
+    m = (low + low.T + sp.diags(rng.uniform(1.0, 2.0, n))).tocsr()
+    m.sort_indices()
+    csr = (m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data.copy(), n)
+    for rows in ("3", "5", "512"):
+        A = tune(csr, {"spx.gpu.sym_segments": "true", "spx.gpu.rowblock_rows": rows, "spx.rt.nr_threads": "2",
+                       "spx.gpu.sym_wide_rows": "700"}, sym=True, host_only=True)
+        f = str(tmp_path / "m.spx")
+        A.save(f)
+        s = Stream(f)
+        assert s.slot_group_col.size == 0 or int(s.slot_group_col.max()) + 8 <= n
+        x = synth.random_x(n)
+        assert np.allclose(s.matvec(x), m @ x, rtol=1e-12, atol=1e-14)
+        sx.mat_restore(f).destroy()                             # (the restore-time validation agrees)
+
+
 @pytest.mark.parametrize("wide", ["512", "1024", "2048"])
 def test_wide_rowblocks_share_their_slots(tmp_path, wide):
     """spx.gpu.sym_wide_rows: consecutive row-blocks with read-once segments go side by side into
