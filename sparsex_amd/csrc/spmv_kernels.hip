@@ -1015,6 +1015,7 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
     hipLaunchKernelGGL(KERNEL<W>, dim3(blocks), dim3(64 * W), LDS, stream, a.rbs, a.passes,      \
                        a.n_rb, a.pass_stride, blocks >> 3, 0u, a.values, a.descs, a.cidx,        \
                        a.segrows, a.x, a.y, a.carry, a.dvalues, a.spill, a.slot_col, a.alpha, a.beta)
+    bool need_symfix = false;
     if (blocks && m->wave_tiles) {
         // a copy of slots + y tile per wavefront: as many wavefronts as fit the LDS
         const int w = m->waves;
@@ -1023,10 +1024,7 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
             if (w == 2) SPX_LAUNCH(csx_spmv_symtile_det_kernel, 2, lds);
             else if (w == 8) SPX_LAUNCH(csx_spmv_symtile_det_kernel, 8, lds);
             else SPX_LAUNCH(csx_spmv_symtile_det_kernel, 4, lds);
-            if (m->n_spill)
-                hipLaunchKernelGGL(csx_symfix_kernel, dim3((unsigned)((((m->nrows + 31) / 32) + 7) & ~(size_t) 7)), dim3(256),
-                                   0, stream, m->fix_ptr, m->fix_idx, m->spill, d_y, alpha,
-                                   (uint32_t) m->nrows);
+            need_symfix = m->n_spill != 0;
         } else {
             if (w == 2) SPX_LAUNCH(csx_spmv_det_kernel, 2, lds);
             else if (w == 8) SPX_LAUNCH(csx_spmv_det_kernel, 8, lds);
@@ -1054,10 +1052,7 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
         } else if (m->waves == 2) SPX_LAUNCH(csx_spmv_symtile_kernel, 2, lds);
         else if (m->waves == 8) SPX_LAUNCH(csx_spmv_symtile_kernel, 8, lds);
         else SPX_LAUNCH(csx_spmv_symtile_kernel, 4, lds);
-        if (m->n_spill && !m->sym_atomic)
-            hipLaunchKernelGGL(csx_symfix_kernel, dim3((unsigned)((((m->nrows + 31) / 32) + 7) & ~(size_t) 7)), dim3(256),
-                               0, stream, m->fix_ptr, m->fix_idx, m->spill, d_y, alpha,
-                               (uint32_t) m->nrows);
+        need_symfix = m->n_spill && !m->sym_atomic;
     } else if (blocks) {
         const size_t lds = m->lds_doubles * sizeof(double);
         if (m->waves == 2) SPX_LAUNCH(csx_spmv_kernel, 2, lds);
@@ -1069,6 +1064,12 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
         hipLaunchKernelGGL(csx_fixup_kernel, dim3((m->n_shared + 63) / 64), dim3(64), 0,
                            stream, m->shared, m->n_shared, m->carry, d_y, alpha, beta,
                            a.dvalues, d_x);
+    // the spilled column sums are added last: a row that is split over several row-blocks gets its
+    // value (beta*y, the diagonal term, its partial sums) from the fix-up kernel above, by a store
+    if (need_symfix)
+        hipLaunchKernelGGL(csx_symfix_kernel, dim3((unsigned)((((m->nrows + 31) / 32) + 7) & ~(size_t) 7)), dim3(256),
+                           0, stream, m->fix_ptr, m->fix_idx, m->spill, d_y, alpha,
+                           (uint32_t) m->nrows);
     HIP_CHECK(hipGetLastError());
 }
 

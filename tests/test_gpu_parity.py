@@ -128,6 +128,39 @@ def test_symmetric_long_rows(segs):
     check_y(csr, x, y, 0.5, 2.0, y0)
 
 
+@pytest.mark.parametrize("opts", [{"spx.gpu.sym_spill": "lists"}, {"spx.gpu.sym_spill": "atomic"},
+                                  {"spx.gpu.deterministic": "true"}], ids=["lists", "atomic", "deterministic"])
+def test_symmetric_long_row_that_tiles_add_to(opts):
+    """A row too long for one row-block (its value comes from the fix-up kernel, by a store) that
+    is also a column of dense tiles further down (their transposed sums are added to it): the
+    spilled sums must come after the fix-up (found by tools/soak_large.py: they were overwritten)."""
+    import scipy.sparse as sp
+    n, R = 30000, 16400
+    rng = np.random.RandomState(12)
+    r1 = np.full(9000, R); c1 = np.sort(rng.choice(R - 8, 9000, replace=False))
+    a8, b8 = np.meshgrid(np.arange(8), np.arange(8), indexing="ij")
+    tr = (8 * np.arange(2100, 2140)[:, None] + a8.ravel()[None, :]).ravel()       # tiles below the long row ...
+    tc = np.tile(R + b8.ravel(), 40)                                              # ... in its column block
+    rb = np.arange(1, n); cb = rb - 1
+    r, c = np.concatenate([r1, tr, rb]), np.concatenate([c1, tc, cb])
+    low = sp.coo_matrix((rng.uniform(0.5, 1.5, r.size), (r, c)), shape=(n, n)).tocsr()
+    low.sum_duplicates()
+    low = sp.tril(low, k=-1)
+    m = (low + low.T + sp.diags(rng.uniform(1.0, 2.0, n))).tocsr()
+    m.sort_indices()
+    csr = (m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data.copy(), n)
+    A = tune(csr, dict(opts), sym=True)
+    assert A.info().n_shared_rows >= 1 and A.info().sym_tiles in (1, 2)
+    x = synth.random_x(n)
+    y = np.full(n, np.nan)
+    A.matvec_mult(0.5, x, y)
+    check_y(csr, x, y, 0.5)
+    y0 = synth.random_x(n, seed=5)
+    y = y0.copy()
+    A.matvec_kernel(2.0, x, -0.5, y)
+    check_y(csr, x, y, 2.0, -0.5, y0)
+
+
 def test_demopatt_reference_scenarios():
     """The reference's own scenario list on its fixtures, 128 loops, alpha 0.5
     (test/scripts/test-sparsex.sh.in:55-244, test/src/sparsex_test.c:57-191)."""

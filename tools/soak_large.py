@@ -1,0 +1,123 @@
+"""Randomised parity on larger matrices (20 k - 300 k rows: many row-blocks, slot windows that
+overflow, wide row-blocks, x windows, 24-bit column offsets), on the GPU against CSR.
+usage: python tools/soak_large.py <first seed> <last seed> [--host]   (--host: tune host-only and
+check the decoded stream instead -- runs without a GPU)"""
+import os, sys
+import numpy as np, scipy.sparse as sp
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from sparsex_amd import synth
+from helpers import tune, check_y
+
+host = "--host" in sys.argv
+a0, b0 = int(sys.argv[1]), int(sys.argv[2])
+
+
+def big_matrix(seed, symmetric):
+    rng = np.random.RandomState(7000 + seed)
+    n = int(rng.choice([20000, 50000, 120000, 300000]))
+    rows, cols = [np.arange(n)], [np.arange(n)]
+    for _ in range(rng.randint(2, 6)):
+        kind = rng.randint(0, 6)
+        if kind == 0:                                   # scatter
+            k = rng.randint(n // 2, 3 * n)
+            rows.append(rng.randint(0, n, k)); cols.append(rng.randint(0, n, k))
+        elif kind == 1:                                 # runs of w columns at a few offsets (a stencil)
+            w = rng.randint(2, 12)
+            for off in rng.randint(-n // 3, n // 3, rng.randint(1, 5)):
+                r = np.arange(max(0, -off), min(n, n - off - w))
+                keep = rng.rand(r.size) > 0.02
+                for q in range(w):
+                    rows.append(r[keep]); cols.append(r[keep] + off + q)
+        elif kind == 2:                                 # band of random nonzeros
+            k = rng.randint(n, 6 * n)
+            r = rng.randint(0, n, k)
+            rows.append(r); cols.append(np.clip(r + rng.randint(-400, 401, k), 0, n - 1))
+        elif kind == 3:                                 # aligned 8x8 tiles near a few block diagonals
+            nb = n // 8
+            for off in rng.randint(-nb // 4, nb // 4, rng.randint(1, 4)):
+                i = np.arange(max(0, -off), min(nb, nb - off))
+                i = i[rng.rand(i.size) < 0.3]
+                a, b = np.meshgrid(np.arange(8), np.arange(8), indexing="ij")
+                rows.append((8 * i[:, None] + a.ravel()[None, :]).ravel())
+                cols.append((8 * (i + off)[:, None] + b.ravel()[None, :]).ravel())
+        elif kind == 4:                                 # a few very long rows
+            for _ in range(rng.randint(1, 3)):
+                r = rng.randint(0, n)
+                c = rng.choice(n, rng.randint(5000, 15000), replace=False)
+                rows.append(np.full(c.size, r)); cols.append(c)
+        else:                                           # 2x2 blocks shifting by two (the nlpkkt stand-in's shape)
+            w = 2 * rng.randint(1, 4)
+            off = 2 * rng.randint(-n // 8, n // 8)
+            k = np.arange(max(0, -off // 2 + 1), min(n // 2, (n - off - w) // 2))
+            for d in (0, 1):
+                for q in range(w):
+                    rows.append(2 * k + d); cols.append(2 * k + off + q)
+    r, c = np.concatenate(rows), np.concatenate(cols)
+    ok = (r >= 0) & (r < n) & (c >= 0) & (c < n)
+    r, c = r[ok], c[ok]
+    if symmetric:
+        r, c = np.concatenate([r, c]), np.concatenate([c, r])
+    m = sp.coo_matrix((np.ones(r.size), (r, c)), shape=(n, n)).tocsr()
+    m.sum_duplicates(); m.sort_indices()
+    m.data = rng.uniform(0.5, 1.5, m.nnz)
+    if symmetric:
+        low = sp.tril(m, k=-1)
+        m = (low + low.T + sp.diags(m.diagonal())).tocsr()
+        m.sort_indices()
+    return (m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data.copy(), n), m
+
+
+def options(seed, symmetric):
+    rng = np.random.RandomState(9000 + seed)
+    o = {"spx.rt.nr_threads": str(rng.choice([1, 3, 8]))}
+    if rng.rand() < 0.5:
+        o["spx.preproc.sampling"] = "none"
+    if rng.rand() < 0.4:
+        o["spx.gpu.rowblock_elems"] = str(rng.choice([700, 2000, 8192]))
+    if rng.rand() < 0.3:
+        o["spx.gpu.rowblock_rows"] = str(rng.choice([64, 512, 1024, 2048]))
+    if symmetric:
+        o["spx.gpu.sym_segments"] = str(rng.choice(["true", "true", "false", "auto"]))
+        o["spx.gpu.sym_wide_rows"] = str(rng.choice([512, 1024, 2048]))
+        o["spx.gpu.sym_segment_min"] = str(rng.choice([2, 3, 5]))
+        if rng.rand() < 0.2:
+            o["spx.gpu.sym_spill"] = str(rng.choice(["lists", "atomic"]))
+        if rng.rand() < 0.1:
+            o["spx.gpu.deterministic"] = "true"
+    o["spx.gpu.waves"] = str(rng.choice([0, 2, 4, 8]))
+    return o
+
+
+bad = 0
+for seed in range(a0, b0):
+    sym = seed % 3 != 0
+    csr, m = big_matrix(seed, sym)
+    n = csr[3]
+    o = options(seed, sym)
+    try:
+        x = synth.random_x(n)
+        if host:
+            from stream_decode import Stream
+            A = tune(csr, o, sym=sym, host_only=True)
+            f = "/tmp/soak_large_%d.spx" % os.getpid()
+            A.save(f)
+            s = Stream(f)
+            s.check_ownership()
+            assert np.allclose(s.matvec(x), m @ x, rtol=1e-12, atol=1e-13), "decoded product"
+        else:
+            A = tune(csr, o, sym=sym)
+            y = np.full(n, np.nan)
+            A.matvec_mult(0.5, x, y)
+            check_y(csr, x, y, 0.5)
+            y0 = synth.random_x(n, seed=seed + 1)
+            y = y0.copy()
+            A.matvec_kernel(2.0, x, -0.5, y)
+            check_y(csr, x, y, 2.0, -0.5, y0)
+        A.destroy()
+        print("seed %d ok: n %d nnz %d sym %d %s" % (seed, n, m.nnz, sym, o), flush=True)
+    except Exception as e:
+        bad += 1
+        print("seed %d FAILED: %s %s n %d %s" % (seed, type(e).__name__, str(e)[:200], n, o), flush=True)
+print("seeds [%d, %d): %d failures" % (a0, b0, bad))
+sys.exit(1 if bad else 0)
