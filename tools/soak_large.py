@@ -1,7 +1,8 @@
 """Randomised parity on larger matrices (20 k - 300 k rows: many row-blocks, slot windows that
 overflow, wide row-blocks, x windows, 24-bit column offsets), on the GPU against CSR.
-usage: python tools/soak_large.py <first seed> <last seed> [--host]   (--host: tune host-only and
-check the decoded stream instead -- runs without a GPU)"""
+usage: python tools/soak_large.py <first seed> <last seed> [--host | --roundtrip]   (--host: tune host-only
+and check the decoded stream instead -- runs without a GPU; --roundtrip: also set entries, save, restore,
+multiply again)"""
 import os, sys
 import numpy as np, scipy.sparse as sp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -114,6 +115,29 @@ for seed in range(a0, b0):
             y = y0.copy()
             A.matvec_kernel(2.0, x, -0.5, y)
             check_y(csr, x, y, 2.0, -0.5, y0)
+            if "--roundtrip" in sys.argv:
+                # a few entries changed, saved, restored in place of the tuned matrix, multiplied again
+                import sparsex_amd as sx
+                rp, ci, va, _ = csr
+                va2 = va.copy()
+                rows = np.repeat(np.arange(n), np.diff(rp))
+                rng = np.random.RandomState(seed)
+                for j in rng.choice(rp[-1], size=20, replace=False):
+                    r, c = int(rows[j]), int(ci[j])
+                    A.set_entry(r, c, 2.5)
+                    va2[j] = 2.5
+                    if sym:
+                        va2[rp[c] + int(np.searchsorted(ci[rp[c]:rp[c + 1]], r))] = 2.5
+                f = "/tmp/soak_large_%d.spx" % os.getpid()
+                A.save(f)
+                A.destroy()
+                sx.options_reset()
+                A = sx.mat_restore(f)
+                y = np.full(n, np.nan)
+                A.matvec_mult(0.5, x, y)
+                check_y((rp, ci, va2, n), x, y, 0.5)
+                for j in rng.choice(rp[-1], size=20, replace=False):
+                    assert A.get_entry(int(rows[j]), int(ci[j])) == va2[j]
         A.destroy()
         print("seed %d ok: n %d nnz %d sym %d %s" % (seed, n, m.nnz, sym, o), flush=True)
     except Exception as e:
