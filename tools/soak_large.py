@@ -2,7 +2,8 @@
 overflow, wide row-blocks, x windows, 24-bit column offsets), on the GPU against CSR.
 usage: python tools/soak_large.py <first seed> <last seed> [--host | --roundtrip]   (--host: tune host-only
 and check the decoded stream instead -- runs without a GPU; --roundtrip: also set entries, save, restore,
-multiply again)"""
+multiply again; SOAK_SIZES=1000000,3000000 for matrices big enough for the size-dependent choices,
+e.g. read-once segments in "auto")"""
 import os, sys
 import numpy as np, scipy.sparse as sp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,7 +17,7 @@ a0, b0 = int(sys.argv[1]), int(sys.argv[2])
 
 def big_matrix(seed, symmetric):
     rng = np.random.RandomState(7000 + seed)
-    n = int(rng.choice([20000, 50000, 120000, 300000]))
+    n = int(rng.choice([int(v) for v in os.environ.get("SOAK_SIZES", "20000,50000,120000,300000").split(",")]))
     rows, cols = [np.arange(n)], [np.arange(n)]
     for _ in range(rng.randint(2, 6)):
         kind = rng.randint(0, 6)
