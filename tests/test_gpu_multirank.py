@@ -39,11 +39,13 @@ def run_bench(world, extra, port):
     ("nlpkkt", ["--edge", "28"], False),
     ("nlpkkt-sym", ["--edge", "28", "--symmetric"], False),
     ("nlpkkt-sym-segments", ["--edge", "28", "--symmetric", "--opt", "spx.gpu.sym_segments=true"], False),
+    # big enough per rank (>= 16 M nonzeros in its triangle) for the library to choose the segments itself
+    ("nlpkkt-sym-auto", ["--edge", "100", "--symmetric", "--host-threads", "16"], False),
     ("nd24k-sym", ["--workload", "syn-nd24k", "--scale", "0.15", "--symmetric"], True),
     ("nd24k-sym-atomic", ["--workload", "syn-nd24k", "--scale", "0.15", "--symmetric",
                           "--opt", "spx.gpu.sym_spill=atomic"], True),
     ("webbase", ["--workload", "syn-webbase", "--scale", "0.1"], False),
-], ids=["nlpkkt", "nlpkkt-sym", "nlpkkt-sym-segments", "nd24k-sym", "nd24k-sym-atomic", "webbase"])
+], ids=["nlpkkt", "nlpkkt-sym", "nlpkkt-sym-segments", "nlpkkt-sym-auto", "nd24k-sym", "nd24k-sym-atomic", "webbase"])
 def test_ranks_share_one_gpu(world, name, extra, tiles):
     out = run_bench(world, extra, 29700 + 10 * world + len(name))
     assert out["n_gpus"] == world and out["scaling"] == "strong" and out["value"] > 0
@@ -55,6 +57,8 @@ def test_ranks_share_one_gpu(world, name, extra, tiles):
     assert all(ranks[i]["rows"][1] == ranks[i + 1]["rows"][0] for i in range(world - 1))
     assert sum(r["nnz"] for r in ranks) == out["config"]["nnz"]
     assert max(r["nnz"] for r in ranks) < 1.5 * min(r["nnz"] for r in ranks)
+    if name in ("nlpkkt-sym-segments", "nlpkkt-sym-auto"):
+        assert "symseg" in out["roofline"]["kernel"]
     sym = out["config"]["symmetric_path"]
     sent = [r["conflict_rows_sent"] for r in ranks]
     if sym:
