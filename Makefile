@@ -26,10 +26,10 @@ all: lib oracle
 
 lib: $(LIB) $(SYNLIB)
 
-# input generator of the nlpkkt stand-in (bench/test data only, no SpMV code)
-$(SYNLIB): tools/synth/nlpkkt_gen.c
+# input generators of the nlpkkt stand-in and of syn-kkt2f (bench/test data only, no SpMV code)
+$(SYNLIB): tools/synth/nlpkkt_gen.c tools/synth/kkt2f_gen.c
 	@mkdir -p $(LIBDIR)
-	$(CC) -O3 -shared -fPIC -o $@ $< -lm
+	$(CC) -O3 -shared -fPIC -o $@ $^ -lm
 
 $(OBJDIR)/%.o: $(CSRC)/%.cpp $(wildcard $(CSRC)/*.hpp) $(wildcard $(CSRC)/*.h) \
                $(wildcard include/sparsex/*.h) include/sparsex_hip.h

@@ -43,8 +43,10 @@ MALL_BYTES = 256 << 20  # Infinity Cache
 ALPHA = 0.5
 BATCHES = 5             # OUTER_LOOPS of the reference harness
 REF_BASELINE_THREADS = [8, 16, 32, 64]   # the counts cpu_baseline() may try
-DEFAULT_EDGE = 190      # syn-nlpkkt grid edge: 13.9 M rows, 734 M nonzeros (nlpkkt240: 760 M), 5.9 GB of values
-SAMPLE_EDGE = 60        # its CPU-baseline sample: the same generator at 1/8 of the nonzeros
+DEFAULT_EDGE = 240      # syn-nlpkkt grid edge = nlpkkt240's: 27 993 600 rows, 769 M nonzeros (nlpkkt240: 760.6 M), 6.2 GB of values
+SAMPLE_EDGE = 150       # its CPU-baseline sample: the same generator at 1/4 of the nonzeros (187 M, 1.5 GB of values:
+                        # three times the 2 x 256 MB of L3 of the GPU box's host)
+SLICED = {"syn-nlpkkt": "nlpkkt", "syn-kkt2f": "kkt2f"}     # workloads with a row-sliced generator (sparsex_amd/synth.py)
 
 
 # ---- workloads -----------------------------------------------------------------------------
@@ -100,7 +102,7 @@ class Workload:
     def __init__(self, args, rank, world):
         from sparsex_amd import synth
         self.name = args.workload
-        if args.mtx or args.workload != "syn-nlpkkt":
+        if args.mtx or args.workload not in SLICED:
             rp, ci, va, n = make_workload(args.workload, args.scale, mtx=args.mtx)
             counts = np.diff(rp)
             cuts = nnz_balanced_cuts(counts, world)
@@ -110,15 +112,24 @@ class Workload:
             self.label = (os.path.basename(args.mtx) if args.mtx else
                           "%s (stand-in for SuiteSparse %s)" % (args.workload, args.workload.replace("syn-", "")))
         else:
-            # every rank generates only its rows (tools/synth/nlpkkt_gen.c)
+            # every rank generates only its rows (tools/synth/nlpkkt_gen.c, kkt2f_gen.c)
             self.edge = args.edge
-            counts = synth.nlpkkt_row_counts(args.edge)
+            gen = SLICED[args.workload]
+            counts = synth._row_counts(gen, args.edge)
             n = counts.size
             cuts = nnz_balanced_cuts(counts, world)
             lo, hi = cuts[rank], cuts[rank + 1]
-            self.rp, self.ci, self.va, _ = synth.syn_nlpkkt_rows(args.edge, lo, hi, counts=counts)
-            self.label = ("syn-nlpkkt, grid edge %d (stand-in for SuiteSparse nlpkkt240, which is edge 240: "
-                          "same KKT stencil structure, %.1f M rows)" % (args.edge, n / 1e6))
+            self.rp, self.ci, self.va, _ = synth._rows(gen, args.edge, lo, hi, counts, synth.SEED_BASE + 4)
+            if gen == "nlpkkt":
+                self.label = ("syn-nlpkkt, grid edge %d: the stand-in SURVEY section 8(d) specifies for SuiteSparse "
+                              "nlpkkt240 (order 2N^3+6N^2 = %.2f M rows%s, KKT blocks [H A^T; A D] with 27-point "
+                              "stencils, %.2f nonzeros per row in runs of three columns; nlpkkt240: 27.99 M rows, "
+                              "760.6 M nonzeros, 27.17 per row)" % (
+                                  args.edge, n / 1e6, " = nlpkkt240's" if args.edge == 240 else "",
+                                  float(counts.sum(dtype=np.int64)) / n))
+            else:
+                self.label = ("syn-kkt2f, grid edge %d (rounds 1-2's matrix: two fully coupled fields, 54 nonzeros per "
+                              "row in runs of six columns; NOT the nlpkkt stand-in, kept for comparison)" % args.edge)
         self.n, self.lo, self.hi, self.cuts = int(n), int(lo), int(hi), cuts
         self.nnz = int(counts.sum(dtype=np.int64))
         self.nnz_local = int(self.rp[-1])
@@ -515,10 +526,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128, help="SpMVs per batch (LOOPS); %d batches are timed" % BATCHES)
     ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--workload", default="syn-nlpkkt", choices=["syn-cant", "syn-nd24k", "syn-webbase", "syn-nlpkkt", "syn-bandrandom"])
+    ap.add_argument("--workload", default="syn-nlpkkt", choices=["syn-cant", "syn-nd24k", "syn-webbase", "syn-nlpkkt", "syn-kkt2f", "syn-bandrandom"])
     ap.add_argument("--edge", type=int, default=DEFAULT_EDGE,
-                    help="syn-nlpkkt: grid edge (240 = the order of nlpkkt240; the default %d gives 734 M "
-                         "nonzeros, 5.9 GB of values)" % DEFAULT_EDGE)
+                    help="syn-nlpkkt / syn-kkt2f: grid edge (default %d = the order of nlpkkt240: 769 M "
+                         "nonzeros, 6.2 GB of values)" % DEFAULT_EDGE)
     ap.add_argument("--scale", type=float, default=1.0, help="size factor of the other synthetic workloads")
     ap.add_argument("--mtx", default=None,
                     help="Matrix Market file to use instead of the synthetic stand-in")
@@ -720,7 +731,7 @@ def main():
         b_alg = algorithmic_bytes(args.symmetric, wl.nnz_local, rows_local, n, lower_local)
         launch_s = devs / args.steps
         achieved = b_alg / launch_s / 1e9
-        tkey = "%s%s%s" % (args.workload, "-e%d" % args.edge if args.workload == "syn-nlpkkt" else "",
+        tkey = "%s%s%s" % (args.workload, "-e%d" % args.edge if args.workload in SLICED else "",
                            "-sym" if args.symmetric else "")
         std = world == 1 and args.scale == 1.0 and not args.opt and not args.mtx
         if not args.symmetric:

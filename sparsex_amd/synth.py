@@ -100,8 +100,44 @@ def syn_webbase(scale=1.0, seed=SEED_BASE + 3):
 
 
 def syn_nlpkkt(N=12, seed=SEED_BASE + 4):
-    """KKT system [H A^T; A D] from 27-point stencils on an N^3 grid
-    (nlpkkt240 is N=240: 27 993 600 rows, ~760M nnz; tests use small N)."""
+    """The nlpkkt stand-in of SURVEY.md section 8(d): KKT system [H A^T; A D] of order
+    2 N^3 + 6 N^2 -- N^3 states, 6 N^2 boundary controls, N^3 multipliers; H and D
+    diagonal, A = [27-point stencil of the grid | one entry per boundary face] -- about
+    27 nonzeros per row in runs of three consecutive columns, symmetric, full diagonal
+    (nlpkkt240 is N = 240: 27 993 600 rows, ~760 M nonzeros; tests use small N).  The
+    pattern is that of tools/synth/nlpkkt_gen.c (syn_nlpkkt_rows)."""
+    rng = np.random.RandomState(seed & 0x7FFFFFFF)
+    N3, N2 = N ** 3, N ** 2
+    P = N3 + 6 * N2
+    n = P + N3
+    idx = np.arange(N3)
+    z, y, x = idx // N2, (idx // N) % N, idx % N
+    rows, cols = [np.arange(n)], [np.arange(n)]
+    for dz in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                zz, yy, xx = z + dz, y + dy, x + dx
+                ok = (zz >= 0) & (zz < N) & (yy >= 0) & (yy < N) & (xx >= 0) & (xx < N)
+                rows.append(P + idx[ok])                       # A_y: multiplier row, state column
+                cols.append((zz * N2 + yy * N + xx)[ok])
+    a, b = np.meshgrid(np.arange(N), np.arange(N), indexing="ij")
+    a, b = a.ravel(), b.ravel()
+    cells = [a * N + b, (N - 1) * N2 + a * N + b, a * N2 + b, a * N2 + (N - 1) * N + b,
+             a * N2 + b * N, a * N2 + b * N + (N - 1)]
+    for q, cell in enumerate(cells):                           # A_u: one entry per face
+        rows.append(P + cell)
+        cols.append(N3 + q * N2 + np.arange(N2))
+    r = np.concatenate(rows)
+    c = np.concatenate(cols)
+    r, c = np.concatenate([r, c]), np.concatenate([c, r])     # + A^T
+    return _finish(r, c, n, rng, symmetric=True)
+
+
+def syn_kkt2f(N=12, seed=SEED_BASE + 4):
+    """Two fully coupled interleaved fields on an N^3 grid with 27-point stencils plus
+    6 N^2 constraint rows: 54 nonzeros per row in runs of six consecutive columns.
+    (Rounds 1-2 used this as their nlpkkt stand-in; it is twice as dense per row as
+    nlpkkt240 and kept for comparison only.)"""
     rng = np.random.RandomState(seed & 0x7FFFFFFF)
     n1 = 2 * N ** 3
     n2 = 6 * N ** 2 if N >= 3 else 0
@@ -160,34 +196,75 @@ _SYNLIB = None
 
 
 def _synlib():
-    """libspxsynth.so (tools/synth/nlpkkt_gen.c, built by `make lib`): the
-    row-sliced generator of the nlpkkt stand-in."""
+    """libspxsynth.so (tools/synth/nlpkkt_gen.c and kkt2f_gen.c, built by `make lib`):
+    the row-sliced generators of the nlpkkt stand-in and of syn-kkt2f."""
     global _SYNLIB
     if _SYNLIB is None:
         import ctypes as C
         import os
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libspxsynth.so")
         L = C.CDLL(path)
-        L.spx_syn_nlpkkt_nrows.restype = C.c_int64
-        L.spx_syn_nlpkkt_nrows.argtypes = [C.c_int]
-        L.spx_syn_nlpkkt_counts.restype = None
-        L.spx_syn_nlpkkt_counts.argtypes = [C.c_int, C.c_void_p]
-        L.spx_syn_nlpkkt_rows.restype = C.c_int64
-        L.spx_syn_nlpkkt_rows.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_uint64, C.c_void_p,
-                                          C.c_void_p, C.c_void_p]
+        for g in ("nlpkkt", "kkt2f"):
+            f = getattr(L, "spx_syn_%s_nrows" % g)
+            f.restype, f.argtypes = C.c_int64, [C.c_int]
+            f = getattr(L, "spx_syn_%s_counts" % g)
+            f.restype, f.argtypes = None, [C.c_int, C.c_void_p]
+            f = getattr(L, "spx_syn_%s_rows" % g)
+            f.restype = C.c_int64
+            f.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
         _SYNLIB = L
     return _SYNLIB
 
 
+def _nrows(gen, N):
+    return int(getattr(_synlib(), "spx_syn_%s_nrows" % gen)(int(N)))
+
+
+def _row_counts(gen, N):
+    cnt = np.empty(_nrows(gen, N), dtype=np.int32)
+    getattr(_synlib(), "spx_syn_%s_counts" % gen)(int(N), cnt.ctypes.data)
+    return cnt
+
+
+def _rows(gen, N, lo, hi, counts, seed):
+    n = _nrows(gen, N)
+    hi = n if hi is None else hi
+    if counts is None:
+        counts = _row_counts(gen, N)
+    rp = np.zeros(hi - lo + 1, dtype=np.int64)
+    np.cumsum(counts[lo:hi], dtype=np.int64, out=rp[1:])
+    nnz = int(rp[-1])
+    assert nnz < 2 ** 31, "slice too large for 32-bit row pointers"
+    ci = np.empty(nnz, dtype=np.int32)
+    va = np.empty(nnz, dtype=np.float64)
+    fn = getattr(_synlib(), "spx_syn_%s_rows" % gen)
+    # large slices: row ranges of equal nonzero counts on a few threads (the C call drops the GIL)
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    T = max(1, min(len(os.sched_getaffinity(0)), 32, nnz >> 22))
+    cuts = [int(np.searchsorted(rp, nnz * t // T, side="left")) for t in range(T)] + [hi - lo]
+
+    def piece(t):
+        a, b = cuts[t], cuts[t + 1]
+        if b <= a:
+            return 0
+        rpl = np.empty(b - a + 1, dtype=np.int64)
+        k0 = int(rp[a])
+        return fn(int(N), int(lo + a), int(lo + b), int(seed), rpl.ctypes.data,
+                  ci.ctypes.data + 4 * k0, va.ctypes.data + 8 * k0)
+    with ThreadPoolExecutor(T) as ex:
+        got = sum(ex.map(piece, range(T)))
+    assert got == nnz
+    return rp.astype(np.int32), ci, va, n
+
+
 def nlpkkt_nrows(N):
-    return int(_synlib().spx_syn_nlpkkt_nrows(int(N)))
+    return _nrows("nlpkkt", N)
 
 
 def nlpkkt_row_counts(N):
     """Nonzeros of every row of syn_nlpkkt_rows(N) (int32, all rows)."""
-    cnt = np.empty(nlpkkt_nrows(N), dtype=np.int32)
-    _synlib().spx_syn_nlpkkt_counts(int(N), cnt.ctypes.data)
-    return cnt
+    return _row_counts("nlpkkt", N)
 
 
 def syn_nlpkkt_rows(N, lo=0, hi=None, counts=None, seed=SEED_BASE + 4):
@@ -196,19 +273,20 @@ def syn_nlpkkt_rows(N, lo=0, hi=None, counts=None, seed=SEED_BASE + 4):
     the rows it owns (values: symmetric hash of the coordinate pair, diagonal
     dominant).  Returns (rowptr int32 relative to the slice, colind int32,
     values float64, n) with n the order of the WHOLE matrix."""
-    n = nlpkkt_nrows(N)
-    hi = n if hi is None else hi
-    if counts is None:
-        counts = nlpkkt_row_counts(N)
-    nnz = int(counts[lo:hi].sum(dtype=np.int64))
-    assert nnz < 2 ** 31, "slice too large for 32-bit row pointers"
-    rp = np.zeros(hi - lo + 1, dtype=np.int64)
-    ci = np.zeros(nnz, dtype=np.int32)
-    va = np.zeros(nnz, dtype=np.float64)
-    got = _synlib().spx_syn_nlpkkt_rows(int(N), int(lo), int(hi), int(seed), rp.ctypes.data,
-                                        ci.ctypes.data, va.ctypes.data)
-    assert got == nnz
-    return rp.astype(np.int32), ci, va, n
+    return _rows("nlpkkt", N, lo, hi, counts, seed)
+
+
+def kkt2f_nrows(N):
+    return _nrows("kkt2f", N)
+
+
+def kkt2f_row_counts(N):
+    return _row_counts("kkt2f", N)
+
+
+def syn_kkt2f_rows(N, lo=0, hi=None, counts=None, seed=SEED_BASE + 4):
+    """Rows [lo, hi) of syn-kkt2f (the pattern of syn_kkt2f(N)), generated in C."""
+    return _rows("kkt2f", N, lo, hi, counts, seed)
 
 
 def nlpkkt_edge(scale):
@@ -217,10 +295,9 @@ def nlpkkt_edge(scale):
 
 
 def syn_nlpkkt_scaled(scale=1.0):
-    """syn_nlpkkt with the grid edge derived from a size factor: scale 1 is
-    nlpkkt240 itself (N = 240, ~760 M nonzeros); the default single-GPU stand-in
-    uses scale = 1/64 (N = 60, ~22.7 M nonzeros)."""
-    return syn_nlpkkt(max(3, int(round(240.0 * scale ** (1.0 / 3.0)))))
+    """syn_nlpkkt_rows with the grid edge derived from a size factor: scale 1 is the
+    order of nlpkkt240 itself (N = 240, 769 M nonzeros)."""
+    return syn_nlpkkt_rows(nlpkkt_edge(scale))
 
 
 WORKLOADS = {
@@ -228,5 +305,6 @@ WORKLOADS = {
     "syn-nd24k": syn_nd24k,
     "syn-webbase": syn_webbase,
     "syn-nlpkkt": syn_nlpkkt_scaled,
+    "syn-kkt2f": lambda scale=1.0: syn_kkt2f_rows(nlpkkt_edge(scale)),
     "syn-bandrandom": lambda scale=1.0: syn_bandrandom(max(2000, int(200000 * scale))),
 }

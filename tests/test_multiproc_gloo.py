@@ -86,6 +86,8 @@ def _slice_worker(rank, world, port, symmetric, gen, tmpdir, ret):
     try:
         if gen == "nlpkkt":
             rp, ci, va, n = synth.syn_nlpkkt_rows(9)
+        elif gen == "kkt2f":
+            rp, ci, va, n = synth.syn_kkt2f_rows(9)
         else:
             rp, ci, va, n = synth.syn_nd24k(0.02)
         a = sp.csr_matrix((va, ci, rp), shape=(n, n))
@@ -134,15 +136,19 @@ def _slice_worker(rank, world, port, symmetric, gen, tmpdir, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("gen", ["nlpkkt", "nd24k"])
+@pytest.mark.parametrize("gen", ["nlpkkt", "kkt2f", "nd24k"])
 @pytest.mark.parametrize("symmetric", [False, True])
 @pytest.mark.parametrize("world", [2, 3])
 def test_row_slices_exchange_plan_gloo(tmp_path, world, symmetric, gen):
-    port = 29850 + (os.getpid() % 100) + 7 * world + (3 if symmetric else 0) + (40 if gen == "nd24k" else 0)
+    port = 29850 + (os.getpid() % 100) + 7 * world + (3 if symmetric else 0) + {"nlpkkt": 0, "kkt2f": 80, "nd24k": 40}[gen]
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_slice_worker, args=(world, port, symmetric, gen, str(tmp_path), ret), nprocs=world, join=True)
     assert all(ret[r][0] for r in range(world))
     if symmetric:
         # rank 0 sends nothing; the others send far less than an n-long all-reduce would move
-        assert ret[0][1] == 0 and all(0 < ret[r][1] < ret[r][2] // 2 for r in range(1, world))
+        # (banded matrices.  In the KKT layout of syn-nlpkkt the stored triangle is the multiplier
+        # rows, whose mirror image lands on the state rows -- a band of THAT block, owned by the
+        # first ranks: still never more than the rows in front of the sender)
+        limit = (lambda r: ret[r][2]) if gen == "nlpkkt" else (lambda r: ret[r][2] // 2)
+        assert ret[0][1] == 0 and all(0 < ret[r][1] < limit(r) for r in range(1, world))

@@ -237,11 +237,12 @@ def _scattered_sym(n=6000, per_row=9, seed=23):
 @pytest.mark.parametrize("mode", ["true", "false", "auto"])
 @pytest.mark.parametrize("name,gen,auto_on", [
     # (auto: only beyond 16 M nonzeros in the triangle -- tests/test_gpu_fullsize.py has such a case)
-    ("nlpkkt", lambda: synth.syn_nlpkkt_rows(10), False),     # stencil rows: runs of four and six columns
+    ("kkt2f", lambda: synth.syn_kkt2f_rows(10), False),      # stencil rows: runs of four and six columns
+    ("nlpkkt", lambda: synth.syn_nlpkkt_rows(10), False),    # KKT blocks: the triangle is the multiplier rows, runs of three
     ("cant", lambda: synth.syn_cant(0.05), False),
     ("nd24k", lambda: synth.syn_nd24k(0.02), False),          # dense tiles take the triangle first
     ("scattered", lambda: _scattered_sym(), False),           # hardly any runs
-], ids=["nlpkkt", "cant", "nd24k", "scattered"])
+], ids=["kkt2f", "nlpkkt", "cant", "nd24k", "scattered"])
 def test_symmetric_row_segments_are_stored_once(tmp_path, name, gen, auto_on, mode, threads):
     """spx.gpu.sym_segments: runs of >= 3 consecutive columns of the lower triangle become
     SPX_PASS_SYMSEG passes -- stored once, the lane forms the row sum AND hands value * x[row]
@@ -292,7 +293,7 @@ def test_symmetric_row_segments_are_stored_once(tmp_path, name, gen, auto_on, mo
 @pytest.mark.parametrize("min_run", ["2", "3", "5"])
 def test_shortest_read_once_run(tmp_path, min_run):
     """spx.gpu.sym_segment_min: shorter runs of the lower triangle stay on the mirrored path."""
-    csr = synth.syn_nlpkkt_rows(12)
+    csr = synth.syn_kkt2f_rows(12)
     rp, ci, va, n = csr
     A = tune(csr, {"spx.gpu.sym_segments": "true", "spx.gpu.sym_segment_min": min_run, "spx.rt.nr_threads": "2"},
              sym=True, host_only=True)
@@ -341,7 +342,7 @@ def test_slot_groups_stay_inside_the_matrix(tmp_path):
 def test_wide_rowblocks_share_their_slots(tmp_path, wide):
     """spx.gpu.sym_wide_rows: consecutive row-blocks with read-once segments go side by side into
     one (one y tile, one set of slots); their passes carry the first row of their part."""
-    csr = synth.syn_nlpkkt_rows(24)
+    csr = synth.syn_kkt2f_rows(24)
     rp, ci, va, n = csr
     va = va.copy()
     A = tune((rp, ci, va, n), {"spx.gpu.sym_segments": "true", "spx.gpu.sym_wide_rows": wide, "spx.rt.nr_threads": "2"},

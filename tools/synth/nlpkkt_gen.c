@@ -2,13 +2,31 @@
  * nlpkkt_gen.c -- row-sliced generator of the syn-nlpkkt stand-in (bench/test
  * INPUT generation only; nothing here takes part in the SpMV).
  *
- * Same pattern as sparsex_amd/synth.py::syn_nlpkkt (KKT layout [H A^T; A D] of
- * two interleaved fields on an N^3 grid with 27-point stencils plus 6*N^2
- * constraint rows), but produced row by row, so that a process can generate
- * just the rows it owns of a matrix that would not fit a Python/scipy pass
- * (nlpkkt240 scale).  Values are a symmetric hash of (min(r,c), max(r,c)) in
- * U(-1,1); the diagonal is 1 + the row's absolute off-diagonal sum, like the
- * scipy generator's.
+ * order n = 2*N^3 + 6*N^2 (N = 240: 27 993 600, the order
+ * of SuiteSparse nlpkkt240), KKT layout [H A^T; A D] with 27-point stencils,
+ * about 27 nonzeros per row, symmetric with a full diagonal.  The unknowns are
+ *
+ *     [0, N^3)                 state, one per grid point       (primal)
+ *     [N^3, N^3 + 6 N^2)       boundary control, one per face  (primal)
+ *     [P, P + N^3)             multipliers, one per grid point (dual), P = N^3 + 6 N^2
+ *
+ * and the blocks
+ *     H  (P x P)     diagonal
+ *     A  (N^3 x P)   = [A_y | A_u]: A_y the 27-point stencil of the grid (row s holds
+ *                      the columns of the up to 27 neighbours of grid point s, i.e.
+ *                      nine runs of three consecutive columns), A_u one entry per
+ *                      face: the constraint of the grid point the face belongs to
+ *     D  (N^3 x N^3) diagonal
+ * so that a state row holds its diagonal and 27 entries of A^T, a multiplier row 27
+ * entries of A, its faces and its diagonal: 2*(3N-2)^3 + 12*N^2 + n nonzeros
+ * (N = 240: 768 977 264, 27.47 per row; nlpkkt240 itself: 760.6 M, 27.17 per row).
+ *
+ * Values are a symmetric hash of (min(r,c), max(r,c)) in U(-1,1); the diagonal is
+ * 1 + the row's absolute off-diagonal sum.  The same pattern comes out of
+ * sparsex_amd/synth.py::syn_nlpkkt (scipy, small N); this file produces it row by
+ * row, so that a process can generate just the rows it owns of a matrix that would
+ * not fit a scipy pass.  Rounds 1-2 used a different matrix under this name (two
+ * fully coupled interleaved fields, 54 nonzeros per row): now tools/synth/kkt2f_gen.c.
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -30,62 +48,90 @@ static inline double pair_value(uint64_t seed, int64_t r, int64_t c, int64_t n)
     return (double) (h >> 11) * (2.0 / 9007199254740992.0) - 1.0;   /* U(-1, 1) */
 }
 
-typedef struct {
-    int64_t N, n1, n2, n;
-    int64_t *ext_ptr;      /* per H row: extra columns (constraint couplings)  */
-    int32_t *ext_col;
-} Gen;
+typedef struct { int64_t N, N2, N3, P, n; } Kkt;
 
-static void gen_init(Gen *g, int N)
+static void kkt_init(Kkt *g, int N)
 {
     g->N = N;
-    g->n1 = 2 * (int64_t) N * N * N;
-    g->n2 = N >= 3 ? 6 * (int64_t) N * N : 0;
-    g->n = g->n1 + g->n2;
-    g->ext_ptr = (int64_t *) calloc((size_t) g->n1 + 2, sizeof(int64_t));
-    g->ext_col = (int32_t *) malloc(sizeof(int32_t) * (size_t) (2 * g->n2 + 1));
-    for (int64_t f = 0; f < g->n2; ++f) {
-        const int64_t t = (f * 7919) % g->n1, t1 = (t + 1) % g->n1;
-        ++g->ext_ptr[t + 2];
-        ++g->ext_ptr[t1 + 2];
-    }
-    for (int64_t r = 0; r < g->n1; ++r) g->ext_ptr[r + 2] += g->ext_ptr[r + 1];
-    /* ext_ptr[r+1] is now the fill cursor of row r */
-    for (int64_t f = 0; f < g->n2; ++f) {
-        const int64_t t = (f * 7919) % g->n1, t1 = (t + 1) % g->n1;
-        g->ext_col[g->ext_ptr[t + 1]++] = (int32_t) (g->n1 + f);
-        g->ext_col[g->ext_ptr[t1 + 1]++] = (int32_t) (g->n1 + f);
-    }
+    g->N2 = (int64_t) N * N;
+    g->N3 = g->N2 * N;
+    g->P = g->N3 + 6 * g->N2;
+    g->n = g->P + g->N3;
 }
 
-static void gen_free(Gen *g)
+static inline int stencil_count(const Kkt *g, int64_t s)
 {
-    free(g->ext_ptr);
-    free(g->ext_col);
-}
-
-static inline int stencil_count(int64_t N, int64_t s)
-{
-    const int64_t z = s / (N * N), y = (s / N) % N, x = s % N;
+    const int64_t N = g->N, z = s / g->N2, y = (s / N) % N, x = s % N;
     const int cz = 1 + (z > 0) + (z < N - 1), cy = 1 + (y > 0) + (y < N - 1),
               cx = 1 + (x > 0) + (x < N - 1);
     return cz * cy * cx;
 }
 
-/* nnz of every row of the matrix */
-void spx_syn_nlpkkt_counts(int N, int32_t *counts)
+/* the faces grid point s belongs to, ascending; returns their number */
+static inline int faces_of(const Kkt *g, int64_t s, int64_t *f)
 {
-    Gen g;
-    gen_init(&g, N);
-    for (int64_t r = 0; r < g.n1; ++r)
-        counts[r] = 2 * stencil_count(g.N, r >> 1) + (int32_t) (g.ext_ptr[r + 1] - g.ext_ptr[r]);
-    for (int64_t f = 0; f < g.n2; ++f) counts[g.n1 + f] = 3;
-    gen_free(&g);
+    const int64_t N = g->N, z = s / g->N2, y = (s / N) % N, x = s % N;
+    int k = 0;
+    if (z == 0) f[k++] = y * N + x;
+    if (z == N - 1) f[k++] = g->N2 + y * N + x;
+    if (y == 0) f[k++] = 2 * g->N2 + z * N + x;
+    if (y == N - 1) f[k++] = 3 * g->N2 + z * N + x;
+    if (x == 0) f[k++] = 4 * g->N2 + z * N + y;
+    if (x == N - 1) f[k++] = 5 * g->N2 + z * N + y;
+    return k;
+}
+
+/* the grid point face f belongs to */
+static inline int64_t cell_of(const Kkt *g, int64_t f)
+{
+    const int64_t N = g->N, q = f / g->N2, a = (f % g->N2) / N, b = f % N;
+    switch (q) {
+    case 0: return a * N + b;
+    case 1: return (N - 1) * g->N2 + a * N + b;
+    case 2: return a * g->N2 + b;
+    case 3: return a * g->N2 + (N - 1) * N + b;
+    case 4: return a * g->N2 + b * N;
+    default: return a * g->N2 + b * N + (N - 1);
+    }
 }
 
 int64_t spx_syn_nlpkkt_nrows(int N)
 {
-    return 2 * (int64_t) N * N * N + (N >= 3 ? 6 * (int64_t) N * N : 0);
+    Kkt g;
+    kkt_init(&g, N);
+    return g.n;
+}
+
+/* nnz of every row of the matrix */
+void spx_syn_nlpkkt_counts(int N, int32_t *counts)
+{
+    Kkt g;
+    int64_t f[6];
+    kkt_init(&g, N);
+    for (int64_t s = 0; s < g.N3; ++s) {
+        const int c = stencil_count(&g, s);
+        counts[s] = 1 + c;
+        counts[g.P + s] = c + faces_of(&g, s, f) + 1;
+    }
+    for (int64_t k = 0; k < 6 * g.N2; ++k) counts[g.N3 + k] = 2;
+}
+
+/* the up to 27 neighbours of grid point s, ascending, each added to `base` */
+static inline int64_t stencil_cols(const Kkt *g, int64_t s, int64_t base, int32_t *col)
+{
+    const int64_t N = g->N, z = s / g->N2, y = (s / N) % N, x = s % N;
+    int64_t k = 0;
+    for (int dz = -1; dz <= 1; ++dz) {
+        if (z + dz < 0 || z + dz >= N) continue;
+        for (int dy = -1; dy <= 1; ++dy) {
+            if (y + dy < 0 || y + dy >= N) continue;
+            for (int dx = -1; dx <= 1; ++dx) {
+                if (x + dx < 0 || x + dx >= N) continue;
+                col[k++] = (int32_t) (base + (z + dz) * g->N2 + (y + dy) * N + (x + dx));
+            }
+        }
+    }
+    return k;
 }
 
 /* rows [lo, hi): colind/values in CSR order (columns ascending), rowptr relative
@@ -93,45 +139,37 @@ int64_t spx_syn_nlpkkt_nrows(int N)
 int64_t spx_syn_nlpkkt_rows(int N, int64_t lo, int64_t hi, uint64_t seed, int64_t *rowptr,
                             int32_t *colind, double *values)
 {
-    Gen g;
-    gen_init(&g, N);
-    int64_t k = 0;
+    Kkt g;
+    kkt_init(&g, N);
+    int64_t k = 0, f[6];
     rowptr[0] = 0;
     for (int64_t r = lo; r < hi; ++r) {
         const int64_t k0 = k;
-        int64_t kd = -1;
-        if (r < g.n1) {
-            const int64_t s = r >> 1;
-            const int64_t z = s / (g.N * g.N), y = (s / g.N) % g.N, x = s % g.N;
-            for (int dz = -1; dz <= 1; ++dz) {
-                if (z + dz < 0 || z + dz >= g.N) continue;
-                for (int dy = -1; dy <= 1; ++dy) {
-                    if (y + dy < 0 || y + dy >= g.N) continue;
-                    for (int dx = -1; dx <= 1; ++dx) {
-                        if (x + dx < 0 || x + dx >= g.N) continue;
-                        const int64_t d = (z + dz) * g.N * g.N + (y + dy) * g.N + (x + dx);
-                        colind[k++] = (int32_t) (2 * d);
-                        colind[k++] = (int32_t) (2 * d + 1);
-                    }
-                }
-            }
-            for (int64_t e = g.ext_ptr[r]; e < g.ext_ptr[r + 1]; ++e) colind[k++] = g.ext_col[e];
-        } else {
-            const int64_t f = r - g.n1;
-            const int64_t t = (f * 7919) % g.n1, t1 = (t + 1) % g.n1;
-            colind[k++] = (int32_t) (t < t1 ? t : t1);
-            colind[k++] = (int32_t) (t < t1 ? t1 : t);
+        int64_t kd;
+        if (r < g.N3) {                       /* state: diagonal, then A_y^T            */
+            kd = k;
+            colind[k++] = (int32_t) r;
+            k += stencil_cols(&g, r, g.P, colind + k);
+        } else if (r < g.P) {                 /* control: diagonal, then A_u^T          */
+            kd = k;
+            colind[k++] = (int32_t) r;
+            colind[k++] = (int32_t) (g.P + cell_of(&g, r - g.N3));
+        } else {                              /* multiplier: A_y, A_u, diagonal         */
+            const int64_t s = r - g.P;
+            k += stencil_cols(&g, s, 0, colind + k);
+            const int nf = faces_of(&g, s, f);
+            for (int i = 0; i < nf; ++i) colind[k++] = (int32_t) (g.N3 + f[i]);
+            kd = k;
             colind[k++] = (int32_t) r;
         }
         double sum = 0.0;
         for (int64_t e = k0; e < k; ++e) {
-            if (colind[e] == r) { kd = e; continue; }
+            if (e == kd) continue;
             values[e] = pair_value(seed, r, colind[e], g.n);
             sum += fabs(values[e]);
         }
         values[kd] = sum + 1.0;
         rowptr[r - lo + 1] = k;
     }
-    gen_free(&g);
     return k;
 }
