@@ -96,20 +96,49 @@ def nnz_balanced_cuts(counts, world):
     return cuts + [int(counts.size)]
 
 
-class Workload:
-    """The rows [lo, hi) this rank owns of the global n x n matrix."""
+def stored_counts_csr(rp, ci, row0=0):
+    """Per row of a CSR slice starting at global row `row0`: entries on and below the diagonal."""
+    n = rp.size - 1
+    out = np.zeros(n, dtype=np.int64)
+    for r0 in range(0, n, 1 << 20):
+        r1 = min(n, r0 + (1 << 20))
+        rows = np.repeat(np.arange(r0, r1, dtype=np.int64), np.diff(rp[r0:r1 + 1]))
+        out[r0:r1] = np.bincount(rows[ci[rp[r0]:rp[r1]] <= rows + row0] - r0, minlength=r1 - r0)
+    return out
 
-    def __init__(self, args, rank, world):
+
+MTX_NAMES = {"syn-cant": "cant.mtx", "syn-nd24k": "nd24k.mtx", "syn-webbase": "webbase-1M.mtx",
+             "syn-nlpkkt": "nlpkkt240.mtx"}
+
+
+def mtx_for(workload):
+    """The real SuiteSparse file behind a stand-in, when SPX_MTX_DIR holds it."""
+    d = os.environ.get("SPX_MTX_DIR")
+    f = MTX_NAMES.get(workload)
+    if d and f and os.path.exists(os.path.join(d, f)):
+        return os.path.join(d, f)
+    return None
+
+
+class Workload:
+    """The rows [lo, hi) this rank owns of the global n x n matrix.  The rows are dealt to the
+    ranks by nonzeros with the reference's rule; on the symmetric path by the nonzeros that path
+    stores (lower triangle + diagonal), as the reference's symmetric partitioning counts them
+    (SparseInternal.hpp:131-144 over the lower-triangle elements of SparsePartition.hpp:1087-1129)."""
+
+    def __init__(self, args, rank, world, symmetric):
         from sparsex_amd import synth
         self.name = args.workload
-        if args.mtx or args.workload not in SLICED:
-            rp, ci, va, n = make_workload(args.workload, args.scale, mtx=args.mtx)
+        self.mtx = args.mtx or mtx_for(args.workload)
+        if self.mtx or args.workload not in SLICED:
+            rp, ci, va, n = make_workload(args.workload, args.scale, mtx=self.mtx)
             counts = np.diff(rp)
-            cuts = nnz_balanced_cuts(counts, world)
+            stored = stored_counts_csr(rp, ci) if symmetric else None
+            cuts = nnz_balanced_cuts(stored if symmetric else counts, world)
             lo, hi = cuts[rank], cuts[rank + 1]
             self.rp = (rp[lo:hi + 1] - rp[lo]).astype(np.int32)
             self.ci, self.va = ci[rp[lo]:rp[hi]], va[rp[lo]:rp[hi]]
-            self.label = (os.path.basename(args.mtx) if args.mtx else
+            self.label = (os.path.basename(self.mtx) + " (SuiteSparse file)" if self.mtx else
                           "%s (stand-in for SuiteSparse %s)" % (args.workload, args.workload.replace("syn-", "")))
         else:
             # every rank generates only its rows (tools/synth/nlpkkt_gen.c, kkt2f_gen.c)
@@ -117,7 +146,8 @@ class Workload:
             gen = SLICED[args.workload]
             counts = synth._row_counts(gen, args.edge)
             n = counts.size
-            cuts = nnz_balanced_cuts(counts, world)
+            stored = synth.stored_row_counts(gen, args.edge, counts) if symmetric else None
+            cuts = nnz_balanced_cuts(stored if symmetric else counts, world)
             lo, hi = cuts[rank], cuts[rank + 1]
             self.rp, self.ci, self.va, _ = synth._rows(gen, args.edge, lo, hi, counts, synth.SEED_BASE + 4)
             if gen == "nlpkkt":
@@ -133,6 +163,9 @@ class Workload:
         self.n, self.lo, self.hi, self.cuts = int(n), int(lo), int(hi), cuts
         self.nnz = int(counts.sum(dtype=np.int64))
         self.nnz_local = int(self.rp[-1])
+        # what this rank stores on the symmetric path: strictly lower nonzeros of its rows (+ its diagonal)
+        self.lower_local = int(stored[lo:hi].sum(dtype=np.int64)) - (hi - lo) if symmetric else None
+        self.stored_total = int(stored.sum(dtype=np.int64)) if symmetric else self.nnz
 
     def local_csr(self):
         import scipy.sparse as sp
@@ -470,8 +503,10 @@ def run_config(torch, sx, name, symmetric, steps, warmup, cpu_budget, T, csr=Non
     other path), measured like the main line."""
     from sparsex_amd import synth
     import scipy.sparse as sp
+    mtx = None
     if csr is None:
-        csr = make_workload(name, 1.0)
+        mtx = mtx_for(name)              # the real SuiteSparse file, where SPX_MTX_DIR holds it
+        csr = make_workload(name, 1.0, mtx=mtx)
     rp, ci, va, n = csr
     nnz = int(rp[-1])
     A = tune(csr, {"spx.rt.nr_threads": T, "spx.rt.device": torch.cuda.current_device(),
@@ -504,6 +539,7 @@ def run_config(torch, sx, name, symmetric, steps, warmup, cpu_budget, T, csr=Non
     launch_s = devs / steps
     out = {"gflops": round(2.0 * nnz * steps / wall / 1e9, 2), "us_per_spmv": round(1e6 * wall / steps, 3),
            "nnz": nnz, "nrows": n, "symmetric_path": symmetric,
+           "data": "file: " + os.path.basename(mtx) if mtx else "synthetic",
            "roofline": {"bound": "hbm", "achieved": round(b_alg / launch_s / 1e9, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(b_alg / launch_s / 1e9 / HBM_PEAK_GBS, 4),
                         "kernel": kernel_name(info, symmetric, 1), "avg_launch_us": round(1e6 * launch_s, 3),
@@ -521,6 +557,254 @@ def run_config(torch, sx, name, symmetric, steps, warmup, cpu_budget, T, csr=Non
     return out
 
 
+class Watchdog:
+    """Bounds a collective set-up phase (communicator creation, attaching the exchange plan, the
+    first exchange): a rank whose peer died would wait inside RCCL for ever and eat the lease.
+    On expiry the process reports and leaves with a non-zero code -- it is never re-exec'ed."""
+
+    def __init__(self, seconds, what):
+        import threading
+        self.what = what
+        self.timer = threading.Timer(seconds, self._fire)
+        self.timer.daemon = True
+        self.seconds = seconds
+
+    def _fire(self):
+        sys.stderr.write("bench.py: rank %s: '%s' did not finish within %d s; giving up\n" % (
+            os.environ.get("RANK", "0"), self.what, self.seconds))
+        sys.stderr.flush()
+        os._exit(86)
+
+    def __enter__(self):
+        self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.timer.cancel()
+        return False
+
+
+SETUP_TIMEOUT_S = int(os.environ.get("SPX_BENCH_SETUP_TIMEOUT", "300"))
+
+
+def make_transport(ctx):
+    """The exchange transport of a multi-rank run: RCCL point-to-point inside the library; the
+    same plan over torch.distributed where that cannot be created on every rank (reported)."""
+    torch, dist, sx = ctx["torch"], ctx["dist"], ctx["sx"]
+    rank, world, dev, backend = ctx["rank"], ctx["world"], ctx["dev"], ctx["backend"]
+    from sparsex_amd.dist_torch import torch_transport
+    if backend != "nccl":
+        return torch_transport(rank, world), "torch.distributed/%s staged through the host (test path)" % backend
+    transport = None
+    # (every rank first shows that its library can reach librccl at all: a rank that
+    # cannot would leave the others waiting inside the communicator's initialisation)
+    try:
+        mine_id = sx.rccl_unique_id()
+    except sx.SpxError:
+        mine_id = None
+    can = torch.tensor([1 if mine_id is not None else 0], device=dev)
+    dist.all_reduce(can, op=dist.ReduceOp.MIN)
+    ids = [mine_id if rank == 0 and int(can.item()) else None]
+    dist.broadcast_object_list(ids, src=0)
+    if ids[0] is not None:
+        try:
+            with Watchdog(SETUP_TIMEOUT_S, "spx_hip_transport_rccl (ncclCommInitRank)"):
+                transport = sx.RcclTransport(ids[0], rank, world)
+        except sx.SpxError:
+            transport = None
+    # every rank must hold the same kind of transport
+    ok = torch.tensor([1 if transport is not None else 0], device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()):
+        return transport, "RCCL point-to-point inside libsparsex (spx_hip_transport_rccl)"
+    # stand-by, reported as such: the same plan over torch.distributed's RCCL group,
+    # staged through device buffers (sparsex_amd/dist_torch.py)
+    print("bench.py: the library's RCCL transport could not be created on every rank; "
+          "falling back to torch.distributed all_to_all", file=sys.stderr)
+    if transport is not None:
+        transport.destroy()
+    return (torch_transport(rank, world, staging_device=dev),
+            "STAND-BY: torch.distributed all_to_all_single (RCCL) staged through device buffers")
+
+
+def run_path(ctx, args, symmetric):
+    """Generates this rank's rows, tunes them, (several ranks) attaches the exchange plan, gates
+    the product against CSR and times it.  Returns the facts of the path; rank 0's carry the line."""
+    torch, dist, sx = ctx["torch"], ctx["dist"], ctx["sx"]
+    rank, world, dev = ctx["rank"], ctx["world"], ctx["dev"]
+    barrier, reduce_max = ctx["barrier"], ctx["reduce_max"]
+    from sparsex_amd import synth
+
+    t_gen = time.perf_counter()
+    wl = Workload(args, rank, world, symmetric)
+    t_gen = time.perf_counter() - t_gen
+    n, lo, hi = wl.n, wl.lo, wl.hi
+    T = args.host_threads or max(1, min(host_cores() // max(world, 1), 32))
+    opts = {"spx.rt.nr_threads": T, "spx.rt.device": torch.cuda.current_device(),
+            "spx.matrix.symmetric": "true" if symmetric else "false",
+            "spx.rt.keep_encoded": "false"}
+    if world > 1:
+        opts.update({"spx.rt.row_offset": lo, "spx.rt.global_rows": n})
+    for o in args.opt:
+        k, v = o.split("=", 1)
+        opts[k] = v
+    A = tune((wl.rp, wl.ci, wl.va, n), opts, nrows=hi - lo)
+    info = A.info()
+    assert (info.row_lo, info.row_hi) == (lo, hi)
+
+    plan = None
+    if world > 1:
+        # the exchange that completes y lives in the library; torch.distributed only carried the
+        # 128-byte id.  Attaching is collective: it fails on every rank or on none.
+        with Watchdog(SETUP_TIMEOUT_S, "spx_hip_mat_dist_attach"):
+            A.dist_attach(ctx["transport"])
+        plan = A.dist_plan()
+
+    xh = synth.random_x(n)
+    x = torch.from_numpy(xh).to(dev)
+    y = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
+
+    def step(stream, flags=sx.SPX_DIST_GATHER_Y):
+        # several ranks: ONE ITERATION STEP -- the local product, (symmetric) the conflict-row
+        # exchange, and the hand-round of the finished slices of y, so that every rank holds the
+        # whole of y, i.e. the next x (x is replicated)
+        if world > 1:
+            A.hip_matvec_dist(ALPHA, x.data_ptr(), 0.0, y.data_ptr(), flags, stream)
+        else:
+            A.hip_matvec_mult(ALPHA, x.data_ptr(), y.data_ptr(), stream)
+
+    def step_owned(stream):                  # without the hand-round: the owned rows of y only
+        step(stream, sx.SPX_DIST_OWNED_ROWS)
+
+    def step_local(stream):                  # the kernels alone, no exchange at all
+        A.hip_matvec_mult(ALPHA, x.data_ptr(), y.data_ptr(), stream)
+
+    # correctness gate before timing: this rank's rows against the CSR product
+    # (kernel ablations built by tools/build_variant.sh compute wrong results on
+    # purpose; their lines are marked and never a bench result)
+    ablation = os.environ.get("SPX_BENCH_ABLATION") == "1"
+    cur = torch.cuda.current_stream().cuda_stream
+    with Watchdog(SETUP_TIMEOUT_S, "the first product (first exchange)"):
+        step_owned(cur) if world > 1 else step(cur)
+        torch.cuda.synchronize()
+    a_local = wl.local_csr()
+    parity = parity_gate(torch, y, a_local, xh, lo, hi, ablation)
+    if world > 1:
+        # ... and, with the slices handed round, all of y on every rank
+        step(cur)
+        torch.cuda.synchronize()
+        chk = torch.tensor([float(torch.nan_to_num(y, nan=1e300).abs().sum())], dtype=torch.float64,
+                           device=dev if ctx["backend"] == "nccl" else "cpu")
+        sums = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(sums, chk)
+        assert all(abs(float(s) - float(sums[0])) <= 1e-9 * abs(float(sums[0])) for s in sums), \
+            "gathered y differs between the ranks"
+        parity_gate(torch, y, a_local, xh, lo, hi, ablation)
+    del a_local
+
+    for _ in range(args.warmup):
+        step(cur)
+    barrier()
+    use_graph = args.graph and world == 1
+    wall, devs, graphed, walls = time_batches(torch, step, args.steps, barrier, reduce_max, use_graph)
+    collective = None
+    launch_s = devs / args.steps
+    if world > 1:
+        w_owned, _, _, _ = time_batches(torch, step_owned, args.steps, barrier, reduce_max, False)
+        w_local, d_local, _, _ = time_batches(torch, step_local, args.steps, barrier, reduce_max, False)
+        launch_s = d_local / args.steps       # the roofline is the kernels' (HIP events, this rank)
+        gf = lambda w: round(2.0 * wl.nnz * args.steps / w / 1e9, 2)
+        collective = {"full_step_gflops": gf(wall), "owned_rows_only_gflops": gf(w_owned),
+                      "kernels_only_gflops": gf(w_local),
+                      "full_step_ms": round(1e3 * wall / args.steps, 5),
+                      "owned_rows_only_ms": round(1e3 * w_owned / args.steps, 5),
+                      "kernels_only_ms": round(1e3 * w_local / args.steps, 5),
+                      "y_handround_bytes_received_per_rank": 8 * (n - (hi - lo)),
+                      "what": "full step = local product%s + hand-round of the finished slices of y (every rank "
+                              "ends with all of y = the next x); `value` is the full step" % (
+                                  " + conflict-row exchange" if symmetric else "")}
+
+    # per-rank facts the line reports for every rank
+    mine = {"rank": rank, "rows": [lo, hi], "nnz": wl.nnz_local,
+            "balance_nnz": wl.lower_local + (hi - lo) if symmetric else wl.nnz_local,   # what the rows were dealt by
+            "nnz_stored": int(info.nnz_stored), "rowblocks": int(info.n_rowblocks),
+            "tune_seconds": round(info.tune_seconds, 2), "emit_upload_seconds": round(info.emit_seconds, 2),
+            "kernels_us": round(1e6 * launch_s, 2),
+            "conflict_rows_sent": int(plan["send_rows"].size) if world > 1 else 0,
+            "conflict_entries_received": int(plan["n_recv"]) if world > 1 else 0}
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+
+    rows_local = hi - lo
+    b_alg = algorithmic_bytes(symmetric, wl.nnz_local, rows_local, n, wl.lower_local)
+    achieved = b_alg / launch_s / 1e9
+    tkey = "%s%s%s" % (args.workload, "-e%d" % args.edge if args.workload in SLICED else "",
+                       "-sym" if symmetric else "")
+    std = world == 1 and args.scale == 1.0 and not args.opt and not wl.mtx
+    if not symmetric:
+        par = "rows partitioned by nonzeros over %d rank%s; x replicated; every rank completes its own rows of y " \
+              "(no exchange needed for that)%s" % (
+                  world, "s" if world > 1 else "",
+                  "; then the slices of y are handed round, pairwise, so that every rank holds the next x"
+                  if world > 1 else "")
+    else:
+        par = "rows partitioned by stored nonzeros (lower triangle + diagonal) over %d rank%s; x replicated; each " \
+              "rank sends the sums for its conflict rows (rows in front of its own that its lower triangle " \
+              "touches) to their owners, packed, pairwise (no n-long all-reduce)%s" % (
+                  world, "s" if world > 1 else "", "; then the slices of y are handed round" if world > 1 else "")
+    out = {
+        "value": round(2.0 * wl.nnz * args.steps / wall / 1e9, 3),
+        "ms_per_step": round(1e3 * wall / args.steps, 6),
+        "data": "file" if wl.mtx else "synthetic",
+        "protocol": {"batches": BATCHES, "steps_per_batch": args.steps, "reported": "median batch "
+                     "(max over ranks per batch)", "batch_ms": [round(1e3 * w, 4) for w in walls],
+                     "reference": "src/bench/Bench.cpp:29-30, SparsexModule.cpp:65-79"},
+        "config": {"workload": wl.label, "nrows": n, "nnz": wl.nnz,
+                   "symmetric_path": bool(symmetric), "partitions_per_gpu": T,
+                   "launch": "one hipGraph of %d captured launches per batch" % args.steps if graphed
+                             else "stream launches",
+                   "parallelism": par, "transport": ctx["transport_name"],
+                   "collective_in_value": ("included: every step ends with all of y on every rank"
+                                           if world > 1 else "none needed"),
+                   "generate_seconds": round(t_gen, 2)},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": measured_traffic(tkey) if std else None,
+                     "traffic_source": "committed PMC run of this command (profiles/traffic.json)" if std else None,
+                     "kernel": kernel_name(info, symmetric, world),
+                     "algorithmic_bytes_per_launch": int(b_alg),
+                     "avg_launch_us": round(1e6 * launch_s, 3),
+                     "cache_resident": bool(info.value_bytes + info.index_bytes < MALL_BYTES),
+                     "scope": "rank 0's GPU: its stored values, x and its rows of y once per launch"
+                              + (" (kernels only: timed without the exchange)" if world > 1 else "")},
+        "format": {"nnz_stored": int(info.nnz_stored), "unit_elems": int(info.n_unit_elems),
+                   "delta_elems": int(info.n_delta_elems), "units": int(info.n_units),
+                   "rowblocks": int(info.n_rowblocks), "waves_per_workgroup": int(info.waves),
+                   "index_bytes_per_nnz": round(info.index_bytes / max(int(info.nnz_stored), 1), 3),
+                   "index_bytes": int(info.index_bytes), "value_bytes": int(info.value_bytes),
+                   "csr_equivalent_bytes": int(12 * wl.nnz_local + 4 * (rows_local + 1) + 8 * n + 8 * rows_local),
+                   "tune_seconds": round(info.tune_seconds, 3),
+                   "emit_upload_seconds": round(info.emit_seconds, 3)},
+        "ranks": per_rank,
+        "parity": parity,
+    }
+    if collective:
+        out["collective"] = collective
+    if world == 1 and not symmetric:
+        peak = measured_read_peak(sx, torch)
+        out["roofline"]["measured_stream_read_peak"] = round(peak, 1)
+        out["roofline"]["frac_of_measured_read_peak"] = round(achieved / peak, 4)
+    if world == 1 and rank == 0:
+        out["host_api"] = host_api_rate(A, xh, n, wl.nnz)
+    if ablation:
+        out["INVALID_ablation_build"] = os.environ.get("SPX_LIB_PATH", "")
+    A.destroy()
+    del x, y
+    return out, wl, T
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -532,13 +816,15 @@ def main():
                          "nonzeros, 6.2 GB of values)" % DEFAULT_EDGE)
     ap.add_argument("--scale", type=float, default=1.0, help="size factor of the other synthetic workloads")
     ap.add_argument("--mtx", default=None,
-                    help="Matrix Market file to use instead of the synthetic stand-in")
+                    help="Matrix Market file to use instead of the synthetic stand-in (also: SPX_MTX_DIR with "
+                         "cant.mtx / nd24k.mtx / webbase-1M.mtx / nlpkkt240.mtx)")
     ap.add_argument("--symmetric", action="store_true")
     ap.add_argument("--host-threads", type=int, default=0,
                     help="host preprocessing partitions per GPU (default: min(cores / ranks, 32))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true",
-                    help="N = 1: skip the other BASELINE configurations (cant, nd24k symmetric, webbase)")
+                    help="N = 1: skip the other BASELINE configurations (cant, nd24k symmetric, webbase); "
+                         "N > 1: skip the second run on the symmetric path")
     ap.add_argument("--no-graph", dest="graph", action="store_false",
                     help="launch the steps of a batch one by one instead of replaying them as one hipGraph "
                          "(stream capture; the default on one GPU, where a step is kernels only)")
@@ -563,10 +849,11 @@ def main():
         share = backend != "nccl" or os.environ.get("SPX_BENCH_SHARE_GPU") == "1"
         dev_id = local_rank % torch.cuda.device_count() if share else local_rank
         torch.cuda.set_device(dev_id)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_id))
-        else:
-            dist.init_process_group(backend)
+        with Watchdog(SETUP_TIMEOUT_S, "torch.distributed process group"):
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", dev_id))
+            else:
+                dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -583,224 +870,38 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    t_gen = time.perf_counter()
-    wl = Workload(args, rank, world)
-    t_gen = time.perf_counter() - t_gen
-    n, lo, hi = wl.n, wl.lo, wl.hi
-    T = args.host_threads or max(1, min(host_cores() // max(world, 1), 32))
-    opts = {"spx.rt.nr_threads": T, "spx.rt.device": torch.cuda.current_device(),
-            "spx.matrix.symmetric": "true" if args.symmetric else "false",
-            "spx.rt.keep_encoded": "false"}
+    ctx = {"torch": torch, "dist": dist, "sx": sx, "rank": rank, "world": world, "dev": dev,
+           "backend": backend, "barrier": barrier, "reduce_max": reduce_max,
+           "transport": None, "transport_name": "none"}
     if world > 1:
-        opts.update({"spx.rt.row_offset": lo, "spx.rt.global_rows": n})
-    for o in args.opt:
-        k, v = o.split("=", 1)
-        opts[k] = v
-    A = tune((wl.rp, wl.ci, wl.va, n), opts, nrows=hi - lo)
-    info = A.info()
-    assert (info.row_lo, info.row_hi) == (lo, hi)
+        ctx["transport"], ctx["transport_name"] = make_transport(ctx)
 
-    # several ranks: the exchange that completes y lives in the library (RCCL
-    # point-to-point over xGMI); torch.distributed only carries the 128-byte id
-    transport_name = "none"
-    if world > 1:
-        if backend == "nccl":
-            transport = None
-            # (every rank first shows that its library can reach librccl at all: a rank that
-            # cannot would leave the others waiting inside the communicator's initialisation)
-            try:
-                mine_id = sx.rccl_unique_id()
-            except sx.SpxError:
-                mine_id = None
-            can = torch.tensor([1 if mine_id is not None else 0], device=dev)
-            dist.all_reduce(can, op=dist.ReduceOp.MIN)
-            ids = [mine_id if rank == 0 and int(can.item()) else None]
-            dist.broadcast_object_list(ids, src=0)
-            if ids[0] is not None:
-                try:
-                    transport = sx.RcclTransport(ids[0], rank, world)
-                except sx.SpxError:
-                    transport = None
-            # every rank must hold the same kind of transport
-            ok = torch.tensor([1 if transport is not None else 0], device=dev)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()):
-                transport_name = "RCCL point-to-point inside libsparsex (spx_hip_transport_rccl)"
-            else:
-                # stand-by, reported as such: the same plan over torch.distributed's RCCL group,
-                # staged through device buffers (sparsex_amd/dist_torch.py)
-                print("bench.py: the library's RCCL transport could not be created on every rank; "
-                      "falling back to torch.distributed all_to_all", file=sys.stderr)
-                if transport is not None:
-                    transport.destroy()
-                from sparsex_amd.dist_torch import torch_transport
-                transport = torch_transport(rank, world, staging_device=dev)
-                transport_name = "STAND-BY: torch.distributed all_to_all_single (RCCL) staged through device buffers"
-        else:
-            from sparsex_amd.dist_torch import torch_transport
-            transport = torch_transport(rank, world)
-            transport_name = "torch.distributed/%s staged through the host (test path)" % backend
-        try:
-            A.dist_attach(transport)
-            attached = 1
-        except sx.SpxError as e:
-            print("bench.py: rank %d could not attach the exchange plan (%s)" % (rank, e), file=sys.stderr)
-            attached = 0
-        if backend == "nccl":
-            ok = torch.tensor([attached], device=dev)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if not int(ok.item()) and not transport_name.startswith("STAND-BY"):
-                # (as above: everybody changes to the stand-by transport together)
-                transport.destroy()
-                from sparsex_amd.dist_torch import torch_transport
-                transport = torch_transport(rank, world, staging_device=dev)
-                transport_name = "STAND-BY: torch.distributed all_to_all_single (RCCL) staged through device buffers"
-                A.dist_attach(transport)
-                attached = 1
-        assert attached, "no exchange plan"
-        plan = A.dist_plan()
-
-    xh = synth.random_x(n)
-    x = torch.from_numpy(xh).to(dev)
-    y = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
-
-    def step(stream, flags=sx.SPX_DIST_OWNED_ROWS):
-        if world > 1:
-            A.hip_matvec_dist(ALPHA, x.data_ptr(), 0.0, y.data_ptr(), flags, stream)
-        else:
-            A.hip_matvec_mult(ALPHA, x.data_ptr(), y.data_ptr(), stream)
-
-    def step_local(stream):                  # the kernels alone, no exchange
-        A.hip_matvec_mult(ALPHA, x.data_ptr(), y.data_ptr(), stream)
-
-    # correctness gate before timing: this rank's rows against the CSR product
-    # (kernel ablations built by tools/build_variant.sh compute wrong results on
-    # purpose; their lines are marked and never a bench result)
-    ablation = os.environ.get("SPX_BENCH_ABLATION") == "1"
-    step(torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
-    a_local = wl.local_csr()
-    parity = parity_gate(torch, y, a_local, xh, lo, hi, ablation)
-    if world > 1:
-        # ... and, with the slices handed round, all of y on every rank
-        step(torch.cuda.current_stream().cuda_stream, sx.SPX_DIST_GATHER_Y)
-        torch.cuda.synchronize()
-        chk = torch.tensor([float(torch.nan_to_num(y, nan=1e300).abs().sum())], dtype=torch.float64,
-                           device=dev if backend == "nccl" else "cpu")
-        sums = [torch.zeros_like(chk) for _ in range(world)]
-        dist.all_gather(sums, chk)
-        assert all(abs(float(s) - float(sums[0])) <= 1e-9 * abs(float(sums[0])) for s in sums), \
-            "gathered y differs between the ranks"
-        parity_gate(torch, y, a_local, xh, lo, hi, ablation)
-    lower_local = None
-    if args.symmetric:
-        rows = np.repeat(np.arange(lo, hi, dtype=np.int64), np.diff(wl.rp))
-        lower_local = int((wl.ci < rows).sum())
-        del rows
-    del a_local
-
-    cur = torch.cuda.current_stream().cuda_stream
-    for _ in range(args.warmup):
-        step(cur)
-    barrier()
-    use_graph = args.graph and world == 1
-    wall, devs, graphed, walls = time_batches(torch, step, args.steps, barrier, reduce_max, use_graph)
-    extra = {}
-    if world > 1:
-        w2, _, _, _ = time_batches(torch, step_local, args.steps, barrier, reduce_max, False)
-        w3, _, _, _ = time_batches(torch, lambda s: step(s, sx.SPX_DIST_GATHER_Y), args.steps, barrier,
-                                   reduce_max, False)
-        extra = {"kernels_only_gflops": round(2.0 * wl.nnz * args.steps / w2 / 1e9, 2),
-                 "with_y_allgather_gflops": round(2.0 * wl.nnz * args.steps / w3 / 1e9, 2)}
-
-    # per-rank facts the line reports for every rank
-    mine = {"rank": rank, "rows": [lo, hi], "nnz": wl.nnz_local, "rowblocks": int(info.n_rowblocks),
-            "tune_seconds": round(info.tune_seconds, 2), "emit_upload_seconds": round(info.emit_seconds, 2),
-            "avg_launch_us": round(1e6 * devs / args.steps, 2),
-            "conflict_rows_sent": int(plan["send_rows"].size) if world > 1 else 0,
-            "conflict_entries_received": int(plan["n_recv"]) if world > 1 else 0}
-    per_rank = [mine]
-    if world > 1:
-        per_rank = [None] * world
-        dist.all_gather_object(per_rank, mine)
-
+    res, wl, T = run_path(ctx, args, args.symmetric)
+    out = None
     if rank == 0:
-        ms_per_step = 1e3 * wall / args.steps
-        gflops = 2.0 * wl.nnz * args.steps / wall / 1e9
-        rows_local = hi - lo
-        b_alg = algorithmic_bytes(args.symmetric, wl.nnz_local, rows_local, n, lower_local)
-        launch_s = devs / args.steps
-        achieved = b_alg / launch_s / 1e9
-        tkey = "%s%s%s" % (args.workload, "-e%d" % args.edge if args.workload in SLICED else "",
-                           "-sym" if args.symmetric else "")
-        std = world == 1 and args.scale == 1.0 and not args.opt and not args.mtx
-        if not args.symmetric:
-            par = "rows partitioned by nonzeros over %d rank%s; x replicated; no collective: every rank " \
-                  "completes its own rows of y" % (world, "s" if world > 1 else "")
-        else:
-            par = "rows partitioned by nonzeros over %d rank%s; x replicated; symmetric storage: each rank " \
-                  "sends the sums for its conflict rows (rows in front of its own that its lower triangle " \
-                  "touches) to their owners, packed, pairwise (no n-long all-reduce)" % (
-                      world, "s" if world > 1 else "")
-        out = {
-            "metric": "SpMV GFLOP/s (2*nnz/t, alpha=0.5, x/y resident in HBM)",
-            "value": round(gflops, 3), "unit": "GFLOP/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 6), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64",
-            "data": "file" if args.mtx else "synthetic",
-            "protocol": {"batches": BATCHES, "steps_per_batch": args.steps, "reported": "median batch "
-                         "(max over ranks per batch)", "batch_ms": [round(1e3 * w, 4) for w in walls],
-                         "reference": "src/bench/Bench.cpp:29-30, SparsexModule.cpp:65-79"},
-            "config": {"workload": wl.label, "nrows": n, "nnz": wl.nnz,
-                       "symmetric_path": bool(args.symmetric), "partitions_per_gpu": T,
-                       "launch": "one hipGraph of %d captured launches per batch" % args.steps if graphed
-                                 else "stream launches",
-                       "parallelism": par, "transport": transport_name,
-                       "collective_in_value": ("included: pack, pairwise exchange and ordered add complete the "
-                                               "owned rows inside every step" if args.symmetric and world > 1
-                                               else "none needed"),
-                       "generate_seconds": round(t_gen, 2)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": measured_traffic(tkey) if std else None,
-                         "kernel": kernel_name(info, args.symmetric, world),
-                         "algorithmic_bytes_per_launch": int(b_alg),
-                         "avg_launch_us": round(1e6 * launch_s, 3),
-                         "cache_resident": bool(info.value_bytes + info.index_bytes < MALL_BYTES),
-                         "scope": "rank 0's GPU: its stored values, x and its rows of y once per launch"},
-            "format": {"nnz_stored": int(info.nnz_stored), "unit_elems": int(info.n_unit_elems),
-                       "delta_elems": int(info.n_delta_elems), "units": int(info.n_units),
-                       "rowblocks": int(info.n_rowblocks), "waves_per_workgroup": int(info.waves),
-                       "index_bytes_per_nnz": round(info.index_bytes / max(int(info.nnz_stored), 1), 3),
-                       "index_bytes": int(info.index_bytes), "value_bytes": int(info.value_bytes),
-                       "csr_equivalent_bytes": int(12 * wl.nnz_local + 4 * (rows_local + 1) + 8 * n + 8 * rows_local),
-                       "tune_seconds": round(info.tune_seconds, 3),
-                       "emit_upload_seconds": round(info.emit_seconds, 3)},
-            "ranks": per_rank,
-            "parity": parity,
-        }
-        if extra:
-            out["collective"] = extra
-        if world == 1 and not args.symmetric:
-            peak = measured_read_peak(sx, torch)
-            out["roofline"]["measured_stream_read_peak"] = round(peak, 1)
-            out["roofline"]["frac_of_measured_read_peak"] = round(achieved / peak, 4)
-        if world == 1:
-            out["host_api"] = host_api_rate(A, xh, n, wl.nnz)
-        if ablation:
-            out["INVALID_ablation_build"] = os.environ.get("SPX_LIB_PATH", "")
-    A.destroy()
+        out = {"metric": "SpMV GFLOP/s (2*nnz/t, alpha=0.5, x/y resident in HBM)",
+               "value": res.pop("value"), "unit": "GFLOP/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": res.pop("ms_per_step"), "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f64"}
+        out.update(res)
+    if world > 1 and not args.symmetric and not args.no_configs:
+        # the same matrix through the symmetric path in the same invocation: here the conflict rows
+        # really travel (RCCL point-to-point) before the hand-round
+        del wl
+        res_s, wl, _ = run_path(ctx, args, True)
+        if rank == 0:
+            out["symmetric"] = res_s
     if world > 1:
-        transport.destroy()
-    del x, y
+        ctx["transport"].destroy()
+    n = wl.n
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            if args.workload == "syn-nlpkkt" and not args.mtx and args.edge > SAMPLE_EDGE:
+            if args.workload == "syn-nlpkkt" and not wl.mtx and args.edge > SAMPLE_EDGE:
                 csr_s = synth.syn_nlpkkt_rows(SAMPLE_EDGE)
-                note = "sample: syn-nlpkkt at grid edge %d (%.1f M nonzeros; the bench matrix's generator at " \
-                       "1/%d of its nonzeros); " % (SAMPLE_EDGE, csr_s[0][-1] / 1e6,
-                                                    round(wl.nnz / max(int(csr_s[0][-1]), 1)))
+                note = "sample: syn-nlpkkt at grid edge %d (%.1f M nonzeros, %.2f GB of values -- beyond the host's " \
+                       "last-level caches; the bench matrix's generator at 1/%d of its nonzeros); " % (
+                           SAMPLE_EDGE, csr_s[0][-1] / 1e6, 8e-9 * csr_s[0][-1], round(wl.nnz / max(int(csr_s[0][-1]), 1)))
             else:
                 csr_s = (wl.rp, wl.ci, wl.va, n)
                 note = "sample: the whole bench matrix; "
@@ -812,7 +913,7 @@ def main():
                 # the bench matrix itself through the symmetric path (BASELINE config 4's path:
                 # lower triangle + diagonal stored, every value read once)
                 sample, snote = None, ""
-                if not args.no_cpu_baseline and args.edge > SAMPLE_EDGE:
+                if not args.no_cpu_baseline and args.edge > SAMPLE_EDGE and not wl.mtx:
                     sample = synth.syn_nlpkkt_rows(SAMPLE_EDGE)
                     snote = "sample: syn-nlpkkt at grid edge %d (%.1f M nonzeros); " % (SAMPLE_EDGE, sample[0][-1] / 1e6)
                 cfgs["syn-nlpkkt --symmetric (the bench matrix)"] = run_config(

@@ -4,6 +4,8 @@
 
 #include <algorithm>
 #include <cstring>
+#include <memory>
+#include <string>
 
 namespace spx {
 
@@ -25,6 +27,11 @@ void host_exchange(const spx_hip_transport_t &t, const std::vector<uint64_t> &se
 
 }  // namespace
 
+// The plan is built collectively, and a rank that fails between two exchanges would leave
+// the others waiting in theirs (with RCCL: forever).  So nothing throws between the first
+// exchange and the last: a rank that finds something wrong locally keeps taking part, with
+// empty lists, and says so in a status word that travels with the counts and once more at
+// the very end -- every rank sees every status, and all of them fail together.
 DistPlan *dist_build_plan(const spx_hip_transport_t &t, idx_t own_lo, idx_t own_hi, idx_t nrows,
                           const std::vector<idx_t> &conflict_rows, bool on_device)
 {
@@ -34,6 +41,8 @@ DistPlan *dist_build_plan(const spx_hip_transport_t &t, idx_t own_lo, idx_t own_
     p->rank = t.rank;
     p->world = t.world;
     const size_t W = (size_t) t.world, me = (size_t) t.rank;
+    std::string bad;                        // first local complaint ("" = fine so far)
+    auto complain = [&bad](const char *what) { if (bad.empty()) bad = what; };
 
     // 1. everybody's rows
     {
@@ -53,72 +62,82 @@ DistPlan *dist_build_plan(const spx_hip_transport_t &t, idx_t own_lo, idx_t own_
         // the ranges must tile [0, nrows) in rank order
         idx_t at = 0;
         for (size_t q = 0; q < W; ++q) {
-            if (p->row_lo[q] != at || p->row_hi[q] < at) throw FatalError("row ranges of the processes do not tile the matrix");
+            if (p->row_lo[q] != at || p->row_hi[q] < at) complain("row ranges of the processes do not tile the matrix");
             at = p->row_hi[q];
         }
-        if (at != nrows) throw FatalError("row ranges of the processes do not cover the matrix");
+        if (at != nrows) complain("row ranges of the processes do not cover the matrix");
     }
 
     // 2. this process' conflict rows, by owner (they are ascending)
     p->send_rows = conflict_rows;
     p->send_off.assign(W, 0);
     p->send_cnt.assign(W, 0);
-    {
+    if (bad.empty()) {
         size_t k = 0;
         for (size_t q = 0; q < W; ++q) {
             p->send_off[q] = k;
             while (k < conflict_rows.size() && conflict_rows[k] < p->row_hi[q]) {
-                if (q >= me) throw FatalError("conflict row not in front of the own rows");
+                if (q >= me) complain("conflict row not in front of the own rows");
                 ++k;
             }
             p->send_cnt[q] = k - p->send_off[q];
         }
-        if (k != conflict_rows.size()) throw FatalError("conflict row outside the matrix");
+        if (k != conflict_rows.size()) complain("conflict row outside the matrix");
+    }
+    if (!bad.empty()) {                     // keeps taking part, with nothing to send
+        p->send_rows.clear();
+        p->send_off.assign(W, 0);
+        p->send_cnt.assign(W, 0);
     }
 
-    // 3. counts, then the row lists themselves
+    // 3. per peer: {entries I send you, my status: bit 0 = something is wrong here,
+    //    bit 1 = I send something to somebody}
     p->recv_off.assign(W, 0);
     p->recv_cnt.assign(W, 0);
+    bool any_bad = !bad.empty();
     {
-        std::vector<uint64_t> send(W), recv(W, 0);
-        std::vector<size_t> off(W), one(W, 1);
+        const uint64_t status = (bad.empty() ? 0u : 1u) | (p->send_rows.empty() ? 0u : 2u);
+        std::vector<uint64_t> send(2 * W), recv(2 * W, 0);
+        std::vector<size_t> off(W), two(W, 2);
         for (size_t q = 0; q < W; ++q) {
-            send[q] = p->send_cnt[q];
-            off[q] = q;
+            send[2 * q] = p->send_cnt[q];
+            send[2 * q + 1] = status;
+            off[q] = 2 * q;
         }
-        one[me] = 0;
-        host_exchange(t, send, off, one, recv, off, one);
+        two[me] = 0;
+        host_exchange(t, send, off, two, recv, off, two);
         size_t k = 0;
+        p->any_exchange = !p->send_rows.empty();
         for (size_t q = 0; q < W; ++q) {
             p->recv_off[q] = k;
-            p->recv_cnt[q] = q == me ? 0 : (size_t) recv[q];
+            p->recv_cnt[q] = q == me ? 0 : (size_t) recv[2 * q];
             k += p->recv_cnt[q];
+            if (q != me) {
+                any_bad = any_bad || (recv[2 * q + 1] & 1u);
+                p->any_exchange = p->any_exchange || (recv[2 * q + 1] & 2u);
+            }
         }
         p->n_recv = k;
     }
+    // (every rank has seen every status word: all of them leave here, or none)
+    if (any_bad)
+        throw FatalError(bad.empty() ? "another process could not build its part of the exchange plan" : bad);
+
+    // 4. the row lists themselves
     std::vector<uint64_t> recv_rows(p->n_recv, 0);
     {
-        std::vector<uint64_t> send(conflict_rows.begin(), conflict_rows.end());
+        std::vector<uint64_t> send(p->send_rows.begin(), p->send_rows.end());
         host_exchange(t, send, p->send_off, p->send_cnt, recv_rows, p->recv_off, p->recv_cnt);
-    }
-    // 4. does anybody exchange anything?  (a general matrix: nobody)
-    {
-        std::vector<uint64_t> send(W, conflict_rows.empty() ? 0 : 1), recv(W, 0);
-        std::vector<size_t> off(W), one(W, 1);
-        for (size_t q = 0; q < W; ++q) off[q] = q;
-        one[me] = 0;
-        host_exchange(t, send, off, one, recv, off, one);
-        p->any_exchange = !conflict_rows.empty();
-        for (size_t q = 0; q < W; ++q) p->any_exchange = p->any_exchange || (q != me && recv[q]);
     }
 
     // 5. per own row: where in the receive buffer its sums arrive (fixed order)
     {
-        std::vector<std::pair<idx_t, uint32_t>> pr(p->n_recv);
+        std::vector<std::pair<idx_t, uint32_t>> pr;
+        pr.reserve(p->n_recv);
         for (size_t k = 0; k < p->n_recv; ++k) {
             const idx_t r = (idx_t) recv_rows[k];
-            if (r < own_lo || r >= own_hi) throw FatalError("received a conflict row that is not owned here");
-            pr[k] = std::make_pair(r, (uint32_t) k);
+            if (r < own_lo || r >= own_hi) { complain("received a conflict row that is not owned here"); continue; }
+            pr.push_back(std::make_pair(r, (uint32_t) k));
         }
         std::sort(pr.begin(), pr.end());
         p->fix_ptr.push_back(0);
@@ -143,7 +162,30 @@ DistPlan *dist_build_plan(const spx_hip_transport_t &t, idx_t own_lo, idx_t own_
     }
     p->gat_send_cnt[me] = p->gat_recv_cnt[me] = 0;
 
-    if (on_device) p->dev = dist_device_create(*p);
+    if (on_device && bad.empty()) {
+        try {
+            p->dev = dist_device_create(*p);
+        } catch (const FatalError &e) {
+            complain(e.what.c_str());
+        }
+    }
+
+    // 7. did everybody get this far in one piece?  (a rank without its plan would leave
+    //    the others waiting in the first SpMV's exchange)
+    {
+        std::vector<uint64_t> send(W, bad.empty() ? 0u : 1u), recv(W, 0);
+        std::vector<size_t> off(W), one(W, 1);
+        for (size_t q = 0; q < W; ++q) off[q] = q;
+        one[me] = 0;
+        host_exchange(t, send, off, one, recv, off, one);
+        bool other = false;
+        for (size_t q = 0; q < W; ++q) other = other || (q != me && recv[q]);
+        if (!bad.empty() || other) {
+            dist_device_free(p->dev);
+            p->dev = nullptr;
+            throw FatalError(bad.empty() ? "another process could not build its part of the exchange plan" : bad);
+        }
+    }
     return p.release();
 }
 

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <vector>
 
 namespace spx {
 
@@ -162,6 +163,11 @@ struct RcclCtx {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
     hipStream_t setup_stream = nullptr;
+    // set-up exchanges: a status word per peer (allocated with the communicator, so that a
+    // rank can always say that something went wrong on its side) and the staging buffers
+    double *st_send = nullptr, *st_recv = nullptr;       // `world` doubles each
+    double *stage_s = nullptr, *stage_r = nullptr;
+    size_t cap_s = 0, cap_r = 0;
 };
 
 int rccl_exchange_device(void *ctx_, const double *send, const size_t *soff, const size_t *scnt,
@@ -185,35 +191,71 @@ int rccl_exchange_device(void *ctx_, const double *send, const size_t *soff, con
     return 0;
 }
 
+static bool grow(double *&buf, size_t &cap, size_t want)
+{
+    if (want <= cap) return true;
+    if (buf) (void) hipFree(buf);
+    buf = nullptr;
+    cap = 0;
+    if (hipMalloc(reinterpret_cast<void **>(&buf), want * 8) != hipSuccess) {
+        (void) hipGetLastError();
+        return false;
+    }
+    cap = want;
+    return true;
+}
+
 int rccl_exchange_host(void *ctx_, const uint64_t *send, const size_t *soff, const size_t *scnt,
                        uint64_t *recv, const size_t *roff, const size_t *rcnt)
 {
     // set-up time only: staged through device buffers (8-byte words travel as doubles,
-    // nothing looks at the bits)
+    // nothing looks at the bits).  Whatever can fail locally -- growing the staging
+    // buffers, the upload -- happens BEFORE the group, and its outcome travels first, as a
+    // status word per peer through buffers that exist since the communicator was made: a
+    // rank that cannot take part in the payload exchange says so, and every rank returns
+    // -1 together instead of waiting for it inside ncclRecv.
     RcclCtx *c = static_cast<RcclCtx *>(ctx_);
+    const size_t W = (size_t) c->world;
     size_t ns = 0, nr = 0;
     for (int q = 0; q < c->world; ++q) {
         if (q == c->rank) continue;
         ns = std::max(ns, soff[q] + scnt[q]);
         nr = std::max(nr, roff[q] + rcnt[q]);
     }
-    double *ds = nullptr, *dr = nullptr;
-    int ret = -1;
-    if (hipMalloc(reinterpret_cast<void **>(&ds), std::max<size_t>(ns, 1) * 8) == hipSuccess &&
-        hipMalloc(reinterpret_cast<void **>(&dr), std::max<size_t>(nr, 1) * 8) == hipSuccess &&
-        (ns == 0 || hipMemcpyAsync(ds, send, ns * 8, hipMemcpyHostToDevice, c->setup_stream) == hipSuccess) &&
-        rccl_exchange_device(c, ds, soff, scnt, dr, roff, rcnt, c->setup_stream) == 0 &&
-        hipStreamSynchronize(c->setup_stream) == hipSuccess) {
-        // only the segments that were received are defined
-        ret = 0;
-        for (int q = 0; q < c->world && ret == 0; ++q)
-            if (q != c->rank && rcnt[q] &&
-                hipMemcpy(recv + roff[q], dr + roff[q], rcnt[q] * 8, hipMemcpyDeviceToHost) != hipSuccess)
-                ret = -1;
+    bool ok = grow(c->stage_s, c->cap_s, std::max<size_t>(ns, 1)) && grow(c->stage_r, c->cap_r, std::max<size_t>(nr, 1));
+    if (ok && ns && hipMemcpyAsync(c->stage_s, send, ns * 8, hipMemcpyHostToDevice, c->setup_stream) != hipSuccess) {
+        (void) hipGetLastError();
+        ok = false;
     }
-    (void) hipFree(ds);
-    (void) hipFree(dr);
-    return ret;
+    // the status round: one word to and from every peer
+    std::vector<double> st(W, ok ? 0.0 : 1.0), got(W, 0.0);
+    std::vector<size_t> off(W), one(W, 1);
+    for (size_t q = 0; q < W; ++q) off[q] = q;
+    one[(size_t) c->rank] = 0;
+    if (hipMemcpyAsync(c->st_send, st.data(), W * 8, hipMemcpyHostToDevice, c->setup_stream) != hipSuccess ||
+        rccl_exchange_device(c, c->st_send, off.data(), one.data(), c->st_recv, off.data(), one.data(),
+                             c->setup_stream) != 0 ||
+        hipMemcpyAsync(got.data(), c->st_recv, W * 8, hipMemcpyDeviceToHost, c->setup_stream) != hipSuccess ||
+        hipStreamSynchronize(c->setup_stream) != hipSuccess) {
+        (void) hipGetLastError();
+        log_msg(LOG_ERR, "RCCL transport: the status round of a set-up exchange failed\n");
+        return -1;
+    }
+    for (size_t q = 0; q < W; ++q)
+        if (q != (size_t) c->rank && got[q] != 0.0) ok = false;
+    if (!ok) {
+        log_msg(LOG_ERR, "RCCL transport: a rank could not stage its set-up exchange; all ranks give up\n");
+        return -1;
+    }
+    if (rccl_exchange_device(c, c->stage_s, soff, scnt, c->stage_r, roff, rcnt, c->setup_stream) != 0 ||
+        hipStreamSynchronize(c->setup_stream) != hipSuccess)
+        return -1;
+    // only the segments that were received are defined
+    for (int q = 0; q < c->world; ++q)
+        if (q != c->rank && rcnt[q] &&
+            hipMemcpy(recv + roff[q], c->stage_r + roff[q], rcnt[q] * 8, hipMemcpyDeviceToHost) != hipSuccess)
+            return -1;
+    return 0;
 }
 
 }  // namespace
@@ -251,7 +293,14 @@ spx_hip_transport_t *spx_hip_transport_rccl(const void *id, int rank, int world)
             spx::log_msg(spx::LOG_ERR, "RCCL communicator: %s\n", r.GetErrorString(rc));
             return NULL;
         }
-        if (hipStreamCreateWithFlags(&c->setup_stream, hipStreamNonBlocking) != hipSuccess) return NULL;
+        if (hipStreamCreateWithFlags(&c->setup_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&c->st_send), (size_t) world * 8) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&c->st_recv), (size_t) world * 8) != hipSuccess) {
+            // (the communicator exists on the other ranks: leaving it half-made here would make
+            // their first exchange wait; it is destroyed, which they see as an error)
+            (void) r.CommDestroy(c->comm);
+            return NULL;
+        }
         spx_hip_transport_t *t = new spx_hip_transport_t;
         t->ctx = c.release();
         t->rank = rank;
@@ -273,6 +322,8 @@ void spx_hip_transport_destroy(spx_hip_transport_t *t)
     if (c) {
         if (c->comm) (void) spx::rccl().CommDestroy(c->comm);
         if (c->setup_stream) (void) hipStreamDestroy(c->setup_stream);
+        (void) hipFree(c->st_send); (void) hipFree(c->st_recv);
+        (void) hipFree(c->stage_s); (void) hipFree(c->stage_r);
         delete c;
     }
     delete t;

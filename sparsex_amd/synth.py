@@ -289,6 +289,29 @@ def syn_kkt2f_rows(N, lo=0, hi=None, counts=None, seed=SEED_BASE + 4):
     return _rows("kkt2f", N, lo, hi, counts, seed)
 
 
+def stored_row_counts(gen, N, counts=None):
+    """Per row: the nonzeros on and below the diagonal -- what the symmetric path stores, and
+    what its rows are balanced by when they are dealt to several processes."""
+    if counts is None:
+        counts = _row_counts(gen, N)
+    if gen == "nlpkkt":
+        # states and controls keep their diagonal, the multiplier rows everything
+        # (tools/synth/nlpkkt_gen.c: the blocks A_y, A_u lie below the diagonal)
+        P = int(N) ** 3 + 6 * int(N) ** 2
+        out = counts.copy()
+        out[:P] = 1
+        return out
+    out = np.empty_like(counts)
+    n = counts.size
+    step = 1 << 20
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        rp, ci, _, _ = _rows(gen, N, lo, hi, counts, SEED_BASE + 4)
+        rows = np.repeat(np.arange(lo, hi, dtype=np.int64), np.diff(rp))
+        out[lo:hi] = np.bincount((rows - lo)[ci <= rows], minlength=hi - lo)
+    return out
+
+
 def nlpkkt_edge(scale):
     """Grid edge for a size factor: scale 1 is nlpkkt240's order (N = 240)."""
     return max(3, int(round(240.0 * scale ** (1.0 / 3.0))))

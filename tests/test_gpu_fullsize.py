@@ -4,6 +4,8 @@ product is cheap even at 28 M nonzeros) the size-independent properties of the
 operation are checked: linearity, agreement of the general and the symmetric
 path, symmetry of the bilinear form, the beta path, and a checksum through the
 column sums."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -18,10 +20,13 @@ FULL = [
     ("syn-cant", lambda: synth.syn_cant(1.0), True),
     ("syn-nd24k", lambda: synth.syn_nd24k(1.0), True),
     ("syn-webbase", lambda: synth.syn_webbase(1.0), False),
-    # BASELINE config 4's stand-in at a tenth of its nonzeros (77 M, 616 MB of values: beyond the
-    # Infinity Cache); the bench gates the full 734 M on every run
-    ("syn-nlpkkt-e90", lambda: synth.syn_nlpkkt_rows(90), True),
-]
+    # BASELINE config 4's stand-in at an eighth of its nonzeros (95 M, 760 MB of values: beyond the
+    # Infinity Cache); the bench gates the full 769 M on every run, and SPX_TEST_BENCH_SIZE=1 adds
+    # the bench size itself here (minutes of host time: generation, CSR product, tuning)
+    ("syn-nlpkkt-e120", lambda: synth.syn_nlpkkt_rows(120), True),
+    # rounds 1-2's matrix (runs of six columns): 77 M nonzeros
+    ("syn-kkt2f-e90", lambda: synth.syn_kkt2f_rows(90), True),
+] + ([("syn-nlpkkt-e240", lambda: synth.syn_nlpkkt_rows(240), True)] if os.environ.get("SPX_TEST_BENCH_SIZE") == "1" else [])
 
 
 @pytest.fixture(scope="module", params=FULL, ids=[f[0] for f in FULL])
@@ -76,7 +81,7 @@ def test_full_size_symmetric_path_agrees_with_general(case):
     n = csr[3]
     S = tune(csr, {"spx.rt.nr_threads": "8", "spx.rt.keep_encoded": "false"}, sym=True)
     # beyond 16 M nonzeros in the triangle, runs of consecutive columns are read once
-    assert (S.info().sym_segments > 0) == (name == "syn-nlpkkt-e90")
+    assert (S.info().sym_segments > 0) == name.startswith(("syn-nlpkkt-e", "syn-kkt2f-e"))
     x, z = synth.random_x(n), synth.random_x(n, seed=23)
     yg, ys = mult(A, 0.5, x), mult(S, 0.5, x)
     check_y(csr, x, ys, 0.5)

@@ -36,39 +36,52 @@ def run_bench(world, extra, port):
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("name,extra,tiles", [
+    # (a general-path run on several ranks also takes the symmetric path, in the same invocation)
     ("nlpkkt", ["--edge", "28"], False),
     ("nlpkkt-sym", ["--edge", "28", "--symmetric"], False),
     ("nlpkkt-sym-segments", ["--edge", "28", "--symmetric", "--opt", "spx.gpu.sym_segments=true"], False),
+    ("kkt2f-sym", ["--workload", "syn-kkt2f", "--edge", "28", "--symmetric"], False),
+    ("kkt2f-sym-segments", ["--workload", "syn-kkt2f", "--edge", "28", "--symmetric",
+                            "--opt", "spx.gpu.sym_segments=true"], False),
     # big enough per rank (>= 16 M nonzeros in its triangle) for the library to choose the segments itself
-    ("nlpkkt-sym-auto", ["--edge", "100", "--symmetric", "--host-threads", "16"], False),
+    ("kkt2f-sym-auto", ["--workload", "syn-kkt2f", "--edge", "100", "--symmetric", "--host-threads", "16"], False),
     ("nd24k-sym", ["--workload", "syn-nd24k", "--scale", "0.15", "--symmetric"], True),
     ("nd24k-sym-atomic", ["--workload", "syn-nd24k", "--scale", "0.15", "--symmetric",
                           "--opt", "spx.gpu.sym_spill=atomic"], True),
     ("webbase", ["--workload", "syn-webbase", "--scale", "0.1"], False),
-], ids=["nlpkkt", "nlpkkt-sym", "nlpkkt-sym-segments", "nlpkkt-sym-auto", "nd24k-sym", "nd24k-sym-atomic", "webbase"])
+], ids=["nlpkkt", "nlpkkt-sym", "nlpkkt-sym-segments", "kkt2f-sym", "kkt2f-sym-segments", "kkt2f-sym-auto",
+        "nd24k-sym", "nd24k-sym-atomic", "webbase"])
 def test_ranks_share_one_gpu(world, name, extra, tiles):
     out = run_bench(world, extra, 29700 + 10 * world + len(name))
     assert out["n_gpus"] == world and out["scaling"] == "strong" and out["value"] > 0
-    assert out["parity"]["max_err_over_fp64_bound"] <= 1.0
-    ranks = out["ranks"]
-    assert [r["rank"] for r in ranks] == list(range(world))
-    # the ranks' rows tile the matrix in order, with comparable nonzero counts
-    assert ranks[0]["rows"][0] == 0 and ranks[-1]["rows"][1] == out["config"]["nrows"]
-    assert all(ranks[i]["rows"][1] == ranks[i + 1]["rows"][0] for i in range(world - 1))
-    assert sum(r["nnz"] for r in ranks) == out["config"]["nnz"]
-    assert max(r["nnz"] for r in ranks) < 1.5 * min(r["nnz"] for r in ranks)
-    if name in ("nlpkkt-sym-segments", "nlpkkt-sym-auto"):
+    paths = [out] + ([out["symmetric"]] if "symmetric" in out else [])
+    assert ("symmetric" in out) == (not out["config"]["symmetric_path"])
+    if name in ("kkt2f-sym-segments", "kkt2f-sym-auto", "nlpkkt-sym-segments"):
         assert "symseg" in out["roofline"]["kernel"]
-    sym = out["config"]["symmetric_path"]
-    sent = [r["conflict_rows_sent"] for r in ranks]
-    if sym:
-        # real cross-rank coupling: every rank but the first adds into rows of the ranks in
-        # front of it, and what travels is far less than an n-long all-reduce would move
-        assert sent[0] == 0 and all(0 < s < out["config"]["nrows"] // 2 for s in sent[1:])
-        assert sum(r["conflict_entries_received"] for r in ranks) == sum(sent)
-        assert "collective" in out and out["collective"]["kernels_only_gflops"] > 0
-    else:
-        assert sent == [0] * world
+    for res in paths:
+        assert res["parity"]["max_err_over_fp64_bound"] <= 1.0
+        ranks = res["ranks"]
+        assert [r["rank"] for r in ranks] == list(range(world))
+        # the ranks' rows tile the matrix in order, with comparable nonzero counts (of what they store)
+        assert ranks[0]["rows"][0] == 0 and ranks[-1]["rows"][1] == res["config"]["nrows"]
+        assert all(ranks[i]["rows"][1] == ranks[i + 1]["rows"][0] for i in range(world - 1))
+        assert sum(r["nnz"] for r in ranks) == res["config"]["nnz"]
+        assert max(r["balance_nnz"] for r in ranks) < 1.5 * min(r["balance_nnz"] for r in ranks)
+        # `value` is a full iteration step: it includes the hand-round of y (and the exchange)
+        col = res["collective"]
+        assert res["config"]["collective_in_value"].startswith("included")
+        assert col["full_step_gflops"] == pytest.approx(res["value"], rel=1e-3)
+        assert col["full_step_ms"] >= col["owned_rows_only_ms"] * 0.8 and col["kernels_only_gflops"] > 0
+        assert col["y_handround_bytes_received_per_rank"] > 0
+        sym = res["config"]["symmetric_path"]
+        sent = [r["conflict_rows_sent"] for r in ranks]
+        if sym:
+            # real cross-rank coupling: every rank but the first adds into rows of the ranks in
+            # front of it, and what travels is less than an n-long all-reduce would move
+            assert sent[0] == 0 and all(0 < s < res["config"]["nrows"] // 2 for s in sent[1:])
+            assert sum(r["conflict_entries_received"] for r in ranks) == sum(sent)
+        else:
+            assert sent == [0] * world
 
 
 @pytest.mark.gpu

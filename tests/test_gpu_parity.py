@@ -19,6 +19,7 @@ CASES = [
     ("web", lambda: synth.syn_webbase(0.02)),
     ("nd24k", lambda: synth.syn_nd24k(0.02)),
     ("kkt", lambda: synth.syn_nlpkkt(8)),
+    ("kkt2f", lambda: synth.syn_kkt2f(7)),
     ("band", lambda: synth.syn_bandrandom(20000)),        # leftovers gather from the LDS x window
 ]
 OPTS = [
@@ -195,11 +196,12 @@ def test_demopatt_reference_scenarios():
         check_y(csr, x, y, 0.5)
 
 
+@pytest.mark.parametrize("gen", ["kkt2f", "nlpkkt"])
 @pytest.mark.parametrize("wide", ["512", "1024", "2048"])
-def test_symmetric_segments_in_wide_rowblocks(wide):
+def test_symmetric_segments_in_wide_rowblocks(wide, gen):
     """spx.gpu.sym_wide_rows: row-blocks of up to 2048 rows (several planned ones side by side,
     common slots) give the same product."""
-    csr = synth.syn_nlpkkt_rows(36)
+    csr = synth.syn_kkt2f_rows(36) if gen == "kkt2f" else synth.syn_nlpkkt_rows(40)
     n = csr[3]
     A = tune(csr, {"spx.gpu.sym_segments": "true", "spx.gpu.sym_wide_rows": wide, "spx.rt.nr_threads": "4"}, sym=True)
     assert A.info().sym_segments == 2
@@ -220,8 +222,9 @@ def test_symmetric_segments_in_wide_rowblocks(wide):
 @pytest.mark.parametrize("name,gen", [
     ("cant", lambda: synth.syn_cant(0.1)),
     ("nd24k", lambda: synth.syn_nd24k(0.05)),
-    ("kkt", lambda: synth.syn_nlpkkt_rows(20)),
-], ids=["cant", "nd24k", "kkt"])
+    ("kkt2f", lambda: synth.syn_kkt2f_rows(20)),
+    ("nlpkkt", lambda: synth.syn_nlpkkt_rows(24)),
+], ids=["cant", "nd24k", "kkt2f", "nlpkkt"])
 def test_symmetric_read_once_segments(name, gen, threads, segs):
     """spx.gpu.sym_segments: runs of consecutive columns of the lower triangle are read once --
     the lane adds its row sum to the y tile and value * x[row] to the columns' rows (LDS slots
