@@ -142,7 +142,9 @@ def ref_matvec(exports, symmetric, x, nrows, alpha=1.0, build=True):
             return None
         L = C.CDLL(fn)
         m = build_ref.RefCsxMatrix()
-        vals = np.ascontiguousarray(e["values"], dtype=np.float64)
+        # (the templates load the value FOLLOWING a unit's last one before they notice the
+        # unit has ended, e.g. horiz_sym_tmpl.c:38-39: one element of slack, never used)
+        vals = np.concatenate([np.asarray(e["values"], dtype=np.float64), [0.0]])
         ctl = np.ascontiguousarray(e["ctl"], dtype=np.uint8)
         m.values = _dp(vals)
         m.ctl = ctl.ctypes.data_as(C.POINTER(C.c_uint8))
