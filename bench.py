@@ -42,10 +42,11 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (guides/MI355X_MICROARCH.md)
 MALL_BYTES = 256 << 20  # Infinity Cache
 ALPHA = 0.5
 BATCHES = 5             # OUTER_LOOPS of the reference harness
-REF_BASELINE_THREADS = [8, 16, 32, 64]   # the counts cpu_baseline() may try
+REF_BASELINE_THREADS = [8, 16, 32, 64, 128]   # the counts cpu_baseline() may try (the largest three the host has cores for)
 DEFAULT_EDGE = 240      # syn-nlpkkt grid edge = nlpkkt240's: 27 993 600 rows, 769 M nonzeros (nlpkkt240: 760.6 M), 6.2 GB of values
 SAMPLE_EDGE = 150       # its CPU-baseline sample: the same generator at 1/4 of the nonzeros (187 M, 1.5 GB of values:
                         # three times the 2 x 256 MB of L3 of the GPU box's host)
+SYMMETRIC_WORKLOADS = ("syn-nlpkkt", "syn-kkt2f", "syn-cant", "syn-nd24k")
 SLICED = {"syn-nlpkkt": "nlpkkt", "syn-kkt2f": "kkt2f"}     # workloads with a row-sliced generator (sparsex_amd/synth.py)
 
 
@@ -218,22 +219,77 @@ def baseline_workloads():
             ("syn-webbase", lambda: synth.syn_webbase(1.0), False)]
 
 
-def prebuild_reference_baseline(only=None):
+def prebuild_reference_baseline(only=None, edge=60):
     """build(): instantiate the reference's templates (oracle/_ref) for the pattern
-    sets the baselines meet at the thread counts bench.py may pick on the GPU box."""
+    sets the baselines meet at the thread counts bench.py may pick on the GPU box.
+    The nlpkkt sample is tuned here at a smaller grid edge (the container has 8 cores);
+    which patterns a partition holds, and in which order it met them, varies with the
+    partition boundaries, so every ordered selection of the ids seen is built."""
+    import itertools
     from oracle import build_ref
+    from sparsex_amd import synth
     done = set()
     for name, gen, sym in baseline_workloads():
         if only and name not in only:
             continue
-        csr = gen()
+        csr = synth.syn_nlpkkt_rows(edge) if name == "syn-nlpkkt" else gen()
+        seen, flags = set(), set()
         for t in REF_BASELINE_THREADS:
             for e in baseline_partitions(csr, t, sym):
                 key = _ref_key(e) + (sym,)
+                seen.update(key[0])
+                flags.add(key[1:])
                 if key[0] and key not in done:
                     build_ref.build(key[0], sym, key[1], key[2], opt="-O3")
                     done.add(key)
+        if name == "syn-nlpkkt" and 0 < len(seen) <= 5:
+            for k in range(1, len(seen) + 1):
+                for ids in itertools.permutations(sorted(seen), k):
+                    for fl in flags:
+                        key = (ids,) + fl
+                        if key not in done:
+                            build_ref.build(ids, sym, fl[0], fl[1], opt="-O3")
+                            done.add(key)
     return len(done)
+
+
+def host_topology():
+    """[(cpu, socket, core)] of the hardware threads this process may run on."""
+    out = []
+    for c in sorted(os.sched_getaffinity(0)):
+        try:
+            base = "/sys/devices/system/cpu/cpu%d/topology/" % c
+            pkg = int(open(base + "physical_package_id").read())
+            core = int(open(base + "core_id").read())
+        except (OSError, ValueError):
+            pkg, core = 0, c
+        out.append((c, pkg, core))
+    return out
+
+
+def pick_cpus(threads):
+    """CPUs for `threads` pinned workers: one hardware thread per physical core, the
+    sockets filled evenly and in turn (partition i next to partition i + 1), SMT
+    siblings only when there are more threads than cores."""
+    topo = host_topology()
+    by_sock = {}
+    for c, pkg, core in topo:
+        by_sock.setdefault(pkg, {}).setdefault(core, []).append(c)
+    socks = sorted(by_sock)
+    firsts = {p: [sorted(v)[0] for _, v in sorted(by_sock[p].items())] for p in socks}
+    rest = {p: [c for _, v in sorted(by_sock[p].items()) for c in sorted(v)[1:]] for p in socks}
+    cpus = []
+    per = -(-threads // len(socks))
+    for p in socks:
+        take = (firsts[p] + rest[p])[:per]
+        cpus += take
+    cpus = cpus[:threads]
+    spare = [c for c, _, _ in topo if c not in cpus]
+    while len(cpus) < threads and spare:
+        cpus.append(spare.pop(0))
+    while len(cpus) < threads:                      # more threads than CPUs: share
+        cpus.append(cpus[len(cpus) % max(len(topo), 1)])
+    return cpus, len(socks), sum(len(firsts[p]) for p in socks)
 
 
 def _time_baseline(ex, csr, x, n, threads, symmetric, loops, batches=5):
@@ -250,7 +306,21 @@ def _time_baseline(ex, csr, x, n, threads, symmetric, loops, batches=5):
     L.oracle_time_threads_sym.argtypes = [C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_long,
                                           C.c_double, C.c_int, C.c_int, vp, vp, vp]
     y = np.zeros(n)
-    cpus = (C.c_int * threads)(*sorted(os.sched_getaffinity(0))[:threads])
+    cpu_list, _, _ = pick_cpus(threads)
+    cpus = (C.c_int * threads)(*cpu_list)
+    # first touch: every partition's values / ctl / diagonal are copied by a thread that runs
+    # on the CPU its worker will be pinned to, so the pages land on that CPU's memory node
+    # (the reference's per-thread preprocessing allocates a partition's arrays on the thread that
+    # built it, include/sparsex/internals/CsxBuild.hpp:134-202)
+    home = os.sched_getaffinity(0)
+    try:
+        for i, e in enumerate(ex):
+            os.sched_setaffinity(0, {cpu_list[i]})
+            for k in ("values", "ctl", "dvalues"):
+                if e.get(k) is not None:
+                    e[k] = np.array(e[k], copy=True)
+    finally:
+        os.sched_setaffinity(0, home)
     # the reference's own template code, one specialised routine per partition, where
     # oracle/_ref holds a build for every partition's pattern set
     sos = []
@@ -342,9 +412,10 @@ def cpu_baseline(csr, symmetric, budget_s=20.0, sample=""):
     from sparsex_amd import synth
     rp, ci, va, n = csr
     cores = host_cores()
+    _, sockets, phys = pick_cpus(1)
     nnz = int(rp[-1])
     x = synth.random_x(n)
-    cands = [t for t in REF_BASELINE_THREADS if t <= cores] or [cores]
+    cands = ([t for t in REF_BASELINE_THREADS if t <= cores] or [cores])[-3:]
     best = None
     tried = {}
     t_start = time.perf_counter()
@@ -366,9 +437,12 @@ def cpu_baseline(csr, symmetric, budget_s=20.0, sample=""):
     return {"value": round(2.0 * nnz / sec / 1e9, 3), "unit": "GFLOP/s", "cores": t,
             "kind": kind,
             "sample": "%smedian of 5 batches x %d SpMVs (alpha=0.5), one partition per pinned thread, "
-                      "%s; thread counts tried (GFLOP/s): %s; host has %d cores" % (
-                          sample, loops, "local buffers + conflict-map reduction" if symmetric
-                          else "spin barriers", json.dumps(tried), cores)}
+                      "threads spread over the %d socket%s (one per physical core first), every partition's arrays "
+                      "first-touched on its worker's CPU, %s; thread counts tried (GFLOP/s): %s; host has %d "
+                      "hardware threads on %d physical cores" % (
+                          sample, loops, sockets, "s" if sockets > 1 else "",
+                          "local buffers + conflict-map reduction" if symmetric
+                          else "spin barriers", json.dumps(tried), cores, phys)}
 
 
 # ---- measurement helpers ------------------------------------------------------------------
@@ -885,7 +959,7 @@ def main():
                "ms_per_step": res.pop("ms_per_step"), "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": "f64"}
         out.update(res)
-    if world > 1 and not args.symmetric and not args.no_configs:
+    if world > 1 and not args.symmetric and not args.no_configs and args.workload in SYMMETRIC_WORKLOADS and not args.mtx:
         # the same matrix through the symmetric path in the same invocation: here the conflict rows
         # really travel (RCCL point-to-point) before the hand-round
         del wl
@@ -905,7 +979,7 @@ def main():
             else:
                 csr_s = (wl.rp, wl.ci, wl.va, n)
                 note = "sample: the whole bench matrix; "
-            out["cpu_baseline"] = cpu_baseline(csr_s, args.symmetric, 20.0, note)
+            out["cpu_baseline"] = cpu_baseline(csr_s, args.symmetric, 30.0, note)
             del csr_s
         if world == 1 and not args.no_configs and args.workload == "syn-nlpkkt" and not args.mtx:
             cfgs = {}

@@ -52,9 +52,12 @@ typedef struct {              /* map_t, include/sparsex/internals/Map.hpp:23-27 
 typedef struct {
     int nthreads;
     slot_t *slots;
-    atomic_int count;
-    atomic_int sense;
-    atomic_int stop;
+    /* (a cache line each: the arrivals' read-modify-writes of `count` must not invalidate the
+       line the waiters spin on -- with 128 threads on two sockets that is what a barrier costs) */
+    _Alignas(64) atomic_int count;
+    _Alignas(64) atomic_int sense;
+    _Alignas(64) atomic_int stop;
+    _Alignas(64) int pad_;
     /* symmetric */
     int symmetric;
     double **locals;          /* [nthreads] raw buffers, locals[0] = y            */
@@ -69,7 +72,7 @@ static void barrier_wait(pool_t *p, int *local_sense)
         atomic_store(&p->count, p->nthreads);
         atomic_store(&p->sense, *local_sense);
     } else {
-        while (atomic_load(&p->sense) != *local_sense)
+        while (atomic_load_explicit(&p->sense, memory_order_acquire) != *local_sense)
             __builtin_ia32_pause();
     }
 }

@@ -466,6 +466,8 @@ static void emit_and_upload(spx_matrix_t *A)
     A->first_block_row = A->own_lo;
     for (const SpxRowBlock &rb : gs.rbs) A->first_block_row = std::min<idx_t>(A->first_block_row, (idx_t) rb.row0);
     finalize_stream(gs, (size_t) A->nrows);
+    if (sym) mark_private_rowblocks(gs, (size_t) A->nrows, A->own_lo, A->own_hi);
+    std::vector<std::pair<uint32_t, uint32_t>>().swap(gs.direct_cols);
     gs.waves = (uint32_t) A->waves;
     gs.sym_atomic = A->sym_atomic && !A->deterministic;
     gs.deterministic = A->deterministic;

@@ -3,6 +3,7 @@
 #include "threads.hpp"
 
 #include <algorithm>
+#include <iterator>
 #include <cassert>
 #include <cstring>
 
@@ -624,6 +625,13 @@ void RbBuilder::slot_symseg_groups(const SpxRowBlock &rb)
             out.push_back(one);
         }
     }
+    for (const Group &g : out) {
+        if (g.slot0 != SPX_NO_SLOT) continue;
+        const int dcol = (g.kind == SPX_KIND_HORIZ || g.kind == SPX_KIND_DIAG) ? (int) g.step
+                         : (g.kind == SPX_KIND_ADIAG ? -(int) g.step : 0);
+        for (uint32_t sidx = 0; sidx < g.nseg; ++sidx)
+            out_.direct_cols.emplace_back((uint32_t)((int64_t) g.col0 + (int64_t) sidx * dcol), (uint32_t) g.width);
+    }
     groups_.swap(out);
 }
 
@@ -963,6 +971,7 @@ void append_stream(GpuStream &dst, GpuStream &&src)
         dst.cidx.swap(src.cidx);
         dst.segrows.swap(src.segrows);
         dst.spill_col.swap(src.spill_col);
+        dst.direct_cols.swap(src.direct_cols);
         dst.rbs.swap(src.rbs);
         dst.shared.swap(src.shared);
     } else {
@@ -982,6 +991,7 @@ void append_stream(GpuStream &dst, GpuStream &&src)
         dst.cidx.insert(dst.cidx.end(), src.cidx.begin(), src.cidx.end());
         dst.segrows.insert(dst.segrows.end(), src.segrows.begin(), src.segrows.end());
         dst.spill_col.insert(dst.spill_col.end(), src.spill_col.begin(), src.spill_col.end());
+        dst.direct_cols.insert(dst.direct_cols.end(), src.direct_cols.begin(), src.direct_cols.end());
         dst.rbs.insert(dst.rbs.end(), src.rbs.begin(), src.rbs.end());
         dst.shared.insert(dst.shared.end(), src.shared.begin(), src.shared.end());
     }
@@ -1256,6 +1266,25 @@ void finalize_stream(GpuStream &s, size_t nrows)
     s.pass_stride = stride;
 }
 
+void mark_private_rowblocks(GpuStream &s, size_t nrows, idx_t own_lo, idx_t own_hi)
+{
+    std::vector<char> touched(nrows + 8, 0);
+    for (uint32_t g : s.slot_group_col)
+        for (uint32_t c = g; c < g + 8; ++c) touched[c] = 1;
+    for (const auto &d : s.direct_cols)
+        for (uint32_t c = d.first; c < d.first + d.second && c < nrows; ++c) touched[c] = 1;
+    for (uint32_t r : s.mirror_rows) touched[r] = 1;
+    // (prefix counts: a row-block asks about a range of rows)
+    std::vector<uint32_t> upto(nrows + 1, 0);
+    for (size_t r = 0; r < nrows; ++r) upto[r + 1] = upto[r] + (touched[r] ? 1u : 0u);
+    for (SpxRowBlock &rb : s.rbs) {
+        rb.flags &= (uint8_t) ~SPX_RB_PRIVATE;
+        const size_t lo = rb.row0, hi = (size_t) rb.row0 + rb.n_rows;
+        if ((rb.flags & SPX_RB_SHARED) || (idx_t) lo < own_lo || (idx_t) hi > own_hi || hi > nrows) continue;
+        if (upto[hi] == upto[lo]) rb.flags |= SPX_RB_PRIVATE;
+    }
+}
+
 void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsigned nthreads)
 {
     assert(p.type == ENC_H);
@@ -1409,19 +1438,52 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsi
     // at a time, the lanes want width.
     auto recut_plan = [&](size_t pl, std::vector<RowSeg> &rowsegs) {
         if (!prm.recut_linear) return;
-        std::vector<Single> pts;
-        for (const Piece &pc : lin_pieces[pl]) {
-            const Elem &u = p.elems[pc.elem];
-            for (size_t k = pc.a; k < pc.b; ++k) {
-                idx_t r, c;
-                unit_elem_coords(u, k, r, c);
-                pts.push_back(Single{r - 1, c - 1, p.pool[u.voff + k]});
-            }
-        }
         auto by_row_col = [](const Single &a, const Single &b) {
             return a.row < b.row || (a.row == b.row && a.col < b.col);
         };
-        std::sort(pts.begin(), pts.end(), by_row_col);
+        // A mined unit whose nonzeros have no neighbours along their rows gains nothing from the
+        // re-cut -- each of its nonzeros would end up a leftover with a column offset and a row
+        // of its own (4 bytes of index per nonzero, a gather pass) where the unit is one 8-byte
+        // descriptor for the whole run: the main diagonal of a KKT system, whose rows hold their
+        // stencil far from it, is such a unit.  Those stay what the miner made them.
+        std::vector<Single> pts;
+        {
+            struct Pt { Single s; uint32_t piece; };
+            std::vector<Pt> all;
+            for (size_t q = 0; q < lin_pieces[pl].size(); ++q) {
+                const Piece &pc = lin_pieces[pl][q];
+                const Elem &u = p.elems[pc.elem];
+                for (size_t k = pc.a; k < pc.b; ++k) {
+                    idx_t r, c;
+                    unit_elem_coords(u, k, r, c);
+                    all.push_back(Pt{Single{r - 1, c - 1, p.pool[u.voff + k]}, (uint32_t) q});
+                }
+            }
+            std::sort(all.begin(), all.end(), [&](const Pt &a, const Pt &b) { return by_row_col(a.s, b.s); });
+            std::vector<uint32_t> with_neighbour(lin_pieces[pl].size(), 0);
+            for (size_t a = 0; a < all.size();) {
+                size_t b = a + 1;
+                while (b < all.size() && all[b].s.row == all[a].s.row && all[b].s.col == all[b - 1].s.col + 1) ++b;
+                if (b - a >= 2)
+                    for (size_t k = a; k < b; ++k) ++with_neighbour[all[k].piece];
+                a = b;
+            }
+            std::vector<char> kept(lin_pieces[pl].size(), 0);
+            for (size_t q = 0; q < lin_pieces[pl].size(); ++q) {
+                const Piece &pc = lin_pieces[pl][q];
+                if (with_neighbour[q] == 0 && pc.b - pc.a >= 4) {
+                    kept[q] = 1;
+                    pieces[pl].push_back(pc);
+                }
+            }
+            pts.reserve(all.size());
+            std::vector<Piece> rest;
+            for (size_t q = 0; q < lin_pieces[pl].size(); ++q)
+                if (!kept[q]) rest.push_back(lin_pieces[pl][q]);
+            for (const Pt &t : all)
+                if (!kept[t.piece]) pts.push_back(t.s);
+            lin_pieces[pl].swap(rest);
+        }
         size_t nseg = 0;
         for (size_t a = 0; a < pts.size(); ++nseg) {
             size_t b = a + 1;
@@ -1510,9 +1572,29 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsi
         for (size_t i = 0; i < plans.size();) {
             size_t j = i + 1;
             if (joinable(i, true)) {
+                // (... as long as the columns in front of the row-block that its segments touch
+                // still fit its slots: a segment without a slot adds to y itself, one global
+                // atomic per nonzero -- a 27-point stencil of edge 240 reaches 3 x (rows + 482)
+                // columns, which overflowed the former 4096 slots at 1024 rows and cost 2x)
+                const idx_t row0g = p.row_start + plans[i].row_lo;
+                auto seg_groups = [&](size_t q, std::vector<idx_t> &g) {
+                    g.clear();
+                    for (const SymSeg *sg : rb_segs[q])
+                        for (idx_t c = sg->col & ~(idx_t) 7; c < sg->col + sg->width && c < row0g; c += 8) g.push_back(c);
+                    std::sort(g.begin(), g.end());
+                    g.erase(std::unique(g.begin(), g.end()), g.end());
+                };
+                std::vector<idx_t> uni, g, merged;
+                seg_groups(i, uni);
                 while (j < plans.size() && joinable(j, true) &&
-                       (size_t)(plans[j].row_hi - plans[i].row_lo) <= wide_seg)
+                       (size_t)(plans[j].row_hi - plans[i].row_lo) <= wide_seg) {
+                    seg_groups(j, g);
+                    merged.clear();
+                    std::set_union(uni.begin(), uni.end(), g.begin(), g.end(), std::back_inserter(merged));
+                    if (merged.size() * 8 > SPX_MAX_WIDE_SLOTS) break;
+                    uni.swap(merged);
                     ++j;
+                }
             } else if (joinable(i, false)) {
                 size_t e = elems_of(i);
                 while (j < plans.size() && joinable(j, false) &&

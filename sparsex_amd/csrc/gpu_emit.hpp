@@ -10,6 +10,7 @@
 #include "gpu_format.h"
 #include "partition.hpp"
 
+#include <utility>
 #include <vector>
 
 namespace spx {
@@ -50,6 +51,9 @@ struct GpuStream {
     // multiples of eight); slot i of the stream belongs to column
     // slot_group_col[i / 8] + i % 8
     std::vector<uint32_t> slot_group_col;
+    // host side, emission only: {first column, width} of read-once segments that found no slot
+    // and add straight to y (what mark_private_rowblocks needs to know besides the slots)
+    std::vector<std::pair<uint32_t, uint32_t>> direct_cols;
     // symmetric slice: mirror-image nonzeros that land, thinly spread, on rows in front of
     // the own rows (a stencil matrix's constraint couplings seen from the last process) are
     // not worth row-blocks of their own (a workgroup per handful of nonzeros): they are kept
@@ -127,6 +131,10 @@ void append_stream(GpuStream &dst, GpuStream &&src);
 // its row-block header: one dependent memory round trip less per workgroup.
 // Only the used entries are ever read.  Call once, after the last emit_gpu().
 void finalize_stream(GpuStream &s, size_t nrows);
+
+// Symmetric path, after finalize_stream: flags the row-blocks whose rows receive nothing from
+// outside (SPX_RB_PRIVATE, see gpu_format.h).  Only row-blocks inside [own_lo, own_hi) qualify.
+void mark_private_rowblocks(GpuStream &s, size_t nrows, idx_t own_lo, idx_t own_hi);
 
 // Symmetric path: the strictly lower triangle held by `lower` (rows local to
 // the partition) plus its mirror image, as one general partition in global

@@ -57,7 +57,8 @@
                                      (streams with SPX_PASS_SYMSEG only).  A descriptor
                                      still holds a 9-bit row; its pass adds the first row
                                      of its part of the row-block (SpxPass::elem0)      */
-#define SPX_MAX_WIDE_SLOTS 4096   /* transposed-sum slots of such a row-block           */
+#define SPX_MAX_WIDE_SLOTS 8192   /* transposed-sum slots of such a row-block (64 KB of LDS;
+                                     with the y tile 80 KB: two workgroups per CU)        */
 #define SPX_MAX_RB_ELEMS   8192   /* nonzeros per row-block (16-bit counters)    */
 #define SPX_MAX_SEG_WIDTH  8      /* columns per row segment                      */
 #define SPX_HORIZ_CHUNK    8      /* horizontal units are cut into such chunks   */
@@ -175,6 +176,11 @@ typedef struct {
 
 #define SPX_RB_SHARED 1u  /* owns one chunk of an over-long row; the partial
                              goes to carry[carry_slot] and a fix-up kernel sums */
+#define SPX_RB_PRIVATE 2u /* symmetric path, atomic hand-over: nobody else adds to the rows of
+                             this row-block (no slot group of any row-block, no slot-less
+                             read-once segment, no mirror list reaches them), so it STORES them,
+                             y = alpha * (sums + d * x) + beta * y, and csx_sym_init_kernel leaves
+                             them out: no init pass and no read-modify-write for these rows  */
 
 /* rows split over several row-blocks: y[row] = sum of carry[first..first+n) */
 typedef struct {

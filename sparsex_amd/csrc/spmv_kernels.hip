@@ -20,6 +20,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -52,6 +53,8 @@ struct KernelArgs {
     double *spill;           // symmetric tiles: transposed sums of columns owned by other row-blocks
     const uint32_t *slot_col;  // ... or (atomic hand-over) the first column of every group of eight slots
     double alpha, beta;
+    const double *dvalues_priv;   // atomic hand-over: diagonal for the row-blocks that store their rows
+    double beta_priv;             // ... and the caller's beta for them (beta above is 1 after the init pass)
     uint32_t n_rb;
     uint32_t pass_stride;    // pass headers of row-block i start at passes[i * pass_stride]
 };
@@ -607,8 +610,19 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, uint32_t blocks_p
     if (rb.flags & SPX_RB_SHARED) {
         if (threadIdx.x == 0) a.carry[rb.carry_slot] = tile[0];
     } else if (ATOMIC) {
-        for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS)
-            atomicAdd(&a.y[(size_t) rb.row0 + i], a.alpha * tile[i]);
+        if ((rb.flags & SPX_RB_PRIVATE) && a.dvalues_priv) {
+            // nobody else adds to these rows (mark_private_rowblocks): stored, with the diagonal
+            // term and beta * y; the init pass leaves them out
+            for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS) {
+                const size_t g = (size_t) rb.row0 + i;
+                double t = a.alpha * (tile[i] + a.dvalues_priv[g] * a.x[g]);
+                if (a.beta_priv != 0.0) t += a.beta_priv * a.y[g];
+                a.y[g] = t;
+            }
+        } else {
+            for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS)
+                atomicAdd(&a.y[(size_t) rb.row0 + i], a.alpha * tile[i]);
+        }
 #ifndef SPX_ABL_SEG_NOFLUSH
         for (int i = threadIdx.x; i < n_slots; i += BLOCK_THREADS)
             atomicAdd(&a.y[(size_t) gcol_lds[i >> 3] + (i & 7)], a.alpha * lds[i]);
@@ -634,13 +648,13 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, uint32_t blocks_p
     uint32_t blocks_per_xcd, uint32_t /*pad*/, const double *values_, const SpxUnitDesc *descs_, \
     const uint8_t *cidx_, const uint16_t *segrows_, const double *x_, double *y_,               \
     double *carry_, const double *dvalues_, double *spill_, const uint32_t *slot_col_,         \
-    double alpha_, double beta_
+    double alpha_, double beta_, const double *dvalues_priv_, double beta_priv_
 #define SPX_KERNEL_ARGS(a)                                                                       \
     KernelArgs a;                                                                                \
     a.rbs = rbs_; a.passes = passes_; a.n_rb = n_rb_; a.pass_stride = pass_stride_;              \
     a.values = values_; a.descs = descs_; a.cidx = cidx_; a.segrows = segrows_; a.x = x_;        \
     a.y = y_; a.carry = carry_; a.dvalues = dvalues_; a.spill = spill_; a.slot_col = slot_col_;  \
-    a.alpha = alpha_;                                                                            \
+    a.alpha = alpha_; a.dvalues_priv = dvalues_priv_; a.beta_priv = beta_priv_;                  \
     a.beta = beta_
 
 // (Individual scalar arguments, most urgent first.  Preloading them into SGPRs
@@ -817,12 +831,17 @@ struct DeviceMatrix {
     uint32_t *fix_ptr = nullptr, *fix_idx = nullptr;
     size_t n_fix_ptr = 0, n_fix_idx = 0;
     bool sym_atomic = false;   // transposed sums go straight into y (global atomics), no second kernel
+    size_t n_private_rb = 0;
+    size_t max_slot_groups = 0;   // of the row-block with the most slots
     bool has_symsegs = false;     // the stream holds SPX_PASS_SYMSEG passes
     bool has_symtiles = false;    // ... SPX_PASS_SYMTILE passes
     bool wave_tiles = false;      // a y tile per wavefront, summed in wavefront order before the write-out
     bool deterministic = false;   // spx.gpu.deterministic: wave tiles + fixed-order hand-overs, pinned
     uint32_t *slot_col = nullptr;
     size_t n_slot_col = 0;
+    // rows of SPX_RB_PRIVATE row-blocks, merged and ascending: the init pass of the atomic
+    // hand-over leaves them out (empty when there are too many pieces to be worth it)
+    std::vector<std::pair<size_t, size_t>> private_rows;
     // symmetric slice: thin mirror image as a CSR over rows of other processes
     uint32_t n_mirror_rows = 0;
     size_t n_mirror_nnz = 0;
@@ -926,7 +945,19 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
         m->mirror_val = upload(s.mirror_val);
     }
     m->sym_atomic = (s.sym_atomic || m->has_symsegs) && m->has_tiles;
-    if (m->has_symsegs && (size_t) m->lds_doubles * sizeof(double) + 2048u > 64u * 1024u) {
+    {
+        std::vector<std::pair<size_t, size_t>> pr;
+        for (const SpxRowBlock &rb : s.rbs)
+            if (rb.flags & SPX_RB_PRIVATE) pr.emplace_back((size_t) rb.row0, (size_t) rb.row0 + rb.n_rows);
+        std::sort(pr.begin(), pr.end());
+        for (const auto &r : pr) {
+            if (!m->private_rows.empty() && m->private_rows.back().second == r.first) m->private_rows.back().second = r.second;
+            else m->private_rows.push_back(r);
+        }
+        m->n_private_rb = pr.size();
+        for (const SpxRowBlock &rb : s.rbs) m->max_slot_groups = std::max<size_t>(m->max_slot_groups, (rb.n_slots + 7u) / 8u);
+    }
+    if (m->has_symsegs && (size_t) m->lds_doubles * sizeof(double) + 8192u > 64u * 1024u) {
         // wide row-blocks with an x window on top: beyond the default dynamic LDS limit
         const int bytes = 160 * 1024;
         (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&csx_spmv_symseg_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -988,6 +1019,8 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
     a.dvalues = fused ? m->dvalues : nullptr;
     a.pass_stride = m->pass_stride;
     a.slot_col = m->slot_col;
+    a.dvalues_priv = nullptr;      // (set where the atomic hand-over honours SPX_RB_PRIVATE)
+    a.beta_priv = 0.0;
 
     uint32_t blocks = (m->n_rb + 7u) & ~7u;
     if (m->symmetric && !fused) {
@@ -998,10 +1031,27 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
         // process owns or adds to -- are anybody's business)
         const int t = 256;
         const size_t first = m->init_lo, last = m->init_lo ? m->own_hi : m->nrows;
-        if (last > first)
-            hipLaunchKernelGGL(csx_sym_init_kernel, dim3((unsigned)((last - first + t - 1) / t)),
-                               dim3(t), 0, stream, d_y, d_x, m->dvalues, first, last,
-                               m->own_lo, m->own_hi, alpha, beta);
+        auto init_rows = [&](size_t lo, size_t hi) {
+            if (hi > lo)
+                hipLaunchKernelGGL(csx_sym_init_kernel, dim3((unsigned)((hi - lo + t - 1) / t)),
+                                   dim3(t), 0, stream, d_y, d_x, m->dvalues, lo, hi,
+                                   m->own_lo, m->own_hi, alpha, beta);
+        };
+        if (m->sym_atomic && !m->wave_tiles && m->private_rows.size() <= 8) {
+            // (row-blocks that nobody else adds to store their rows themselves: SPX_RB_PRIVATE)
+            size_t at = first;
+            for (const auto &r : m->private_rows) {
+                if (r.second <= at) continue;
+                if (r.first >= last) break;
+                init_rows(at, std::min(std::max(r.first, at), last));
+                at = std::max(at, r.second);
+            }
+            init_rows(at, last);
+            a.dvalues_priv = m->dvalues;
+            a.beta_priv = beta;
+        }
+        else
+            init_rows(first, last);
         // the thin mirror list stores its rows; whatever else lands on them (spilled tile
         // sums) is added afterwards
         if (m->n_mirror_rows)
@@ -1014,7 +1064,8 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
 #define SPX_LAUNCH(KERNEL, W, LDS)                                                               \
     hipLaunchKernelGGL(KERNEL<W>, dim3(blocks), dim3(64 * W), LDS, stream, a.rbs, a.passes,      \
                        a.n_rb, a.pass_stride, blocks >> 3, 0u, a.values, a.descs, a.cidx,        \
-                       a.segrows, a.x, a.y, a.carry, a.dvalues, a.spill, a.slot_col, a.alpha, a.beta)
+                       a.segrows, a.x, a.y, a.carry, a.dvalues, a.spill, a.slot_col, a.alpha, a.beta, \
+                       a.dvalues_priv, a.beta_priv)
     bool need_symfix = false;
     if (blocks && m->wave_tiles) {
         // a copy of slots + y tile per wavefront: as many wavefronts as fit the LDS
@@ -1034,7 +1085,7 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
         // symmetric tiles: slots + y tile in dynamic LDS, then the rows collect
         // what other row-blocks spilled for them
         const size_t lds = m->lds_doubles * sizeof(double);
-        const size_t lds_a = lds + SPX_MAX_WIDE_SLOTS / 8 * sizeof(uint32_t);   // + the slot groups' columns
+        const size_t lds_a = lds + m->max_slot_groups * sizeof(uint32_t);   // + the slot groups' columns
         if (m->sym_atomic && m->has_symsegs && !m->has_symtiles) {
             // (16 wavefronts per workgroup, so that 2048-row row-blocks keep the SIMDs full, were
             // measured: 0.90 ms against 0.835 with 8, syn-nlpkkt; not built)

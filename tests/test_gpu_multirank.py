@@ -55,7 +55,7 @@ def test_ranks_share_one_gpu(world, name, extra, tiles):
     out = run_bench(world, extra, 29700 + 10 * world + len(name))
     assert out["n_gpus"] == world and out["scaling"] == "strong" and out["value"] > 0
     paths = [out] + ([out["symmetric"]] if "symmetric" in out else [])
-    assert ("symmetric" in out) == (not out["config"]["symmetric_path"])
+    assert ("symmetric" in out) == (not out["config"]["symmetric_path"] and name != "webbase")
     if name in ("kkt2f-sym-segments", "kkt2f-sym-auto", "nlpkkt-sym-segments"):
         assert "symseg" in out["roofline"]["kernel"]
     for res in paths:

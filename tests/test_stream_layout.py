@@ -354,7 +354,11 @@ def test_wide_rowblocks_share_their_slots(tmp_path, wide):
     assert rows.max() <= int(wide) and (rows.max() > 512) == (wide != "512")
     if wide != "512":
         # fewer slots in total: a column that two neighbouring row-blocks reached is one slot now
-        assert int(s.rbs["n_slots"].astype(np.int64).sum()) < 0.8 * 2 * n
+        B = tune((rp, ci, va, n), {"spx.gpu.sym_segments": "true", "spx.gpu.sym_wide_rows": "512", "spx.rt.nr_threads": "2"},
+                 sym=True, host_only=True)
+        g = str(tmp_path / "narrow.spx")
+        B.save(g)
+        assert int(s.rbs["n_slots"].astype(np.int64).sum()) < 0.8 * int(Stream(g).rbs["n_slots"].astype(np.int64).sum())
         wide_rb = s.rbs[rows > 512][0]
         bases = {int(s.passes[int(wide_rb["pass_off"]) + t]["elem0"]) for t in range(int(wide_rb["n_pass"]))
                  if int(s.passes[int(wide_rb["pass_off"]) + t]["kind"]) in (0, 5)}
