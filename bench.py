@@ -192,6 +192,26 @@ def host_cores():
         return os.cpu_count() or 1
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup CPU bandwidth limit), or None.  The GPU
+    boxes of this pool show 256 hardware threads but run under `cpu.max = 1600000 100000`, i.e.
+    16 CPUs: more spinning threads than that are throttled, not run in parallel."""
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] == "max":
+                    return None
+                return float(txt[0]) / float(txt[1])
+            q = float(txt[0])
+            if q <= 0:
+                return None
+            return q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        except (OSError, ValueError, IndexError):
+            continue
+    return None
+
+
 # ---- CPU baseline (the only place that touches oracle/) -----------------------------------
 
 def baseline_partitions(csr, threads, symmetric):
@@ -415,12 +435,15 @@ def cpu_baseline(csr, symmetric, budget_s=20.0, sample=""):
     _, sockets, phys = pick_cpus(1)
     nnz = int(rp[-1])
     x = synth.random_x(n)
-    cands = ([t for t in REF_BASELINE_THREADS if t <= cores] or [cores])[-3:]
+    quota = cpu_quota()
+    # (threads beyond twice the container's CPU quota only measure the throttling of the spin barriers)
+    usable = cores if quota is None else max(1, min(cores, int(2 * quota)))
+    cands = ([t for t in REF_BASELINE_THREADS if t <= usable] or [usable])[-3:]
     best = None
     tried = {}
     t_start = time.perf_counter()
     share = budget_s / max(len(cands), 1)
-    for t in cands[::-1] if cores >= 64 else cands:
+    for t in cands[::-1] if usable >= 64 else cands:
         # (many-core hosts: start at the larger counts, where the best has been)
         if tried and time.perf_counter() - t_start > budget_s:
             break
@@ -442,7 +465,9 @@ def cpu_baseline(csr, symmetric, budget_s=20.0, sample=""):
                       "hardware threads on %d physical cores" % (
                           sample, loops, sockets, "s" if sockets > 1 else "",
                           "local buffers + conflict-map reduction" if symmetric
-                          else "spin barriers", json.dumps(tried), cores, phys)}
+                          else "spin barriers", json.dumps(tried), cores, phys) + (
+                          "" if quota is None else "; the container's CPU quota (cgroup cpu.max) is %.0f CPUs -- "
+                          "'all physical cores' of the host are not available to this process" % quota)}
 
 
 # ---- measurement helpers ------------------------------------------------------------------

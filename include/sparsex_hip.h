@@ -30,6 +30,9 @@
  *                           of merging equal row segments of consecutive rows
  *   spx.gpu.recut_linear    "false": vertical / diagonal / strided units always run one
  *                           nonzero per lane, even where they line up along rows
+ *   spx.gpu.keep_units      "false": ... even those none of whose nonzeros has a neighbour along
+ *                           its row (default: such a unit stays one descriptor -- the main diagonal
+ *                           of a KKT system -- instead of a leftover nonzero per row)
  *   spx.gpu.wave_tiles      a y tile per wavefront instead of one per workgroup: "true",
  *                           "false", "auto" (default: spx_mat_tune() measures it)
  *   spx.gpu.deterministic   "true": bit-identical repeated products (wave tiles, the
@@ -88,6 +91,12 @@ extern "C" {
  * time (they share its scratch: the partial sums of over-long rows, the spill array
  * of the symmetric tiles, the exchange buffers); different matrices are independent.
  * The calling thread's current HIP device must be the matrix's device (checked).
+ * spx_mat_set_entry() on a tuned matrix patches the value where it lives, in HBM, after a
+ * hipDeviceSynchronize(): products still in flight finish with the old value; a captured
+ * graph replayed later reads the new one.
+ * Once an exchange plan is attached (spx_hip_mat_dist_attach), the plain entry points above
+ * write only the rows this process owns or adds to, [first conflict row, last owned row):
+ * the rest of y_dev is left as it is (it is nobody's business any more).
  */
 spx_error_t spx_hip_matvec_mult(spx_value_t alpha, const spx_matrix_t *A,
                                 const spx_value_t *x_dev, spx_value_t *y_dev,

@@ -439,6 +439,10 @@ static void emit_and_upload(spx_matrix_t *A)
             }
             A->has_symsegs = use_segs;
             if (use_segs) A->sym_atomic = true;
+            // (read-once segments always hand over atomically, on top of the init pass: rows
+            // without nonzeros of their own -- the state rows of a KKT system, whose stored
+            // triangle lies in the multiplier rows -- need no row-block)
+            if (use_segs) gp.skip_empty = true;
             emit_pieces(fulls, &tiles, use_segs ? &segs : nullptr);
             // thinly spread mirror image on rows of other processes: a CSR over those rows
             for (size_t k = 0; k < thin.size(); ++k) {
@@ -489,6 +493,13 @@ static void emit_and_upload(spx_matrix_t *A)
     if (!A->host_only) {
         A->dev = device_upload(gs, (size_t) A->nrows, (size_t) A->ncols, sym, A->own_lo, A->own_hi,
                                A->device_ordinal);
+        // (a matrix that is attached to an exchange plan keeps its limited init range over a
+        // re-upload: the state lives with the matrix, not with the device copy)
+        if (A->dist && sym) {
+            idx_t first_init = A->first_block_row;
+            if (A->has_tiles && !A->conflict_rows.empty()) first_init = std::min(first_init, A->conflict_rows.front());
+            device_set_init_rows(A->dev, (size_t) first_init);
+        }
         keep_index(A, std::move(gs));
     } else {
         A->host_stream.reset(new GpuStream(std::move(gs)));
@@ -742,6 +753,7 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     A->emit_params.sym_remine = cfg.get_bool("spx.gpu.sym_remine");
     A->emit_params.sym_once = cfg.get_bool("spx.gpu.sym_once");
     A->emit_params.recut_linear = cfg.get_bool("spx.gpu.recut_linear");
+    A->emit_params.keep_units = cfg.get_bool("spx.gpu.keep_units");
     A->emit_params.x_window = cfg.get_bool("spx.gpu.x_window");
     {
         const std::string m = cfg.get_str("spx.gpu.sym_segments");

@@ -1471,7 +1471,7 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsi
             std::vector<char> kept(lin_pieces[pl].size(), 0);
             for (size_t q = 0; q < lin_pieces[pl].size(); ++q) {
                 const Piece &pc = lin_pieces[pl][q];
-                if (with_neighbour[q] == 0 && pc.b - pc.a >= 4) {
+                if (prm.keep_units && with_neighbour[q] == 0 && pc.b - pc.a >= 4) {
                     kept[q] = 1;
                     pieces[pl].push_back(pc);
                 }

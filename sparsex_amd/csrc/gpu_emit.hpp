@@ -106,6 +106,8 @@ struct GpuEmitParams {
                                   // rows share one descriptor as a dense block
     bool recut_linear = true;     // spx.gpu.recut_linear: nonzeros of vertical / diagonal /
                                   // strided units that line up along their rows run as row segments
+    bool keep_units = true;       // spx.gpu.keep_units: ... but a mined unit none of whose nonzeros has a
+                                  // neighbour along its row stays the unit it is (one descriptor)
     bool sym_remine = true;       // spx.gpu.sym_remine (see append_sym_expanded)
     bool x_window = true;         // spx.gpu.x_window: stage a window of x in LDS for leftovers
                                   // whose columns lie close together

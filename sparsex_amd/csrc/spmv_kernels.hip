@@ -59,6 +59,14 @@ struct KernelArgs {
     uint32_t pass_stride;    // pass headers of row-block i start at passes[i * pass_stride]
 };
 
+// XCD-aware order of the row-blocks: workgroup b runs on XCD b % 8; XCD x walks the row-blocks
+// [first[x], first[x + 1]) in turn, a contiguous part of the matrix that holds an eighth of its
+// VALUES (not of its row-blocks: a symmetric KKT matrix keeps its stored triangle in the second
+// half of its rows, and an eighth of the row-blocks by count left five XCDs without work)
+struct XcdSplit {
+    uint32_t first[9];
+};
+
 // wavefronts per workgroup: the kernels exist for 2, 4 and 8 (spx.gpu.waves, or
 // measured at tune time: small matrices like 2, leftover-heavy ones 8)
 constexpr int MAX_WAVES_PER_BLOCK = 8;
@@ -502,7 +510,7 @@ __device__ __forceinline__ void run_pass(const KernelArgs &a, const SpxRowBlock 
 // only thing in this library whose order of additions is not fixed is the LDS adds
 // of different wavefronts of a workgroup into the shared tile.
 template <bool SYM, bool ATOMIC, int WAVES_PER_BLOCK, bool DET = false, bool SEGS = false, bool TILES = true>
-__device__ __forceinline__ void spmv_body(const KernelArgs &a, uint32_t blocks_per_xcd,
+__device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &xs,
                                           double *lds)
 {
     constexpr int BLOCK_THREADS = 64 * WAVES_PER_BLOCK;
@@ -511,10 +519,11 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, uint32_t blocks_p
 #endif
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // XCD-aware order: workgroup b runs on XCD b % 8; give each XCD one
-    // contiguous eighth of the row-blocks (the grid is a multiple of 8)
-    const uint32_t rb_idx = (blockIdx.x & 7u) * blocks_per_xcd + (blockIdx.x >> 3);
-    if (rb_idx >= a.n_rb) return;
+    // XCD-aware order: workgroup b runs on XCD b % 8 and takes that XCD's next row-block
+    // (the grid is 8 x the longest of the eight lists)
+    const uint32_t xcd = blockIdx.x & 7u;
+    const uint32_t rb_idx = xs.first[xcd] + (blockIdx.x >> 3);
+    if (rb_idx >= xs.first[xcd + 1u]) return;
 
     // the pass headers sit at a fixed stride, so the wave's first two are
     // fetched together with the row-block header, not after it
@@ -645,7 +654,7 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, uint32_t blocks_p
 
 #define SPX_KERNEL_PARAMS                                                                        \
     const SpxRowBlock *rbs_, const SpxPass *passes_, uint32_t n_rb_, uint32_t pass_stride_,      \
-    uint32_t blocks_per_xcd, uint32_t /*pad*/, const double *values_, const SpxUnitDesc *descs_, \
+    XcdSplit xcd_split, const double *values_, const SpxUnitDesc *descs_, \
     const uint8_t *cidx_, const uint16_t *segrows_, const double *x_, double *y_,               \
     double *carry_, const double *dvalues_, double *spill_, const uint32_t *slot_col_,         \
     double alpha_, double beta_, const double *dvalues_priv_, double beta_priv_
@@ -667,7 +676,7 @@ void csx_spmv_kernel(SPX_KERNEL_PARAMS)
 {
     SPX_KERNEL_ARGS(a);
     extern __shared__ double lds_dyn[];      // y tile, then the x window
-    spmv_body<false, false, WAVES>(a, blocks_per_xcd, lds_dyn);
+    spmv_body<false, false, WAVES>(a, xcd_split, lds_dyn);
 }
 
 template <int WAVES>
@@ -676,7 +685,7 @@ void csx_spmv_symtile_kernel(SPX_KERNEL_PARAMS)
 {
     SPX_KERNEL_ARGS(a);
     extern __shared__ double lds_dyn[];
-    spmv_body<true, false, WAVES>(a, blocks_per_xcd, lds_dyn);
+    spmv_body<true, false, WAVES>(a, xcd_split, lds_dyn);
 }
 
 // the atomic hand-over kernel for streams that also hold read-once row segments
@@ -687,7 +696,7 @@ void csx_spmv_symseg_kernel(SPX_KERNEL_PARAMS)
 {
     SPX_KERNEL_ARGS(a);
     extern __shared__ double lds_dyn[];
-    spmv_body<true, true, WAVES, false, true>(a, blocks_per_xcd, lds_dyn);
+    spmv_body<true, true, WAVES, false, true>(a, xcd_split, lds_dyn);
 }
 
 // ... and the same for streams with such segments and no tiles at all (a stencil matrix)
@@ -697,7 +706,7 @@ void csx_spmv_symseg_notile_kernel(SPX_KERNEL_PARAMS)
 {
     SPX_KERNEL_ARGS(a);
     extern __shared__ double lds_dyn[];
-    spmv_body<true, true, WAVES, false, true, false>(a, blocks_per_xcd, lds_dyn);
+    spmv_body<true, true, WAVES, false, true, false>(a, xcd_split, lds_dyn);
 }
 
 template <int WAVES>
@@ -706,7 +715,7 @@ void csx_spmv_det_kernel(SPX_KERNEL_PARAMS)
 {
     SPX_KERNEL_ARGS(a);
     extern __shared__ double lds_dyn[];      // a y tile per wavefront, then the x window
-    spmv_body<false, false, WAVES, true>(a, blocks_per_xcd, lds_dyn);
+    spmv_body<false, false, WAVES, true>(a, xcd_split, lds_dyn);
 }
 
 template <int WAVES>
@@ -715,7 +724,7 @@ void csx_spmv_symtile_det_kernel(SPX_KERNEL_PARAMS)
 {
     SPX_KERNEL_ARGS(a);
     extern __shared__ double lds_dyn[];
-    spmv_body<true, false, WAVES, true>(a, blocks_per_xcd, lds_dyn);
+    spmv_body<true, false, WAVES, true>(a, xcd_split, lds_dyn);
 }
 
 // (forcing eight wavefronts per SIMD on this kernel -- amdgpu_waves_per_eu(8, 8): 64 VGPRs and
@@ -726,7 +735,7 @@ void csx_spmv_symtile_atomic_kernel(SPX_KERNEL_PARAMS)
 {
     SPX_KERNEL_ARGS(a);
     extern __shared__ double lds_dyn[];
-    spmv_body<true, true, WAVES>(a, blocks_per_xcd, lds_dyn);
+    spmv_body<true, true, WAVES>(a, xcd_split, lds_dyn);
 }
 
 // symmetric tiles, second step: every row collects the transposed sums that
@@ -813,6 +822,7 @@ struct DeviceMatrix {
     uint32_t pass_stride = 1;
     size_t own_lo = 0, own_hi = 0;
     size_t init_lo = 0;       // symmetric slice with an exchange plan: first row to clear
+    bool init_limited = false;   // ... and whether one is attached (spx_hip_mat_dist_attach)
     uint32_t n_rb = 0, n_shared = 0, n_carry = 0;
     SpxRowBlock *rbs = nullptr;
     double *values = nullptr;
@@ -826,6 +836,7 @@ struct DeviceMatrix {
     // symmetric tiles
     bool has_tiles = false;
     int waves = 4;            // wavefronts per workgroup of the SpMV kernel (2, 4 or 8)
+    int waves_req = 4;        // ... as asked for (per-wavefront tiles may lower `waves` to fit the LDS)
     uint32_t n_spill = 0, lds_doubles = SPX_MAX_RB_ROWS;
     double *spill = nullptr;
     uint32_t *fix_ptr = nullptr, *fix_idx = nullptr;
@@ -833,6 +844,8 @@ struct DeviceMatrix {
     bool sym_atomic = false;   // transposed sums go straight into y (global atomics), no second kernel
     size_t n_private_rb = 0;
     size_t max_slot_groups = 0;   // of the row-block with the most slots
+    XcdSplit xcd_split;           // row-blocks of every XCD (balanced by values)
+    uint32_t xcd_longest = 0;     // ... and the length of the longest list
     bool has_symsegs = false;     // the stream holds SPX_PASS_SYMSEG passes
     bool has_symtiles = false;    // ... SPX_PASS_SYMTILE passes
     bool wave_tiles = false;      // a y tile per wavefront, summed in wavefront order before the write-out
@@ -893,7 +906,7 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
     m->symmetric = symmetric;
     m->sym_fused = symmetric && s.sym_fused;
     m->pass_stride = s.pass_stride;
-    m->waves = (s.waves == 2 || s.waves == 8) ? (int) s.waves : 4;
+    m->waves = m->waves_req = (s.waves == 2 || s.waves == 8) ? (int) s.waves : 4;
     m->own_lo = (size_t) own_lo;
     m->own_hi = (size_t) own_hi;
     m->n_rb = (uint32_t) s.rbs.size();
@@ -956,6 +969,26 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
         }
         m->n_private_rb = pr.size();
         for (const SpxRowBlock &rb : s.rbs) m->max_slot_groups = std::max<size_t>(m->max_slot_groups, (rb.n_slots + 7u) / 8u);
+    }
+    {
+        // an eighth of the work to every XCD: values held (+ a constant per row-block for its
+        // headers and its write-out)
+        const size_t n = s.rbs.size();
+        std::vector<uint64_t> upto(n + 1, 0);
+        for (size_t i = 0; i < n; ++i) {
+            const uint64_t end = i + 1 < n ? s.rbs[i + 1].val_off : (uint64_t) s.values.size();
+            upto[i + 1] = upto[i] + (end > s.rbs[i].val_off ? end - s.rbs[i].val_off : 0) + 64u + 2u * s.rbs[i].n_rows;
+        }
+        m->xcd_split.first[0] = 0;
+        for (uint32_t x = 1; x < 8; ++x) {
+            const uint64_t want = upto[n] * x / 8;
+            size_t i = (size_t)(std::lower_bound(upto.begin(), upto.end(), want) - upto.begin());
+            i = std::min(std::max<size_t>(i, m->xcd_split.first[x - 1]), n);
+            m->xcd_split.first[x] = (uint32_t) i;
+        }
+        m->xcd_split.first[8] = (uint32_t) n;
+        for (uint32_t x = 0; x < 8; ++x)
+            m->xcd_longest = std::max(m->xcd_longest, m->xcd_split.first[x + 1] - m->xcd_split.first[x]);
     }
     if (m->has_symsegs && (size_t) m->lds_doubles * sizeof(double) + 8192u > 64u * 1024u) {
         // wide row-blocks with an x window on top: beyond the default dynamic LDS limit
@@ -1022,7 +1055,7 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
     a.dvalues_priv = nullptr;      // (set where the atomic hand-over honours SPX_RB_PRIVATE)
     a.beta_priv = 0.0;
 
-    uint32_t blocks = (m->n_rb + 7u) & ~7u;
+    uint32_t blocks = 8u * m->xcd_longest;
     if (m->symmetric && !fused) {
         // y <- beta*y + alpha*diag*x on the owned rows, 0 elsewhere; the
         // row-blocks (stored lower triangle and its mirror image) then
@@ -1030,7 +1063,7 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
         // (attached to an exchange plan: only [init_lo, own_hi) -- the rows this
         // process owns or adds to -- are anybody's business)
         const int t = 256;
-        const size_t first = m->init_lo, last = m->init_lo ? m->own_hi : m->nrows;
+        const size_t first = m->init_limited ? m->init_lo : 0, last = m->init_limited ? m->own_hi : m->nrows;
         auto init_rows = [&](size_t lo, size_t hi) {
             if (hi > lo)
                 hipLaunchKernelGGL(csx_sym_init_kernel, dim3((unsigned)((hi - lo + t - 1) / t)),
@@ -1063,7 +1096,7 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
     a.spill = m->spill;
 #define SPX_LAUNCH(KERNEL, W, LDS)                                                               \
     hipLaunchKernelGGL(KERNEL<W>, dim3(blocks), dim3(64 * W), LDS, stream, a.rbs, a.passes,      \
-                       a.n_rb, a.pass_stride, blocks >> 3, 0u, a.values, a.descs, a.cidx,        \
+                       a.n_rb, a.pass_stride, m->xcd_split, a.values, a.descs, a.cidx,                \
                        a.segrows, a.x, a.y, a.carry, a.dvalues, a.spill, a.slot_col, a.alpha, a.beta, \
                        a.dvalues_priv, a.beta_priv)
     bool need_symfix = false;
@@ -1124,7 +1157,11 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
     HIP_CHECK(hipGetLastError());
 }
 
-void device_set_init_rows(DeviceMatrix *m, size_t first_row) { m->init_lo = first_row; }
+void device_set_init_rows(DeviceMatrix *m, size_t first_row)
+{
+    m->init_lo = first_row;
+    m->init_limited = true;
+}
 
 void device_set_sym_atomic(DeviceMatrix *m, bool on)
 {
@@ -1136,10 +1173,13 @@ void device_set_sym_atomic(DeviceMatrix *m, bool on)
 void device_set_wave_tiles(DeviceMatrix *m, bool on)
 {
     m->wave_tiles = on;
-    if (!on) return;
+    if (!on) {
+        m->waves = m->waves_req;       // (a trial with per-wavefront tiles may have lowered it)
+        return;
+    }
     m->sym_atomic = false;
     const size_t per_copy = (size_t) m->lds_doubles * sizeof(double);
-    int w = m->waves;
+    int w = m->waves_req;
     while (w > 2 && (size_t) w * per_copy > 160u * 1024u) w /= 2;
     if ((size_t) w * per_copy > 160u * 1024u) throw FatalError("row-blocks too large for per-wavefront tiles");
     m->waves = w;
@@ -1164,7 +1204,7 @@ bool device_has_spill(const DeviceMatrix *m) { return m->has_tiles && m->n_spill
 
 void device_set_waves(DeviceMatrix *m, int waves)
 {
-    m->waves = (waves == 2 || waves == 8) ? waves : 4;
+    m->waves = m->waves_req = (waves == 2 || waves == 8) ? waves : 4;
     if (m->wave_tiles) device_set_wave_tiles(m, true);     // (re-checks the LDS budget)
 }
 
@@ -1313,6 +1353,7 @@ void device_poke_mirror(DeviceMatrix *m, size_t index, double value)
 {
     if (index >= m->n_mirror_nnz) throw FatalError("value index outside the mirror list");
     HIP_CHECK(hipSetDevice(m->device));
+    HIP_CHECK(hipDeviceSynchronize());     // (see device_poke)
     HIP_CHECK(hipMemcpy(m->mirror_val + index, &value, sizeof(value), hipMemcpyHostToDevice));
 }
 
@@ -1331,6 +1372,9 @@ void device_poke(DeviceMatrix *m, bool diagonal, size_t index, double value)
     if (diagonal ? (!m->dvalues || index >= m->nrows) : index >= m->n_values)
         throw FatalError("value index outside the stream");
     HIP_CHECK(hipSetDevice(m->device));
+    // products enqueued on a non-blocking stream (spx_hip_matvec_*) are not ordered against
+    // this copy by themselves: wait for whatever the device still runs before the value changes
+    HIP_CHECK(hipDeviceSynchronize());
     HIP_CHECK(hipMemcpy((diagonal ? m->dvalues : m->values) + index, &value, sizeof(value),
                         hipMemcpyHostToDevice));
 }

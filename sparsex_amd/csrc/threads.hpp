@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <exception>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -49,19 +50,35 @@ void parallel_for(size_t n, unsigned nthreads, F fn)
         for (;;) {
             const size_t i = next.fetch_add(1);
             if (i >= n) return;
+            // (whatever a piece throws -- a FatalError, a bad_alloc of a multi-GB vector -- is
+            // carried to the caller: an exception leaving a std::thread would end the process)
+            auto fail = [&](const std::string &what) {
+                std::lock_guard<std::mutex> lk(mtx);
+                if (!failed) err = what;
+                failed = true;
+                next.store(n);
+            };
             try {
                 fn(i);
             } catch (const FatalError &e) {
-                std::lock_guard<std::mutex> lk(mtx);
-                if (!failed) err = e.what;
-                failed = true;
-                next.store(n);
+                fail(e.what);
+            } catch (const std::exception &e) {
+                fail(std::string("host worker: ") + e.what());
+            } catch (...) {
+                fail("host worker: unknown exception");
             }
         }
     };
     const unsigned t = (unsigned) std::min<size_t>(nthreads, n);
     std::vector<std::thread> th;
-    for (unsigned k = 1; k < t; ++k) th.emplace_back(work);
+    th.reserve(t);
+    for (unsigned k = 1; k < t; ++k) {
+        try {
+            th.emplace_back(work);
+        } catch (const std::exception &) {
+            break;                  // no more threads to be had: the ones running (and the caller) do the work
+        }
+    }
     work();
     for (auto &x : th) x.join();
     if (failed) throw FatalError(err);

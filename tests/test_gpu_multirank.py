@@ -70,7 +70,7 @@ def test_ranks_share_one_gpu(world, name, extra, tiles):
         # `value` is a full iteration step: it includes the hand-round of y (and the exchange)
         col = res["collective"]
         assert res["config"]["collective_in_value"].startswith("included")
-        assert col["full_step_gflops"] == pytest.approx(res["value"], rel=1e-3)
+        assert col["full_step_gflops"] == pytest.approx(res["value"], rel=5e-3, abs=0.02)
         assert col["full_step_ms"] >= col["owned_rows_only_ms"] * 0.8 and col["kernels_only_gflops"] > 0
         assert col["y_handround_bytes_received_per_rank"] > 0
         sym = res["config"]["symmetric_path"]
