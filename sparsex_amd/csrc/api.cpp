@@ -462,8 +462,40 @@ static void emit_and_upload(spx_matrix_t *A)
             if (gs.sym_fused) full.nr_rows = (size_t) A->nrows;
             emit_gpu(full, gp, gs, hw);
         }
-    } else {
+    } else if (A->col_phases <= 1) {
         emit_pieces(A->parts, nullptr);
+    } else {
+        // column phases: the matrix as a sum of column slices, every slice a run of row-blocks
+        // of its own that is launched after the one in front of it (SPX_RB_PHASE_START).  A unit
+        // goes where its anchor column lies.  Slice 0 covers every row (it stores y), the
+        // others only rows that hold something of theirs (they add).
+        const size_t K = A->col_phases;
+        GpuEmitParams keep = gp;
+        gp.max_rows = std::max<size_t>(gp.max_rows, SPX_MAX_WIDE_ROWS);    // (a slice of a row is short)
+        for (size_t k = 0; k < K; ++k) {
+            const idx_t c_lo = (idx_t)((int64_t) A->ncols * (int64_t) k / (int64_t) K) + 1;           // 1-based
+            const idx_t c_hi = (idx_t)((int64_t) A->ncols * (int64_t)(k + 1) / (int64_t) K) + 1;
+            std::vector<Partition> sub(nown);
+            parallel_for(nown, hw, [&](size_t i) {
+                const Partition &p = A->parts[i];
+                Partition &q = sub[i];
+                q.nr_rows = p.nr_rows; q.nr_cols = p.nr_cols; q.type = p.type; q.row_start = p.row_start;
+                q.pool = p.pool;
+                for (size_t e = 0; e < p.elems_size; ++e)
+                    if (p.elems[e].col >= c_lo && p.elems[e].col < c_hi) {
+                        q.elems.push_back(p.elems[e]);
+                        q.nnz += p.elems[e].size;
+                    }
+                q.elems_size = q.elems.size();
+            });
+            gp.skip_empty = k > 0;
+            const size_t rb0 = gs.rbs.size();
+            emit_pieces(sub, nullptr);
+            if (k > 0 && gs.rbs.size() > rb0) gs.rbs[rb0].flags |= SPX_RB_PHASE_START;
+        }
+        gp = keep;
+        // (an over-long row is summed by a fix-up kernel that stores: not with slices that add)
+        if (!gs.shared.empty()) throw FatalError("column phases: the matrix holds rows that are split over row-blocks");
     }
     A->conflict_rows.clear();
     if (sym && !gs.sym_fused) stream_touched_rows(gs, A->own_lo, A->conflict_rows);
@@ -800,11 +832,49 @@ static spx_matrix_t *do_tune(spx_input_t *in)
         throw FatalError("bad spx.gpu.wave_tiles");
     }
     A->wave_tiles = wt_mode == "true" ? 1 : 0;          // (auto: off until measured)
-    emit_and_upload(A.get());
+    const std::string ph_mode = cfg.get_str("spx.gpu.col_phases");
+    long ph_fixed = ph_mode == "auto" ? 0 : strtol(ph_mode.c_str(), nullptr, 10);
+    if (ph_mode != "auto" && (ph_fixed < 1 || ph_fixed > 8)) {
+        log_msg(LOG_ERR, "spx.gpu.col_phases: 1 .. 8 or auto\n");
+        throw FatalError("bad spx.gpu.col_phases");
+    }
+    A->col_phases = (!sym && ph_fixed > 1) ? (size_t) ph_fixed : 1;
+    try {
+        emit_and_upload(A.get());
+    } catch (const FatalError &) {
+        if (A->col_phases <= 1) throw;
+        A->col_phases = 1;                              // (over-long rows: no phases)
+        emit_and_upload(A.get());
+    }
     const bool tune_spill = spill_mode == "auto" && !A->deterministic && !A->has_symsegs;
     const bool tune_wt = wt_mode == "auto" && !A->deterministic && !A->has_symsegs;
     if (A->dev && A->nnz_stored >= 100000 && (autotune || tune_spill || tune_wt))
         autotune_launch(A.get(), autotune, tune_spill, tune_wt);
+    // column phases (auto): where the leftovers dominate and x is far larger than the L2 of an
+    // XCD, the gathers miss it more often than not (syn-webbase: 1.6 M line fills for 2.5 M
+    // gathers); slices of the columns that fit are measured against the plain stream
+    if (A->dev && !sym && ph_mode == "auto" && A->n_shared == 0 && A->nnz_stored >= 100000 &&
+        2 * A->n_delta_elems >= A->nnz_stored && (size_t) A->ncols * sizeof(val_t) >= ((size_t) 6 << 20)) {
+        auto best_of = [&]() {
+            double best = device_time_spmv(A->dev, 10, 100);
+            for (int rep = 0; rep < 3; ++rep) best = std::min(best, device_time_spmv(A->dev, 0, 100));
+            return best;
+        };
+        const double t_plain = best_of();
+        const size_t K = std::min<size_t>(8, ((size_t) A->ncols * sizeof(val_t) + ((size_t) 5 << 19) - 1) / ((size_t) 5 << 19));   // 2.5 MB of x per slice
+        double t_ph = 2.0 * t_plain;
+        try {
+            A->col_phases = K;
+            emit_and_upload(A.get());
+            t_ph = best_of();
+        } catch (const FatalError &) {
+        }
+        if (t_ph >= 0.97 * t_plain) {
+            A->col_phases = 1;
+            emit_and_upload(A.get());
+        }
+        log_msg(LOG_INFO, "column phases: %zu slices %.2f us, plain %.2f us per SpMV\n", K, 1e6 * t_ph, 1e6 * t_plain);
+    }
     if (!cfg.get_bool("spx.rt.keep_encoded")) {
         A->parts.clear();
         A->parts.shrink_to_fit();

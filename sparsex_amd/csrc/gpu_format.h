@@ -176,6 +176,12 @@ typedef struct {
 
 #define SPX_RB_SHARED 1u  /* owns one chunk of an over-long row; the partial
                              goes to carry[carry_slot] and a fix-up kernel sums */
+#define SPX_RB_PHASE_START 4u /* general path, column phases (spx.gpu.col_phases): the stream holds the
+                             matrix as a sum of column slices, A = A_0 + A_1 + ..., each slice a run of
+                             row-blocks of its own, launched one after the other: slice k > 0 adds to
+                             what the slices in front of it stored (beta = 1), and a workgroup only
+                             ever gathers x from one slice of the columns -- a slice that fits the 4 MB
+                             of L2 of an XCD.  This flag marks the first row-block of a slice k > 0  */
 #define SPX_RB_PRIVATE 2u /* symmetric path, atomic hand-over: nobody else adds to the rows of
                              this row-block (no slot group of any row-block, no slot-less
                              read-once segment, no mirror list reaches them), so it STORES them,

@@ -843,9 +843,12 @@ struct DeviceMatrix {
     size_t n_fix_ptr = 0, n_fix_idx = 0;
     bool sym_atomic = false;   // transposed sums go straight into y (global atomics), no second kernel
     size_t n_private_rb = 0;
+    bool use_private = false;  // SPX_RB_PRIVATE honoured (few large pieces; else one init launch over everything)
     size_t max_slot_groups = 0;   // of the row-block with the most slots
-    XcdSplit xcd_split;           // row-blocks of every XCD (balanced by values)
-    uint32_t xcd_longest = 0;     // ... and the length of the longest list
+    // one launch per column phase (general path; otherwise a single one over all row-blocks):
+    // the row-blocks of every XCD (balanced by values) and the length of the longest list
+    std::vector<XcdSplit> xcd_split;
+    std::vector<uint32_t> xcd_longest;
     bool has_symsegs = false;     // the stream holds SPX_PASS_SYMSEG passes
     bool has_symtiles = false;    // ... SPX_PASS_SYMTILE passes
     bool wave_tiles = false;      // a y tile per wavefront, summed in wavefront order before the write-out
@@ -968,27 +971,43 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
             else m->private_rows.push_back(r);
         }
         m->n_private_rb = pr.size();
+        // worth it where it takes a good part of the init pass away in a few pieces (every gap
+        // is a launch of its own: syn-nd24k, a 25 us product, lost 4 us to nine of them)
+        size_t covered = 0;
+        for (const auto &r : m->private_rows) covered += r.second - r.first;
+        if (m->private_rows.size() > 4 || covered * 4 < nrows) m->private_rows.clear();
+        m->use_private = !m->private_rows.empty();
         for (const SpxRowBlock &rb : s.rbs) m->max_slot_groups = std::max<size_t>(m->max_slot_groups, (rb.n_slots + 7u) / 8u);
     }
     {
-        // an eighth of the work to every XCD: values held (+ a constant per row-block for its
-        // headers and its write-out)
+        // an eighth of the work of a launch to every XCD: values held (+ a constant per
+        // row-block for its headers and its write-out)
         const size_t n = s.rbs.size();
         std::vector<uint64_t> upto(n + 1, 0);
         for (size_t i = 0; i < n; ++i) {
             const uint64_t end = i + 1 < n ? s.rbs[i + 1].val_off : (uint64_t) s.values.size();
             upto[i + 1] = upto[i] + (end > s.rbs[i].val_off ? end - s.rbs[i].val_off : 0) + 64u + 2u * s.rbs[i].n_rows;
         }
-        m->xcd_split.first[0] = 0;
-        for (uint32_t x = 1; x < 8; ++x) {
-            const uint64_t want = upto[n] * x / 8;
-            size_t i = (size_t)(std::lower_bound(upto.begin(), upto.end(), want) - upto.begin());
-            i = std::min(std::max<size_t>(i, m->xcd_split.first[x - 1]), n);
-            m->xcd_split.first[x] = (uint32_t) i;
+        std::vector<size_t> starts(1, 0);
+        for (size_t i = 1; i < n; ++i)
+            if (s.rbs[i].flags & SPX_RB_PHASE_START) starts.push_back(i);
+        starts.push_back(n);
+        for (size_t ph = 0; ph + 1 < starts.size(); ++ph) {
+            const size_t lo = starts[ph], hi = starts[ph + 1];
+            XcdSplit xs;
+            xs.first[0] = (uint32_t) lo;
+            for (uint32_t x = 1; x < 8; ++x) {
+                const uint64_t want = upto[lo] + (upto[hi] - upto[lo]) * x / 8;
+                size_t i = (size_t)(std::lower_bound(upto.begin() + lo, upto.begin() + hi + 1, want) - upto.begin());
+                i = std::min(std::max<size_t>(i, xs.first[x - 1]), hi);
+                xs.first[x] = (uint32_t) i;
+            }
+            xs.first[8] = (uint32_t) hi;
+            uint32_t longest = 0;
+            for (uint32_t x = 0; x < 8; ++x) longest = std::max(longest, xs.first[x + 1] - xs.first[x]);
+            m->xcd_split.push_back(xs);
+            m->xcd_longest.push_back(longest);
         }
-        m->xcd_split.first[8] = (uint32_t) n;
-        for (uint32_t x = 0; x < 8; ++x)
-            m->xcd_longest = std::max(m->xcd_longest, m->xcd_split.first[x + 1] - m->xcd_split.first[x]);
     }
     if (m->has_symsegs && (size_t) m->lds_doubles * sizeof(double) + 8192u > 64u * 1024u) {
         // wide row-blocks with an x window on top: beyond the default dynamic LDS limit
@@ -1055,7 +1074,9 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
     a.dvalues_priv = nullptr;      // (set where the atomic hand-over honours SPX_RB_PRIVATE)
     a.beta_priv = 0.0;
 
-    uint32_t blocks = 8u * m->xcd_longest;
+    uint32_t blocks = 0;
+    XcdSplit xcd_now;
+    const size_t n_launch = m->xcd_split.size();
     if (m->symmetric && !fused) {
         // y <- beta*y + alpha*diag*x on the owned rows, 0 elsewhere; the
         // row-blocks (stored lower triangle and its mirror image) then
@@ -1070,7 +1091,7 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
                                    dim3(t), 0, stream, d_y, d_x, m->dvalues, lo, hi,
                                    m->own_lo, m->own_hi, alpha, beta);
         };
-        if (m->sym_atomic && !m->wave_tiles && m->private_rows.size() <= 8) {
+        if (m->sym_atomic && !m->wave_tiles && m->use_private) {
             // (row-blocks that nobody else adds to store their rows themselves: SPX_RB_PRIVATE)
             size_t at = first;
             for (const auto &r : m->private_rows) {
@@ -1096,52 +1117,58 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
     a.spill = m->spill;
 #define SPX_LAUNCH(KERNEL, W, LDS)                                                               \
     hipLaunchKernelGGL(KERNEL<W>, dim3(blocks), dim3(64 * W), LDS, stream, a.rbs, a.passes,      \
-                       a.n_rb, a.pass_stride, m->xcd_split, a.values, a.descs, a.cidx,                \
+                       a.n_rb, a.pass_stride, xcd_now, a.values, a.descs, a.cidx,                     \
                        a.segrows, a.x, a.y, a.carry, a.dvalues, a.spill, a.slot_col, a.alpha, a.beta, \
                        a.dvalues_priv, a.beta_priv)
     bool need_symfix = false;
-    if (blocks && m->wave_tiles) {
-        // a copy of slots + y tile per wavefront: as many wavefronts as fit the LDS
-        const int w = m->waves;
-        const size_t lds = (size_t) w * m->lds_doubles * sizeof(double);
-        if (m->has_tiles) {
-            if (w == 2) SPX_LAUNCH(csx_spmv_symtile_det_kernel, 2, lds);
-            else if (w == 8) SPX_LAUNCH(csx_spmv_symtile_det_kernel, 8, lds);
-            else SPX_LAUNCH(csx_spmv_symtile_det_kernel, 4, lds);
-            need_symfix = m->n_spill != 0;
-        } else {
-            if (w == 2) SPX_LAUNCH(csx_spmv_det_kernel, 2, lds);
-            else if (w == 8) SPX_LAUNCH(csx_spmv_det_kernel, 8, lds);
-            else SPX_LAUNCH(csx_spmv_det_kernel, 4, lds);
+    for (size_t ph = 0; ph < n_launch; ++ph) {
+        // (column phases: slice k > 0 adds to what the slices in front of it stored)
+        xcd_now = m->xcd_split[ph];
+        blocks = 8u * m->xcd_longest[ph];
+        if (ph > 0) a.beta = 1.0;
+        if (blocks && m->wave_tiles) {
+            // a copy of slots + y tile per wavefront: as many wavefronts as fit the LDS
+            const int w = m->waves;
+            const size_t lds = (size_t) w * m->lds_doubles * sizeof(double);
+            if (m->has_tiles) {
+                if (w == 2) SPX_LAUNCH(csx_spmv_symtile_det_kernel, 2, lds);
+                else if (w == 8) SPX_LAUNCH(csx_spmv_symtile_det_kernel, 8, lds);
+                else SPX_LAUNCH(csx_spmv_symtile_det_kernel, 4, lds);
+                need_symfix = m->n_spill != 0;
+            } else {
+                if (w == 2) SPX_LAUNCH(csx_spmv_det_kernel, 2, lds);
+                else if (w == 8) SPX_LAUNCH(csx_spmv_det_kernel, 8, lds);
+                else SPX_LAUNCH(csx_spmv_det_kernel, 4, lds);
+            }
+        } else if (blocks && m->has_tiles) {
+            // symmetric tiles: slots + y tile in dynamic LDS, then the rows collect
+            // what other row-blocks spilled for them
+            const size_t lds = m->lds_doubles * sizeof(double);
+            const size_t lds_a = lds + m->max_slot_groups * sizeof(uint32_t);   // + the slot groups' columns
+            if (m->sym_atomic && m->has_symsegs && !m->has_symtiles) {
+                // (16 wavefronts per workgroup, so that 2048-row row-blocks keep the SIMDs full, were
+                // measured: 0.90 ms against 0.835 with 8, syn-nlpkkt; not built)
+                if (m->waves == 2) SPX_LAUNCH(csx_spmv_symseg_notile_kernel, 2, lds_a);
+                else if (m->waves == 8) SPX_LAUNCH(csx_spmv_symseg_notile_kernel, 8, lds_a);
+                else SPX_LAUNCH(csx_spmv_symseg_notile_kernel, 4, lds_a);
+            } else if (m->sym_atomic && m->has_symsegs) {
+                if (m->waves == 2) SPX_LAUNCH(csx_spmv_symseg_kernel, 2, lds_a);
+                else if (m->waves == 8) SPX_LAUNCH(csx_spmv_symseg_kernel, 8, lds_a);
+                else SPX_LAUNCH(csx_spmv_symseg_kernel, 4, lds_a);
+            } else if (m->sym_atomic) {
+                if (m->waves == 2) SPX_LAUNCH(csx_spmv_symtile_atomic_kernel, 2, lds_a);
+                else if (m->waves == 8) SPX_LAUNCH(csx_spmv_symtile_atomic_kernel, 8, lds_a);
+                else SPX_LAUNCH(csx_spmv_symtile_atomic_kernel, 4, lds_a);
+            } else if (m->waves == 2) SPX_LAUNCH(csx_spmv_symtile_kernel, 2, lds);
+            else if (m->waves == 8) SPX_LAUNCH(csx_spmv_symtile_kernel, 8, lds);
+            else SPX_LAUNCH(csx_spmv_symtile_kernel, 4, lds);
+            need_symfix = m->n_spill && !m->sym_atomic;
+        } else if (blocks) {
+            const size_t lds = m->lds_doubles * sizeof(double);
+            if (m->waves == 2) SPX_LAUNCH(csx_spmv_kernel, 2, lds);
+            else if (m->waves == 8) SPX_LAUNCH(csx_spmv_kernel, 8, lds);
+            else SPX_LAUNCH(csx_spmv_kernel, 4, lds);
         }
-    } else if (blocks && m->has_tiles) {
-        // symmetric tiles: slots + y tile in dynamic LDS, then the rows collect
-        // what other row-blocks spilled for them
-        const size_t lds = m->lds_doubles * sizeof(double);
-        const size_t lds_a = lds + m->max_slot_groups * sizeof(uint32_t);   // + the slot groups' columns
-        if (m->sym_atomic && m->has_symsegs && !m->has_symtiles) {
-            // (16 wavefronts per workgroup, so that 2048-row row-blocks keep the SIMDs full, were
-            // measured: 0.90 ms against 0.835 with 8, syn-nlpkkt; not built)
-            if (m->waves == 2) SPX_LAUNCH(csx_spmv_symseg_notile_kernel, 2, lds_a);
-            else if (m->waves == 8) SPX_LAUNCH(csx_spmv_symseg_notile_kernel, 8, lds_a);
-            else SPX_LAUNCH(csx_spmv_symseg_notile_kernel, 4, lds_a);
-        } else if (m->sym_atomic && m->has_symsegs) {
-            if (m->waves == 2) SPX_LAUNCH(csx_spmv_symseg_kernel, 2, lds_a);
-            else if (m->waves == 8) SPX_LAUNCH(csx_spmv_symseg_kernel, 8, lds_a);
-            else SPX_LAUNCH(csx_spmv_symseg_kernel, 4, lds_a);
-        } else if (m->sym_atomic) {
-            if (m->waves == 2) SPX_LAUNCH(csx_spmv_symtile_atomic_kernel, 2, lds_a);
-            else if (m->waves == 8) SPX_LAUNCH(csx_spmv_symtile_atomic_kernel, 8, lds_a);
-            else SPX_LAUNCH(csx_spmv_symtile_atomic_kernel, 4, lds_a);
-        } else if (m->waves == 2) SPX_LAUNCH(csx_spmv_symtile_kernel, 2, lds);
-        else if (m->waves == 8) SPX_LAUNCH(csx_spmv_symtile_kernel, 8, lds);
-        else SPX_LAUNCH(csx_spmv_symtile_kernel, 4, lds);
-        need_symfix = m->n_spill && !m->sym_atomic;
-    } else if (blocks) {
-        const size_t lds = m->lds_doubles * sizeof(double);
-        if (m->waves == 2) SPX_LAUNCH(csx_spmv_kernel, 2, lds);
-        else if (m->waves == 8) SPX_LAUNCH(csx_spmv_kernel, 8, lds);
-        else SPX_LAUNCH(csx_spmv_kernel, 4, lds);
     }
 #undef SPX_LAUNCH
     if (m->n_shared)

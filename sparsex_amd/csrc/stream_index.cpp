@@ -67,14 +67,21 @@ inline bool is_gather(const SpxPass &ps)
 
 void stream_locate(const GpuStream &s, idx_t row, idx_t col, std::vector<size_t> &out)
 {
-    // row-blocks are emitted in ascending row order: first one that ends behind `row`
-    size_t lo = 0, hi = s.rbs.size();
+    // row-blocks are emitted in ascending row order -- inside every column phase (most streams
+    // hold one): in each, the first row-block that ends behind `row`
+    std::vector<size_t> starts(1, 0);
+    for (size_t i = 1; i < s.rbs.size(); ++i)
+        if (s.rbs[i].flags & SPX_RB_PHASE_START) starts.push_back(i);
+    starts.push_back(s.rbs.size());
+    for (size_t ph = 0; ph + 1 < starts.size(); ++ph) {
+    size_t lo = starts[ph], hi = starts[ph + 1];
+    const size_t end = hi;
     while (lo < hi) {
         const size_t mid = (lo + hi) / 2;
         if ((int64_t) s.rbs[mid].row0 + s.rbs[mid].n_rows <= (int64_t) row) lo = mid + 1;
         else hi = mid;
     }
-    for (size_t i = lo; i < s.rbs.size() && (int64_t) s.rbs[i].row0 <= (int64_t) row; ++i) {
+    for (size_t i = lo; i < end && (int64_t) s.rbs[i].row0 <= (int64_t) row; ++i) {
         const SpxRowBlock &rb = s.rbs[i];
         if ((int64_t) row >= (int64_t) rb.row0 + rb.n_rows) continue;
         const int64_t rrel = (int64_t) row - rb.row0;
@@ -110,6 +117,7 @@ void stream_locate(const GpuStream &s, idx_t row, idx_t col, std::vector<size_t>
                 }
             }
         }
+    }
     }
 }
 

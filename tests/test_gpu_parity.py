@@ -316,3 +316,27 @@ def test_deterministic_mode_is_bitwise_repeatable(name, gen, sym):
         y2 = yb.copy()
         A.matvec_kernel(1.5, x, -0.5, y2)
         assert np.array_equal(y1, y2)
+
+
+@pytest.mark.parametrize("phases", ["2", "3", "auto"])
+@pytest.mark.parametrize("name,gen", [
+    ("web", lambda: synth.syn_webbase(0.1)),
+    ("band", lambda: synth.syn_bandrandom(30000)),
+    ("cant", lambda: synth.syn_cant(0.05)),
+], ids=["web", "band", "cant"])
+def test_column_phases(name, gen, phases):
+    """spx.gpu.col_phases: column slices launched one after the other (slice k > 0 adds to y):
+    same product, alpha/beta kernel included."""
+    csr = gen()
+    n = csr[3]
+    A = tune(csr, {"spx.gpu.col_phases": phases, "spx.rt.nr_threads": "2"})
+    x = synth.random_x(n)
+    y = np.full(n, np.nan)
+    A.matvec_mult(0.5, x, y)
+    check_y(csr, x, y, 0.5)
+    yo, _ = oracle_y(A, x, 0.5)
+    check_vs_oracle(csr, x, y, yo, 0.5)
+    y0 = synth.random_x(n, seed=3)
+    y1 = y0.copy()
+    A.matvec_kernel(1.5, x, -0.25, y1)
+    check_y(csr, x, y1, 1.5, -0.25, y0)

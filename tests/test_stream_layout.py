@@ -428,3 +428,66 @@ def test_symmetric_tiles_inside_a_single_rowblock_gpu():
     y = y0.copy()
     A.matvec_kernel(-1.5, x, 0.5, y)
     check_y(csr, x, y, -1.5, 0.5, y0)
+
+
+@pytest.mark.parametrize("phases", ["2", "3", "5"])
+def test_column_phases(tmp_path, phases):
+    """spx.gpu.col_phases: the stream holds the matrix as a sum of column slices, each a run of
+    row-blocks of its own (first one flagged SPX_RB_PHASE_START = 4); slice 0 covers every row,
+    the others only rows that hold something of theirs.  Same product, entries found where they
+    are, restored as saved."""
+    csr = synth.syn_webbase(0.03)
+    rp, ci, va, n = csr
+    A = tune(csr, {"spx.gpu.col_phases": phases, "spx.rt.nr_threads": "2"}, host_only=True)
+    f = str(tmp_path / "m.spx")
+    A.save(f)
+    s = Stream(f)
+    starts = np.flatnonzero((s.rbs["flags"] & 4) != 0)
+    assert len(starts) == int(phases) - 1 and starts[0] > 0
+    bounds = [0] + [int(v) for v in starts] + [len(s.rbs)]
+    K = int(phases)
+    for k in range(K):
+        part = s.rbs[bounds[k]:bounds[k + 1]]
+        r0 = part["row0"].astype(np.int64)
+        assert np.all(np.diff(r0) > 0)                                   # ascending inside a slice
+        if k == 0:
+            assert int(part["n_rows"].astype(np.int64).sum()) == n       # slice 0 stores every row
+    r, c, v, b, m = dense_of(s)
+    lo = np.array([n * k // K for k in range(K + 1)])
+    for k in range(K):                                                   # a slice holds its columns only
+        idx = np.flatnonzero((b >= bounds[k]) & (b < bounds[k + 1]))
+        assert np.all((c[idx] >= lo[k]) & (c[idx] < lo[k + 1]))
+    a = sp.csr_matrix((va, ci, rp), shape=(n, n))
+    assert abs(m.tocsr() - a).max() == 0
+    x = synth.random_x(n)
+    assert np.allclose(s.matvec(x), a @ x, rtol=1e-12, atol=1e-14)
+    row = n // 2
+    while rp[row] == rp[row + 1]:
+        row += 1
+    for k in range(rp[row], rp[row + 1]):
+        assert A.get_entry(row, int(ci[k])) == va[k]
+    A.set_entry(row, int(ci[rp[row]]), 4.25)
+    A.save(f)
+    B = sx.mat_restore(f)
+    assert B.get_entry(row, int(ci[rp[row]])) == 4.25
+
+
+def test_column_phases_give_way_to_overlong_rows(tmp_path):
+    """A row that is split over several row-blocks is summed by a fix-up kernel that stores:
+    such a matrix is emitted without phases."""
+    n = 40000
+    rng = np.random.RandomState(3)
+    cols = np.sort(rng.choice(n, 30000, replace=False))        # > 8192 of them in every third of the columns
+    rows = np.concatenate([np.zeros(cols.size, dtype=np.int64), np.arange(1, n)])
+    cc = np.concatenate([cols, rng.randint(0, n, n - 1)])
+    m = sp.coo_matrix((rng.uniform(-1, 1, rows.size), (rows, cc)), shape=(n, n)).tocsr()
+    m.sum_duplicates(); m.sort_indices()
+    csr = (m.indptr.astype(np.int32), m.indices.astype(np.int32), m.data.copy(), n)
+    A = tune(csr, {"spx.gpu.col_phases": "3"}, host_only=True)
+    assert A.info().n_shared_rows == 1
+    f = str(tmp_path / "m.spx")
+    A.save(f)
+    s = Stream(f)
+    assert not ((s.rbs["flags"] & 4) != 0).any()
+    x = synth.random_x(n)
+    assert np.allclose(s.matvec(x), m @ x, rtol=1e-12, atol=1e-14)
