@@ -6,7 +6,7 @@
 # CPU baselines).
 # usage: tools/refresh_profiles.sh <round-tag>       e.g. r02
 set -u
-R=${1:-r02}
+R=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 bash "$ROOT/tools/profile.sh" ${R}_nlpkkt > /dev/null 2>&1
 bash "$ROOT/tools/profile.sh" ${R}_nlpkkt_sym --symmetric > /dev/null 2>&1
