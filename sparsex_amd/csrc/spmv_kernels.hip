@@ -71,6 +71,40 @@ struct XcdSplit {
 // measured at tune time: small matrices like 2, leftover-heavy ones 8)
 constexpr int MAX_WAVES_PER_BLOCK = 8;
 
+// Loads of the matrix stream (values, descriptors): every byte is used once per product, so
+// they are marked non-temporal -- they should not push x out of the L2 (a stencil row-block
+// reads the same lines of x again two z-planes of row-blocks later; with the values allocated in
+// L2 like anything else, x came from the fabric 4.5 times per product instead of once).
+// SPX_STREAM_TEMPORAL builds the plain loads for comparison.
+typedef double spx_d2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int spx_u2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 ld_stream(const double2 *p)
+{
+#ifdef SPX_STREAM_TEMPORAL
+    return *p;
+#else
+    const spx_d2_t v = __builtin_nontemporal_load(reinterpret_cast<const spx_d2_t *>(p));
+    return make_double2(v.x, v.y);
+#endif
+}
+__device__ __forceinline__ double ld_stream(const double *p)
+{
+#ifdef SPX_STREAM_TEMPORAL
+    return *p;
+#else
+    return __builtin_nontemporal_load(p);
+#endif
+}
+__device__ __forceinline__ uint2 ld_stream(const uint2 *p)
+{
+#ifdef SPX_STREAM_TEMPORAL
+    return *p;
+#else
+    const spx_u2_t v = __builtin_nontemporal_load(reinterpret_cast<const spx_u2_t *>(p));
+    return make_uint2(v.x, v.y);
+#endif
+}
+
 // set bits of `mask` in lanes 1..lane (bit 0 is never set by the emitter)
 __device__ __forceinline__ uint32_t starts_upto(uint64_t mask, int lane)
 {
@@ -127,7 +161,7 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
             }
         } else {
             const uint32_t rank = (uint32_t) ps[b].rank0 + (active[b] ? starts_upto(ps[b].mask, lane) : 0u);
-            q[b] = *reinterpret_cast<const uint2 *>(a.descs + rb.desc_off + rank);
+            q[b] = ld_stream(reinterpret_cast<const uint2 *>(a.descs + rb.desc_off + rank));
         }
     }
     double2 v2[B][W / 2 > 0 ? W / 2 : 1];
@@ -137,8 +171,8 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
         const double *vals = a.values + rb.val_off + ps[b].val_off;
 #pragma unroll
         for (int p = 0; p < W / 2; ++p)
-            v2[b][p] = *reinterpret_cast<const double2 *>(vals + (uint32_t) p * 2u * nseg[b] + l[b] * 2u);
-        if (W & 1) v1[b] = vals[(uint32_t) (W / 2) * 2u * nseg[b] + l[b]];
+            v2[b][p] = ld_stream(reinterpret_cast<const double2 *>(vals + (uint32_t) p * 2u * nseg[b] + l[b] * 2u));
+        if (W & 1) v1[b] = ld_stream(vals + (uint32_t) (W / 2) * 2u * nseg[b] + l[b]);
     }
 #ifdef SPX_ABL_VALSONLY
     {
@@ -326,7 +360,7 @@ __device__ __forceinline__ void symtile_pass(const KernelArgs &a, const SpxRowBl
     double2 v2[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p)
-        v2[p] = *reinterpret_cast<const double2 *>(vals + (uint32_t) p * 2u * nseg + l * 2u);
+        v2[p] = ld_stream(reinterpret_cast<const double2 *>(vals + (uint32_t) p * 2u * nseg + l * 2u));
     const int i = (int) (l & 7u);
     const int row = (int) (ps.elem0 + (q.y & 511u)) + i;
     const uint32_t slot = q.y >> 9;
@@ -420,55 +454,80 @@ __device__ __forceinline__ void symtile_pass(const KernelArgs &a, const SpxRowBl
 // addresses; lanes of neighbouring rows mostly hit different ones) -- every value is read
 // once and used twice.  A segment without slots adds straight to y (global atomics; the
 // kernel's hand-over is atomic anyway).
-template <int W>
-__device__ __forceinline__ void symseg_pass(const KernelArgs &a, const SpxRowBlock &rb,
-                                            const SpxPass &ps, double *slots, double *tile, int lane)
+template <int W, int B>
+__device__ __forceinline__ void symseg_passes(const KernelArgs &a, const SpxRowBlock &rb,
+                                              const SpxPass (&ps)[B], double *slots, double *tile, int lane)
 {
-    const uint32_t nseg = ps.nseg;
-    const bool active = (uint32_t) lane < nseg;
-    const uint32_t l = active ? (uint32_t) lane : 0u;
-    const uint32_t rank = (uint32_t) ps.rank0 + 2u * (active ? starts_upto(ps.mask, lane) : 0u);
-    const uint2 q = *reinterpret_cast<const uint2 *>(a.descs + rb.desc_off + rank);
-    const uint32_t slot0 = a.descs[rb.desc_off + rank + 1u].col0;
-    const double *vals = a.values + rb.val_off + ps.val_off;
-    double v[W];
+    // (B passes of the same width at once, stage by stage like the unit passes: all descriptors,
+    // then all values, then x -- the pass is a chain of dependent loads, and with three values
+    // per lane one pass alone keeps too little in flight: the ablation build that hands nothing
+    // over still took 0.96 of the full kernel's 1.07 ms on the bench matrix)
+    bool active[B];
+    uint32_t l[B], nseg[B], slot0[B];
+    uint2 q[B];
 #pragma unroll
-    for (int p = 0; p < W / 2; ++p) {
-        const double2 vv = *reinterpret_cast<const double2 *>(vals + (uint32_t) p * 2u * nseg + l * 2u);
-        v[2 * p] = vv.x;
-        v[2 * p + 1] = vv.y;
+    for (int b = 0; b < B; ++b) {
+        nseg[b] = ps[b].nseg;
+        active[b] = (uint32_t) lane < nseg[b];
+        l[b] = active[b] ? (uint32_t) lane : 0u;
+        const uint32_t rank = (uint32_t) ps[b].rank0 + 2u * (active[b] ? starts_upto(ps[b].mask, lane) : 0u);
+        q[b] = ld_stream(reinterpret_cast<const uint2 *>(a.descs + rb.desc_off + rank));
+        slot0[b] = __builtin_nontemporal_load(&a.descs[rb.desc_off + rank + 1u].col0);
     }
-    if (W & 1) v[W - 1] = vals[(uint32_t) (W / 2) * 2u * nseg + l];
-    const uint32_t bits = q.y;
-    const int s = (int) ((ps.seg0 + l - ((bits >> 9) & 8191u)) & 0xffffu);
-    const uint32_t kind = (bits >> 22) & 7u;
-    const int step = (int) (bits >> 25);
-    const int drow = kind == SPX_KIND_BLOCK ? 1 : (kind >= SPX_KIND_VERT ? step : 0);
-    const int dcol = (kind == SPX_KIND_HORIZ || kind == SPX_KIND_DIAG) ? step : (kind == SPX_KIND_ADIAG ? -step : 0);
-    const int row = (int) (ps.elem0 + (bits & 511u)) + s * drow;
-    const uint32_t col = q.x + (uint32_t) (s * dcol);
-    const double *xp = a.x + col;
-    const double xr = a.x[rb.row0 + (uint32_t) row];
-    double t = 0.0;
+    double v[B][W];
 #pragma unroll
-    for (int w = 0; w < W; ++w) t = fma(v[w], xp[w], t);
-    if (!active) return;
-    atomicAdd(&tile[row], t);
-    if (slot0 != SPX_NO_SLOT) {
-        double *sl = slots + slot0 + (uint32_t) (s * dcol);
+    for (int b = 0; b < B; ++b) {
+        const double *vals = a.values + rb.val_off + ps[b].val_off;
+#pragma unroll
+        for (int p = 0; p < W / 2; ++p) {
+            const double2 vv = ld_stream(reinterpret_cast<const double2 *>(vals + (uint32_t) p * 2u * nseg[b] + l[b] * 2u));
+            v[b][2 * p] = vv.x;
+            v[b][2 * p + 1] = vv.y;
+        }
+        if (W & 1) v[b][W - 1] = ld_stream(vals + (uint32_t) (W / 2) * 2u * nseg[b] + l[b]);
+    }
+    int row[B], sdc[B];
+    uint32_t col[B];
+    double xr[B], x[B][W];
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        const uint32_t bits = q[b].y;
+        const int s = (int) ((ps[b].seg0 + l[b] - ((bits >> 9) & 8191u)) & 0xffffu);
+        const uint32_t kind = (bits >> 22) & 7u;
+        const int step = (int) (bits >> 25);
+        const int drow = kind == SPX_KIND_BLOCK ? 1 : (kind >= SPX_KIND_VERT ? step : 0);
+        const int dcol = (kind == SPX_KIND_HORIZ || kind == SPX_KIND_DIAG) ? step : (kind == SPX_KIND_ADIAG ? -step : 0);
+        row[b] = (int) (ps[b].elem0 + (bits & 511u)) + s * drow;
+        sdc[b] = s * dcol;
+        col[b] = q[b].x + (uint32_t) sdc[b];
+        const double *xp = a.x + col[b];
+        xr[b] = a.x[rb.row0 + (uint32_t) row[b]];
+#pragma unroll
+        for (int w = 0; w < W; ++w) x[b][w] = xp[w];
+    }
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) t = fma(v[b][w], x[b][w], t);
+        if (!active[b]) continue;
+        atomicAdd(&tile[row[b]], t);
+        if (slot0[b] != SPX_NO_SLOT) {
+            double *sl = slots + slot0[b] + (uint32_t) sdc[b];
 #ifdef SPX_ABL_SEG_NOSLOTADD
-        double u = 0.0;
+            double u = 0.0;
 #pragma unroll
-        for (int w = 0; w < W; ++w) u += v[w] * xr;
-        if (u == 1.2345) sl[0] = u;
+            for (int w = 0; w < W; ++w) u += v[b][w] * xr[b];
+            if (u == 1.2345) sl[0] = u;
 #else
 #pragma unroll
-        for (int w = 0; w < W; ++w) atomicAdd(&sl[w], v[w] * xr);
+            for (int w = 0; w < W; ++w) atomicAdd(&sl[w], v[b][w] * xr[b]);
 #endif
-    } else {
-        double *yp = a.y + col;
+        } else {
+            double *yp = a.y + col[b];
 #pragma unroll
-        for (int w = 0; w < W; ++w) atomicAdd(&yp[w], a.alpha * (v[w] * xr));
+            for (int w = 0; w < W; ++w) atomicAdd(&yp[w], a.alpha * (v[b][w] * xr[b]));
+        }
     }
 }
 
@@ -476,14 +535,32 @@ __device__ __forceinline__ void run_symseg(const KernelArgs &a, const SpxRowBloc
                                            double *slots, double *tile, int lane)
 {
     switch (ps.width) {            // wave-uniform
-    case 2: symseg_pass<2>(a, rb, ps, slots, tile, lane); break;
-    case 3: symseg_pass<3>(a, rb, ps, slots, tile, lane); break;
-    case 4: symseg_pass<4>(a, rb, ps, slots, tile, lane); break;
-    case 5: symseg_pass<5>(a, rb, ps, slots, tile, lane); break;
-    case 6: symseg_pass<6>(a, rb, ps, slots, tile, lane); break;
-    case 7: symseg_pass<7>(a, rb, ps, slots, tile, lane); break;
-    default: symseg_pass<8>(a, rb, ps, slots, tile, lane); break;
+    case 2: symseg_passes<2, 1>(a, rb, {ps}, slots, tile, lane); break;
+    case 3: symseg_passes<3, 1>(a, rb, {ps}, slots, tile, lane); break;
+    case 4: symseg_passes<4, 1>(a, rb, {ps}, slots, tile, lane); break;
+    case 5: symseg_passes<5, 1>(a, rb, {ps}, slots, tile, lane); break;
+    case 6: symseg_passes<6, 1>(a, rb, {ps}, slots, tile, lane); break;
+    case 7: symseg_passes<7, 1>(a, rb, {ps}, slots, tile, lane); break;
+    default: symseg_passes<8, 1>(a, rb, {ps}, slots, tile, lane); break;
     }
+}
+
+// two read-once passes of the same width (<= 4: the registers of two wider ones would cost
+// the kernel its eight wavefronts per SIMD) side by side
+__device__ __forceinline__ bool run_symseg2(const KernelArgs &a, const SpxRowBlock &rb, const SpxPass &p0,
+                                            const SpxPass &p1, double *slots, double *tile, int lane)
+{
+#ifdef SPX_SYMSEG_SINGLE
+    return false;
+#else
+    if (p0.width != p1.width || p0.width > 4) return false;
+    switch (p0.width) {
+    case 2: symseg_passes<2, 2>(a, rb, {p0, p1}, slots, tile, lane); break;
+    case 3: symseg_passes<3, 2>(a, rb, {p0, p1}, slots, tile, lane); break;
+    default: symseg_passes<4, 2>(a, rb, {p0, p1}, slots, tile, lane); break;
+    }
+    return true;
+#endif
 }
 
 __device__ __forceinline__ void run_pass(const KernelArgs &a, const SpxRowBlock &rb,
@@ -570,6 +647,10 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &x
             // read-once row segments (atomic hand-over only); whatever shares the round runs on its own
             // (one at a time: two side by side, as the unit passes run, need 100 VGPRs instead of 62,
             // four wavefronts per SIMD instead of eight; measured 0.84 -> 0.97 ms on syn-nlpkkt)
+            if (two && p0.kind == SPX_PASS_SYMSEG && p1.kind == SPX_PASS_SYMSEG &&
+                run_symseg2(a, rb, p0, p1, mine, tile, lane)) {
+                // (both done)
+            } else {
             if (p0.kind == SPX_PASS_SYMSEG) run_symseg(a, rb, p0, mine, tile, lane);
             else if (TILES && p0.kind == SPX_PASS_SYMTILE) symtile_pass(a, rb, p0, mine, tile, lane);
             else run_pass(a, rb, p0, tile, win, lane);
@@ -577,6 +658,7 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &x
                 if (p1.kind == SPX_PASS_SYMSEG) run_symseg(a, rb, p1, mine, tile, lane);
                 else if (TILES && p1.kind == SPX_PASS_SYMTILE) symtile_pass(a, rb, p1, mine, tile, lane);
                 else run_pass(a, rb, p1, tile, win, lane);
+            }
             }
         } else if (SYM && TILES && p0.kind == SPX_PASS_SYMTILE) {
             symtile_pass(a, rb, p0, mine, tile, lane);
