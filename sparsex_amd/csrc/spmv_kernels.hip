@@ -71,16 +71,18 @@ struct XcdSplit {
 // measured at tune time: small matrices like 2, leftover-heavy ones 8)
 constexpr int MAX_WAVES_PER_BLOCK = 8;
 
-// Loads of the matrix stream (values, descriptors): every byte is used once per product, so
-// they are marked non-temporal -- they should not push x out of the L2 (a stencil row-block
-// reads the same lines of x again two z-planes of row-blocks later; with the values allocated in
-// L2 like anything else, x came from the fabric 4.5 times per product instead of once).
-// SPX_STREAM_TEMPORAL builds the plain loads for comparison.
+// Loads of the matrix stream (values, descriptors).  Every byte of it is used once per product,
+// so marking them non-temporal (global_load ... nt: they should not push x out of the L2) looked
+// right -- the PMC passes show x coming from the fabric ~4.5 times per product on the bench
+// matrix -- and measured wrong (profiles/r03/ablation.md section 4): the bench matrix 3 % slower,
+// and the matrices that live in the Infinity Cache (cant, nd24k, webbase) 3-9 % slower, because
+// across the launches of a solver loop their VALUES are what the caches serve.  SPX_STREAM_NT
+// builds the non-temporal variant for comparison.
 typedef double spx_d2_t __attribute__((ext_vector_type(2)));
 typedef unsigned int spx_u2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double2 ld_stream(const double2 *p)
 {
-#ifdef SPX_STREAM_TEMPORAL
+#ifndef SPX_STREAM_NT
     return *p;
 #else
     const spx_d2_t v = __builtin_nontemporal_load(reinterpret_cast<const spx_d2_t *>(p));
@@ -89,7 +91,7 @@ __device__ __forceinline__ double2 ld_stream(const double2 *p)
 }
 __device__ __forceinline__ double ld_stream(const double *p)
 {
-#ifdef SPX_STREAM_TEMPORAL
+#ifndef SPX_STREAM_NT
     return *p;
 #else
     return __builtin_nontemporal_load(p);
@@ -97,7 +99,7 @@ __device__ __forceinline__ double ld_stream(const double *p)
 }
 __device__ __forceinline__ uint2 ld_stream(const uint2 *p)
 {
-#ifdef SPX_STREAM_TEMPORAL
+#ifndef SPX_STREAM_NT
     return *p;
 #else
     const spx_u2_t v = __builtin_nontemporal_load(reinterpret_cast<const spx_u2_t *>(p));
@@ -472,7 +474,7 @@ __device__ __forceinline__ void symseg_passes(const KernelArgs &a, const SpxRowB
         l[b] = active[b] ? (uint32_t) lane : 0u;
         const uint32_t rank = (uint32_t) ps[b].rank0 + 2u * (active[b] ? starts_upto(ps[b].mask, lane) : 0u);
         q[b] = ld_stream(reinterpret_cast<const uint2 *>(a.descs + rb.desc_off + rank));
-        slot0[b] = __builtin_nontemporal_load(&a.descs[rb.desc_off + rank + 1u].col0);
+        slot0[b] = a.descs[rb.desc_off + rank + 1u].col0;
     }
     double v[B][W];
 #pragma unroll
