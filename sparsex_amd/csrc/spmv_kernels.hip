@@ -115,6 +115,14 @@ __device__ __forceinline__ uint32_t starts_upto(uint64_t mask, int lane)
     return below + (uint32_t)((mask >> lane) & 1ull);
 }
 
+// lane l <- lane l + 1 across the whole wavefront (DPP wave_shl:1; lane 63 gets 0)
+__device__ __forceinline__ double wave_shl1(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 // B unit passes of the same width at once: lane l owns one row segment of W
 // consecutive columns in each of them.  All descriptor loads go out first,
 // then all value loads, then the x gathers: one memory round trip per stage
@@ -237,7 +245,34 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
             // every segment of the pass starts on an even column (and x is 16-byte
             // aligned) they come as 16-byte loads, half as many instructions
             // (measured on the symmetric tile pass: 9 -> 5 loads, 29.1 -> 26.6 us).
-            if (W >= 2 && (reinterpret_cast<uintptr_t>(a.x) & 15u) == 0 && __all((col & 1u) == 0u)) {
+            // A pass whose lanes are consecutive segments of ONE diagonal stack (a stencil: lane l
+            // holds row r + l, columns c + l ... c + l + W - 1) reads x[c ... c + nseg + W - 2]: each
+            // lane loads its first element, takes the others from the lanes to its right (DPP
+            // wave shift), and only the last W - 1 lanes load theirs -- one full-width load instead
+            // of W.  (With the x gathers compiled out the bench matrix's product took 1.22 instead
+            // of 1.44 ms: profiles/r03/ablation.md section 6.)
+#ifndef SPX_NO_CHAIN_X
+            const uint32_t bits0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) bits);
+            const bool chain = W >= 2 && W <= 4 && ps[b].mask == 0ull && nseg[b] >= (uint32_t) W &&
+                               ((bits0 >> 22) & 7u) == SPX_KIND_DIAG && (bits0 >> 25) == 1u;
+#else
+            const bool chain = false;
+#endif
+            if (chain) {
+                const uint32_t n = nseg[b];
+                const double xa = xp[0];
+                double xt[W];
+                const bool tail = (uint32_t) lane + (uint32_t) (W - 1) >= n && (uint32_t) lane < n;
+#pragma unroll
+                for (int w = 1; w < W; ++w) xt[w] = tail ? xp[w] : 0.0;
+                x[0] = xa;
+                double sh = xa;
+#pragma unroll
+                for (int w = 1; w < W; ++w) {
+                    sh = wave_shl1(sh);
+                    x[w] = ((uint32_t) lane + (uint32_t) w < n) ? sh : xt[w];
+                }
+            } else if (W >= 2 && (reinterpret_cast<uintptr_t>(a.x) & 15u) == 0 && __all((col & 1u) == 0u)) {
                 const double2 *xp2 = reinterpret_cast<const double2 *>(xp);
 #pragma unroll
                 for (int p = 0; p < W / 2; ++p) {
@@ -504,8 +539,33 @@ __device__ __forceinline__ void symseg_passes(const KernelArgs &a, const SpxRowB
         col[b] = q[b].x + (uint32_t) sdc[b];
         const double *xp = a.x + col[b];
         xr[b] = a.x[rb.row0 + (uint32_t) row[b]];
+        // (lanes that are consecutive segments of one diagonal stack: one full-width load of x,
+        // the rest from the neighbours -- see unit_passes)
+#ifndef SPX_NO_CHAIN_X
+        const uint32_t bits0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) bits);
+        const bool chain = W <= 4 && ps[b].mask == 0ull && nseg[b] >= (uint32_t) W &&
+                           ((bits0 >> 22) & 7u) == SPX_KIND_DIAG && (bits0 >> 25) == 1u;
+#else
+        const bool chain = false;
+#endif
+        if (chain) {
+            const uint32_t n = nseg[b];
+            const double xa = xp[0];
+            double xt[W];
+            const bool tail = (uint32_t) lane + (uint32_t) (W - 1) >= n && (uint32_t) lane < n;
 #pragma unroll
-        for (int w = 0; w < W; ++w) x[b][w] = xp[w];
+            for (int w = 1; w < W; ++w) xt[w] = tail ? xp[w] : 0.0;
+            x[b][0] = xa;
+            double sh = xa;
+#pragma unroll
+            for (int w = 1; w < W; ++w) {
+                sh = wave_shl1(sh);
+                x[b][w] = ((uint32_t) lane + (uint32_t) w < n) ? sh : xt[w];
+            }
+        } else {
+#pragma unroll
+            for (int w = 0; w < W; ++w) x[b][w] = xp[w];
+        }
     }
 #pragma unroll
     for (int b = 0; b < B; ++b) {
