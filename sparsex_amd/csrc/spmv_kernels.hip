@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -247,11 +248,12 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
             // (measured on the symmetric tile pass: 9 -> 5 loads, 29.1 -> 26.6 us).
             // A pass whose lanes are consecutive segments of ONE diagonal stack (a stencil: lane l
             // holds row r + l, columns c + l ... c + l + W - 1) reads x[c ... c + nseg + W - 2]: each
-            // lane loads its first element, takes the others from the lanes to its right (DPP
-            // wave shift), and only the last W - 1 lanes load theirs -- one full-width load instead
-            // of W.  (With the x gathers compiled out the bench matrix's product took 1.22 instead
-            // of 1.44 ms: profiles/r03/ablation.md section 6.)
-#ifndef SPX_NO_CHAIN_X
+            // lane could load its first element only and take the others from the lanes to its
+            // right (DPP wave shift), one full-width load instead of W.  Built (-DSPX_CHAIN_X) and
+            // measured slower on every workload (profiles/r03/ablation.md section 6: the x loads of
+            // neighbouring lanes hit the same L1 lines anyway, the shifts and the masked tail loads
+            // are extra work); not enabled.
+#ifdef SPX_CHAIN_X
             const uint32_t bits0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) bits);
             const bool chain = W >= 2 && W <= 4 && ps[b].mask == 0ull && nseg[b] >= (uint32_t) W &&
                                ((bits0 >> 22) & 7u) == SPX_KIND_DIAG && (bits0 >> 25) == 1u;
@@ -541,7 +543,7 @@ __device__ __forceinline__ void symseg_passes(const KernelArgs &a, const SpxRowB
         xr[b] = a.x[rb.row0 + (uint32_t) row[b]];
         // (lanes that are consecutive segments of one diagonal stack: one full-width load of x,
         // the rest from the neighbours -- see unit_passes)
-#ifndef SPX_NO_CHAIN_X
+#ifdef SPX_CHAIN_X
         const uint32_t bits0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) bits);
         const bool chain = W <= 4 && ps[b].mask == 0ull && nseg[b] >= (uint32_t) W &&
                            ((bits0 >> 22) & 7u) == SPX_KIND_DIAG && (bits0 >> 25) == 1u;
@@ -661,8 +663,10 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &x
     // XCD-aware order: workgroup b runs on XCD b % 8 and takes that XCD's next row-block
     // (the grid is 8 x the longest of the eight lists)
     const uint32_t xcd = blockIdx.x & 7u;
-    const uint32_t rb_idx = xs.first[xcd] + (blockIdx.x >> 3);
-    if (rb_idx >= xs.first[xcd + 1u]) return;
+    // (first[0] == ~0: experiment SPX_XCD_INTERLEAVE -- the row-blocks dealt round robin)
+    const bool deal = xs.first[0] == 0xFFFFFFFFu;
+    const uint32_t rb_idx = deal ? blockIdx.x : xs.first[xcd] + (blockIdx.x >> 3);
+    if (rb_idx >= xs.first[deal ? 8u : xcd + 1u]) return;
 
     // the pass headers sit at a fixed stride, so the wave's first two are
     // fetched together with the row-block header, not after it
@@ -1149,6 +1153,10 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
             xs.first[8] = (uint32_t) hi;
             uint32_t longest = 0;
             for (uint32_t x = 0; x < 8; ++x) longest = std::max(longest, xs.first[x + 1] - xs.first[x]);
+            if (getenv("SPX_XCD_INTERLEAVE") && starts.size() == 2) {
+                xs.first[0] = 0xFFFFFFFFu;
+                longest = (uint32_t)((n + 7) / 8);
+            }
             m->xcd_split.push_back(xs);
             m->xcd_longest.push_back(longest);
         }
