@@ -505,6 +505,7 @@ static void emit_and_upload(spx_matrix_t *A)
     if (sym) mark_private_rowblocks(gs, (size_t) A->nrows, A->own_lo, A->own_hi);
     std::vector<std::pair<uint32_t, uint32_t>>().swap(gs.direct_cols);
     gs.waves = (uint32_t) A->waves;
+    gs.band_order = Config::instance().get_bool("spx.gpu.band_order");
     gs.sym_atomic = A->sym_atomic && !A->deterministic;
     gs.deterministic = A->deterministic;
     gs.wave_tiles = A->deterministic || A->wave_tiles == 1;

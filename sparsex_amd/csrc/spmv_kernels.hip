@@ -17,6 +17,8 @@
 // alpha*a*x[c] to y[r]; on the symmetric path the stream also holds the mirror
 // image of every stored unit, so a(r,c) contributes alpha*a*x[r] to y[c] too.
 #include "device.hpp"
+#include "stream_index.hpp"
+#include "threads.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -997,6 +999,10 @@ struct DeviceMatrix {
     // the row-blocks of every XCD (balanced by values) and the length of the longest list
     std::vector<XcdSplit> xcd_split;
     std::vector<uint32_t> xcd_longest;
+    // launch order (stream_band_order): device row-block i is row-block launch_order[i] of the
+    // stream as the host holds it (empty: the same order); band_stride: the row distance found
+    std::vector<uint32_t> launch_order;
+    size_t band_stride = 0;
     bool has_symsegs = false;     // the stream holds SPX_PASS_SYMSEG passes
     bool has_symtiles = false;    // ... SPX_PASS_SYMTILE passes
     bool wave_tiles = false;      // a y tile per wavefront, summed in wavefront order before the write-out
@@ -1016,6 +1022,7 @@ struct DeviceMatrix {
     double *p_x = nullptr, *p_y = nullptr;      // pinned
     uint64_t x_version = 0;                      // contents of d_x (0: unknown)
     hipStream_t host_stream = nullptr;
+    std::vector<hipEvent_t> stage_events;       // one behind every piece of a staged download
     size_t value_bytes = 0, index_bytes = 0;
     size_t n_values = 0, n_descs = 0, n_passes = 0, n_cidx = 0, n_segrows = 0;
 };
@@ -1063,10 +1070,8 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
     m->n_rb = (uint32_t) s.rbs.size();
     m->n_shared = (uint32_t) s.shared.size();
     m->n_carry = s.n_carry;
-    m->rbs = upload(s.rbs);
     m->values = upload(s.values, 160);
     m->descs = upload(s.descs, 8);
-    m->passes = upload(s.passes, (size_t) s.pass_stride + 2 * MAX_WAVES_PER_BLOCK);
     m->cidx = upload(s.cidx, 64);
     m->segrows = upload(s.segrows, 80);
     m->shared = upload(s.shared);
@@ -1161,6 +1166,46 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
             m->xcd_longest.push_back(longest);
         }
     }
+    {
+        // row-blocks and their pass headers go up in launch order: inside every XCD's part,
+        // strips of a plane across the planes where the rows read x in recurring bands
+        // (stream_band_order; spx.gpu.band_order=false / SPX_NO_BAND_ORDER leave the stream's order)
+        std::vector<uint32_t> order;
+        if (s.band_order && !getenv("SPX_NO_BAND_ORDER")) {
+            order.resize(s.rbs.size());
+            for (size_t i = 0; i < order.size(); ++i) order[i] = (uint32_t) i;
+            bool any = false;
+            for (const XcdSplit &xs : m->xcd_split) {
+                if (xs.first[0] == 0xFFFFFFFFu) continue;
+                for (uint32_t x = 0; x < 8; ++x) {
+                    size_t S = 0;
+                    const std::vector<uint32_t> part = stream_band_order(s, xs.first[x], xs.first[x + 1], S);
+                    if (part.empty()) continue;
+                    std::copy(part.begin(), part.end(), order.begin() + xs.first[x]);
+                    m->band_stride = S;
+                    any = true;
+                }
+            }
+            if (!any) order.clear();
+        }
+        if (order.empty()) {
+            m->rbs = upload(s.rbs);
+            m->passes = upload(s.passes, (size_t) s.pass_stride + 2 * MAX_WAVES_PER_BLOCK);
+        } else {
+            const size_t stride = s.pass_stride;
+            std::vector<SpxRowBlock> rbs(s.rbs.size());
+            std::vector<SpxPass> passes(s.passes.size());
+            for (size_t i = 0; i < order.size(); ++i) {
+                rbs[i] = s.rbs[order[i]];
+                rbs[i].pass_off = (uint32_t)(i * stride);
+                std::copy(s.passes.begin() + (size_t) order[i] * stride, s.passes.begin() + ((size_t) order[i] + 1) * stride,
+                          passes.begin() + i * stride);
+            }
+            m->rbs = upload(rbs);
+            m->passes = upload(passes, stride + 2 * MAX_WAVES_PER_BLOCK);
+            m->launch_order.swap(order);
+        }
+    }
     if (m->has_symsegs && (size_t) m->lds_doubles * sizeof(double) + 8192u > 64u * 1024u) {
         // wide row-blocks with an x window on top: beyond the default dynamic LDS limit
         const int bytes = 160 * 1024;
@@ -1201,6 +1246,7 @@ void device_free(DeviceMatrix *m)
     if (m->p_x) (void) hipHostFree(m->p_x);
     if (m->p_y) (void) hipHostFree(m->p_y);
     if (m->host_stream) (void) hipStreamDestroy(m->host_stream);
+    for (hipEvent_t e : m->stage_events) (void) hipEventDestroy(e);
     delete m;
 }
 
@@ -1426,6 +1472,41 @@ double device_time_spmv(DeviceMatrix *m, int warmup, int launches)
 // Host-vector entry point: x (and y when it is read) go through pinned staging
 // buffers and asynchronous copies on one private stream -- a pageable
 // hipMemcpy stages internally as well, but synchronously and chunk by chunk.
+// Large user buffers are staged in pieces, a few threads copying a piece while the
+// DMA engine moves the one in front of it (and the other way round on the way back):
+// the reference's clients hand over plain malloc'ed vectors (SPX_VEC_AS_IS), and a
+// single-threaded copy of 224 MB into the staging buffer took longer than the DMA.
+namespace {
+
+constexpr size_t STAGE_PIECE = (size_t) 16 << 20;      // bytes
+
+void copy_threads(void *dst, const void *src, size_t bytes)
+{
+    const unsigned t = bytes >= ((size_t) 4 << 20) ? std::min(4u, host_threads()) : 1u;
+    if (t <= 1) {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    const size_t part = ((bytes / t) + 63) & ~(size_t) 63;
+    parallel_for(t, t, [&](size_t k) {
+        const size_t a = std::min(bytes, k * part), b = k + 1 == t ? bytes : std::min(bytes, (k + 1) * part);
+        if (b > a) std::memcpy(static_cast<char *>(dst) + a, static_cast<const char *>(src) + a, b - a);
+    });
+}
+
+// host (pageable) -> device through the pinned buffer `stage`
+void upload_staged(double *d, double *stage, const double *h, size_t bytes, hipStream_t st)
+{
+    for (size_t off = 0; off < bytes; off += STAGE_PIECE) {
+        const size_t n = std::min(STAGE_PIECE, bytes - off);
+        copy_threads(reinterpret_cast<char *>(stage) + off, reinterpret_cast<const char *>(h) + off, n);
+        HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char *>(d) + off, reinterpret_cast<char *>(stage) + off, n,
+                                 hipMemcpyHostToDevice, st));
+    }
+}
+
+}  // namespace
+
 void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x, bool x_pinned,
                       double beta, double *h_y, bool y_pinned,
                       const std::function<void(double *, void *)> &after, uint64_t x_version)
@@ -1435,12 +1516,8 @@ void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x, bool x_p
     ensure_staging(m);
     hipStream_t st = m->host_stream;
     if (!x_version || x_version != m->x_version) {
-        const double *src_x = h_x;
-        if (!x_pinned) {
-            std::memcpy(m->p_x, h_x, xb);
-            src_x = m->p_x;
-        }
-        HIP_CHECK(hipMemcpyAsync(m->d_x, src_x, xb, hipMemcpyHostToDevice, st));
+        if (x_pinned) HIP_CHECK(hipMemcpyAsync(m->d_x, h_x, xb, hipMemcpyHostToDevice, st));
+        else upload_staged(m->d_x, m->p_x, h_x, xb, st);
         m->x_version = x_version;
     }
     // y travels to the device only when it is read: beta != 0, or this process
@@ -1448,18 +1525,41 @@ void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x, bool x_p
     const bool whole = m->own_lo == 0 && m->own_hi == m->nrows && (!m->symmetric || m->sym_fused);
     // (atomic hand-over reads y only through the init kernel's beta*y: nothing to upload when beta == 0)
     if (beta != 0.0 || !whole) {
-        const double *src_y = h_y;
-        if (!y_pinned) {
-            std::memcpy(m->p_y, h_y, yb);
-            src_y = m->p_y;
-        }
-        HIP_CHECK(hipMemcpyAsync(m->d_y, src_y, yb, hipMemcpyHostToDevice, st));
+        if (y_pinned) HIP_CHECK(hipMemcpyAsync(m->d_y, h_y, yb, hipMemcpyHostToDevice, st));
+        else upload_staged(m->d_y, m->p_y, h_y, yb, st);
     }
     device_spmv(m, alpha, m->d_x, beta, m->d_y, st);
     if (after) after(m->d_y, st);
-    HIP_CHECK(hipMemcpyAsync(y_pinned ? h_y : m->p_y, m->d_y, yb, hipMemcpyDeviceToHost, st));
-    HIP_CHECK(hipStreamSynchronize(st));
-    if (!y_pinned) std::memcpy(h_y, m->p_y, yb);
+    if (y_pinned) {
+        HIP_CHECK(hipMemcpyAsync(h_y, m->d_y, yb, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        return;
+    }
+    // back in pieces: an event behind every piece, the host copies a piece out of the
+    // staging buffer while the next one is on its way
+    const size_t pieces = (yb + STAGE_PIECE - 1) / STAGE_PIECE;
+    if (pieces <= 1) {
+        HIP_CHECK(hipMemcpyAsync(m->p_y, m->d_y, yb, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        std::memcpy(h_y, m->p_y, yb);
+        return;
+    }
+    while (m->stage_events.size() < pieces) {
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        m->stage_events.push_back(e);
+    }
+    for (size_t k = 0; k < pieces; ++k) {
+        const size_t off = k * STAGE_PIECE, n = std::min(STAGE_PIECE, yb - off);
+        HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char *>(m->p_y) + off, reinterpret_cast<char *>(m->d_y) + off, n,
+                                 hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipEventRecord(m->stage_events[k], st));
+    }
+    for (size_t k = 0; k < pieces; ++k) {
+        const size_t off = k * STAGE_PIECE, n = std::min(STAGE_PIECE, yb - off);
+        HIP_CHECK(hipEventSynchronize(m->stage_events[k]));
+        copy_threads(reinterpret_cast<char *>(h_y) + off, reinterpret_cast<char *>(m->p_y) + off, n);
+    }
 }
 
 bool device_stream_is_capturing(void *stream)
@@ -1502,6 +1602,20 @@ void device_download(const DeviceMatrix *m, GpuStream &s)
     download(s.values, m->values, m->n_values);
     download(s.descs, m->descs, m->n_descs);
     download(s.passes, m->passes, m->n_passes);
+    if (!m->launch_order.empty()) {
+        // back into the stream's own (ascending) order
+        const size_t stride = m->pass_stride;
+        std::vector<SpxRowBlock> rbs(s.rbs.size());
+        std::vector<SpxPass> passes(s.passes.size());
+        for (size_t i = 0; i < m->launch_order.size(); ++i) {
+            const size_t o = m->launch_order[i];
+            rbs[o] = s.rbs[i];
+            rbs[o].pass_off = (uint32_t)(o * stride);
+            std::copy(s.passes.begin() + i * stride, s.passes.begin() + (i + 1) * stride, passes.begin() + o * stride);
+        }
+        s.rbs.swap(rbs);
+        s.passes.swap(passes);
+    }
     download(s.cidx, m->cidx, m->n_cidx);
     download(s.segrows, m->segrows, m->n_segrows);
     download(s.shared, m->shared, m->n_shared);

@@ -2,6 +2,7 @@
 #include "stream_index.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace spx {
@@ -168,6 +169,86 @@ void stream_locate_mirror(const GpuStream &s, idx_t row, idx_t col, std::vector<
     const size_t t = (size_t) (it - s.mirror_rows.begin());
     for (uint32_t k = s.mirror_ptr[t]; k < s.mirror_ptr[t + 1]; ++k)
         if (s.mirror_col[k] == (uint32_t) col) out.push_back(k);
+}
+
+namespace {
+
+// first columns of the clusters of unit descriptors of a row-block, relative to its first row
+// (clusters: descriptor columns closer together than `gap`)
+void band_offsets(const GpuStream &s, const SpxRowBlock &rb, int64_t gap, std::vector<int64_t> &out)
+{
+    std::vector<int64_t> cols;
+    for (uint32_t t = 0; t < rb.n_pass; ++t) {
+        const SpxPass &ps = s.passes[(size_t) rb.pass_off + t];
+        if (ps.kind != SPX_PASS_UNIT && ps.kind != SPX_PASS_SYMSEG) continue;
+        const uint32_t stride = ps.kind == SPX_PASS_SYMSEG ? 2u : 1u;
+        const uint32_t n = popcount_upto(ps.mask, (uint32_t) ps.nseg - 1u) + 1u;
+        for (uint32_t k = 0; k < n; ++k)
+            cols.push_back((int64_t) s.descs[(size_t) rb.desc_off + ps.rank0 + stride * k].col0);
+    }
+    out.clear();
+    if (cols.empty()) return;
+    std::sort(cols.begin(), cols.end());
+    out.push_back(cols[0] - (int64_t) rb.row0);
+    for (size_t i = 1; i < cols.size(); ++i)
+        if (cols[i] - cols[i - 1] > gap) out.push_back(cols[i] - (int64_t) rb.row0);
+}
+
+}  // namespace
+
+std::vector<uint32_t> stream_band_order(const GpuStream &s, size_t lo, size_t hi, size_t &stride_rows)
+{
+    stride_rows = 0;
+    std::vector<uint32_t> order;
+    if (hi <= lo + 512) return order;                  // (a few hundred row-blocks are in flight at once anyway)
+    // 1. the distance: row-blocks with exactly three bands, equally spaced, far apart; most of a
+    //    sample must agree on it
+    std::vector<int64_t> found, off;
+    const size_t samples = 48;
+    for (size_t k = 0; k < samples; ++k) {
+        const SpxRowBlock &rb = s.rbs[lo + (hi - lo) * (2 * k + 1) / (2 * samples)];
+        const int64_t rows = std::max<int64_t>(rb.n_rows, 64);
+        band_offsets(s, rb, 4 * rows, off);
+        // (three bands in a row at equal distances, far apart; other clusters -- the main
+        // diagonal of a KKT system, a few boundary columns -- may sit anywhere around them)
+        for (size_t i = 0; i + 2 < off.size() && off.size() <= 8; ++i) {
+            const int64_t d1 = off[i + 1] - off[i], d2 = off[i + 2] - off[i + 1];
+            if (d1 < 32 * rows || std::llabs(d1 - d2) > 8) continue;
+            found.push_back((d1 + d2) / 2);
+            break;
+        }
+    }
+    if (found.size() * 4 < samples * 3) return order;
+    std::sort(found.begin(), found.end());
+    const int64_t S = found[found.size() / 2];
+    size_t agree = 0;
+    for (int64_t v : found) agree += std::llabs(v - S) <= 8 ? 1 : 0;
+    if (agree * 4 < samples * 3 || S <= 0) return order;
+    // 2. the order: (strip of the plane, plane, position in the strip)
+    const int64_t row_first = (int64_t) s.rbs[lo].row0;
+    int64_t rows_total = 0;
+    for (size_t i = lo; i < hi; ++i) {
+        if ((int64_t) s.rbs[i].row0 < row_first) return std::vector<uint32_t>();     // (not ascending: leave it)
+        rows_total += s.rbs[i].n_rows;
+    }
+    if ((int64_t) s.rbs[hi - 1].row0 - row_first < 3 * S) return order;             // fewer than three planes: nothing to gain
+    const int64_t avg_rows = std::max<int64_t>(rows_total / (int64_t)(hi - lo), 1);
+    const int64_t strip = std::max<int64_t>(24 * avg_rows, 1);                       // ~24 row-blocks of a plane per strip
+    struct Key { int64_t strip, plane, pos; uint32_t idx; };
+    std::vector<Key> keys(hi - lo);
+    for (size_t i = lo; i < hi; ++i) {
+        const int64_t r = (int64_t) s.rbs[i].row0 - row_first;
+        keys[i - lo] = Key{(r % S) / strip, r / S, r % S, (uint32_t) i};
+    }
+    std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
+        if (a.strip != b.strip) return a.strip < b.strip;
+        if (a.plane != b.plane) return a.plane < b.plane;
+        return a.pos < b.pos;
+    });
+    order.resize(hi - lo);
+    for (size_t k = 0; k < keys.size(); ++k) order[k] = keys[k].idx;
+    stride_rows = (size_t) S;
+    return order;
 }
 
 bool stream_validate(const GpuStream &s, size_t nrows, size_t ncols, size_t n_values,

@@ -33,6 +33,17 @@ void stream_locate_mirror(const GpuStream &s, idx_t row, idx_t col, std::vector<
 // (include/sparsex/internals/CsxBuild.hpp:400-451).
 void stream_touched_rows(const GpuStream &s, idx_t below, std::vector<idx_t> &rows);
 
+// Launch order for matrices whose rows read x in bands that recur at a fixed row distance (a
+// 3-D stencil: the bands of the z-planes above and below; the distance S is N^2 rows).  Walking
+// the row-blocks of an XCD's part plane by plane, a band comes round again S rows -- some 190
+// row-blocks and 12 MB of values -- later, long after the XCD's 4 MB L2 has dropped it, and x is
+// fetched through the fabric once per band instead of once.  Returns, for the row-blocks
+// [lo, hi) of one part, the order in which to walk them: strips of `strip_rows` rows of a plane,
+// the same strip of every plane in turn, then the next strip -- so that the row-blocks in flight
+// at any time share their bands.  Empty when no such distance is found (most matrices).
+// `stride_rows` receives S (0: none).  Pure reordering: row-blocks are independent of each other.
+std::vector<uint32_t> stream_band_order(const GpuStream &s, size_t lo, size_t hi, size_t &stride_rows);
+
 // Structural checks of a finalized stream (array-size relations, offsets of
 // every row-block and pass inside their arrays, rows and columns inside the
 // matrix, LDS budget).  Returns false and a reason on the first violation.
