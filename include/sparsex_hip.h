@@ -30,6 +30,12 @@
  *                           of merging equal row segments of consecutive rows
  *   spx.gpu.recut_linear    "false": vertical / diagonal / strided units always run one
  *                           nonzero per lane, even where they line up along rows
+ *   spx.gpu.col_phases      general path: the stream as a sum of K column slices launched in turn (slice k > 0
+ *                           adds to y), each slice's x fitting an XCD's L2: 1 (off), 2..8, or "auto" (default:
+ *                           measured at tune time for leftover-dominated matrices whose x exceeds 6 MB; the
+ *                           plain stream won on syn-webbase, profiles/r03/ablation.md)
+ *   spx.gpu.band_order      "true": row-blocks are launched strip by strip across the planes of a stencil
+ *                           instead of in row order (measured 4-7 % slower on the KKT stand-in: off)
  *   spx.gpu.keep_units      "false": ... even those none of whose nonzeros has a neighbour along
  *                           its row (default: such a unit stays one descriptor -- the main diagonal
  *                           of a KKT system -- instead of a leftover nonzero per row)
