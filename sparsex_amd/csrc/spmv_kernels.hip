@@ -527,6 +527,20 @@ __device__ __forceinline__ void symseg_passes(const KernelArgs &a, const SpxRowB
         }
         if (W & 1) v[b][W - 1] = ld_stream(vals + (uint32_t) (W / 2) * 2u * nseg[b] + l[b]);
     }
+#ifdef SPX_ABL_SEG_VALSONLY
+    {
+        // (ablation: the stream of the passes alone -- descriptors and values)
+        double t = 0.0;
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            t += (double) q[b].x + (double) slot0[b];
+#pragma unroll
+            for (int w = 0; w < W; ++w) t += v[b][w];
+        }
+        if (t == 1.2345) tile[0] = t;
+        return;
+    }
+#endif
     int row[B], sdc[B];
     uint32_t col[B];
     double xr[B], x[B][W];
@@ -542,7 +556,11 @@ __device__ __forceinline__ void symseg_passes(const KernelArgs &a, const SpxRowB
         sdc[b] = s * dcol;
         col[b] = q[b].x + (uint32_t) sdc[b];
         const double *xp = a.x + col[b];
+#ifdef SPX_ABL_SEG_NOX
+        xr[b] = (double) row[b];
+#else
         xr[b] = a.x[rb.row0 + (uint32_t) row[b]];
+#endif
         // (lanes that are consecutive segments of one diagonal stack: one full-width load of x,
         // the rest from the neighbours -- see unit_passes)
 #ifdef SPX_CHAIN_X
@@ -567,8 +585,13 @@ __device__ __forceinline__ void symseg_passes(const KernelArgs &a, const SpxRowB
                 x[b][w] = ((uint32_t) lane + (uint32_t) w < n) ? sh : xt[w];
             }
         } else {
+#ifdef SPX_ABL_SEG_NOX
+#pragma unroll
+            for (int w = 0; w < W; ++w) x[b][w] = (double) col[b];
+#else
 #pragma unroll
             for (int w = 0; w < W; ++w) x[b][w] = xp[w];
+#endif
         }
     }
 #pragma unroll
