@@ -537,7 +537,6 @@ static void emit_and_upload(spx_matrix_t *A)
     } else {
         A->host_stream.reset(new GpuStream(std::move(gs)));
     }
-    A->dirty = false;
 }
 
 // Launch parameters are measured, not guessed: small matrices (one round of
@@ -704,7 +703,6 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     A->last_part = last;
     A->full_colind = cfg.get_bool("spx.matrix.full_colind");
     A->dev = nullptr;
-    A->dirty = false;
     A->host_only = host_only;
     A->device_ordinal = (int) cfg.get_long("spx.rt.device");
 
@@ -1278,7 +1276,6 @@ bool get_partition(FILE *f, Partition &p, std::vector<val_t> &diag)
 
 extern "C" {
 
-static bool refresh_if_dirty(const spx_matrix_t *A_);
 
 spx_error_t spx_mat_save(const spx_matrix_t *A, const char *filename)
 {
@@ -1292,7 +1289,6 @@ spx_error_t spx_mat_save(const spx_matrix_t *A, const char *filename)
     }
     // the file must show what the matrix holds now (the reference writes
     // set_entry straight into the arrays it archives, src/api/matvec.c:409-425)
-    if (!refresh_if_dirty(A)) return SPX_FAILURE;
     GpuStream tmp;
     const GpuStream *gs = A->host_stream.get();
     if (!gs) {
@@ -1454,7 +1450,6 @@ spx_matrix_t *spx_mat_restore(const char *filename)
     A->deterministic = gs->deterministic;
     A->wave_tiles = gs->wave_tiles ? 1 : 0;
     A->tune_seconds = 0.0;
-    A->dirty = false;
     A->auto_rb = false;
     const double t0 = now_sec();
     Config &cfg = Config::instance();
@@ -1636,30 +1631,9 @@ static spx_error_t check_mv(const spx_matrix_t *A, const spx_vector_t *x, spx_ve
     return SPX_SUCCESS;
 }
 
-// values changed through spx_mat_set_entry: rebuild the stream once
-static bool refresh_if_dirty(const spx_matrix_t *A_)
-{
-    spx_matrix_t *A = const_cast<spx_matrix_t *>(A_);
-    if (!A->dirty) return true;
-    std::lock_guard<std::mutex> lk(A->mtx);
-    if (!A->dirty) return true;
-    if (A->parts.empty()) {
-        SETERROR_1(SPX_ERR_TUNED_MAT, "matrix is marked changed but holds no encoded partitions to rebuild from");
-        return false;
-    }
-    try {
-        emit_and_upload(A);
-    } catch (const FatalError &e) {
-        SETERROR_1(SPX_ERR_TUNED_MAT, e.what.c_str());
-        return false;
-    }
-    return true;
-}
-
 static spx_error_t run_host(const spx_matrix_t *A, spx_value_t alpha, const spx_vector_t *x,
                             spx_value_t beta, spx_vector_t *y)
 {
-    if (!refresh_if_dirty(A)) return SPX_FAILURE;
     if (!A->dev) {
         SETERROR_1(SPX_ERR_TUNED_MAT,
                    "matrix was tuned with spx.rt.host_only=true: no HIP executor");
@@ -1744,12 +1718,6 @@ spx_error_t spx_hip_matvec_kernel(spx_value_t alpha, const spx_matrix_t *A,
                                   spx_value_t *y_dev, void *stream)
 {
     if (check_dev(A, x_dev, y_dev) != SPX_SUCCESS) return SPX_FAILURE;
-    if (A->dirty && device_stream_is_capturing(stream)) {
-        // (rebuilding the stream allocates and copies synchronously: not inside a capture)
-        SETERROR_1(SPX_ERR_TUNED_MAT, "the matrix has pending changes: multiply once outside the stream capture first");
-        return SPX_FAILURE;
-    }
-    if (!refresh_if_dirty(A)) return SPX_FAILURE;
     try {
         device_spmv(A->dev, alpha, x_dev, beta, y_dev, stream);
     } catch (const FatalError &e) {
@@ -1768,7 +1736,6 @@ spx_error_t spx_hip_matvec_dist(spx_value_t alpha, const spx_matrix_t *A,
         SETERROR_1(SPX_ERR_TUNED_MAT, "matrix has no exchange plan (spx_hip_mat_dist_attach)");
         return SPX_FAILURE;
     }
-    if (!refresh_if_dirty(A)) return SPX_FAILURE;
     try {
         device_spmv(A->dev, alpha, x_dev, beta, y_dev, stream);
         dist_complete(A->dist, y_dev, (flags & SPX_DIST_GATHER_Y) != 0, stream);

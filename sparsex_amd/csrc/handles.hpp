@@ -71,7 +71,6 @@ struct matrix {
     int spill_mode = -1;        // spx.gpu.sym_spill as asked for: 0 lists, 1 atomic, -1 auto
     int wave_tiles = -1;        // per-wavefront y tiles: 1 / 0, -1 = measured at tune time (spx.gpu.wave_tiles)
     int device_ordinal = -1;
-    bool dirty = false;                       // values changed since the last upload
     std::vector<std::vector<idx_t>> spans;    // per partition and row: reach of its units
     std::vector<idx_t> max_span;              // per partition
     // accounting
