@@ -488,11 +488,15 @@ static void emit_and_upload(spx_matrix_t *A)
                     }
                 q.elems_size = q.elems.size();
             });
-            gp.skip_empty = k > 0;
+            gp.skip_empty = k > 0 || A->col_concurrent;
             const size_t rb0 = gs.rbs.size();
             emit_pieces(sub, nullptr);
             if (k > 0 && gs.rbs.size() > rb0) gs.rbs[rb0].flags |= SPX_RB_PHASE_START;
+            // (a concurrent slice without a single row-block would leave its XCDs' lists undefined)
+            if (A->col_concurrent && gs.rbs.size() == rb0) throw FatalError("column phases: an empty slice");
         }
+        if (A->col_concurrent)
+            for (SpxRowBlock &rb : gs.rbs) rb.flags |= SPX_RB_ACCUM;
         gp = keep;
         // (an over-long row is summed by a fix-up kernel that stores: not with slices that add)
         if (!gs.shared.empty()) throw FatalError("column phases: the matrix holds rows that are split over row-blocks");
@@ -832,12 +836,15 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     }
     A->wave_tiles = wt_mode == "true" ? 1 : 0;          // (auto: off until measured)
     const std::string ph_mode = cfg.get_str("spx.gpu.col_phases");
-    long ph_fixed = ph_mode == "auto" ? 0 : strtol(ph_mode.c_str(), nullptr, 10);
-    if (ph_mode != "auto" && (ph_fixed < 1 || ph_fixed > 8)) {
-        log_msg(LOG_ERR, "spx.gpu.col_phases: 1 .. 8 or auto\n");
+    const bool ph_conc = ph_mode.size() == 2 && ph_mode[0] == 'c';
+    long ph_fixed = ph_mode == "auto" ? 0 : strtol(ph_mode.c_str() + (ph_conc ? 1 : 0), nullptr, 10);
+    if (ph_mode != "auto" && (ph_fixed < 1 || ph_fixed > 8 || (ph_conc && ph_fixed != 2 && ph_fixed != 4 && ph_fixed != 8))) {
+        log_msg(LOG_ERR, "spx.gpu.col_phases: 1 .. 8 (launched in turn), c2 | c4 | c8 (one launch, a group of XCDs each) or auto\n");
         throw FatalError("bad spx.gpu.col_phases");
     }
     A->col_phases = (!sym && ph_fixed > 1) ? (size_t) ph_fixed : 1;
+    A->col_concurrent = A->col_phases > 1 && ph_conc && !A->deterministic;
+    if (A->col_phases > 1 && ph_conc && !A->col_concurrent) A->col_phases = 1;     // (atomic: not with spx.gpu.deterministic)
     try {
         emit_and_upload(A.get());
     } catch (const FatalError &) {
@@ -860,19 +867,25 @@ static spx_matrix_t *do_tune(spx_input_t *in)
             return best;
         };
         const double t_plain = best_of();
-        const size_t K = std::min<size_t>(8, ((size_t) A->ncols * sizeof(val_t) + ((size_t) 5 << 19) - 1) / ((size_t) 5 << 19));   // 2.5 MB of x per slice
+        // slices of at most 2.5 MB of x, each on its own group of XCDs in one launch (2, 4 or 8 of them)
+        size_t K = 2;
+        while (K < 8 && (size_t) A->ncols * sizeof(val_t) > K * ((size_t) 5 << 19)) K *= 2;
         double t_ph = 2.0 * t_plain;
-        try {
-            A->col_phases = K;
-            emit_and_upload(A.get());
-            t_ph = best_of();
-        } catch (const FatalError &) {
+        if (!A->deterministic) {
+            try {
+                A->col_phases = K;
+                A->col_concurrent = true;
+                emit_and_upload(A.get());
+                t_ph = best_of();
+            } catch (const FatalError &) {
+            }
         }
         if (t_ph >= 0.97 * t_plain) {
             A->col_phases = 1;
+            A->col_concurrent = false;
             emit_and_upload(A.get());
         }
-        log_msg(LOG_INFO, "column phases: %zu slices %.2f us, plain %.2f us per SpMV\n", K, 1e6 * t_ph, 1e6 * t_plain);
+        log_msg(LOG_INFO, "column slices: %zu on XCD groups %.2f us, plain %.2f us per SpMV\n", K, 1e6 * t_ph, 1e6 * t_plain);
     }
     if (!cfg.get_bool("spx.rt.keep_encoded")) {
         A->parts.clear();

@@ -182,6 +182,10 @@ typedef struct {
                              what the slices in front of it stored (beta = 1), and a workgroup only
                              ever gathers x from one slice of the columns -- a slice that fits the 4 MB
                              of L2 of an XCD.  This flag marks the first row-block of a slice k > 0  */
+#define SPX_RB_ACCUM 8u   /* ... or (spx.gpu.col_phases = c2 | c4 | c8) all slices run in ONE launch, slice k on
+                             its own group of 8 / K XCDs, so that an XCD's L2 only ever sees 1 / K of x: every
+                             row-block then ADDS its y tile to y (global atomics, coalesced by rows) on top of
+                             a pass that put beta * y there.  Set on every row-block of such a stream        */
 #define SPX_RB_PRIVATE 2u /* symmetric path, atomic hand-over: nobody else adds to the rows of
                              this row-block (no slot group of any row-block, no slot-less
                              read-once segment, no mirror list reaches them), so it STORES them,

@@ -62,6 +62,7 @@ struct matrix {
     double rb_scale = 1.0;      // chosen by the launch autotuner (multiplies the automatic row-block size)
     int waves = 4;              // wavefronts per workgroup of the SpMV kernel
     size_t col_phases = 1;      // general path: column slices the stream is emitted in (spx.gpu.col_phases)
+    bool col_concurrent = false;   // ... all of them in one launch, a group of XCDs each (SPX_RB_ACCUM)
     bool host_only = false;
     bool has_tiles = false;     // the stream holds SPX_PASS_SYMTILE passes
     bool sym_atomic = false;    // their transposed sums go straight into y (global atomics)

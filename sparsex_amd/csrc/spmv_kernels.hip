@@ -852,6 +852,17 @@ void csx_spmv_kernel(SPX_KERNEL_PARAMS)
     spmv_body<false, false, WAVES>(a, xcd_split, lds_dyn);
 }
 
+// general path, column slices in one launch (SPX_RB_ACCUM): every row-block adds its y tile to
+// y with global atomics (lanes of consecutive rows: 64-byte groups), on top of csx_scale_kernel
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES)
+void csx_spmv_accum_kernel(SPX_KERNEL_PARAMS)
+{
+    SPX_KERNEL_ARGS(a);
+    extern __shared__ double lds_dyn[];
+    spmv_body<false, true, WAVES>(a, xcd_split, lds_dyn);
+}
+
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES)
 void csx_spmv_symtile_kernel(SPX_KERNEL_PARAMS)
@@ -954,6 +965,13 @@ __global__ void csx_fixup_kernel(const SpxSharedRow *shared, uint32_t n_shared,
     y[sr.row] = (beta == 0.0) ? alpha * s : alpha * s + beta * y[sr.row];
 }
 
+// column slices in one launch, first step: y <- beta * y on the rows [lo, hi)
+__global__ void csx_scale_kernel(double *y, size_t lo, size_t hi, double beta)
+{
+    const size_t i = lo + (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < hi) y[i] = beta == 0.0 ? 0.0 : beta * y[i];
+}
+
 // symmetric path, first step: y <- beta*y + alpha*diag(A)*x on the owned
 // rows, 0 elsewhere (the main kernel then accumulates; on several GPUs the
 // per-GPU vectors are summed afterwards)
@@ -1024,6 +1042,7 @@ struct DeviceMatrix {
     std::vector<uint32_t> xcd_longest;
     // launch order (stream_band_order): device row-block i is row-block launch_order[i] of the
     // stream as the host holds it (empty: the same order); band_stride: the row distance found
+    bool accum = false;           // SPX_RB_ACCUM: the column slices run in one launch and add to y
     std::vector<uint32_t> launch_order;
     size_t band_stride = 0;
     bool has_symsegs = false;     // the stream holds SPX_PASS_SYMSEG passes
@@ -1168,6 +1187,30 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
         for (size_t i = 1; i < n; ++i)
             if (s.rbs[i].flags & SPX_RB_PHASE_START) starts.push_back(i);
         starts.push_back(n);
+        m->accum = n > 0 && (s.rbs[0].flags & SPX_RB_ACCUM) != 0;
+        const size_t K = starts.size() - 1;
+        if (m->accum && (K == 2 || K == 4 || K == 8)) {
+            // one launch: slice k on the XCDs [k * 8 / K, (k + 1) * 8 / K), its row-blocks dealt to
+            // them in contiguous parts of equal values
+            XcdSplit xs;
+            const uint32_t per = (uint32_t)(8 / K);
+            for (size_t k = 0; k < K; ++k) {
+                const size_t lo = starts[k], hi = starts[k + 1];
+                for (uint32_t j = 0; j < per; ++j) {
+                    const uint64_t want = upto[lo] + (upto[hi] - upto[lo]) * j / per;
+                    size_t i = (size_t)(std::lower_bound(upto.begin() + lo, upto.begin() + hi + 1, want) - upto.begin());
+                    xs.first[k * per + j] = (uint32_t) std::min(std::max(i, lo), hi);
+                }
+            }
+            xs.first[8] = (uint32_t) n;
+            uint32_t longest = 0;
+            for (uint32_t x = 0; x < 8; ++x) longest = std::max(longest, xs.first[x + 1] - xs.first[x]);
+            m->xcd_split.push_back(xs);
+            m->xcd_longest.push_back(longest);
+            starts.assign(1, n);           // (nothing left for the sequential form below)
+        } else if (m->accum) {
+            throw FatalError("column slices for one launch: 2, 4 or 8 of them");
+        }
         for (size_t ph = 0; ph + 1 < starts.size(); ++ph) {
             const size_t lo = starts[ph], hi = starts[ph + 1];
             XcdSplit xs;
@@ -1335,6 +1378,14 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
                                alpha, m->n_mirror_rows);
         a.beta = beta = 1.0;
     }
+    if (m->accum && !m->symmetric) {
+        // column slices in one launch: beta * y first, every row-block adds on top
+        const int t = 256;
+        const size_t lo = m->own_lo, hi = m->own_hi;
+        if (hi > lo)
+            hipLaunchKernelGGL(csx_scale_kernel, dim3((unsigned)((hi - lo + t - 1) / t)), dim3(t), 0, stream, d_y, lo, hi, beta);
+        a.beta = beta = 1.0;
+    }
     a.spill = m->spill;
 #define SPX_LAUNCH(KERNEL, W, LDS)                                                               \
     hipLaunchKernelGGL(KERNEL<W>, dim3(blocks), dim3(64 * W), LDS, stream, a.rbs, a.passes,      \
@@ -1347,7 +1398,7 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
         xcd_now = m->xcd_split[ph];
         blocks = 8u * m->xcd_longest[ph];
         if (ph > 0) a.beta = 1.0;
-        if (blocks && m->wave_tiles) {
+        if (blocks && m->wave_tiles && !m->accum) {
             // a copy of slots + y tile per wavefront: as many wavefronts as fit the LDS
             const int w = m->waves;
             const size_t lds = (size_t) w * m->lds_doubles * sizeof(double);
@@ -1384,6 +1435,11 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
             else if (m->waves == 8) SPX_LAUNCH(csx_spmv_symtile_kernel, 8, lds);
             else SPX_LAUNCH(csx_spmv_symtile_kernel, 4, lds);
             need_symfix = m->n_spill && !m->sym_atomic;
+        } else if (blocks && m->accum) {
+            const size_t lds = m->lds_doubles * sizeof(double);
+            if (m->waves == 2) SPX_LAUNCH(csx_spmv_accum_kernel, 2, lds);
+            else if (m->waves == 8) SPX_LAUNCH(csx_spmv_accum_kernel, 8, lds);
+            else SPX_LAUNCH(csx_spmv_accum_kernel, 4, lds);
         } else if (blocks) {
             const size_t lds = m->lds_doubles * sizeof(double);
             if (m->waves == 2) SPX_LAUNCH(csx_spmv_kernel, 2, lds);

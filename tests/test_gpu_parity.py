@@ -318,7 +318,7 @@ def test_deterministic_mode_is_bitwise_repeatable(name, gen, sym):
         assert np.array_equal(y1, y2)
 
 
-@pytest.mark.parametrize("phases", ["2", "3", "auto"])
+@pytest.mark.parametrize("phases", ["2", "3", "c2", "c4", "c8", "auto"])
 @pytest.mark.parametrize("name,gen", [
     ("web", lambda: synth.syn_webbase(0.1)),
     ("band", lambda: synth.syn_bandrandom(30000)),

@@ -430,7 +430,7 @@ def test_symmetric_tiles_inside_a_single_rowblock_gpu():
     check_y(csr, x, y, -1.5, 0.5, y0)
 
 
-@pytest.mark.parametrize("phases", ["2", "3", "5"])
+@pytest.mark.parametrize("phases", ["2", "3", "5", "c2", "c4"])
 def test_column_phases(tmp_path, phases):
     """spx.gpu.col_phases: the stream holds the matrix as a sum of column slices, each a run of
     row-blocks of its own (first one flagged SPX_RB_PHASE_START = 4); slice 0 covers every row,
@@ -443,14 +443,16 @@ def test_column_phases(tmp_path, phases):
     A.save(f)
     s = Stream(f)
     starts = np.flatnonzero((s.rbs["flags"] & 4) != 0)
-    assert len(starts) == int(phases) - 1 and starts[0] > 0
+    concurrent = phases.startswith("c")       # one launch, a group of XCDs per slice: every row-block adds (flag 8)
+    K = int(phases.lstrip("c"))
+    assert len(starts) == K - 1 and starts[0] > 0
+    assert bool((s.rbs["flags"] & 8).all()) == concurrent and bool((s.rbs["flags"] & 8).any()) == concurrent
     bounds = [0] + [int(v) for v in starts] + [len(s.rbs)]
-    K = int(phases)
     for k in range(K):
         part = s.rbs[bounds[k]:bounds[k + 1]]
         r0 = part["row0"].astype(np.int64)
         assert np.all(np.diff(r0) > 0)                                   # ascending inside a slice
-        if k == 0:
+        if k == 0 and not concurrent:
             assert int(part["n_rows"].astype(np.int64).sum()) == n       # slice 0 stores every row
     r, c, v, b, m = dense_of(s)
     lo = np.array([n * k // K for k in range(K + 1)])
