@@ -30,10 +30,16 @@
  *                           of merging equal row segments of consecutive rows
  *   spx.gpu.recut_linear    "false": vertical / diagonal / strided units always run one
  *                           nonzero per lane, even where they line up along rows
- *   spx.gpu.col_phases      general path: the stream as a sum of K column slices launched in turn (slice k > 0
- *                           adds to y), each slice's x fitting an XCD's L2: 1 (off), 2..8, or "auto" (default:
- *                           measured at tune time for leftover-dominated matrices whose x exceeds 6 MB; the
- *                           plain stream won on syn-webbase, profiles/r03/ablation.md)
+ *   spx.gpu.col_phases      general path: the stream as a sum of K column slices, A = A_0 + A_1 + ..., each a run of
+ *                           row-blocks of its own, so that a workgroup only gathers from 1 / K of x (a slice that
+ *                           fits the 4 MB of L2 of an XCD).  "c2" | "c4" | "c8": all slices in ONE launch, slice k on
+ *                           its own group of 8 / K XCDs, every row-block adding its y tile on top of a beta * y pass
+ *                           (global atomics: not with spx.gpu.deterministic); "2" .. "8": the slices launched one
+ *                           after the other (slice k > 0 adds to y; measured slower than the plain stream:
+ *                           every launch has a ~10 us critical path); "1": off; "auto" (default): for
+ *                           leftover-dominated matrices whose x exceeds 6 MB, two and four concurrent slices
+ *                           are measured against the plain stream at tune time and the fastest stays
+ *                           (syn-webbase: 38.7 us plain, 32.6 us with two slices; profiles/r03/ablation.md)
  *   spx.gpu.band_order      "true": row-blocks are launched strip by strip across the planes of a stencil
  *                           instead of in row order (measured 4-7 % slower on the KKT stand-in: off)
  *   spx.gpu.keep_units      "false": ... even those none of whose nonzeros has a neighbour along

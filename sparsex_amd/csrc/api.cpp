@@ -867,22 +867,31 @@ static spx_matrix_t *do_tune(spx_input_t *in)
             return best;
         };
         const double t_plain = best_of();
-        // slices of at most 2.5 MB of x, each on its own group of XCDs in one launch (2, 4 or 8 of them)
-        size_t K = 2;
-        while (K < 8 && (size_t) A->ncols * sizeof(val_t) > K * ((size_t) 5 << 19)) K *= 2;
-        double t_ph = 2.0 * t_plain;
+        // two and four slices of the columns, each on its own group of XCDs in one launch: fewer
+        // line fills per gather against shorter row pieces and one more atomic hand-over of y per
+        // slice (syn-webbase: 38.7 us plain, 32.6 with two, 35.6 with four, 54.6 with eight)
+        size_t K = 1;
+        double t_ph = t_plain;
         if (!A->deterministic) {
-            try {
-                A->col_phases = K;
-                A->col_concurrent = true;
-                emit_and_upload(A.get());
-                t_ph = best_of();
-            } catch (const FatalError &) {
+            for (size_t k : {(size_t) 2, (size_t) 4}) {
+                if ((size_t) A->ncols * sizeof(val_t) < k * ((size_t) 3 << 19)) break;      // (slices below 1.5 MB of x: nothing to gain)
+                try {
+                    A->col_phases = k;
+                    A->col_concurrent = true;
+                    emit_and_upload(A.get());
+                    const double t = best_of();
+                    if (t < 0.97 * t_ph) {
+                        t_ph = t;
+                        K = k;
+                    }
+                } catch (const FatalError &) {
+                    break;
+                }
             }
         }
-        if (t_ph >= 0.97 * t_plain) {
-            A->col_phases = 1;
-            A->col_concurrent = false;
+        if (A->col_phases != K || !A->col_concurrent) {
+            A->col_phases = K;
+            A->col_concurrent = K > 1;
             emit_and_upload(A.get());
         }
         log_msg(LOG_INFO, "column slices: %zu on XCD groups %.2f us, plain %.2f us per SpMV\n", K, 1e6 * t_ph, 1e6 * t_plain);
