@@ -23,6 +23,11 @@ for seed in range(a, b):
     else:
         o["spx.gpu.rowblock_rows"] = str([512, 1024, 2048][seed % 3 if seed % 9 else 2])
     o["spx.gpu.waves"] = str([0, 2, 4, 8][seed % 4])
+    # round 3: column slices (one launch / launched in turn), kept units, band launch order
+    if not sym:
+        o["spx.gpu.col_phases"] = ["1", "c2", "c4", "2", "3", "c8", "auto"][seed % 7]
+    o["spx.gpu.keep_units"] = "false" if seed % 5 == 0 else "true"
+    o["spx.gpu.band_order"] = "true" if seed % 4 == 1 else "false"
     try:
         A = tune(csr, o, sym=sym)
         x = synth.random_x(n)
