@@ -340,3 +340,38 @@ def test_column_phases(name, gen, phases):
     y1 = y0.copy()
     A.matvec_kernel(1.5, x, -0.25, y1)
     check_y(csr, x, y1, 1.5, -0.25, y0)
+
+
+def test_band_launch_order_keeps_the_product_and_the_stream(tmp_path):
+    """spx.gpu.band_order: where the rows read x in bands that recur at a fixed row distance (a 3-D
+    stencil), the row-blocks of every XCD's part go up in another launch order (device copy only).
+    The product is the same, entries are found and set where they are, and a saved matrix holds the
+    stream in its own order again."""
+    csr = synth.syn_nlpkkt_rows(48)
+    rp, ci, va, n = csr
+    va = va.copy()
+    opts = {"spx.gpu.band_order": "true", "spx.gpu.rowblock_elems": "700", "spx.rt.nr_threads": "4",
+            "spx.gpu.waves": "4", "spx.gpu.wave_tiles": "false"}      # (pinned: nothing the launch tuner measures goes into the file)
+    A = tune((rp, ci, va, n), opts)
+    P = tune((rp, ci, va, n), dict(opts, **{"spx.gpu.band_order": "false"}))
+    assert A.info().n_rowblocks == P.info().n_rowblocks > 4096
+    x = synth.random_x(n)
+    y = np.full(n, np.nan)
+    A.matvec_mult(0.5, x, y)
+    check_y((rp, ci, va, n), x, y, 0.5)
+    row = n - 1000
+    k = int(rp[row])
+    assert A.get_entry(row, int(ci[k])) == va[k]
+    A.set_entry(row, int(ci[k]), 3.5)
+    va[k] = 3.5
+    fa, fp = str(tmp_path / "a.spx"), str(tmp_path / "p.spx")
+    A.save(fa)
+    P.set_entry(row, int(ci[k]), 3.5)
+    P.save(fp)
+    # same bytes as the matrix that was never reordered (the order is the device's business)
+    assert open(fa, "rb").read() == open(fp, "rb").read()
+    B = sx.mat_restore(fa)
+    y2 = np.full(n, np.nan)
+    B.matvec_mult(0.5, x, y2)
+    check_y((rp, ci, va, n), x, y2, 0.5)
+    assert B.get_entry(row, int(ci[k])) == 3.5

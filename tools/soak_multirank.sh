@@ -11,6 +11,9 @@ run() {
   if echo "$out" | grep -q '^{"metric"'; then echo "ok   world $w $*  $(echo "$out" | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['parity']['max_err_over_fp64_bound'], d['roofline']['kernel'][:60])")"; else echo "FAIL world $w $*"; echo "$out" | cut -c1-300; fail=1; fi
 }
 for w in 2 3 4; do
+  run $w --edge 30
+  run $w --workload syn-kkt2f --edge 24
+  run $w --workload syn-kkt2f --edge 24 --symmetric --opt spx.gpu.sym_segments=true
   for e in 22 37; do
     run $w --edge $e --symmetric --opt spx.gpu.sym_segments=true --opt spx.gpu.sym_wide_rows=2048
     run $w --edge $e --symmetric --opt spx.gpu.sym_segments=true --opt spx.gpu.sym_wide_rows=512 --opt spx.gpu.sym_segment_min=4

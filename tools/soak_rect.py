@@ -27,6 +27,7 @@ for seed in range(a0, b0):
         continue
     o = random_options(seed)
     o["spx.gpu.rowblock_rows"] = str([3, 512, 1024, 2048][seed % 4])
+    o["spx.gpu.col_phases"] = ["1", "c2", "c4", "3", "c8", "auto"][seed % 6]        # round 3
     try:
         sx.options_reset()
         for k, v in o.items():
