@@ -985,6 +985,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # several ranks: the whole run is bounded as well -- a rank that hangs in an exchange inside the
+    # timed region (a peer died) must not sit on the lease; on expiry it leaves with code 86
+    overall = Watchdog(int(os.environ.get("SPX_BENCH_TOTAL_TIMEOUT", "1500")), "bench.py on several ranks") if world > 1 else None
+    if overall:
+        overall.__enter__()
     ctx = {"torch": torch, "dist": dist, "sx": sx, "rank": rank, "world": world, "dev": dev,
            "backend": backend, "barrier": barrier, "reduce_max": reduce_max,
            "transport": None, "transport_name": "none"}
@@ -1046,6 +1051,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if overall:
+        overall.__exit__(None, None, None)
 
 
 if __name__ == "__main__":
