@@ -238,7 +238,12 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
             const int dcol = (kind == SPX_KIND_HORIZ || kind == SPX_KIND_DIAG)
                                  ? step : (kind == SPX_KIND_ADIAG ? -step : 0);
             row[b] = (int) (ps[b].elem0 + (bits & 511u)) + s * drow;
+#ifdef SPX_ABL_XSMALL
+            // (ablation: the same x loads, all of them out of 8 KB of x -- L1 / L2 hits)
+            const uint32_t col = (q[b].x + (uint32_t) (s * dcol)) & 1023u;
+#else
             const uint32_t col = q[b].x + (uint32_t) (s * dcol);
+#endif
             const double *xp = a.x + col;
 #ifdef SPX_ABL_NOX
 #pragma unroll
