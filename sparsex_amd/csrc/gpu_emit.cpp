@@ -332,6 +332,12 @@ void RbBuilder::emit_unit_passes(SpxRowBlock &rb, bool sym, uint32_t row_base)
                 out_.values[base + spx_pass_value_index((uint32_t) l, w, (uint32_t) nseg, width)] =
                     gvals_[g.voff + (size_t) lanes[l].s * width + w];
         }
+        if (!sym && ps.mask == 0) {
+            // one descriptor for the whole pass: it travels in the pass header (SPX_PASSF_INLINE)
+            const SpxUnitDesc &d = out_.descs[(size_t) rb.desc_off + ps.rank0];
+            ps.mask = (uint64_t) d.col0 | ((uint64_t) d.bits << 32);
+            ps.flags |= SPX_PASSF_INLINE;
+        }
         out_.passes.push_back(ps);
         ++rb.n_pass;
         lanes.clear();

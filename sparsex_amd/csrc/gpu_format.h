@@ -126,9 +126,16 @@ static inline uint32_t spx_desc_bits(uint32_t row0, uint32_t sstart, uint32_t ki
     return (row0 & 511u) | ((sstart & 8191u) << 9) | ((kind & 7u) << 22) | ((step & 127u) << 25);
 }
 
+#define SPX_PASSF_INLINE 1u  /* unit pass whose lanes all belong to ONE descriptor (its start mask would be
+                                zero): `mask` holds that descriptor instead, {col0, bits}.  The wavefront has
+                                it with the pass header -- which is fetched a round ahead -- and computes rows
+                                and x addresses without waiting for a descriptor load: one dependent round
+                                trip per pass instead of two (the descriptor is in `descs` as well, where the
+                                host-side decoders keep reading it)                                      */
 typedef struct {
     uint64_t mask;       /* unit pass, bit l: lane l's segment starts a new unit;
-                            bit 0 is never set                                  */
+                            bit 0 is never set.  SPX_PASSF_INLINE: the pass' only
+                            descriptor, col0 | (uint64_t) bits << 32               */
     uint32_t val_off;    /* first value of the pass, relative to the row-block  */
     uint16_t rank0;      /* unit pass: descriptor of lane 0's segment           */
     uint16_t seg0;       /* unit pass: segments in front of lane 0
@@ -137,7 +144,7 @@ typedef struct {
     uint8_t  nseg;       /* active lanes, 1..64                                  */
     uint8_t  width;      /* W: nonzeros per lane                                 */
     uint8_t  kind;       /* SPX_PASS_UNIT / _GATHER / _GATHER_LDS / _SYMTILE      */
-    uint8_t  pad_;
+    uint8_t  flags;      /* SPX_PASSF_*                                          */
     uint32_t elem0;      /* gather pass: leftover nonzeros of the row-block in
                             front of this pass (index of its first column offset)
                             other passes: added to the rows of their descriptors
@@ -208,6 +215,12 @@ static inline uint32_t spx_pass_value_index(uint32_t lane, uint32_t w, uint32_t 
     uint32_t pair = w >> 1;
     if ((width & 1u) && w == width - 1u) return pair * 2u * nseg + lane;
     return pair * 2u * nseg + lane * 2u + (w & 1u);
+}
+
+/* the start mask of a unit pass (an inline descriptor stands for "no starts") */
+static inline uint64_t spx_pass_mask(const SpxPass *ps)
+{
+    return (ps->flags & SPX_PASSF_INLINE) ? 0ull : ps->mask;
 }
 
 #endif /* SPX_GPU_FORMAT_H */

@@ -173,8 +173,17 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
                     goff[b][w] = reinterpret_cast<const uint16_t *>(cidx)[e0 + (uint32_t) w * nseg[b]];
             }
         } else {
-            const uint32_t rank = (uint32_t) ps[b].rank0 + (active[b] ? starts_upto(ps[b].mask, lane) : 0u);
-            q[b] = ld_stream(reinterpret_cast<const uint2 *>(a.descs + rb.desc_off + rank));
+#ifndef SPX_NO_INLINE_DESC
+            if (ps[b].flags & SPX_PASSF_INLINE) {
+                // the pass' only descriptor came with its header (wave-uniform, in SGPRs)
+                q[b].x = (uint32_t) ps[b].mask;
+                q[b].y = (uint32_t) (ps[b].mask >> 32);
+            } else
+#endif
+            {
+                const uint32_t rank = (uint32_t) ps[b].rank0 + (active[b] ? starts_upto(ps[b].mask, lane) : 0u);
+                q[b] = ld_stream(reinterpret_cast<const uint2 *>(a.descs + rb.desc_off + rank));
+            }
         }
     }
     double2 v2[B][W / 2 > 0 ? W / 2 : 1];
@@ -262,7 +271,7 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
             // are extra work); not enabled.
 #ifdef SPX_CHAIN_X
             const uint32_t bits0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) bits);
-            const bool chain = W >= 2 && W <= 4 && ps[b].mask == 0ull && nseg[b] >= (uint32_t) W &&
+            const bool chain = W >= 2 && W <= 4 && (ps[b].mask == 0ull || (ps[b].flags & SPX_PASSF_INLINE)) && nseg[b] >= (uint32_t) W &&
                                ((bits0 >> 22) & 7u) == SPX_KIND_DIAG && (bits0 >> 25) == 1u;
 #else
             const bool chain = false;

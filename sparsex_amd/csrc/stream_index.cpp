@@ -24,7 +24,7 @@ inline void unit_lane(const GpuStream &s, const SpxRowBlock &rb, const SpxPass &
 {
     // (read-once symmetric segments: two entries per unit, the second holds the slot)
     const uint32_t stride = ps.kind == SPX_PASS_SYMSEG ? 2u : 1u;
-    const uint32_t rank = (uint32_t) ps.rank0 + stride * popcount_upto(ps.mask, l);
+    const uint32_t rank = (uint32_t) ps.rank0 + stride * popcount_upto(spx_pass_mask(&ps), l);
     const SpxUnitDesc &d = s.descs[(size_t) rb.desc_off + rank];
     if (slot) *slot = stride == 2 ? s.descs[(size_t) rb.desc_off + rank + 1].col0 : SPX_NO_SLOT;
     const uint32_t bits = d.bits;
@@ -182,7 +182,7 @@ void band_offsets(const GpuStream &s, const SpxRowBlock &rb, int64_t gap, std::v
         const SpxPass &ps = s.passes[(size_t) rb.pass_off + t];
         if (ps.kind != SPX_PASS_UNIT && ps.kind != SPX_PASS_SYMSEG) continue;
         const uint32_t stride = ps.kind == SPX_PASS_SYMSEG ? 2u : 1u;
-        const uint32_t n = popcount_upto(ps.mask, (uint32_t) ps.nseg - 1u) + 1u;
+        const uint32_t n = popcount_upto(spx_pass_mask(&ps), (uint32_t) ps.nseg - 1u) + 1u;
         for (uint32_t k = 0; k < n; ++k)
             cols.push_back((int64_t) s.descs[(size_t) rb.desc_off + ps.rank0 + stride * k].col0);
     }
@@ -342,8 +342,13 @@ bool stream_validate(const GpuStream &s, size_t nrows, size_t ncols, size_t n_va
                 const bool sym = ps.kind == SPX_PASS_SYMSEG;
                 SPX_REQUIRE(ps.kind == SPX_PASS_UNIT || sym, "pass kind");
                 SPX_REQUIRE(!sym || s.sym_atomic, "read-once segments without the atomic hand-over");
-                SPX_REQUIRE((ps.mask & 1ull) == 0, "segment-start mask");
-                const uint32_t last = (uint32_t) ps.rank0 + (sym ? 2u : 1u) * popcount_upto(ps.mask, nseg - 1) + (sym ? 1u : 0u);
+                SPX_REQUIRE((spx_pass_mask(&ps) & 1ull) == 0, "segment-start mask");
+                SPX_REQUIRE(!(ps.flags & SPX_PASSF_INLINE) ||
+                            (!sym && (size_t) rb.desc_off + ps.rank0 < s.descs.size() &&
+                             ps.mask == ((uint64_t) s.descs[(size_t) rb.desc_off + ps.rank0].col0 |
+                                         ((uint64_t) s.descs[(size_t) rb.desc_off + ps.rank0].bits << 32))),
+                            "inline descriptor");
+                const uint32_t last = (uint32_t) ps.rank0 + (sym ? 2u : 1u) * popcount_upto(spx_pass_mask(&ps), nseg - 1) + (sym ? 1u : 0u);
                 SPX_REQUIRE((size_t) rb.desc_off + last < s.descs.size(), "descriptor range");
                 for (uint32_t l = 0; l < nseg; ++l) {
                     int64_t r, c;

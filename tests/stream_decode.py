@@ -13,7 +13,7 @@ RB = np.dtype([("val_off", "<u8"), ("pass_off", "<u4"), ("desc_off", "<u4"), ("c
                ("carry_slot", "<u4"), ("spill_off", "<u4"), ("xwin_base", "<u4"), ("xwin_len", "<u2"),
                ("near_off", "<u2"), ("hi_off", "<u4"), ("pad2", "<u4")])
 PASS = np.dtype([("mask", "<u8"), ("val_off", "<u4"), ("rank0", "<u2"), ("seg0", "<u2"),
-                 ("nseg", "u1"), ("width", "u1"), ("kind", "u1"), ("pad", "u1"), ("elem0", "<u4")])
+                 ("nseg", "u1"), ("width", "u1"), ("kind", "u1"), ("flags", "u1"), ("elem0", "<u4")])
 DESC = np.dtype([("col0", "<u4"), ("bits", "<u4")])
 SHARED = np.dtype([("row", "<u4"), ("first_slot", "<u4"), ("n_slots", "<u4")])
 assert RB.itemsize == 64 and PASS.itemsize == 24 and DESC.itemsize == 8
@@ -81,11 +81,18 @@ class Stream:
                     # entries per unit, the second holds the slot; every value counts twice)
                     sym = ps["kind"] == 5
                     nseg, W, mask = int(ps["nseg"]), int(ps["width"]), int(ps["mask"])
+                    inline = bool(int(ps["flags"]) & 1)   # the pass' only descriptor sits in its header (`mask`)
+                    if inline:
+                        assert not sym
+                        one = np.zeros(1, dtype=DESC)
+                        one["col0"], one["bits"] = mask & 0xffffffff, mask >> 32
+                        assert one[0] == self.descs[int(rb["desc_off"]) + int(ps["rank0"])], "inline descriptor differs"
+                        mask = 0
                     assert 1 <= nseg <= 64 and 1 <= W <= 8 and not (mask & 1)
                     lanes = np.arange(nseg)
                     starts = np.array([(mask >> l) & 1 for l in range(nseg)])
                     rank = int(ps["rank0"]) + (2 if sym else 1) * np.cumsum(starts)
-                    d = self.descs[int(rb["desc_off"]) + rank]
+                    d = np.repeat(one, nseg) if inline else self.descs[int(rb["desc_off"]) + rank]
                     bits = d["bits"].astype(np.int64)
                     s = (int(ps["seg0"]) + lanes - ((bits >> 9) & 8191)) & 0xffff
                     kind, step = (bits >> 22) & 7, bits >> 25
