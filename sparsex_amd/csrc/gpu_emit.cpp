@@ -45,8 +45,8 @@ struct Group {
 
 class RbBuilder {
 public:
-    RbBuilder(const Partition &p, GpuStream &out, bool stack = true, bool x_window = true)
-        : p_(p), out_(out), stack_(stack), x_window_(x_window) {}
+    RbBuilder(const Partition &p, GpuStream &out, bool stack = true, bool x_window = true, bool inline_desc = true)
+        : p_(p), out_(out), stack_(stack), x_window_(x_window), inline_desc_(inline_desc) {}
 
     // rows [lo, hi) of the partition with what the planner cut out for them
     struct Part {
@@ -106,6 +106,7 @@ private:
     GpuStream &out_;
     bool stack_;
     bool x_window_;
+    bool inline_desc_;
     std::vector<Group> groups_;
     std::vector<val_t> gvals_;
     std::vector<idx_t> slot_groups_;   // first columns of the row-block's slot groups (ascending)
@@ -332,8 +333,9 @@ void RbBuilder::emit_unit_passes(SpxRowBlock &rb, bool sym, uint32_t row_base)
                 out_.values[base + spx_pass_value_index((uint32_t) l, w, (uint32_t) nseg, width)] =
                     gvals_[g.voff + (size_t) lanes[l].s * width + w];
         }
-        if (!sym && ps.mask == 0) {
-            // one descriptor for the whole pass: it travels in the pass header (SPX_PASSF_INLINE)
+        if (ps.mask == 0 && inline_desc_) {
+            // one descriptor for the whole pass: it travels in the pass header (SPX_PASSF_INLINE;
+            // a read-once pass still fetches its slot entry, which it needs last)
             const SpxUnitDesc &d = out_.descs[(size_t) rb.desc_off + ps.rank0];
             ps.mask = (uint64_t) d.col0 | ((uint64_t) d.bits << 32);
             ps.flags |= SPX_PASSF_INLINE;
@@ -1661,7 +1663,7 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsi
         else emit_plan(jobs[k].first, bld, dst);
     };
     if (nthreads <= 1 || jobs.size() < 64) {
-        RbBuilder bld(p, out, prm.stack_segments, prm.x_window);
+        RbBuilder bld(p, out, prm.stack_segments, prm.x_window, prm.inline_desc);
         for (size_t k = 0; k < jobs.size(); ++k) emit_job(k, bld, out);
         return;
     }
@@ -1669,7 +1671,7 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsi
     std::vector<GpuStream> locs(n_chunks);
     parallel_for(n_chunks, nthreads, [&](size_t c) {
         const size_t lo = jobs.size() * c / n_chunks, hi = jobs.size() * (c + 1) / n_chunks;
-        RbBuilder bld(p, locs[c], prm.stack_segments, prm.x_window);
+        RbBuilder bld(p, locs[c], prm.stack_segments, prm.x_window, prm.inline_desc);
         for (size_t k = lo; k < hi; ++k) emit_job(k, bld, locs[c]);
     });
     for (GpuStream &l : locs) append_stream(out, std::move(l));

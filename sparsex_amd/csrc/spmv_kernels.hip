@@ -181,7 +181,8 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
             } else
 #endif
             {
-                const uint32_t rank = (uint32_t) ps[b].rank0 + (active[b] ? starts_upto(ps[b].mask, lane) : 0u);
+                const uint64_t mk = (ps[b].flags & SPX_PASSF_INLINE) ? 0ull : ps[b].mask;
+                const uint32_t rank = (uint32_t) ps[b].rank0 + (active[b] ? starts_upto(mk, lane) : 0u);
                 q[b] = ld_stream(reinterpret_cast<const uint2 *>(a.descs + rb.desc_off + rank));
             }
         }
@@ -525,9 +526,20 @@ __device__ __forceinline__ void symseg_passes(const KernelArgs &a, const SpxRowB
         nseg[b] = ps[b].nseg;
         active[b] = (uint32_t) lane < nseg[b];
         l[b] = active[b] ? (uint32_t) lane : 0u;
-        const uint32_t rank = (uint32_t) ps[b].rank0 + 2u * (active[b] ? starts_upto(ps[b].mask, lane) : 0u);
-        q[b] = ld_stream(reinterpret_cast<const uint2 *>(a.descs + rb.desc_off + rank));
-        slot0[b] = a.descs[rb.desc_off + rank + 1u].col0;
+#ifndef SPX_NO_INLINE_DESC
+        if (ps[b].flags & SPX_PASSF_INLINE) {
+            // (the pass' only descriptor came with its header; its slot entry is needed last)
+            q[b].x = (uint32_t) ps[b].mask;
+            q[b].y = (uint32_t) (ps[b].mask >> 32);
+            slot0[b] = a.descs[rb.desc_off + (uint32_t) ps[b].rank0 + 1u].col0;
+        } else
+#endif
+        {
+            const uint64_t mk = (ps[b].flags & SPX_PASSF_INLINE) ? 0ull : ps[b].mask;
+            const uint32_t rank = (uint32_t) ps[b].rank0 + 2u * (active[b] ? starts_upto(mk, lane) : 0u);
+            q[b] = ld_stream(reinterpret_cast<const uint2 *>(a.descs + rb.desc_off + rank));
+            slot0[b] = a.descs[rb.desc_off + rank + 1u].col0;
+        }
     }
     double v[B][W];
 #pragma unroll
@@ -579,7 +591,7 @@ __device__ __forceinline__ void symseg_passes(const KernelArgs &a, const SpxRowB
         // the rest from the neighbours -- see unit_passes)
 #ifdef SPX_CHAIN_X
         const uint32_t bits0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) bits);
-        const bool chain = W <= 4 && ps[b].mask == 0ull && nseg[b] >= (uint32_t) W &&
+        const bool chain = W <= 4 && (ps[b].mask == 0ull || (ps[b].flags & SPX_PASSF_INLINE)) && nseg[b] >= (uint32_t) W &&
                            ((bits0 >> 22) & 7u) == SPX_KIND_DIAG && (bits0 >> 25) == 1u;
 #else
         const bool chain = false;

@@ -344,7 +344,7 @@ bool stream_validate(const GpuStream &s, size_t nrows, size_t ncols, size_t n_va
                 SPX_REQUIRE(!sym || s.sym_atomic, "read-once segments without the atomic hand-over");
                 SPX_REQUIRE((spx_pass_mask(&ps) & 1ull) == 0, "segment-start mask");
                 SPX_REQUIRE(!(ps.flags & SPX_PASSF_INLINE) ||
-                            (!sym && (size_t) rb.desc_off + ps.rank0 < s.descs.size() &&
+                            ((size_t) rb.desc_off + ps.rank0 < s.descs.size() &&
                              ps.mask == ((uint64_t) s.descs[(size_t) rb.desc_off + ps.rank0].col0 |
                                          ((uint64_t) s.descs[(size_t) rb.desc_off + ps.rank0].bits << 32))),
                             "inline descriptor");

@@ -83,7 +83,6 @@ class Stream:
                     nseg, W, mask = int(ps["nseg"]), int(ps["width"]), int(ps["mask"])
                     inline = bool(int(ps["flags"]) & 1)   # the pass' only descriptor sits in its header (`mask`)
                     if inline:
-                        assert not sym
                         one = np.zeros(1, dtype=DESC)
                         one["col0"], one["bits"] = mask & 0xffffffff, mask >> 32
                         assert one[0] == self.descs[int(rb["desc_off"]) + int(ps["rank0"])], "inline descriptor differs"
