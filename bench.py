@@ -521,8 +521,14 @@ def measured_traffic(key):
 def kernel_name(info, symmetric, world):
     w = int(info.waves)
     tiles = int(info.sym_tiles)
-    gen = "csx_spmv_det_kernel<%d> (a y tile per wavefront)" % w if int(info.wave_tiles) else "csx_spmv_kernel<%d>" % w
+    gen = "csx_spmv_det_kernel<%d> (a y tile per wavefront)" % w if int(info.wave_tiles) else (
+        "csx_spmv_quad_kernel<%d>" % w if int(info.quad) else "csx_spmv_kernel<%d>" % w)
     if not symmetric:
+        k = int(info.col_slices)
+        if k > 1:
+            return "csx_scale_kernel + csx_spmv_accum_kernel<%d> (%d column slices, a group of %d XCDs each)" % (w, k, 8 // k)
+        if k < -1:
+            return gen + " x %d (column slices launched in turn)" % -k
         return gen
     if tiles == 2 and int(info.sym_segments):
         main = "csx_sym_init_kernel + csx_spmv_symseg_%skernel<%d>" % ("notile_" if int(info.sym_segments) == 2 else "", w)

@@ -48,7 +48,8 @@ class HipInfo(C.Structure):
                 ("symmetric", C.c_int32), ("on_device", C.c_int32),
                 ("device", C.c_int32), ("waves", C.c_int32), ("sym_tiles", C.c_int32),
                 ("tune_seconds", C.c_double),
-                ("emit_seconds", C.c_double), ("wave_tiles", C.c_int32), ("sym_segments", C.c_int32)]
+                ("emit_seconds", C.c_double), ("wave_tiles", C.c_int32), ("sym_segments", C.c_int32),
+                ("quad", C.c_int32), ("col_slices", C.c_int32)]
 
 
 class CsxExport(C.Structure):

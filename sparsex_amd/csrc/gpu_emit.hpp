@@ -74,6 +74,7 @@ struct GpuStream {
     // finalize_stream() ran (0: packed, as the emitter appends them)
     uint32_t pass_stride = 0;
     uint32_t waves = 4;           // wavefronts per workgroup the kernel is launched with
+    bool quad = false;            // general path: launch csx_spmv_quad_kernel (spx.gpu.quad, measured at tune time)
     bool band_order = false;      // spx.gpu.band_order: launch order by strips across recurring bands of x (device side only)
     // accounting
     size_t nnz_stored = 0;        // nonzeros held in `values` (without padding)

@@ -361,6 +361,18 @@ __device__ __forceinline__ void run_units(const KernelArgs &a, const SpxRowBlock
     }
 }
 
+// four unit passes of the same narrow width side by side (general kernels): with three values per
+// lane a pair of passes keeps too little in flight per wavefront
+__device__ __forceinline__ void run_units4(const KernelArgs &a, const SpxRowBlock &rb,
+                                           const SpxPass (&ps)[4], double *tile, const double *win, int lane)
+{
+    switch (ps[0].width) {         // wave-uniform
+    case 1: unit_passes<1, 4, 0>(a, rb, ps, tile, win, lane); break;
+    case 2: unit_passes<2, 4, 0>(a, rb, ps, tile, win, lane); break;
+    default: unit_passes<3, 4, 0>(a, rb, ps, tile, win, lane); break;
+    }
+}
+
 // lane ^ 1, ^ 2, ^ 4 inside groups of eight lanes as DPP moves (VALU) instead of
 // ds_bpermute (__shfl_xor goes through the LDS crossbar): quad_perm for 1 and 2,
 // row_half_mirror followed by a reversed quad for 4 (lane i <- 7-i <- (7-i)^3 = i^4).
@@ -701,7 +713,8 @@ __device__ __forceinline__ void run_pass(const KernelArgs &a, const SpxRowBlock 
 // own, and the copies are summed in wavefront order before the write-out -- the
 // only thing in this library whose order of additions is not fixed is the LDS adds
 // of different wavefronts of a workgroup into the shared tile.
-template <bool SYM, bool ATOMIC, int WAVES_PER_BLOCK, bool DET = false, bool SEGS = false, bool TILES = true>
+template <bool SYM, bool ATOMIC, int WAVES_PER_BLOCK, bool DET = false, bool SEGS = false, bool TILES = true,
+          bool QUAD = false>
 __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &xs,
                                           double *lds)
 {
@@ -725,6 +738,12 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &x
     const SpxRowBlock rb = a.rbs[rb_idx];
     SpxPass p0 = passes[wave];
     SpxPass p1 = passes[wave + WAVES_PER_BLOCK];         // (the table is padded by one stride)
+    // (the quad kernel keeps the pair after that in hand as well: four narrow unit passes run side by side)
+    SpxPass n0 = p0, n1 = p1;
+    if (QUAD) {
+        n0 = passes[wave + 2 * WAVES_PER_BLOCK];
+        n1 = passes[wave + 3 * WAVES_PER_BLOCK];
+    }
     const int n_rows = rb.n_rows;
     const int n_slots = SYM ? (int) rb.n_slots : 0;
     const int core = n_slots + n_rows;                       // doubles per copy of slots + y tile
@@ -760,6 +779,21 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &x
 #endif
     for (int t = wave; t < n_pass; t += 2 * WAVES_PER_BLOCK) {
         const bool two = t + WAVES_PER_BLOCK < n_pass;
+#ifndef SPX_NO_QUAD
+        if (QUAD && t + 3 * WAVES_PER_BLOCK < n_pass && p0.kind == SPX_PASS_UNIT && p0.width <= 3 &&
+            p1.kind == SPX_PASS_UNIT && n0.kind == SPX_PASS_UNIT && n1.kind == SPX_PASS_UNIT &&
+            p1.width == p0.width && n0.width == p0.width && n1.width == p0.width) {
+            run_units4(a, rb, {p0, p1, n0, n1}, tile, win, lane);
+            t += 2 * WAVES_PER_BLOCK;                   // (two more passes taken)
+            if (t + 2 * WAVES_PER_BLOCK < n_pass) {
+                p0 = passes[t + 2 * WAVES_PER_BLOCK];
+                p1 = passes[t + 3 * WAVES_PER_BLOCK];
+                n0 = passes[t + 4 * WAVES_PER_BLOCK];
+                n1 = passes[t + 5 * WAVES_PER_BLOCK];
+            }
+            continue;
+        }
+#endif
         if (SEGS && (p0.kind == SPX_PASS_SYMSEG || (two && p1.kind == SPX_PASS_SYMSEG))) {
             // read-once row segments (atomic hand-over only); whatever shares the round runs on its own
             // (one at a time: two side by side, as the unit passes run, need 100 VGPRs instead of 62,
@@ -797,8 +831,15 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &x
             run_pass(a, rb, p0, tile, win, lane);
         }
         if (t + 2 * WAVES_PER_BLOCK < n_pass) {
-            p0 = passes[t + 2 * WAVES_PER_BLOCK];
-            p1 = passes[t + 3 * WAVES_PER_BLOCK];
+            if (QUAD) {
+                p0 = n0;
+                p1 = n1;
+                n0 = passes[t + 4 * WAVES_PER_BLOCK];
+                n1 = passes[t + 5 * WAVES_PER_BLOCK];
+            } else {
+                p0 = passes[t + 2 * WAVES_PER_BLOCK];
+                p1 = passes[t + 3 * WAVES_PER_BLOCK];
+            }
         }
     }
     __syncthreads();
@@ -887,6 +928,18 @@ void csx_spmv_accum_kernel(SPX_KERNEL_PARAMS)
     SPX_KERNEL_ARGS(a);
     extern __shared__ double lds_dyn[];
     spmv_body<false, true, WAVES>(a, xcd_split, lds_dyn);
+}
+
+// the general kernel with four narrow unit passes (width <= 3) side by side per wavefront: 78
+// instead of 56 VGPRs (six wavefronts per SIMD instead of eight) for twice the loads in flight
+// per wavefront; spx_mat_tune measures it against the plain kernel (spx.gpu.quad)
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES)
+void csx_spmv_quad_kernel(SPX_KERNEL_PARAMS)
+{
+    SPX_KERNEL_ARGS(a);
+    extern __shared__ double lds_dyn[];
+    spmv_body<false, false, WAVES, false, false, true, true>(a, xcd_split, lds_dyn);
 }
 
 template <int WAVES>
@@ -1068,6 +1121,7 @@ struct DeviceMatrix {
     std::vector<uint32_t> xcd_longest;
     // launch order (stream_band_order): device row-block i is row-block launch_order[i] of the
     // stream as the host holds it (empty: the same order); band_stride: the row distance found
+    bool quad = false;            // general path: csx_spmv_quad_kernel (measured at tune time)
     bool accum = false;           // SPX_RB_ACCUM: the column slices run in one launch and add to y
     std::vector<uint32_t> launch_order;
     size_t band_stride = 0;
@@ -1282,7 +1336,7 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
         }
         if (order.empty()) {
             m->rbs = upload(s.rbs);
-            m->passes = upload(s.passes, (size_t) s.pass_stride + 2 * MAX_WAVES_PER_BLOCK);
+            m->passes = upload(s.passes, (size_t) s.pass_stride + 6 * MAX_WAVES_PER_BLOCK);
         } else {
             const size_t stride = s.pass_stride;
             std::vector<SpxRowBlock> rbs(s.rbs.size());
@@ -1294,7 +1348,7 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
                           passes.begin() + i * stride);
             }
             m->rbs = upload(rbs);
-            m->passes = upload(passes, stride + 2 * MAX_WAVES_PER_BLOCK);
+            m->passes = upload(passes, stride + 6 * MAX_WAVES_PER_BLOCK);
             m->launch_order.swap(order);
         }
     }
@@ -1308,6 +1362,7 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
         (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&csx_spmv_symseg_notile_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&csx_spmv_symseg_notile_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     }
+    m->quad = s.quad && !symmetric && !m->accum;
     if (s.deterministic) device_set_deterministic(m, true);
     else if (s.wave_tiles) device_set_wave_tiles(m, true);
     m->n_values = s.values.size(); m->n_descs = s.descs.size(); m->n_passes = s.passes.size();
@@ -1466,6 +1521,11 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
             if (m->waves == 2) SPX_LAUNCH(csx_spmv_accum_kernel, 2, lds);
             else if (m->waves == 8) SPX_LAUNCH(csx_spmv_accum_kernel, 8, lds);
             else SPX_LAUNCH(csx_spmv_accum_kernel, 4, lds);
+        } else if (blocks && m->quad) {
+            const size_t lds = m->lds_doubles * sizeof(double);
+            if (m->waves == 2) SPX_LAUNCH(csx_spmv_quad_kernel, 2, lds);
+            else if (m->waves == 8) SPX_LAUNCH(csx_spmv_quad_kernel, 8, lds);
+            else SPX_LAUNCH(csx_spmv_quad_kernel, 4, lds);
         } else if (blocks) {
             const size_t lds = m->lds_doubles * sizeof(double);
             if (m->waves == 2) SPX_LAUNCH(csx_spmv_kernel, 2, lds);
@@ -1531,6 +1591,9 @@ void device_set_deterministic(DeviceMatrix *m, bool on)
 bool device_get_deterministic(const DeviceMatrix *m) { return m->deterministic; }
 bool device_get_sym_atomic(const DeviceMatrix *m) { return m->sym_atomic; }
 bool device_has_spill(const DeviceMatrix *m) { return m->has_tiles && m->n_spill; }
+
+void device_set_quad(DeviceMatrix *m, bool on) { m->quad = on && !m->symmetric && !m->accum && !m->wave_tiles; }
+bool device_get_quad(const DeviceMatrix *m) { return m->quad; }
 
 void device_set_waves(DeviceMatrix *m, int waves)
 {
@@ -1739,6 +1802,7 @@ void device_download(const DeviceMatrix *m, GpuStream &s)
     s.sym_atomic = m->sym_atomic;
     s.deterministic = m->deterministic;
     s.wave_tiles = m->wave_tiles;
+    s.quad = m->quad;
     if (m->n_spill) download(s.slot_group_col, m->slot_col, m->n_slot_col);
     if (m->n_spill) {
         download(s.fix_ptr, m->fix_ptr, m->n_fix_ptr);
