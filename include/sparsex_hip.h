@@ -46,8 +46,9 @@
  *                           (default: it travels in the pass header, SPX_PASSF_INLINE: one dependent round trip
  *                           per pass instead of two; 4-5 % on the KKT stand-in)
  *   spx.gpu.quad            general path, four narrow unit passes (width <= 3) side by side per wavefront
- *                           (csx_spmv_quad_kernel: 78 VGPRs, six wavefronts per SIMD): "true", "false", or
- *                           "auto" (default: spx_mat_tune() measures it against the plain kernel)
+ *                           (csx_spmv_quad_kernel: 78 VGPRs, six wavefronts per SIMD): "true", "auto" (spx_mat_tune()
+ *                           measures it against the plain kernel) or "false" (default: it never measured faster,
+ *                           profiles/r03/ablation.md section 10)
  *   spx.gpu.keep_units      "false": ... even those none of whose nonzeros has a neighbour along
  *                           its row (default: such a unit stays one descriptor -- the main diagonal
  *                           of a KKT system -- instead of a leftover nonzero per row)

@@ -48,7 +48,7 @@ void Config::reset_defaults()
     props_["spx.gpu.rowblock_rows"] = "512";   // max rows owned by one row-block
     props_["spx.gpu.stack_segments"] = "true"; // merge stacked row segments into block descriptors
     props_["spx.gpu.waves"] = "0";             // wavefronts per workgroup: 2, 4, 8; 0 = measured at tune time
-    props_["spx.gpu.quad"] = "auto";           // general path: four narrow unit passes side by side per wavefront: true | false | auto (measured)
+    props_["spx.gpu.quad"] = "false";          // general path: four narrow unit passes side by side per wavefront: true | false | auto (measured); never won: off
     props_["spx.gpu.inline_desc"] = "true";    // single-descriptor unit passes carry their descriptor in the pass header
     props_["spx.gpu.band_order"] = "false";    // launch order: strips across the planes of a stencil (measured slower: off)
     props_["spx.gpu.col_phases"] = "auto";     // general path: column slices launched in turn: 1 (off), 2..8, auto (measured)
