@@ -52,7 +52,10 @@ def run_bench(world, extra, port):
 ], ids=["nlpkkt", "nlpkkt-sym", "nlpkkt-sym-segments", "kkt2f-sym", "kkt2f-sym-segments", "kkt2f-sym-auto",
         "nd24k-sym", "nd24k-sym-atomic", "webbase"])
 def test_ranks_share_one_gpu(world, name, extra, tiles):
-    out = run_bench(world, extra, 29700 + 10 * world + len(name))
+    # (a port of its own per case: the cases run side by side under pytest -n)
+    names = ["nlpkkt", "nlpkkt-sym", "nlpkkt-sym-segments", "kkt2f-sym", "kkt2f-sym-segments", "kkt2f-sym-auto",
+             "nd24k-sym", "nd24k-sym-atomic", "webbase"]
+    out = run_bench(world, extra, 29600 + 20 * world + names.index(name))
     assert out["n_gpus"] == world and out["scaling"] == "strong" and out["value"] > 0
     paths = [out] + ([out["symmetric"]] if "symmetric" in out else [])
     assert ("symmetric" in out) == (not out["config"]["symmetric_path"] and name != "webbase")
