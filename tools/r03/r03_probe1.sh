@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-3 probe: host topology, mining ablation (default vs xform=none), symmetric row-block widths
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/r03b; mkdir -p $OUT; cd $ROOT
 { lscpu | head -30; echo; cat /sys/fs/cgroup/cpu.max 2>/dev/null; cat /sys/fs/cgroup/cpu/cpu.cfs_quota_us 2>/dev/null; numactl -H 2>/dev/null | head -20; python -c "import os;print(sorted(os.sched_getaffinity(0))[:8], len(os.sched_getaffinity(0)))"; } > $OUT/host.txt 2>&1
 M=$OUT/mining.md

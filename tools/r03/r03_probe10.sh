@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-3 probe 10: where the read-once kernel's stream time goes (more ablation builds); HBM temperature next to the run-to-run spread
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/r03k; mkdir -p $OUT; cd $ROOT
 for v in SEG_VALSONLY SEG_NOX SEG_NOFLUSH; do bash tools/build_variant.sh $v "-DSPX_ABL_$v" > /dev/null 2>&1; done
 bash tools/build_variant.sh SEG_NOX_NOFLUSH "-DSPX_ABL_SEG_NOX -DSPX_ABL_SEG_NOFLUSH" > /dev/null 2>&1

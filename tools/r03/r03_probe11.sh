@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-3 probe 11: column slices in ONE launch, a group of XCDs per slice (spx.gpu.col_phases = c2 | c4 | c8)
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/r03l; mkdir -p $OUT; cd $ROOT
 python -m pytest tests/test_gpu_parity.py -q -x -k "column_phases" > $OUT/pytest_phases.log 2>&1; tail -n 3 $OUT/pytest_phases.log
 S=$OUT/probe11.md

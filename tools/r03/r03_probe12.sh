@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-3 probe 12: is x a bandwidth or an instruction / latency cost?  (ablation: the same x loads out of 8 KB)
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/r03m; mkdir -p $OUT; cd $ROOT
 bash tools/build_variant.sh XSMALL "-DSPX_ABL_XSMALL" > /dev/null 2>&1
 bash tools/build_variant.sh NOX "-DSPX_ABL_NOX" > /dev/null 2>&1

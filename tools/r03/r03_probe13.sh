@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-3 probe 13: the descriptor of a single-descriptor unit pass inline in its header (one dependent round trip per pass instead of two)
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/r03n; mkdir -p $OUT; cd $ROOT
 python -m pytest tests/test_gpu_parity.py tests/test_gpu_random.py -x -q -n 4 > $OUT/pytest_parity.log 2>&1; tail -n 3 $OUT/pytest_parity.log
 bash tools/build_variant.sh NOINLINE "-DSPX_NO_INLINE_DESC" > /dev/null 2>&1

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-3 probe 14: inline descriptors on / off inside one process (spx.gpu.inline_desc)
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/r03o; mkdir -p $OUT; cd $ROOT
 python -m pytest tests/test_gpu_parity.py tests/test_gpu_random.py tests/test_stream_layout.py -x -q -n 4 -m gpu > $OUT/pytest_parity.log 2>&1; tail -n 3 $OUT/pytest_parity.log
 S=$OUT/probe14.md

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-3 probe 15: four narrow unit passes side by side (spx.gpu.quad), in-process A/B; what auto picks
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/r03p; mkdir -p $OUT; cd $ROOT
 python -m pytest tests/test_gpu_parity.py tests/test_gpu_random.py -x -q -n 4 > $OUT/pytest_parity.log 2>&1; tail -n 3 $OUT/pytest_parity.log
 S=$OUT/probe15.md

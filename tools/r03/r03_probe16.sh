@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-3 probe 16: hardware counters of the general kernel on syn-nlpkkt e120, full build and x loads compiled out
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/r03q; mkdir -p $OUT; cd $ROOT
 ( cd /tmp && TMPDIR=/tmp rocprofv3 --list-avail 2>/dev/null | grep -oE "\b(SQ|TA|TCP|TCC|TD|GRBM|SPI)_[A-Za-z0-9_]+" | sort -u > $OUT/counters_avail.txt ); wc -l $OUT/counters_avail.txt
 bash tools/build_variant.sh NOX "-DSPX_ABL_NOX" > /dev/null 2>&1

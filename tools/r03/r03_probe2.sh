@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-3 probe 2: isolated units kept as units (general path), larger slot windows + private row-blocks (symmetric path)
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/r03c; mkdir -p $OUT; cd $ROOT
 S=$OUT/probe2.md
 python tools/abl.py syn-nlpkkt --edge 120 --header default: > $S 2>$OUT/err.txt

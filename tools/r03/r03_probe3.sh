@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-3 probe 3: A/B of kept units (general), XCD split by values + no empty row-blocks (symmetric, wide row-blocks)
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/r03d; mkdir -p $OUT; cd $ROOT
 S=$OUT/probe3.md
 python tools/abl.py syn-nlpkkt --edge 120 --header keep: nokeep:spx.gpu.keep_units=false keep2: nokeep2:spx.gpu.keep_units=false > $S 2>$OUT/err.txt

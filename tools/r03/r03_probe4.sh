@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-3 probe 4: column phases on syn-webbase; bench.py vs tools/abl.py on the bench matrix
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/r03e; mkdir -p $OUT; cd $ROOT
 S=$OUT/probe4.md
 python tools/abl.py syn-webbase --header --steps 300 p1:spx.gpu.col_phases=1 p2:spx.gpu.col_phases=2 p3:spx.gpu.col_phases=3 p4:spx.gpu.col_phases=4 p5:spx.gpu.col_phases=5 p6:spx.gpu.col_phases=6 p8:spx.gpu.col_phases=8 auto: p1w4:spx.gpu.col_phases=1,spx.gpu.waves=4 p4w4:spx.gpu.col_phases=4,spx.gpu.waves=4 p4w8:spx.gpu.col_phases=4,spx.gpu.waves=8 p4r512:spx.gpu.col_phases=4,spx.gpu.rowblock_elems=1024 p4r4k:spx.gpu.col_phases=4,spx.gpu.rowblock_elems=4096 > $S 2>$OUT/err.txt

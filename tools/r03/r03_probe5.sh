@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-3 probe 5: non-temporal loads of the matrix stream, two read-once passes side by side (A/B builds made on the box)
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/r03f; mkdir -p $OUT; cd $ROOT
 bash tools/build_variant.sh TEMPORAL "-DSPX_STREAM_TEMPORAL" > /dev/null 2>&1
 bash tools/build_variant.sh SINGLE "-DSPX_SYMSEG_SINGLE" > /dev/null 2>&1

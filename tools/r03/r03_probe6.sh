@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-3 probe 6: what x costs the general kernel on the bench matrix (ablation build), load balance of eight slices
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/r03g; mkdir -p $OUT; cd $ROOT
 bash tools/build_variant.sh NOX "-DSPX_ABL_NOX" > /dev/null 2>&1
 bash tools/build_variant.sh NOATOMIC "-DSPX_ABL_NOATOMIC" > /dev/null 2>&1

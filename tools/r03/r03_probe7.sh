@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-3 probe 7: x of a diagonal stack through one full-width load + DPP wave shifts (A/B builds made on the box)
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/r03h; mkdir -p $OUT; cd $ROOT
 python -m pytest tests/test_gpu_parity.py tests/test_gpu_random.py -x -q -n 4 > $OUT/pytest_parity.log 2>&1; tail -n 3 $OUT/pytest_parity.log
 bash tools/build_variant.sh NOCHAIN "-DSPX_NO_CHAIN_X" > /dev/null 2>&1

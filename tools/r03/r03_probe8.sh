@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-3 probe 8: run-to-run spread of the bench matrix's product in separate processes; row-blocks dealt round robin
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/r03i; mkdir -p $OUT; cd $ROOT
 line() { python3 -c "
 import sys, json

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3: everything profiles/r03/ holds (rocprofv3 kernel stats, PMC passes, plain bench lines), then where
 # the read-once segment kernel's time goes on the bench matrix (ablation builds, made on the box)
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd $ROOT
 bash tools/refresh_profiles.sh r03 > gpurun_out/r03_refresh.log 2>&1
 tail -n 40 gpurun_out/r03_refresh.log

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3: extended randomised parity with the round's options in the draw (column slices, kept units, band order)
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/r03_soak; mkdir -p $OUT; cd $ROOT
 ( timeout 900 python tools/soak_random.py 0 700 > $OUT/random_a.log 2>&1; tail -n 3 $OUT/random_a.log ) &
 ( timeout 900 python tools/soak_random.py 700 1400 > $OUT/random_b.log 2>&1; tail -n 3 $OUT/random_b.log ) &

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3: the long soak (the round's options in every draw)
-ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/r03_soak2; mkdir -p $OUT; cd $ROOT
 python -m pytest tests/test_gpu_parity.py -q -x -k "band_launch_order" > $OUT/pytest_band.log 2>&1; tail -n 3 $OUT/pytest_band.log
 for k in 0 1 2 3; do ( timeout 1500 python tools/soak_random.py $((1400 + k * 1200)) $((2600 + k * 1200)) > $OUT/random_$k.log 2>&1; tail -n 2 $OUT/random_$k.log ) & done
