@@ -82,6 +82,9 @@ constexpr int MAX_WAVES_PER_BLOCK = 8;
 // across the launches of a solver loop their VALUES are what the caches serve.  SPX_STREAM_NT
 // builds the non-temporal variant for comparison.
 typedef double spx_d2_t __attribute__((ext_vector_type(2)));
+// two doubles at any 8-byte aligned address as ONE load (global_load_dwordx4 needs no 16-byte
+// alignment on gfx9): the x of a row segment comes in pairs wherever its first column lies
+typedef double spx_d2u_t __attribute__((ext_vector_type(2), aligned(8)));
 typedef unsigned int spx_u2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double2 ld_stream(const double2 *p)
 {
@@ -291,6 +294,18 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
                     sh = wave_shl1(sh);
                     x[w] = ((uint32_t) lane + (uint32_t) w < n) ? sh : xt[w];
                 }
+#ifndef SPX_X_PAIRS_ALIGNED_ONLY
+            } else if (W >= 2) {
+                // (pairs at any alignment: W / 2 + (W & 1) load instructions instead of W)
+                const spx_d2u_t *xp2 = reinterpret_cast<const spx_d2u_t *>(xp);
+#pragma unroll
+                for (int p = 0; p < W / 2; ++p) {
+                    const spx_d2u_t xx = xp2[p];
+                    x[2 * p] = xx.x;
+                    x[2 * p + 1] = xx.y;
+                }
+                if (W & 1) x[W - 1] = xp[W - 1];
+#else
             } else if (W >= 2 && (reinterpret_cast<uintptr_t>(a.x) & 15u) == 0 && __all((col & 1u) == 0u)) {
                 const double2 *xp2 = reinterpret_cast<const double2 *>(xp);
 #pragma unroll
@@ -300,6 +315,7 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
                     x[2 * p + 1] = xx.y;
                 }
                 if (W & 1) x[W - 1] = xp[W - 1];
+#endif
             } else {
 #pragma unroll
                 for (int w = 0; w < W; ++w) x[w] = xp[w];
@@ -626,6 +642,15 @@ __device__ __forceinline__ void symseg_passes(const KernelArgs &a, const SpxRowB
 #ifdef SPX_ABL_SEG_NOX
 #pragma unroll
             for (int w = 0; w < W; ++w) x[b][w] = (double) col[b];
+#elif !defined(SPX_X_PAIRS_ALIGNED_ONLY)
+            const spx_d2u_t *xp2 = reinterpret_cast<const spx_d2u_t *>(xp);
+#pragma unroll
+            for (int p = 0; p < W / 2; ++p) {
+                const spx_d2u_t xx = xp2[p];
+                x[b][2 * p] = xx.x;
+                x[b][2 * p + 1] = xx.y;
+            }
+            if (W & 1) x[b][W - 1] = xp[W - 1];
 #else
 #pragma unroll
             for (int w = 0; w < W; ++w) x[b][w] = xp[w];
