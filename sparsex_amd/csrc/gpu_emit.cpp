@@ -1607,9 +1607,12 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsi
                 }
             } else if (joinable(i, false)) {
                 size_t e = elems_of(i);
+                // (spx.gpu.rowblock_elems beyond 8192 only takes effect here: planned row-blocks hold
+                // at most 8192 nonzeros each -- 16-bit counters -- but several of them may go side by side)
+                const size_t join_target = std::max<size_t>(target, std::min<size_t>(prm.target_elems, 4 * SPX_MAX_RB_ELEMS));
                 while (j < plans.size() && joinable(j, false) &&
                        (size_t)(plans[j].row_hi - plans[i].row_lo) <= wide_any &&
-                       e + elems_of(j) <= target + elems_of(j) / 2) {      // (overshoot by half a part at most)
+                       e + elems_of(j) <= join_target + elems_of(j) / 2) {      // (overshoot by half a part at most)
                     e += elems_of(j);
                     ++j;
                 }
