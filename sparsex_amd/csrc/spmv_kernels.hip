@@ -756,8 +756,13 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &x
     SpxPass p0 = passes[wave];
     SpxPass p1 = passes[wave + WAVES_PER_BLOCK];         // (the table is padded by one stride)
     // (the quad kernel keeps the pair after that in hand as well: four narrow unit passes run side by side)
+#ifdef SPX_PASS_PREFETCH
+    constexpr bool AHEAD = true;        // (experiment: every kernel keeps the next pair of pass headers in hand)
+#else
+    constexpr bool AHEAD = QUAD;
+#endif
     SpxPass n0 = p0, n1 = p1;
-    if (QUAD) {
+    if (AHEAD) {
         n0 = passes[wave + 2 * WAVES_PER_BLOCK];
         n1 = passes[wave + 3 * WAVES_PER_BLOCK];
     }
@@ -848,7 +853,7 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &x
             run_pass(a, rb, p0, tile, win, lane);
         }
         if (t + 2 * WAVES_PER_BLOCK < n_pass) {
-            if (QUAD) {
+            if (AHEAD) {
                 p0 = n0;
                 p1 = n1;
                 n0 = passes[t + 4 * WAVES_PER_BLOCK];
