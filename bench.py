@@ -774,17 +774,20 @@ def run_path(ctx, args, symmetric):
     x = torch.from_numpy(xh).to(dev)
     y = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
 
-    def step(stream, flags=sx.SPX_DIST_GATHER_Y):
+    def step(stream, flags=sx.SPX_DIST_HALO_X):
         # several ranks: ONE ITERATION STEP -- the local product, (symmetric) the conflict-row
-        # exchange, and the hand-round of the finished slices of y, so that every rank holds the
-        # whole of y, i.e. the next x (x is replicated)
+        # exchange, and the halo exchange: every rank receives exactly the entries of the other
+        # ranks' slices of y that its own rows read as x, so that x <- y can follow at once
         if world > 1:
             A.hip_matvec_dist(ALPHA, x.data_ptr(), 0.0, y.data_ptr(), flags, stream)
         else:
             A.hip_matvec_mult(ALPHA, x.data_ptr(), y.data_ptr(), stream)
 
-    def step_owned(stream):                  # without the hand-round: the owned rows of y only
+    def step_owned(stream):                  # without any hand-over of y: the owned rows only
         step(stream, sx.SPX_DIST_OWNED_ROWS)
+
+    def step_gather(stream):                 # rounds 2-3's step: whole slices of y handed round (x replicated)
+        step(stream, sx.SPX_DIST_GATHER_Y)
 
     def step_local(stream):                  # the kernels alone, no exchange at all
         A.hip_matvec_mult(ALPHA, x.data_ptr(), y.data_ptr(), stream)
@@ -799,9 +802,10 @@ def run_path(ctx, args, symmetric):
         torch.cuda.synchronize()
     a_local = wl.local_csr()
     parity = parity_gate(torch, y, a_local, xh, lo, hi, ablation)
+    halo = None
     if world > 1:
         # ... and, with the slices handed round, all of y on every rank
-        step(cur)
+        step_gather(cur)
         torch.cuda.synchronize()
         chk = torch.tensor([float(torch.nan_to_num(y, nan=1e300).abs().sum())], dtype=torch.float64,
                            device=dev if ctx["backend"] == "nccl" else "cpu")
@@ -810,6 +814,24 @@ def run_path(ctx, args, symmetric):
         assert all(abs(float(s) - float(sums[0])) <= 1e-9 * abs(float(sums[0])) for s in sums), \
             "gathered y differs between the ranks"
         parity_gate(torch, y, a_local, xh, lo, hi, ablation)
+        # ... and the halo exchange: into a vector of NaNs; the own rows pass the gate again, and
+        # every entry this rank's rows read as x equals what the hand-round of whole slices brought
+        halo = A.dist_halo()
+        y_full = y.clone()
+        y.fill_(float("nan"))
+        step(cur)
+        torch.cuda.synchronize()
+        parity_gate(torch, y, a_local, xh, lo, hi, ablation)
+        hc = torch.from_numpy(halo["recv_cols"]).to(dev)
+        scale = float(torch.nan_to_num(y_full).abs().max())
+        herr = float((y[hc] - y_full[hc]).abs().max()) if hc.numel() else 0.0
+        assert ablation or (herr == herr and herr <= 1e-12 * scale), "halo entries differ from the gathered y: %g" % herr
+        need = np.unique(a_local.indices)
+        need = need[(need < lo) | (need >= hi)]
+        if symmetric:
+            need = need[need < lo]              # (the stored triangle's columns)
+        assert np.array_equal(need, halo["recv_cols"]), "halo list != columns the rank's rows read"
+        del y_full, hc
     del a_local
 
     for _ in range(args.warmup):
@@ -831,17 +853,23 @@ def run_path(ctx, args, symmetric):
     launch_s = devs / args.steps
     if world > 1:
         w_owned, _, _, _ = time_batches(torch, step_owned, args.steps, barrier, reduce_max, False)
+        w_gather, _, _, _ = time_batches(torch, step_gather, args.steps, barrier, reduce_max, False)
         w_local, d_local, _, _ = time_batches(torch, step_local, args.steps, barrier, reduce_max, False)
         launch_s = d_local / args.steps       # the roofline is the kernels' (HIP events, this rank)
         gf = lambda w: round(2.0 * wl.nnz * args.steps / w / 1e9, 2)
         collective = {"full_step_gflops": gf(wall), "owned_rows_only_gflops": gf(w_owned),
-                      "kernels_only_gflops": gf(w_local),
+                      "gather_y_step_gflops": gf(w_gather), "kernels_only_gflops": gf(w_local),
                       "full_step_ms": round(1e3 * wall / args.steps, 5),
                       "owned_rows_only_ms": round(1e3 * w_owned / args.steps, 5),
+                      "gather_y_step_ms": round(1e3 * w_gather / args.steps, 5),
                       "kernels_only_ms": round(1e3 * w_local / args.steps, 5),
+                      "halo_bytes_received_per_rank": 8 * int(halo["recv_cols"].size),
+                      "halo_bytes_sent_per_rank": 8 * int(halo["send_rows"].size),
                       "y_handround_bytes_received_per_rank": 8 * (n - (hi - lo)),
-                      "what": "full step = local product%s + hand-round of the finished slices of y (every rank "
-                              "ends with all of y = the next x); `value` is the full step" % (
+                      "what": "full step = local product%s + halo exchange (every rank receives exactly the entries "
+                              "of the others' slices of y that its rows read as x: x <- y can follow); `value` is the "
+                              "full step; gather_y_step = the same with whole slices handed round instead "
+                              "(x replicated, rounds 2-3's step)" % (
                                   " + conflict-row exchange" if symmetric else "")}
 
     # per-rank facts the line reports for every rank
@@ -851,7 +879,9 @@ def run_path(ctx, args, symmetric):
             "tune_seconds": round(info.tune_seconds, 2), "emit_upload_seconds": round(info.emit_seconds, 2),
             "kernels_us": round(1e6 * launch_s, 2),
             "conflict_rows_sent": int(plan["send_rows"].size) if world > 1 else 0,
-            "conflict_entries_received": int(plan["n_recv"]) if world > 1 else 0}
+            "conflict_entries_received": int(plan["n_recv"]) if world > 1 else 0,
+            "halo_entries_received": int(halo["recv_cols"].size) if world > 1 else 0,
+            "halo_entries_sent": int(halo["send_rows"].size) if world > 1 else 0}
     per_rank = [mine]
     if world > 1:
         per_rank = [None] * world
@@ -867,13 +897,13 @@ def run_path(ctx, args, symmetric):
         par = "rows partitioned by nonzeros over %d rank%s; x replicated; every rank completes its own rows of y " \
               "(no exchange needed for that)%s" % (
                   world, "s" if world > 1 else "",
-                  "; then the slices of y are handed round, pairwise, so that every rank holds the next x"
-                  if world > 1 else "")
+                  "; then every rank receives the entries of the others' slices that its rows read as x (halo "
+                  "exchange, pairwise, packed)" if world > 1 else "")
     else:
         par = "rows partitioned by stored nonzeros (lower triangle + diagonal) over %d rank%s; x replicated; each " \
               "rank sends the sums for its conflict rows (rows in front of its own that its lower triangle " \
               "touches) to their owners, packed, pairwise (no n-long all-reduce)%s" % (
-                  world, "s" if world > 1 else "", "; then the slices of y are handed round" if world > 1 else "")
+                  world, "s" if world > 1 else "", "; then the halo exchange of y" if world > 1 else "")
     out = {
         "value": round(2.0 * wl.nnz * args.steps / wall / 1e9, 3),
         "ms_per_step": round(1e3 * wall / args.steps, 6),
@@ -887,7 +917,8 @@ def run_path(ctx, args, symmetric):
                    "launch": "one hipGraph of %d captured launches per batch" % args.steps if graphed
                              else "stream launches",
                    "parallelism": par, "transport": ctx["transport_name"],
-                   "collective_in_value": ("included: every step ends with all of y on every rank"
+                   "collective_in_value": ("included: every step ends with each rank holding its rows of y and the "
+                                           "entries of the other ranks' rows that it reads as x"
                                            if world > 1 else "none needed"),
                    "generate_seconds": round(t_gen, 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,

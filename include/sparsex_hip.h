@@ -224,6 +224,11 @@ spx_error_t spx_hip_mat_dist_attach(spx_matrix_t *A, const spx_hip_transport_t *
 
 #define SPX_DIST_OWNED_ROWS 0   /* y[row_lo, row_hi) complete on return, the rest unspecified */
 #define SPX_DIST_GATHER_Y   1   /* all of y complete on every process */
+#define SPX_DIST_HALO_X     2   /* y[row_lo, row_hi) complete, and of the other processes' rows exactly the
+                                   entries that THIS process' rows read as x (its halo, see
+                                   spx_hip_mat_dist_halo): what an iteration x <- y needs here, nothing
+                                   more.  Every owner packs the entries each of the others asked for at
+                                   attach time and sends them pairwise; ignored with SPX_DIST_GATHER_Y */
 /* y <- alpha*A*x + beta*y over all processes; device pointers of full length,
  * everything enqueued on `stream`.  Collective. */
 spx_error_t spx_hip_matvec_dist(spx_value_t alpha, const spx_matrix_t *A,
@@ -245,6 +250,19 @@ typedef struct {
     int32_t any_exchange;                   /* some process sends something           */
 } spx_hip_dist_plan_t;
 spx_error_t spx_hip_mat_dist_plan(const spx_matrix_t *A, spx_hip_dist_plan_t *plan);
+
+/* The halo of x of an attached matrix (arrays owned by the matrix): the columns outside its
+ * own rows that this process' stream reads (found by walking the stream itself), grouped by
+ * owner, and the own rows the other processes asked for, grouped by the process that asked. */
+typedef struct {
+    int64_t n_recv;                         /* entries this process needs of the others        */
+    const spx_index_t *recv_cols;           /* ascending, i.e. grouped by owner                */
+    const size_t *recv_off, *recv_cnt;      /* [world] segment of every owner                  */
+    int64_t n_send;                         /* own entries the others need (with repetitions)  */
+    const spx_index_t *send_rows;           /* grouped by the process that asked, ascending    */
+    const size_t *send_off, *send_cnt;      /* [world] segment of every such process           */
+} spx_hip_dist_halo_t;
+spx_error_t spx_hip_mat_dist_halo(const spx_matrix_t *A, spx_hip_dist_halo_t *halo);
 
 /* ---- introspection ---------------------------------------------------------- */
 typedef struct {

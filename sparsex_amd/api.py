@@ -524,8 +524,17 @@ class DistPlanStruct(C.Structure):
                 ("any_exchange", C.c_int32)]
 
 
+class DistHaloStruct(C.Structure):
+    """``spx_hip_dist_halo_t``."""
+    _fields_ = [("n_recv", C.c_int64), ("recv_cols", C.POINTER(C.c_int)),
+                ("recv_off", C.POINTER(C.c_size_t)), ("recv_cnt", C.POINTER(C.c_size_t)),
+                ("n_send", C.c_int64), ("send_rows", C.POINTER(C.c_int)),
+                ("send_off", C.POINTER(C.c_size_t)), ("send_cnt", C.POINTER(C.c_size_t))]
+
+
 SPX_DIST_OWNED_ROWS = 0
 SPX_DIST_GATHER_Y = 1
+SPX_DIST_HALO_X = 2
 SPX_RCCL_ID_BYTES = 128
 
 
@@ -628,6 +637,22 @@ def _dist_plan(self):
             "fix_pos": arr(p.fix_pos, p.n_recv, np.int64), "any_exchange": bool(p.any_exchange)}
 
 
+def _dist_halo(self):
+    """``spx_hip_mat_dist_halo`` as a dict of numpy copies: the entries of x this process needs
+    of the others (``recv_cols``, by owner) and the own entries the others asked for."""
+    L = lib()
+    L.spx_hip_mat_dist_halo.argtypes = [C.c_void_p, C.POINTER(DistHaloStruct)]
+    h = DistHaloStruct()
+    if L.spx_hip_mat_dist_halo(self.handle, C.byref(h)) != SPX_SUCCESS:
+        raise SpxError("spx_hip_mat_dist_halo failed (see stderr)")
+    W = int(self.dist_plan()["world"])
+
+    def arr(ptr, n):
+        return np.ctypeslib.as_array(ptr, shape=(n,)).astype(np.int64) if n else np.zeros(0, dtype=np.int64)
+    return {"recv_cols": arr(h.recv_cols, h.n_recv), "recv_off": arr(h.recv_off, W), "recv_cnt": arr(h.recv_cnt, W),
+            "send_rows": arr(h.send_rows, h.n_send), "send_off": arr(h.send_off, W), "send_cnt": arr(h.send_cnt, W)}
+
+
 def _hip_matvec_dist(self, alpha, x_ptr, beta, y_ptr, flags=SPX_DIST_OWNED_ROWS, stream=0):
     """``spx_hip_matvec_dist`` (collective)."""
     L = lib()
@@ -639,4 +664,5 @@ def _hip_matvec_dist(self, alpha, x_ptr, beta, y_ptr, flags=SPX_DIST_OWNED_ROWS,
 
 Matrix.dist_attach = _dist_attach
 Matrix.dist_plan = _dist_plan
+Matrix.dist_halo = _dist_halo
 Matrix.hip_matvec_dist = _hip_matvec_dist

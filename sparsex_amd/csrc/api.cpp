@@ -503,6 +503,8 @@ static void emit_and_upload(spx_matrix_t *A)
     }
     A->conflict_rows.clear();
     if (sym && !gs.sym_fused) stream_touched_rows(gs, A->own_lo, A->conflict_rows);
+    A->halo_cols.clear();
+    if (A->own_lo > 0 || A->own_hi < A->nrows) stream_read_cols(gs, A->own_lo, A->own_hi, (size_t) A->ncols, A->halo_cols);
     A->first_block_row = A->own_lo;
     for (const SpxRowBlock &rb : gs.rbs) A->first_block_row = std::min<idx_t>(A->first_block_row, (idx_t) rb.row0);
     finalize_stream(gs, (size_t) A->nrows);
@@ -510,6 +512,7 @@ static void emit_and_upload(spx_matrix_t *A)
     std::vector<std::pair<uint32_t, uint32_t>>().swap(gs.direct_cols);
     gs.waves = (uint32_t) A->waves;
     gs.band_order = Config::instance().get_bool("spx.gpu.band_order");
+    gs.arena = Config::instance().get_bool("spx.gpu.arena");
     gs.quad = A->quad == 1;
     gs.sym_atomic = A->sym_atomic && !A->deterministic;
     gs.deterministic = A->deterministic;
@@ -1504,6 +1507,7 @@ spx_matrix_t *spx_mat_restore(const char *filename)
     A->device_ordinal = (int) cfg.get_long("spx.rt.device");
     A->full_colind = cfg.get_bool("spx.matrix.full_colind");
     if (A->symmetric && !gs->sym_fused) stream_touched_rows(*gs, A->own_lo, A->conflict_rows);
+    if (A->own_lo > 0 || A->own_hi < A->nrows) stream_read_cols(*gs, A->own_lo, A->own_hi, (size_t) A->ncols, A->halo_cols);
     A->first_block_row = A->own_lo;
     for (const SpxRowBlock &rb : gs->rbs) A->first_block_row = std::min<idx_t>(A->first_block_row, (idx_t) rb.row0);
     try {
@@ -1690,7 +1694,7 @@ static spx_error_t run_host(const spx_matrix_t *A, spx_value_t alpha, const spx_
         // a row-partitioned matrix with an exchange plan: every process ends up
         // with all of y in host memory, as the reference's caller expects
         std::function<void(double *, void *)> after;
-        if (A->dist) after = [A](double *d_y, void *st) { dist_complete(A->dist, d_y, true, st); };
+        if (A->dist) after = [A](double *d_y, void *st) { dist_complete(A->dist, d_y, true, false, st); };
         device_spmv_host(A->dev, alpha, x->elements, x->alloc_type == ALLOC_PINNED, beta,
                          y->elements, y->alloc_type == ALLOC_PINNED, after, vec_version(x));
         vec_touch(y);
@@ -1785,7 +1789,7 @@ spx_error_t spx_hip_matvec_dist(spx_value_t alpha, const spx_matrix_t *A,
     }
     try {
         device_spmv(A->dev, alpha, x_dev, beta, y_dev, stream);
-        dist_complete(A->dist, y_dev, (flags & SPX_DIST_GATHER_Y) != 0, stream);
+        dist_complete(A->dist, y_dev, (flags & SPX_DIST_GATHER_Y) != 0, (flags & SPX_DIST_HALO_X) != 0, stream);
     } catch (const FatalError &e) {
         SETERROR_1(SPX_ERR_TUNED_MAT, e.what.c_str());
         return SPX_FAILURE;

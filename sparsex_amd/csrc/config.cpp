@@ -50,6 +50,7 @@ void Config::reset_defaults()
     props_["spx.gpu.waves"] = "0";             // wavefronts per workgroup: 2, 4, 8; 0 = measured at tune time
     props_["spx.gpu.quad"] = "false";          // general path: four narrow unit passes side by side per wavefront: true | false | auto (measured); never won: off
     props_["spx.gpu.inline_desc"] = "true";    // single-descriptor unit passes carry their descriptor in the pass header
+    props_["spx.gpu.arena"] = "true";          // one HBM allocation for all arrays of a tuned matrix (false: one per array)
     props_["spx.gpu.band_order"] = "false";    // launch order: strips across the planes of a stencil (measured slower: off)
     props_["spx.gpu.col_phases"] = "auto";     // general path: column slices launched in turn: 1 (off), 2..8, auto (measured)
     props_["spx.gpu.keep_units"] = "true";     // re-cut: mined units without row neighbours stay units

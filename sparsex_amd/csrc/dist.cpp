@@ -33,7 +33,8 @@ void host_exchange(const spx_hip_transport_t &t, const std::vector<uint64_t> &se
 // empty lists, and says so in a status word that travels with the counts and once more at
 // the very end -- every rank sees every status, and all of them fail together.
 DistPlan *dist_build_plan(const spx_hip_transport_t &t, idx_t own_lo, idx_t own_hi, idx_t nrows,
-                          const std::vector<idx_t> &conflict_rows, bool on_device)
+                          const std::vector<idx_t> &conflict_rows, const std::vector<idx_t> &halo_cols,
+                          bool on_device)
 {
     if (t.world < 1 || t.rank < 0 || t.rank >= t.world) throw FatalError("transport: bad rank/world");
     std::unique_ptr<DistPlan> p(new DistPlan);
@@ -151,6 +152,60 @@ DistPlan *dist_build_plan(const spx_hip_transport_t &t, idx_t own_lo, idx_t own_
         if (!pr.empty()) p->fix_ptr.push_back((uint32_t) pr.size());
     }
 
+    // 5b. the halo of x: every process tells the owners which of their entries its rows read (its
+    //     list is ascending, i.e. grouped by owner); an owner keeps, per process that asked, the
+    //     rows to pack for it.  Same discipline as above: nothing throws between the exchanges.
+    {
+        p->halo_cols = halo_cols;
+        p->halo_recv_off.assign(W, 0);
+        p->halo_recv_cnt.assign(W, 0);
+        size_t k = 0;
+        for (size_t q = 0; q < W; ++q) {
+            p->halo_recv_off[q] = k;
+            while (k < p->halo_cols.size() && p->halo_cols[k] < p->row_hi[q]) {
+                if (q == me) complain("halo column inside the own rows");
+                ++k;
+            }
+            p->halo_recv_cnt[q] = k - p->halo_recv_off[q];
+        }
+        if (k != p->halo_cols.size()) complain("halo column outside the matrix");
+        if (!bad.empty()) {
+            p->halo_cols.clear();
+            p->halo_recv_off.assign(W, 0);
+            p->halo_recv_cnt.assign(W, 0);
+        }
+        // how many entries every process wants of mine
+        std::vector<uint64_t> send(W), recv(W, 0);
+        std::vector<size_t> off(W), one(W, 1);
+        for (size_t q = 0; q < W; ++q) {
+            send[q] = p->halo_recv_cnt[q];
+            off[q] = q;
+        }
+        one[me] = 0;
+        host_exchange(t, send, off, one, recv, off, one);
+        p->halo_send_off.assign(W, 0);
+        p->halo_send_cnt.assign(W, 0);
+        size_t ns = 0;
+        for (size_t q = 0; q < W; ++q) {
+            p->halo_send_off[q] = ns;
+            p->halo_send_cnt[q] = q == me ? 0 : (size_t) recv[q];
+            ns += p->halo_send_cnt[q];
+        }
+        // ... and which
+        std::vector<uint64_t> want(p->halo_cols.begin(), p->halo_cols.end()), asked(ns, 0);
+        host_exchange(t, want, p->halo_recv_off, p->halo_recv_cnt, asked, p->halo_send_off, p->halo_send_cnt);
+        p->halo_send_rows.resize(ns);
+        for (size_t i = 0; i < ns; ++i) {
+            const idx_t r = (idx_t) asked[i];
+            if (r < own_lo || r >= own_hi) {
+                complain("asked for a halo entry that is not owned here");
+                p->halo_send_rows[i] = own_lo < own_hi ? own_lo : 0;
+            } else {
+                p->halo_send_rows[i] = r;
+            }
+        }
+    }
+
     // 6. the slices of y, in place
     p->gat_send_off.assign(W, (size_t) own_lo);
     p->gat_send_cnt.assign(W, (size_t)(own_hi - own_lo));
@@ -196,7 +251,7 @@ void dist_free_plan(DistPlan *p)
     delete p;
 }
 
-void dist_complete(DistPlan *p, double *d_y, bool gather, void *stream)
+void dist_complete(DistPlan *p, double *d_y, bool gather, bool halo, void *stream)
 {
     if (p->world <= 1) return;
     const spx_hip_transport_t &t = p->transport;
@@ -209,10 +264,20 @@ void dist_complete(DistPlan *p, double *d_y, bool gather, void *stream)
             throw FatalError("transport: device exchange failed");
         dist_device_unpack(p->dev, d_y, stream);
     }
-    if (gather &&
-        t.exchange_device(t.ctx, d_y, p->gat_send_off.data(), p->gat_send_cnt.data(), d_y,
-                          p->gat_recv_off.data(), p->gat_recv_cnt.data(), stream) != 0)
-        throw FatalError("transport: gathering y failed");
+    if (gather) {
+        if (t.exchange_device(t.ctx, d_y, p->gat_send_off.data(), p->gat_send_cnt.data(), d_y,
+                              p->gat_recv_off.data(), p->gat_recv_cnt.data(), stream) != 0)
+            throw FatalError("transport: gathering y failed");
+    } else if (halo) {
+        // only what the receivers' rows read: packed, pairwise, scattered to its place in y
+        // (collective: a process without a halo of its own still serves the others')
+        const double *sendbuf = dist_device_halo_pack(p->dev, d_y, stream);
+        if (t.exchange_device(t.ctx, sendbuf, p->halo_send_off.data(), p->halo_send_cnt.data(),
+                              dist_device_halo_recvbuf(p->dev), p->halo_recv_off.data(), p->halo_recv_cnt.data(),
+                              stream) != 0)
+            throw FatalError("transport: halo exchange failed");
+        dist_device_halo_scatter(p->dev, d_y, stream);
+    }
 }
 
 }  // namespace spx
@@ -229,7 +294,7 @@ spx_error_t spx_hip_mat_dist_attach(spx_matrix_t *A, const spx_hip_transport_t *
             dist_free_plan(A->dist);
             A->dist = nullptr;
         }
-        A->dist = dist_build_plan(*t, A->own_lo, A->own_hi, A->nrows, A->conflict_rows,
+        A->dist = dist_build_plan(*t, A->own_lo, A->own_hi, A->nrows, A->conflict_rows, A->halo_cols,
                                   A->dev != nullptr);
         // the exchange takes over what the caller-side all-reduce needed: rows this
         // process neither owns nor adds to are nobody's business any more
@@ -271,6 +336,25 @@ spx_error_t spx_hip_mat_dist_plan(const spx_matrix_t *A, spx_hip_dist_plan_t *pl
     plan->fix_ptr = p.fix_ptr.data();
     plan->fix_pos = p.fix_pos.data();
     plan->any_exchange = p.any_exchange ? 1 : 0;
+    return SPX_SUCCESS;
+}
+
+spx_error_t spx_hip_mat_dist_halo(const spx_matrix_t *A, spx_hip_dist_halo_t *halo)
+{
+    if (!A || !halo || !A->dist) {
+        SETERROR_1(SPX_ERR_ARG_INVALID, "matrix has no exchange plan (spx_hip_mat_dist_attach)");
+        return SPX_FAILURE;
+    }
+    const DistPlan &p = *A->dist;
+    memset(halo, 0, sizeof(*halo));
+    halo->n_recv = (int64_t) p.halo_cols.size();
+    halo->recv_cols = p.halo_cols.data();
+    halo->recv_off = p.halo_recv_off.data();
+    halo->recv_cnt = p.halo_recv_cnt.data();
+    halo->n_send = (int64_t) p.halo_send_rows.size();
+    halo->send_rows = p.halo_send_rows.data();
+    halo->send_off = p.halo_send_off.data();
+    halo->send_cnt = p.halo_send_cnt.data();
     return SPX_SUCCESS;
 }
 

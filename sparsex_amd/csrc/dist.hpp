@@ -27,18 +27,27 @@ struct DistPlan {
     std::vector<uint32_t> fix_ptr, fix_pos;       // per such row: positions in the receive buffer
     bool any_exchange = false;                    // some process sends something
     std::vector<size_t> gat_send_off, gat_send_cnt, gat_recv_off, gat_recv_cnt;   // slices of y, in place
+    // the halo of x (SPX_DIST_HALO_X): instead of handing whole slices of y round, every process
+    // receives exactly the entries its own rows read as x
+    std::vector<idx_t> halo_cols;                 // entries this process needs (ascending: grouped by owner)
+    std::vector<size_t> halo_recv_off, halo_recv_cnt;   // per owner
+    std::vector<idx_t> halo_send_rows;            // own entries the others need, grouped by the process that asked
+    std::vector<size_t> halo_send_off, halo_send_cnt;   // per such process
     DistDevice *dev = nullptr;
 };
 
 // Collective.  `conflict_rows`: rows in front of own_lo this process adds to.
 // Throws FatalError.
+// `halo_cols`: entries of x outside the own rows that this process' products read.
 DistPlan *dist_build_plan(const spx_hip_transport_t &t, idx_t own_lo, idx_t own_hi, idx_t nrows,
-                          const std::vector<idx_t> &conflict_rows, bool on_device);
+                          const std::vector<idx_t> &conflict_rows, const std::vector<idx_t> &halo_cols,
+                          bool on_device);
 void dist_free_plan(DistPlan *p);
 
 // after the local SpMV on `stream`: hand the sums for other processes' rows to
 // their owners and add what arrives; then (gather) pass the finished slices round
-void dist_complete(DistPlan *p, double *d_y, bool gather, void *stream);
+// ... or (halo) send every process the entries of the own slice that its rows read as x
+void dist_complete(DistPlan *p, double *d_y, bool gather, bool halo, void *stream);
 
 // device side (dist_kernels.hip)
 DistDevice *dist_device_create(const DistPlan &p);
@@ -46,5 +55,8 @@ void dist_device_free(DistDevice *d);
 const double *dist_device_pack(DistDevice *d, const double *d_y, void *stream);
 double *dist_device_recvbuf(DistDevice *d);
 void dist_device_unpack(DistDevice *d, double *d_y, void *stream);
+const double *dist_device_halo_pack(DistDevice *d, const double *d_y, void *stream);
+double *dist_device_halo_recvbuf(DistDevice *d);
+void dist_device_halo_scatter(DistDevice *d, double *d_y, void *stream);
 
 }  // namespace spx

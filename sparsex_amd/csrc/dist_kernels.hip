@@ -41,6 +41,10 @@ struct DistDevice {
     double *sendbuf = nullptr, *recvbuf = nullptr;
     idx_t *fix_rows = nullptr;
     uint32_t *fix_ptr = nullptr, *fix_pos = nullptr;
+    // halo of x
+    size_t n_halo_send = 0, n_halo_recv = 0;
+    idx_t *halo_send_rows = nullptr, *halo_cols = nullptr;
+    double *halo_sendbuf = nullptr, *halo_recvbuf = nullptr;
 };
 
 // sendbuf[k] = y[send_rows[k]]: the sums this process formed for rows of others
@@ -59,6 +63,13 @@ __global__ void dist_unpack_kernel(const idx_t *rows, const uint32_t *ptr, const
     double s = 0.0;
     for (uint32_t k = ptr[t]; k < ptr[t + 1]; ++k) s += buf[pos[k]];
     y[rows[t]] += s;
+}
+
+// y[cols[k]] = what the owner of entry cols[k] sent for it (distinct entries, plain stores)
+__global__ void dist_scatter_kernel(const idx_t *cols, const double *buf, double *y, size_t n)
+{
+    const size_t k = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) y[cols[k]] = buf[k];
 }
 
 template <typename T>
@@ -84,6 +95,12 @@ DistDevice *dist_device_create(const DistPlan &p)
     d->fix_pos = to_device(p.fix_pos);
     HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d->sendbuf), std::max<size_t>(d->n_send, 1) * sizeof(double)));
     HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d->recvbuf), std::max<size_t>(d->n_recv, 1) * sizeof(double)));
+    d->n_halo_send = p.halo_send_rows.size();
+    d->n_halo_recv = p.halo_cols.size();
+    d->halo_send_rows = to_device(p.halo_send_rows);
+    d->halo_cols = to_device(p.halo_cols);
+    HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d->halo_sendbuf), std::max<size_t>(d->n_halo_send, 1) * sizeof(double)));
+    HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d->halo_recvbuf), std::max<size_t>(d->n_halo_recv, 1) * sizeof(double)));
     return d;
 }
 
@@ -92,6 +109,8 @@ void dist_device_free(DistDevice *d)
     if (!d) return;
     (void) hipFree(d->send_rows); (void) hipFree(d->fix_rows); (void) hipFree(d->fix_ptr);
     (void) hipFree(d->fix_pos); (void) hipFree(d->sendbuf); (void) hipFree(d->recvbuf);
+    (void) hipFree(d->halo_send_rows); (void) hipFree(d->halo_cols);
+    (void) hipFree(d->halo_sendbuf); (void) hipFree(d->halo_recvbuf);
     delete d;
 }
 
@@ -111,6 +130,23 @@ void dist_device_unpack(DistDevice *d, double *d_y, void *stream)
         hipLaunchKernelGGL(dist_unpack_kernel, dim3((unsigned) ((d->n_fix + 255) / 256)), dim3(256), 0,
                            static_cast<hipStream_t>(stream), d->fix_rows, d->fix_ptr, d->fix_pos,
                            d->recvbuf, d_y, d->n_fix);
+}
+
+const double *dist_device_halo_pack(DistDevice *d, const double *d_y, void *stream)
+{
+    if (d->n_halo_send)
+        hipLaunchKernelGGL(dist_pack_kernel, dim3((unsigned) ((d->n_halo_send + 255) / 256)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), d->halo_send_rows, d_y, d->halo_sendbuf, d->n_halo_send);
+    return d->halo_sendbuf;
+}
+
+double *dist_device_halo_recvbuf(DistDevice *d) { return d->halo_recvbuf; }
+
+void dist_device_halo_scatter(DistDevice *d, double *d_y, void *stream)
+{
+    if (d->n_halo_recv)
+        hipLaunchKernelGGL(dist_scatter_kernel, dim3((unsigned) ((d->n_halo_recv + 255) / 256)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), d->halo_cols, d->halo_recvbuf, d_y, d->n_halo_recv);
 }
 
 // ---- RCCL transport --------------------------------------------------------------------------

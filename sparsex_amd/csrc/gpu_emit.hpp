@@ -76,6 +76,7 @@ struct GpuStream {
     uint32_t waves = 4;           // wavefronts per workgroup the kernel is launched with
     bool quad = false;            // general path: launch csx_spmv_quad_kernel (spx.gpu.quad, measured at tune time)
     bool band_order = false;      // spx.gpu.band_order: launch order by strips across recurring bands of x (device side only)
+    bool arena = true;            // spx.gpu.arena: all arrays of the stream in one HBM allocation (device side only)
     // accounting
     size_t nnz_stored = 0;        // nonzeros held in `values` (without padding)
     size_t n_unit_elems = 0;

@@ -55,6 +55,9 @@ struct matrix {
     // symmetric matrix of which this process holds a slice: the rows in front of
     // its own that it adds to (the reference's conflict map, CsxBuild.hpp:400-451)
     std::vector<idx_t> conflict_rows;
+    // columns of x outside the own rows that this process' stream reads (stream_read_cols): what it
+    // needs of the other processes' slices of a vector -- the halo of SPX_DIST_HALO_X
+    std::vector<idx_t> halo_cols;
     idx_t first_block_row = 0;                // first row a row-block of this process covers (<= own_lo)
     spx::DistPlan *dist = nullptr;            // set by spx_hip_mat_dist_attach
     GpuEmitParams emit_params;

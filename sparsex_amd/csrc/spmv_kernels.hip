@@ -1169,6 +1169,11 @@ struct DeviceMatrix {
     std::vector<hipEvent_t> stage_events;       // one behind every piece of a staged download
     size_t value_bytes = 0, index_bytes = 0;
     size_t n_values = 0, n_descs = 0, n_passes = 0, n_cidx = 0, n_segrows = 0;
+    // every array of the stream lives in ONE allocation (2 MB-aligned pieces): one mapping, one
+    // run of physically contiguous fragments as far as the driver can give them
+    // (spx.gpu.arena=false / SPX_NO_ARENA: an allocation per array, as rounds 1-3 had it)
+    void *arena = nullptr;
+    size_t arena_bytes = 0;
 };
 
 int device_count()
@@ -1178,18 +1183,57 @@ int device_count()
     return n;
 }
 
-template <typename T>
-static T *upload(const std::vector<T> &v, size_t slack_elems = 0)
-{
-    size_t bytes = (v.size() + slack_elems) * sizeof(T);
-    if (bytes == 0) bytes = sizeof(T);
-    T *d = nullptr;
-    HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d), bytes));
-    HIP_CHECK(hipMemset(d, 0, bytes));
-    if (!v.empty())
-        HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-    return d;
-}
+// The arrays of a stream are placed together: device_upload() notes what goes where (`put`) and
+// `Placement::flush` allocates once, clears the lot and copies every array to its place.
+struct Placement {
+    struct Item { void **dst; const void *src; size_t copy_bytes, alloc_bytes; };
+    std::vector<Item> items;
+    template <typename T>
+    void put(T **dst, const std::vector<T> &v, size_t slack_elems = 0)
+    {
+        size_t bytes = (v.size() + slack_elems) * sizeof(T);
+        if (bytes == 0) bytes = sizeof(T);
+        items.push_back(Item{reinterpret_cast<void **>(dst), v.data(), v.size() * sizeof(T), bytes});
+    }
+    static size_t piece(size_t bytes)
+    {
+        const size_t a = bytes >= ((size_t) 1 << 20) ? ((size_t) 2 << 20) : 256u;
+        return (bytes + a - 1) / a * a;
+    }
+    void flush(DeviceMatrix *m, bool arena)
+    {
+        if (!arena) {
+            for (const Item &it : items) {
+                void *d = nullptr;
+                HIP_CHECK(hipMalloc(&d, it.alloc_bytes));
+                *it.dst = d;
+                HIP_CHECK(hipMemset(d, 0, it.alloc_bytes));
+                if (it.copy_bytes) HIP_CHECK(hipMemcpy(d, it.src, it.copy_bytes, hipMemcpyHostToDevice));
+            }
+            return;
+        }
+        // large arrays first, each on a 2 MB boundary; the small ones share the tail
+        size_t total = 0;
+        for (const Item &it : items) total += piece(it.alloc_bytes);
+        total = (total + ((size_t) 2 << 20) - 1) & ~(((size_t) 2 << 20) - 1);
+        void *base = nullptr;
+        HIP_CHECK(hipMalloc(&base, total));
+        m->arena = base;
+        m->arena_bytes = total;
+        HIP_CHECK(hipMemset(base, 0, total));
+        std::vector<size_t> order(items.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return items[a].alloc_bytes > items[b].alloc_bytes; });
+        size_t at = 0;
+        for (size_t i : order) {
+            const Item &it = items[i];
+            char *d = static_cast<char *>(base) + at;
+            *it.dst = d;
+            if (it.copy_bytes) HIP_CHECK(hipMemcpy(d, it.src, it.copy_bytes, hipMemcpyHostToDevice));
+            at += piece(it.alloc_bytes);
+        }
+    }
+};
 
 DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
                             bool symmetric, idx_t own_lo, idx_t own_hi, int device)
@@ -1214,17 +1258,21 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
     m->n_rb = (uint32_t) s.rbs.size();
     m->n_shared = (uint32_t) s.shared.size();
     m->n_carry = s.n_carry;
-    m->values = upload(s.values, 160);
-    m->descs = upload(s.descs, 8);
-    m->cidx = upload(s.cidx, 64);
-    m->segrows = upload(s.segrows, 80);
-    m->shared = upload(s.shared);
-    std::vector<double> zero_carry(s.n_carry ? s.n_carry : 1, 0.0);
-    m->carry = upload(zero_carry);
+    Placement place;
+    const std::vector<double> no_doubles;                 // (cleared arrays: nothing to copy)
+    std::vector<double> dv;                               // host copies that must live until the flush
+    std::vector<SpxRowBlock> rbs_ordered;
+    std::vector<SpxPass> passes_ordered;
+    place.put(&m->values, s.values, 160);
+    place.put(&m->descs, s.descs, 8);
+    place.put(&m->cidx, s.cidx, 64);
+    place.put(&m->segrows, s.segrows, 80);
+    place.put(&m->shared, s.shared);
+    place.put(&m->carry, no_doubles, s.n_carry ? s.n_carry : 1);
     if (symmetric) {
-        std::vector<double> dv = s.dvalues;
+        dv = s.dvalues;
         dv.resize(nrows, 0.0);
-        m->dvalues = upload(dv);
+        place.put(&m->dvalues, dv);
     }
     m->n_spill = s.n_spill;
     m->lds_doubles = s.lds_doubles;
@@ -1240,22 +1288,21 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
             m->has_symtiles = s.passes[rb.pass_off + k].kind == SPX_PASS_SYMTILE;
     // (n_slots + n_rows <= 3584 doubles = 28 KB: within the default dynamic LDS limit)
     if (s.n_spill) {
-        std::vector<double> zero_spill(s.n_spill, 0.0);
-        m->spill = upload(zero_spill);
-        m->fix_ptr = upload(s.fix_ptr);
-        m->fix_idx = upload(s.fix_idx);
+        place.put(&m->spill, no_doubles, s.n_spill);
+        place.put(&m->fix_ptr, s.fix_ptr);
+        place.put(&m->fix_idx, s.fix_idx);
         m->n_fix_ptr = s.fix_ptr.size();
         m->n_fix_idx = s.fix_idx.size();
-        m->slot_col = upload(s.slot_group_col);
+        place.put(&m->slot_col, s.slot_group_col);
         m->n_slot_col = s.slot_group_col.size();
     }
     if (!s.mirror_rows.empty()) {
         m->n_mirror_rows = (uint32_t) s.mirror_rows.size();
         m->n_mirror_nnz = s.mirror_col.size();
-        m->mirror_rows = upload(s.mirror_rows);
-        m->mirror_ptr = upload(s.mirror_ptr);
-        m->mirror_col = upload(s.mirror_col);
-        m->mirror_val = upload(s.mirror_val);
+        place.put(&m->mirror_rows, s.mirror_rows);
+        place.put(&m->mirror_ptr, s.mirror_ptr);
+        place.put(&m->mirror_col, s.mirror_col);
+        place.put(&m->mirror_val, s.mirror_val);
     }
     m->sym_atomic = (s.sym_atomic || m->has_symsegs) && m->has_tiles;
     {
@@ -1357,20 +1404,22 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
             if (!any) order.clear();
         }
         if (order.empty()) {
-            m->rbs = upload(s.rbs);
-            m->passes = upload(s.passes, (size_t) s.pass_stride + 6 * MAX_WAVES_PER_BLOCK);
+            place.put(&m->rbs, s.rbs);
+            place.put(&m->passes, s.passes, (size_t) s.pass_stride + 6 * MAX_WAVES_PER_BLOCK);
         } else {
             const size_t stride = s.pass_stride;
-            std::vector<SpxRowBlock> rbs(s.rbs.size());
-            std::vector<SpxPass> passes(s.passes.size());
+            std::vector<SpxRowBlock> &rbs = rbs_ordered;
+            std::vector<SpxPass> &passes = passes_ordered;
+            rbs.resize(s.rbs.size());
+            passes.resize(s.passes.size());
             for (size_t i = 0; i < order.size(); ++i) {
                 rbs[i] = s.rbs[order[i]];
                 rbs[i].pass_off = (uint32_t)(i * stride);
                 std::copy(s.passes.begin() + (size_t) order[i] * stride, s.passes.begin() + ((size_t) order[i] + 1) * stride,
                           passes.begin() + i * stride);
             }
-            m->rbs = upload(rbs);
-            m->passes = upload(passes, stride + 6 * MAX_WAVES_PER_BLOCK);
+            place.put(&m->rbs, rbs);
+            place.put(&m->passes, passes, stride + 6 * MAX_WAVES_PER_BLOCK);
             m->launch_order.swap(order);
         }
     }
@@ -1391,25 +1440,38 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
     m->n_cidx = s.cidx.size(); m->n_segrows = s.segrows.size();
     m->value_bytes = s.values.size() * sizeof(double);
     m->index_bytes = s.index_bytes();
+    try {
+        place.flush(m, s.arena && !getenv("SPX_NO_ARENA"));
+    } catch (...) {
+        device_free(m);
+        throw;
+    }
+    if (getenv("SPX_LOG_PLACEMENT"))
+        log_msg(LOG_ERR, "placement: arena %p (%zu MB) values %p descs %p passes %p rbs %p\n", m->arena, m->arena_bytes >> 20,
+                (void *) m->values, (void *) m->descs, (void *) m->passes, (void *) m->rbs);
     return m;
 }
 
 void device_free(DeviceMatrix *m)
 {
     if (!m) return;
-    (void) hipFree(m->rbs); (void) hipFree(m->values); (void) hipFree(m->descs);
-    (void) hipFree(m->passes);
-    (void) hipFree(m->cidx); (void) hipFree(m->segrows); (void) hipFree(m->shared);
-    (void) hipFree(m->carry);
-    if (m->dvalues) (void) hipFree(m->dvalues);
-    if (m->spill) (void) hipFree(m->spill);
-    if (m->fix_ptr) (void) hipFree(m->fix_ptr);
-    if (m->fix_idx) (void) hipFree(m->fix_idx);
-    if (m->slot_col) (void) hipFree(m->slot_col);
-    if (m->mirror_rows) (void) hipFree(m->mirror_rows);
-    if (m->mirror_ptr) (void) hipFree(m->mirror_ptr);
-    if (m->mirror_col) (void) hipFree(m->mirror_col);
-    if (m->mirror_val) (void) hipFree(m->mirror_val);
+    if (m->arena) {
+        (void) hipFree(m->arena);
+    } else {
+        (void) hipFree(m->rbs); (void) hipFree(m->values); (void) hipFree(m->descs);
+        (void) hipFree(m->passes);
+        (void) hipFree(m->cidx); (void) hipFree(m->segrows); (void) hipFree(m->shared);
+        (void) hipFree(m->carry);
+        if (m->dvalues) (void) hipFree(m->dvalues);
+        if (m->spill) (void) hipFree(m->spill);
+        if (m->fix_ptr) (void) hipFree(m->fix_ptr);
+        if (m->fix_idx) (void) hipFree(m->fix_idx);
+        if (m->slot_col) (void) hipFree(m->slot_col);
+        if (m->mirror_rows) (void) hipFree(m->mirror_rows);
+        if (m->mirror_ptr) (void) hipFree(m->mirror_ptr);
+        if (m->mirror_col) (void) hipFree(m->mirror_col);
+        if (m->mirror_val) (void) hipFree(m->mirror_val);
+    }
     if (m->d_x) (void) hipFree(m->d_x);
     if (m->d_y) (void) hipFree(m->d_y);
     if (m->p_x) (void) hipHostFree(m->p_x);

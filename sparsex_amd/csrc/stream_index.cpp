@@ -162,6 +162,41 @@ void stream_touched_rows(const GpuStream &s, idx_t below, std::vector<idx_t> &ro
         if (mark[(size_t) r]) rows.push_back(r);
 }
 
+void stream_read_cols(const GpuStream &s, idx_t own_lo, idx_t own_hi, size_t ncols, std::vector<idx_t> &cols)
+{
+    cols.clear();
+    std::vector<char> mark(ncols, 0);
+    auto hit = [&](int64_t c) {
+        if (c >= 0 && (size_t) c < ncols) mark[(size_t) c] = 1;
+    };
+    for (const SpxRowBlock &rb : s.rbs) {
+        for (uint32_t t = 0; t < rb.n_pass; ++t) {
+            const SpxPass &ps = s.passes[(size_t) rb.pass_off + t];
+            const uint32_t nseg = ps.nseg, W = ps.width;
+            for (uint32_t l = 0; l < nseg; ++l) {
+                if (is_gather(ps)) {
+                    const uint32_t sr = s.segrows[(size_t) rb.seg_off + ps.seg0 + l];
+                    for (uint32_t w = 0; w < W && w < SPX_SEGROW_LEN(sr); ++w)
+                        hit(gather_col(s, rb, ps, (size_t) ps.elem0 + l + (size_t) w * nseg));
+                } else if (ps.kind == SPX_PASS_SYMTILE) {
+                    const SpxUnitDesc &d = s.descs[(size_t) rb.desc_off + ps.rank0 + (l >> 3)];
+                    for (uint32_t w = 0; w < 8; ++w) hit((int64_t) d.col0 + w);
+                    // (the transposed products multiply x of the lane's own row)
+                    hit((int64_t) rb.row0 + (int64_t) ps.elem0 + (int64_t) (d.bits & 511u) + (l & 7u));
+                } else {
+                    int64_t r, c0;
+                    unit_lane(s, rb, ps, l, r, c0);
+                    for (uint32_t w = 0; w < W; ++w) hit(c0 + w);
+                    if (ps.kind == SPX_PASS_SYMSEG) hit((int64_t) rb.row0 + r);
+                }
+            }
+        }
+    }
+    for (uint32_t c : s.mirror_col) hit((int64_t) c);
+    for (size_t c = 0; c < ncols; ++c)
+        if (mark[c] && ((idx_t) c < own_lo || (idx_t) c >= own_hi)) cols.push_back((idx_t) c);
+}
+
 void stream_locate_mirror(const GpuStream &s, idx_t row, idx_t col, std::vector<size_t> &out)
 {
     auto it = std::lower_bound(s.mirror_rows.begin(), s.mirror_rows.end(), (uint32_t) row);

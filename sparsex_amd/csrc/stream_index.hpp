@@ -33,6 +33,13 @@ void stream_locate_mirror(const GpuStream &s, idx_t row, idx_t col, std::vector<
 // (include/sparsex/internals/CsxBuild.hpp:400-451).
 void stream_touched_rows(const GpuStream &s, idx_t below, std::vector<idx_t> &rows);
 
+// Columns of x outside [own_lo, own_hi) that the products of this stream read, ascending, unique
+// (padding lanes excluded).  For a process that holds the rows [own_lo, own_hi) of a row-partitioned
+// matrix these are the entries of the OTHER processes' slices it needs as x -- all it needs of them:
+// the halo of spx_hip_matvec_dist(..., SPX_DIST_HALO_X).  The reference has no counterpart (its
+// threads share x); the closest is the column walk of its map, CsxBuild.hpp:432-451.
+void stream_read_cols(const GpuStream &s, idx_t own_lo, idx_t own_hi, size_t ncols, std::vector<idx_t> &cols);
+
 // Launch order for matrices whose rows read x in bands that recur at a fixed row distance (a
 // 3-D stencil: the bands of the z-planes above and below; the distance S is N^2 rows).  Walking
 // the row-blocks of an XCD's part plane by plane, a band comes round again S rows -- some 190

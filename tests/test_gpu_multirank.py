@@ -9,6 +9,7 @@ the symmetric exchange carries real sums.  The children are started before they
 touch the GPU; nothing is re-exec'ed."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -17,16 +18,26 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(world, extra, port):
+def free_port():
+    """A TCP port nobody listens on right now (bound to port 0, read back, released): fixed
+    numbers per case collided across back-to-back runs of the suite (EADDRINUSE)."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def run_bench(world, extra, port=None, timeout=900, host_threads=2):
+    port = port or free_port()
     env = dict(os.environ)
     env.update({"SPX_BENCH_BACKEND": "gloo", "MASTER_ADDR": "127.0.0.1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-           "--gpus", str(world), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--host-threads", "2"] + extra
+           "--gpus", str(world), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--host-threads",
+           str(host_threads)] + extra
     if world == 1:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
                "--no-cpu-baseline", "--no-configs", "--host-threads", "2"] + extra
-    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
     assert len(lines) == 1, p.stdout[-2000:]
@@ -52,13 +63,14 @@ def run_bench(world, extra, port):
 ], ids=["nlpkkt", "nlpkkt-sym", "nlpkkt-sym-segments", "kkt2f-sym", "kkt2f-sym-segments", "kkt2f-sym-auto",
         "nd24k-sym", "nd24k-sym-atomic", "webbase"])
 def test_ranks_share_one_gpu(world, name, extra, tiles):
-    # (a port of its own per case: the cases run side by side under pytest -n)
-    names = ["nlpkkt", "nlpkkt-sym", "nlpkkt-sym-segments", "kkt2f-sym", "kkt2f-sym-segments", "kkt2f-sym-auto",
-             "nd24k-sym", "nd24k-sym-atomic", "webbase"]
-    out = run_bench(world, extra, 29600 + 20 * world + names.index(name))
+    out = run_bench(world, extra)
+    check_line(out, world, name)
+
+
+def check_line(out, world, name):
     assert out["n_gpus"] == world and out["scaling"] == "strong" and out["value"] > 0
     paths = [out] + ([out["symmetric"]] if "symmetric" in out else [])
-    assert ("symmetric" in out) == (not out["config"]["symmetric_path"] and name != "webbase")
+    assert ("symmetric" in out) == (not out["config"]["symmetric_path"] and name not in ("webbase", "nlpkkt-only"))
     if name in ("kkt2f-sym-segments", "kkt2f-sym-auto", "nlpkkt-sym-segments"):
         assert "symseg" in out["roofline"]["kernel"]
     for res in paths:
@@ -70,12 +82,16 @@ def test_ranks_share_one_gpu(world, name, extra, tiles):
         assert all(ranks[i]["rows"][1] == ranks[i + 1]["rows"][0] for i in range(world - 1))
         assert sum(r["nnz"] for r in ranks) == res["config"]["nnz"]
         assert max(r["balance_nnz"] for r in ranks) < 1.5 * min(r["balance_nnz"] for r in ranks)
-        # `value` is a full iteration step: it includes the hand-round of y (and the exchange)
+        # `value` is a full iteration step: it includes the halo exchange of y (and the conflict exchange);
+        # the halo is at most what the hand-round of whole slices would bring
         col = res["collective"]
         assert res["config"]["collective_in_value"].startswith("included")
         assert col["full_step_gflops"] == pytest.approx(res["value"], rel=5e-3, abs=0.02)
         assert col["full_step_ms"] >= col["owned_rows_only_ms"] * 0.8 and col["kernels_only_gflops"] > 0
-        assert col["y_handround_bytes_received_per_rank"] > 0
+        assert col["gather_y_step_ms"] > 0
+        assert col["halo_bytes_received_per_rank"] <= col["y_handround_bytes_received_per_rank"]   # (rank 0's)
+        assert all(8 * r["halo_entries_received"] <= 8 * (res["config"]["nrows"] - (r["rows"][1] - r["rows"][0])) for r in ranks)
+        assert sum(r["halo_entries_received"] for r in ranks) == sum(r["halo_entries_sent"] for r in ranks) > 0
         sym = res["config"]["symmetric_path"]
         sent = [r["conflict_rows_sent"] for r in ranks]
         if sym:
@@ -88,10 +104,47 @@ def test_ranks_share_one_gpu(world, name, extra, tiles):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("symmetric", [False, True], ids=["nlpkkt-e240-8", "nlpkkt-e240-sym-8"])
+def test_contract_matrix_on_eight_ranks(symmetric):
+    """BASELINE config 5 at its real size through the real plan: syn-nlpkkt at grid edge 240
+    (27 993 600 rows, 769 M nonzeros) row-partitioned over EIGHT ranks with the reference's rule
+    (SparseInternal.hpp:131-144; symmetric: by stored nonzeros, the local buffers of
+    src/api/matvec.c:302-318 become the conflict rows of CsxBuild.hpp:400-581, added in the order of
+    Vector.cpp:291-299).  Eight fresh processes share the one GPU of this box; each generates and
+    tunes only its slice (96 M nonzeros, 0.77 GB of values), gloo carries the exchange.  bench.py
+    gates every rank against the CSR product of its own rows for SPX_DIST_OWNED_ROWS, then with
+    SPX_DIST_GATHER_Y (all ranks must hold the same y), then with SPX_DIST_HALO_X (own rows again,
+    and the halo entries against the gathered y).  The byte counts are those of DESIGN.md section 8."""
+    world, N = 8, 240
+    n, P = 2 * N ** 3 + 6 * N ** 2, N ** 3 + 6 * N ** 2
+    out = run_bench(world, ["--edge", str(N), "--no-configs"] + (["--symmetric"] if symmetric else []),
+                    timeout=2400, host_threads=2)
+    check_line(out, world, "nlpkkt-sym" if symmetric else "nlpkkt-only")
+    assert out["config"]["nrows"] == n and out["config"]["nnz"] == 768977264
+    ranks, col = out["ranks"], out["collective"]
+    rows = [r["rows"][1] - r["rows"][0] for r in ranks]
+    if not symmetric:
+        # equal nonzeros = (nearly) equal rows: 28 MB slices, 7 x 28 MB per rank in the hand-round
+        assert all(abs(k - n / world) < 0.01 * n / world for k in rows)
+        assert col["y_handround_bytes_received_per_rank"] == 8 * (n - rows[0])
+        # in this order of the unknowns a rank of state rows reads a whole slice of multipliers
+        # (and the other way round): the halo is about one slice, an eighth of the hand-round
+        assert all(0.9 * n / world < r["halo_entries_received"] < 1.2 * n / world for r in ranks)
+    else:
+        # dealt by STORED nonzeros: rank 0 holds every state and control row (diagonal only) and the
+        # first multiplier rows; every other rank adds into 1.93 M state rows (its conflict rows)
+        assert ranks[0]["rows"][0] == 0 and ranks[0]["rows"][1] > P
+        for r in ranks[1:]:
+            assert 1.85e6 < r["conflict_rows_sent"] < 2.0e6
+            assert r["halo_entries_received"] == r["conflict_rows_sent"]      # the same columns, read as x
+        assert ranks[0]["conflict_entries_received"] == sum(r["conflict_rows_sent"] for r in ranks[1:])
+
+
+@pytest.mark.gpu
 def test_one_rank_runs_the_same_workload():
     """N = 1 is the same matrix on one GPU (what makes the N-axis a strong-scaling curve)."""
-    one = run_bench(1, ["--edge", "28"], 29790)
-    two = run_bench(2, ["--edge", "28"], 29791)
+    one = run_bench(1, ["--edge", "28"])
+    two = run_bench(2, ["--edge", "28"])
     assert one["config"]["nnz"] == two["config"]["nnz"] and one["config"]["nrows"] == two["config"]["nrows"]
     assert one["config"]["workload"] == two["config"]["workload"]
     assert one["scaling"] == two["scaling"] == "strong"

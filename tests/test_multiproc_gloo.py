@@ -130,6 +130,24 @@ def _slice_worker(rank, world, port, symmetric, gen, tmpdir, ret):
             y[r] += recv[plan["fix_pos"][plan["fix_ptr"][t]:plan["fix_ptr"][t + 1]]].sum()
         want_y = (a @ x)[lo:hi]
         ok = np.allclose(y[lo:hi], want_y, rtol=1e-12, atol=1e-14)
+        # the halo of x (SPX_DIST_HALO_X): exactly the columns outside the slice that its stored
+        # nonzeros reach (general: all of them; symmetric: the lower triangle's), by owner; the
+        # owners hold the matching lists of rows to pack, and after the exchange this rank has
+        # every entry of the full product that its own rows read as x
+        halo = A.dist_halo()
+        sl = a[lo:hi].tocoo()
+        outside = sl.col[(sl.col < lo) | ((sl.col >= hi) & (not symmetric))]
+        assert np.array_equal(halo["recv_cols"], np.unique(outside)), (halo["recv_cols"][:8], np.unique(outside)[:8])
+        owner = np.searchsorted(np.asarray(cuts[1:]), halo["recv_cols"], side="right")
+        assert np.array_equal(np.bincount(owner, minlength=world), halo["recv_cnt"])
+        assert np.all((halo["send_rows"] >= lo) & (halo["send_rows"] < hi))
+        hs = torch.from_numpy(y[halo["send_rows"]].copy())
+        hr = torch.empty(int(halo["recv_cnt"].sum()), dtype=torch.float64)
+        dist.all_to_all_single(hr, hs, [int(v) for v in halo["recv_cnt"]], [int(v) for v in halo["send_cnt"]])
+        y[halo["recv_cols"]] = hr.numpy()
+        ok = ok and np.allclose(y[halo["recv_cols"]], (a @ x)[halo["recv_cols"]], rtol=1e-12, atol=1e-14)
+        # ... which is less than the slices of y handed round (general path: far less on a banded matrix)
+        ret["halo%d" % rank] = (int(halo["recv_cols"].size), n - (hi - lo))
         # bytes that travel: the conflict entries, not n doubles
         ret[rank] = (bool(ok), int(plan["send_rows"].size), n)
     finally:
@@ -145,6 +163,9 @@ def test_row_slices_exchange_plan_gloo(tmp_path, world, symmetric, gen):
     ret = mgr.dict()
     mp.spawn(_slice_worker, args=(world, port, symmetric, gen, str(tmp_path), ret), nprocs=world, join=True)
     assert all(ret[r][0] for r in range(world))
+    assert all(ret["halo%d" % r][0] <= ret["halo%d" % r][1] for r in range(world))
+    if gen in ("kkt2f", "nd24k"):          # banded: the halo is a part of the other ranks' slices only
+        assert all(ret["halo%d" % r][0] < ret["halo%d" % r][1] for r in range(world))
     if symmetric:
         # rank 0 sends nothing; the others send far less than an n-long all-reduce would move
         # (banded matrices.  In the KKT layout of syn-nlpkkt the stored triangle is the multiplier
