@@ -127,12 +127,39 @@ class Workload:
     stores (lower triangle + diagonal), as the reference's symmetric partitioning counts them
     (SparseInternal.hpp:131-144 over the lower-triangle elements of SparsePartition.hpp:1087-1129)."""
 
-    def __init__(self, args, rank, world, symmetric):
+    def __init__(self, args, rank, world, symmetric, dist=None):
         from sparsex_amd import synth
+        import sparsex_amd as sx
         self.name = args.workload
         self.mtx = args.mtx or mtx_for(args.workload)
+        reorder = getattr(args, "dist_reorder", "none") if world > 1 else "none"
+        mode = {"rcm": sx.SPX_DIST_REORDER_RCM, "rcm_owner": sx.SPX_DIST_REORDER_RCM_OWNER}.get(reorder)
+        self.reorder, self.reorder_seconds = reorder, 0.0
+
+        def share(arr, n_items, dtype):
+            """rank 0's array on every rank (torch.distributed broadcast)"""
+            import torch
+            t = torch.from_numpy(arr) if rank == 0 else torch.empty(n_items, dtype=dtype)
+            if dist.get_backend() == "nccl":
+                t = t.cuda()
+            dist.broadcast(t, src=0)
+            return t.cpu().numpy()
+
         if self.mtx or args.workload not in SLICED:
             rp, ci, va, n = make_workload(args.workload, args.scale, mtx=self.mtx)
+            if mode:
+                # the partition-aware numbering (spx_hip_dist_reorder): P A P^T, here from the whole matrix
+                import scipy.sparse as sp
+                import torch
+                t0 = time.perf_counter()
+                perm = sx.dist_reorder(rp, ci, n, world, mode) if rank == 0 else None
+                perm = share(perm, n, torch.int32)
+                inv = np.empty(n, dtype=np.int64)
+                inv[perm] = np.arange(n)
+                a = sp.csr_matrix((va, ci, rp), shape=(n, n))[inv][:, inv].tocsr()
+                a.sort_indices()
+                rp, ci, va = a.indptr.astype(np.int32), a.indices.astype(np.int32), a.data
+                self.reorder_seconds = time.perf_counter() - t0
             counts = np.diff(rp)
             stored = stored_counts_csr(rp, ci) if symmetric else None
             cuts = nnz_balanced_cuts(stored if symmetric else counts, world)
@@ -148,9 +175,37 @@ class Workload:
             counts = synth._row_counts(gen, args.edge)
             n = counts.size
             stored = synth.stored_row_counts(gen, args.edge, counts) if symmetric else None
+            if mode:
+                # rank 0 computes the numbering from the pattern of the whole matrix (no values) and, on the
+                # symmetric path, what every row stores in it; the others receive both and generate just
+                # the rows the numbering deals them (tools/synth/nlpkkt_gen.c::spx_syn_nlpkkt_rows_perm)
+                import torch
+                t0 = time.perf_counter()
+                perm = stored_new = None
+                if rank == 0:
+                    rp_f, ci_f = synth._pattern(gen, args.edge, counts)
+                    perm = sx.dist_reorder(rp_f, ci_f, n, world, mode, pattern_symmetric=True)
+                    if symmetric:
+                        stored_new = np.zeros(n, dtype=np.int32)
+                        for r0 in range(0, n, 1 << 20):
+                            r1 = min(n, r0 + (1 << 20))
+                            rows = np.repeat(np.arange(r0, r1, dtype=np.int64), counts[r0:r1])
+                            below = perm[ci_f[rp_f[r0]:rp_f[r1]]] <= perm[rows]
+                            stored_new[perm[r0:r1]] = np.bincount((rows - r0)[below], minlength=r1 - r0)
+                    del rp_f, ci_f
+                perm = share(perm, n, torch.int32)
+                inv = np.empty(n, dtype=np.int64)
+                inv[perm] = np.arange(n)
+                counts_old, counts = counts, counts[inv]
+                if symmetric:
+                    stored = share(stored_new, n, torch.int32)
+                self.reorder_seconds = time.perf_counter() - t0
             cuts = nnz_balanced_cuts(stored if symmetric else counts, world)
             lo, hi = cuts[rank], cuts[rank + 1]
-            self.rp, self.ci, self.va, _ = synth._rows(gen, args.edge, lo, hi, counts, synth.SEED_BASE + 4)
+            if mode:
+                self.rp, self.ci, self.va, _ = synth._rows_perm(gen, args.edge, inv[lo:hi], perm, counts_old, synth.SEED_BASE + 4)
+            else:
+                self.rp, self.ci, self.va, _ = synth._rows(gen, args.edge, lo, hi, counts, synth.SEED_BASE + 4)
             if gen == "nlpkkt":
                 self.label = ("syn-nlpkkt, grid edge %d: the stand-in SURVEY section 8(d) specifies for SuiteSparse "
                               "nlpkkt240 (order 2N^3+6N^2 = %.2f M rows%s, KKT blocks [H A^T; A D] with 27-point "
@@ -161,6 +216,8 @@ class Workload:
             else:
                 self.label = ("syn-kkt2f, grid edge %d (rounds 1-2's matrix: two fully coupled fields, 54 nonzeros per "
                               "row in runs of six columns; NOT the nlpkkt stand-in, kept for comparison)" % args.edge)
+        if mode:
+            self.label += "; unknowns renumbered with spx_hip_dist_reorder(%s) for %d ranks (P A P^T: the same operator)" % (reorder, world)
         self.n, self.lo, self.hi, self.cuts = int(n), int(lo), int(hi), cuts
         self.nnz = int(counts.sum(dtype=np.int64))
         self.nnz_local = int(self.rp[-1])
@@ -746,7 +803,7 @@ def run_path(ctx, args, symmetric):
     from sparsex_amd import synth
 
     t_gen = time.perf_counter()
-    wl = Workload(args, rank, world, symmetric)
+    wl = Workload(args, rank, world, symmetric, dist)
     t_gen = time.perf_counter() - t_gen
     n, lo, hi = wl.n, wl.lo, wl.hi
     T = args.host_threads or max(1, min(host_cores() // max(world, 1), 32))
@@ -920,7 +977,8 @@ def run_path(ctx, args, symmetric):
                    "collective_in_value": ("included: every step ends with each rank holding its rows of y and the "
                                            "entries of the other ranks' rows that it reads as x"
                                            if world > 1 else "none needed"),
-                   "generate_seconds": round(t_gen, 2)},
+                   "generate_seconds": round(t_gen, 2), "dist_reorder": wl.reorder,
+                   "dist_reorder_seconds": round(wl.reorder_seconds, 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": measured_traffic(tkey) if std else None,
@@ -981,6 +1039,9 @@ def main():
                     help="launch the steps of a batch one by one instead of replaying them as one hipGraph "
                          "(stream capture; the default on one GPU, where a step is kernels only)")
     ap.add_argument("--opt", action="append", default=[], help="extra option=value")
+    ap.add_argument("--dist-reorder", default="none", choices=["none", "rcm", "rcm_owner"],
+                    help="several ranks: renumber the unknowns with spx_hip_dist_reorder before the rows are dealt "
+                         "(rank 0 computes the permutation from the pattern and broadcasts it)")
     args = ap.parse_args()
 
     import torch

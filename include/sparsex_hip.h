@@ -251,6 +251,30 @@ typedef struct {
 } spx_hip_dist_plan_t;
 spx_error_t spx_hip_mat_dist_plan(const spx_matrix_t *A, spx_hip_dist_plan_t *plan);
 
+/* Partition-aware numbering for a row-partitioned matrix.  Ranges of rows dealt by nonzeros follow the
+ * order in which the application numbers its unknowns; where that order keeps coupled unknowns far
+ * apart (a KKT matrix [H A^T; A D]: a range of state rows reads a whole range of multipliers), every
+ * process needs a large part of the other processes' vectors.  spx_hip_dist_reorder() computes, from the
+ * CSR pattern of the whole (square) matrix, a permutation perm[old] = new (0-based, `nrows` entries,
+ * caller's array) after which the ranges couple mostly with themselves:
+ *   SPX_DIST_REORDER_RCM        reverse Cuthill-McKee (the order spx_mat_tune(.., SPX_MAT_REORDER) uses)
+ *   SPX_DIST_REORDER_RCM_OWNER  that order only decides WHICH of `world` ranges (equal nonzeros) a row
+ *                               belongs to; inside a range the rows keep their original order, so the
+ *                               substructures of the original numbering (runs, diagonals, blocks) survive
+ * `flags`: SPX_DIST_PATTERN_SYMMETRIC promises that the pattern equals its transpose (it is then used
+ * where it lies; otherwise A + A^T is built).  The caller applies the permutation to rows, columns and
+ * vectors (P A P^T, spx_vec_reorder semantics), e.g. rank 0 computes it once and hands it to the others.
+ * With the whole matrix given to every process (spx.rt.gpu_rank / gpu_world), the option
+ * spx.rt.dist_reorder = none | rcm | rcm_owner makes spx_mat_tune() do all of this itself
+ * (spx_mat_get_perm() returns the permutation).  Reference: its reordering is Rcm.hpp:85-121 on one
+ * process; it has no partition-aware form. */
+#define SPX_DIST_REORDER_RCM        1
+#define SPX_DIST_REORDER_RCM_OWNER  2
+#define SPX_DIST_PATTERN_SYMMETRIC  1
+spx_error_t spx_hip_dist_reorder(const spx_index_t *rowptr, const spx_index_t *colind, spx_index_t nrows,
+                                 int indexing /* SPX_INDEX_ZERO_BASED | SPX_INDEX_ONE_BASED */, int world,
+                                 int mode, int flags, spx_index_t *perm);
+
 /* The halo of x of an attached matrix (arrays owned by the matrix): the columns outside its
  * own rows that this process' stream reads (found by walking the stream itself), grouped by
  * owner, and the own rows the other processes asked for, grouped by the process that asked. */

@@ -607,6 +607,26 @@ class CallbackTransport:
         pass
 
 
+SPX_DIST_REORDER_RCM = 1
+SPX_DIST_REORDER_RCM_OWNER = 2
+SPX_DIST_PATTERN_SYMMETRIC = 1
+
+
+def dist_reorder(rowptr, colind, nrows, world, mode=SPX_DIST_REORDER_RCM_OWNER, pattern_symmetric=False):
+    """``spx_hip_dist_reorder``: perm[old] = new (int32) for the zero-based CSR pattern of a square
+    matrix that is to be dealt to ``world`` processes by nonzeros."""
+    L = lib()
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+    colind = np.ascontiguousarray(colind, dtype=np.int32)
+    perm = np.empty(int(nrows), dtype=np.int32)
+    L.spx_hip_dist_reorder.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    rc = L.spx_hip_dist_reorder(rowptr.ctypes.data, colind.ctypes.data, int(nrows), SPX_INDEX_ZERO_BASED, int(world),
+                                int(mode), SPX_DIST_PATTERN_SYMMETRIC if pattern_symmetric else 0, perm.ctypes.data)
+    if rc != SPX_SUCCESS:
+        raise SpxError("spx_hip_dist_reorder failed (see stderr)")
+    return perm
+
+
 def _dist_attach(self, transport):
     """``spx_hip_mat_dist_attach`` (collective)."""
     L = lib()

@@ -948,10 +948,27 @@ spx_matrix_t *spx_mat_tune(spx_input_t *in, ...)
         SETWARNING(SPX_WARN_REORDER);      // a row slice cannot be reordered on its own
         option = 0;
     }
+    // spx.rt.dist_reorder: the whole matrix given to every process of a multi-GPU job -- a
+    // partition-aware permutation in front of the nonzero-balanced cut (sparsex_hip.h)
+    int re_mode = SPX_DIST_REORDER_RCM;
+    size_t re_world = 1;
+    {
+        const std::string dr = Config::instance().get_str("spx.rt.dist_reorder");
+        const long world = Config::instance().get_long("spx.rt.gpu_world");
+        if (dr != "none" && dr != "rcm" && dr != "rcm_owner") {
+            SETERROR_1(SPX_ERR_ARG_INVALID, "spx.rt.dist_reorder: none, rcm or rcm_owner");
+            return SPX_INVALID_MAT;
+        }
+        if (dr != "none" && world > 1 && Config::instance().get_long("spx.rt.global_rows") <= 0) {
+            option = SPX_MAT_REORDER;
+            re_mode = dr == "rcm_owner" ? SPX_DIST_REORDER_RCM_OWNER : SPX_DIST_REORDER_RCM;
+            re_world = (size_t) world;
+        }
+    }
     if (option == SPX_MAT_REORDER) {
         TripletInput *re = nullptr;
         try {
-            re = reorder_rcm(*in->mat, perm);
+            re = reorder_rcm(*in->mat, perm, re_mode, re_world);
         } catch (const FatalError &) {
             re = nullptr;
             perm.clear();
@@ -1655,6 +1672,30 @@ void spx_options_set_from_env()
 }
 
 void spx_hip_options_reset(void) { Config::instance().reset_defaults(); }
+
+spx_error_t spx_hip_dist_reorder(const spx_index_t *rowptr, const spx_index_t *colind, spx_index_t nrows,
+                                 int indexing, int world, int mode, int flags, spx_index_t *perm)
+{
+    if (!rowptr || !colind || !perm || nrows < 0 || world < 1 ||
+        (indexing != SPX_INDEX_ZERO_BASED && indexing != SPX_INDEX_ONE_BASED) ||
+        (mode != SPX_DIST_REORDER_RCM && mode != SPX_DIST_REORDER_RCM_OWNER)) {
+        SETERROR_1(SPX_ERR_ARG_INVALID, "invalid argument");
+        return SPX_FAILURE;
+    }
+    try {
+        std::vector<idx_t> p;
+        dist_reorder_csr(rowptr, colind, (size_t) nrows, indexing == SPX_INDEX_ZERO_BASED,
+                         (flags & SPX_DIST_PATTERN_SYMMETRIC) != 0, (size_t) world, mode, p);
+        std::copy(p.begin(), p.end(), perm);
+    } catch (const FatalError &e) {
+        SETERROR_1(SPX_ERR_ARG_INVALID, e.what.c_str());
+        return SPX_FAILURE;
+    } catch (const std::bad_alloc &) {
+        SETERROR_0(SPX_ERR_MEM_ALLOC);
+        return SPX_FAILURE;
+    }
+    return SPX_SUCCESS;
+}
 
 void spx_hip_xform(int from, int to, spx_index_t *row, spx_index_t *col,
                    spx_index_t nr_rows, spx_index_t nr_cols)

@@ -10,15 +10,15 @@ namespace spx {
 
 namespace {
 
+template <typename P>
 struct Bfs {
-    const std::vector<size_t> &ptr;
-    const std::vector<idx_t> &adj;
+    const P *ptr;
+    const idx_t *adj;
     std::vector<uint32_t> stamp;   // visit stamp per vertex
     std::vector<idx_t> queue;
     uint32_t epoch = 0;
 
-    Bfs(size_t n, const std::vector<size_t> &p, const std::vector<idx_t> &a)
-        : ptr(p), adj(a), stamp(n, 0) { queue.reserve(n); }
+    Bfs(size_t n, const P *p, const idx_t *a) : ptr(p), adj(a), stamp(n, 0) { queue.reserve(n); }
 
     size_t degree(idx_t v) const { return ptr[(size_t) v + 1] - ptr[(size_t) v]; }
 
@@ -39,7 +39,7 @@ struct Bfs {
             ++nlev;
             for (; head < level_end; ++head) {
                 const idx_t v = queue[head];
-                for (size_t k = ptr[(size_t) v]; k < ptr[(size_t) v + 1]; ++k) {
+                for (size_t k = (size_t) ptr[(size_t) v]; k < (size_t) ptr[(size_t) v + 1]; ++k) {
                     const idx_t w = adj[k];
                     if (done[(size_t) w] || stamp[(size_t) w] == epoch) continue;
                     stamp[(size_t) w] = epoch;
@@ -51,12 +51,10 @@ struct Bfs {
     }
 };
 
-}  // namespace
-
-void rcm_order(size_t n, const std::vector<size_t> &ptr, const std::vector<idx_t> &adj,
-               std::vector<idx_t> &perm)
+template <typename P>
+void rcm_order_impl(size_t n, const P *ptr, const idx_t *adj, std::vector<idx_t> &perm)
 {
-    Bfs bfs(n, ptr, adj);
+    Bfs<P> bfs(n, ptr, adj);
     std::vector<char> done(n, 0);
     std::vector<idx_t> order;   // Cuthill-McKee visiting order
     order.reserve(n);
@@ -95,7 +93,7 @@ void rcm_order(size_t n, const std::vector<size_t> &ptr, const std::vector<idx_t
         while (head < order.size()) {
             const idx_t v = order[head++];
             nbrs.clear();
-            for (size_t k = ptr[(size_t) v]; k < ptr[(size_t) v + 1]; ++k) {
+            for (size_t k = (size_t) ptr[(size_t) v]; k < (size_t) ptr[(size_t) v + 1]; ++k) {
                 const idx_t w = adj[k];
                 if (!done[(size_t) w]) {
                     done[(size_t) w] = 1;
@@ -113,7 +111,99 @@ void rcm_order(size_t n, const std::vector<size_t> &ptr, const std::vector<idx_t
     for (size_t i = 0; i < n; ++i) perm[(size_t) order[n - 1 - i]] = (idx_t) i;
 }
 
-TripletInput *reorder_rcm(MatrixInput &in, std::vector<idx_t> &perm)
+}  // namespace
+
+void rcm_order(size_t n, const std::vector<size_t> &ptr, const std::vector<idx_t> &adj,
+               std::vector<idx_t> &perm)
+{
+    rcm_order_impl(n, ptr.data(), adj.data(), perm);
+}
+
+void owner_order(const std::vector<idx_t> &order_perm, const std::vector<size_t> &weight, size_t world,
+                 std::vector<idx_t> &perm)
+{
+    const size_t n = order_perm.size();
+    // position -> vertex, then cut the positions into `world` ranges of equal weight with the
+    // reference's rule (SparseInternal.hpp:131-144: range i takes vertices until it holds
+    // (total - taken) / (world - i))
+    std::vector<idx_t> at(n);
+    for (size_t v = 0; v < n; ++v) at[(size_t) order_perm[v]] = (idx_t) v;
+    size_t total = 0;
+    for (size_t v = 0; v < n; ++v) total += weight[v];
+    std::vector<uint32_t> owner(n, 0);
+    std::vector<size_t> count(world + 1, 0);
+    size_t taken = 0, pos = 0;
+    for (size_t g = 0; g < world; ++g) {
+        const size_t limit = (total - taken) / (world - g);
+        size_t mine = 0;
+        while (pos < n && (g + 1 == world || mine < limit)) {
+            mine += weight[(size_t) at[pos]];
+            owner[(size_t) at[pos]] = (uint32_t) g;
+            ++count[g + 1];
+            ++pos;
+        }
+        taken += mine;
+    }
+    // inside a range the vertices keep their original order
+    for (size_t g = 0; g < world; ++g) count[g + 1] += count[g];
+    perm.assign(n, 0);
+    std::vector<size_t> fill(count.begin(), count.end() - 1);
+    for (size_t v = 0; v < n; ++v) perm[v] = (idx_t) fill[owner[v]]++;
+}
+
+void dist_reorder_csr(const idx_t *rowptr, const idx_t *colind, size_t n, bool zero_based, bool pattern_symmetric,
+                      size_t world, int mode, std::vector<idx_t> &perm)
+{
+    if (world < 1) throw FatalError("dist reorder: bad number of processes");
+    const idx_t base = zero_based ? 0 : 1;
+    std::vector<size_t> weight(n);
+    for (size_t v = 0; v < n; ++v) weight[v] = (size_t)(rowptr[v + 1] - rowptr[v]);
+    std::vector<idx_t> order;
+    if (pattern_symmetric && zero_based) {
+        // the pattern is its own adjacency (a diagonal entry is a self loop: the walks skip it)
+        rcm_order_impl(n, rowptr, colind, order);
+    } else {
+        // A + A^T without the diagonal, duplicates removed
+        std::vector<size_t> ptr(n + 1, 0);
+        for (size_t r = 0; r < n; ++r)
+            for (idx_t k = rowptr[r] - base; k < rowptr[r + 1] - base; ++k) {
+                const size_t c = (size_t)(colind[k] - base);
+                if (c >= n) throw FatalError("dist reorder: column outside the matrix");
+                if (c != r) {
+                    ++ptr[r + 1];
+                    ++ptr[c + 1];
+                }
+            }
+        for (size_t i = 0; i < n; ++i) ptr[i + 1] += ptr[i];
+        std::vector<idx_t> adj(ptr[n]);
+        {
+            std::vector<size_t> fill(ptr.begin(), ptr.end() - 1);
+            for (size_t r = 0; r < n; ++r)
+                for (idx_t k = rowptr[r] - base; k < rowptr[r + 1] - base; ++k) {
+                    const size_t c = (size_t)(colind[k] - base);
+                    if (c != r) {
+                        adj[fill[r]++] = (idx_t) c;
+                        adj[fill[c]++] = (idx_t) r;
+                    }
+                }
+        }
+        std::vector<size_t> uptr(n + 1, 0);
+        size_t w = 0;
+        for (size_t v = 0; v < n; ++v) {
+            const size_t b = ptr[v], e = ptr[v + 1];
+            std::sort(adj.begin() + (ptrdiff_t) b, adj.begin() + (ptrdiff_t) e);
+            for (size_t k = b; k < e; ++k)
+                if (k == b || adj[k] != adj[k - 1]) adj[w++] = adj[k];
+            uptr[v + 1] = w;
+        }
+        adj.resize(w);
+        rcm_order_impl(n, uptr.data(), adj.data(), order);
+    }
+    if (mode == SPX_DIST_REORDER_RCM_OWNER) owner_order(order, weight, world, perm);
+    else perm.swap(order);
+}
+
+TripletInput *reorder_rcm(MatrixInput &in, std::vector<idx_t> &perm, int mode, size_t world)
 {
     perm.clear();
     const size_t n = in.nr_rows;
@@ -168,6 +258,14 @@ TripletInput *reorder_rcm(MatrixInput &in, std::vector<idx_t> &perm)
     log_msg(LOG_INFO, "Reordering input matrix...\n");
     size_t bw0 = 0, bw1 = 0;
     rcm_order(n, uptr, adj, perm);
+    if (mode == SPX_DIST_REORDER_RCM_OWNER && world > 1) {
+        // the order only deals the rows to the processes; inside a process they keep their places
+        std::vector<size_t> weight(n, 0);
+        for (const Triplet &e : out->elems) ++weight[(size_t) e.row - 1];
+        std::vector<idx_t> own;
+        owner_order(perm, weight, world, own);
+        perm.swap(own);
+    }
     for (Triplet &e : out->elems) {
         bw0 = std::max<size_t>(bw0, (size_t) std::abs((long) e.row - (long) e.col));
         e.row = perm[(size_t) e.row - 1] + 1;

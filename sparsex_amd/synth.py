@@ -212,6 +212,9 @@ def _synlib():
             f = getattr(L, "spx_syn_%s_rows" % g)
             f.restype = C.c_int64
             f.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.spx_syn_nlpkkt_rows_perm.restype = C.c_int64
+        L.spx_syn_nlpkkt_rows_perm.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_uint64, C.c_void_p,
+                                               C.c_void_p, C.c_void_p]
         _SYNLIB = L
     return _SYNLIB
 
@@ -251,6 +254,70 @@ def _rows(gen, N, lo, hi, counts, seed):
         rpl = np.empty(b - a + 1, dtype=np.int64)
         k0 = int(rp[a])
         return fn(int(N), int(lo + a), int(lo + b), int(seed), rpl.ctypes.data,
+                  ci.ctypes.data + 4 * k0, va.ctypes.data + 8 * k0)
+    with ThreadPoolExecutor(T) as ex:
+        got = sum(ex.map(piece, range(T)))
+    assert got == nnz
+    return rp.astype(np.int32), ci, va, n
+
+
+def _pattern(gen, N, counts=None):
+    """Row pointers and column indices of the whole matrix, no values (what a partition-aware
+    numbering is computed from: sparsex_amd.dist_reorder)."""
+    assert gen == "nlpkkt", "pattern-only generation exists for syn-nlpkkt"
+    n = _nrows(gen, N)
+    if counts is None:
+        counts = _row_counts(gen, N)
+    rp = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(counts, dtype=np.int64, out=rp[1:])
+    nnz = int(rp[-1])
+    assert nnz < 2 ** 31
+    ci = np.empty(nnz, dtype=np.int32)
+    fn = getattr(_synlib(), "spx_syn_%s_rows" % gen)
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    T = max(1, min(len(os.sched_getaffinity(0)), 32, nnz >> 22))
+    cuts = [int(np.searchsorted(rp, nnz * t // T, side="left")) for t in range(T)] + [n]
+
+    def piece(t):
+        a, b = cuts[t], cuts[t + 1]
+        if b <= a:
+            return 0
+        rpl = np.empty(b - a + 1, dtype=np.int64)
+        return fn(int(N), int(a), int(b), 0, rpl.ctypes.data, ci.ctypes.data + 4 * int(rp[a]), None)
+    with ThreadPoolExecutor(T) as ex:
+        got = sum(ex.map(piece, range(T)))
+    assert got == nnz
+    return rp.astype(np.int32), ci
+
+
+def _rows_perm(gen, N, rows_old, perm, counts, seed):
+    """The rows `rows_old` (original numbering) of P A P^T, perm[old] = new: CSR with renumbered,
+    sorted columns (tools/synth/nlpkkt_gen.c::spx_syn_nlpkkt_rows_perm)."""
+    assert gen == "nlpkkt", "permuted row generation exists for syn-nlpkkt"
+    rows_old = np.ascontiguousarray(rows_old, dtype=np.int64)
+    perm = np.ascontiguousarray(perm, dtype=np.int32)
+    n = _nrows(gen, N)
+    m = rows_old.size
+    rp = np.zeros(m + 1, dtype=np.int64)
+    np.cumsum(counts[rows_old], dtype=np.int64, out=rp[1:])
+    nnz = int(rp[-1])
+    assert nnz < 2 ** 31, "slice too large for 32-bit row pointers"
+    ci = np.empty(nnz, dtype=np.int32)
+    va = np.empty(nnz, dtype=np.float64)
+    fn = _synlib().spx_syn_nlpkkt_rows_perm
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    T = max(1, min(len(os.sched_getaffinity(0)), 32, nnz >> 22))
+    cuts = [int(np.searchsorted(rp, nnz * t // T, side="left")) for t in range(T)] + [m]
+
+    def piece(t):
+        a, b = cuts[t], cuts[t + 1]
+        if b <= a:
+            return 0
+        rpl = np.empty(b - a + 1, dtype=np.int64)
+        k0 = int(rp[a])
+        return fn(int(N), rows_old.ctypes.data + 8 * a, int(b - a), perm.ctypes.data, int(seed), rpl.ctypes.data,
                   ci.ctypes.data + 4 * k0, va.ctypes.data + 8 * k0)
     with ThreadPoolExecutor(T) as ex:
         got = sum(ex.map(piece, range(T)))

@@ -162,14 +162,47 @@ int64_t spx_syn_nlpkkt_rows(int N, int64_t lo, int64_t hi, uint64_t seed, int64_
             kd = k;
             colind[k++] = (int32_t) r;
         }
-        double sum = 0.0;
-        for (int64_t e = k0; e < k; ++e) {
-            if (e == kd) continue;
-            values[e] = pair_value(seed, r, colind[e], g.n);
-            sum += fabs(values[e]);
+        if (values) {                         /* (NULL: the pattern alone) */
+            double sum = 0.0;
+            for (int64_t e = k0; e < k; ++e) {
+                if (e == kd) continue;
+                values[e] = pair_value(seed, r, colind[e], g.n);
+                sum += fabs(values[e]);
+            }
+            values[kd] = sum + 1.0;
         }
-        values[kd] = sum + 1.0;
         rowptr[r - lo + 1] = k;
+    }
+    return k;
+}
+
+/* The rows rows[0..m) (original numbering, any order) of P A P^T for the permutation perm[old] = new:
+ * row i of the result is original row rows[i], its columns renumbered and sorted ascending, its
+ * values those of the original matrix.  rowptr has m + 1 entries.  (A process of a multi-GPU run
+ * generates just the rows the partition-aware numbering deals it: bench.py --dist-reorder.) */
+int64_t spx_syn_nlpkkt_rows_perm(int N, const int64_t *rows, int64_t m, const int32_t *perm, uint64_t seed,
+                                 int64_t *rowptr, int32_t *colind, double *values)
+{
+    int64_t k = 0, rp2[2];
+    int32_t c[40];
+    double v[40];
+    rowptr[0] = 0;
+    for (int64_t i = 0; i < m; ++i) {
+        const int64_t cnt = spx_syn_nlpkkt_rows(N, rows[i], rows[i] + 1, seed, rp2, c, values ? v : NULL);
+        for (int64_t e = 0; e < cnt; ++e) {      /* insertion sort by new column (at most 34 entries) */
+            const int32_t cn = perm[c[e]];
+            const double vv = values ? v[e] : 0.0;
+            int64_t j = k + e;
+            while (j > k && colind[j - 1] > cn) {
+                colind[j] = colind[j - 1];
+                if (values) values[j] = values[j - 1];
+                --j;
+            }
+            colind[j] = cn;
+            if (values) values[j] = vv;
+        }
+        k += cnt;
+        rowptr[i + 1] = k;
     }
     return k;
 }
