@@ -831,7 +831,10 @@ def run_path(ctx, args, symmetric):
     x = torch.from_numpy(xh).to(dev)
     y = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
 
-    def step(stream, flags=sx.SPX_DIST_HALO_X):
+    # (general path: the halo exchange is pipelined over parts of the own product, SPX_DIST_OVERLAP)
+    FULL = sx.SPX_DIST_HALO_X | (0 if symmetric else sx.SPX_DIST_OVERLAP)
+
+    def step(stream, flags=FULL):
         # several ranks: ONE ITERATION STEP -- the local product, (symmetric) the conflict-row
         # exchange, and the halo exchange: every rank receives exactly the entries of the other
         # ranks' slices of y that its own rows read as x, so that x <- y can follow at once
@@ -842,6 +845,9 @@ def run_path(ctx, args, symmetric):
 
     def step_owned(stream):                  # without any hand-over of y: the owned rows only
         step(stream, sx.SPX_DIST_OWNED_ROWS)
+
+    def step_halo_plain(stream):             # the halo exchange after the whole product, one stream
+        step(stream, sx.SPX_DIST_HALO_X)
 
     def step_gather(stream):                 # rounds 2-3's step: whole slices of y handed round (x replicated)
         step(stream, sx.SPX_DIST_GATHER_Y)
@@ -888,6 +894,14 @@ def run_path(ctx, args, symmetric):
         if symmetric:
             need = need[need < lo]              # (the stored triangle's columns)
         assert np.array_equal(need, halo["recv_cols"]), "halo list != columns the rank's rows read"
+        if FULL != sx.SPX_DIST_HALO_X:
+            # ... and the plain order (whole product, then the exchange) once more, the same way
+            y.fill_(float("nan"))
+            step_halo_plain(cur)
+            torch.cuda.synchronize()
+            parity_gate(torch, y, a_local, xh, lo, hi, ablation)
+            herr = float((y[hc] - y_full[hc]).abs().max()) if hc.numel() else 0.0
+            assert ablation or (herr == herr and herr <= 1e-12 * scale), "halo entries (plain order) differ: %g" % herr
         del y_full, hc
     del a_local
 
@@ -911,6 +925,7 @@ def run_path(ctx, args, symmetric):
     if world > 1:
         w_owned, _, _, _ = time_batches(torch, step_owned, args.steps, barrier, reduce_max, False)
         w_gather, _, _, _ = time_batches(torch, step_gather, args.steps, barrier, reduce_max, False)
+        w_plain = wall if FULL == sx.SPX_DIST_HALO_X else time_batches(torch, step_halo_plain, args.steps, barrier, reduce_max, False)[0]
         w_local, d_local, _, _ = time_batches(torch, step_local, args.steps, barrier, reduce_max, False)
         launch_s = d_local / args.steps       # the roofline is the kernels' (HIP events, this rank)
         gf = lambda w: round(2.0 * wl.nnz * args.steps / w / 1e9, 2)
@@ -919,12 +934,15 @@ def run_path(ctx, args, symmetric):
                       "full_step_ms": round(1e3 * wall / args.steps, 5),
                       "owned_rows_only_ms": round(1e3 * w_owned / args.steps, 5),
                       "gather_y_step_ms": round(1e3 * w_gather / args.steps, 5),
+                      "halo_step_not_overlapped_ms": round(1e3 * w_plain / args.steps, 5),
+                      "overlap_rounds": len(A.dist_rounds()) if FULL != sx.SPX_DIST_HALO_X else 0,
                       "kernels_only_ms": round(1e3 * w_local / args.steps, 5),
                       "halo_bytes_received_per_rank": 8 * int(halo["recv_cols"].size),
                       "halo_bytes_sent_per_rank": 8 * int(halo["send_rows"].size),
                       "y_handround_bytes_received_per_rank": 8 * (n - (hi - lo)),
                       "what": "full step = local product%s + halo exchange (every rank receives exactly the entries "
-                              "of the others' slices of y that its rows read as x: x <- y can follow); `value` is the "
+                              "of the others' slices of y that its rows read as x: x <- y can follow; general path: the "
+                              "exchange runs in rounds behind the parts of the product); `value` is the "
                               "full step; gather_y_step = the same with whole slices handed round instead "
                               "(x replicated, rounds 2-3's step)" % (
                                   " + conflict-row exchange" if symmetric else "")}

@@ -229,6 +229,12 @@ spx_error_t spx_hip_mat_dist_attach(spx_matrix_t *A, const spx_hip_transport_t *
                                    spx_hip_mat_dist_halo): what an iteration x <- y needs here, nothing
                                    more.  Every owner packs the entries each of the others asked for at
                                    attach time and sends them pairwise; ignored with SPX_DIST_GATHER_Y */
+#define SPX_DIST_OVERLAP    4   /* with SPX_DIST_HALO_X on the general path: the own product runs in
+                                   spx.rt.dist_chunks launches over consecutive parts of the rows, and the
+                                   halo entries of part k travel on a second stream while part k + 1 is
+                                   computed; `stream` waits for the last round.  Same result; where the
+                                   stream cannot be cut (or on the symmetric path, whose conflict rows are
+                                   complete only after the whole product) the plain order is used */
 /* y <- alpha*A*x + beta*y over all processes; device pointers of full length,
  * everything enqueued on `stream`.  Collective. */
 spx_error_t spx_hip_matvec_dist(spx_value_t alpha, const spx_matrix_t *A,
@@ -287,6 +293,15 @@ typedef struct {
     const size_t *send_off, *send_cnt;      /* [world] segment of every such process           */
 } spx_hip_dist_halo_t;
 spx_error_t spx_hip_mat_dist_halo(const spx_matrix_t *A, spx_hip_dist_halo_t *halo);
+
+/* The rounds of the overlapped step (SPX_DIST_OVERLAP) of an attached matrix: round r moves, per
+ * peer, the segment [off, off + cnt) of the halo send list (spx_hip_dist_halo_t::send_rows) out and
+ * the segment of the halo receive list (recv_cols) in -- the entries that lie in part r of their
+ * owner's rows.  Over all rounds every entry travels exactly once.  0 rounds: none planned
+ * (spx.rt.dist_chunks <= 1). */
+int spx_hip_mat_dist_rounds(const spx_matrix_t *A);
+spx_error_t spx_hip_mat_dist_round(const spx_matrix_t *A, int round, const size_t **send_off, const size_t **send_cnt,
+                                   const size_t **recv_off, const size_t **recv_cnt);
 
 /* ---- introspection ---------------------------------------------------------- */
 typedef struct {

@@ -535,6 +535,7 @@ class DistHaloStruct(C.Structure):
 SPX_DIST_OWNED_ROWS = 0
 SPX_DIST_GATHER_Y = 1
 SPX_DIST_HALO_X = 2
+SPX_DIST_OVERLAP = 4
 SPX_RCCL_ID_BYTES = 128
 
 
@@ -673,6 +674,23 @@ def _dist_halo(self):
             "send_rows": arr(h.send_rows, h.n_send), "send_off": arr(h.send_off, W), "send_cnt": arr(h.send_cnt, W)}
 
 
+def _dist_rounds(self):
+    """The rounds of the overlapped step as a list of dicts of [world] arrays (send_off, send_cnt,
+    recv_off, recv_cnt): segments of the halo lists that travel in every round."""
+    L = lib()
+    L.spx_hip_mat_dist_rounds.argtypes = [C.c_void_p]
+    L.spx_hip_mat_dist_round.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.POINTER(C.c_size_t))] * 4
+    W = int(self.dist_plan()["world"])
+    out = []
+    for r in range(L.spx_hip_mat_dist_rounds(self.handle)):
+        ptrs = [C.POINTER(C.c_size_t)() for _ in range(4)]
+        if L.spx_hip_mat_dist_round(self.handle, r, *[C.byref(p) for p in ptrs]) != SPX_SUCCESS:
+            raise SpxError("spx_hip_mat_dist_round failed")
+        out.append({k: np.ctypeslib.as_array(p, shape=(W,)).astype(np.int64)
+                    for k, p in zip(("send_off", "send_cnt", "recv_off", "recv_cnt"), ptrs)})
+    return out
+
+
 def _hip_matvec_dist(self, alpha, x_ptr, beta, y_ptr, flags=SPX_DIST_OWNED_ROWS, stream=0):
     """``spx_hip_matvec_dist`` (collective)."""
     L = lib()
@@ -685,4 +703,5 @@ def _hip_matvec_dist(self, alpha, x_ptr, beta, y_ptr, flags=SPX_DIST_OWNED_ROWS,
 Matrix.dist_attach = _dist_attach
 Matrix.dist_plan = _dist_plan
 Matrix.dist_halo = _dist_halo
+Matrix.dist_rounds = _dist_rounds
 Matrix.hip_matvec_dist = _hip_matvec_dist

@@ -1829,6 +1829,11 @@ spx_error_t spx_hip_matvec_dist(spx_value_t alpha, const spx_matrix_t *A,
         return SPX_FAILURE;
     }
     try {
+        if ((flags & SPX_DIST_OVERLAP) && (flags & SPX_DIST_HALO_X) && !(flags & SPX_DIST_GATHER_Y) &&
+            !A->symmetric && A->dist->rounds && A->dist->world > 1) {
+            dist_step_overlapped(A->dist, A->dev, alpha, x_dev, beta, y_dev, stream);
+            return SPX_SUCCESS;
+        }
         device_spmv(A->dev, alpha, x_dev, beta, y_dev, stream);
         dist_complete(A->dist, y_dev, (flags & SPX_DIST_GATHER_Y) != 0, (flags & SPX_DIST_HALO_X) != 0, stream);
     } catch (const FatalError &e) {

@@ -9,6 +9,7 @@
 
 #include <functional>
 #include <string>
+#include <vector>
 
 namespace spx {
 
@@ -25,6 +26,14 @@ void device_free(DeviceMatrix *m);
 // (a hipStream_t passed as void*; NULL = default stream).
 void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
                  double *d_y, void *stream);
+
+// The product in K launches over consecutive parts of the row-blocks (equal work each), so that
+// the exchange of a row-partitioned matrix can start on the rows of part k while part k + 1 is
+// computed (dist.cpp).  Plain general streams only: device_plan_chunks returns 0 for the others;
+// `row_bounds` receives the first row of every part and the end of the own rows.
+size_t device_plan_chunks(DeviceMatrix *m, size_t K, std::vector<size_t> &row_bounds);
+void device_spmv_chunk(DeviceMatrix *m, size_t k, double alpha, const double *d_x, double beta,
+                       double *d_y, void *stream);
 
 // host-vector convenience path used by spx_matvec_*: H2D x (and y when
 // beta != 0), kernel, D2H y; synchronous.  Vectors the library allocated itself

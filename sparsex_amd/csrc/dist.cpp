@@ -1,6 +1,7 @@
 // dist.cpp -- see dist.hpp.
 #include "dist.hpp"
 #include "handles.hpp"
+#include "config.hpp"
 
 #include <algorithm>
 #include <cstring>
@@ -244,6 +245,94 @@ DistPlan *dist_build_plan(const spx_hip_transport_t &t, idx_t own_lo, idx_t own_
     return p.release();
 }
 
+void dist_plan_overlap(DistPlan *p, const std::vector<size_t> &chunk_rows)
+{
+    const size_t W = (size_t) p->world, me = (size_t) p->rank;
+    constexpr size_t KMAX = 64;
+    const spx_hip_transport_t &t = p->transport;
+    p->my_chunks = chunk_rows.size() > 1 ? std::min(chunk_rows.size() - 1, KMAX) : 0;
+    p->chunk_rows.assign(chunk_rows.begin(), chunk_rows.begin() + (p->my_chunks ? p->my_chunks + 1 : 0));
+    // everybody's part bounds: {K, bounds[0..K]} padded to KMAX + 2 words
+    const size_t L = KMAX + 2;
+    std::vector<uint64_t> send(L, 0), recv(W * L, 0);
+    send[0] = p->my_chunks;
+    for (size_t k = 0; k <= p->my_chunks && p->my_chunks; ++k) send[1 + k] = p->chunk_rows[k];
+    std::vector<size_t> soff(W, 0), scnt(W, L), roff(W), rcnt(W, L);
+    for (size_t q = 0; q < W; ++q) roff[q] = q * L;
+    scnt[me] = rcnt[me] = 0;
+    if (W > 1) {
+        if (!t.exchange_host || t.exchange_host(t.ctx, send.data(), soff.data(), scnt.data(), recv.data(), roff.data(), rcnt.data()) != 0)
+            throw FatalError("transport: host exchange failed");
+    }
+    std::copy(send.begin(), send.end(), recv.begin() + me * L);
+    size_t R = 1;
+    for (size_t q = 0; q < W; ++q) R = std::max<size_t>(R, (size_t) recv[q * L]);
+    p->rounds = R;
+    // round of a row of process q: the part that holds it (a process without parts: round 0)
+    auto round_of = [&](size_t q, idx_t row) -> size_t {
+        const size_t K = (size_t) recv[q * L];
+        if (K == 0) return 0;
+        const uint64_t *b = recv.data() + q * L + 1;
+        size_t k = (size_t)(std::upper_bound(b, b + K + 1, (uint64_t) row) - b);
+        return k == 0 ? 0 : std::min(k - 1, K - 1);
+    };
+    p->rd_send_off.assign(R, std::vector<size_t>(W, 0));
+    p->rd_send_cnt.assign(R, std::vector<size_t>(W, 0));
+    p->rd_recv_off.assign(R, std::vector<size_t>(W, 0));
+    p->rd_recv_cnt.assign(R, std::vector<size_t>(W, 0));
+    std::vector<std::vector<uint32_t>> pack(R), scat(R);
+    for (size_t q = 0; q < W; ++q) {
+        // what I send q: my rows, ascending -> my rounds in order
+        size_t at = p->halo_send_off[q];
+        const size_t end = at + p->halo_send_cnt[q];
+        for (size_t r = 0; r < R; ++r) {
+            p->rd_send_off[r][q] = at;
+            while (at < end && round_of(me, p->halo_send_rows[at]) <= r) pack[r].push_back((uint32_t) at++);
+            p->rd_send_cnt[r][q] = at - p->rd_send_off[r][q];
+        }
+        // what q sends me: its rows, ascending -> its rounds in order
+        at = p->halo_recv_off[q];
+        const size_t rend = at + p->halo_recv_cnt[q];
+        for (size_t r = 0; r < R; ++r) {
+            p->rd_recv_off[r][q] = at;
+            while (at < rend && round_of(q, p->halo_cols[at]) <= r) scat[r].push_back((uint32_t) at++);
+            p->rd_recv_cnt[r][q] = at - p->rd_recv_off[r][q];
+        }
+    }
+    p->rd_pack_pos.clear(); p->rd_scat_pos.clear();
+    p->rd_pack_ptr.assign(1, 0); p->rd_scat_ptr.assign(1, 0);
+    for (size_t r = 0; r < R; ++r) {
+        p->rd_pack_pos.insert(p->rd_pack_pos.end(), pack[r].begin(), pack[r].end());
+        p->rd_scat_pos.insert(p->rd_scat_pos.end(), scat[r].begin(), scat[r].end());
+        p->rd_pack_ptr.push_back(p->rd_pack_pos.size());
+        p->rd_scat_ptr.push_back(p->rd_scat_pos.size());
+    }
+    if (p->dev) dist_device_set_rounds(p->dev, *p);
+}
+
+void dist_step_overlapped(DistPlan *p, DeviceMatrix *m, double alpha, const double *d_x, double beta,
+                          double *d_y, void *stream)
+{
+    const spx_hip_transport_t &t = p->transport;
+    if (!p->rounds || !p->dev) throw FatalError("no overlapped step planned for this matrix");
+    void *comm = dist_device_comm_stream(p->dev);
+    for (size_t r = 0; r < p->rounds; ++r) {
+        if (p->my_chunks == 0) {
+            if (r == 0) device_spmv(m, alpha, d_x, beta, d_y, stream);
+        } else if (r < p->my_chunks) {
+            device_spmv_chunk(m, r, alpha, d_x, beta, d_y, stream);
+        }
+        dist_device_round_begin(p->dev, r, stream);
+        dist_device_round_pack(p->dev, r, d_y);
+        if (t.exchange_device(t.ctx, dist_device_halo_sendbuf(p->dev), p->rd_send_off[r].data(), p->rd_send_cnt[r].data(),
+                              dist_device_halo_recvbuf(p->dev), p->rd_recv_off[r].data(), p->rd_recv_cnt[r].data(),
+                              comm) != 0)
+            throw FatalError("transport: halo exchange failed");
+        dist_device_round_scatter(p->dev, r, d_y);
+    }
+    dist_device_rounds_end(p->dev, stream);
+}
+
 void dist_free_plan(DistPlan *p)
 {
     if (!p) return;
@@ -296,6 +385,17 @@ spx_error_t spx_hip_mat_dist_attach(spx_matrix_t *A, const spx_hip_transport_t *
         }
         A->dist = dist_build_plan(*t, A->own_lo, A->own_hi, A->nrows, A->conflict_rows, A->halo_cols,
                                   A->dev != nullptr);
+        // the overlapped step (general path, spx.rt.dist_chunks parts; collective as well)
+        {
+            std::vector<size_t> bounds;
+            const long K = Config::instance().get_long("spx.rt.dist_chunks");
+            if (A->dev && !A->symmetric && K > 1) device_plan_chunks(A->dev, (size_t) K, bounds);
+            if (!A->dev && !A->symmetric && K > 1 && A->own_hi - A->own_lo >= 2 * K) {
+                // (host-only matrix: equal parts of the rows, so that the plan itself can be tested without a GPU)
+                for (long k = 0; k <= K; ++k) bounds.push_back((size_t) A->own_lo + (size_t)(A->own_hi - A->own_lo) * (size_t) k / (size_t) K);
+            }
+            if (K > 1) dist_plan_overlap(A->dist, bounds);
+        }
         // the exchange takes over what the caller-side all-reduce needed: rows this
         // process neither owns nor adds to are nobody's business any more
         // (the thin mirror list stores its rows, it needs no cleared y; spilled tile sums in
@@ -336,6 +436,25 @@ spx_error_t spx_hip_mat_dist_plan(const spx_matrix_t *A, spx_hip_dist_plan_t *pl
     plan->fix_ptr = p.fix_ptr.data();
     plan->fix_pos = p.fix_pos.data();
     plan->any_exchange = p.any_exchange ? 1 : 0;
+    return SPX_SUCCESS;
+}
+
+int spx_hip_mat_dist_rounds(const spx_matrix_t *A)
+{
+    return (A && A->dist) ? (int) A->dist->rounds : 0;
+}
+
+spx_error_t spx_hip_mat_dist_round(const spx_matrix_t *A, int round, const size_t **send_off, const size_t **send_cnt,
+                                   const size_t **recv_off, const size_t **recv_cnt)
+{
+    if (!A || !A->dist || round < 0 || (size_t) round >= A->dist->rounds || !send_off || !send_cnt || !recv_off || !recv_cnt) {
+        SETERROR_1(SPX_ERR_ARG_INVALID, "no such round of the overlapped step");
+        return SPX_FAILURE;
+    }
+    *send_off = A->dist->rd_send_off[(size_t) round].data();
+    *send_cnt = A->dist->rd_send_cnt[(size_t) round].data();
+    *recv_off = A->dist->rd_recv_off[(size_t) round].data();
+    *recv_cnt = A->dist->rd_recv_cnt[(size_t) round].data();
     return SPX_SUCCESS;
 }
 

@@ -8,6 +8,7 @@
 #include <sparsex_hip.h>
 
 #include "common.hpp"
+#include "device.hpp"
 
 #include <vector>
 
@@ -33,6 +34,15 @@ struct DistPlan {
     std::vector<size_t> halo_recv_off, halo_recv_cnt;   // per owner
     std::vector<idx_t> halo_send_rows;            // own entries the others need, grouped by the process that asked
     std::vector<size_t> halo_send_off, halo_send_cnt;   // per such process
+    // overlap (SPX_DIST_OVERLAP): the own product runs in `my_chunks` launches over consecutive parts of
+    // the rows; the halo entries of part k travel (round k, on a second stream) while part k + 1 is
+    // computed.  Every process takes part in `rounds` = the largest part count of any process.
+    size_t my_chunks = 0, rounds = 0;
+    std::vector<size_t> chunk_rows;                               // my_chunks + 1 row bounds
+    std::vector<std::vector<size_t>> rd_send_off, rd_send_cnt;    // [round][peer] inside the halo send buffer
+    std::vector<std::vector<size_t>> rd_recv_off, rd_recv_cnt;    // [round][peer] inside the halo receive buffer
+    std::vector<uint32_t> rd_pack_pos, rd_scat_pos;               // positions to pack / scatter, round by round
+    std::vector<size_t> rd_pack_ptr, rd_scat_ptr;                 // rounds + 1 offsets into them
     DistDevice *dev = nullptr;
 };
 
@@ -43,6 +53,15 @@ DistPlan *dist_build_plan(const spx_hip_transport_t &t, idx_t own_lo, idx_t own_
                           const std::vector<idx_t> &conflict_rows, const std::vector<idx_t> &halo_cols,
                           bool on_device);
 void dist_free_plan(DistPlan *p);
+
+// Collective, after dist_build_plan: agree on the rounds of the overlapped step.  `chunk_rows`: the
+// row bounds of this process' parts (empty: its stream cannot be cut -- it sends everything in round 0).
+void dist_plan_overlap(DistPlan *p, const std::vector<size_t> &chunk_rows);
+
+// the overlapped step of the general path: part k of the product on `stream`, round k of the halo
+// exchange behind it on the plan's second stream; returns with `stream` waiting for the last round
+void dist_step_overlapped(DistPlan *p, DeviceMatrix *m, double alpha, const double *d_x, double beta,
+                          double *d_y, void *stream);
 
 // after the local SpMV on `stream`: hand the sums for other processes' rows to
 // their owners and add what arrives; then (gather) pass the finished slices round
@@ -58,5 +77,13 @@ void dist_device_unpack(DistDevice *d, double *d_y, void *stream);
 const double *dist_device_halo_pack(DistDevice *d, const double *d_y, void *stream);
 double *dist_device_halo_recvbuf(DistDevice *d);
 void dist_device_halo_scatter(DistDevice *d, double *d_y, void *stream);
+// overlapped step: round lists on the device, the second stream and its events
+void dist_device_set_rounds(DistDevice *d, const DistPlan &p);
+void *dist_device_comm_stream(DistDevice *d);
+void dist_device_round_begin(DistDevice *d, size_t round, void *main_stream);   // comm stream waits for the part just launched
+void dist_device_round_pack(DistDevice *d, size_t round, const double *d_y);
+void dist_device_round_scatter(DistDevice *d, size_t round, double *d_y);
+void dist_device_rounds_end(DistDevice *d, void *main_stream);                    // main stream waits for the last round
+double *dist_device_halo_sendbuf(DistDevice *d);
 
 }  // namespace spx

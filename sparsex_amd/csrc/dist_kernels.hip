@@ -45,6 +45,11 @@ struct DistDevice {
     size_t n_halo_send = 0, n_halo_recv = 0;
     idx_t *halo_send_rows = nullptr, *halo_cols = nullptr;
     double *halo_sendbuf = nullptr, *halo_recvbuf = nullptr;
+    // overlapped step
+    uint32_t *rd_pack_pos = nullptr, *rd_scat_pos = nullptr;
+    std::vector<size_t> rd_pack_ptr, rd_scat_ptr;
+    hipStream_t comm = nullptr;
+    hipEvent_t ev_part = nullptr, ev_done = nullptr;
 };
 
 // sendbuf[k] = y[send_rows[k]]: the sums this process formed for rows of others
@@ -70,6 +75,18 @@ __global__ void dist_scatter_kernel(const idx_t *cols, const double *buf, double
 {
     const size_t k = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) y[cols[k]] = buf[k];
+}
+
+// the same through position lists (one round of the overlapped step)
+__global__ void dist_pack_pos_kernel(const uint32_t *pos, const idx_t *rows, const double *y, double *buf, size_t n)
+{
+    const size_t k = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) buf[pos[k]] = y[rows[pos[k]]];
+}
+__global__ void dist_scatter_pos_kernel(const uint32_t *pos, const idx_t *cols, const double *buf, double *y, size_t n)
+{
+    const size_t k = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) y[cols[pos[k]]] = buf[pos[k]];
 }
 
 template <typename T>
@@ -111,6 +128,10 @@ void dist_device_free(DistDevice *d)
     (void) hipFree(d->fix_pos); (void) hipFree(d->sendbuf); (void) hipFree(d->recvbuf);
     (void) hipFree(d->halo_send_rows); (void) hipFree(d->halo_cols);
     (void) hipFree(d->halo_sendbuf); (void) hipFree(d->halo_recvbuf);
+    (void) hipFree(d->rd_pack_pos); (void) hipFree(d->rd_scat_pos);
+    if (d->ev_part) (void) hipEventDestroy(d->ev_part);
+    if (d->ev_done) (void) hipEventDestroy(d->ev_done);
+    if (d->comm) (void) hipStreamDestroy(d->comm);
     delete d;
 }
 
@@ -147,6 +168,51 @@ void dist_device_halo_scatter(DistDevice *d, double *d_y, void *stream)
     if (d->n_halo_recv)
         hipLaunchKernelGGL(dist_scatter_kernel, dim3((unsigned) ((d->n_halo_recv + 255) / 256)), dim3(256), 0,
                            static_cast<hipStream_t>(stream), d->halo_cols, d->halo_recvbuf, d_y, d->n_halo_recv);
+}
+
+void dist_device_set_rounds(DistDevice *d, const DistPlan &p)
+{
+    (void) hipFree(d->rd_pack_pos); (void) hipFree(d->rd_scat_pos);
+    d->rd_pack_pos = to_device(p.rd_pack_pos);
+    d->rd_scat_pos = to_device(p.rd_scat_pos);
+    d->rd_pack_ptr = p.rd_pack_ptr;
+    d->rd_scat_ptr = p.rd_scat_ptr;
+    if (!d->comm) {
+        HIP_CHECK(hipStreamCreateWithFlags(&d->comm, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&d->ev_part, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&d->ev_done, hipEventDisableTiming));
+    }
+}
+
+void *dist_device_comm_stream(DistDevice *d) { return d->comm; }
+double *dist_device_halo_sendbuf(DistDevice *d) { return d->halo_sendbuf; }
+
+void dist_device_round_begin(DistDevice *d, size_t, void *main_stream)
+{
+    HIP_CHECK(hipEventRecord(d->ev_part, static_cast<hipStream_t>(main_stream)));
+    HIP_CHECK(hipStreamWaitEvent(d->comm, d->ev_part, 0));
+}
+
+void dist_device_round_pack(DistDevice *d, size_t r, const double *d_y)
+{
+    const size_t lo = d->rd_pack_ptr[r], n = d->rd_pack_ptr[r + 1] - lo;
+    if (n)
+        hipLaunchKernelGGL(dist_pack_pos_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, d->comm,
+                           d->rd_pack_pos + lo, d->halo_send_rows, d_y, d->halo_sendbuf, n);
+}
+
+void dist_device_round_scatter(DistDevice *d, size_t r, double *d_y)
+{
+    const size_t lo = d->rd_scat_ptr[r], n = d->rd_scat_ptr[r + 1] - lo;
+    if (n)
+        hipLaunchKernelGGL(dist_scatter_pos_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, d->comm,
+                           d->rd_scat_pos + lo, d->halo_cols, d->halo_recvbuf, d_y, n);
+}
+
+void dist_device_rounds_end(DistDevice *d, void *main_stream)
+{
+    HIP_CHECK(hipEventRecord(d->ev_done, d->comm));
+    HIP_CHECK(hipStreamWaitEvent(static_cast<hipStream_t>(main_stream), d->ev_done, 0));
 }
 
 // ---- RCCL transport --------------------------------------------------------------------------

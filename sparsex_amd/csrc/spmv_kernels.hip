@@ -1174,6 +1174,12 @@ struct DeviceMatrix {
     // (spx.gpu.arena=false / SPX_NO_ARENA: an allocation per array, as rounds 1-3 had it)
     void *arena = nullptr;
     size_t arena_bytes = 0;
+    // chunked launches (device_plan_chunks / device_spmv_chunk: the exchange of a row-partitioned
+    // matrix overlaps with the product): work in front of every row-block, its first row
+    std::vector<uint64_t> rb_upto;
+    std::vector<uint32_t> rb_row0;
+    std::vector<XcdSplit> chunk_split;
+    std::vector<uint32_t> chunk_longest;
 };
 
 int device_count()
@@ -1332,6 +1338,9 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
             const uint64_t end = i + 1 < n ? s.rbs[i + 1].val_off : (uint64_t) s.values.size();
             upto[i + 1] = upto[i] + (end > s.rbs[i].val_off ? end - s.rbs[i].val_off : 0) + 64u + 2u * s.rbs[i].n_rows;
         }
+        m->rb_upto = upto;
+        m->rb_row0.resize(n);
+        for (size_t i = 0; i < n; ++i) m->rb_row0[i] = s.rbs[i].row0;
         std::vector<size_t> starts(1, 0);
         for (size_t i = 1; i < n; ++i)
             if (s.rbs[i].flags & SPX_RB_PHASE_START) starts.push_back(i);
@@ -1628,6 +1637,70 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
         hipLaunchKernelGGL(csx_symfix_kernel, dim3((unsigned)((((m->nrows + 31) / 32) + 7) & ~(size_t) 7)), dim3(256),
                            0, stream, m->fix_ptr, m->fix_idx, m->spill, d_y, alpha,
                            (uint32_t) m->nrows);
+    HIP_CHECK(hipGetLastError());
+}
+
+// ---- the product in K launches over consecutive parts of the row-blocks ---------------------------
+// (general path, plain stream: one launch phase, no column slices, no rows split over row-blocks,
+// stream order = row order).  Returns the number of parts (0: this stream cannot be cut) and the
+// first row of every part (+ the end) in `row_bounds`.
+size_t device_plan_chunks(DeviceMatrix *m, size_t K, std::vector<size_t> &row_bounds)
+{
+    row_bounds.clear();
+    m->chunk_split.clear();
+    m->chunk_longest.clear();
+    const size_t n = m->n_rb;
+    if (m->symmetric || m->accum || m->n_shared || m->xcd_split.size() != 1 || !m->launch_order.empty() ||
+        m->wave_tiles || m->quad || n < 64 || K < 2 || m->rb_upto.size() != n + 1)
+        return 0;
+    for (size_t i = 1; i < n; ++i)
+        if (m->rb_row0[i] < m->rb_row0[i - 1]) return 0;
+    K = std::min<size_t>(K, n / 32);
+    std::vector<size_t> cut(K + 1, 0);
+    for (size_t k = 1; k < K; ++k) {
+        const uint64_t want = m->rb_upto[n] * k / K;
+        size_t i = (size_t)(std::lower_bound(m->rb_upto.begin(), m->rb_upto.end(), want) - m->rb_upto.begin());
+        cut[k] = std::min(std::max(i, cut[k - 1]), n);
+    }
+    cut[K] = n;
+    for (size_t k = 0; k < K; ++k) {
+        const size_t lo = cut[k], hi = cut[k + 1];
+        XcdSplit xs;
+        xs.first[0] = (uint32_t) lo;
+        for (uint32_t x = 1; x < 8; ++x) {
+            const uint64_t want = m->rb_upto[lo] + (m->rb_upto[hi] - m->rb_upto[lo]) * x / 8;
+            size_t i = (size_t)(std::lower_bound(m->rb_upto.begin() + lo, m->rb_upto.begin() + hi + 1, want) - m->rb_upto.begin());
+            xs.first[x] = (uint32_t) std::min(std::max<size_t>(i, xs.first[x - 1]), hi);
+        }
+        xs.first[8] = (uint32_t) hi;
+        uint32_t longest = 0;
+        for (uint32_t x = 0; x < 8; ++x) longest = std::max(longest, xs.first[x + 1] - xs.first[x]);
+        m->chunk_split.push_back(xs);
+        m->chunk_longest.push_back(longest);
+        row_bounds.push_back(lo < n ? (size_t) m->rb_row0[lo] : m->own_hi);
+    }
+    row_bounds[0] = m->own_lo;
+    row_bounds.push_back(m->own_hi);
+    return K;
+}
+
+void device_spmv_chunk(DeviceMatrix *m, size_t k, double alpha, const double *d_x, double beta, double *d_y, void *stream_)
+{
+    if (k >= m->chunk_split.size()) throw FatalError("no such part of the stream (device_plan_chunks)");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const XcdSplit xs = m->chunk_split[k];
+    const uint32_t blocks = 8u * m->chunk_longest[k];
+    if (!blocks) return;
+    const size_t lds = m->lds_doubles * sizeof(double);
+#define SPX_LAUNCH_CHUNK(W)                                                                                  \
+    hipLaunchKernelGGL(csx_spmv_kernel<W>, dim3(blocks), dim3(64 * W), lds, stream, m->rbs, m->passes, m->n_rb, \
+                       m->pass_stride, xs, m->values, m->descs, m->cidx, m->segrows, d_x, d_y, m->carry,        \
+                       (const double *) nullptr, (double *) nullptr, (const uint32_t *) nullptr, alpha, beta,  \
+                       (const double *) nullptr, 0.0)
+    if (m->waves == 2) SPX_LAUNCH_CHUNK(2);
+    else if (m->waves == 8) SPX_LAUNCH_CHUNK(8);
+    else SPX_LAUNCH_CHUNK(4);
+#undef SPX_LAUNCH_CHUNK
     HIP_CHECK(hipGetLastError());
 }
 

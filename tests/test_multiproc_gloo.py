@@ -146,6 +146,29 @@ def _slice_worker(rank, world, port, symmetric, gen, tmpdir, ret):
         dist.all_to_all_single(hr, hs, [int(v) for v in halo["recv_cnt"]], [int(v) for v in halo["send_cnt"]])
         y[halo["recv_cols"]] = hr.numpy()
         ok = ok and np.allclose(y[halo["recv_cols"]], (a @ x)[halo["recv_cols"]], rtol=1e-12, atol=1e-14)
+        # the overlapped step (SPX_DIST_OVERLAP): the same entries in rounds -- round r carries what
+        # lies in part r of the owner's rows (host-only matrices are cut into equal row parts); every
+        # entry travels exactly once, and after the last round the halo is what the one-shot exchange brought
+        rounds = A.dist_rounds()
+        if not symmetric:
+            assert len(rounds) == 4
+            y2 = y.copy()
+            y2[halo["recv_cols"]] = np.nan
+            sendbuf = y[halo["send_rows"]].copy()
+            recvbuf = np.full(int(halo["recv_cnt"].sum()), np.nan)
+            seen_s, seen_r = np.zeros(sendbuf.size, dtype=int), np.zeros(recvbuf.size, dtype=int)
+            for rd in rounds:
+                spos = np.concatenate([np.arange(o, o + c) for o, c in zip(rd["send_off"], rd["send_cnt"])]).astype(np.int64)
+                rpos = np.concatenate([np.arange(o, o + c) for o, c in zip(rd["recv_off"], rd["recv_cnt"])]).astype(np.int64)
+                seen_s[spos] += 1
+                seen_r[rpos] += 1
+                got = torch.empty(rpos.size, dtype=torch.float64)
+                dist.all_to_all_single(got, torch.from_numpy(sendbuf[spos].copy()), [int(v) for v in rd["recv_cnt"]],
+                                       [int(v) for v in rd["send_cnt"]])
+                recvbuf[rpos] = got.numpy()
+                y2[halo["recv_cols"][rpos]] = recvbuf[rpos]
+            assert np.all(seen_s == 1) and np.all(seen_r == 1)
+            ok = ok and np.array_equal(y2[halo["recv_cols"]], y[halo["recv_cols"]])
         # ... which is less than the slices of y handed round (general path: far less on a banded matrix)
         ret["halo%d" % rank] = (int(halo["recv_cols"].size), n - (hi - lo))
         # bytes that travel: the conflict entries, not n doubles

@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("mode", choices=["save", "time", "soak"])
+    ap.add_argument("mode", choices=["save", "time", "soak", "place"])
     ap.add_argument("file")
     ap.add_argument("--edge", type=int, default=240)
     ap.add_argument("--steps", type=int, default=40)
@@ -51,6 +51,35 @@ def main():
         A.save(args.file)
         print(json.dumps({"saved": args.file, "nnz": int(info.nnz), "waves": int(info.waves),
                           "tune_s": info.tune_seconds, "emit_s": info.emit_seconds}), flush=True)
+        return
+
+    if args.mode == "place":
+        # the same stream uploaded again and again inside ONE process, with allocations of other sizes
+        # kept in between, so that every upload lands on other physical pages: does the level move?
+        keep = []
+        n = None
+        for i, hold_mb in enumerate([0, 64, 1024, 3, 4096, 200, 16384, 1]):
+            if hold_mb:
+                keep.append(torch.empty(hold_mb << 17, dtype=torch.float64, device="cuda"))
+            A = sx.mat_restore(args.file)
+            if n is None:
+                n = A.nrows
+                x = torch.from_numpy(synth.random_x(n)).cuda()
+                y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+            st = torch.cuda.current_stream().cuda_stream
+            for _ in range(5):
+                A.hip_matvec_mult(bench.ALPHA, x.data_ptr(), y.data_ptr(), st)
+            ts = []
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.steps):
+                    A.hip_matvec_mult(bench.ALPHA, x.data_ptr(), y.data_ptr(), st)
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(round(1e3 * e0.elapsed_time(e1) / args.steps, 2))
+            print("PLACE upload %d after holding %d MB more: %s us" % (i, hold_mb, ts), flush=True)
+            A.destroy()
         return
 
     t0 = time.perf_counter()
