@@ -45,10 +45,6 @@
  *   spx.gpu.inline_desc     "false": unit passes whose lanes share one descriptor load it like any other
  *                           (default: it travels in the pass header, SPX_PASSF_INLINE: one dependent round trip
  *                           per pass instead of two; 4-5 % on the KKT stand-in)
- *   spx.gpu.quad            general path, four narrow unit passes (width <= 3) side by side per wavefront
- *                           (csx_spmv_quad_kernel: 78 VGPRs, six wavefronts per SIMD): "true", "auto" (spx_mat_tune()
- *                           measures it against the plain kernel) or "false" (default: it never measured faster,
- *                           profiles/r03/ablation.md section 10)
  *   spx.gpu.keep_units      "false": ... even those none of whose nonzeros has a neighbour along
  *                           its row (default: such a unit stays one descriptor -- the main diagonal
  *                           of a KKT system -- instead of a leftover nonzero per row)
@@ -332,7 +328,7 @@ typedef struct {
     int32_t sym_segments;    /* the stream holds row segments of the lower triangle
                                 that are read once and used twice (SPX_PASS_SYMSEG):
                                 1 = next to dense tiles, 2 = and no tiles           */
-    int32_t quad;            /* general path: the kernel variant with four narrow unit
+    int32_t quad;            /* reserved (0): round 3's kernel variant with four narrow unit
                                 passes side by side per wavefront is in use          */
     int32_t col_slices;      /* general path, spx.gpu.col_phases: K > 1 column slices in one
                                 launch (a group of XCDs each), -K: launched in turn, else 1 */

@@ -513,7 +513,6 @@ static void emit_and_upload(spx_matrix_t *A)
     gs.waves = (uint32_t) A->waves;
     gs.band_order = Config::instance().get_bool("spx.gpu.band_order");
     gs.arena = Config::instance().get_bool("spx.gpu.arena");
-    gs.quad = A->quad == 1;
     gs.sym_atomic = A->sym_atomic && !A->deterministic;
     gs.deterministic = A->deterministic;
     gs.wave_tiles = A->deterministic || A->wave_tiles == 1;
@@ -794,6 +793,7 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     A->emit_params.recut_linear = cfg.get_bool("spx.gpu.recut_linear");
     A->emit_params.keep_units = cfg.get_bool("spx.gpu.keep_units");
     A->emit_params.inline_desc = cfg.get_bool("spx.gpu.inline_desc");
+    A->emit_params.pair_x = cfg.get_bool("spx.gpu.pair_x");
     A->emit_params.x_window = cfg.get_bool("spx.gpu.x_window");
     {
         const std::string m = cfg.get_str("spx.gpu.sym_segments");
@@ -840,12 +840,6 @@ static spx_matrix_t *do_tune(spx_input_t *in)
         throw FatalError("bad spx.gpu.wave_tiles");
     }
     A->wave_tiles = wt_mode == "true" ? 1 : 0;          // (auto: off until measured)
-    const std::string quad_mode = cfg.get_str("spx.gpu.quad");
-    if (quad_mode != "auto" && quad_mode != "true" && quad_mode != "false") {
-        log_msg(LOG_ERR, "spx.gpu.quad: true, false or auto\n");
-        throw FatalError("bad spx.gpu.quad");
-    }
-    A->quad = quad_mode == "true" ? 1 : (quad_mode == "false" ? 0 : -1);
     const std::string ph_mode = cfg.get_str("spx.gpu.col_phases");
     const bool ph_conc = ph_mode.size() == 2 && ph_mode[0] == 'c';
     long ph_fixed = ph_mode == "auto" ? 0 : strtol(ph_mode.c_str() + (ph_conc ? 1 : 0), nullptr, 10);
@@ -867,21 +861,6 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     const bool tune_wt = wt_mode == "auto" && !A->deterministic && !A->has_symsegs;
     if (A->dev && A->nnz_stored >= 100000 && (autotune || tune_spill || tune_wt))
         autotune_launch(A.get(), autotune, tune_spill, tune_wt);
-    // four narrow unit passes side by side (general path): more in flight per wavefront against
-    // six instead of eight wavefronts per SIMD -- measured
-    if (A->dev && !sym && A->quad < 0 && A->nnz_stored >= 100000 && !device_get_wave_tiles(A->dev)) {
-        auto best_of = [&]() {
-            double best = device_time_spmv(A->dev, 10, 100);
-            for (int rep = 0; rep < 3; ++rep) best = std::min(best, device_time_spmv(A->dev, 0, 100));
-            return best;
-        };
-        const double t_plain = best_of();
-        device_set_quad(A->dev, true);
-        const double t_quad = device_get_quad(A->dev) ? best_of() : 2.0 * t_plain;
-        A->quad = t_quad < 0.985 * t_plain ? 1 : 0;
-        device_set_quad(A->dev, A->quad == 1);
-        log_msg(LOG_INFO, "quad passes: %.2f us, pairs %.2f us per SpMV\n", 1e6 * t_quad, 1e6 * t_plain);
-    }
     // column phases (auto): where the leftovers dominate and x is far larger than the L2 of an
     // XCD, the gathers miss it more often than not (syn-webbase: 1.6 M line fills for 2.5 M
     // gathers); slices of the columns that fit are measured against the plain stream
@@ -1390,7 +1369,7 @@ spx_error_t spx_mat_save(const spx_matrix_t *A, const char *filename)
     h.waves = gs->waves;
     h.n_encoded = (uint32_t) A->parts.size();
     h.sym_atomic = gs->sym_atomic ? 1u : 0u;
-    h.pad3 = (gs->deterministic ? 1u : 0u) | (gs->wave_tiles ? 2u : 0u) | (gs->quad ? 4u : 0u);
+    h.pad3 = (gs->deterministic ? 1u : 0u) | (gs->wave_tiles ? 2u : 0u);
     h.checksum = stream_checksum(*gs);
     bool good = fwrite(kMagic, 1, 8, f) == 8 && fwrite(&h, sizeof(h), 1, f) == 1;
     std::vector<int32_t> bnd;
@@ -1479,7 +1458,6 @@ spx_matrix_t *spx_mat_restore(const char *filename)
         gs->sym_atomic = h.sym_atomic != 0;
         gs->deterministic = (h.pad3 & 1u) != 0;
         gs->wave_tiles = (h.pad3 & 2u) != 0;
-        gs->quad = (h.pad3 & 4u) != 0;
         gs->nnz_stored = h.nnz_stored; gs->n_unit_elems = h.n_unit_elems;
         gs->n_delta_elems = h.n_delta_elems; gs->n_units = h.n_units;
         good = stream_checksum(*gs) == h.checksum;
@@ -1515,7 +1493,6 @@ spx_matrix_t *spx_mat_restore(const char *filename)
     A->sym_atomic = gs->sym_atomic;
     A->deterministic = gs->deterministic;
     A->wave_tiles = gs->wave_tiles ? 1 : 0;
-    A->quad = gs->quad ? 1 : 0;
     A->tune_seconds = 0.0;
     A->auto_rb = false;
     const double t0 = now_sec();
@@ -1877,7 +1854,7 @@ spx_error_t spx_hip_mat_info(const spx_matrix_t *A, spx_hip_info_t *info)
     info->wave_tiles = A->dev ? (device_get_wave_tiles(A->dev) ? 1 : 0) : (A->wave_tiles == 1 || A->deterministic ? 1 : 0);
     info->sym_segments = A->has_symsegs ? (A->has_symtiles ? 1 : 2) : 0;
     info->col_slices = A->col_phases > 1 ? (A->col_concurrent ? (int32_t) A->col_phases : -(int32_t) A->col_phases) : 1;
-    info->quad = A->dev ? (device_get_quad(A->dev) ? 1 : 0) : (A->quad == 1 ? 1 : 0);
+    info->quad = 0;                  // (reserved: the four-pass kernel variant of round 3 is gone)
     info->tune_seconds = A->tune_seconds;
     info->emit_seconds = A->emit_seconds;
     return SPX_SUCCESS;

@@ -50,7 +50,7 @@ void Config::reset_defaults()
     props_["spx.gpu.rowblock_rows"] = "512";   // max rows owned by one row-block
     props_["spx.gpu.stack_segments"] = "true"; // merge stacked row segments into block descriptors
     props_["spx.gpu.waves"] = "0";             // wavefronts per workgroup: 2, 4, 8; 0 = measured at tune time
-    props_["spx.gpu.quad"] = "false";          // general path: four narrow unit passes side by side per wavefront: true | false | auto (measured); never won: off
+    props_["spx.gpu.pair_x"] = "true";         // unit passes that read the same x next to each other: a wavefront loads x once for the pair
     props_["spx.gpu.inline_desc"] = "true";    // single-descriptor unit passes carry their descriptor in the pass header
     props_["spx.gpu.arena"] = "true";          // one HBM allocation for all arrays of a tuned matrix (false: one per array)
     props_["spx.gpu.band_order"] = "false";    // launch order: strips across the planes of a stencil (measured slower: off)

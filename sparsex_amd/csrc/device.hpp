@@ -77,10 +77,6 @@ void device_set_wave_tiles(DeviceMatrix *m, bool on);
 bool device_get_wave_tiles(const DeviceMatrix *m);
 bool device_has_tiles(const DeviceMatrix *m);
 
-// general path: the kernel variant that runs four narrow unit passes side by side per wavefront
-void device_set_quad(DeviceMatrix *m, bool on);
-bool device_get_quad(const DeviceMatrix *m);
-
 // wavefronts per workgroup of the SpMV kernel: 2, 4 or 8
 void device_set_waves(DeviceMatrix *m, int waves);
 int device_get_waves(const DeviceMatrix *m);

@@ -74,7 +74,6 @@ struct GpuStream {
     // finalize_stream() ran (0: packed, as the emitter appends them)
     uint32_t pass_stride = 0;
     uint32_t waves = 4;           // wavefronts per workgroup the kernel is launched with
-    bool quad = false;            // general path: launch csx_spmv_quad_kernel (spx.gpu.quad, measured at tune time)
     bool band_order = false;      // spx.gpu.band_order: launch order by strips across recurring bands of x (device side only)
     bool arena = true;            // spx.gpu.arena: all arrays of the stream in one HBM allocation (device side only)
     // accounting
@@ -110,6 +109,7 @@ struct GpuEmitParams {
     bool recut_linear = true;     // spx.gpu.recut_linear: nonzeros of vertical / diagonal /
                                   // strided units that line up along their rows run as row segments
     bool inline_desc = true;      // spx.gpu.inline_desc: SPX_PASSF_INLINE
+    bool pair_x = true;           // spx.gpu.pair_x: unit passes that read the same x are emitted next to each other
     bool keep_units = true;       // spx.gpu.keep_units: ... but a mined unit none of whose nonzeros has a
                                   // neighbour along its row stays the unit it is (one descriptor)
     bool sym_remine = true;       // spx.gpu.sym_remine (see append_sym_expanded)

@@ -64,7 +64,6 @@ struct matrix {
     bool auto_rb = false;
     double rb_scale = 1.0;      // chosen by the launch autotuner (multiplies the automatic row-block size)
     int waves = 4;              // wavefronts per workgroup of the SpMV kernel
-    int quad = -1;              // spx.gpu.quad: 1 / 0, -1 = measured at tune time
     size_t col_phases = 1;      // general path: column slices the stream is emitted in (spx.gpu.col_phases)
     bool col_concurrent = false;   // ... all of them in one launch, a group of XCDs each (SPX_RB_ACCUM)
     bool host_only = false;

@@ -74,16 +74,44 @@ struct XcdSplit {
 // measured at tune time: small matrices like 2, leftover-heavy ones 8)
 constexpr int MAX_WAVES_PER_BLOCK = 8;
 
-// Loads of the matrix stream (values, descriptors): plain loads.  (Marking them non-temporal, so that
-// they would not push x out of the L2, measured slower on every workload: profiles/r03/ablation.md
-// section 4.)
+// Loads of the matrix stream (values, descriptors).  Every byte of it is used once per product,
+// so marking them non-temporal (global_load ... nt: they should not push x out of the L2) looked
+// right -- the PMC passes show x coming from the fabric ~4.5 times per product on the bench
+// matrix -- and measured wrong (profiles/r03/ablation.md section 4): the bench matrix 3 % slower,
+// and the matrices that live in the Infinity Cache (cant, nd24k, webbase) 3-9 % slower, because
+// across the launches of a solver loop their VALUES are what the caches serve.  SPX_STREAM_NT
+// builds the non-temporal variant for comparison.
 typedef double spx_d2_t __attribute__((ext_vector_type(2)));
 // two doubles at any 8-byte aligned address as ONE load (global_load_dwordx4 needs no 16-byte
 // alignment on gfx9): the x of a row segment comes in pairs wherever its first column lies
 typedef double spx_d2u_t __attribute__((ext_vector_type(2), aligned(8)));
-__device__ __forceinline__ double2 ld_stream(const double2 *p) { return *p; }
-__device__ __forceinline__ double ld_stream(const double *p) { return *p; }
-__device__ __forceinline__ uint2 ld_stream(const uint2 *p) { return *p; }
+typedef unsigned int spx_u2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 ld_stream(const double2 *p)
+{
+#ifndef SPX_STREAM_NT
+    return *p;
+#else
+    const spx_d2_t v = __builtin_nontemporal_load(reinterpret_cast<const spx_d2_t *>(p));
+    return make_double2(v.x, v.y);
+#endif
+}
+__device__ __forceinline__ double ld_stream(const double *p)
+{
+#ifndef SPX_STREAM_NT
+    return *p;
+#else
+    return __builtin_nontemporal_load(p);
+#endif
+}
+__device__ __forceinline__ uint2 ld_stream(const uint2 *p)
+{
+#ifndef SPX_STREAM_NT
+    return *p;
+#else
+    const spx_u2_t v = __builtin_nontemporal_load(reinterpret_cast<const spx_u2_t *>(p));
+    return make_uint2(v.x, v.y);
+#endif
+}
 
 // set bits of `mask` in lanes 1..lane (bit 0 is never set by the emitter)
 __device__ __forceinline__ uint32_t starts_upto(uint64_t mask, int lane)
@@ -91,6 +119,14 @@ __device__ __forceinline__ uint32_t starts_upto(uint64_t mask, int lane)
     const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                                      __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
     return below + (uint32_t)((mask >> lane) & 1ull);
+}
+
+// lane l <- lane l + 1 across the whole wavefront (DPP wave_shl:1; lane 63 gets 0)
+__device__ __forceinline__ double wave_shl1(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
 }
 
 // B unit passes of the same width at once: lane l owns one row segment of W
@@ -140,11 +176,13 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
                     goff[b][w] = reinterpret_cast<const uint16_t *>(cidx)[e0 + (uint32_t) w * nseg[b]];
             }
         } else {
+#ifndef SPX_NO_INLINE_DESC
             if (ps[b].flags & SPX_PASSF_INLINE) {
                 // the pass' only descriptor came with its header (wave-uniform, in SGPRs)
                 q[b].x = (uint32_t) ps[b].mask;
                 q[b].y = (uint32_t) (ps[b].mask >> 32);
             } else
+#endif
             {
                 const uint64_t mk = (ps[b].flags & SPX_PASSF_INLINE) ? 0ull : ps[b].mask;
                 const uint32_t rank = (uint32_t) ps[b].rank0 + (active[b] ? starts_upto(mk, lane) : 0u);
@@ -162,24 +200,25 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
             v2[b][p] = ld_stream(reinterpret_cast<const double2 *>(vals + (uint32_t) p * 2u * nseg[b] + l[b] * 2u));
         if (W & 1) v1[b] = ld_stream(vals + (uint32_t) (W / 2) * 2u * nseg[b] + l[b]);
     }
+#ifdef SPX_ABL_VALSONLY
+    {
+        double t = 0.0;
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+#pragma unroll
+            for (int p = 0; p < W / 2; ++p) t += v2[b][p].x + v2[b][p].y;
+            if (W & 1) t += v1[b];
+            t += (double) q[b].x;
+        }
+        if (t == 1.2345) tile[0] = t;
+        return;
+    }
+#endif
     int row[B];
     double acc[B];
-    // SHARE: the two passes read the same x -- both carry ONE descriptor in their headers (wave-
-    // uniform: the comparison is scalar), these agree in first column, kind and step, and lane l
-    // is the same segment of its stack in both (rows differ: neighbouring grid lines of a stencil
-    // read the same line of x; the emitter puts such passes next to each other,
-    // RbBuilder::emit_unit_passes).  x is loaded once for the pair.
-    bool share = false;
-    if (B == 2 && G == 0) {
-        const uint32_t b0 = (uint32_t) (ps[0].mask >> 32), b1 = (uint32_t) (ps[B - 1].mask >> 32);
-        share = (ps[0].flags & ps[B - 1].flags & SPX_PASSF_INLINE) != 0 && nseg[0] == nseg[B - 1] &&
-                (uint32_t) ps[0].mask == (uint32_t) ps[B - 1].mask && (b0 >> 22) == (b1 >> 22) &&
-                (((uint32_t) ps[0].seg0 - ((b0 >> 9) & 8191u)) & 0xffffu) ==
-                    (((uint32_t) ps[B - 1].seg0 - ((b1 >> 9) & 8191u)) & 0xffffu);
-    }
-    double x[B][W];
 #pragma unroll
     for (int b = 0; b < B; ++b) {
+        double x[W];
         if (G == 2) {
             // (a piece shorter than the pass is padded: nothing is multiplied there)
             row[b] = (int) SPX_SEGROW_ROW(q[b].x);
@@ -187,7 +226,7 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
 #pragma unroll
             for (int w = 0; w < W; ++w) {
                 const double xv = win[goff[b][w]];
-                x[b][w] = w < len ? xv : 0.0;
+                x[w] = w < len ? xv : 0.0;
             }
         } else if (G) {
             row[b] = (int) SPX_SEGROW_ROW(q[b].x);
@@ -195,8 +234,12 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
             const double *xp = a.x + rb.cbase;
 #pragma unroll
             for (int w = 0; w < W; ++w) {
+#ifdef SPX_ABL_NOX
+                x[w] = (double) goff[b][w];
+#else
                 const double xv = xp[goff[b][w]];
-                x[b][w] = w < len ? xv : 0.0;
+                x[w] = w < len ? xv : 0.0;
+#endif
             }
         } else {
             // segment index inside its unit, then its row / first column
@@ -208,38 +251,91 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
             const int dcol = (kind == SPX_KIND_HORIZ || kind == SPX_KIND_DIAG)
                                  ? step : (kind == SPX_KIND_ADIAG ? -step : 0);
             row[b] = (int) (ps[b].elem0 + (bits & 511u)) + s * drow;
+#ifdef SPX_ABL_XSMALL
+            // (ablation: the same x loads, all of them out of 8 KB of x -- L1 / L2 hits)
+            const uint32_t col = (q[b].x + (uint32_t) (s * dcol)) & 1023u;
+#else
             const uint32_t col = q[b].x + (uint32_t) (s * dcol);
+#endif
             const double *xp = a.x + col;
-            // The x loads cost address-unit issue slots like the value loads do: they come in pairs
-            // at any alignment, W / 2 + (W & 1) load instructions instead of W.  (One full-width load
-            // per diagonal stack with the other W - 1 columns taken from the neighbouring lanes by
-            // DPP shifts was built and measured slower: profiles/r03/ablation.md section 6.)
-            if (b > 0 && share) {
+#ifdef SPX_ABL_NOX
 #pragma unroll
-                for (int w = 0; w < W; ++w) x[b][w] = x[0][w];
+            for (int w = 0; w < W; ++w) x[w] = (double) col;
+#else
+            // The x loads cost address-unit issue slots like the value loads do: where
+            // every segment of the pass starts on an even column (and x is 16-byte
+            // aligned) they come as 16-byte loads, half as many instructions
+            // (measured on the symmetric tile pass: 9 -> 5 loads, 29.1 -> 26.6 us).
+            // A pass whose lanes are consecutive segments of ONE diagonal stack (a stencil: lane l
+            // holds row r + l, columns c + l ... c + l + W - 1) reads x[c ... c + nseg + W - 2]: each
+            // lane could load its first element only and take the others from the lanes to its
+            // right (DPP wave shift), one full-width load instead of W.  Built (-DSPX_CHAIN_X) and
+            // measured slower on every workload (profiles/r03/ablation.md section 6: the x loads of
+            // neighbouring lanes hit the same L1 lines anyway, the shifts and the masked tail loads
+            // are extra work); not enabled.
+#ifdef SPX_CHAIN_X
+            const uint32_t bits0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) bits);
+            const bool chain = W >= 2 && W <= 4 && (ps[b].mask == 0ull || (ps[b].flags & SPX_PASSF_INLINE)) && nseg[b] >= (uint32_t) W &&
+                               ((bits0 >> 22) & 7u) == SPX_KIND_DIAG && (bits0 >> 25) == 1u;
+#else
+            const bool chain = false;
+#endif
+            if (chain) {
+                const uint32_t n = nseg[b];
+                const double xa = xp[0];
+                double xt[W];
+                const bool tail = (uint32_t) lane + (uint32_t) (W - 1) >= n && (uint32_t) lane < n;
+#pragma unroll
+                for (int w = 1; w < W; ++w) xt[w] = tail ? xp[w] : 0.0;
+                x[0] = xa;
+                double sh = xa;
+#pragma unroll
+                for (int w = 1; w < W; ++w) {
+                    sh = wave_shl1(sh);
+                    x[w] = ((uint32_t) lane + (uint32_t) w < n) ? sh : xt[w];
+                }
+#ifndef SPX_X_PAIRS_ALIGNED_ONLY
             } else if (W >= 2) {
+                // (pairs at any alignment: W / 2 + (W & 1) load instructions instead of W)
                 const spx_d2u_t *xp2 = reinterpret_cast<const spx_d2u_t *>(xp);
 #pragma unroll
                 for (int p = 0; p < W / 2; ++p) {
                     const spx_d2u_t xx = xp2[p];
-                    x[b][2 * p] = xx.x;
-                    x[b][2 * p + 1] = xx.y;
+                    x[2 * p] = xx.x;
+                    x[2 * p + 1] = xx.y;
                 }
-                if (W & 1) x[b][W - 1] = xp[W - 1];
+                if (W & 1) x[W - 1] = xp[W - 1];
+#else
+            } else if (W >= 2 && (reinterpret_cast<uintptr_t>(a.x) & 15u) == 0 && __all((col & 1u) == 0u)) {
+                const double2 *xp2 = reinterpret_cast<const double2 *>(xp);
+#pragma unroll
+                for (int p = 0; p < W / 2; ++p) {
+                    const double2 xx = xp2[p];
+                    x[2 * p] = xx.x;
+                    x[2 * p + 1] = xx.y;
+                }
+                if (W & 1) x[W - 1] = xp[W - 1];
+#endif
             } else {
 #pragma unroll
-                for (int w = 0; w < W; ++w) x[b][w] = xp[w];
+                for (int w = 0; w < W; ++w) x[w] = xp[w];
             }
+#endif
         }
         double t = 0.0;
 #pragma unroll
         for (int p = 0; p < W / 2; ++p) {
-            t = fma(v2[b][p].x, x[b][2 * p], t);
-            t = fma(v2[b][p].y, x[b][2 * p + 1], t);
+            t = fma(v2[b][p].x, x[2 * p], t);
+            t = fma(v2[b][p].y, x[2 * p + 1], t);
         }
-        if (W & 1) t = fma(v1[b], x[b][W - 1], t);
+        if (W & 1) t = fma(v1[b], x[W - 1], t);
         acc[b] = t;
     }
+#ifdef SPX_ABL_NOATOMIC
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+        if (active[b] && acc[b] == 1.2345) tile[row[b]] = acc[b];
+#else
     if (G == 1 && rb.n_rows == 1) {
         // a chunk of one over-long row: every lane targets tile[0]
         double t = 0.0;
@@ -253,6 +349,7 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
 #pragma unroll
     for (int b = 0; b < B; ++b)
         if (active[b]) atomicAdd(&tile[row[b]], acc[b]);
+#endif
 }
 
 template <int B, int G>
@@ -280,6 +377,18 @@ __device__ __forceinline__ void run_units(const KernelArgs &a, const SpxRowBlock
     }
 }
 
+// four unit passes of the same narrow width side by side (general kernels): with three values per
+// lane a pair of passes keeps too little in flight per wavefront
+__device__ __forceinline__ void run_units4(const KernelArgs &a, const SpxRowBlock &rb,
+                                           const SpxPass (&ps)[4], double *tile, const double *win, int lane)
+{
+    switch (ps[0].width) {         // wave-uniform
+    case 1: unit_passes<1, 4, 0>(a, rb, ps, tile, win, lane); break;
+    case 2: unit_passes<2, 4, 0>(a, rb, ps, tile, win, lane); break;
+    default: unit_passes<3, 4, 0>(a, rb, ps, tile, win, lane); break;
+    }
+}
+
 // lane ^ 1, ^ 2, ^ 4 inside groups of eight lanes as DPP moves (VALU) instead of
 // ds_bpermute (__shfl_xor goes through the LDS crossbar): quad_perm for 1 and 2,
 // row_half_mirror followed by a reversed quad for 4 (lane i <- 7-i <- (7-i)^3 = i^4).
@@ -292,15 +401,27 @@ __device__ __forceinline__ double dpp_mov_f64(double v)
 }
 __device__ __forceinline__ double xchg1(double v)
 {
+#ifdef SPX_SYM_BPERMUTE
+    return __shfl_xor(v, 1);
+#else
     return dpp_mov_f64<0xB1>(v);                       // quad_perm [1,0,3,2]
+#endif
 }
 __device__ __forceinline__ double xchg2(double v)
 {
+#ifdef SPX_SYM_BPERMUTE
+    return __shfl_xor(v, 2);
+#else
     return dpp_mov_f64<0x4E>(v);                       // quad_perm [2,3,0,1]
+#endif
 }
 __device__ __forceinline__ double xchg4(double v)
 {
+#ifdef SPX_SYM_BPERMUTE
+    return __shfl_xor(v, 4);
+#else
     return dpp_mov_f64<0x1B>(dpp_mov_f64<0x141>(v));   // row_half_mirror, then quad_perm [3,2,1,0]
+#endif
 }
 
 // A pass of symmetric tiles (SPX_PASS_SYMTILE): lanes 8t..8t+7 hold the rows of
@@ -327,6 +448,16 @@ __device__ __forceinline__ void symtile_pass(const KernelArgs &a, const SpxRowBl
     const int i = (int) (l & 7u);
     const int row = (int) (ps.elem0 + (q.y & 511u)) + i;
     const uint32_t slot = q.y >> 9;
+#ifdef SPX_ABL_SYM_VALSONLY
+    {
+        // (ablation: the stream of the pass alone -- descriptor and values)
+        double t = (double) q.x;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) t += v2[p].x + v2[p].y;
+        if (t == 1.2345) tile[0] = t;
+        return;
+    }
+#endif
     const double xr = a.x[rb.row0 + (uint32_t) row];
     const double *xp = a.x + q.x;
     double v[8], t = 0.0, p8[8];
@@ -355,6 +486,11 @@ __device__ __forceinline__ void symtile_pass(const KernelArgs &a, const SpxRowBl
         t = fma(v[w], xc[w], t);
         p8[w] = active ? v[w] * xr : 0.0;
     }
+#ifdef SPX_ABL_SYM_NOSHFL
+    double cs = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) cs += p8[w];
+#else
     // exchange with lane^4: lanes 0-3 collect columns 0-3, lanes 4-7 columns 4-7
     double p4[4];
     {
@@ -385,10 +521,15 @@ __device__ __forceinline__ void symtile_pass(const KernelArgs &a, const SpxRowBl
         const double keep = hi ? p2[1] : p2[0];
         cs = keep + xchg1(send);
     }
+#endif
+#ifdef SPX_ABL_SYM_NOATOMIC
+    if (active && t + cs == 1.2345) tile[row] = t;
+#else
     if (active) {
         atomicAdd(&tile[row], t);
         atomicAdd(&slots[slot + (uint32_t) i], cs);
     }
+#endif
 }
 
 // A pass of read-once row segments of a symmetric matrix (SPX_PASS_SYMSEG): a unit pass
@@ -413,12 +554,14 @@ __device__ __forceinline__ void symseg_passes(const KernelArgs &a, const SpxRowB
         nseg[b] = ps[b].nseg;
         active[b] = (uint32_t) lane < nseg[b];
         l[b] = active[b] ? (uint32_t) lane : 0u;
+#ifndef SPX_NO_INLINE_DESC
         if (ps[b].flags & SPX_PASSF_INLINE) {
             // (the pass' only descriptor came with its header; its slot entry is needed last)
             q[b].x = (uint32_t) ps[b].mask;
             q[b].y = (uint32_t) (ps[b].mask >> 32);
             slot0[b] = a.descs[rb.desc_off + (uint32_t) ps[b].rank0 + 1u].col0;
         } else
+#endif
         {
             const uint64_t mk = (ps[b].flags & SPX_PASSF_INLINE) ? 0ull : ps[b].mask;
             const uint32_t rank = (uint32_t) ps[b].rank0 + 2u * (active[b] ? starts_upto(mk, lane) : 0u);
@@ -438,6 +581,20 @@ __device__ __forceinline__ void symseg_passes(const KernelArgs &a, const SpxRowB
         }
         if (W & 1) v[b][W - 1] = ld_stream(vals + (uint32_t) (W / 2) * 2u * nseg[b] + l[b]);
     }
+#ifdef SPX_ABL_SEG_VALSONLY
+    {
+        // (ablation: the stream of the passes alone -- descriptors and values)
+        double t = 0.0;
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            t += (double) q[b].x + (double) slot0[b];
+#pragma unroll
+            for (int w = 0; w < W; ++w) t += v[b][w];
+        }
+        if (t == 1.2345) tile[0] = t;
+        return;
+    }
+#endif
     int row[B], sdc[B];
     uint32_t col[B];
     double xr[B], x[B][W];
@@ -453,10 +610,44 @@ __device__ __forceinline__ void symseg_passes(const KernelArgs &a, const SpxRowB
         sdc[b] = s * dcol;
         col[b] = q[b].x + (uint32_t) sdc[b];
         const double *xp = a.x + col[b];
+#ifdef SPX_ABL_SEG_NOX
+        xr[b] = (double) row[b];
+#else
         xr[b] = a.x[rb.row0 + (uint32_t) row[b]];
-        // (x in unaligned pairs, as the unit passes load it, measured 2.3 % slower here: one load per column)
+#endif
+        // (lanes that are consecutive segments of one diagonal stack: one full-width load of x,
+        // the rest from the neighbours -- see unit_passes)
+#ifdef SPX_CHAIN_X
+        const uint32_t bits0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) bits);
+        const bool chain = W <= 4 && (ps[b].mask == 0ull || (ps[b].flags & SPX_PASSF_INLINE)) && nseg[b] >= (uint32_t) W &&
+                           ((bits0 >> 22) & 7u) == SPX_KIND_DIAG && (bits0 >> 25) == 1u;
+#else
+        const bool chain = false;
+#endif
+        if (chain) {
+            const uint32_t n = nseg[b];
+            const double xa = xp[0];
+            double xt[W];
+            const bool tail = (uint32_t) lane + (uint32_t) (W - 1) >= n && (uint32_t) lane < n;
 #pragma unroll
-        for (int w = 0; w < W; ++w) x[b][w] = xp[w];
+            for (int w = 1; w < W; ++w) xt[w] = tail ? xp[w] : 0.0;
+            x[b][0] = xa;
+            double sh = xa;
+#pragma unroll
+            for (int w = 1; w < W; ++w) {
+                sh = wave_shl1(sh);
+                x[b][w] = ((uint32_t) lane + (uint32_t) w < n) ? sh : xt[w];
+            }
+        } else {
+#ifdef SPX_ABL_SEG_NOX
+#pragma unroll
+            for (int w = 0; w < W; ++w) x[b][w] = (double) col[b];
+#else
+            // (x in unaligned pairs, as the unit passes load it, measured 2.3 % slower here: one load per column)
+#pragma unroll
+            for (int w = 0; w < W; ++w) x[b][w] = xp[w];
+#endif
+        }
     }
 #pragma unroll
     for (int b = 0; b < B; ++b) {
@@ -467,8 +658,15 @@ __device__ __forceinline__ void symseg_passes(const KernelArgs &a, const SpxRowB
         atomicAdd(&tile[row[b]], t);
         if (slot0[b] != SPX_NO_SLOT) {
             double *sl = slots + slot0[b] + (uint32_t) sdc[b];
+#ifdef SPX_ABL_SEG_NOSLOTADD
+            double u = 0.0;
+#pragma unroll
+            for (int w = 0; w < W; ++w) u += v[b][w] * xr[b];
+            if (u == 1.2345) sl[0] = u;
+#else
 #pragma unroll
             for (int w = 0; w < W; ++w) atomicAdd(&sl[w], v[b][w] * xr[b]);
+#endif
         } else {
             double *yp = a.y + col[b];
 #pragma unroll
@@ -496,6 +694,9 @@ __device__ __forceinline__ void run_symseg(const KernelArgs &a, const SpxRowBloc
 __device__ __forceinline__ bool run_symseg2(const KernelArgs &a, const SpxRowBlock &rb, const SpxPass &p0,
                                             const SpxPass &p1, double *slots, double *tile, int lane)
 {
+#ifdef SPX_SYMSEG_SINGLE
+    return false;
+#else
     if (p0.width != p1.width || p0.width > 4) return false;
     switch (p0.width) {
     case 2: symseg_passes<2, 2>(a, rb, {p0, p1}, slots, tile, lane); break;
@@ -503,6 +704,7 @@ __device__ __forceinline__ bool run_symseg2(const KernelArgs &a, const SpxRowBlo
     default: symseg_passes<4, 2>(a, rb, {p0, p1}, slots, tile, lane); break;
     }
     return true;
+#endif
 }
 
 __device__ __forceinline__ void run_pass(const KernelArgs &a, const SpxRowBlock &rb,
@@ -528,11 +730,15 @@ __device__ __forceinline__ void run_pass(const KernelArgs &a, const SpxRowBlock 
 // own, and the copies are summed in wavefront order before the write-out -- the
 // only thing in this library whose order of additions is not fixed is the LDS adds
 // of different wavefronts of a workgroup into the shared tile.
-template <bool SYM, bool ATOMIC, int WAVES_PER_BLOCK, bool DET = false, bool SEGS = false, bool TILES = true>
+template <bool SYM, bool ATOMIC, int WAVES_PER_BLOCK, bool DET = false, bool SEGS = false, bool TILES = true,
+          bool QUAD = false>
 __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &xs,
                                           double *lds)
 {
     constexpr int BLOCK_THREADS = 64 * WAVES_PER_BLOCK;
+#ifdef SPX_ABL_EMPTY
+    if (a.alpha != 123.0) return;
+#endif
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // XCD-aware order: workgroup b runs on XCD b % 8 and takes that XCD's next row-block
@@ -544,14 +750,22 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &x
     if (rb_idx >= xs.first[deal ? 8u : xcd + 1u]) return;
 
     // the pass headers sit at a fixed stride, so the wave's first two are
-    // fetched together with the row-block header, not after it.  A wavefront takes the passes
-    // in ADJACENT pairs -- wave w: (2w, 2w + 1), then (2w + 2W, 2w + 2W + 1), ... -- whatever the
-    // workgroup's wavefront count: the emitter puts passes that read the same x next to each
-    // other (unit_passes: SHARE), and neighbours have the same width more often than not
+    // fetched together with the row-block header, not after it
     const SpxPass *passes = a.passes + (size_t) rb_idx * a.pass_stride;
     const SpxRowBlock rb = a.rbs[rb_idx];
-    SpxPass p0 = passes[2 * wave];
-    SpxPass p1 = passes[2 * wave + 1];                   // (the table is padded by one stride)
+    SpxPass p0 = passes[wave];
+    SpxPass p1 = passes[wave + WAVES_PER_BLOCK];         // (the table is padded by one stride)
+    // (the quad kernel keeps the pair after that in hand as well: four narrow unit passes run side by side)
+#ifdef SPX_PASS_PREFETCH
+    constexpr bool AHEAD = true;        // (experiment: every kernel keeps the next pair of pass headers in hand)
+#else
+    constexpr bool AHEAD = QUAD;
+#endif
+    SpxPass n0 = p0, n1 = p1;
+    if (AHEAD) {
+        n0 = passes[wave + 2 * WAVES_PER_BLOCK];
+        n1 = passes[wave + 3 * WAVES_PER_BLOCK];
+    }
     const int n_rows = rb.n_rows;
     const int n_slots = SYM ? (int) rb.n_slots : 0;
     const int core = n_slots + n_rows;                       // doubles per copy of slots + y tile
@@ -578,25 +792,46 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &x
     }
     __syncthreads();
 
-    // two passes at a time when they have the same shape (they mostly do: passes are sorted by
-    // width), so that their loads overlap
+    // wave w takes passes w, w+4, ..., two at a time when they have the same
+    // shape (they mostly do: passes are sorted by width), so that their loads
+    // overlap
     const int n_pass = rb.n_pass;
-    for (int t = 2 * wave; t < n_pass; t += 2 * WAVES_PER_BLOCK) {
-        const bool two = t + 1 < n_pass;
+#ifdef SPX_ABL_NOPASS
+    if (a.alpha == 123.0)
+#endif
+    for (int t = wave; t < n_pass; t += 2 * WAVES_PER_BLOCK) {
+        const bool two = t + WAVES_PER_BLOCK < n_pass;
+#ifndef SPX_NO_QUAD
+        if (QUAD && t + 3 * WAVES_PER_BLOCK < n_pass && p0.kind == SPX_PASS_UNIT && p0.width <= 3 &&
+            p1.kind == SPX_PASS_UNIT && n0.kind == SPX_PASS_UNIT && n1.kind == SPX_PASS_UNIT &&
+            p1.width == p0.width && n0.width == p0.width && n1.width == p0.width) {
+            run_units4(a, rb, {p0, p1, n0, n1}, tile, win, lane);
+            t += 2 * WAVES_PER_BLOCK;                   // (two more passes taken)
+            if (t + 2 * WAVES_PER_BLOCK < n_pass) {
+                p0 = passes[t + 2 * WAVES_PER_BLOCK];
+                p1 = passes[t + 3 * WAVES_PER_BLOCK];
+                n0 = passes[t + 4 * WAVES_PER_BLOCK];
+                n1 = passes[t + 5 * WAVES_PER_BLOCK];
+            }
+            continue;
+        }
+#endif
         if (SEGS && (p0.kind == SPX_PASS_SYMSEG || (two && p1.kind == SPX_PASS_SYMSEG))) {
             // read-once row segments (atomic hand-over only); whatever shares the round runs on its own
+            // (one at a time: two side by side, as the unit passes run, need 100 VGPRs instead of 62,
+            // four wavefronts per SIMD instead of eight; measured 0.84 -> 0.97 ms on syn-nlpkkt)
             if (two && p0.kind == SPX_PASS_SYMSEG && p1.kind == SPX_PASS_SYMSEG &&
                 run_symseg2(a, rb, p0, p1, mine, tile, lane)) {
                 // (both done)
             } else {
-                if (p0.kind == SPX_PASS_SYMSEG) run_symseg(a, rb, p0, mine, tile, lane);
-                else if (TILES && p0.kind == SPX_PASS_SYMTILE) symtile_pass(a, rb, p0, mine, tile, lane);
-                else run_pass(a, rb, p0, tile, win, lane);
-                if (two) {
-                    if (p1.kind == SPX_PASS_SYMSEG) run_symseg(a, rb, p1, mine, tile, lane);
-                    else if (TILES && p1.kind == SPX_PASS_SYMTILE) symtile_pass(a, rb, p1, mine, tile, lane);
-                    else run_pass(a, rb, p1, tile, win, lane);
-                }
+            if (p0.kind == SPX_PASS_SYMSEG) run_symseg(a, rb, p0, mine, tile, lane);
+            else if (TILES && p0.kind == SPX_PASS_SYMTILE) symtile_pass(a, rb, p0, mine, tile, lane);
+            else run_pass(a, rb, p0, tile, win, lane);
+            if (two) {
+                if (p1.kind == SPX_PASS_SYMSEG) run_symseg(a, rb, p1, mine, tile, lane);
+                else if (TILES && p1.kind == SPX_PASS_SYMTILE) symtile_pass(a, rb, p1, mine, tile, lane);
+                else run_pass(a, rb, p1, tile, win, lane);
+            }
             }
         } else if (SYM && TILES && p0.kind == SPX_PASS_SYMTILE) {
             symtile_pass(a, rb, p0, mine, tile, lane);
@@ -618,8 +853,15 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &x
             run_pass(a, rb, p0, tile, win, lane);
         }
         if (t + 2 * WAVES_PER_BLOCK < n_pass) {
-            p0 = passes[t + 2 * WAVES_PER_BLOCK];
-            p1 = passes[t + 2 * WAVES_PER_BLOCK + 1];
+            if (AHEAD) {
+                p0 = n0;
+                p1 = n1;
+                n0 = passes[t + 4 * WAVES_PER_BLOCK];
+                n1 = passes[t + 5 * WAVES_PER_BLOCK];
+            } else {
+                p0 = passes[t + 2 * WAVES_PER_BLOCK];
+                p1 = passes[t + 3 * WAVES_PER_BLOCK];
+            }
         }
     }
     __syncthreads();
@@ -652,8 +894,10 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &x
             for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS)
                 atomicAdd(&a.y[(size_t) rb.row0 + i], a.alpha * tile[i]);
         }
+#ifndef SPX_ABL_SEG_NOFLUSH
         for (int i = threadIdx.x; i < n_slots; i += BLOCK_THREADS)
             atomicAdd(&a.y[(size_t) gcol_lds[i >> 3] + (i & 7)], a.alpha * lds[i]);
+#endif
     } else {
         for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS) {
             const size_t g = (size_t) rb.row0 + i;
@@ -664,8 +908,10 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &x
             a.y[g] = t;
         }
     }
+#ifndef SPX_ABL_SYM_NOSPILL
     if (SYM && !ATOMIC)
         for (int i = threadIdx.x; i < n_slots; i += BLOCK_THREADS) a.spill[rb.spill_off + i] = lds[i];
+#endif
 }
 
 #define SPX_KERNEL_PARAMS                                                                        \
@@ -704,6 +950,18 @@ void csx_spmv_accum_kernel(SPX_KERNEL_PARAMS)
     SPX_KERNEL_ARGS(a);
     extern __shared__ double lds_dyn[];
     spmv_body<false, true, WAVES>(a, xcd_split, lds_dyn);
+}
+
+// the general kernel with four narrow unit passes (width <= 3) side by side per wavefront: 78
+// instead of 56 VGPRs (six wavefronts per SIMD instead of eight) for twice the loads in flight
+// per wavefront; spx_mat_tune measures it against the plain kernel (spx.gpu.quad)
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES)
+void csx_spmv_quad_kernel(SPX_KERNEL_PARAMS)
+{
+    SPX_KERNEL_ARGS(a);
+    extern __shared__ double lds_dyn[];
+    spmv_body<false, false, WAVES, false, false, true, true>(a, xcd_split, lds_dyn);
 }
 
 template <int WAVES>
@@ -885,6 +1143,7 @@ struct DeviceMatrix {
     std::vector<uint32_t> xcd_longest;
     // launch order (stream_band_order): device row-block i is row-block launch_order[i] of the
     // stream as the host holds it (empty: the same order); band_stride: the row distance found
+    bool quad = false;            // general path: csx_spmv_quad_kernel (measured at tune time)
     bool accum = false;           // SPX_RB_ACCUM: the column slices run in one launch and add to y
     std::vector<uint32_t> launch_order;
     size_t band_stride = 0;
@@ -910,17 +1169,6 @@ struct DeviceMatrix {
     std::vector<hipEvent_t> stage_events;       // one behind every piece of a staged download
     size_t value_bytes = 0, index_bytes = 0;
     size_t n_values = 0, n_descs = 0, n_passes = 0, n_cidx = 0, n_segrows = 0;
-    // every array of the stream lives in ONE allocation (2 MB-aligned pieces): one mapping, one
-    // run of physically contiguous fragments as far as the driver can give them
-    // (spx.gpu.arena=false / SPX_NO_ARENA: an allocation per array, as rounds 1-3 had it)
-    void *arena = nullptr;
-    size_t arena_bytes = 0;
-    // chunked launches (device_plan_chunks / device_spmv_chunk: the exchange of a row-partitioned
-    // matrix overlaps with the product): work in front of every row-block, its first row
-    std::vector<uint64_t> rb_upto;
-    std::vector<uint32_t> rb_row0;
-    std::vector<XcdSplit> chunk_split;
-    std::vector<uint32_t> chunk_longest;
 };
 
 int device_count()
@@ -930,57 +1178,18 @@ int device_count()
     return n;
 }
 
-// The arrays of a stream are placed together: device_upload() notes what goes where (`put`) and
-// `Placement::flush` allocates once, clears the lot and copies every array to its place.
-struct Placement {
-    struct Item { void **dst; const void *src; size_t copy_bytes, alloc_bytes; };
-    std::vector<Item> items;
-    template <typename T>
-    void put(T **dst, const std::vector<T> &v, size_t slack_elems = 0)
-    {
-        size_t bytes = (v.size() + slack_elems) * sizeof(T);
-        if (bytes == 0) bytes = sizeof(T);
-        items.push_back(Item{reinterpret_cast<void **>(dst), v.data(), v.size() * sizeof(T), bytes});
-    }
-    static size_t piece(size_t bytes)
-    {
-        const size_t a = bytes >= ((size_t) 1 << 20) ? ((size_t) 2 << 20) : 256u;
-        return (bytes + a - 1) / a * a;
-    }
-    void flush(DeviceMatrix *m, bool arena)
-    {
-        if (!arena) {
-            for (const Item &it : items) {
-                void *d = nullptr;
-                HIP_CHECK(hipMalloc(&d, it.alloc_bytes));
-                *it.dst = d;
-                HIP_CHECK(hipMemset(d, 0, it.alloc_bytes));
-                if (it.copy_bytes) HIP_CHECK(hipMemcpy(d, it.src, it.copy_bytes, hipMemcpyHostToDevice));
-            }
-            return;
-        }
-        // large arrays first, each on a 2 MB boundary; the small ones share the tail
-        size_t total = 0;
-        for (const Item &it : items) total += piece(it.alloc_bytes);
-        total = (total + ((size_t) 2 << 20) - 1) & ~(((size_t) 2 << 20) - 1);
-        void *base = nullptr;
-        HIP_CHECK(hipMalloc(&base, total));
-        m->arena = base;
-        m->arena_bytes = total;
-        HIP_CHECK(hipMemset(base, 0, total));
-        std::vector<size_t> order(items.size());
-        for (size_t i = 0; i < order.size(); ++i) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return items[a].alloc_bytes > items[b].alloc_bytes; });
-        size_t at = 0;
-        for (size_t i : order) {
-            const Item &it = items[i];
-            char *d = static_cast<char *>(base) + at;
-            *it.dst = d;
-            if (it.copy_bytes) HIP_CHECK(hipMemcpy(d, it.src, it.copy_bytes, hipMemcpyHostToDevice));
-            at += piece(it.alloc_bytes);
-        }
-    }
-};
+template <typename T>
+static T *upload(const std::vector<T> &v, size_t slack_elems = 0)
+{
+    size_t bytes = (v.size() + slack_elems) * sizeof(T);
+    if (bytes == 0) bytes = sizeof(T);
+    T *d = nullptr;
+    HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d), bytes));
+    HIP_CHECK(hipMemset(d, 0, bytes));
+    if (!v.empty())
+        HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return d;
+}
 
 DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
                             bool symmetric, idx_t own_lo, idx_t own_hi, int device)
@@ -1005,21 +1214,17 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
     m->n_rb = (uint32_t) s.rbs.size();
     m->n_shared = (uint32_t) s.shared.size();
     m->n_carry = s.n_carry;
-    Placement place;
-    const std::vector<double> no_doubles;                 // (cleared arrays: nothing to copy)
-    std::vector<double> dv;                               // host copies that must live until the flush
-    std::vector<SpxRowBlock> rbs_ordered;
-    std::vector<SpxPass> passes_ordered;
-    place.put(&m->values, s.values, 160);
-    place.put(&m->descs, s.descs, 8);
-    place.put(&m->cidx, s.cidx, 64);
-    place.put(&m->segrows, s.segrows, 80);
-    place.put(&m->shared, s.shared);
-    place.put(&m->carry, no_doubles, s.n_carry ? s.n_carry : 1);
+    m->values = upload(s.values, 160);
+    m->descs = upload(s.descs, 8);
+    m->cidx = upload(s.cidx, 64);
+    m->segrows = upload(s.segrows, 80);
+    m->shared = upload(s.shared);
+    std::vector<double> zero_carry(s.n_carry ? s.n_carry : 1, 0.0);
+    m->carry = upload(zero_carry);
     if (symmetric) {
-        dv = s.dvalues;
+        std::vector<double> dv = s.dvalues;
         dv.resize(nrows, 0.0);
-        place.put(&m->dvalues, dv);
+        m->dvalues = upload(dv);
     }
     m->n_spill = s.n_spill;
     m->lds_doubles = s.lds_doubles;
@@ -1035,21 +1240,22 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
             m->has_symtiles = s.passes[rb.pass_off + k].kind == SPX_PASS_SYMTILE;
     // (n_slots + n_rows <= 3584 doubles = 28 KB: within the default dynamic LDS limit)
     if (s.n_spill) {
-        place.put(&m->spill, no_doubles, s.n_spill);
-        place.put(&m->fix_ptr, s.fix_ptr);
-        place.put(&m->fix_idx, s.fix_idx);
+        std::vector<double> zero_spill(s.n_spill, 0.0);
+        m->spill = upload(zero_spill);
+        m->fix_ptr = upload(s.fix_ptr);
+        m->fix_idx = upload(s.fix_idx);
         m->n_fix_ptr = s.fix_ptr.size();
         m->n_fix_idx = s.fix_idx.size();
-        place.put(&m->slot_col, s.slot_group_col);
+        m->slot_col = upload(s.slot_group_col);
         m->n_slot_col = s.slot_group_col.size();
     }
     if (!s.mirror_rows.empty()) {
         m->n_mirror_rows = (uint32_t) s.mirror_rows.size();
         m->n_mirror_nnz = s.mirror_col.size();
-        place.put(&m->mirror_rows, s.mirror_rows);
-        place.put(&m->mirror_ptr, s.mirror_ptr);
-        place.put(&m->mirror_col, s.mirror_col);
-        place.put(&m->mirror_val, s.mirror_val);
+        m->mirror_rows = upload(s.mirror_rows);
+        m->mirror_ptr = upload(s.mirror_ptr);
+        m->mirror_col = upload(s.mirror_col);
+        m->mirror_val = upload(s.mirror_val);
     }
     m->sym_atomic = (s.sym_atomic || m->has_symsegs) && m->has_tiles;
     {
@@ -1079,9 +1285,6 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
             const uint64_t end = i + 1 < n ? s.rbs[i + 1].val_off : (uint64_t) s.values.size();
             upto[i + 1] = upto[i] + (end > s.rbs[i].val_off ? end - s.rbs[i].val_off : 0) + 64u + 2u * s.rbs[i].n_rows;
         }
-        m->rb_upto = upto;
-        m->rb_row0.resize(n);
-        for (size_t i = 0; i < n; ++i) m->rb_row0[i] = s.rbs[i].row0;
         std::vector<size_t> starts(1, 0);
         for (size_t i = 1; i < n; ++i)
             if (s.rbs[i].flags & SPX_RB_PHASE_START) starts.push_back(i);
@@ -1154,22 +1357,20 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
             if (!any) order.clear();
         }
         if (order.empty()) {
-            place.put(&m->rbs, s.rbs);
-            place.put(&m->passes, s.passes, (size_t) s.pass_stride + 6 * MAX_WAVES_PER_BLOCK);
+            m->rbs = upload(s.rbs);
+            m->passes = upload(s.passes, (size_t) s.pass_stride + 6 * MAX_WAVES_PER_BLOCK);
         } else {
             const size_t stride = s.pass_stride;
-            std::vector<SpxRowBlock> &rbs = rbs_ordered;
-            std::vector<SpxPass> &passes = passes_ordered;
-            rbs.resize(s.rbs.size());
-            passes.resize(s.passes.size());
+            std::vector<SpxRowBlock> rbs(s.rbs.size());
+            std::vector<SpxPass> passes(s.passes.size());
             for (size_t i = 0; i < order.size(); ++i) {
                 rbs[i] = s.rbs[order[i]];
                 rbs[i].pass_off = (uint32_t)(i * stride);
                 std::copy(s.passes.begin() + (size_t) order[i] * stride, s.passes.begin() + ((size_t) order[i] + 1) * stride,
                           passes.begin() + i * stride);
             }
-            place.put(&m->rbs, rbs);
-            place.put(&m->passes, passes, stride + 6 * MAX_WAVES_PER_BLOCK);
+            m->rbs = upload(rbs);
+            m->passes = upload(passes, stride + 6 * MAX_WAVES_PER_BLOCK);
             m->launch_order.swap(order);
         }
     }
@@ -1183,44 +1384,32 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
         (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&csx_spmv_symseg_notile_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&csx_spmv_symseg_notile_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     }
+    m->quad = s.quad && !symmetric && !m->accum;
     if (s.deterministic) device_set_deterministic(m, true);
     else if (s.wave_tiles) device_set_wave_tiles(m, true);
     m->n_values = s.values.size(); m->n_descs = s.descs.size(); m->n_passes = s.passes.size();
     m->n_cidx = s.cidx.size(); m->n_segrows = s.segrows.size();
     m->value_bytes = s.values.size() * sizeof(double);
     m->index_bytes = s.index_bytes();
-    try {
-        place.flush(m, s.arena && !getenv("SPX_NO_ARENA"));
-    } catch (...) {
-        device_free(m);
-        throw;
-    }
-    if (getenv("SPX_LOG_PLACEMENT"))
-        log_msg(LOG_ERR, "placement: arena %p (%zu MB) values %p descs %p passes %p rbs %p\n", m->arena, m->arena_bytes >> 20,
-                (void *) m->values, (void *) m->descs, (void *) m->passes, (void *) m->rbs);
     return m;
 }
 
 void device_free(DeviceMatrix *m)
 {
     if (!m) return;
-    if (m->arena) {
-        (void) hipFree(m->arena);
-    } else {
-        (void) hipFree(m->rbs); (void) hipFree(m->values); (void) hipFree(m->descs);
-        (void) hipFree(m->passes);
-        (void) hipFree(m->cidx); (void) hipFree(m->segrows); (void) hipFree(m->shared);
-        (void) hipFree(m->carry);
-        if (m->dvalues) (void) hipFree(m->dvalues);
-        if (m->spill) (void) hipFree(m->spill);
-        if (m->fix_ptr) (void) hipFree(m->fix_ptr);
-        if (m->fix_idx) (void) hipFree(m->fix_idx);
-        if (m->slot_col) (void) hipFree(m->slot_col);
-        if (m->mirror_rows) (void) hipFree(m->mirror_rows);
-        if (m->mirror_ptr) (void) hipFree(m->mirror_ptr);
-        if (m->mirror_col) (void) hipFree(m->mirror_col);
-        if (m->mirror_val) (void) hipFree(m->mirror_val);
-    }
+    (void) hipFree(m->rbs); (void) hipFree(m->values); (void) hipFree(m->descs);
+    (void) hipFree(m->passes);
+    (void) hipFree(m->cidx); (void) hipFree(m->segrows); (void) hipFree(m->shared);
+    (void) hipFree(m->carry);
+    if (m->dvalues) (void) hipFree(m->dvalues);
+    if (m->spill) (void) hipFree(m->spill);
+    if (m->fix_ptr) (void) hipFree(m->fix_ptr);
+    if (m->fix_idx) (void) hipFree(m->fix_idx);
+    if (m->slot_col) (void) hipFree(m->slot_col);
+    if (m->mirror_rows) (void) hipFree(m->mirror_rows);
+    if (m->mirror_ptr) (void) hipFree(m->mirror_ptr);
+    if (m->mirror_col) (void) hipFree(m->mirror_col);
+    if (m->mirror_val) (void) hipFree(m->mirror_val);
     if (m->d_x) (void) hipFree(m->d_x);
     if (m->d_y) (void) hipFree(m->d_y);
     if (m->p_x) (void) hipHostFree(m->p_x);
@@ -1354,6 +1543,11 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
             if (m->waves == 2) SPX_LAUNCH(csx_spmv_accum_kernel, 2, lds);
             else if (m->waves == 8) SPX_LAUNCH(csx_spmv_accum_kernel, 8, lds);
             else SPX_LAUNCH(csx_spmv_accum_kernel, 4, lds);
+        } else if (blocks && m->quad) {
+            const size_t lds = m->lds_doubles * sizeof(double);
+            if (m->waves == 2) SPX_LAUNCH(csx_spmv_quad_kernel, 2, lds);
+            else if (m->waves == 8) SPX_LAUNCH(csx_spmv_quad_kernel, 8, lds);
+            else SPX_LAUNCH(csx_spmv_quad_kernel, 4, lds);
         } else if (blocks) {
             const size_t lds = m->lds_doubles * sizeof(double);
             if (m->waves == 2) SPX_LAUNCH(csx_spmv_kernel, 2, lds);
@@ -1372,70 +1566,6 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
         hipLaunchKernelGGL(csx_symfix_kernel, dim3((unsigned)((((m->nrows + 31) / 32) + 7) & ~(size_t) 7)), dim3(256),
                            0, stream, m->fix_ptr, m->fix_idx, m->spill, d_y, alpha,
                            (uint32_t) m->nrows);
-    HIP_CHECK(hipGetLastError());
-}
-
-// ---- the product in K launches over consecutive parts of the row-blocks ---------------------------
-// (general path, plain stream: one launch phase, no column slices, no rows split over row-blocks,
-// stream order = row order).  Returns the number of parts (0: this stream cannot be cut) and the
-// first row of every part (+ the end) in `row_bounds`.
-size_t device_plan_chunks(DeviceMatrix *m, size_t K, std::vector<size_t> &row_bounds)
-{
-    row_bounds.clear();
-    m->chunk_split.clear();
-    m->chunk_longest.clear();
-    const size_t n = m->n_rb;
-    if (m->symmetric || m->accum || m->n_shared || m->xcd_split.size() != 1 || !m->launch_order.empty() ||
-        m->wave_tiles || n < 64 || K < 2 || m->rb_upto.size() != n + 1)
-        return 0;
-    for (size_t i = 1; i < n; ++i)
-        if (m->rb_row0[i] < m->rb_row0[i - 1]) return 0;
-    K = std::min<size_t>(K, n / 32);
-    std::vector<size_t> cut(K + 1, 0);
-    for (size_t k = 1; k < K; ++k) {
-        const uint64_t want = m->rb_upto[n] * k / K;
-        size_t i = (size_t)(std::lower_bound(m->rb_upto.begin(), m->rb_upto.end(), want) - m->rb_upto.begin());
-        cut[k] = std::min(std::max(i, cut[k - 1]), n);
-    }
-    cut[K] = n;
-    for (size_t k = 0; k < K; ++k) {
-        const size_t lo = cut[k], hi = cut[k + 1];
-        XcdSplit xs;
-        xs.first[0] = (uint32_t) lo;
-        for (uint32_t x = 1; x < 8; ++x) {
-            const uint64_t want = m->rb_upto[lo] + (m->rb_upto[hi] - m->rb_upto[lo]) * x / 8;
-            size_t i = (size_t)(std::lower_bound(m->rb_upto.begin() + lo, m->rb_upto.begin() + hi + 1, want) - m->rb_upto.begin());
-            xs.first[x] = (uint32_t) std::min(std::max<size_t>(i, xs.first[x - 1]), hi);
-        }
-        xs.first[8] = (uint32_t) hi;
-        uint32_t longest = 0;
-        for (uint32_t x = 0; x < 8; ++x) longest = std::max(longest, xs.first[x + 1] - xs.first[x]);
-        m->chunk_split.push_back(xs);
-        m->chunk_longest.push_back(longest);
-        row_bounds.push_back(lo < n ? (size_t) m->rb_row0[lo] : m->own_hi);
-    }
-    row_bounds[0] = m->own_lo;
-    row_bounds.push_back(m->own_hi);
-    return K;
-}
-
-void device_spmv_chunk(DeviceMatrix *m, size_t k, double alpha, const double *d_x, double beta, double *d_y, void *stream_)
-{
-    if (k >= m->chunk_split.size()) throw FatalError("no such part of the stream (device_plan_chunks)");
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const XcdSplit xs = m->chunk_split[k];
-    const uint32_t blocks = 8u * m->chunk_longest[k];
-    if (!blocks) return;
-    const size_t lds = m->lds_doubles * sizeof(double);
-#define SPX_LAUNCH_CHUNK(W)                                                                                  \
-    hipLaunchKernelGGL(csx_spmv_kernel<W>, dim3(blocks), dim3(64 * W), lds, stream, m->rbs, m->passes, m->n_rb, \
-                       m->pass_stride, xs, m->values, m->descs, m->cidx, m->segrows, d_x, d_y, m->carry,        \
-                       (const double *) nullptr, (double *) nullptr, (const uint32_t *) nullptr, alpha, beta,  \
-                       (const double *) nullptr, 0.0)
-    if (m->waves == 2) SPX_LAUNCH_CHUNK(2);
-    else if (m->waves == 8) SPX_LAUNCH_CHUNK(8);
-    else SPX_LAUNCH_CHUNK(4);
-#undef SPX_LAUNCH_CHUNK
     HIP_CHECK(hipGetLastError());
 }
 
@@ -1483,6 +1613,9 @@ void device_set_deterministic(DeviceMatrix *m, bool on)
 bool device_get_deterministic(const DeviceMatrix *m) { return m->deterministic; }
 bool device_get_sym_atomic(const DeviceMatrix *m) { return m->sym_atomic; }
 bool device_has_spill(const DeviceMatrix *m) { return m->has_tiles && m->n_spill; }
+
+void device_set_quad(DeviceMatrix *m, bool on) { m->quad = on && !m->symmetric && !m->accum && !m->wave_tiles; }
+bool device_get_quad(const DeviceMatrix *m) { return m->quad; }
 
 void device_set_waves(DeviceMatrix *m, int waves)
 {
@@ -1691,6 +1824,7 @@ void device_download(const DeviceMatrix *m, GpuStream &s)
     s.sym_atomic = m->sym_atomic;
     s.deterministic = m->deterministic;
     s.wave_tiles = m->wave_tiles;
+    s.quad = m->quad;
     if (m->n_spill) download(s.slot_group_col, m->slot_col, m->n_slot_col);
     if (m->n_spill) {
         download(s.fix_ptr, m->fix_ptr, m->n_fix_ptr);
