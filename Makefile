@@ -27,7 +27,7 @@ all: lib oracle
 lib: $(LIB) $(SYNLIB)
 
 # input generators of the nlpkkt stand-in and of syn-kkt2f (bench/test data only, no SpMV code)
-$(SYNLIB): tools/synth/nlpkkt_gen.c tools/synth/kkt2f_gen.c
+$(SYNLIB): tools/synth/nlpkkt_gen.c tools/synth/kkt2f_gen.c tools/synth/mm_write.c
 	@mkdir -p $(LIBDIR)
 	$(CC) -O3 -shared -fPIC -o $@ $^ -lm
 

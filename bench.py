@@ -500,11 +500,14 @@ def cpu_baseline(csr, symmetric, budget_s=20.0, sample=""):
     tried = {}
     t_start = time.perf_counter()
     share = budget_s / max(len(cands), 1)
+    first_part = None          # partition 0 of the smallest thread count tried: the T = 1 point
     for t in cands[::-1] if usable >= 64 else cands:
         # (many-core hosts: start at the larger counts, where the best has been)
         if tried and time.perf_counter() - t_start > budget_s:
             break
         ex = baseline_partitions(csr, t, symmetric)
+        if first_part is None or t < first_part[1]:
+            first_part = (dict(ex[0]), t)
         sec, kind, _ = _time_baseline(ex, csr, x, n, t, symmetric, loops=2, batches=1)
         loops = int(min(max(0.5 * share / max(sec, 1e-6) / 5, 2), 256))
         sec, kind, _ = _time_baseline(ex, csr, x, n, t, symmetric, loops=loops, batches=5)
@@ -514,8 +517,22 @@ def cpu_baseline(csr, symmetric, budget_s=20.0, sample=""):
         elif sec > 2.0 * best[0]:
             break       # well past the knee: further counts only burn the time budget
     sec, kind, t, loops = best
+    # T = 1: ONE pinned thread runs the reference's routine over the first of the
+    # partitions the matrix was tuned into for the smallest thread count above -- the single-thread rate of
+    # the same code on a part that lies beyond a core's caches, without tuning the sample a second time
+    # with one partition (minutes on one thread)
+    single = None
+    if first_part is not None and not symmetric:
+        e0, t_of = first_part
+        nnz0 = int(e0["nnz"])
+        s1, k1, _ = _time_baseline([e0], csr, x, n, 1, False, loops=2, batches=1)
+        l1 = int(min(max(4.0 / max(s1, 1e-6) / 5, 2), 128))
+        s1, k1, _ = _time_baseline([e0], csr, x, n, 1, False, loops=l1, batches=5)
+        single = {"value": round(2.0 * nnz0 / s1 / 1e9, 3), "unit": "GFLOP/s", "cores": 1, "kind": k1,
+                  "sample": "one pinned thread over partition 0 of %d of the sample (%d nonzeros, %.0f MB of values), "
+                            "median of 5 batches x %d SpMVs" % (t_of, nnz0, 8e-6 * nnz0, l1)}
     return {"value": round(2.0 * nnz / sec / 1e9, 3), "unit": "GFLOP/s", "cores": t,
-            "kind": kind,
+            "kind": kind, "single_thread": single,
             "sample": "%smedian of 5 batches x %d SpMVs (alpha=0.5), one partition per pinned thread, "
                       "threads spread over the %d socket%s (one per physical core first), every partition's arrays "
                       "first-touched on its worker's CPU, %s; thread counts tried (GFLOP/s): %s; host has %d "
@@ -815,7 +832,20 @@ def run_path(ctx, args, symmetric):
     for o in args.opt:
         k, v = o.split("=", 1)
         opts[k] = v
-    A = tune((wl.rp, wl.ci, wl.va, n), opts, nrows=hi - lo)
+    load_s = None
+    if wl.mtx and world == 1:
+        # the file goes through the library's own reader (spx_input_load_mmf: banner, mirror image of
+        # a symmetric file, row-major sort -- reference Mmf.hpp:331-478); scipy's copy above is the checker's
+        sx.options_reset()
+        for k, v in opts.items():
+            sx.option_set(k, str(v))
+        t0 = time.perf_counter()
+        inp = sx.input_load_mmf(wl.mtx)
+        load_s = time.perf_counter() - t0
+        A = sx.mat_tune(inp)
+        A._input = inp
+    else:
+        A = tune((wl.rp, wl.ci, wl.va, n), opts, nrows=hi - lo)
     info = A.info()
     assert (info.row_lo, info.row_hi) == (lo, hi)
 
@@ -920,6 +950,32 @@ def run_path(ctx, args, symmetric):
                         "stream_launches_ms_per_step": round(1e3 * wall2 / args.steps, 6)}
         if wall2 < wall:
             wall, devs, graphed, walls = wall2, devs2, False, walls2
+    # the reference bench's own call (src/bench/SparsexModule.cpp:54-71): y <- ALPHA*A*x + BETA*y on tuned
+    # vectors, timed the same way (one more read of y per product)
+    kernel_call = None
+    if world == 1:
+        BETA = 0.5
+        ref = None
+        if not ablation:
+            y.fill_(0.25)
+            A.hip_matvec_kernel(ALPHA, x.data_ptr(), BETA, y.data_ptr(), cur)
+            torch.cuda.synchronize()
+            ref = y.clone()
+            y.fill_(float("nan"))
+            step(cur)
+            torch.cuda.synchronize()
+            errk = float((ref - (y + BETA * 0.25)).abs().max())
+            assert errk <= 1e-12 * max(1.0, float(ref.abs().max())), "beta path differs from mult + beta*y: %g" % errk
+            y.fill_(0.0)
+
+        def step_kernel(stream):
+            A.hip_matvec_kernel(ALPHA, x.data_ptr(), BETA, y.data_ptr(), stream)
+        wk, dk, _, _ = time_batches(torch, step_kernel, args.steps, barrier, reduce_max, False)
+        kernel_call = {"call": "spx_hip_matvec_kernel(alpha=%.1f, A, x, beta=%.1f, y)" % (ALPHA, BETA),
+                       "ms_per_step": round(1e3 * wk / args.steps, 6), "gflops": round(2.0 * wl.nnz * args.steps / wk / 1e9, 2),
+                       "avg_launch_us": round(1e6 * dk / args.steps, 3),
+                       "reference": "src/bench/SparsexModule.cpp:54-71"}
+        del ref
     collective = None
     launch_s = devs / args.steps
     if world > 1:
@@ -995,7 +1051,10 @@ def run_path(ctx, args, symmetric):
                    "collective_in_value": ("included: every step ends with each rank holding its rows of y and the "
                                            "entries of the other ranks' rows that it reads as x"
                                            if world > 1 else "none needed"),
-                   "generate_seconds": round(t_gen, 2), "dist_reorder": wl.reorder,
+                   "generate_seconds": round(t_gen, 2),
+                   "mmf_load_seconds": round(load_s, 2) if load_s is not None else None,
+                   "input": ("spx_input_load_mmf(%s)" % os.path.basename(wl.mtx)) if load_s is not None else "spx_input_load_csr",
+                   "dist_reorder": wl.reorder,
                    "dist_reorder_seconds": round(wl.reorder_seconds, 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -1004,6 +1063,10 @@ def run_path(ctx, args, symmetric):
                      "kernel": kernel_name(info, symmetric, world),
                      "algorithmic_bytes_per_launch": int(b_alg),
                      "avg_launch_us": round(1e6 * launch_s, 3),
+                     # (the node's memory side has two speeds at identical reported clocks: profiles/r04/spread.md)
+                     "spread_group": (("fast (< 1.30 ms)" if launch_s < 1.30e-3 else "slow (>= 1.30 ms)")
+                                      if world == 1 and not symmetric and args.workload == "syn-nlpkkt" and args.edge == DEFAULT_EDGE
+                                      and not wl.mtx else None),
                      "cache_resident": bool(info.value_bytes + info.index_bytes < MALL_BYTES),
                      "scope": "rank 0's GPU: its stored values, x and its rows of y once per launch"
                               + (" (kernels only: timed without the exchange)" if world > 1 else "")},
@@ -1018,6 +1081,8 @@ def run_path(ctx, args, symmetric):
         "ranks": per_rank,
         "parity": parity,
     }
+    if kernel_call:
+        out["matvec_kernel"] = kernel_call
     if collective:
         out["collective"] = collective
     if world == 1 and not symmetric:
@@ -1050,6 +1115,9 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0,
                     help="host preprocessing partitions per GPU (default: min(cores / ranks, 32))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="time the CPU baseline on the whole bench matrix instead of its edge-%d sample (a minute or two "
+                         "more of host time and ~60 GB of host memory at edge 240)" % SAMPLE_EDGE)
     ap.add_argument("--no-configs", action="store_true",
                     help="N = 1: skip the other BASELINE configurations (cant, nd24k symmetric, webbase); "
                          "N > 1: skip the second run on the symmetric path")
@@ -1133,7 +1201,7 @@ def main():
     n = wl.n
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            if args.workload == "syn-nlpkkt" and not wl.mtx and args.edge > SAMPLE_EDGE:
+            if args.workload == "syn-nlpkkt" and not wl.mtx and args.edge > SAMPLE_EDGE and not args.cpu_baseline_full:
                 csr_s = synth.syn_nlpkkt_rows(SAMPLE_EDGE)
                 note = "sample: syn-nlpkkt at grid edge %d (%.1f M nonzeros, %.2f GB of values -- beyond the host's " \
                        "last-level caches; the bench matrix's generator at 1/%d of its nonzeros); " % (
@@ -1141,6 +1209,9 @@ def main():
             else:
                 csr_s = (wl.rp, wl.ci, wl.va, n)
                 note = "sample: the whole bench matrix; "
+            if args.workload == "syn-nlpkkt" and args.edge > SAMPLE_EDGE and not args.cpu_baseline_full:
+                note += "(the whole edge-%d matrix: --cpu-baseline-full; the default run keeps to the sample so that it " \
+                        "finishes within minutes) " % args.edge
             out["cpu_baseline"] = cpu_baseline(csr_s, args.symmetric, 30.0, note)
             del csr_s
         if world == 1 and not args.no_configs and args.workload == "syn-nlpkkt" and not args.mtx:

@@ -50,9 +50,8 @@ void Config::reset_defaults()
     props_["spx.gpu.rowblock_rows"] = "512";   // max rows owned by one row-block
     props_["spx.gpu.stack_segments"] = "true"; // merge stacked row segments into block descriptors
     props_["spx.gpu.waves"] = "0";             // wavefronts per workgroup: 2, 4, 8; 0 = measured at tune time
-    props_["spx.gpu.pair_x"] = "true";         // unit passes that read the same x next to each other: a wavefront loads x once for the pair
     props_["spx.gpu.inline_desc"] = "true";    // single-descriptor unit passes carry their descriptor in the pass header
-    props_["spx.gpu.arena"] = "true";          // one HBM allocation for all arrays of a tuned matrix (false: one per array)
+    props_["spx.gpu.arena"] = "false";         // true: one HBM allocation for all arrays of a tuned matrix (measured: no gain, profiles/r04/spread.md)
     props_["spx.gpu.band_order"] = "false";    // launch order: strips across the planes of a stencil (measured slower: off)
     props_["spx.gpu.col_phases"] = "auto";     // general path: column slices launched in turn: 1 (off), 2..8, auto (measured)
     props_["spx.gpu.keep_units"] = "true";     // re-cut: mined units without row neighbours stay units

@@ -127,56 +127,61 @@ void Encoder::remove_ignore(const XformSeq &seq)
 
 void Encoder::compute_sort_splits()
 {
-    // split by nonzeros: a window closes at the first row that brings it to
-    // at least sort_window_size_ elements
-    size_t nr_rows = spm_->rowptr_size() - 1;
-    size_t cnt = 0;
+    // One pass over the rows produces the sampling windows as (first row, end row, nonzeros): a
+    // window ends with the row that brings it to sort_window_size_ nonzeros.  What is left at the
+    // end joins the last window's count; it also extends that window to the last row unless it
+    // holds more than half a window of nonzeros -- then it stays a row range of its own (with a
+    // boundary, but without a count: the reference's vectors differ in length by two there).
+    // A matrix smaller than one window is a single window (the reference reads back() of an
+    // empty vector in that case).
+    struct Window { size_t first, end, nnz; };
+    std::vector<Window> win;
+    const size_t rows = spm_->rowptr_size() - 1;
+    Window cur{0, 0, 0};
+    for (size_t r = 0; r < rows; ++r) {
+        cur.nnz += (size_t)(spm_->rowptr[r + 1] - spm_->rowptr[r]);
+        if (cur.nnz >= sort_window_size_) {
+            cur.end = r + 1;
+            win.push_back(cur);
+            cur = Window{r + 1, 0, 0};
+        }
+    }
+    bool tail_range = false;
+    if (cur.nnz) {
+        if (win.empty()) {
+            win.push_back(Window{0, rows, cur.nnz});
+        } else {
+            win.back().nnz += cur.nnz;
+            if (cur.nnz > sort_window_size_ / 2) tail_range = true;
+            else win.back().end = rows;
+        }
+    }
     sort_splits_.push_back(0);
-    for (size_t i = 0; i < nr_rows; ++i) {
-        size_t ncnt = cnt + (size_t)(spm_->rowptr[i + 1] - spm_->rowptr[i]);
-        if (ncnt < sort_window_size_) {
-            cnt = ncnt;
-        } else {
-            sort_splits_.push_back(i + 1);
-            sort_splits_nzeros_.push_back(ncnt);
-            cnt = 0;
-        }
+    for (const Window &w : win) {
+        sort_splits_.push_back(w.end);
+        sort_splits_nzeros_.push_back(w.nnz);
     }
-    if (cnt) {
-        if (sort_splits_nzeros_.empty()) {
-            // the reference dereferences back() of an empty vector here; a
-            // matrix smaller than one window becomes a single window
-            sort_splits_nzeros_.push_back(cnt);
-            sort_splits_.push_back(nr_rows);
-            return;
-        }
-        sort_splits_nzeros_.back() += cnt;
-        if (cnt > sort_window_size_ / 2) {
-            sort_splits_.push_back(nr_rows);
-        } else {
-            sort_splits_.pop_back();
-            sort_splits_.push_back(nr_rows);
-        }
-    }
+    if (tail_range) sort_splits_.push_back(rows);
 }
 
 void Encoder::select_splits()
 {
-    size_t nr_splits = sort_splits_.size();
-    size_t nr_samples = samples_max_;
-    // the reference leaves unassigned slots uninitialised; zero is used here
-    selected_splits_.assign(nr_samples, 0);
-    if (nr_samples == nr_splits) {
-        for (size_t i = 0; i < nr_splits; ++i) selected_splits_[i] = i;
-        return;
+    // Which windows are sampled, as a formula of the slot number i.  With K boundaries and S
+    // samples (S <= K): all of them when S == K; otherwise, when S exceeds K / 2, the first
+    // `head` = K / 2 windows are taken as they are and only the remaining S - head samples are
+    // spread, evenly (stride `skip`), over the remaining K - head -- written, as in the reference,
+    // over the FIRST slots again, so a slot keeps its own number only behind the spread ones, and a
+    // slot behind both is never assigned (zero here; uninitialised there).
+    const size_t K = sort_splits_.size(), S = samples_max_;
+    selected_splits_.assign(S, 0);
+    const size_t head = (S != K && S > K / 2) ? K / 2 : 0;
+    const size_t spread = S == K ? 0 : S - head;
+    const size_t skip = S == K ? 0 : (K - head) / (spread + 1);
+    for (size_t i = 0; i < S; ++i) {
+        if (S == K) selected_splits_[i] = i;
+        else if (i < spread) selected_splits_[i] = (i + 1) * skip;
+        else if (i < head) selected_splits_[i] = i;
     }
-    if (nr_samples > nr_splits / 2) {
-        for (size_t i = 0; i < nr_splits / 2; ++i) selected_splits_[i] = i;
-        nr_samples -= nr_splits / 2;
-        nr_splits -= nr_splits / 2;
-    }
-    size_t skip = nr_splits / (nr_samples + 1);
-    for (size_t i = 0; i < nr_samples; ++i) selected_splits_[i] = (i + 1) * skip;
 }
 
 // ---- statistics --------------------------------------------------------------------
@@ -231,28 +236,24 @@ void Encoder::update_stats(Partition *sp, std::vector<idx_t> &xs,
     delta_encode(xs);
     rl_encode(xs, rles);
 
-    idx_t col = 0;               // non-zero once the first run has been seen
-    bool last_rle_patt = false;  // previous run was a candidate unit
-    for (const Rle &rle : rles) {
-        // a run may swallow the stray element in front of it (:1359-1367)
-        bool absorb = (col != 0) && !last_rle_patt;
-        size_t real_limit = absorb ? prm_.min_limit - 1 : prm_.min_limit;
-        if (rle.freq > 1 && rle.freq >= real_limit) {
-            size_t real_nnz = absorb ? rle.freq + 1 : rle.freq;
-            size_t rem = real_nnz % prm_.max_limit;
-            size_t patt_nnz = real_nnz;
-            size_t patt_units = real_nnz / prm_.max_limit + (rem != 0);
-            if (rem && rem < prm_.min_limit) {
-                --patt_units;      // remainder too short to form a unit
-                patt_nnz -= rem;
-            }
-            stats.append(Instantiation(sp->type, (size_t) rle.val),
-                         StatsData(patt_nnz, patt_units));
-            last_rle_patt = true;
-        } else {
-            last_rle_patt = false;
-        }
-        col += rle.val;
+    // What a run of `len` equal deltas is worth: units of at most max_limit elements; a last piece
+    // shorter than min_limit is no unit and its elements do not count (:1376-1398)
+    auto worth = [this](size_t len) {
+        size_t units = len / prm_.max_limit, covered = len;
+        const size_t last = len % prm_.max_limit;
+        if (last && last >= prm_.min_limit) ++units;
+        else covered -= last;
+        return StatsData(covered, units);
+    };
+    // A run counts as `freq` elements -- or freq + 1 when the element in front of it is free to
+    // join: there is one (this is not the row's first run) and the run before did not become a
+    // unit itself (:1359-1367).  It must have more than one delta and reach min_limit that way.
+    bool at_row_start = true, prev_became_unit = false;
+    for (const Rle &run : rles) {
+        const size_t len = run.freq + ((!at_row_start && !prev_became_unit) ? 1 : 0);
+        prev_became_unit = run.freq > 1 && len >= prm_.min_limit;
+        if (prev_became_unit) stats.append(Instantiation(sp->type, (size_t) run.val), worth(len));
+        if (run.val != 0) at_row_start = false;
     }
     xs.clear();
 }

@@ -45,9 +45,8 @@ struct Group {
 
 class RbBuilder {
 public:
-    RbBuilder(const Partition &p, GpuStream &out, bool stack = true, bool x_window = true, bool inline_desc = true,
-              bool pair_x = true)
-        : p_(p), out_(out), stack_(stack), x_window_(x_window), inline_desc_(inline_desc), pair_x_(pair_x) {}
+    RbBuilder(const Partition &p, GpuStream &out, bool stack = true, bool x_window = true, bool inline_desc = true)
+        : p_(p), out_(out), stack_(stack), x_window_(x_window), inline_desc_(inline_desc) {}
 
     // rows [lo, hi) of the partition with what the planner cut out for them
     struct Part {
@@ -108,7 +107,6 @@ private:
     bool stack_;
     bool x_window_;
     bool inline_desc_;
-    bool pair_x_;        // spx.gpu.pair_x: passes that read the same x next to each other (see emit_unit_passes)
     std::vector<Group> groups_;
     std::vector<val_t> gvals_;
     std::vector<idx_t> slot_groups_;   // first columns of the row-block's slot groups (ascending)
@@ -304,126 +302,23 @@ void RbBuilder::stack_groups()
 
 void RbBuilder::emit_unit_passes(SpxRowBlock &rb, bool sym, uint32_t row_base)
 {
-    // -- Passes that read the same x, next to each other.  A wavefront takes the passes of a
-    // row-block in adjacent pairs and loads x ONCE for a pair whose lanes read the same columns
-    // (unit_passes, SHARE: the x loads are what separates the kernel from a bare stream of its
-    // values, profiles/r03/ablation.md section 9).  In a stencil matrix the rows of neighbouring
-    // grid lines read the same line of x -- row r through its band dy = +1, row r + N through
-    // dy = 0 -- as diagonal stacks with the same first columns and different rows.  Such stacks
-    // (same width, column step 1, their column ranges overlapping in >= PAIR_MIN segments) are cut
-    // at the ends of the overlap and the two overlapping pieces become a COUPLE: both are cut
-    // into passes of their own at the same positions (every such pass lies inside one stack: its
-    // descriptor travels in the header) and emitted alternately, A0 B0 A1 B1 ...  Stacks of any
-    // other kind pair up when they agree in first column, length, kind and step.
-    constexpr uint32_t PAIR_MIN = 48;      // lanes of a pass that must be in use (of 64)
-    std::vector<std::pair<uint32_t, uint32_t>> couples;
-    std::vector<char> coupled;
-    if (!sym && pair_x_ && inline_desc_ && groups_.size() > 1) {
-        auto piece = [&](const Group &g, uint32_t o, uint32_t m) {      // segments [o, o + m) of a stack
-            Group q = g;
-            const int drow = g.kind == SPX_KIND_BLOCK ? 1 : (g.kind >= SPX_KIND_VERT ? (int) g.step : 0);
-            const int dcol = (g.kind == SPX_KIND_HORIZ || g.kind == SPX_KIND_DIAG) ? (int) g.step
-                             : (g.kind == SPX_KIND_ADIAG ? -(int) g.step : 0);
-            q.row0 = (uint16_t)(g.row0 + (int) o * drow);
-            q.col0 = (uint32_t)((int64_t) g.col0 + (int64_t) o * dcol);
-            q.nseg = (uint16_t) m;
-            q.voff = g.voff + o * g.width;
-            return q;
-        };
-        // (1) diagonal stacks with column step 1: by overlap
-        std::vector<Group> work, done;
-        for (const Group &g : groups_) {
-            if (g.kind == SPX_KIND_DIAG && g.step == 1 && g.nseg >= PAIR_MIN) work.push_back(g);
-            else done.push_back(g);
-        }
-        std::vector<std::pair<Group, Group>> found;
-        while (!work.empty()) {
-            // the stack that starts first; its partner: the one with the longest overlap
-            size_t ia = 0;
-            for (size_t i = 1; i < work.size(); ++i)
-                if (work[i].width < work[ia].width || (work[i].width == work[ia].width && work[i].col0 < work[ia].col0)) ia = i;
-            const Group A = work[ia];
-            work.erase(work.begin() + (ptrdiff_t) ia);
-            size_t ib = work.size();
-            uint32_t best = 0;
-            for (size_t i = 0; i < work.size(); ++i) {
-                const Group &B = work[i];
-                if (B.width != A.width) continue;
-                const int64_t lo = std::max<int64_t>(A.col0, B.col0);
-                const int64_t hi = std::min<int64_t>((int64_t) A.col0 + A.nseg, (int64_t) B.col0 + B.nseg);
-                if (hi - lo >= (int64_t) PAIR_MIN && (uint32_t)(hi - lo) > best) {
-                    best = (uint32_t)(hi - lo);
-                    ib = i;
-                }
-            }
-            if (ib == work.size()) {
-                done.push_back(A);
-                continue;
-            }
-            const Group B = work[ib];
-            work.erase(work.begin() + (ptrdiff_t) ib);
-            const uint32_t lo = std::max(A.col0, B.col0);
-            found.emplace_back(piece(A, lo - A.col0, best), piece(B, lo - B.col0, best));
-            // what sticks out on either side goes back (it may find a partner of its own)
-            for (const Group *g : {&A, &B}) {
-                const uint32_t before = lo - g->col0, after = g->nseg - before - best;
-                if (before) (before >= PAIR_MIN ? work : done).push_back(piece(*g, 0, before));
-                if (after) (after >= PAIR_MIN ? work : done).push_back(piece(*g, before + best, after));
-            }
-        }
-        // (2) everything else: equal first column, length, kind, step, width
-        std::vector<char> used(done.size(), 0);
-        for (size_t i = 0; i < done.size(); ++i) {
-            if (used[i] || done[i].nseg < PAIR_MIN) continue;
-            for (size_t j = i + 1; j < done.size(); ++j) {
-                const Group &a = done[i], &b = done[j];
-                if (!used[j] && a.col0 == b.col0 && a.nseg == b.nseg && a.width == b.width && a.kind == b.kind && a.step == b.step &&
-                    a.kind != SPX_KIND_HORIZ) {
-                    found.emplace_back(a, b);
-                    used[i] = used[j] = 1;
-                    break;
-                }
-            }
-        }
-        if (!found.empty()) {
-            std::stable_sort(found.begin(), found.end(), [](const std::pair<Group, Group> &x, const std::pair<Group, Group> &y) {
-                return x.first.width < y.first.width;
-            });
-            std::vector<Group> all;
-            for (const auto &c : found) {
-                couples.emplace_back((uint32_t) all.size(), (uint32_t) all.size() + 1);
-                all.push_back(c.first);
-                all.push_back(c.second);
-            }
-            coupled.assign(all.size(), 1);
-            for (size_t i = 0; i < done.size(); ++i)
-                if (!used[i]) all.push_back(done[i]);
-            coupled.resize(all.size(), 0);
-            groups_.swap(all);
-        }
-    }
-    if (coupled.empty()) coupled.assign(groups_.size(), 0);
-
     // passes hold segments of one width: order the groups by width
-    std::vector<uint32_t> order;
-    for (uint32_t i = 0; i < groups_.size(); ++i)
-        if (!coupled[i]) order.push_back(i);
+    std::vector<uint32_t> order(groups_.size());
+    for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
         return groups_[a].width < groups_[b].width;
     });
     struct Slot { uint32_t desc; uint32_t grp; uint16_t s; };
     std::vector<Slot> lanes;
     uint32_t seg_counter = 0;
-    // `seg0`: the number of lane 0's segment in the numbering the descriptors use (a stack's
-    // segments are numbered consecutively from the `sstart` its descriptor holds)
-    auto flush = [&](uint8_t width, uint32_t seg0) {
+    auto flush = [&](uint8_t width) {
         if (lanes.empty()) return;
         SpxPass ps;
         std::memset(&ps, 0, sizeof(ps));
         if (out_.values.size() % 2) out_.values.push_back(0.0);
         ps.val_off = (uint32_t)(out_.values.size() - rb.val_off);
         ps.rank0 = (uint16_t) lanes[0].desc;
-        ps.seg0 = (uint16_t) seg0;
+        ps.seg0 = (uint16_t)(seg_counter - lanes.size());
         ps.nseg = (uint8_t) lanes.size();
         ps.width = width;
         ps.kind = sym ? SPX_PASS_SYMSEG : SPX_PASS_UNIT;
@@ -449,11 +344,17 @@ void RbBuilder::emit_unit_passes(SpxRowBlock &rb, bool sym, uint32_t row_base)
         ++rb.n_pass;
         lanes.clear();
     };
-    auto add_desc = [&](const Group &g) {
+    uint8_t cur_w = 0;
+    for (uint32_t gi : order) {
+        const Group &g = groups_[gi];
+        if (g.width != cur_w) {
+            flush(cur_w);
+            cur_w = g.width;
+        }
         SpxUnitDesc d;
         d.col0 = g.col0;
         d.bits = spx_desc_bits(g.row0, seg_counter, g.kind, g.step);
-        const uint32_t di = (uint32_t)(out_.descs.size() - rb.desc_off);
+        uint32_t di = (uint32_t)(out_.descs.size() - rb.desc_off);
         out_.descs.push_back(d);
         if (sym) {
             SpxUnitDesc d2;        // second half of a symmetric unit's descriptor: its slot
@@ -462,38 +363,13 @@ void RbBuilder::emit_unit_passes(SpxRowBlock &rb, bool sym, uint32_t row_base)
             out_.descs.push_back(d2);
         }
         ++out_.n_units;
-        return di;
-    };
-    // couples first (an even number of passes, so that the rest starts on a pair boundary too)
-    for (const auto &c : couples) {
-        const Group &ga = groups_[c.first], &gb = groups_[c.second];
-        const uint32_t sa = seg_counter, da = add_desc(ga);
-        seg_counter += ga.nseg;
-        const uint32_t sb = seg_counter, db = add_desc(gb);
-        seg_counter += gb.nseg;
-        for (uint32_t o = 0; o < ga.nseg; o += SPX_PASS_SEGS) {
-            const uint32_t m = std::min<uint32_t>(SPX_PASS_SEGS, ga.nseg - o);
-            for (uint32_t k = 0; k < m; ++k) lanes.push_back(Slot{da, c.first, (uint16_t)(o + k)});
-            flush(ga.width, sa + o);
-            for (uint32_t k = 0; k < m; ++k) lanes.push_back(Slot{db, c.second, (uint16_t)(o + k)});
-            flush(gb.width, sb + o);
-        }
-    }
-    uint8_t cur_w = 0;
-    for (uint32_t gi : order) {
-        const Group &g = groups_[gi];
-        if (g.width != cur_w) {
-            flush(cur_w, seg_counter - (uint32_t) lanes.size());
-            cur_w = g.width;
-        }
-        const uint32_t di = add_desc(g);
         for (uint16_t s = 0; s < g.nseg; ++s) {
             lanes.push_back(Slot{di, gi, s});
             ++seg_counter;
-            if (lanes.size() == SPX_PASS_SEGS) flush(cur_w, seg_counter - (uint32_t) lanes.size());
+            if (lanes.size() == SPX_PASS_SEGS) flush(cur_w);
         }
     }
-    flush(cur_w, seg_counter - (uint32_t) lanes.size());
+    flush(cur_w);
 }
 
 // Leftover nonzeros as row pieces: every row's leftovers are cut into pieces of
@@ -1790,7 +1666,7 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsi
         else emit_plan(jobs[k].first, bld, dst);
     };
     if (nthreads <= 1 || jobs.size() < 64) {
-        RbBuilder bld(p, out, prm.stack_segments, prm.x_window, prm.inline_desc, prm.pair_x);
+        RbBuilder bld(p, out, prm.stack_segments, prm.x_window, prm.inline_desc);
         for (size_t k = 0; k < jobs.size(); ++k) emit_job(k, bld, out);
         return;
     }
@@ -1798,7 +1674,7 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsi
     std::vector<GpuStream> locs(n_chunks);
     parallel_for(n_chunks, nthreads, [&](size_t c) {
         const size_t lo = jobs.size() * c / n_chunks, hi = jobs.size() * (c + 1) / n_chunks;
-        RbBuilder bld(p, locs[c], prm.stack_segments, prm.x_window, prm.inline_desc, prm.pair_x);
+        RbBuilder bld(p, locs[c], prm.stack_segments, prm.x_window, prm.inline_desc);
         for (size_t k = lo; k < hi; ++k) emit_job(k, bld, locs[c]);
     });
     for (GpuStream &l : locs) append_stream(out, std::move(l));

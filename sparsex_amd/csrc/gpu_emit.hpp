@@ -75,7 +75,14 @@ struct GpuStream {
     uint32_t pass_stride = 0;
     uint32_t waves = 4;           // wavefronts per workgroup the kernel is launched with
     bool band_order = false;      // spx.gpu.band_order: launch order by strips across recurring bands of x (device side only)
-    bool arena = true;            // spx.gpu.arena: all arrays of the stream in one HBM allocation (device side only)
+    // column slices in one launch (SPX_RB_ACCUM): how every row of every row-block reaches y -- two bits
+    // per row, 32 words per row-block: 0 nothing to add (the slice holds no nonzero of the row), 1 STORE
+    // alpha * sum + beta * y (no other slice holds a nonzero of the row; rows without any nonzero belong
+    // to the first slice), 2 ADD (several slices do: y <- beta * y goes first, over accum_shared_rows
+    // only).  Derived from the stream (stream_accum_row_modes), not saved.
+    std::vector<uint32_t> accum_rowmode;
+    std::vector<uint32_t> accum_shared_rows;
+    bool arena = false;           // spx.gpu.arena: all arrays of the stream in one HBM allocation (device side only)
     // accounting
     size_t nnz_stored = 0;        // nonzeros held in `values` (without padding)
     size_t n_unit_elems = 0;
@@ -109,7 +116,6 @@ struct GpuEmitParams {
     bool recut_linear = true;     // spx.gpu.recut_linear: nonzeros of vertical / diagonal /
                                   // strided units that line up along their rows run as row segments
     bool inline_desc = true;      // spx.gpu.inline_desc: SPX_PASSF_INLINE
-    bool pair_x = true;           // spx.gpu.pair_x: unit passes that read the same x are emitted next to each other
     bool keep_units = true;       // spx.gpu.keep_units: ... but a mined unit none of whose nonzeros has a
                                   // neighbour along its row stays the unit it is (one descriptor)
     bool sym_remine = true;       // spx.gpu.sym_remine (see append_sym_expanded)

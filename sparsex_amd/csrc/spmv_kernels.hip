@@ -164,19 +164,6 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
     }
     int row[B];
     double acc[B];
-    // SHARE: the two passes read the same x -- both carry ONE descriptor in their headers (wave-
-    // uniform: the comparison is scalar), these agree in first column, kind and step, and lane l
-    // is the same segment of its stack in both (rows differ: neighbouring grid lines of a stencil
-    // read the same line of x; the emitter puts such passes next to each other,
-    // RbBuilder::emit_unit_passes).  x is loaded once for the pair.
-    bool share = false;
-    if (B == 2 && G == 0) {
-        const uint32_t b0 = (uint32_t) (ps[0].mask >> 32), b1 = (uint32_t) (ps[B - 1].mask >> 32);
-        share = (ps[0].flags & ps[B - 1].flags & SPX_PASSF_INLINE) != 0 && nseg[0] == nseg[B - 1] &&
-                (uint32_t) ps[0].mask == (uint32_t) ps[B - 1].mask && (b0 >> 22) == (b1 >> 22) &&
-                (((uint32_t) ps[0].seg0 - ((b0 >> 9) & 8191u)) & 0xffffu) ==
-                    (((uint32_t) ps[B - 1].seg0 - ((b1 >> 9) & 8191u)) & 0xffffu);
-    }
     double x[B][W];
 #pragma unroll
     for (int b = 0; b < B; ++b) {
@@ -214,10 +201,7 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
             // at any alignment, W / 2 + (W & 1) load instructions instead of W.  (One full-width load
             // per diagonal stack with the other W - 1 columns taken from the neighbouring lanes by
             // DPP shifts was built and measured slower: profiles/r03/ablation.md section 6.)
-            if (b > 0 && share) {
-#pragma unroll
-                for (int w = 0; w < W; ++w) x[b][w] = x[0][w];
-            } else if (W >= 2) {
+            if (W >= 2) {
                 const spx_d2u_t *xp2 = reinterpret_cast<const spx_d2u_t *>(xp);
 #pragma unroll
                 for (int p = 0; p < W / 2; ++p) {
@@ -544,14 +528,11 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &x
     if (rb_idx >= xs.first[deal ? 8u : xcd + 1u]) return;
 
     // the pass headers sit at a fixed stride, so the wave's first two are
-    // fetched together with the row-block header, not after it.  A wavefront takes the passes
-    // in ADJACENT pairs -- wave w: (2w, 2w + 1), then (2w + 2W, 2w + 2W + 1), ... -- whatever the
-    // workgroup's wavefront count: the emitter puts passes that read the same x next to each
-    // other (unit_passes: SHARE), and neighbours have the same width more often than not
+    // fetched together with the row-block header, not after it
     const SpxPass *passes = a.passes + (size_t) rb_idx * a.pass_stride;
     const SpxRowBlock rb = a.rbs[rb_idx];
-    SpxPass p0 = passes[2 * wave];
-    SpxPass p1 = passes[2 * wave + 1];                   // (the table is padded by one stride)
+    SpxPass p0 = passes[wave];
+    SpxPass p1 = passes[wave + WAVES_PER_BLOCK];         // (the table is padded by one stride)
     const int n_rows = rb.n_rows;
     const int n_slots = SYM ? (int) rb.n_slots : 0;
     const int core = n_slots + n_rows;                       // doubles per copy of slots + y tile
@@ -578,11 +559,11 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &x
     }
     __syncthreads();
 
-    // two passes at a time when they have the same shape (they mostly do: passes are sorted by
-    // width), so that their loads overlap
+    // wave w takes passes w, w + W, ..., two at a time when they have the same shape (they mostly
+    // do: passes are sorted by width), so that their loads overlap
     const int n_pass = rb.n_pass;
-    for (int t = 2 * wave; t < n_pass; t += 2 * WAVES_PER_BLOCK) {
-        const bool two = t + 1 < n_pass;
+    for (int t = wave; t < n_pass; t += 2 * WAVES_PER_BLOCK) {
+        const bool two = t + WAVES_PER_BLOCK < n_pass;
         if (SEGS && (p0.kind == SPX_PASS_SYMSEG || (two && p1.kind == SPX_PASS_SYMSEG))) {
             // read-once row segments (atomic hand-over only); whatever shares the round runs on its own
             if (two && p0.kind == SPX_PASS_SYMSEG && p1.kind == SPX_PASS_SYMSEG &&
@@ -619,7 +600,7 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &x
         }
         if (t + 2 * WAVES_PER_BLOCK < n_pass) {
             p0 = passes[t + 2 * WAVES_PER_BLOCK];
-            p1 = passes[t + 2 * WAVES_PER_BLOCK + 1];
+            p1 = passes[t + 3 * WAVES_PER_BLOCK];
         }
     }
     __syncthreads();
@@ -638,6 +619,23 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &x
     // ---------------- write the owned rows ------------------------------------------------
     if (rb.flags & SPX_RB_SHARED) {
         if (threadIdx.x == 0) a.carry[rb.carry_slot] = tile[0];
+    } else if (ATOMIC && !SYM && a.slot_col) {
+        // column slices in one launch, per-row modes (stream_accum_row_modes): a row that only this
+        // slice holds nonzeros of is STORED (alpha * sum + beta * y: no pre-pass, no read-modify-write
+        // at the memory side), a row shared with other slices is added to (csx_scale_rows_kernel has
+        // put beta * y there), a row this slice has nothing of is left alone
+        const uint32_t *rm = a.slot_col + (size_t) rb_idx * 32u;
+        for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS) {
+            const uint32_t mode = (rm[i >> 4] >> ((i & 15) * 2)) & 3u;
+            const size_t g = (size_t) rb.row0 + i;
+            if (mode == 1u) {
+                double t = a.alpha * tile[i];
+                if (a.beta_priv != 0.0) t += a.beta_priv * a.y[g];
+                a.y[g] = t;
+            } else if (mode == 2u) {
+                atomicAdd(&a.y[g], a.alpha * tile[i]);
+            }
+        }
     } else if (ATOMIC) {
         if ((rb.flags & SPX_RB_PRIVATE) && a.dvalues_priv) {
             // nobody else adds to these rows (mark_private_rowblocks): stored, with the diagonal
@@ -815,6 +813,13 @@ __global__ void csx_scale_kernel(double *y, size_t lo, size_t hi, double beta)
     if (i < hi) y[i] = beta == 0.0 ? 0.0 : beta * y[i];
 }
 
+// ... or, with per-row modes, on the rows that several slices add to only
+__global__ void csx_scale_rows_kernel(double *y, const uint32_t *rows, size_t n, double beta)
+{
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[rows[i]] = beta == 0.0 ? 0.0 : beta * y[rows[i]];
+}
+
 // symmetric path, first step: y <- beta*y + alpha*diag(A)*x on the owned
 // rows, 0 elsewhere (the main kernel then accumulates; on several GPUs the
 // per-GPU vectors are summed afterwards)
@@ -888,6 +893,12 @@ struct DeviceMatrix {
     bool accum = false;           // SPX_RB_ACCUM: the column slices run in one launch and add to y
     std::vector<uint32_t> launch_order;
     size_t band_stride = 0;
+    // ... and where the values of the stream's row-block o went (val_orig_off[o] -> val_new_off[o];
+    // empty: values where the stream has them)
+    std::vector<size_t> val_orig_off, val_new_off;
+    // column slices in one launch: per-row modes and the rows that several slices add to
+    uint32_t *accum_rowmode = nullptr, *accum_shared_rows = nullptr;
+    size_t n_accum_shared = 0;
     bool has_symsegs = false;     // the stream holds SPX_PASS_SYMSEG passes
     bool has_symtiles = false;    // ... SPX_PASS_SYMTILE passes
     bool wave_tiles = false;      // a y tile per wavefront, summed in wavefront order before the write-out
@@ -912,7 +923,8 @@ struct DeviceMatrix {
     size_t n_values = 0, n_descs = 0, n_passes = 0, n_cidx = 0, n_segrows = 0;
     // every array of the stream lives in ONE allocation (2 MB-aligned pieces): one mapping, one
     // run of physically contiguous fragments as far as the driver can give them
-    // (spx.gpu.arena=false / SPX_NO_ARENA: an allocation per array, as rounds 1-3 had it)
+    // (spx.gpu.arena=true; default: an allocation per array -- the arena changed nothing in the
+    // run-to-run spread it was built to test, profiles/r04/spread.md)
     void *arena = nullptr;
     size_t arena_bytes = 0;
     // chunked launches (device_plan_chunks / device_spmv_chunk: the exchange of a row-partitioned
@@ -1010,8 +1022,8 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
     std::vector<double> dv;                               // host copies that must live until the flush
     std::vector<SpxRowBlock> rbs_ordered;
     std::vector<SpxPass> passes_ordered;
-    place.put(&m->values, s.values, 160);
-    place.put(&m->descs, s.descs, 8);
+    std::vector<double> values_ordered;                   // band order: values and descriptors move with their row-blocks
+    std::vector<SpxUnitDesc> descs_ordered;
     place.put(&m->cidx, s.cidx, 64);
     place.put(&m->segrows, s.segrows, 80);
     place.put(&m->shared, s.shared);
@@ -1153,7 +1165,14 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
             }
             if (!any) order.clear();
         }
+        if (order.empty() && m->accum && s.accum_rowmode.size() == s.rbs.size() * 32) {
+            place.put(&m->accum_rowmode, s.accum_rowmode);
+            place.put(&m->accum_shared_rows, s.accum_shared_rows);
+            m->n_accum_shared = s.accum_shared_rows.size();
+        }
         if (order.empty()) {
+            place.put(&m->values, s.values, 160);
+            place.put(&m->descs, s.descs, 8);
             place.put(&m->rbs, s.rbs);
             place.put(&m->passes, s.passes, (size_t) s.pass_stride + 6 * MAX_WAVES_PER_BLOCK);
         } else {
@@ -1167,6 +1186,43 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
                 rbs[i].pass_off = (uint32_t)(i * stride);
                 std::copy(s.passes.begin() + (size_t) order[i] * stride, s.passes.begin() + ((size_t) order[i] + 1) * stride,
                           passes.begin() + i * stride);
+            }
+            // The values (and descriptors) of a row-block move with it: the XCD then still reads ONE
+            // ascending stream of values while its row-blocks walk the planes strip by strip (round 3
+            // reordered the headers only -- the values of a part were then read at 12 MB jumps, which
+            // cost more than the re-fetches of x it saved: profiles/r03/ablation.md section 8)
+            const size_t n = s.rbs.size();
+            bool ascending = true;
+            for (size_t i = 0; i + 1 < n; ++i)
+                ascending = ascending && s.rbs[i + 1].val_off >= s.rbs[i].val_off && s.rbs[i + 1].desc_off >= s.rbs[i].desc_off;
+            if (ascending && n) {
+                values_ordered.assign(s.values.size(), 0.0);
+                descs_ordered.resize(s.descs.size());
+                m->val_orig_off.resize(n + 1);
+                m->val_new_off.resize(n + 1);
+                for (size_t i = 0; i < n; ++i) m->val_orig_off[i] = s.rbs[i].val_off;
+                m->val_orig_off[n] = s.values.size();
+                size_t vat = s.rbs[0].val_off, dat = s.rbs[0].desc_off;
+                std::copy(s.values.begin(), s.values.begin() + (ptrdiff_t) vat, values_ordered.begin());
+                std::copy(s.descs.begin(), s.descs.begin() + (ptrdiff_t) dat, descs_ordered.begin());
+                for (size_t i = 0; i < n; ++i) {
+                    const size_t o = order[i];
+                    const size_t v0 = s.rbs[o].val_off, v1 = o + 1 < n ? s.rbs[o + 1].val_off : s.values.size();
+                    const size_t d0 = s.rbs[o].desc_off, d1 = o + 1 < n ? s.rbs[o + 1].desc_off : s.descs.size();
+                    std::copy(s.values.begin() + (ptrdiff_t) v0, s.values.begin() + (ptrdiff_t) v1, values_ordered.begin() + (ptrdiff_t) vat);
+                    std::copy(s.descs.begin() + (ptrdiff_t) d0, s.descs.begin() + (ptrdiff_t) d1, descs_ordered.begin() + (ptrdiff_t) dat);
+                    rbs[i].val_off = vat;
+                    rbs[i].desc_off = (uint32_t) dat;
+                    m->val_new_off[o] = vat;
+                    vat += v1 - v0;
+                    dat += d1 - d0;
+                }
+                m->val_new_off[n] = vat;
+                place.put(&m->values, values_ordered, 160);
+                place.put(&m->descs, descs_ordered, 8);
+            } else {
+                place.put(&m->values, s.values, 160);
+                place.put(&m->descs, s.descs, 8);
             }
             place.put(&m->rbs, rbs);
             place.put(&m->passes, passes, stride + 6 * MAX_WAVES_PER_BLOCK);
@@ -1220,6 +1276,8 @@ void device_free(DeviceMatrix *m)
         if (m->mirror_ptr) (void) hipFree(m->mirror_ptr);
         if (m->mirror_col) (void) hipFree(m->mirror_col);
         if (m->mirror_val) (void) hipFree(m->mirror_val);
+        if (m->accum_rowmode) (void) hipFree(m->accum_rowmode);
+        if (m->accum_shared_rows) (void) hipFree(m->accum_shared_rows);
     }
     if (m->d_x) (void) hipFree(m->d_x);
     if (m->d_y) (void) hipFree(m->d_y);
@@ -1292,7 +1350,16 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
                                alpha, m->n_mirror_rows);
         a.beta = beta = 1.0;
     }
-    if (m->accum && !m->symmetric) {
+    if (m->accum && !m->symmetric && m->accum_rowmode) {
+        // column slices in one launch, per-row modes: beta * y only where several slices add
+        const int t = 256;
+        if (m->n_accum_shared)
+            hipLaunchKernelGGL(csx_scale_rows_kernel, dim3((unsigned)((m->n_accum_shared + t - 1) / t)), dim3(t), 0, stream,
+                               d_y, m->accum_shared_rows, m->n_accum_shared, beta);
+        a.slot_col = m->accum_rowmode;
+        a.beta_priv = beta;
+        a.beta = beta = 1.0;
+    } else if (m->accum && !m->symmetric) {
         // column slices in one launch: beta * y first, every row-block adds on top
         const int t = 256;
         const size_t lo = m->own_lo, hi = m->own_hi;
@@ -1672,6 +1739,40 @@ void device_download(const DeviceMatrix *m, GpuStream &s)
         }
         s.rbs.swap(rbs);
         s.passes.swap(passes);
+        if (!m->val_new_off.empty()) {
+            const size_t n = s.rbs.size();
+            std::vector<double> values(s.values.size());
+            std::vector<SpxUnitDesc> descs(s.descs.size());
+            std::copy(s.values.begin(), s.values.begin() + (ptrdiff_t) m->val_orig_off[0], values.begin());
+            // (descriptors: the row-blocks' own offsets on the device are the new ones; the original
+            // ones follow from the lengths, in stream order)
+            size_t dat = n ? s.rbs[0].desc_off : 0;
+            {
+                size_t first = s.descs.size();
+                for (size_t o = 0; o < n; ++o) first = std::min<size_t>(first, s.rbs[o].desc_off);
+                dat = n ? first : 0;
+                std::copy(s.descs.begin(), s.descs.begin() + (ptrdiff_t) dat, descs.begin());
+            }
+            // length of every row-block's descriptors: to the next offset in DEVICE order
+            std::vector<std::pair<uint32_t, size_t>> by_dev;
+            for (size_t o = 0; o < n; ++o) by_dev.emplace_back(s.rbs[o].desc_off, o);
+            std::sort(by_dev.begin(), by_dev.end());
+            std::vector<size_t> dlen(n, 0);
+            for (size_t k = 0; k < n; ++k)
+                dlen[by_dev[k].second] = (k + 1 < n ? by_dev[k + 1].first : s.descs.size()) - by_dev[k].first;
+            for (size_t o = 0; o < n; ++o) {
+                const size_t len = m->val_orig_off[o + 1] - m->val_orig_off[o];
+                std::copy(s.values.begin() + (ptrdiff_t) m->val_new_off[o], s.values.begin() + (ptrdiff_t)(m->val_new_off[o] + len),
+                          values.begin() + (ptrdiff_t) m->val_orig_off[o]);
+                std::copy(s.descs.begin() + s.rbs[o].desc_off, s.descs.begin() + s.rbs[o].desc_off + (ptrdiff_t) dlen[o],
+                          descs.begin() + (ptrdiff_t) dat);
+                s.rbs[o].val_off = m->val_orig_off[o];
+                s.rbs[o].desc_off = (uint32_t) dat;
+                dat += dlen[o];
+            }
+            s.values.swap(values);
+            s.descs.swap(descs);
+        }
     }
     download(s.cidx, m->cidx, m->n_cidx);
     download(s.segrows, m->segrows, m->n_segrows);
@@ -1707,13 +1808,22 @@ void device_poke_mirror(DeviceMatrix *m, size_t index, double value)
     HIP_CHECK(hipMemcpy(m->mirror_val + index, &value, sizeof(value), hipMemcpyHostToDevice));
 }
 
+// position in HBM of value `index` of the stream (the band order moves values with their row-blocks)
+static size_t value_position(const DeviceMatrix *m, size_t index)
+{
+    if (m->val_new_off.empty() || index < m->val_orig_off.front()) return index;
+    const size_t o = (size_t)(std::upper_bound(m->val_orig_off.begin(), m->val_orig_off.end(), index) - m->val_orig_off.begin()) - 1;
+    if (o + 1 >= m->val_orig_off.size()) return index;
+    return m->val_new_off[o] + (index - m->val_orig_off[o]);
+}
+
 double device_peek(const DeviceMatrix *m, bool diagonal, size_t index)
 {
     if (diagonal ? (!m->dvalues || index >= m->nrows) : index >= m->n_values)
         throw FatalError("value index outside the stream");
     HIP_CHECK(hipSetDevice(m->device));
     double v = 0.0;
-    HIP_CHECK(hipMemcpy(&v, (diagonal ? m->dvalues : m->values) + index, sizeof(v), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(&v, diagonal ? m->dvalues + index : m->values + value_position(m, index), sizeof(v), hipMemcpyDeviceToHost));
     return v;
 }
 
@@ -1725,7 +1835,7 @@ void device_poke(DeviceMatrix *m, bool diagonal, size_t index, double value)
     // products enqueued on a non-blocking stream (spx_hip_matvec_*) are not ordered against
     // this copy by themselves: wait for whatever the device still runs before the value changes
     HIP_CHECK(hipDeviceSynchronize());
-    HIP_CHECK(hipMemcpy((diagonal ? m->dvalues : m->values) + index, &value, sizeof(value),
+    HIP_CHECK(hipMemcpy(diagonal ? m->dvalues + index : m->values + value_position(m, index), &value, sizeof(value),
                         hipMemcpyHostToDevice));
 }
 
