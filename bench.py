@@ -579,17 +579,37 @@ def host_api_rate(A, xh, n, nnz, calls=20):
             "us_per_call": round(sec * 1e6, 1), "gflops": round(2.0 * nnz / sec / 1e9, 1)}
 
 
-def measured_traffic(key):
+def measured_traffic(key, kernel=None):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes
     (profiles/traffic.json, produced by tools/profile.sh + tools/collect_profiles.py:
     FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc runs of this very
     command, FETCH_SIZE doubled per the gfx950 note of the microarchitecture
-    guide); None when this configuration was not profiled."""
+    guide); None when this configuration was not profiled -- or when the counters were
+    taken on another kernel variant than the one that ran now (`kernel`: the launch
+    tuner's pick moves between boxes; the name in the file must be part of it)."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return json.load(f)[key]["hbm_bytes_per_launch"]
+            e = json.load(f)[key]
     except (OSError, KeyError, ValueError):
         return None
+    if kernel is not None:
+        import re
+        m = re.search(r"csx_spmv[a-z_]*kernel<\d>", e.get("kernel", ""))
+        if m is None or m.group(0) not in kernel:
+            return None
+    return e["hbm_bytes_per_launch"]
+
+
+def traffic_note(key, kernel):
+    """Why `traffic` is null although the configuration was profiled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            e = json.load(f)[key]
+    except (OSError, KeyError, ValueError):
+        return "this configuration has no committed PMC pass"
+    if measured_traffic(key, kernel) is None:
+        return "the committed PMC pass is of `%s`, this run launched `%s`: not comparable" % (e.get("kernel", "?")[:70], kernel)
+    return "committed PMC run of this command (profiles/traffic.json)"
 
 
 def kernel_name(info, symmetric, world):
@@ -728,7 +748,8 @@ def run_config(torch, sx, name, symmetric, steps, warmup, cpu_budget, T, csr=Non
                         "unit": "GB/s", "frac": round(b_alg / launch_s / 1e9 / HBM_PEAK_GBS, 4),
                         "kernel": kernel_name(info, symmetric, 1), "avg_launch_us": round(1e6 * launch_s, 3),
                         "algorithmic_bytes_per_launch": int(b_alg),
-                        "traffic": measured_traffic(traffic_key or (name + ("-sym" if symmetric else "")))},
+                        "traffic": measured_traffic(traffic_key or (name + ("-sym" if symmetric else "")), kernel_name(info, symmetric, 1)),
+                        "traffic_source": traffic_note(traffic_key or (name + ("-sym" if symmetric else "")), kernel_name(info, symmetric, 1))},
            "cache_resident": bool(info.value_bytes + info.index_bytes < MALL_BYTES),
            "index_bytes_per_nnz": round(info.index_bytes / max(int(info.nnz_stored), 1), 3),
            "tune_seconds": round(info.tune_seconds, 3), "emit_upload_seconds": round(info.emit_seconds, 3),
@@ -1058,8 +1079,8 @@ def run_path(ctx, args, symmetric):
                    "dist_reorder_seconds": round(wl.reorder_seconds, 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": measured_traffic(tkey) if std else None,
-                     "traffic_source": "committed PMC run of this command (profiles/traffic.json)" if std else None,
+                     "traffic": measured_traffic(tkey, kernel_name(info, symmetric, world)) if std else None,
+                     "traffic_source": traffic_note(tkey, kernel_name(info, symmetric, world)) if std else None,
                      "kernel": kernel_name(info, symmetric, world),
                      "algorithmic_bytes_per_launch": int(b_alg),
                      "avg_launch_us": round(1e6 * launch_s, 3),

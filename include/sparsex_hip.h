@@ -335,6 +335,13 @@ typedef struct {
 } spx_hip_info_t;
 
 spx_error_t spx_hip_mat_info(const spx_matrix_t *A, spx_hip_info_t *info);
+/* The same for a caller compiled against another revision of this header: at most `size` bytes
+ * (the caller's sizeof(spx_hip_info_t)) are written -- the struct only ever grows at its end.
+ * spx_hip_mat_info() writes sizeof(spx_hip_info_t) of THIS header; SPX_HIP_ABI_VERSION changes
+ * whenever the struct grows (round 3 added quad and col_slices: version 3; unchanged since). */
+#define SPX_HIP_ABI_VERSION 3
+spx_error_t spx_hip_mat_info_sized(const spx_matrix_t *A, void *info, size_t size);
+int spx_hip_abi_version(void);
 
 /* ---- export in the reference's CSX layout --------------------------------------
  * `part` is a global partition number owned by this process.  The arrays

@@ -58,6 +58,42 @@ def _subst(text, mapping):
     return text
 
 
+
+def row_and_column_hooks(symmetric, row_jumps, full_colind):
+    """The text CsxJit substitutes for ${new_row_hook} and ${next_x}, and the argument list of a
+    unit routine's call -- typed here from include/sparsex/internals/CsxJit.hpp:359-413 (DoNewRowHook)
+    and :640-672; tests/test_oracle_golden.py::test_hook_text_equals_the_reference extracts the
+    literals from that file and compares (in the container that holds the reference)."""
+    hooks = {}
+    if not symmetric:
+        if row_jumps:
+            hooks["new_row_hook"] = ("if (test_bit(&flags, CTL_RJMP_BIT))\n"
+                                     "\t\t\t\ty_curr += ul_get(&ctl);\n"
+                                     "\t\t\telse\n\t\t\t\ty_curr++;")
+        else:
+            hooks["new_row_hook"] = "y_curr++;"
+        hooks["next_x"] = ("x_curr = x + u32_get(&ctl);" if full_colind
+                           else "x_curr += ul_get(&ctl);")
+        call = "(&ctl, size, &v, &x_curr, &y_curr, scale_f);"
+    else:
+        if row_jumps:
+            hooks["new_row_hook"] = (
+                "if (test_bit(&flags, CTL_RJMP_BIT)) {\n"
+                "\t\t\t\tint jmp = ul_get(&ctl);\n"
+                "\t\t\t\tfor (i = 0; i < jmp; i++) {\n"
+                "\t\t\t\t\ty[y_indx] += x[y_indx] * (*dv) * scale_f;\n"
+                "\t\t\t\t\ty_indx++;\n\t\t\t\t\tdv++;\n\t\t\t\t}\n"
+                "\t\t\t} else {\n"
+                "\t\t\t\ty[y_indx] += x[y_indx] * (*dv) * scale_f;\n"
+                "\t\t\t\ty_indx++;\n\t\t\t\tdv++;\n\t\t\t}\n")
+        else:
+            hooks["new_row_hook"] = ("y[y_indx] += x[y_indx] * (*dv) * scale_f;\n"
+                                     "\t\t\ty_indx++;\n\t\t\tdv++;\n")
+        hooks["next_x"] = ("x_indx = u32_get(&ctl);" if full_colind
+                           else "x_indx += ul_get(&ctl);")
+        call = "(&ctl, size, &v, x, y, cur, &x_indx, &y_indx, scale_f);"
+    return hooks, call
+
 def generate_source(id_map, symmetric, row_jumps, full_colind):
     """The C text CsxJit would hand to its compiler for this partition."""
     sfx = "_sym" if symmetric else ""
@@ -97,33 +133,8 @@ def generate_source(id_map, symmetric, row_jumps, full_colind):
         entries[slot] = name
 
     hooks = {"spmv_func_definitions": "\n".join(defs)}
-    if not symmetric:
-        if row_jumps:
-            hooks["new_row_hook"] = ("if (test_bit(&flags, CTL_RJMP_BIT))\n"
-                                     "\t\t\t\ty_curr += ul_get(&ctl);\n"
-                                     "\t\t\telse\n\t\t\t\ty_curr++;")
-        else:
-            hooks["new_row_hook"] = "y_curr++;"
-        hooks["next_x"] = ("x_curr = x + u32_get(&ctl);" if full_colind
-                           else "x_curr += ul_get(&ctl);")
-        call = "(&ctl, size, &v, &x_curr, &y_curr, scale_f);"
-    else:
-        if row_jumps:
-            hooks["new_row_hook"] = (
-                "if (test_bit(&flags, CTL_RJMP_BIT)) {\n"
-                "\t\t\t\tint jmp = ul_get(&ctl);\n"
-                "\t\t\t\tfor (i = 0; i < jmp; i++) {\n"
-                "\t\t\t\t\ty[y_indx] += x[y_indx] * (*dv) * scale_f;\n"
-                "\t\t\t\t\ty_indx++;\n\t\t\t\t\tdv++;\n\t\t\t\t}\n"
-                "\t\t\t} else {\n"
-                "\t\t\t\ty[y_indx] += x[y_indx] * (*dv) * scale_f;\n"
-                "\t\t\t\ty_indx++;\n\t\t\t\tdv++;\n\t\t\t}\n")
-        else:
-            hooks["new_row_hook"] = ("y[y_indx] += x[y_indx] * (*dv) * scale_f;\n"
-                                     "\t\t\ty_indx++;\n\t\t\tdv++;\n")
-        hooks["next_x"] = ("x_indx = u32_get(&ctl);" if full_colind
-                           else "x_indx += ul_get(&ctl);")
-        call = "(&ctl, size, &v, x, y, cur, &x_indx, &y_indx, scale_f);"
+    fixed, call = row_and_column_hooks(symmetric, row_jumps, full_colind)
+    hooks.update(fixed)
     if len(entries) == 1:
         hooks["body_hook"] = "yr += " + list(entries.values())[0] + call
     else:

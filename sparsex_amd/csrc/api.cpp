@@ -1493,6 +1493,13 @@ spx_matrix_t *spx_mat_restore(const char *filename)
     A->sym_atomic = gs->sym_atomic;
     A->deterministic = gs->deterministic;
     A->wave_tiles = gs->wave_tiles ? 1 : 0;
+    {
+        // (column slices: what spx_hip_mat_info reports comes from the flags the stream carries)
+        size_t slices = 1;
+        for (size_t i = 1; i < gs->rbs.size(); ++i) slices += (gs->rbs[i].flags & SPX_RB_PHASE_START) ? 1 : 0;
+        A->col_phases = slices;
+        A->col_concurrent = slices > 1 && !gs->rbs.empty() && (gs->rbs[0].flags & SPX_RB_ACCUM);
+    }
     A->tune_seconds = 0.0;
     A->auto_rb = false;
     const double t0 = now_sec();
@@ -1824,6 +1831,19 @@ spx_error_t spx_hip_matvec_dist(spx_value_t alpha, const spx_matrix_t *A,
 // ======================================================================================
 //  extensions: info / export
 // ======================================================================================
+
+int spx_hip_abi_version(void) { return SPX_HIP_ABI_VERSION; }
+
+spx_error_t spx_hip_mat_info_sized(const spx_matrix_t *A, void *info, size_t size)
+{
+    spx_hip_info_t full;
+    if (!info || spx_hip_mat_info(A, &full) != SPX_SUCCESS) {
+        if (!info) SETERROR_1(SPX_ERR_ARG_INVALID, "invalid argument");
+        return SPX_FAILURE;
+    }
+    memcpy(info, &full, std::min(size, sizeof(full)));
+    return SPX_SUCCESS;
+}
 
 spx_error_t spx_hip_mat_info(const spx_matrix_t *A, spx_hip_info_t *info)
 {

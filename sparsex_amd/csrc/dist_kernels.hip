@@ -334,11 +334,16 @@ int rccl_exchange_host(void *ctx_, const uint64_t *send, const size_t *soff, con
     std::vector<size_t> off(W), one(W, 1);
     for (size_t q = 0; q < W; ++q) off[q] = q;
     one[(size_t) c->rank] = 0;
-    if (hipMemcpyAsync(c->st_send, st.data(), W * 8, hipMemcpyHostToDevice, c->setup_stream) != hipSuccess ||
-        rccl_exchange_device(c, c->st_send, off.data(), one.data(), c->st_recv, off.data(), one.data(),
+    // (the status words go up with a synchronous copy; should even that fail, this rank STILL enters
+    // the group -- with whatever the buffer held last -- because a rank that stays away leaves its
+    // peers waiting inside ncclRecv, and RCCL has no timeout: it then fails locally, and the peers
+    // are bounded by their caller's watchdog, bench.py's Watchdog for one)
+    const bool staged = hipMemcpy(c->st_send, st.data(), W * 8, hipMemcpyHostToDevice) == hipSuccess;
+    if (!staged) (void) hipGetLastError();
+    if (rccl_exchange_device(c, c->st_send, off.data(), one.data(), c->st_recv, off.data(), one.data(),
                              c->setup_stream) != 0 ||
         hipMemcpyAsync(got.data(), c->st_recv, W * 8, hipMemcpyDeviceToHost, c->setup_stream) != hipSuccess ||
-        hipStreamSynchronize(c->setup_stream) != hipSuccess) {
+        hipStreamSynchronize(c->setup_stream) != hipSuccess || !staged) {
         (void) hipGetLastError();
         log_msg(LOG_ERR, "RCCL transport: the status round of a set-up exchange failed\n");
         return -1;
@@ -398,9 +403,13 @@ spx_hip_transport_t *spx_hip_transport_rccl(const void *id, int rank, int world)
         if (hipStreamCreateWithFlags(&c->setup_stream, hipStreamNonBlocking) != hipSuccess ||
             hipMalloc(reinterpret_cast<void **>(&c->st_send), (size_t) world * 8) != hipSuccess ||
             hipMalloc(reinterpret_cast<void **>(&c->st_recv), (size_t) world * 8) != hipSuccess) {
-            // (the communicator exists on the other ranks: leaving it half-made here would make
-            // their first exchange wait; it is destroyed, which they see as an error)
+            // (the communicator exists on the other ranks and destroying it here does not reach them:
+            // a peer that goes on to its first exchange waits until its caller's watchdog ends it)
             (void) r.CommDestroy(c->comm);
+            if (c->setup_stream) (void) hipStreamDestroy(c->setup_stream);
+            (void) hipFree(c->st_send);
+            (void) hipFree(c->st_recv);
+            (void) hipGetLastError();
             return NULL;
         }
         spx_hip_transport_t *t = new spx_hip_transport_t;

@@ -897,6 +897,7 @@ struct DeviceMatrix {
     // empty: values where the stream has them)
     std::vector<size_t> val_orig_off, val_new_off;
     // column slices in one launch: per-row modes and the rows that several slices add to
+    bool launched_since_edit = true;      // a product was enqueued since the last set_entry (device_poke waits once)
     uint32_t *accum_rowmode = nullptr, *accum_shared_rows = nullptr;
     size_t n_accum_shared = 0;
     bool has_symsegs = false;     // the stream holds SPX_PASS_SYMSEG passes
@@ -1296,6 +1297,7 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
     if (hipGetDevice(&cur) != hipSuccess || cur != m->device)
         throw FatalError("the matrix lives on HIP device " + std::to_string(m->device) +
                          ", the calling thread's current device is " + std::to_string(cur));
+    m->launched_since_edit = true;
     KernelArgs a;
     a.rbs = m->rbs; a.values = m->values; a.descs = m->descs; a.passes = m->passes;
     a.cidx = m->cidx; a.segrows = m->segrows; a.x = d_x; a.y = d_y;
@@ -1489,6 +1491,7 @@ size_t device_plan_chunks(DeviceMatrix *m, size_t K, std::vector<size_t> &row_bo
 void device_spmv_chunk(DeviceMatrix *m, size_t k, double alpha, const double *d_x, double beta, double *d_y, void *stream_)
 {
     if (k >= m->chunk_split.size()) throw FatalError("no such part of the stream (device_plan_chunks)");
+    m->launched_since_edit = true;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const XcdSplit xs = m->chunk_split[k];
     const uint32_t blocks = 8u * m->chunk_longest[k];
@@ -1800,11 +1803,28 @@ void device_download(const DeviceMatrix *m, GpuStream &s)
     if (m->symmetric) download(s.dvalues, m->dvalues, m->nrows);
 }
 
+// Products enqueued on a non-blocking stream (spx_hip_matvec_*) are not ordered against a blocking
+// copy by themselves: before the first value changes after a product was enqueued, wait for whatever
+// the device still runs -- ONCE, not per entry (a client that refreshes every value through
+// spx_mat_set_entry would pay a device-wide wait per nonzero).  A stream of the device that is being
+// captured makes the wait fail: that is reported, the value is not touched.
+static void quiesce_before_edit(DeviceMatrix *m)
+{
+    if (!m->launched_since_edit) return;
+    const hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        (void) hipGetLastError();
+        throw FatalError(std::string("cannot change a value while the device cannot be waited for (") + hipGetErrorString(e) +
+                         "): is a stream being captured?");
+    }
+    m->launched_since_edit = false;
+}
+
 void device_poke_mirror(DeviceMatrix *m, size_t index, double value)
 {
     if (index >= m->n_mirror_nnz) throw FatalError("value index outside the mirror list");
     HIP_CHECK(hipSetDevice(m->device));
-    HIP_CHECK(hipDeviceSynchronize());     // (see device_poke)
+    quiesce_before_edit(m);
     HIP_CHECK(hipMemcpy(m->mirror_val + index, &value, sizeof(value), hipMemcpyHostToDevice));
 }
 
@@ -1832,9 +1852,7 @@ void device_poke(DeviceMatrix *m, bool diagonal, size_t index, double value)
     if (diagonal ? (!m->dvalues || index >= m->nrows) : index >= m->n_values)
         throw FatalError("value index outside the stream");
     HIP_CHECK(hipSetDevice(m->device));
-    // products enqueued on a non-blocking stream (spx_hip_matvec_*) are not ordered against
-    // this copy by themselves: wait for whatever the device still runs before the value changes
-    HIP_CHECK(hipDeviceSynchronize());
+    quiesce_before_edit(m);
     HIP_CHECK(hipMemcpy(diagonal ? m->dvalues + index : m->values + value_position(m, index), &value, sizeof(value),
                         hipMemcpyHostToDevice));
 }

@@ -363,6 +363,54 @@ bool stream_validate(const GpuStream &s, size_t nrows, size_t ncols, size_t n_va
     SPX_REQUIRE(s.rbs.empty() || s.pass_stride >= 1, "pass stride missing");
     SPX_REQUIRE(s.passes.size() == s.rbs.size() * (size_t) s.pass_stride, "pass table size");
     SPX_REQUIRE(s.waves == 2 || s.waves == 4 || s.waves == 8, "wavefronts per workgroup");
+    // row-block flags are not covered by anything else a file is checked against, and the kernels
+    // trust them: SPX_RB_ACCUM on every row-block or on none, with 2, 4 or 8 column slices; a
+    // SPX_RB_PRIVATE row-block (it STORES its rows) must be one nobody else adds to -- no slot group
+    // of any row-block, no slot-less read-once segment, no mirror list reaches its rows -- and must
+    // not be part of an over-long row
+    {
+        size_t n_accum = 0, n_phase = 0;
+        for (size_t i = 0; i < s.rbs.size(); ++i) {
+            n_accum += (s.rbs[i].flags & SPX_RB_ACCUM) ? 1 : 0;
+            n_phase += (i && (s.rbs[i].flags & SPX_RB_PHASE_START)) ? 1 : 0;
+        }
+        SPX_REQUIRE(n_accum == 0 || n_accum == s.rbs.size(), "column-slice flag on some row-blocks only");
+        SPX_REQUIRE(n_accum == 0 || n_phase == 1 || n_phase == 3 || n_phase == 7, "column slices in one launch: 2, 4 or 8");
+        bool any_private = false;
+        for (const SpxRowBlock &rb : s.rbs) any_private = any_private || (rb.flags & SPX_RB_PRIVATE);
+        if (any_private) {
+            std::vector<char> reached(nrows, 0);
+            for (uint32_t c : s.slot_group_col)
+                for (size_t k = 0; k < 8; ++k)
+                    if ((size_t) c + k < nrows) reached[(size_t) c + k] = 1;
+            for (uint32_t r : s.mirror_rows)
+                if (r < nrows) reached[r] = 1;
+            for (const SpxRowBlock &rb : s.rbs) {
+                SPX_REQUIRE((size_t) rb.pass_off + rb.n_pass <= s.passes.size(), "pass range");
+                for (uint32_t t = 0; t < rb.n_pass; ++t) {
+                    const SpxPass &ps = s.passes[(size_t) rb.pass_off + t];
+                    if (ps.kind != SPX_PASS_SYMSEG) continue;
+                    for (uint32_t l = 0; l < ps.nseg; ++l) {
+                        const uint32_t rank = (uint32_t) ps.rank0 + 2u * popcount_upto(spx_pass_mask(&ps), l);
+                        SPX_REQUIRE((size_t) rb.desc_off + rank + 1 < s.descs.size(), "descriptor range");
+                        int64_t r, c;
+                        uint32_t slot;
+                        unit_lane(s, rb, ps, l, r, c, &slot);
+                        if (slot != SPX_NO_SLOT) continue;
+                        for (uint32_t w = 0; w < ps.width; ++w)
+                            if (c + w >= 0 && (size_t)(c + w) < nrows) reached[(size_t)(c + w)] = 1;
+                    }
+                }
+            }
+            for (const SpxRowBlock &rb : s.rbs) {
+                if (!(rb.flags & SPX_RB_PRIVATE)) continue;
+                SPX_REQUIRE(!(rb.flags & SPX_RB_SHARED), "a row-block that stores its rows holds part of an over-long row");
+                for (uint32_t r = 0; r < rb.n_rows; ++r)
+                    SPX_REQUIRE((size_t) rb.row0 + r < nrows && !reached[(size_t) rb.row0 + r],
+                                "a row-block that stores its rows is added to by another one");
+            }
+        }
+    }
     SPX_REQUIRE(s.lds_doubles <= SPX_MAX_WIDE_SLOTS + SPX_MAX_WIDE_ROWS + SPX_MAX_XWIN, "LDS budget");
     SPX_REQUIRE(s.n_spill == 0 || (s.fix_ptr.size() == nrows + 1 && s.fix_idx.size() == s.n_spill),
                 "spill lists");

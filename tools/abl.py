@@ -71,7 +71,10 @@ def main():
         A.hip_matvec_mult(bench.ALPHA, x.data_ptr(), y.data_ptr(), st_)
         torch.cuda.synchronize()
         err = float(np.max(np.abs(y.cpu().numpy() - yc) / bound))
-        assert err <= 1.0 or os.environ.get("SPX_BENCH_ABLATION") == "1", "parity gate failed: %g" % err
+        ablation = os.environ.get("SPX_BENCH_ABLATION") == "1"
+        assert err <= 1.0 or ablation, "parity gate failed: %g" % err
+        if ablation:             # (a build that computes wrong results on purpose: the row says so)
+            name = "INVALID (ablation build, err / bound %.3g) %s" % (err, name)
         for _ in range(10):
             A.hip_matvec_mult(bench.ALPHA, x.data_ptr(), y.data_ptr(), st_)
         ts = []
