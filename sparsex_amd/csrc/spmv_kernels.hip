@@ -893,9 +893,6 @@ struct DeviceMatrix {
     bool accum = false;           // SPX_RB_ACCUM: the column slices run in one launch and add to y
     std::vector<uint32_t> launch_order;
     size_t band_stride = 0;
-    // ... and where the values of the stream's row-block o went (val_orig_off[o] -> val_new_off[o];
-    // empty: values where the stream has them)
-    std::vector<size_t> val_orig_off, val_new_off;
     // column slices in one launch: per-row modes and the rows that several slices add to
     bool launched_since_edit = true;      // a product was enqueued since the last set_entry (device_poke waits once)
     uint32_t *accum_rowmode = nullptr, *accum_shared_rows = nullptr;
@@ -1023,8 +1020,6 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
     std::vector<double> dv;                               // host copies that must live until the flush
     std::vector<SpxRowBlock> rbs_ordered;
     std::vector<SpxPass> passes_ordered;
-    std::vector<double> values_ordered;                   // band order: values and descriptors move with their row-blocks
-    std::vector<SpxUnitDesc> descs_ordered;
     place.put(&m->cidx, s.cidx, 64);
     place.put(&m->segrows, s.segrows, 80);
     place.put(&m->shared, s.shared);
@@ -1188,43 +1183,8 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
                 std::copy(s.passes.begin() + (size_t) order[i] * stride, s.passes.begin() + ((size_t) order[i] + 1) * stride,
                           passes.begin() + i * stride);
             }
-            // The values (and descriptors) of a row-block move with it: the XCD then still reads ONE
-            // ascending stream of values while its row-blocks walk the planes strip by strip (round 3
-            // reordered the headers only -- the values of a part were then read at 12 MB jumps, which
-            // cost more than the re-fetches of x it saved: profiles/r03/ablation.md section 8)
-            const size_t n = s.rbs.size();
-            bool ascending = true;
-            for (size_t i = 0; i + 1 < n; ++i)
-                ascending = ascending && s.rbs[i + 1].val_off >= s.rbs[i].val_off && s.rbs[i + 1].desc_off >= s.rbs[i].desc_off;
-            if (ascending && n) {
-                values_ordered.assign(s.values.size(), 0.0);
-                descs_ordered.resize(s.descs.size());
-                m->val_orig_off.resize(n + 1);
-                m->val_new_off.resize(n + 1);
-                for (size_t i = 0; i < n; ++i) m->val_orig_off[i] = s.rbs[i].val_off;
-                m->val_orig_off[n] = s.values.size();
-                size_t vat = s.rbs[0].val_off, dat = s.rbs[0].desc_off;
-                std::copy(s.values.begin(), s.values.begin() + (ptrdiff_t) vat, values_ordered.begin());
-                std::copy(s.descs.begin(), s.descs.begin() + (ptrdiff_t) dat, descs_ordered.begin());
-                for (size_t i = 0; i < n; ++i) {
-                    const size_t o = order[i];
-                    const size_t v0 = s.rbs[o].val_off, v1 = o + 1 < n ? s.rbs[o + 1].val_off : s.values.size();
-                    const size_t d0 = s.rbs[o].desc_off, d1 = o + 1 < n ? s.rbs[o + 1].desc_off : s.descs.size();
-                    std::copy(s.values.begin() + (ptrdiff_t) v0, s.values.begin() + (ptrdiff_t) v1, values_ordered.begin() + (ptrdiff_t) vat);
-                    std::copy(s.descs.begin() + (ptrdiff_t) d0, s.descs.begin() + (ptrdiff_t) d1, descs_ordered.begin() + (ptrdiff_t) dat);
-                    rbs[i].val_off = vat;
-                    rbs[i].desc_off = (uint32_t) dat;
-                    m->val_new_off[o] = vat;
-                    vat += v1 - v0;
-                    dat += d1 - d0;
-                }
-                m->val_new_off[n] = vat;
-                place.put(&m->values, values_ordered, 160);
-                place.put(&m->descs, descs_ordered, 8);
-            } else {
-                place.put(&m->values, s.values, 160);
-                place.put(&m->descs, s.descs, 8);
-            }
+            place.put(&m->values, s.values, 160);
+            place.put(&m->descs, s.descs, 8);
             place.put(&m->rbs, rbs);
             place.put(&m->passes, passes, stride + 6 * MAX_WAVES_PER_BLOCK);
             m->launch_order.swap(order);
@@ -1742,40 +1702,6 @@ void device_download(const DeviceMatrix *m, GpuStream &s)
         }
         s.rbs.swap(rbs);
         s.passes.swap(passes);
-        if (!m->val_new_off.empty()) {
-            const size_t n = s.rbs.size();
-            std::vector<double> values(s.values.size());
-            std::vector<SpxUnitDesc> descs(s.descs.size());
-            std::copy(s.values.begin(), s.values.begin() + (ptrdiff_t) m->val_orig_off[0], values.begin());
-            // (descriptors: the row-blocks' own offsets on the device are the new ones; the original
-            // ones follow from the lengths, in stream order)
-            size_t dat = n ? s.rbs[0].desc_off : 0;
-            {
-                size_t first = s.descs.size();
-                for (size_t o = 0; o < n; ++o) first = std::min<size_t>(first, s.rbs[o].desc_off);
-                dat = n ? first : 0;
-                std::copy(s.descs.begin(), s.descs.begin() + (ptrdiff_t) dat, descs.begin());
-            }
-            // length of every row-block's descriptors: to the next offset in DEVICE order
-            std::vector<std::pair<uint32_t, size_t>> by_dev;
-            for (size_t o = 0; o < n; ++o) by_dev.emplace_back(s.rbs[o].desc_off, o);
-            std::sort(by_dev.begin(), by_dev.end());
-            std::vector<size_t> dlen(n, 0);
-            for (size_t k = 0; k < n; ++k)
-                dlen[by_dev[k].second] = (k + 1 < n ? by_dev[k + 1].first : s.descs.size()) - by_dev[k].first;
-            for (size_t o = 0; o < n; ++o) {
-                const size_t len = m->val_orig_off[o + 1] - m->val_orig_off[o];
-                std::copy(s.values.begin() + (ptrdiff_t) m->val_new_off[o], s.values.begin() + (ptrdiff_t)(m->val_new_off[o] + len),
-                          values.begin() + (ptrdiff_t) m->val_orig_off[o]);
-                std::copy(s.descs.begin() + s.rbs[o].desc_off, s.descs.begin() + s.rbs[o].desc_off + (ptrdiff_t) dlen[o],
-                          descs.begin() + (ptrdiff_t) dat);
-                s.rbs[o].val_off = m->val_orig_off[o];
-                s.rbs[o].desc_off = (uint32_t) dat;
-                dat += dlen[o];
-            }
-            s.values.swap(values);
-            s.descs.swap(descs);
-        }
     }
     download(s.cidx, m->cidx, m->n_cidx);
     download(s.segrows, m->segrows, m->n_segrows);
@@ -1828,22 +1754,13 @@ void device_poke_mirror(DeviceMatrix *m, size_t index, double value)
     HIP_CHECK(hipMemcpy(m->mirror_val + index, &value, sizeof(value), hipMemcpyHostToDevice));
 }
 
-// position in HBM of value `index` of the stream (the band order moves values with their row-blocks)
-static size_t value_position(const DeviceMatrix *m, size_t index)
-{
-    if (m->val_new_off.empty() || index < m->val_orig_off.front()) return index;
-    const size_t o = (size_t)(std::upper_bound(m->val_orig_off.begin(), m->val_orig_off.end(), index) - m->val_orig_off.begin()) - 1;
-    if (o + 1 >= m->val_orig_off.size()) return index;
-    return m->val_new_off[o] + (index - m->val_orig_off[o]);
-}
-
 double device_peek(const DeviceMatrix *m, bool diagonal, size_t index)
 {
     if (diagonal ? (!m->dvalues || index >= m->nrows) : index >= m->n_values)
         throw FatalError("value index outside the stream");
     HIP_CHECK(hipSetDevice(m->device));
     double v = 0.0;
-    HIP_CHECK(hipMemcpy(&v, diagonal ? m->dvalues + index : m->values + value_position(m, index), sizeof(v), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(&v, (diagonal ? m->dvalues : m->values) + index, sizeof(v), hipMemcpyDeviceToHost));
     return v;
 }
 
@@ -1853,7 +1770,7 @@ void device_poke(DeviceMatrix *m, bool diagonal, size_t index, double value)
         throw FatalError("value index outside the stream");
     HIP_CHECK(hipSetDevice(m->device));
     quiesce_before_edit(m);
-    HIP_CHECK(hipMemcpy(diagonal ? m->dvalues + index : m->values + value_position(m, index), &value, sizeof(value),
+    HIP_CHECK(hipMemcpy((diagonal ? m->dvalues : m->values) + index, &value, sizeof(value),
                         hipMemcpyHostToDevice));
 }
 

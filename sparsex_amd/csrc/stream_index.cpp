@@ -203,7 +203,7 @@ void stream_accum_row_modes(GpuStream &s, size_t nrows)
     s.accum_rowmode.clear();
     s.accum_shared_rows.clear();
     const size_t n = s.rbs.size();
-    if (!n || !(s.rbs[0].flags & SPX_RB_ACCUM)) return;
+    if (!n || !(s.rbs[0].flags & SPX_RB_ACCUM) || getenv("SPX_NO_ROW_MODES")) return;      // (the variable: A/B against the plain form)
     // slice of every row-block; which slices hold a nonzero of every row
     std::vector<uint8_t> slice(n, 0), touched(nrows, 0);
     uint8_t k = 0;
