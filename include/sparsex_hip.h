@@ -290,6 +290,14 @@ typedef struct {
 } spx_hip_dist_halo_t;
 spx_error_t spx_hip_mat_dist_halo(const spx_matrix_t *A, spx_hip_dist_halo_t *halo);
 
+/* y <- alpha*A*x + beta*y in `parts` launches over consecutive parts of the rows (equal work each),
+ * one after the other on `stream`: what SPX_DIST_OVERLAP interleaves its rounds with, for a caller that
+ * wants to interleave communication of its own (or to measure what cutting the launch costs).  General
+ * path, plain streams; where the stream cannot be cut the product runs as one launch.  Returns the number
+ * of launches through *launched (may be NULL). */
+spx_error_t spx_hip_matvec_parts(spx_value_t alpha, const spx_matrix_t *A, const spx_value_t *x_dev,
+                                 spx_value_t beta, spx_value_t *y_dev, int parts, void *stream, int *launched);
+
 /* The rounds of the overlapped step (SPX_DIST_OVERLAP) of an attached matrix: round r moves, per
  * peer, the segment [off, off + cnt) of the halo send list (spx_hip_dist_halo_t::send_rows) out and
  * the segment of the halo receive list (recv_cols) in -- the entries that lie in part r of their

@@ -674,6 +674,17 @@ def _dist_halo(self):
             "send_rows": arr(h.send_rows, h.n_send), "send_off": arr(h.send_off, W), "send_cnt": arr(h.send_cnt, W)}
 
 
+def _hip_matvec_parts(self, alpha, x_ptr, beta, y_ptr, parts, stream=0):
+    """``spx_hip_matvec_parts``: the product in ``parts`` launches over consecutive parts of the rows."""
+    L = lib()
+    L.spx_hip_matvec_parts.argtypes = [C.c_double, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_void_p,
+                                       C.POINTER(C.c_int)]
+    n = C.c_int(0)
+    if L.spx_hip_matvec_parts(alpha, self.handle, x_ptr, beta, y_ptr, int(parts), stream, C.byref(n)) != SPX_SUCCESS:
+        raise SpxError("spx_hip_matvec_parts failed (see stderr)")
+    return n.value
+
+
 def _dist_rounds(self):
     """The rounds of the overlapped step as a list of dicts of [world] arrays (send_off, send_cnt,
     recv_off, recv_cnt): segments of the halo lists that travel in every round."""
@@ -704,4 +715,5 @@ Matrix.dist_attach = _dist_attach
 Matrix.dist_plan = _dist_plan
 Matrix.dist_halo = _dist_halo
 Matrix.dist_rounds = _dist_rounds
+Matrix.hip_matvec_parts = _hip_matvec_parts
 Matrix.hip_matvec_dist = _hip_matvec_dist

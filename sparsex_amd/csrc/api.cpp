@@ -1804,6 +1804,28 @@ spx_error_t spx_hip_matvec_kernel(spx_value_t alpha, const spx_matrix_t *A,
     return SPX_SUCCESS;
 }
 
+spx_error_t spx_hip_matvec_parts(spx_value_t alpha, const spx_matrix_t *A, const spx_value_t *x_dev,
+                                 spx_value_t beta, spx_value_t *y_dev, int parts, void *stream, int *launched)
+{
+    if (check_dev(A, x_dev, y_dev) != SPX_SUCCESS) return SPX_FAILURE;
+    try {
+        std::vector<size_t> bounds;
+        const size_t K = (A->symmetric || parts < 2) ? 0 : device_plan_chunks(A->dev, (size_t) parts, bounds);
+        if (K == 0) {
+            device_spmv(A->dev, alpha, x_dev, beta, y_dev, stream);
+        } else {
+            for (size_t k = 0; k < K; ++k) device_spmv_chunk(A->dev, k, alpha, x_dev, beta, y_dev, stream);
+            // (an attached plan keeps its own cut: put it back)
+            if (A->dist && A->dist->my_chunks) device_plan_chunks(A->dev, A->dist->my_chunks, bounds);
+        }
+        if (launched) *launched = K ? (int) K : 1;
+    } catch (const FatalError &e) {
+        SETERROR_1(SPX_ERR_TUNED_MAT, e.what.c_str());
+        return SPX_FAILURE;
+    }
+    return SPX_SUCCESS;
+}
+
 spx_error_t spx_hip_matvec_dist(spx_value_t alpha, const spx_matrix_t *A,
                                 const spx_value_t *x_dev, spx_value_t beta,
                                 spx_value_t *y_dev, int flags, void *stream)

@@ -76,7 +76,7 @@ struct GpuStream {
     uint32_t waves = 4;           // wavefronts per workgroup the kernel is launched with
     bool band_order = false;      // spx.gpu.band_order: launch order by strips across recurring bands of x (device side only)
     // column slices in one launch (SPX_RB_ACCUM): how every row of every row-block reaches y -- two bits
-    // per row, 32 words per row-block: 0 nothing to add (the slice holds no nonzero of the row), 1 STORE
+    // per row, SPX_ROWMODE_WORDS words per row-block: 0 nothing to add (the slice holds no nonzero of the row), 1 STORE
     // alpha * sum + beta * y (no other slice holds a nonzero of the row; rows without any nonzero belong
     // to the first slice), 2 ADD (several slices do: y <- beta * y goes first, over accum_shared_rows
     // only).  Derived from the stream (stream_accum_row_modes), not saved.

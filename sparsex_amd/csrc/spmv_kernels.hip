@@ -624,7 +624,7 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &x
         // slice holds nonzeros of is STORED (alpha * sum + beta * y: no pre-pass, no read-modify-write
         // at the memory side), a row shared with other slices is added to (csx_scale_rows_kernel has
         // put beta * y there), a row this slice has nothing of is left alone
-        const uint32_t *rm = a.slot_col + (size_t) rb_idx * 32u;
+        const uint32_t *rm = a.slot_col + (size_t) rb_idx * SPX_ROWMODE_WORDS;
         for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS) {
             const uint32_t mode = (rm[i >> 4] >> ((i & 15) * 2)) & 3u;
             const size_t g = (size_t) rb.row0 + i;
@@ -1161,7 +1161,7 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
             }
             if (!any) order.clear();
         }
-        if (order.empty() && m->accum && s.accum_rowmode.size() == s.rbs.size() * 32) {
+        if (order.empty() && m->accum && s.accum_rowmode.size() == s.rbs.size() * SPX_ROWMODE_WORDS) {
             place.put(&m->accum_rowmode, s.accum_rowmode);
             place.put(&m->accum_shared_rows, s.accum_shared_rows);
             m->n_accum_shared = s.accum_shared_rows.size();

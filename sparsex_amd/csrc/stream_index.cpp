@@ -226,10 +226,14 @@ void stream_accum_row_modes(GpuStream &s, size_t nrows)
     };
     for (size_t i = 0; i < n; ++i)
         rows_of(i, [&](size_t row) { if (row < nrows) touched[row] |= (uint8_t)(1u << slice[i]); });
-    s.accum_rowmode.assign(n * 32, 0);
+    s.accum_rowmode.assign(n * SPX_ROWMODE_WORDS, 0);
     for (size_t i = 0; i < n; ++i) {
         const SpxRowBlock &rb = s.rbs[i];
         const uint8_t me = (uint8_t)(1u << slice[i]);
+        if (rb.n_rows > SPX_MAX_WIDE_ROWS) {
+            s.accum_rowmode.clear();
+            return;
+        }
         for (uint32_t r = 0; r < rb.n_rows; ++r) {
             const size_t row = (size_t) rb.row0 + r;
             const uint8_t t = row < nrows ? touched[row] : 0;
@@ -237,7 +241,7 @@ void stream_accum_row_modes(GpuStream &s, size_t nrows)
             if (t == 0) mode = slice[i] == 0 ? 1u : 0u;         // nobody's: the first slice writes beta * y
             else if (!(t & me)) mode = 0;
             else mode = (t == me) ? 1u : 2u;
-            s.accum_rowmode[i * 32 + (r >> 4)] |= mode << ((r & 15u) * 2u);
+            s.accum_rowmode[i * SPX_ROWMODE_WORDS + (r >> 4)] |= mode << ((r & 15u) * 2u);
         }
     }
     // every row must be written exactly once: stored by one row-block, or cleared by the pass over
@@ -247,7 +251,7 @@ void stream_accum_row_modes(GpuStream &s, size_t nrows)
     for (size_t i = 0; i < n; ++i) {
         const SpxRowBlock &rb = s.rbs[i];
         for (uint32_t r = 0; r < rb.n_rows; ++r)
-            if (((s.accum_rowmode[i * 32 + (r >> 4)] >> ((r & 15u) * 2u)) & 3u) == 1u && (size_t) rb.row0 + r < nrows)
+            if (((s.accum_rowmode[i * SPX_ROWMODE_WORDS + (r >> 4)] >> ((r & 15u) * 2u)) & 3u) == 1u && (size_t) rb.row0 + r < nrows)
                 ++stores[(size_t) rb.row0 + r];
     }
     for (size_t row = 0; row < nrows; ++row) {

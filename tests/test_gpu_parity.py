@@ -375,3 +375,27 @@ def test_band_launch_order_keeps_the_product_and_the_stream(tmp_path):
     B.matvec_mult(0.5, x, y2)
     check_y((rp, ci, va, n), x, y2, 0.5)
     assert B.get_entry(row, int(ci[k])) == 3.5
+
+
+@pytest.mark.parametrize("parts", [2, 4, 7])
+def test_product_in_parts(parts):
+    """spx_hip_matvec_parts: the product in several launches over consecutive parts of the rows (what
+    the overlapped multi-GPU step interleaves its exchange rounds with): the same y, beta included."""
+    import torch
+    csr = synth.syn_nlpkkt_rows(40)
+    rp, ci, va, n = csr
+    A = tune(csr, {"spx.gpu.rowblock_elems": "1024", "spx.rt.nr_threads": "4"})
+    xh = synth.random_x(n)
+    x = torch.from_numpy(xh).cuda()
+    y0 = synth.random_x(n, seed=9)
+    y = torch.from_numpy(y0.copy()).cuda()
+    k = A.hip_matvec_parts(0.5, x.data_ptr(), -0.75, y.data_ptr(), parts, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert k == parts
+    check_y(csr, xh, y.cpu().numpy(), 0.5, -0.75, y0)
+    # a symmetric matrix is not cut: one launch, same product
+    S = tune(csr, {"spx.rt.nr_threads": "4"}, sym=True)
+    y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+    assert S.hip_matvec_parts(0.5, x.data_ptr(), 0.0, y.data_ptr(), parts, torch.cuda.current_stream().cuda_stream) == 1
+    torch.cuda.synchronize()
+    check_y(csr, xh, y.cpu().numpy(), 0.5)
