@@ -133,6 +133,8 @@ class Workload:
         self.name = args.workload
         self.mtx = args.mtx or mtx_for(args.workload)
         reorder = getattr(args, "dist_reorder", "none") if world > 1 else "none"
+        if reorder == "auto":
+            reorder = "rcm_owner" if (args.workload in SLICED and SLICED[args.workload] == "nlpkkt") or args.workload not in SLICED else "none"
         mode = {"rcm": sx.SPX_DIST_REORDER_RCM, "rcm_owner": sx.SPX_DIST_REORDER_RCM_OWNER}.get(reorder)
         self.reorder, self.reorder_seconds = reorder, 0.0
 
@@ -1146,9 +1148,11 @@ def main():
                     help="launch the steps of a batch one by one instead of replaying them as one hipGraph "
                          "(stream capture; the default on one GPU, where a step is kernels only)")
     ap.add_argument("--opt", action="append", default=[], help="extra option=value")
-    ap.add_argument("--dist-reorder", default="none", choices=["none", "rcm", "rcm_owner"],
+    ap.add_argument("--dist-reorder", default="auto", choices=["auto", "none", "rcm", "rcm_owner"],
                     help="several ranks: renumber the unknowns with spx_hip_dist_reorder before the rows are dealt "
-                         "(rank 0 computes the permutation from the pattern and broadcasts it)")
+                         "(rank 0 computes the permutation from the pattern and broadcasts it); auto = rcm_owner on "
+                         "several ranks -- P A P^T is the same operator, and a rank then reads a thin shell of its "
+                         "neighbours' unknowns instead of a whole slice (profiles/r04/slices_one_gpu_proxy_e240_raw.md)")
     args = ap.parse_args()
 
     import torch

@@ -509,7 +509,6 @@ static void emit_and_upload(spx_matrix_t *A)
     for (const SpxRowBlock &rb : gs.rbs) A->first_block_row = std::min<idx_t>(A->first_block_row, (idx_t) rb.row0);
     finalize_stream(gs, (size_t) A->nrows);
     if (sym) mark_private_rowblocks(gs, (size_t) A->nrows, A->own_lo, A->own_hi);
-    if (!sym && A->own_lo == 0 && A->own_hi == A->nrows) stream_accum_row_modes(gs, (size_t) A->nrows);
     std::vector<std::pair<uint32_t, uint32_t>>().swap(gs.direct_cols);
     gs.waves = (uint32_t) A->waves;
     gs.band_order = Config::instance().get_bool("spx.gpu.band_order");
@@ -1509,7 +1508,6 @@ spx_matrix_t *spx_mat_restore(const char *filename)
     A->full_colind = cfg.get_bool("spx.matrix.full_colind");
     if (A->symmetric && !gs->sym_fused) stream_touched_rows(*gs, A->own_lo, A->conflict_rows);
     if (A->own_lo > 0 || A->own_hi < A->nrows) stream_read_cols(*gs, A->own_lo, A->own_hi, (size_t) A->ncols, A->halo_cols);
-    if (!A->symmetric && A->own_lo == 0 && A->own_hi == A->nrows) stream_accum_row_modes(*gs, (size_t) A->nrows);
     A->first_block_row = A->own_lo;
     for (const SpxRowBlock &rb : gs->rbs) A->first_block_row = std::min<idx_t>(A->first_block_row, (idx_t) rb.row0);
     try {

@@ -75,13 +75,6 @@ struct GpuStream {
     uint32_t pass_stride = 0;
     uint32_t waves = 4;           // wavefronts per workgroup the kernel is launched with
     bool band_order = false;      // spx.gpu.band_order: launch order by strips across recurring bands of x (device side only)
-    // column slices in one launch (SPX_RB_ACCUM): how every row of every row-block reaches y -- two bits
-    // per row, SPX_ROWMODE_WORDS words per row-block: 0 nothing to add (the slice holds no nonzero of the row), 1 STORE
-    // alpha * sum + beta * y (no other slice holds a nonzero of the row; rows without any nonzero belong
-    // to the first slice), 2 ADD (several slices do: y <- beta * y goes first, over accum_shared_rows
-    // only).  Derived from the stream (stream_accum_row_modes), not saved.
-    std::vector<uint32_t> accum_rowmode;
-    std::vector<uint32_t> accum_shared_rows;
     bool arena = false;           // spx.gpu.arena: all arrays of the stream in one HBM allocation (device side only)
     // accounting
     size_t nnz_stored = 0;        // nonzeros held in `values` (without padding)

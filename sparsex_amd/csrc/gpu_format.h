@@ -193,7 +193,6 @@ typedef struct {
                              its own group of 8 / K XCDs, so that an XCD's L2 only ever sees 1 / K of x: every
                              row-block then ADDS its y tile to y (global atomics, coalesced by rows) on top of
                              a pass that put beta * y there.  Set on every row-block of such a stream        */
-#define SPX_ROWMODE_WORDS (SPX_MAX_WIDE_ROWS / 16)   /* u32 words of per-row write modes per row-block (two bits a row) */
 #define SPX_RB_PRIVATE 2u /* symmetric path, atomic hand-over: nobody else adds to the rows of
                              this row-block (no slot group of any row-block, no slot-less
                              read-once segment, no mirror list reaches them), so it STORES them,

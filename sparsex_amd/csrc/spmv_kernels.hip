@@ -619,23 +619,6 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &x
     // ---------------- write the owned rows ------------------------------------------------
     if (rb.flags & SPX_RB_SHARED) {
         if (threadIdx.x == 0) a.carry[rb.carry_slot] = tile[0];
-    } else if (ATOMIC && !SYM && a.slot_col) {
-        // column slices in one launch, per-row modes (stream_accum_row_modes): a row that only this
-        // slice holds nonzeros of is STORED (alpha * sum + beta * y: no pre-pass, no read-modify-write
-        // at the memory side), a row shared with other slices is added to (csx_scale_rows_kernel has
-        // put beta * y there), a row this slice has nothing of is left alone
-        const uint32_t *rm = a.slot_col + (size_t) rb_idx * SPX_ROWMODE_WORDS;
-        for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS) {
-            const uint32_t mode = (rm[i >> 4] >> ((i & 15) * 2)) & 3u;
-            const size_t g = (size_t) rb.row0 + i;
-            if (mode == 1u) {
-                double t = a.alpha * tile[i];
-                if (a.beta_priv != 0.0) t += a.beta_priv * a.y[g];
-                a.y[g] = t;
-            } else if (mode == 2u) {
-                atomicAdd(&a.y[g], a.alpha * tile[i]);
-            }
-        }
     } else if (ATOMIC) {
         if ((rb.flags & SPX_RB_PRIVATE) && a.dvalues_priv) {
             // nobody else adds to these rows (mark_private_rowblocks): stored, with the diagonal
@@ -813,13 +796,6 @@ __global__ void csx_scale_kernel(double *y, size_t lo, size_t hi, double beta)
     if (i < hi) y[i] = beta == 0.0 ? 0.0 : beta * y[i];
 }
 
-// ... or, with per-row modes, on the rows that several slices add to only
-__global__ void csx_scale_rows_kernel(double *y, const uint32_t *rows, size_t n, double beta)
-{
-    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) y[rows[i]] = beta == 0.0 ? 0.0 : beta * y[rows[i]];
-}
-
 // symmetric path, first step: y <- beta*y + alpha*diag(A)*x on the owned
 // rows, 0 elsewhere (the main kernel then accumulates; on several GPUs the
 // per-GPU vectors are summed afterwards)
@@ -893,10 +869,7 @@ struct DeviceMatrix {
     bool accum = false;           // SPX_RB_ACCUM: the column slices run in one launch and add to y
     std::vector<uint32_t> launch_order;
     size_t band_stride = 0;
-    // column slices in one launch: per-row modes and the rows that several slices add to
     bool launched_since_edit = true;      // a product was enqueued since the last set_entry (device_poke waits once)
-    uint32_t *accum_rowmode = nullptr, *accum_shared_rows = nullptr;
-    size_t n_accum_shared = 0;
     bool has_symsegs = false;     // the stream holds SPX_PASS_SYMSEG passes
     bool has_symtiles = false;    // ... SPX_PASS_SYMTILE passes
     bool wave_tiles = false;      // a y tile per wavefront, summed in wavefront order before the write-out
@@ -1161,11 +1134,6 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
             }
             if (!any) order.clear();
         }
-        if (order.empty() && m->accum && s.accum_rowmode.size() == s.rbs.size() * SPX_ROWMODE_WORDS) {
-            place.put(&m->accum_rowmode, s.accum_rowmode);
-            place.put(&m->accum_shared_rows, s.accum_shared_rows);
-            m->n_accum_shared = s.accum_shared_rows.size();
-        }
         if (order.empty()) {
             place.put(&m->values, s.values, 160);
             place.put(&m->descs, s.descs, 8);
@@ -1237,8 +1205,6 @@ void device_free(DeviceMatrix *m)
         if (m->mirror_ptr) (void) hipFree(m->mirror_ptr);
         if (m->mirror_col) (void) hipFree(m->mirror_col);
         if (m->mirror_val) (void) hipFree(m->mirror_val);
-        if (m->accum_rowmode) (void) hipFree(m->accum_rowmode);
-        if (m->accum_shared_rows) (void) hipFree(m->accum_shared_rows);
     }
     if (m->d_x) (void) hipFree(m->d_x);
     if (m->d_y) (void) hipFree(m->d_y);
@@ -1312,16 +1278,7 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
                                alpha, m->n_mirror_rows);
         a.beta = beta = 1.0;
     }
-    if (m->accum && !m->symmetric && m->accum_rowmode) {
-        // column slices in one launch, per-row modes: beta * y only where several slices add
-        const int t = 256;
-        if (m->n_accum_shared)
-            hipLaunchKernelGGL(csx_scale_rows_kernel, dim3((unsigned)((m->n_accum_shared + t - 1) / t)), dim3(t), 0, stream,
-                               d_y, m->accum_shared_rows, m->n_accum_shared, beta);
-        a.slot_col = m->accum_rowmode;
-        a.beta_priv = beta;
-        a.beta = beta = 1.0;
-    } else if (m->accum && !m->symmetric) {
+    if (m->accum && !m->symmetric) {
         // column slices in one launch: beta * y first, every row-block adds on top
         const int t = 256;
         const size_t lo = m->own_lo, hi = m->own_hi;

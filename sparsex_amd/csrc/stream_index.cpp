@@ -4,7 +4,6 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
-#include <functional>
 
 namespace spx {
 
@@ -196,73 +195,6 @@ void stream_read_cols(const GpuStream &s, idx_t own_lo, idx_t own_hi, size_t nco
     for (uint32_t c : s.mirror_col) hit((int64_t) c);
     for (size_t c = 0; c < ncols; ++c)
         if (mark[c] && ((idx_t) c < own_lo || (idx_t) c >= own_hi)) cols.push_back((idx_t) c);
-}
-
-void stream_accum_row_modes(GpuStream &s, size_t nrows)
-{
-    s.accum_rowmode.clear();
-    s.accum_shared_rows.clear();
-    const size_t n = s.rbs.size();
-    if (!n || !(s.rbs[0].flags & SPX_RB_ACCUM) || getenv("SPX_NO_ROW_MODES")) return;      // (the variable: A/B against the plain form)
-    // slice of every row-block; which slices hold a nonzero of every row
-    std::vector<uint8_t> slice(n, 0), touched(nrows, 0);
-    uint8_t k = 0;
-    for (size_t i = 0; i < n; ++i) {
-        if (i && (s.rbs[i].flags & SPX_RB_PHASE_START)) ++k;
-        slice[i] = k;
-    }
-    if (k >= 8) return;                                   // (at most eight slices: a bit each)
-    auto rows_of = [&](size_t i, const std::function<void(size_t)> &fn) {
-        const SpxRowBlock &rb = s.rbs[i];
-        for (uint32_t t = 0; t < rb.n_pass; ++t) {
-            const SpxPass &ps = s.passes[(size_t) rb.pass_off + t];
-            for (uint32_t l = 0; l < ps.nseg; ++l) {
-                int64_t r, c;
-                if (is_gather(ps)) r = SPX_SEGROW_ROW(s.segrows[(size_t) rb.seg_off + ps.seg0 + l]);
-                else unit_lane(s, rb, ps, l, r, c);
-                fn((size_t) rb.row0 + (size_t) r);
-            }
-        }
-    };
-    for (size_t i = 0; i < n; ++i)
-        rows_of(i, [&](size_t row) { if (row < nrows) touched[row] |= (uint8_t)(1u << slice[i]); });
-    s.accum_rowmode.assign(n * SPX_ROWMODE_WORDS, 0);
-    for (size_t i = 0; i < n; ++i) {
-        const SpxRowBlock &rb = s.rbs[i];
-        const uint8_t me = (uint8_t)(1u << slice[i]);
-        if (rb.n_rows > SPX_MAX_WIDE_ROWS) {
-            s.accum_rowmode.clear();
-            return;
-        }
-        for (uint32_t r = 0; r < rb.n_rows; ++r) {
-            const size_t row = (size_t) rb.row0 + r;
-            const uint8_t t = row < nrows ? touched[row] : 0;
-            uint32_t mode;
-            if (t == 0) mode = slice[i] == 0 ? 1u : 0u;         // nobody's: the first slice writes beta * y
-            else if (!(t & me)) mode = 0;
-            else mode = (t == me) ? 1u : 2u;
-            s.accum_rowmode[i * SPX_ROWMODE_WORDS + (r >> 4)] |= mode << ((r & 15u) * 2u);
-        }
-    }
-    // every row must be written exactly once: stored by one row-block, or cleared by the pass over
-    // the shared rows; a stream that does not guarantee it keeps the plain form (beta * y over all
-    // rows first, every row-block adds all of its rows)
-    std::vector<uint8_t> stores(nrows, 0);
-    for (size_t i = 0; i < n; ++i) {
-        const SpxRowBlock &rb = s.rbs[i];
-        for (uint32_t r = 0; r < rb.n_rows; ++r)
-            if (((s.accum_rowmode[i * SPX_ROWMODE_WORDS + (r >> 4)] >> ((r & 15u) * 2u)) & 3u) == 1u && (size_t) rb.row0 + r < nrows)
-                ++stores[(size_t) rb.row0 + r];
-    }
-    for (size_t row = 0; row < nrows; ++row) {
-        const bool shared = (touched[row] & (touched[row] - 1)) != 0;
-        if (shared) s.accum_shared_rows.push_back((uint32_t) row);
-        if ((shared && stores[row] != 0) || (!shared && stores[row] != 1)) {
-            s.accum_rowmode.clear();
-            s.accum_shared_rows.clear();
-            return;
-        }
-    }
 }
 
 void stream_locate_mirror(const GpuStream &s, idx_t row, idx_t col, std::vector<size_t> &out)

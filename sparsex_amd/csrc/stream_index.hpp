@@ -40,12 +40,6 @@ void stream_touched_rows(const GpuStream &s, idx_t below, std::vector<idx_t> &ro
 // threads share x); the closest is the column walk of its map, CsxBuild.hpp:432-451.
 void stream_read_cols(const GpuStream &s, idx_t own_lo, idx_t own_hi, size_t ncols, std::vector<idx_t> &cols);
 
-// Column slices in one launch (SPX_RB_ACCUM streams, after finalize_stream): fills
-// GpuStream::accum_rowmode / accum_shared_rows -- which rows a row-block stores, which it adds to,
-// which it leaves alone.  A row-block of such a stream owns <= 512 rows.  (Every row of the matrix
-// must lie in exactly one row-block of every slice that holds a nonzero of it, and in one of the first.)
-void stream_accum_row_modes(GpuStream &s, size_t nrows);
-
 // Launch order for matrices whose rows read x in bands that recur at a fixed row distance (a
 // 3-D stencil: the bands of the z-planes above and below; the distance S is N^2 rows).  Walking
 // the row-blocks of an XCD's part plane by plane, a band comes round again S rows -- some 190
