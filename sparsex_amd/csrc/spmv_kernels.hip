@@ -708,8 +708,12 @@ void csx_spmv_symseg_kernel(SPX_KERNEL_PARAMS)
 }
 
 // ... and the same for streams with such segments and no tiles at all (a stencil matrix)
+// (SPX_SYMSEG_NOTILE_ATTR: room for a kernel attribute, e.g. amdgpu_waves_per_eu, in a variant build)
+#ifndef SPX_SYMSEG_NOTILE_ATTR
+#define SPX_SYMSEG_NOTILE_ATTR
+#endif
 template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES)
+__global__ __launch_bounds__(64 * WAVES) SPX_SYMSEG_NOTILE_ATTR
 void csx_spmv_symseg_notile_kernel(SPX_KERNEL_PARAMS)
 {
     SPX_KERNEL_ARGS(a);
