@@ -68,6 +68,13 @@
  *                           tile and common slots, so that a column several of them reach is
  *                           handed to y once (default 1024, at most 2048; measured on syn-nlpkkt,
  *                           734 M nonzeros: 512 0.842 ms, 1024 0.826 ms, 2048 0.92 ms)
+ *   spx.gpu.arena           "true": every array of a tuned matrix in ONE HBM allocation (2 MB-aligned pieces)
+ *                           instead of one allocation each (default; the arena was built to test whether
+ *                           placement explains the run-to-run spread: it does not, profiles/r04/spread.md)
+ *   spx.rt.dist_reorder     the whole matrix given to every process of a multi-GPU job (spx.rt.gpu_world > 1):
+ *                           "rcm" | "rcm_owner" renumber the unknowns in front of the nonzero-balanced cut
+ *                           (spx_hip_dist_reorder below; spx_mat_get_perm returns the permutation); "none" (default)
+ *   spx.rt.dist_chunks      SPX_DIST_OVERLAP: parts the own product is cut into (default 4; 1: no rounds planned)
  *   spx.gpu.x_window        "false": leftovers never gather from an LDS window of x
  *   spx.vec.device          "true": vectors the library creates keep x's HBM copy
  *                           between spx_matvec_* calls
@@ -107,7 +114,9 @@ extern "C" {
  * of the symmetric tiles, the exchange buffers); different matrices are independent.
  * The calling thread's current HIP device must be the matrix's device (checked).
  * spx_mat_set_entry() on a tuned matrix patches the value where it lives, in HBM, after a
- * hipDeviceSynchronize(): products still in flight finish with the old value; a captured
+ * hipDeviceSynchronize() -- one per batch of edits, not per entry (the first edit after a product was
+ * enqueued waits; it fails, value untouched, while a stream of the device is being captured):
+ * products still in flight finish with the old value; a captured
  * graph replayed later reads the new one.
  * Once an exchange plan is attached (spx_hip_mat_dist_attach), the plain entry points above
  * write only the rows this process owns or adds to, [first conflict row, last owned row):
