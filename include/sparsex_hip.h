@@ -74,7 +74,8 @@
  *   spx.rt.dist_reorder     the whole matrix given to every process of a multi-GPU job (spx.rt.gpu_world > 1):
  *                           "rcm" | "rcm_owner" renumber the unknowns in front of the nonzero-balanced cut
  *                           (spx_hip_dist_reorder below; spx_mat_get_perm returns the permutation); "none" (default)
- *   spx.rt.dist_chunks      SPX_DIST_OVERLAP: parts the own product is cut into (default 4; 1: no rounds planned)
+ *   spx.rt.dist_chunks      SPX_DIST_OVERLAP: parts the own product is cut into (default 4; 1: no rounds planned --
+ *                           on every process or on none: planning the rounds is collective; the counts may differ)
  *   spx.gpu.x_window        "false": leftovers never gather from an LDS window of x
  *   spx.vec.device          "true": vectors the library creates keep x's HBM copy
  *                           between spx_matvec_* calls

@@ -71,7 +71,7 @@ def test_two_ranks_gloo(symmetric):
 
 # ---- the exchange plan of row-sliced matrices (BASELINE config 4's layout) --------------
 
-def _slice_worker(rank, world, port, symmetric, gen, tmpdir, ret):
+def _slice_worker(rank, world, port, symmetric, gen, tmpdir, ret, parts=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -99,6 +99,7 @@ def _slice_worker(rank, world, port, symmetric, gen, tmpdir, ret):
         sx.options_reset()
         for k, v in {"spx.rt.host_only": "true", "spx.preproc.sampling": "none",
                      "spx.rt.nr_threads": "2", "spx.rt.row_offset": lo, "spx.rt.global_rows": n,
+                     "spx.rt.dist_chunks": parts[rank] if parts else 4,
                      "spx.matrix.symmetric": "true" if symmetric else "false"}.items():
             sx.option_set(k, str(v))
         A = sx.mat_tune(sx.input_load_csr(rl, cl, vl, hi - lo, n))
@@ -151,7 +152,7 @@ def _slice_worker(rank, world, port, symmetric, gen, tmpdir, ret):
         # entry travels exactly once, and after the last round the halo is what the one-shot exchange brought
         rounds = A.dist_rounds()
         if not symmetric:
-            assert len(rounds) == 4
+            assert len(rounds) == (max(parts) if parts else 4)
             y2 = y.copy()
             y2[halo["recv_cols"]] = np.nan
             sendbuf = y[halo["send_rows"]].copy()
@@ -196,3 +197,18 @@ def test_row_slices_exchange_plan_gloo(tmp_path, world, symmetric, gen):
         # first ranks: still never more than the rows in front of the sender)
         limit = (lambda r: ret[r][2]) if gen == "nlpkkt" else (lambda r: ret[r][2] // 2)
         assert ret[0][1] == 0 and all(0 < ret[r][1] < limit(r) for r in range(1, world))
+
+
+def test_rounds_with_different_part_counts_gloo(tmp_path):
+    """The ranks may cut their products into different numbers of parts (a rank with few row-blocks
+    gets fewer): everybody takes part in as many rounds as the rank with the most parts, and every
+    halo entry still travels exactly once (checked inside the worker)."""
+    world = 3
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_slice_worker, args=(world, port, False, "nlpkkt", str(tmp_path), ret, [2, 5, 3]), nprocs=world, join=True)
+    assert all(ret[r][0] for r in range(world))
