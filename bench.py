@@ -1086,8 +1086,11 @@ def run_path(ctx, args, symmetric):
                      "kernel": kernel_name(info, symmetric, world),
                      "algorithmic_bytes_per_launch": int(b_alg),
                      "avg_launch_us": round(1e6 * launch_s, 3),
-                     # (the node's memory side has two speeds at identical reported clocks: profiles/r04/spread.md)
-                     "spread_group": (("fast (< 1.30 ms)" if launch_s < 1.30e-3 else "slow (>= 1.30 ms)")
+                     # (the same stream runs at different speeds on different nodes and at different times, at
+                     # identical reported clocks: profiles/r04/spread.md; the line says where this run lies)
+                     "spread_group": (("%.2f ms here; the boxes of round 4 ran this very stream in 1.19-1.40 ms (%s third of that "
+                                       "range; profiles/r04/spread.md)" % (1e3 * launch_s, "fastest" if launch_s < 1.26e-3 else (
+                                           "middle" if launch_s < 1.33e-3 else "slowest")))
                                       if world == 1 and not symmetric and args.workload == "syn-nlpkkt" and args.edge == DEFAULT_EDGE
                                       and not wl.mtx else None),
                      "cache_resident": bool(info.value_bytes + info.index_bytes < MALL_BYTES),
