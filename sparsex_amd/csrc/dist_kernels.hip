@@ -178,7 +178,17 @@ void dist_device_set_rounds(DistDevice *d, const DistPlan &p)
     d->rd_pack_ptr = p.rd_pack_ptr;
     d->rd_scat_ptr = p.rd_scat_ptr;
     if (!d->comm) {
-        HIP_CHECK(hipStreamCreateWithFlags(&d->comm, hipStreamNonBlocking));
+        // (highest priority: its pack / copy / scatter kernels are tiny and must not queue behind the
+        // thousands of workgroups of the product part that runs next to them)
+        int pri_lo = 0, pri_hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&pri_lo, &pri_hi) != hipSuccess) {
+            (void) hipGetLastError();
+            pri_hi = 0;
+        }
+        if (hipStreamCreateWithPriority(&d->comm, hipStreamNonBlocking, pri_hi) != hipSuccess) {
+            (void) hipGetLastError();
+            HIP_CHECK(hipStreamCreateWithFlags(&d->comm, hipStreamNonBlocking));
+        }
         HIP_CHECK(hipEventCreateWithFlags(&d->ev_part, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&d->ev_done, hipEventDisableTiming));
     }
