@@ -1814,7 +1814,7 @@ spx_error_t spx_hip_matvec_parts(spx_value_t alpha, const spx_matrix_t *A, const
         } else {
             for (size_t k = 0; k < K; ++k) device_spmv_chunk(A->dev, k, alpha, x_dev, beta, y_dev, stream);
             // (an attached plan keeps its own cut: put it back)
-            if (A->dist && A->dist->my_chunks) device_plan_chunks(A->dev, A->dist->my_chunks, bounds);
+            if (A->dist && A->dist->my_chunks && A->dist->my_chunks != K) device_plan_chunks(A->dev, A->dist->my_chunks, bounds);
         }
         if (launched) *launched = K ? (int) K : 1;
     } catch (const FatalError &e) {

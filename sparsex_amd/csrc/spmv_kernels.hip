@@ -908,6 +908,8 @@ struct DeviceMatrix {
     std::vector<uint32_t> rb_row0;
     std::vector<XcdSplit> chunk_split;
     std::vector<uint32_t> chunk_longest;
+    std::vector<size_t> chunk_bounds;
+    size_t chunk_asked = 0;
 };
 
 int device_count()
@@ -1371,9 +1373,14 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
 // first row of every part (+ the end) in `row_bounds`.
 size_t device_plan_chunks(DeviceMatrix *m, size_t K, std::vector<size_t> &row_bounds)
 {
+    if (K >= 2 && K == m->chunk_asked && !m->chunk_split.empty()) {      // (the same cut as last time)
+        row_bounds = m->chunk_bounds;
+        return m->chunk_split.size();
+    }
     row_bounds.clear();
     m->chunk_split.clear();
     m->chunk_longest.clear();
+    m->chunk_asked = K;
     const size_t n = m->n_rb;
     if (m->symmetric || m->accum || m->n_shared || m->xcd_split.size() != 1 || !m->launch_order.empty() ||
         m->wave_tiles || n < 64 || K < 2 || m->rb_upto.size() != n + 1)
@@ -1406,6 +1413,7 @@ size_t device_plan_chunks(DeviceMatrix *m, size_t K, std::vector<size_t> &row_bo
     }
     row_bounds[0] = m->own_lo;
     row_bounds.push_back(m->own_hi);
+    m->chunk_bounds = row_bounds;
     return K;
 }
 
