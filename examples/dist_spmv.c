@@ -104,6 +104,27 @@ int main(int argc, char **argv)
     }
     printf("rank %d of %d: rows [%ld, %ld), %ld nonzeros, max |y - exact| = %.3e\n", rank, world, lo, hi, nnz, err);
 
+    /* an iteration x <- y does not need all of y on every rank: SPX_DIST_HALO_X brings, besides the own rows,
+       exactly the entries of the others' rows that THIS rank's rows read (here: BAND entries on either side) */
+    spx_hip_dist_halo_t halo;
+    if (spx_hip_mat_dist_halo(A, &halo) != SPX_SUCCESS) return 1;
+    spx_hip_vec_init(y, -7.0, NULL);
+    if (spx_hip_matvec_dist(1.0, A, spx_hip_vec_data(x), 0.0, spx_hip_vec_data(y), SPX_DIST_HALO_X | SPX_DIST_OVERLAP,
+                            NULL) != SPX_SUCCESS)
+        return 1;
+    spx_hip_vec_download(y, yh, NULL);
+    double err_h = 0.0;
+    for (long k = -1; k < halo.n_recv + rows; k++) {
+        const long i = k < 0 ? lo : (k < halo.n_recv ? (long) halo.recv_cols[k] : lo + (k - halo.n_recv));
+        double want = 0.0;
+        for (long j = i - BAND; j <= i + BAND; j++)
+            if (j >= 0 && j < n) want += entry(i, j);
+        err_h = fmax(err_h, fabs(yh->elements[i] - want));
+    }
+    printf("rank %d of %d: halo of x: %ld entries received, %ld sent; max |y - exact| on own rows + halo = %.3e\n", rank,
+           world, (long) halo.n_recv, (long) halo.n_send, err_h);
+    err = fmax(err, err_h);
+
     spx_hip_vec_destroy(x);
     spx_hip_vec_destroy(y);
     spx_vec_destroy(yh);
