@@ -792,14 +792,7 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     A->emit_params.sym_once = cfg.get_bool("spx.gpu.sym_once");
     A->emit_params.recut_linear = cfg.get_bool("spx.gpu.recut_linear");
     A->emit_params.keep_units = cfg.get_bool("spx.gpu.keep_units");
-    {
-        const std::string m = cfg.get_str("spx.gpu.inline_desc");
-        if (m != "true" && m != "false" && m != "folded") {
-            log_msg(LOG_ERR, "spx.gpu.inline_desc: true, false or folded\n");
-            throw FatalError("bad spx.gpu.inline_desc");
-        }
-        A->emit_params.inline_desc = m == "folded" ? 2 : (m == "true" ? 1 : 0);
-    }
+    A->emit_params.inline_desc = cfg.get_bool("spx.gpu.inline_desc");
     A->emit_params.x_window = cfg.get_bool("spx.gpu.x_window");
     {
         const std::string m = cfg.get_str("spx.gpu.sym_segments");

@@ -45,7 +45,7 @@ struct Group {
 
 class RbBuilder {
 public:
-    RbBuilder(const Partition &p, GpuStream &out, bool stack = true, bool x_window = true, int inline_desc = 1)
+    RbBuilder(const Partition &p, GpuStream &out, bool stack = true, bool x_window = true, bool inline_desc = true)
         : p_(p), out_(out), stack_(stack), x_window_(x_window), inline_desc_(inline_desc) {}
 
     // rows [lo, hi) of the partition with what the planner cut out for them
@@ -106,7 +106,7 @@ private:
     GpuStream &out_;
     bool stack_;
     bool x_window_;
-    int inline_desc_;     // 0: descriptors loaded, 1: in the pass header, 2: folded onto lane 0 (general unit passes)
+    bool inline_desc_;
     std::vector<Group> groups_;
     std::vector<val_t> gvals_;
     std::vector<idx_t> slot_groups_;   // first columns of the row-block's slot groups (ascending)
@@ -339,10 +339,6 @@ void RbBuilder::emit_unit_passes(SpxRowBlock &rb, bool sym, uint32_t row_base)
             const SpxUnitDesc &d = out_.descs[(size_t) rb.desc_off + ps.rank0];
             ps.mask = (uint64_t) d.col0 | ((uint64_t) d.bits << 32);
             ps.flags |= SPX_PASSF_INLINE;
-            if (inline_desc_ == 2 && !sym && ps.elem0 + (d.bits & 511u) + 64u * 127u < 4096u + 64u * 127u) {
-                ps.mask = spx_fold_desc(d.col0, d.bits, ps.seg0, ps.elem0);
-                ps.flags |= SPX_PASSF_FOLDED;
-            }
         }
         out_.passes.push_back(ps);
         ++rb.n_pass;

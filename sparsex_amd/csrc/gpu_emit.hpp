@@ -108,7 +108,7 @@ struct GpuEmitParams {
                                   // rows share one descriptor as a dense block
     bool recut_linear = true;     // spx.gpu.recut_linear: nonzeros of vertical / diagonal /
                                   // strided units that line up along their rows run as row segments
-    int inline_desc = 1;          // spx.gpu.inline_desc: 0 false, 1 true (SPX_PASSF_INLINE), 2 folded (+ SPX_PASSF_FOLDED)
+    bool inline_desc = true;      // spx.gpu.inline_desc: SPX_PASSF_INLINE
     bool keep_units = true;       // spx.gpu.keep_units: ... but a mined unit none of whose nonzeros has a
                                   // neighbour along its row stays the unit it is (one descriptor)
     bool sym_remine = true;       // spx.gpu.sym_remine (see append_sym_expanded)

@@ -132,11 +132,6 @@ static inline uint32_t spx_desc_bits(uint32_t row0, uint32_t sstart, uint32_t ki
                                 and x addresses without waiting for a descriptor load: one dependent round
                                 trip per pass instead of two (the descriptor is in `descs` as well, where the
                                 host-side decoders keep reading it)                                      */
-#define SPX_PASSF_FOLDED 2u  /* with SPX_PASSF_INLINE (general unit passes): `mask` holds that descriptor already
-                                APPLIED to lane 0 of this pass -- column of lane 0 (bits 0-31), row of lane 0 relative
-                                to the row-block, elem0 included (bits 32-43), rows per lane (bits 44-51), columns per
-                                lane + 128 (bits 52-59) -- so that the wavefront forms row = r0 + l * drow and
-                                col = c0 + l * dcol without decoding kind, step and segment numbers (spx_fold_desc)  */
 typedef struct {
     uint64_t mask;       /* unit pass, bit l: lane l's segment starts a new unit;
                             bit 0 is never set.  SPX_PASSF_INLINE: the pass' only
@@ -220,20 +215,6 @@ static inline uint32_t spx_pass_value_index(uint32_t lane, uint32_t w, uint32_t 
     uint32_t pair = w >> 1;
     if ((width & 1u) && w == width - 1u) return pair * 2u * nseg + lane;
     return pair * 2u * nseg + lane * 2u + (w & 1u);
-}
-
-/* the folded form of descriptor d for a pass whose lane 0 is segment seg0 (SPX_PASSF_FOLDED) */
-static inline uint64_t spx_fold_desc(uint32_t col0, uint32_t bits, uint32_t seg0, uint32_t elem0)
-{
-    const int s0 = (int) ((seg0 - ((bits >> 9) & 8191u)) & 0xffffu);
-    const uint32_t kind = (bits >> 22) & 7u;
-    const int step = (int) (bits >> 25);
-    const int drow = kind == SPX_KIND_BLOCK ? 1 : (kind >= SPX_KIND_VERT ? step : 0);
-    const int dcol = (kind == SPX_KIND_HORIZ || kind == SPX_KIND_DIAG) ? step : (kind == SPX_KIND_ADIAG ? -step : 0);
-    const uint32_t r0 = elem0 + (bits & 511u) + (uint32_t) (s0 * drow);
-    const uint32_t c0 = col0 + (uint32_t) (s0 * dcol);
-    const uint32_t hi = (r0 & 4095u) | ((uint32_t) drow << 12) | ((uint32_t) (dcol + 128) << 20);
-    return (uint64_t) c0 | ((uint64_t) hi << 32);
 }
 
 /* the start mask of a unit pass (an inline descriptor stands for "no starts") */

@@ -185,26 +185,6 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
                 const double xv = xp[goff[b][w]];
                 x[b][w] = w < len ? xv : 0.0;
             }
-        } else if (ps[b].flags & SPX_PASSF_FOLDED) {
-            // the pass' only descriptor, already applied to lane 0 (wave-uniform, in SGPRs): row and
-            // first column are one multiply-add each
-            const uint32_t hi = (uint32_t) (ps[b].mask >> 32);
-            row[b] = (int) (hi & 4095u) + (int) l[b] * (int) ((hi >> 12) & 255u);
-            const uint32_t col = (uint32_t) ps[b].mask + (uint32_t) ((int) l[b] * ((int) ((hi >> 20) & 255u) - 128));
-            const double *xp = a.x + col;
-            if (W >= 2) {
-                const spx_d2u_t *xp2 = reinterpret_cast<const spx_d2u_t *>(xp);
-#pragma unroll
-                for (int p = 0; p < W / 2; ++p) {
-                    const spx_d2u_t xx = xp2[p];
-                    x[b][2 * p] = xx.x;
-                    x[b][2 * p + 1] = xx.y;
-                }
-                if (W & 1) x[b][W - 1] = xp[W - 1];
-            } else {
-#pragma unroll
-                for (int w = 0; w < W; ++w) x[b][w] = xp[w];
-            }
         } else {
             // segment index inside its unit, then its row / first column
             const uint32_t bits = q[b].y;

@@ -426,14 +426,10 @@ bool stream_validate(const GpuStream &s, size_t nrows, size_t ncols, size_t n_va
                 SPX_REQUIRE(ps.kind == SPX_PASS_UNIT || sym, "pass kind");
                 SPX_REQUIRE(!sym || s.sym_atomic, "read-once segments without the atomic hand-over");
                 SPX_REQUIRE((spx_pass_mask(&ps) & 1ull) == 0, "segment-start mask");
-                SPX_REQUIRE(!(ps.flags & SPX_PASSF_FOLDED) || ((ps.flags & SPX_PASSF_INLINE) && !sym), "folded descriptor on the wrong pass");
                 SPX_REQUIRE(!(ps.flags & SPX_PASSF_INLINE) ||
                             ((size_t) rb.desc_off + ps.rank0 < s.descs.size() &&
-                             ps.mask == ((ps.flags & SPX_PASSF_FOLDED)
-                                             ? spx_fold_desc(s.descs[(size_t) rb.desc_off + ps.rank0].col0,
-                                                             s.descs[(size_t) rb.desc_off + ps.rank0].bits, ps.seg0, ps.elem0)
-                                             : ((uint64_t) s.descs[(size_t) rb.desc_off + ps.rank0].col0 |
-                                                ((uint64_t) s.descs[(size_t) rb.desc_off + ps.rank0].bits << 32)))),
+                             ps.mask == ((uint64_t) s.descs[(size_t) rb.desc_off + ps.rank0].col0 |
+                                         ((uint64_t) s.descs[(size_t) rb.desc_off + ps.rank0].bits << 32))),
                             "inline descriptor");
                 const uint32_t last = (uint32_t) ps.rank0 + (sym ? 2u : 1u) * popcount_upto(spx_pass_mask(&ps), nseg - 1) + (sym ? 1u : 0u);
                 SPX_REQUIRE((size_t) rb.desc_off + last < s.descs.size(), "descriptor range");

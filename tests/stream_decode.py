@@ -82,19 +82,7 @@ class Stream:
                     sym = ps["kind"] == 5
                     nseg, W, mask = int(ps["nseg"]), int(ps["width"]), int(ps["mask"])
                     inline = bool(int(ps["flags"]) & 1)   # the pass' only descriptor sits in its header (`mask`)
-                    if inline and int(ps["flags"]) & 2:
-                        # folded: the header holds the descriptor applied to lane 0 of this pass
-                        one = self.descs[int(rb["desc_off"]) + int(ps["rank0"]):int(rb["desc_off"]) + int(ps["rank0"]) + 1].copy()
-                        b0 = int(one["bits"][0])
-                        s0 = (int(ps["seg0"]) - ((b0 >> 9) & 8191)) & 0xffff
-                        k0, st0 = (b0 >> 22) & 7, b0 >> 25
-                        dr0 = 1 if k0 == KIND_BLOCK else (st0 if k0 >= KIND_VERT else 0)
-                        dc0 = st0 if k0 in (KIND_HORIZ, KIND_DIAG) else (-st0 if k0 == KIND_ADIAG else 0)
-                        r0 = int(ps["elem0"]) + (b0 & 511) + s0 * dr0
-                        c0 = (int(one["col0"][0]) + s0 * dc0) & 0xffffffff
-                        assert not sym and mask == (c0 | (((r0 & 4095) | (dr0 << 12) | ((dc0 + 128) << 20)) << 32)), "folded descriptor differs"
-                        mask = 0
-                    elif inline:
+                    if inline:
                         one = np.zeros(1, dtype=DESC)
                         one["col0"], one["bits"] = mask & 0xffffffff, mask >> 32
                         assert one[0] == self.descs[int(rb["desc_off"]) + int(ps["rank0"])], "inline descriptor differs"

@@ -399,23 +399,3 @@ def test_product_in_parts(parts):
     assert S.hip_matvec_parts(0.5, x.data_ptr(), 0.0, y.data_ptr(), parts, torch.cuda.current_stream().cuda_stream) == 1
     torch.cuda.synchronize()
     check_y(csr, xh, y.cpu().numpy(), 0.5)
-
-
-@pytest.mark.parametrize("name,gen", [("nlpkkt", lambda: synth.syn_nlpkkt_rows(70)), ("cant", lambda: synth.syn_cant(0.3)),
-                                      ("kkt2f", lambda: synth.syn_kkt2f_rows(40))], ids=["nlpkkt", "cant", "kkt2f"])
-def test_folded_inline_descriptors(name, gen):
-    """spx.gpu.inline_desc=folded: single-descriptor unit passes carry their descriptor already applied to
-    lane 0 (row and column of lane 0, steps per lane): the same product as with the descriptor as it is."""
-    csr = gen()
-    n = csr[3]
-    A = tune(csr, {"spx.gpu.inline_desc": "folded", "spx.rt.nr_threads": "4"})
-    x = synth.random_x(n)
-    y = np.full(n, np.nan)
-    A.matvec_mult(0.5, x, y)
-    check_y(csr, x, y, 0.5)
-    yo, _ = oracle_y(A, x, 0.5)
-    check_vs_oracle(csr, x, y, yo, 0.5)
-    y0 = synth.random_x(n, seed=3)
-    y1 = y0.copy()
-    A.matvec_kernel(1.5, x, -0.25, y1)
-    check_y(csr, x, y1, 1.5, -0.25, y0)
