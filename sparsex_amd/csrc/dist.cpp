@@ -316,13 +316,21 @@ void dist_step_overlapped(DistPlan *p, DeviceMatrix *m, double alpha, const doub
     const spx_hip_transport_t &t = p->transport;
     if (!p->rounds || !p->dev) throw FatalError("no overlapped step planned for this matrix");
     void *comm = dist_device_comm_stream(p->dev);
-    for (size_t r = 0; r < p->rounds; ++r) {
+    // Part r + 1 is enqueued BEFORE round r's exchange is issued: a transport that blocks the host (the
+    // callback transports of the tests stage through host memory) then still has the GPU computing the
+    // next part while it moves the last one's halo; with RCCL both are only enqueued anyway.
+    auto launch_part = [&](size_t r) {
         if (p->my_chunks == 0) {
             if (r == 0) device_spmv(m, alpha, d_x, beta, d_y, stream);
         } else if (r < p->my_chunks) {
             device_spmv_chunk(m, r, alpha, d_x, beta, d_y, stream);
         }
-        dist_device_round_begin(p->dev, r, stream);
+        dist_device_part_done(p->dev, r, stream);          // (an event per part on the launch stream)
+    };
+    launch_part(0);
+    for (size_t r = 0; r < p->rounds; ++r) {
+        if (r + 1 < p->rounds) launch_part(r + 1);
+        dist_device_round_begin(p->dev, r);                // the second stream waits for part r
         dist_device_round_pack(p->dev, r, d_y);
         if (t.exchange_device(t.ctx, dist_device_halo_sendbuf(p->dev), p->rd_send_off[r].data(), p->rd_send_cnt[r].data(),
                               dist_device_halo_recvbuf(p->dev), p->rd_recv_off[r].data(), p->rd_recv_cnt[r].data(),

@@ -80,7 +80,8 @@ void dist_device_halo_scatter(DistDevice *d, double *d_y, void *stream);
 // overlapped step: round lists on the device, the second stream and its events
 void dist_device_set_rounds(DistDevice *d, const DistPlan &p);
 void *dist_device_comm_stream(DistDevice *d);
-void dist_device_round_begin(DistDevice *d, size_t round, void *main_stream);   // comm stream waits for the part just launched
+void dist_device_part_done(DistDevice *d, size_t part, void *main_stream);     // records the part's event on the launch stream
+void dist_device_round_begin(DistDevice *d, size_t round);                      // the second stream waits for that part
 void dist_device_round_pack(DistDevice *d, size_t round, const double *d_y);
 void dist_device_round_scatter(DistDevice *d, size_t round, double *d_y);
 void dist_device_rounds_end(DistDevice *d, void *main_stream);                    // main stream waits for the last round

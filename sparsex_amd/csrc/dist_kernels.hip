@@ -49,7 +49,8 @@ struct DistDevice {
     uint32_t *rd_pack_pos = nullptr, *rd_scat_pos = nullptr;
     std::vector<size_t> rd_pack_ptr, rd_scat_ptr;
     hipStream_t comm = nullptr;
-    hipEvent_t ev_part = nullptr, ev_done = nullptr;
+    std::vector<hipEvent_t> ev_part;      // one per part of the product
+    hipEvent_t ev_done = nullptr;
 };
 
 // sendbuf[k] = y[send_rows[k]]: the sums this process formed for rows of others
@@ -129,7 +130,7 @@ void dist_device_free(DistDevice *d)
     (void) hipFree(d->halo_send_rows); (void) hipFree(d->halo_cols);
     (void) hipFree(d->halo_sendbuf); (void) hipFree(d->halo_recvbuf);
     (void) hipFree(d->rd_pack_pos); (void) hipFree(d->rd_scat_pos);
-    if (d->ev_part) (void) hipEventDestroy(d->ev_part);
+    for (hipEvent_t e : d->ev_part) (void) hipEventDestroy(e);
     if (d->ev_done) (void) hipEventDestroy(d->ev_done);
     if (d->comm) (void) hipStreamDestroy(d->comm);
     delete d;
@@ -189,18 +190,26 @@ void dist_device_set_rounds(DistDevice *d, const DistPlan &p)
             (void) hipGetLastError();
             HIP_CHECK(hipStreamCreateWithFlags(&d->comm, hipStreamNonBlocking));
         }
-        HIP_CHECK(hipEventCreateWithFlags(&d->ev_part, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&d->ev_done, hipEventDisableTiming));
+    }
+    while (d->ev_part.size() < p.rounds) {
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        d->ev_part.push_back(e);
     }
 }
 
 void *dist_device_comm_stream(DistDevice *d) { return d->comm; }
 double *dist_device_halo_sendbuf(DistDevice *d) { return d->halo_sendbuf; }
 
-void dist_device_round_begin(DistDevice *d, size_t, void *main_stream)
+void dist_device_part_done(DistDevice *d, size_t part, void *main_stream)
 {
-    HIP_CHECK(hipEventRecord(d->ev_part, static_cast<hipStream_t>(main_stream)));
-    HIP_CHECK(hipStreamWaitEvent(d->comm, d->ev_part, 0));
+    HIP_CHECK(hipEventRecord(d->ev_part.at(part), static_cast<hipStream_t>(main_stream)));
+}
+
+void dist_device_round_begin(DistDevice *d, size_t round)
+{
+    HIP_CHECK(hipStreamWaitEvent(d->comm, d->ev_part.at(round), 0));
 }
 
 void dist_device_round_pack(DistDevice *d, size_t r, const double *d_y)
