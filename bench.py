@@ -1004,11 +1004,22 @@ def run_path(ctx, args, symmetric):
     if world > 1:
         w_owned, _, _, _ = time_batches(torch, step_owned, args.steps, barrier, reduce_max, False)
         w_gather, _, _, _ = time_batches(torch, step_gather, args.steps, barrier, reduce_max, False)
-        w_plain = wall if FULL == sx.SPX_DIST_HALO_X else time_batches(torch, step_halo_plain, args.steps, barrier, reduce_max, False)[0]
+        w_plain, walls_plain = wall, walls
+        if FULL != sx.SPX_DIST_HALO_X:
+            w_plain, _, _, walls_plain = time_batches(torch, step_halo_plain, args.steps, barrier, reduce_max, False)
         w_local, d_local, _, _ = time_batches(torch, step_local, args.steps, barrier, reduce_max, False)
         launch_s = d_local / args.steps       # the roofline is the kernels' (HIP events, this rank)
         gf = lambda w: round(2.0 * wl.nnz * args.steps / w / 1e9, 2)
-        collective = {"full_step_gflops": gf(wall), "owned_rows_only_gflops": gf(w_owned),
+        # the halo step in rounds behind the parts of the product and the same exchange after the whole
+        # product leave the ranks in the same state: a caller picks the faster, so does `value`
+        w_rounds = wall
+        step_form = "halo exchange in rounds behind the parts of the product (SPX_DIST_HALO_X | SPX_DIST_OVERLAP)" \
+            if FULL != sx.SPX_DIST_HALO_X else "halo exchange after the product (SPX_DIST_HALO_X)"
+        if w_plain < wall:
+            wall, walls = w_plain, walls_plain
+            step_form = "halo exchange after the whole product (SPX_DIST_HALO_X; measured faster than in rounds)"
+        collective = {"full_step_gflops": gf(wall), "owned_rows_only_gflops": gf(w_owned), "full_step_form": step_form,
+                      "halo_step_in_rounds_ms": round(1e3 * w_rounds / args.steps, 5),
                       "gather_y_step_gflops": gf(w_gather), "kernels_only_gflops": gf(w_local),
                       "full_step_ms": round(1e3 * wall / args.steps, 5),
                       "owned_rows_only_ms": round(1e3 * w_owned / args.steps, 5),
@@ -1035,7 +1046,8 @@ def run_path(ctx, args, symmetric):
             "conflict_rows_sent": int(plan["send_rows"].size) if world > 1 else 0,
             "conflict_entries_received": int(plan["n_recv"]) if world > 1 else 0,
             "halo_entries_received": int(halo["recv_cols"].size) if world > 1 else 0,
-            "halo_entries_sent": int(halo["send_rows"].size) if world > 1 else 0}
+            "halo_entries_sent": int(halo["send_rows"].size) if world > 1 else 0,
+            "overlap_parts": A.dist_parts() if world > 1 else 0}
     per_rank = [mine]
     if world > 1:
         per_rank = [None] * world

@@ -314,6 +314,7 @@ spx_error_t spx_hip_matvec_parts(spx_value_t alpha, const spx_matrix_t *A, const
  * owner's rows.  Over all rounds every entry travels exactly once.  0 rounds: none planned
  * (spx.rt.dist_chunks <= 1). */
 int spx_hip_mat_dist_rounds(const spx_matrix_t *A);
+int spx_hip_mat_dist_parts(const spx_matrix_t *A);     /* launches THIS process' product is cut into (0: not cut) */
 spx_error_t spx_hip_mat_dist_round(const spx_matrix_t *A, int round, const size_t **send_off, const size_t **send_cnt,
                                    const size_t **recv_off, const size_t **recv_cnt);
 

@@ -685,6 +685,13 @@ def _hip_matvec_parts(self, alpha, x_ptr, beta, y_ptr, parts, stream=0):
     return n.value
 
 
+def _dist_parts(self):
+    """``spx_hip_mat_dist_parts``: launches this process' product is cut into in the overlapped step."""
+    L = lib()
+    L.spx_hip_mat_dist_parts.argtypes = [C.c_void_p]
+    return int(L.spx_hip_mat_dist_parts(self.handle))
+
+
 def _dist_rounds(self):
     """The rounds of the overlapped step as a list of dicts of [world] arrays (send_off, send_cnt,
     recv_off, recv_cnt): segments of the halo lists that travel in every round."""
@@ -715,5 +722,6 @@ Matrix.dist_attach = _dist_attach
 Matrix.dist_plan = _dist_plan
 Matrix.dist_halo = _dist_halo
 Matrix.dist_rounds = _dist_rounds
+Matrix.dist_parts = _dist_parts
 Matrix.hip_matvec_parts = _hip_matvec_parts
 Matrix.hip_matvec_dist = _hip_matvec_dist

@@ -447,6 +447,11 @@ spx_error_t spx_hip_mat_dist_plan(const spx_matrix_t *A, spx_hip_dist_plan_t *pl
     return SPX_SUCCESS;
 }
 
+int spx_hip_mat_dist_parts(const spx_matrix_t *A)
+{
+    return (A && A->dist) ? (int) A->dist->my_chunks : 0;
+}
+
 int spx_hip_mat_dist_rounds(const spx_matrix_t *A)
 {
     return (A && A->dist) ? (int) A->dist->rounds : 0;

@@ -1383,7 +1383,7 @@ size_t device_plan_chunks(DeviceMatrix *m, size_t K, std::vector<size_t> &row_bo
     m->chunk_asked = K;
     const size_t n = m->n_rb;
     if (m->symmetric || m->accum || m->n_shared || m->xcd_split.size() != 1 || !m->launch_order.empty() ||
-        m->wave_tiles || n < 64 || K < 2 || m->rb_upto.size() != n + 1)
+        n < 64 || K < 2 || m->rb_upto.size() != n + 1)
         return 0;
     for (size_t i = 1; i < n; ++i)
         if (m->rb_row0[i] < m->rb_row0[i - 1]) return 0;
@@ -1425,15 +1425,22 @@ void device_spmv_chunk(DeviceMatrix *m, size_t k, double alpha, const double *d_
     const XcdSplit xs = m->chunk_split[k];
     const uint32_t blocks = 8u * m->chunk_longest[k];
     if (!blocks) return;
-    const size_t lds = m->lds_doubles * sizeof(double);
-#define SPX_LAUNCH_CHUNK(W)                                                                                  \
-    hipLaunchKernelGGL(csx_spmv_kernel<W>, dim3(blocks), dim3(64 * W), lds, stream, m->rbs, m->passes, m->n_rb, \
+    // (the launch tuner may have settled on a y tile per wavefront: the same parts through that kernel)
+    const size_t lds = (m->wave_tiles ? (size_t) m->waves : 1u) * m->lds_doubles * sizeof(double);
+#define SPX_LAUNCH_CHUNK_K(KERNEL, W)                                                                        \
+    hipLaunchKernelGGL(KERNEL<W>, dim3(blocks), dim3(64 * W), lds, stream, m->rbs, m->passes, m->n_rb,       \
                        m->pass_stride, xs, m->values, m->descs, m->cidx, m->segrows, d_x, d_y, m->carry,        \
                        (const double *) nullptr, (double *) nullptr, (const uint32_t *) nullptr, alpha, beta,  \
                        (const double *) nullptr, 0.0)
+#define SPX_LAUNCH_CHUNK(W)                                                                                  \
+    do {                                                                                                     \
+        if (m->wave_tiles) SPX_LAUNCH_CHUNK_K(csx_spmv_det_kernel, W);                                       \
+        else SPX_LAUNCH_CHUNK_K(csx_spmv_kernel, W);                                                         \
+    } while (0)
     if (m->waves == 2) SPX_LAUNCH_CHUNK(2);
     else if (m->waves == 8) SPX_LAUNCH_CHUNK(8);
     else SPX_LAUNCH_CHUNK(4);
+#undef SPX_LAUNCH_CHUNK_K
 #undef SPX_LAUNCH_CHUNK
     HIP_CHECK(hipGetLastError());
 }

@@ -120,7 +120,7 @@ def test_contract_matrix_on_eight_ranks_renumbered():
     ranks, col = out["ranks"], out["collective"]
     assert max(r["halo_entries_received"] for r in ranks) < 0.3 * n / world          # natural order: ~1.0 x n / world
     assert sum(r["halo_entries_received"] for r in ranks) < 0.2 * n
-    assert col["overlap_rounds"] >= 2
+    assert col["overlap_rounds"] >= 2 and all(r["overlap_parts"] >= 2 for r in ranks)
 
 
 @pytest.mark.gpu

@@ -15,7 +15,7 @@ def main():
     for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             n = r["Kernel_Name"]
-            kind = ("part" if "csx_spmv_kernel" in n else "pack" if "dist_pack_pos_kernel" in n else
+            kind = ("part" if ("csx_spmv_kernel" in n or "csx_spmv_det_kernel" in n) else "pack" if "dist_pack_pos_kernel" in n else
                     "scatter" if "dist_scatter_pos_kernel" in n else None)
             if kind:
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), kind, r.get("Stream_Id", r.get("Queue_Id", "?"))))
