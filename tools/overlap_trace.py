@@ -24,8 +24,13 @@ def main():
     if not packs:
         print("no pack kernels in the trace")
         return
-    # the last `steps` steps: a step = K parts, K packs, K scatters
-    tail = rows[max(0, len(rows) - steps * 16):]
+    # the last `steps` overlapped steps: from a few parts in front of the (steps * 4)-th last pack kernel
+    # to the last scatter kernel (later phases of the bench -- plain halo step, kernels only -- follow)
+    scat = [i for i, r in enumerate(rows) if r[2] == "scatter"]
+    first = packs[max(0, len(packs) - steps * 4)]
+    while first > 0 and rows[first - 1][2] == "part" and rows[first][0] - rows[first - 1][0] < 2_000_000:
+        first -= 1
+    tail = rows[first:scat[-1] + 1]
     t0 = tail[0][0]
     print("| kernel | stream / queue | start us | end us | overlaps a part of the product |")
     print("|---|---|---|---|---|")
