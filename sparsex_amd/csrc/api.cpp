@@ -724,6 +724,8 @@ static spx_matrix_t *do_tune(spx_input_t *in)
         build_partitions(*in->mat, P, first, last, A->parts, A->bounds);
     }
 
+    const double t_parts = now_sec();
+    log_msg(LOG_INFO, "partitions built in %.2f s\n", t_parts - t0);
     // one preprocessing thread per owned partition, as the reference does
     // (CsxBuild.hpp:290-326, :344-380)
     auto work = [&](size_t i) {
@@ -761,6 +763,7 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     }
     for (auto &e : errors)
         if (!e.empty()) throw FatalError(e);
+    log_msg(LOG_INFO, "partitions mined and encoded in %.2f s\n", now_sec() - t_parts);
     if (sym) {
         A->parts.resize(nown);
         for (size_t i = 0; i < nown; ++i) {

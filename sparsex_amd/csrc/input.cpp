@@ -1,9 +1,11 @@
 // input.cpp -- see input.hpp.
 #include "input.hpp"
+#include "threads.hpp"
 
 #include <cerrno>
 
 #include <algorithm>
+#include <atomic>
 #include <cassert>
 #include <cstdlib>
 #include <limits>
@@ -375,11 +377,273 @@ size_t take_partition_sym(MatrixInput &in, idx_t row_start, size_t limit,
     return cnt;
 }
 
+// ---- the same cuts straight from CSR arrays, filled in parallel ---------------------------------
+// The element-by-element walk above is what the reference does (and what any MatrixInput gets); for
+// a CSR input whose rows hold ascending columns -- the common case, and 769 M virtual calls on the
+// contract matrix -- the partitions are cut from the row pointers with the SAME rule and their
+// elements written by all host threads.  Every bound, count and array comes out identical
+// (tests/test_encoder.py, tests/test_preproc_oracle.py, tests/test_row_slices.py pin them).
+
+struct CsrView {
+    const idx_t *rowptr, *colind;
+    const val_t *values;
+    size_t nrows;
+    idx_t base;                       // 0 or 1
+    size_t at(size_t r) const { return (size_t)(rowptr[r] - base); }      // elements in front of row r
+};
+
+// rows in ascending column order and row pointers that never step back?  (else: the general walk)
+bool csr_view(MatrixInput &in, CsrView &v)
+{
+    CsrInput *c = dynamic_cast<CsrInput *>(&in);
+    if (!c || in.nr_rows == 0) return false;
+    v.rowptr = c->rowptr_;
+    v.colind = c->colind_;
+    v.values = c->values_;
+    v.nrows = in.nr_rows;
+    v.base = c->zero_based_ ? 0 : 1;
+    std::atomic<bool> ok(true);
+    const size_t CH = 1 << 16, nch = (v.nrows + CH - 1) / CH;
+    parallel_for(nch, host_threads(), [&](size_t k) {
+        if (!ok.load(std::memory_order_relaxed)) return;
+        const size_t r1 = std::min(v.nrows, (k + 1) * CH);
+        for (size_t r = k * CH; r < r1; ++r) {
+            if (v.rowptr[r + 1] < v.rowptr[r] || v.rowptr[r] < v.base) { ok = false; return; }
+            for (size_t j = v.at(r) + 1; j < v.at(r + 1); ++j)
+                if (v.colind[j] <= v.colind[j - 1]) { ok = false; return; }
+        }
+    });
+    return ok.load() && v.at(v.nrows) == in.nnz;
+}
+
+// last row in [lo, hi) that holds an element, or hi if none does
+size_t last_nonempty(const CsrView &v, size_t lo, size_t hi)
+{
+    for (size_t r = hi; r > lo; --r)
+        if (v.at(r) > v.at(r - 1)) return r - 1;
+    return hi;
+}
+
+void finish_partition(Partition &p, size_t got, size_t nr_cols, idx_t row_start)
+{
+    p.elems_size = p.elems.size();
+    p.nnz = got;
+    p.nr_rows = p.rowptr.size() - 1;
+    p.nr_cols = nr_cols;
+    p.row_start = row_start;
+    p.type = ENC_H;
+}
+
+bool build_partitions_csr(MatrixInput &in, size_t nr, size_t first, size_t last,
+                          std::vector<Partition> &parts, std::vector<PartBounds> &bounds)
+{
+    CsrView v;
+    if (!csr_view(in, v)) return false;
+    parts.clear();
+    parts.resize(last - first);
+    bounds.clear();
+    const size_t total = in.nnz;
+    size_t cnt = 0, start = 0;                 // `start`: first input row of the partition
+    struct Range { size_t start, end, got; Partition *p; };
+    std::vector<Range> ranges;
+    for (size_t i = 0; i < nr; ++i) {
+        const size_t limit = (total - cnt) / (nr - i);
+        // rows until the partition holds `limit` elements, closed behind a row that holds some
+        // (take_partition: the walk stops at the first element of the next row once cnt >= limit)
+        size_t end = start, got = 0;           // rows [start, end)
+        const size_t left = v.at(v.nrows) - v.at(start);
+        if (left) {
+            size_t e;                          // last row taken
+            if (limit == 0 || left < limit) {
+                e = last_nonempty(v, start, v.nrows);
+            } else {
+                const size_t target = v.at(start) + limit;
+                size_t lo = start, hi = v.nrows - 1;         // first row r with at(r + 1) >= target
+                while (lo < hi) {
+                    const size_t mid = (lo + hi) / 2;
+                    if (v.at(mid + 1) >= target) hi = mid;
+                    else lo = mid + 1;
+                }
+                e = lo;
+            }
+            end = e + 1;
+            got = v.at(end) - v.at(start);
+        }
+        Partition *p = (i >= first && i < last) ? &parts[i - first] : nullptr;
+        ranges.push_back(Range{start, end, got, p});
+        PartBounds b;
+        b.row_start = (idx_t)(in.row_base + start);
+        b.nr_rows = (idx_t)(end - start);
+        b.nnz = got;
+        bounds.push_back(b);
+        start = end;
+        cnt += got;
+    }
+    if (cnt != total) {
+        log_msg(LOG_ERR, "error in input matrix (matrix has less elements than "
+                "claimed)\n");
+        throw FatalError("element count mismatch");
+    }
+    // fill: pieces of <= 64 K rows of the owned partitions, on all host threads
+    struct Piece { const Range *rg; size_t r0, r1; };
+    std::vector<Piece> pieces;
+    for (const Range &rg : ranges) {
+        if (!rg.p) continue;
+        rg.p->elems.resize(rg.got);
+        rg.p->rowptr.assign(rg.end - rg.start + 1, 0);
+        for (size_t r = rg.start; r < rg.end; r += (1 << 16)) pieces.push_back(Piece{&rg, r, std::min(rg.end, r + (1 << 16))});
+        if (rg.end == rg.start) rg.p->rowptr.assign(1, 0);
+    }
+    const idx_t one_based = v.base ? 0 : 1;
+    parallel_for(pieces.size(), host_threads(), [&](size_t k) {
+        const Piece &pc = pieces[k];
+        Partition &p = *pc.rg->p;
+        const size_t e0 = v.at(pc.rg->start);
+        for (size_t r = pc.r0; r < pc.r1; ++r) {
+            p.rowptr[r - pc.rg->start] = (idx_t)(v.at(r) - e0);
+            const idx_t row = (idx_t)(r - pc.rg->start + 1);
+            for (size_t j = v.at(r); j < v.at(r + 1); ++j)
+                p.elems[j - e0] = make_single(row, v.colind[j] + one_based, v.values[j]);
+        }
+    });
+    for (const Range &rg : ranges) {
+        if (!rg.p) continue;
+        if (rg.end > rg.start) rg.p->rowptr[rg.end - rg.start] = (idx_t) rg.got;
+        finish_partition(*rg.p, rg.got, in.nr_cols, (idx_t)(in.row_base + rg.start));
+    }
+    return true;
+}
+
+bool build_partitions_sym_csr(MatrixInput &in, size_t nr, size_t first, size_t last,
+                              std::vector<PartitionSym> &parts, std::vector<PartBounds> &bounds)
+{
+    CsrView v;
+    if (!csr_view(in, v)) return false;
+    parts.clear();
+    parts.resize(last - first);
+    bounds.clear();
+    const idx_t one_based = v.base ? 0 : 1;
+    // per row: entries strictly below the diagonal, and whether the diagonal entry is there
+    std::vector<uint32_t> lower(v.nrows, 0);
+    std::vector<uint8_t> diag(v.nrows, 0);
+    const size_t CH = 1 << 16, nch = (v.nrows + CH - 1) / CH;
+    parallel_for(nch, host_threads(), [&](size_t k) {
+        const size_t r1 = std::min(v.nrows, (k + 1) * CH);
+        for (size_t r = k * CH; r < r1; ++r) {
+            const idx_t g = (idx_t)(in.row_base + r + 1);                   // global row, 1-based
+            const idx_t *c0 = v.colind + v.at(r), *c1 = v.colind + v.at(r + 1);
+            const idx_t *d = std::lower_bound(c0, c1, (idx_t)(g - one_based));   // first column >= g
+            lower[r] = (uint32_t)(d - c0);
+            diag[r] = (d < c1 && *d + one_based == g) ? 1 : 0;
+        }
+    });
+    size_t total = (in.nnz + in.nr_cols) / 2;
+    if (in.global_rows) {
+        total = 0;
+        for (size_t r = 0; r < v.nrows; ++r) total += lower[r] + diag[r];
+    }
+    struct Range { size_t start, end, n_lower, n_diag; idx_t nrows; PartitionSym *p; };
+    std::vector<Range> ranges;
+    size_t cnt = 0, start = 0;
+    for (size_t i = 0; i < nr; ++i) {
+        const size_t limit = (total - cnt) / (nr - i);
+        // take_partition_sym row by row: a row with strictly lower entries closes the partition in front
+        // of it when the count is reached AND the row before it was the last one that held such entries
+        size_t n_lower = 0, n_diag = 0, r = start;
+        size_t row_prev = start;               // (input row index of relative row 1)
+        bool any_lower = false;
+        for (; r < v.nrows; ++r) {
+            if (lower[r]) {
+                if (r != row_prev) {
+                    if (limit && n_diag + n_lower >= limit && row_prev + 1 == r) break;
+                    row_prev = r;
+                }
+                n_lower += lower[r];
+                any_lower = true;
+            }
+            n_diag += diag[r];
+        }
+        const idx_t last_lower = any_lower ? (idx_t)(row_prev - start + 1) : 0;
+        const idx_t nrows = std::max<idx_t>(last_lower, (idx_t) n_diag);
+        PartitionSym *p = (i >= first && i < last) ? &parts[i - first] : nullptr;
+        ranges.push_back(Range{start, r, n_lower, n_diag, nrows, p});
+        PartBounds b;
+        b.row_start = (idx_t)(in.row_base + start);
+        b.nr_rows = nrows;
+        b.nnz = n_lower + n_diag;
+        bounds.push_back(b);
+        cnt += n_lower + n_diag;
+        // The general walk numbers the next partition's rows from start + nrows and resumes its walk at
+        // row r; with a full diagonal the two coincide (every row walked delivered its diagonal).  Where
+        // they do not (rows without a diagonal entry), the general walk does the job.
+        if (start + (size_t) nrows != r) return false;
+        start = r;
+    }
+    if (cnt != total) {
+        log_msg(LOG_ERR, "error in input matrix (matrix has less elements than "
+                "claimed)\n");
+        throw FatalError("element count mismatch");
+    }
+    struct Piece { const Range *rg; size_t r0, r1; };
+    std::vector<Piece> pieces;
+    std::vector<std::vector<size_t>> lower_at(ranges.size()), diag_at(ranges.size());   // per piece start: offsets
+    for (size_t q = 0; q < ranges.size(); ++q) {
+        const Range &rg = ranges[q];
+        if (!rg.p) continue;
+        Partition &lm = rg.p->lower;
+        lm.elems.resize(rg.n_lower);
+        rg.p->diagonal.resize(rg.n_diag);
+        size_t lo = 0, di = 0;
+        for (size_t r = rg.start; r < rg.end; r += CH) {
+            const size_t r1 = std::min(rg.end, r + CH);
+            pieces.push_back(Piece{&rg, r, r1});
+            lower_at[q].push_back(lo);
+            diag_at[q].push_back(di);
+            for (size_t x = r; x < r1; ++x) {
+                lo += lower[x];
+                di += diag[x];
+            }
+        }
+    }
+    std::vector<size_t> piece_no(pieces.size(), 0);
+    {
+        size_t k = 0;
+        for (size_t q = 0; q < ranges.size(); ++q)
+            for (size_t j = 0; j < lower_at[q].size(); ++j) piece_no[k++] = j;
+    }
+    parallel_for(pieces.size(), host_threads(), [&](size_t k) {
+        const Piece &pc = pieces[k];
+        const size_t q = (size_t)(pc.rg - ranges.data());
+        Partition &lm = pc.rg->p->lower;
+        size_t lo = lower_at[q][piece_no[k]], di = diag_at[q][piece_no[k]];
+        for (size_t r = pc.r0; r < pc.r1; ++r) {
+            const idx_t row = (idx_t)(r - pc.rg->start + 1);
+            const size_t j0 = v.at(r);
+            for (uint32_t t = 0; t < lower[r]; ++t)
+                lm.elems[lo++] = make_single(row, v.colind[j0 + t] + one_based, v.values[j0 + t]);
+            if (diag[r]) pc.rg->p->diagonal[di++] = v.values[j0 + lower[r]];
+        }
+    });
+    for (const Range &rg : ranges) {
+        if (!rg.p) continue;
+        Partition &lm = rg.p->lower;
+        lm.elems_size = lm.elems.size();
+        lm.set_rowptr(lm.elems_size);
+        lm.nnz = rg.n_lower;
+        lm.nr_rows = (size_t) rg.nrows;
+        lm.nr_cols = in.nr_cols;
+        lm.row_start = (idx_t)(in.row_base + rg.start);
+        lm.type = ENC_H;
+    }
+    return true;
+}
+
 }  // namespace
 
 void build_partitions(MatrixInput &in, size_t nr, size_t first, size_t last,
                       std::vector<Partition> &parts, std::vector<PartBounds> &bounds)
 {
+    if (!getenv("SPX_NO_CSR_FAST_PATH") && build_partitions_csr(in, nr, first, last, parts, bounds)) return;
     in.rewind();
     parts.clear();
     parts.resize(last - first);
@@ -424,6 +688,7 @@ void build_partitions_sym(MatrixInput &in, size_t nr, size_t first, size_t last,
         log_msg(LOG_ERR, "symmetric format requested for a non-square matrix\n");
         throw FatalError("non-square symmetric");
     }
+    if (!getenv("SPX_NO_CSR_FAST_PATH") && build_partitions_sym_csr(in, nr, first, last, parts, bounds)) return;
     in.rewind();
     parts.clear();
     parts.resize(last - first);
