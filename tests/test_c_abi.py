@@ -210,3 +210,30 @@ def test_dist_c_example_compiles_and_links(tmp_path):
 def test_dist_c_example_runs_as_one_rank(tmp_path):
     out = subprocess.check_output([_build_dist_example(tmp_path), "1", "0", str(tmp_path / "id"), "50000"]).decode()
     assert "rank 0 of 1" in out and "max |y - exact|" in out
+
+
+def test_round4_extensions_reject_bad_arguments():
+    """The entry points added for row-partitioned matrices fail the reference's way (SPX_FAILURE through
+    the handler) on matrices without an exchange plan, on host-only matrices and on NULL arguments."""
+    L = sx.lib()
+    csr = synth.syn_cant(0.02)
+    A = tune(csr, {}, host_only=True)
+    with pytest.raises(sx.SpxError):
+        A.dist_halo()                      # no plan attached
+    L.spx_hip_mat_dist_rounds.argtypes = [C.c_void_p]
+    L.spx_hip_mat_dist_parts.argtypes = [C.c_void_p]
+    assert L.spx_hip_mat_dist_rounds(A.handle) == 0 and L.spx_hip_mat_dist_parts(A.handle) == 0
+    assert L.spx_hip_mat_dist_rounds(None) == 0
+    L.spx_hip_mat_dist_round.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert L.spx_hip_mat_dist_round(A.handle, 0, None, None, None, None) == sx.SPX_FAILURE
+    # the cut product needs the matrix in HBM
+    with pytest.raises(sx.SpxError):
+        A.hip_matvec_parts(1.0, 0, 0.0, 0, 4)
+    # sized introspection: never more than the caller's size; the ABI version is the header's
+    L.spx_hip_mat_info_sized.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    buf = (C.c_ubyte * 512)(*([0xAB] * 512))
+    assert L.spx_hip_mat_info_sized(A.handle, buf, 24) == sx.SPX_SUCCESS
+    assert all(b == 0xAB for b in bytes(buf)[24:]) and any(b != 0xAB for b in bytes(buf)[:24])
+    assert L.spx_hip_mat_info_sized(A.handle, None, 24) == sx.SPX_FAILURE
+    assert L.spx_hip_abi_version() == 3
+    sx.options_reset()
