@@ -797,15 +797,6 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     A->emit_params.keep_units = cfg.get_bool("spx.gpu.keep_units");
     A->emit_params.inline_desc = cfg.get_bool("spx.gpu.inline_desc");
     A->emit_params.x_window = cfg.get_bool("spx.gpu.x_window");
-    const std::string sweep_mode = cfg.get_str("spx.gpu.gather_sweep");
-    {
-        const long k = sweep_mode == "auto" ? 0 : strtol(sweep_mode.c_str(), nullptr, 10);
-        if (sweep_mode != "auto" && (k < 0 || k == 1 || k > 64)) {
-            log_msg(LOG_ERR, "spx.gpu.gather_sweep: 0, 2 .. 64 or auto\n");
-            throw FatalError("bad spx.gpu.gather_sweep");
-        }
-        A->emit_params.gather_sweep = (unsigned) k;
-    }
     {
         const std::string m = cfg.get_str("spx.gpu.sym_segments");
         if (m != "auto" && m != "true" && m != "false") {
@@ -887,7 +878,6 @@ static spx_matrix_t *do_tune(spx_input_t *in)
         // line fills per gather against shorter row pieces and one more atomic hand-over of y per
         // slice (syn-webbase: 38.7 us plain, 32.6 with two, 35.6 with four, 54.6 with eight)
         size_t K = 1;
-        unsigned S = A->emit_params.gather_sweep;
         double t_ph = t_plain;
         if (!A->deterministic) {
             for (size_t k : {(size_t) 2, (size_t) 4}) {
@@ -906,28 +896,9 @@ static spx_matrix_t *do_tune(spx_input_t *in)
                 }
             }
         }
-        // ... or the plain stream with its leftover passes going through the columns bucket by bucket
-        // (spx.gpu.gather_sweep=auto): no slices, no atomics, no beta * y pass -- the row-blocks of an XCD
-        // sweep x together
-        if (sweep_mode == "auto") {
-            for (unsigned sw : {8u, 16u}) {
-                A->col_phases = 1;
-                A->col_concurrent = false;
-                A->emit_params.gather_sweep = sw;
-                emit_and_upload(A.get());
-                const double t = best_of();
-                log_msg(LOG_INFO, "leftover passes in %u column buckets: %.2f us per SpMV\n", sw, 1e6 * t);
-                if (t < 0.97 * t_ph) {
-                    t_ph = t;
-                    K = 1;
-                    S = sw;
-                }
-            }
-        }
-        if (A->col_phases != K || A->col_concurrent != (K > 1) || A->emit_params.gather_sweep != (K > 1 ? 0u : S)) {
+        if (A->col_phases != K || !A->col_concurrent) {
             A->col_phases = K;
             A->col_concurrent = K > 1;
-            A->emit_params.gather_sweep = K > 1 ? 0u : S;
             emit_and_upload(A.get());
         }
         log_msg(LOG_INFO, "column slices: %zu on XCD groups %.2f us, plain %.2f us per SpMV\n", K, 1e6 * t_ph, 1e6 * t_plain);

@@ -50,7 +50,6 @@ void Config::reset_defaults()
     props_["spx.gpu.rowblock_rows"] = "512";   // max rows owned by one row-block
     props_["spx.gpu.stack_segments"] = "true"; // merge stacked row segments into block descriptors
     props_["spx.gpu.waves"] = "0";             // wavefronts per workgroup: 2, 4, 8; 0 = measured at tune time
-    props_["spx.gpu.gather_sweep"] = "auto";   // leftover passes bucket by bucket of the columns: 0 (off), 2..64 buckets, auto (measured with the column slices)
     props_["spx.gpu.inline_desc"] = "true";    // single-descriptor unit passes carry their descriptor in the pass header
     props_["spx.gpu.arena"] = "false";         // true: one HBM allocation for all arrays of a tuned matrix (measured: no gain, profiles/r04/spread.md)
     props_["spx.gpu.band_order"] = "false";    // launch order: strips across the planes of a stencil (measured slower: off)

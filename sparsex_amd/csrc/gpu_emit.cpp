@@ -45,9 +45,8 @@ struct Group {
 
 class RbBuilder {
 public:
-    RbBuilder(const Partition &p, GpuStream &out, bool stack = true, bool x_window = true, bool inline_desc = true,
-              unsigned gather_sweep = 0)
-        : p_(p), out_(out), stack_(stack), x_window_(x_window), inline_desc_(inline_desc), gather_sweep_(gather_sweep) {}
+    RbBuilder(const Partition &p, GpuStream &out, bool stack = true, bool x_window = true, bool inline_desc = true)
+        : p_(p), out_(out), stack_(stack), x_window_(x_window), inline_desc_(inline_desc) {}
 
     // rows [lo, hi) of the partition with what the planner cut out for them
     struct Part {
@@ -108,7 +107,6 @@ private:
     bool stack_;
     bool x_window_;
     bool inline_desc_;
-    unsigned gather_sweep_;   // spx.gpu.gather_sweep: column buckets the leftover passes of a row-block go through in turn
     std::vector<Group> groups_;
     std::vector<val_t> gvals_;
     std::vector<idx_t> slot_groups_;   // first columns of the row-block's slot groups (ascending)
@@ -443,7 +441,7 @@ void RbBuilder::emit_gather_passes(SpxRowBlock &rb, std::vector<Single> &singles
                                               (uint32_t) rb.n_slots + rb.n_rows + rb.xwin_len);
     }
 
-    struct Piece2 { uint32_t first; uint8_t width; uint16_t bucket; };
+    struct Piece2 { uint32_t first; uint8_t width; };
     size_t pieces_before = 0;
     // one set of passes: `set` sorted by (row, col); offsets of `width` bytes relative
     // to `base`, appended to the row-block's offset area.  Pieces are taken in order
@@ -451,41 +449,24 @@ void RbBuilder::emit_gather_passes(SpxRowBlock &rb, std::vector<Single> &singles
     // shorter ones are padded (zero value, offset 0; the piece's length travels with
     // its row in `segrows`, the lanes skip what is not there).  A pass is closed
     // early when the padding would pass 30 % of it.
-    // `sweep` > 0 (spx.gpu.gather_sweep): the columns [base, base + span) are cut into `sweep` buckets, a
-    // row's leftovers are cut at the bucket borders as well, and the passes go bucket by bucket: the
-    // row-blocks that an XCD runs side by side (all of them at once on a leftover-dominated matrix) then
-    // walk x from its first column to its last TOGETHER, and what the XCD's L2 has to hold is a window
-    // of x a few buckets wide instead of all of it
     auto emit_set = [&](const std::vector<Single> &set, uint8_t kind, idx_t base, unsigned width,
-                        size_t area, unsigned sweep = 0, size_t span = 1) {
+                        size_t area) {
         const size_t m = set.size();
         std::vector<Piece2> pcs;
-        auto bucket_of = [&](const Single &s) {
-            return sweep ? (uint16_t)(((size_t)(s.col - base) * sweep) / span) : (uint16_t) 0;
-        };
         for (size_t i = 0; i < m;) {
             size_t j = i;
             while (j < m && set[j].row == set[i].row) ++j;
-            for (size_t k = i; k < j;) {
-                size_t e = k + 1;
-                const uint16_t bk = bucket_of(set[k]);
-                while (e < j && e - k < SPX_MAX_SEG_WIDTH && bucket_of(set[e]) == bk) ++e;
-                pcs.push_back(Piece2{(uint32_t) k, (uint8_t)(e - k), bk});
-                k = e;
-            }
+            for (size_t k = i; k < j; k += SPX_MAX_SEG_WIDTH)
+                pcs.push_back(Piece2{(uint32_t) k, (uint8_t) std::min<size_t>(SPX_MAX_SEG_WIDTH, j - k)});
             i = j;
         }
-        std::stable_sort(pcs.begin(), pcs.end(), [](const Piece2 &a, const Piece2 &b) {
-            return a.bucket != b.bucket ? a.bucket < b.bucket : a.width < b.width;
-        });
+        std::stable_sort(pcs.begin(), pcs.end(),
+                         [](const Piece2 &a, const Piece2 &b) { return a.width < b.width; });
         // where one pass ends (the same rule below): needed up front for 3-byte offsets,
         // whose high bytes form an array of their own behind all the low halves
         auto pass_end = [&](size_t b) {
             size_t e = b, real = 0;
             while (e < pcs.size() && e - b < SPX_PASS_SEGS) {
-                // (widths ascend inside a bucket only: the next bucket starts a pass of its own once this one
-                // holds a few lanes)
-                if (pcs[e].bucket != pcs[b].bucket && (e - b >= 16 || pcs[e].width < pcs[e - 1].width)) break;
                 const size_t w = pcs[e].width, lanes = e - b + 1;
                 if (e - b >= 16 && (lanes * w - (real + w)) * 10 > lanes * w * 3) break;
                 real += w;
@@ -496,9 +477,7 @@ void RbBuilder::emit_gather_passes(SpxRowBlock &rb, std::vector<Single> &singles
         size_t slots_total = 0;
         for (size_t b = 0; b < pcs.size();) {
             const size_t e = pass_end(b);
-            size_t wmax = 0;
-            for (size_t k = b; k < e; ++k) wmax = std::max<size_t>(wmax, pcs[k].width);
-            slots_total += (e - b) * wmax;
+            slots_total += (e - b) * pcs[e - 1].width;
             b = e;
         }
         size_t hi_area = 0;
@@ -522,8 +501,7 @@ void RbBuilder::emit_gather_passes(SpxRowBlock &rb, std::vector<Single> &singles
         size_t elems_before = 0;
         for (size_t b = 0; b < pcs.size();) {
             const size_t e = pass_end(b);
-            uint32_t W = 0;
-            for (size_t k = b; k < e; ++k) W = std::max<uint32_t>(W, pcs[k].width);
+            const uint32_t W = pcs[e - 1].width;
             const size_t nseg = e - b;
             SpxPass ps;
             std::memset(&ps, 0, sizeof(ps));
@@ -561,7 +539,7 @@ void RbBuilder::emit_gather_passes(SpxRowBlock &rb, std::vector<Single> &singles
         }
         rb.cbase = (uint32_t) cmin;
         rb.cidx_width = ((size_t)(cmax - cmin) < 65536) ? 2 : ((size_t)(cmax - cmin) < (1u << 24) ? 3 : 4);
-        emit_set(singles, SPX_PASS_GATHER, cmin, rb.cidx_width, cbytes, gather_sweep_, (size_t)(cmax - cmin) + 1);
+        emit_set(singles, SPX_PASS_GATHER, cmin, rb.cidx_width, cbytes);
     }
     if (!near.empty()) {
         while (out_.cidx.size() % 16) out_.cidx.push_back(0);
@@ -1688,7 +1666,7 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsi
         else emit_plan(jobs[k].first, bld, dst);
     };
     if (nthreads <= 1 || jobs.size() < 64) {
-        RbBuilder bld(p, out, prm.stack_segments, prm.x_window, prm.inline_desc, prm.gather_sweep);
+        RbBuilder bld(p, out, prm.stack_segments, prm.x_window, prm.inline_desc);
         for (size_t k = 0; k < jobs.size(); ++k) emit_job(k, bld, out);
         return;
     }
@@ -1696,7 +1674,7 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsi
     std::vector<GpuStream> locs(n_chunks);
     parallel_for(n_chunks, nthreads, [&](size_t c) {
         const size_t lo = jobs.size() * c / n_chunks, hi = jobs.size() * (c + 1) / n_chunks;
-        RbBuilder bld(p, locs[c], prm.stack_segments, prm.x_window, prm.inline_desc, prm.gather_sweep);
+        RbBuilder bld(p, locs[c], prm.stack_segments, prm.x_window, prm.inline_desc);
         for (size_t k = lo; k < hi; ++k) emit_job(k, bld, locs[c]);
     });
     for (GpuStream &l : locs) append_stream(out, std::move(l));

@@ -109,7 +109,6 @@ struct GpuEmitParams {
     bool recut_linear = true;     // spx.gpu.recut_linear: nonzeros of vertical / diagonal /
                                   // strided units that line up along their rows run as row segments
     bool inline_desc = true;      // spx.gpu.inline_desc: SPX_PASSF_INLINE
-    unsigned gather_sweep = 0;    // spx.gpu.gather_sweep: column buckets of the leftover passes (0: none)
     bool keep_units = true;       // spx.gpu.keep_units: ... but a mined unit none of whose nonzeros has a
                                   // neighbour along its row stays the unit it is (one descriptor)
     bool sym_remine = true;       // spx.gpu.sym_remine (see append_sym_expanded)
