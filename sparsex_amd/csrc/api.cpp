@@ -355,6 +355,7 @@ static void emit_and_upload(spx_matrix_t *A)
     if (A->auto_rb) gp.target_elems = auto_target_elems(A, A->rb_scale);
     GpuStream gs;
     const unsigned hw = host_threads();
+    const double t_emit0 = now_sec();
     // pieces (partitions, row ranges) are emitted concurrently into streams of
     // their own and joined in order; threads left over work inside a piece
     auto emit_pieces = [&](std::vector<Partition> &pieces, const std::vector<std::vector<SymTile>> *tl,
@@ -501,6 +502,7 @@ static void emit_and_upload(spx_matrix_t *A)
         // (an over-long row is summed by a fix-up kernel that stores: not with slices that add)
         if (!gs.shared.empty()) throw FatalError("column phases: the matrix holds rows that are split over row-blocks");
     }
+    const double t_emit1 = now_sec();
     A->conflict_rows.clear();
     if (sym && !gs.sym_fused) stream_touched_rows(gs, A->own_lo, A->conflict_rows);
     A->halo_cols.clear();
@@ -530,9 +532,12 @@ static void emit_and_upload(spx_matrix_t *A)
         device_free(A->dev);
         A->dev = nullptr;
     }
+    const double t_emit2 = now_sec();
     if (!A->host_only) {
         A->dev = device_upload(gs, (size_t) A->nrows, (size_t) A->ncols, sym, A->own_lo, A->own_hi,
                                A->device_ordinal);
+        log_msg(LOG_INFO, "descriptor stream: emitted in %.2f s, finalized in %.2f s, uploaded in %.2f s (%zu row-blocks)\n",
+                t_emit1 - t_emit0, t_emit2 - t_emit1, now_sec() - t_emit2, gs.rbs.size());
         // (a matrix that is attached to an exchange plan keeps its limited init range over a
         // re-upload: the state lives with the matrix, not with the device copy)
         if (A->dist && sym) {
