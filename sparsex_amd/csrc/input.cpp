@@ -487,12 +487,17 @@ bool build_partitions_csr(MatrixInput &in, size_t nr, size_t first, size_t last,
     // fill: pieces of <= 64 K rows of the owned partitions, on all host threads
     struct Piece { const Range *rg; size_t r0, r1; };
     std::vector<Piece> pieces;
+    // (the arrays are sized -- and thereby first touched -- by several threads: value-initialising
+    // 24 GB of elements of the contract matrix on one thread took longer than filling them)
+    parallel_for(ranges.size(), host_threads(), [&](size_t q) {
+        const Range &rg = ranges[q];
+        if (!rg.p) return;
+        rg.p->elems.resize(rg.got);
+        rg.p->rowptr.assign(rg.end > rg.start ? rg.end - rg.start + 1 : 1, 0);
+    });
     for (const Range &rg : ranges) {
         if (!rg.p) continue;
-        rg.p->elems.resize(rg.got);
-        rg.p->rowptr.assign(rg.end - rg.start + 1, 0);
         for (size_t r = rg.start; r < rg.end; r += (1 << 16)) pieces.push_back(Piece{&rg, r, std::min(rg.end, r + (1 << 16))});
-        if (rg.end == rg.start) rg.p->rowptr.assign(1, 0);
     }
     const idx_t one_based = v.base ? 0 : 1;
     parallel_for(pieces.size(), host_threads(), [&](size_t k) {
@@ -590,9 +595,6 @@ bool build_partitions_sym_csr(MatrixInput &in, size_t nr, size_t first, size_t l
     for (size_t q = 0; q < ranges.size(); ++q) {
         const Range &rg = ranges[q];
         if (!rg.p) continue;
-        Partition &lm = rg.p->lower;
-        lm.elems.resize(rg.n_lower);
-        rg.p->diagonal.resize(rg.n_diag);
         size_t lo = 0, di = 0;
         for (size_t r = rg.start; r < rg.end; r += CH) {
             const size_t r1 = std::min(rg.end, r + CH);
@@ -605,6 +607,12 @@ bool build_partitions_sym_csr(MatrixInput &in, size_t nr, size_t first, size_t l
             }
         }
     }
+    parallel_for(ranges.size(), host_threads(), [&](size_t q) {
+        const Range &rg = ranges[q];
+        if (!rg.p) return;
+        rg.p->lower.elems.resize(rg.n_lower);
+        rg.p->diagonal.resize(rg.n_diag);
+    });
     std::vector<size_t> piece_no(pieces.size(), 0);
     {
         size_t k = 0;
