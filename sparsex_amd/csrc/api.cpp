@@ -557,7 +557,12 @@ static void emit_and_upload(spx_matrix_t *A)
 // candidates, a few hundred launches each; the fastest stays.
 static void autotune_launch(spx_matrix_t *A, bool tune_waves, bool tune_spill, bool tune_wave_tiles)
 {
-    const int W = 10, N = 100;
+    // launches per timing: a hundred for a product of microseconds, fewer where one launch takes a
+    // millisecond (about 20 ms of launches per timing either way; four timings per variant: on the
+    // contract matrix the hundred cost 1.7 s per variant for the same answer)
+    const double t_est = device_time_spmv(A->dev, 2, 3);
+    const int N = (int) std::min(100.0, std::max(8.0, 0.02 / std::max(t_est, 1e-7)));
+    const int W = std::max(2, N / 10);
     if (!tune_waves) {
         // (the wavefront count is pinned: only the hand-over of the tiles' sums is measured)
         if (tune_wave_tiles && !device_has_tiles(A->dev)) {
