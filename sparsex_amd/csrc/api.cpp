@@ -369,7 +369,46 @@ static void emit_and_upload(spx_matrix_t *A)
             if (sl) g.symsegs = &(*sl)[i];
             emit_gpu(pieces[i], g, locs[i], inner);
         });
-        for (GpuStream &l : locs) append_stream(gs, std::move(l));
+        // (the joined arrays are sized once: growing a 6 GB vector piece by piece copies it again and again)
+        {
+            size_t nv = gs.values.size(), nd = gs.descs.size(), np = gs.passes.size(), nc = gs.cidx.size(),
+                   ns = gs.segrows.size(), nr = gs.rbs.size();
+            for (const GpuStream &l : locs) {
+                nv += l.values.size() + 2;
+                nd += l.descs.size();
+                np += l.passes.size();
+                nc += l.cidx.size() + 16;
+                ns += l.segrows.size();
+                nr += l.rbs.size();
+            }
+            // (the first piece is taken over as it is -- append_stream swaps into an empty stream -- and
+            // the room for the others is made behind it in one step)
+            if (n) append_stream(gs, std::move(locs[0]));
+            if (n > 1) {
+                gs.values.reserve(nv);
+                gs.descs.reserve(nd);
+                gs.passes.reserve(np);
+                gs.cidx.reserve(nc);
+                gs.segrows.reserve(ns);
+                gs.rbs.reserve(nr);
+                // The pages behind the first piece are touched by all host threads before the pieces are copied
+                // in one after the other: a fresh 6 GB region faults in at ~1 GB/s on one thread, and that was
+                // most of the time the join took.  (Storage the vector has reserved and not yet given out; a
+                // double needs no construction.)
+                if ((nv - gs.values.size()) * sizeof(val_t) > ((size_t) 64 << 20)) {
+                    val_t *base = gs.values.data();
+                    const size_t lo = gs.values.size(), hi = gs.values.capacity(), step = 4096 / sizeof(val_t);
+                    const size_t chunk = (size_t) 8 << 20, nchunk = (hi - lo + chunk - 1) / chunk;
+                    parallel_for(nchunk, hw, [&](size_t k) {
+                        const size_t b = lo + k * chunk, e = std::min(hi, b + chunk);
+                        for (size_t i = b; i < e; i += step) base[i] = 0.0;
+                    });
+                }
+            }
+        }
+        const double t_join = now_sec();
+        for (size_t i = 1; i < n; ++i) append_stream(gs, std::move(locs[i]));
+        log_msg(LOG_INFO, "descriptor stream: %zu pieces joined in %.2f s\n", n, now_sec() - t_join);
     };
     if (sym) {
         // The GPU stream holds the stored lower triangle and its mirror image
