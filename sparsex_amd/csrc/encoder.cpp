@@ -605,7 +605,8 @@ void Encoder::encode(int type)
     // :863-903
     if (type == ENC_NONE) return;
     spm_->transform(type);
-    std::vector<Elem> out;
+    std::vector<Elem> &out = spm_->scratch;
+    out.clear();
     out.reserve(spm_->elems_size);
     size_t nr = spm_->rowptr_size() - 1;
     for (size_t i = 0; i < nr; ++i) encode_row(i, out);
@@ -633,6 +634,7 @@ void Encoder::encode_all(std::ostream *log)
         enc_seq_.push_back(type);
     }
     spm_->transform(ENC_H);
+    std::vector<Elem>().swap(spm_->scratch);
     if (log) {
         *log << "Encoding sequence: ";
         if (enc_seq_.empty()) *log << enc_full_name(ENC_NONE);
@@ -654,6 +656,7 @@ void Encoder::encode_serial(const XformSeq &seq)
         enc_seq_.push_back(s.type);
     }
     spm_->transform(ENC_H);
+    std::vector<Elem>().swap(spm_->scratch);
 }
 
 }  // namespace spx

@@ -21,6 +21,61 @@ struct Piece {
 struct Single { idx_t row, col; val_t val; };   // 0-based row (partition), 0-based col
 struct RowSeg { idx_t row, col; uint8_t width; val_t v[SPX_MAX_SEG_WIDTH]; };   // same numbering
 
+// Points in (row, col) order.  The points of a row-block -- or of a partition -- span few rows
+// compared with their number, so a counting pass over the rows and a short sort inside every row
+// replaces the comparison sort (whose quicksort also degenerates on the runs mined units leave).
+// Coordinates are unique, so the result is the one std::sort gives.
+template <class T, class RowOf, class ColOf>
+void sort_by_row_col(std::vector<T> &v, RowOf row_of, ColOf col_of)
+{
+    const size_t n = v.size();
+    if (n < 2) return;
+    auto less = [&](const T &a, const T &b) {
+        return row_of(a) < row_of(b) || (row_of(a) == row_of(b) && col_of(a) < col_of(b));
+    };
+    int64_t lo = row_of(v[0]), hi = lo;
+    bool sorted = true;
+    for (size_t i = 1; i < n; ++i) {
+        const int64_t r = row_of(v[i]);
+        lo = std::min(lo, r);
+        hi = std::max(hi, r);
+        sorted = sorted && !less(v[i], v[i - 1]);
+    }
+    if (sorted) return;
+    const uint64_t span = (uint64_t) (hi - lo) + 1;
+    if (n < 64 || span > 4 * (uint64_t) n || n > 0xffffffffull) {
+        std::sort(v.begin(), v.end(), less);
+        return;
+    }
+    std::vector<uint32_t> start(span + 1, 0);
+    for (const T &e : v) ++start[(size_t) (row_of(e) - lo) + 1];
+    for (size_t r = 0; r < span; ++r) start[r + 1] += start[r];
+    std::vector<T> out(n);
+    {
+        std::vector<uint32_t> pos(start.begin(), start.end() - 1);
+        for (const T &e : v) out[pos[(size_t) (row_of(e) - lo)]++] = e;
+    }
+    auto by_col = [&](const T &a, const T &b) { return col_of(a) < col_of(b); };
+    for (size_t r = 0; r < span; ++r) {
+        const size_t a = start[r], b = start[r + 1];
+        if (b - a < 2) continue;
+        if (b - a > 24) { std::sort(out.begin() + a, out.begin() + b, by_col); continue; }
+        for (size_t i = a + 1; i < b; ++i) {
+            if (!by_col(out[i], out[i - 1])) continue;
+            T t = out[i];
+            size_t j = i;
+            for (; j > a && by_col(t, out[j - 1]); --j) out[j] = out[j - 1];
+            out[j] = t;
+        }
+    }
+    v.swap(out);
+}
+
+inline void sort_singles(std::vector<Single> &v)
+{
+    sort_by_row_col(v, [](const Single &s) { return (int64_t) s.row; }, [](const Single &s) { return s.col; });
+}
+
 struct Plan {
     idx_t row_lo, row_hi;   // rows [lo, hi) of the partition
     bool split;             // one over-long row, chunked
@@ -386,9 +441,7 @@ void RbBuilder::emit_unit_passes(SpxRowBlock &rb, bool sym, uint32_t row_base)
 // offsets); the others gather through L2 as before.
 void RbBuilder::emit_gather_passes(SpxRowBlock &rb, std::vector<Single> &singles, idx_t lo)
 {
-    std::sort(singles.begin(), singles.end(), [](const Single &x, const Single &y) {
-        return x.row < y.row || (x.row == y.row && x.col < y.col);
-    });
+    sort_singles(singles);
     const size_t n = singles.size();
     rb.seg_off = (uint32_t) out_.segrows.size();
     while (out_.cidx.size() % 16) out_.cidx.push_back(0);
@@ -807,9 +860,7 @@ static Elem mirror_unit(const Elem &e, const val_t *src, Partition &out)
 // that this finds again.
 static void append_upper_segments(std::vector<Single> &pts, Partition &out)
 {
-    std::sort(pts.begin(), pts.end(), [](const Single &a, const Single &b) {
-        return a.row < b.row || (a.row == b.row && a.col < b.col);
-    });
+    sort_singles(pts);
     struct Seg { idx_t row, col; uint32_t first; uint32_t width; };
     std::vector<Seg> segs;
     for (size_t i = 0; i < pts.size();) {
@@ -905,9 +956,7 @@ void append_sym_expanded(const Partition &lower, Partition &out, bool remine_upp
 static void extract_tiles(std::vector<Single> &pts, std::vector<SymTile> &tiles,
                           std::vector<Single> &rest)
 {
-    std::sort(pts.begin(), pts.end(), [](const Single &a, const Single &b) {
-        return a.row < b.row || (a.row == b.row && a.col < b.col);
-    });
+    sort_singles(pts);
     struct Seg { idx_t row, col; uint32_t first; uint32_t width; };
     std::vector<Seg> segs;
     for (size_t i = 0; i < pts.size();) {
@@ -1120,9 +1169,7 @@ void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<Sy
         symsegs->assign(R, std::vector<SymSeg>());
         parallel_for(P, nthreads, [&](size_t i) {
             std::vector<Single> &pts = rest[i];
-            std::sort(pts.begin(), pts.end(), [](const Single &a, const Single &b) {
-                return a.row < b.row || (a.row == b.row && a.col < b.col);
-            });
+            sort_singles(pts);
             std::vector<Single> loose;
             for (size_t a = 0; a < pts.size();) {
                 size_t b = a + 1;
@@ -1189,9 +1236,7 @@ void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<Sy
             pts.insert(pts.end(), bucket[i][j].begin(), bucket[i][j].end());
             std::vector<Single>().swap(bucket[i][j]);
         }
-        std::sort(pts.begin(), pts.end(), [](const Single &a, const Single &b) {
-            return a.row < b.row || (a.row == b.row && a.col < b.col);
-        });
+        sort_singles(pts);
         // A range that holds only mirror image (rows of other processes): stretches of
         // 512 rows with fewer than 128 nonzeros are not worth a workgroup each -- they
         // leave the row-block stream for the per-row list
@@ -1446,9 +1491,6 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsi
     // at a time, the lanes want width.
     auto recut_plan = [&](size_t pl, std::vector<RowSeg> &rowsegs) {
         if (!prm.recut_linear) return;
-        auto by_row_col = [](const Single &a, const Single &b) {
-            return a.row < b.row || (a.row == b.row && a.col < b.col);
-        };
         // A mined unit whose nonzeros have no neighbours along their rows gains nothing from the
         // re-cut -- each of its nonzeros would end up a leftover with a column offset and a row
         // of its own (4 bytes of index per nonzero, a gather pass) where the unit is one 8-byte
@@ -1467,7 +1509,7 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsi
                     all.push_back(Pt{Single{r - 1, c - 1, p.pool[u.voff + k]}, (uint32_t) q});
                 }
             }
-            std::sort(all.begin(), all.end(), [&](const Pt &a, const Pt &b) { return by_row_col(a.s, b.s); });
+            sort_by_row_col(all, [](const Pt &t) { return (int64_t) t.s.row; }, [](const Pt &t) { return t.s.col; });
             std::vector<uint32_t> with_neighbour(lin_pieces[pl].size(), 0);
             for (size_t a = 0; a < all.size();) {
                 size_t b = a + 1;
@@ -1512,7 +1554,7 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsi
         if (plans[pl].split) return;
         pts.insert(pts.end(), singles[pl].begin(), singles[pl].end());
         singles[pl].clear();
-        std::sort(pts.begin(), pts.end(), by_row_col);
+        sort_singles(pts);
         for (size_t a = 0; a < pts.size();) {
             size_t b = a + 1;
             while (b < pts.size() && b - a < SPX_MAX_SEG_WIDTH && pts[b].row == pts[a].row &&

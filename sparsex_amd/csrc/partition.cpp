@@ -110,17 +110,47 @@ void Partition::set_rowptr(size_t count)
     if ((size_t) rowptr.back() != count) rowptr.push_back((idx_t) count);
 }
 
+// Elements into (row, col) order after their coordinates changed.  Every order the preprocessor
+// asks for walks lines of the matrix -- rows, columns, diagonals, block rows -- and the elements
+// of one line keep their relative order under most changes (a row-major list asked for its
+// diagonals already holds each diagonal from top to bottom), so one stable counting pass over the
+// new row numbers usually IS the sort; where it is not (block rows from row-major order, windows
+// far shorter than their row range) the comparison sort finishes the job.  Coordinates are unique:
+// either way the result is the order std::sort gives.
+static void sort_elems(std::vector<Elem> &elems, size_t n, idx_t max_row, std::vector<Elem> &scratch)
+{
+    auto key = [](const Elem &e) { return (uint64_t) (uint32_t) e.row << 32 | (uint32_t) e.col; };
+    auto less = [&](const Elem &a, const Elem &b) { return key(a) < key(b); };
+    if (n < 2) return;
+    if (n < 256 || n > 0xfffffff0ull || (uint64_t) max_row > 8 * (uint64_t) n) {
+        std::sort(elems.begin(), elems.begin() + n, less);
+        return;
+    }
+    std::vector<uint32_t> start((size_t) max_row + 2, 0);      // rows are 1-based
+    for (size_t i = 0; i < n; ++i) ++start[(size_t) elems[i].row + 1];
+    for (size_t r = 1; r <= (size_t) max_row; ++r) start[r + 1] += start[r];
+    if (scratch.size() < n) scratch.resize(n);      // (kept by the partition: fresh pages cost more than the pass)
+    Elem *out = scratch.data();
+    for (size_t i = 0; i < n; ++i) out[start[(size_t) elems[i].row]++] = elems[i];
+    bool in_order = true;
+    for (size_t i = 1; i < n && in_order; ++i) in_order = key(out[i - 1]) < key(out[i]);
+    std::copy(out, out + n, elems.begin());
+    if (!in_order) std::sort(elems.begin(), elems.begin() + n, less);
+}
+
 void Partition::transform(int t)
 {
     if (type == t) return;
     const idx_t nr = (idx_t) nr_rows, nc = (idx_t) nr_cols;
     const int from = type;
-    for (size_t i = 0; i < elems_size; ++i)
+    idx_t max_row = 0;
+    for (size_t i = 0; i < elems_size; ++i) {
         xform(from, t, elems[i].row, elems[i].col, nr, nc);
-    // The reference sorts band-by-band when both orders belong to the same
-    // row/column family (SparsePartition.hpp:704-734); coordinates are unique,
-    // so a full sort yields the same order.
-    std::sort(elems.begin(), elems.begin() + elems_size, elem_less);
+        max_row = std::max(max_row, elems[i].row);
+    }
+    // (the reference sorts band-by-band when both orders belong to the same row/column family,
+    // SparsePartition.hpp:704-734)
+    sort_elems(elems, elems_size, max_row, scratch);
     if (elems_size) set_rowptr(elems_size);
     type = t;
 }

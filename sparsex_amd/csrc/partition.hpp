@@ -61,6 +61,7 @@ public:
     idx_t row_start = 0;         // first row in the whole matrix (0-based)
     std::vector<Elem> elems;     // only the first elems_size entries are live
     size_t elems_size = 0;
+    std::vector<Elem> scratch;   // transform()'s second buffer while the partition is being mined
     std::vector<idx_t> rowptr;   // rowptr.size()-1 == last non-empty row
     std::vector<val_t> pool;     // values of encoded units
 
