@@ -363,12 +363,14 @@ static void emit_and_upload(spx_matrix_t *A)
         const size_t n = pieces.size();
         std::vector<GpuStream> locs(n);
         const unsigned inner = (unsigned) std::max<size_t>(1, hw / std::max<size_t>(1, std::min<size_t>(n, hw)));
+        const double t_pieces = now_sec();
         parallel_for(n, hw, [&](size_t i) {
             GpuEmitParams g = gp;
             if (tl) g.tiles = &(*tl)[i];
             if (sl) g.symsegs = &(*sl)[i];
             emit_gpu(pieces[i], g, locs[i], inner);
         });
+        const double t_room = now_sec();
         // (the joined arrays are sized once: growing a 6 GB vector piece by piece copies it again and again)
         {
             size_t nv = gs.values.size(), nd = gs.descs.size(), np = gs.passes.size(), nc = gs.cidx.size(),
@@ -408,7 +410,8 @@ static void emit_and_upload(spx_matrix_t *A)
         }
         const double t_join = now_sec();
         for (size_t i = 1; i < n; ++i) append_stream(gs, std::move(locs[i]));
-        log_msg(LOG_INFO, "descriptor stream: %zu pieces joined in %.2f s\n", n, now_sec() - t_join);
+        log_msg(LOG_INFO, "descriptor stream: %zu pieces emitted in %.2f s, room made in %.2f s, joined in %.2f s\n", n,
+                t_room - t_pieces, t_join - t_room, now_sec() - t_join);
     };
     if (sym) {
         // The GPU stream holds the stored lower triangle and its mirror image

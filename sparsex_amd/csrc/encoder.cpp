@@ -380,11 +380,12 @@ Elem Encoder::make_unit(idx_t row, idx_t col, const val_t *vals, size_t size,
     e.size = (uint16_t) size;
     e.type = (uint8_t) type;
     e.pad_ = 0;
+    e.pad2_ = 0;
     return e;
 }
 
 void Encoder::do_encode(idx_t row_no, std::vector<idx_t> &xs,
-                        std::vector<val_t> &vs, std::vector<Elem> &out)
+                        std::vector<val_t> &vs, ElemSink &out)
 {
     const int type = spm_->type;
     if (enc_is_block(type)) {
@@ -443,7 +444,7 @@ void Encoder::do_encode(idx_t row_no, std::vector<idx_t> &xs,
 }
 
 void Encoder::do_encode_block(idx_t row_no, std::vector<idx_t> &xs,
-                              std::vector<val_t> &vs, std::vector<Elem> &out)
+                              std::vector<val_t> &vs, ElemSink &out)
 {
     // :1085-1192 (split_blocks disabled)
     const int type = spm_->type;
@@ -515,7 +516,7 @@ void Encoder::do_encode_block(idx_t row_no, std::vector<idx_t> &xs,
 }
 
 void Encoder::do_encode_block_alt(idx_t row_no, std::vector<idx_t> &xs,
-                                  std::vector<val_t> &vs, std::vector<Elem> &out)
+                                  std::vector<val_t> &vs, ElemSink &out)
 {
     // :1194-1290 -- greedy cover of an aligned band with the accepted block
     // sizes, largest first
@@ -581,7 +582,7 @@ void Encoder::do_encode_block_alt(idx_t row_no, std::vector<idx_t> &xs,
     vs.clear();
 }
 
-void Encoder::encode_row(size_t row, std::vector<Elem> &newrow)
+void Encoder::encode_row(size_t row, ElemSink &newrow)
 {
     // :1292-1319 -- stray elements between units are (re)encoded, units stay
     idx_t begin = spm_->rowptr[row], end = spm_->rowptr[row + 1];
@@ -605,13 +606,13 @@ void Encoder::encode(int type)
     // :863-903
     if (type == ENC_NONE) return;
     spm_->transform(type);
-    std::vector<Elem> &out = spm_->scratch;
-    out.clear();
-    out.reserve(spm_->elems_size);
+    ElemSink out{spm_->elems.data(), 0};
     size_t nr = spm_->rowptr_size() - 1;
-    for (size_t i = 0; i < nr; ++i) encode_row(i, out);
+    for (size_t i = 0; i < nr; ++i) {
+        encode_row(i, out);
+        assert(out.size() <= (size_t) spm_->rowptr[i + 1]);
+    }
     size_t n = out.size();
-    std::copy(out.begin(), out.end(), spm_->elems.begin());
     spm_->elems_size = n;
     spm_->set_rowptr(n);
     add_ignore(type);

@@ -67,13 +67,20 @@ private:
                             StatsCollection &stats);
     unsigned long type_score(int type, const StatsData &d) const;
 
-    void encode_row(size_t row, std::vector<Elem> &newrow);
-    void do_encode(idx_t row_no, std::vector<idx_t> &xs, std::vector<val_t> &vs,
-                   std::vector<Elem> &out);
-    void do_encode_block(idx_t row_no, std::vector<idx_t> &xs,
-                         std::vector<val_t> &vs, std::vector<Elem> &out);
-    void do_encode_block_alt(idx_t row_no, std::vector<idx_t> &xs,
-                             std::vector<val_t> &vs, std::vector<Elem> &out);
+    // Where an encoding round puts its elements: back into the partition's own array, behind
+    // the position it reads at (a round never makes more elements than it has read).
+    struct ElemSink {
+        Elem *base;
+        size_t n;
+        void push_back(const Elem &e) { base[n++] = e; }
+        void pop_back() { --n; }
+        Elem &back() { return base[n - 1]; }
+        size_t size() const { return n; }
+    };
+    void encode_row(size_t row, ElemSink &newrow);
+    void do_encode(idx_t row_no, std::vector<idx_t> &xs, std::vector<val_t> &vs, ElemSink &out);
+    void do_encode_block(idx_t row_no, std::vector<idx_t> &xs, std::vector<val_t> &vs, ElemSink &out);
+    void do_encode_block_alt(idx_t row_no, std::vector<idx_t> &xs, std::vector<val_t> &vs, ElemSink &out);
     Elem make_unit(idx_t row, idx_t col, const val_t *vals, size_t size,
                    int type, size_t delta);
 

@@ -6,6 +6,7 @@
 #include <iterator>
 #include <cassert>
 #include <cstring>
+#include <chrono>
 
 namespace spx {
 
@@ -21,22 +22,23 @@ struct Piece {
 struct Single { idx_t row, col; val_t val; };   // 0-based row (partition), 0-based col
 struct RowSeg { idx_t row, col; uint8_t width; val_t v[SPX_MAX_SEG_WIDTH]; };   // same numbering
 
-// Points in (row, col) order.  The points of a row-block -- or of a partition -- span few rows
-// compared with their number, so a counting pass over the rows and a short sort inside every row
-// replaces the comparison sort (whose quicksort also degenerates on the runs mined units leave).
-// Coordinates are unique, so the result is the one std::sort gives.
-template <class T, class RowOf, class ColOf>
-void sort_by_row_col(std::vector<T> &v, RowOf row_of, ColOf col_of)
+// Sorts by an integer key first and by `within` among equal keys.  The keys of a row-block's or a
+// partition's points (their rows, their columns) span few values compared with their number, so a
+// counting pass over the keys and a short sort inside every bucket replaces the comparison sort
+// (whose quicksort also degenerates on the runs that mined units leave).  Where (key, within) is a
+// total order -- coordinates are unique -- the result is the one std::sort gives.
+template <class T, class KeyOf, class Within>
+void sort_by_key_then(std::vector<T> &v, KeyOf key_of, Within within)
 {
     const size_t n = v.size();
     if (n < 2) return;
     auto less = [&](const T &a, const T &b) {
-        return row_of(a) < row_of(b) || (row_of(a) == row_of(b) && col_of(a) < col_of(b));
+        return key_of(a) < key_of(b) || (key_of(a) == key_of(b) && within(a, b));
     };
-    int64_t lo = row_of(v[0]), hi = lo;
+    int64_t lo = key_of(v[0]), hi = lo;
     bool sorted = true;
     for (size_t i = 1; i < n; ++i) {
-        const int64_t r = row_of(v[i]);
+        const int64_t r = key_of(v[i]);
         lo = std::min(lo, r);
         hi = std::max(hi, r);
         sorted = sorted && !less(v[i], v[i - 1]);
@@ -48,27 +50,32 @@ void sort_by_row_col(std::vector<T> &v, RowOf row_of, ColOf col_of)
         return;
     }
     std::vector<uint32_t> start(span + 1, 0);
-    for (const T &e : v) ++start[(size_t) (row_of(e) - lo) + 1];
+    for (const T &e : v) ++start[(size_t) (key_of(e) - lo) + 1];
     for (size_t r = 0; r < span; ++r) start[r + 1] += start[r];
     std::vector<T> out(n);
     {
         std::vector<uint32_t> pos(start.begin(), start.end() - 1);
-        for (const T &e : v) out[pos[(size_t) (row_of(e) - lo)]++] = e;
+        for (const T &e : v) out[pos[(size_t) (key_of(e) - lo)]++] = e;
     }
-    auto by_col = [&](const T &a, const T &b) { return col_of(a) < col_of(b); };
     for (size_t r = 0; r < span; ++r) {
         const size_t a = start[r], b = start[r + 1];
         if (b - a < 2) continue;
-        if (b - a > 24) { std::sort(out.begin() + a, out.begin() + b, by_col); continue; }
+        if (b - a > 24) { std::sort(out.begin() + a, out.begin() + b, within); continue; }
         for (size_t i = a + 1; i < b; ++i) {
-            if (!by_col(out[i], out[i - 1])) continue;
+            if (!within(out[i], out[i - 1])) continue;
             T t = out[i];
             size_t j = i;
-            for (; j > a && by_col(t, out[j - 1]); --j) out[j] = out[j - 1];
+            for (; j > a && within(t, out[j - 1]); --j) out[j] = out[j - 1];
             out[j] = t;
         }
     }
     v.swap(out);
+}
+
+template <class T, class RowOf, class ColOf>
+void sort_by_row_col(std::vector<T> &v, RowOf row_of, ColOf col_of)
+{
+    sort_by_key_then(v, row_of, [&](const T &a, const T &b) { return col_of(a) < col_of(b); });
 }
 
 inline void sort_singles(std::vector<Single> &v)
@@ -871,11 +878,8 @@ static void append_upper_segments(std::vector<Single> &pts, Partition &out)
         segs.push_back(Seg{pts[i].row, pts[i].col, (uint32_t) i, (uint32_t)(j - i)});
         i = j;
     }
-    std::sort(segs.begin(), segs.end(), [](const Seg &a, const Seg &b) {
-        if (a.col != b.col) return a.col < b.col;
-        if (a.width != b.width) return a.width < b.width;
-        return a.row < b.row;
-    });
+    sort_by_key_then(segs, [](const Seg &a) { return (int64_t) a.col; },
+                     [](const Seg &a, const Seg &b) { return a.width != b.width ? a.width < b.width : a.row < b.row; });
     std::vector<val_t> vals;
     for (size_t i = 0; i < segs.size();) {
         const size_t w = segs[i].width;
@@ -899,6 +903,7 @@ static void append_upper_segments(std::vector<Single> &pts, Partition &out)
             u.voff = out.pool_alloc(vals.data(), vals.size());
             u.size = (uint16_t) vals.size();
             u.pad_ = 0;
+            u.pad2_ = 0;
             if (rows == 1) {            // one row segment
                 u.type = ENC_H;
                 u.delta = 1;
@@ -970,11 +975,8 @@ static void extract_tiles(std::vector<Single> &pts, std::vector<SymTile> &tiles,
         segs.push_back(Seg{pts[i].row, pts[i].col, (uint32_t) i, (uint32_t)(j - i)});
         i = j;
     }
-    std::sort(segs.begin(), segs.end(), [](const Seg &a, const Seg &b) {
-        if (a.col != b.col) return a.col < b.col;
-        if (a.width != b.width) return a.width < b.width;
-        return a.row < b.row;
-    });
+    sort_by_key_then(segs, [](const Seg &a) { return (int64_t) a.col; },
+                     [](const Seg &a, const Seg &b) { return a.width != b.width ? a.width < b.width : a.row < b.row; });
     for (size_t i = 0; i < segs.size();) {
         size_t j = i + 1;
         while (j < segs.size() && segs[j].col == segs[i].col && segs[j].width == segs[i].width &&
@@ -1068,6 +1070,9 @@ void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<Sy
                       std::vector<std::vector<SymSeg>> *symsegs, size_t min_run)
 {
     const size_t P = lowers.size(), R = ranges.size();
+    auto clock = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_mark = clock(), t_step[5] = {0, 0, 0, 0, 0};
+    auto lap = [&](int k) { const double t = clock(); t_step[k] = t - t_mark; t_mark = t; };
     outs.assign(R, Partition());
     tiles.assign(R, std::vector<SymTile>());
     if (!R) return;
@@ -1120,6 +1125,7 @@ void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<Sy
         }
     });
 
+    lap(0);
     // 2. a group of eight rows that holds tiles must fit one row-block: count
     // the nonzeros of the full rows (lower + mirror image) where there are tiles
     size_t n_tiles = 0;
@@ -1161,6 +1167,7 @@ void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<Sy
         }
     }
 
+    lap(1);
     // 2b. read-once row segments: of what is not in a tile, the runs of three and more
     // consecutive columns of a row (cut into pieces of at most eight) are neither mirrored:
     // a lane will add their transposed products to the slots of its row-block
@@ -1207,6 +1214,7 @@ void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<Sy
         });
     }
 
+    lap(2);
     // 3. mirror image of what is not in a tile, dealt to the range of its row
     std::vector<std::vector<std::vector<Single>>> bucket(P, std::vector<std::vector<Single>>(R));
     parallel_for(P, nthreads, [&](size_t i) {
@@ -1218,6 +1226,7 @@ void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<Sy
         }
     });
 
+    lap(3);
     // 4. every range: its points as row segments and blocks, rows relative to
     // the range
     std::vector<std::vector<MirrorPoint>> thin(R);
@@ -1280,6 +1289,9 @@ void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<Sy
     if (sparse_mirror)
         for (size_t j = 0; j < R; ++j)       // (ranges ascend, points inside are sorted: ascending rows)
             sparse_mirror->insert(sparse_mirror->end(), thin[j].begin(), thin[j].end());
+    lap(4);
+    log_msg(LOG_INFO, "symmetric ranges: points and tiles %.2f s, row counts %.2f s, read-once segments %.2f s, "
+            "mirror image dealt %.2f s, ranges built %.2f s\n", t_step[0], t_step[1], t_step[2], t_step[3], t_step[4]);
 }
 
 void finalize_stream(GpuStream &s, size_t nrows)

@@ -24,9 +24,17 @@ struct Elem {
     uint16_t size;      // number of nonzeros covered (1 for singles)
     uint8_t type;       // EncType of the unit, ENC_NONE for singles
     uint8_t pad_;
+    uint32_t pad2_;     // (the struct's tail, named so that saved files do not depend on what memory held)
+
+    // (left as it is on purpose: arrays of elements are sized first and filled by several threads
+    // afterwards -- a zero fill on the sizing thread cost as much as the fill itself.  Every element
+    // is made by make_single / make_unit, which set all fields.)
+    Elem() {}
 
     bool is_unit() const { return delta != 0; }   // Element.hpp:214-219
 };
+
+static_assert(sizeof(Elem) == 32, "saved matrices hold arrays of Elem as they are");
 
 inline bool elem_less(const Elem &a, const Elem &b)
 {
@@ -37,7 +45,7 @@ inline Elem make_single(idx_t r, idx_t c, val_t v)
 {
     Elem e;
     e.row = r; e.col = c; e.val = v; e.voff = 0; e.delta = 0; e.size = 1;
-    e.type = ENC_NONE; e.pad_ = 0;
+    e.type = ENC_NONE; e.pad_ = 0; e.pad2_ = 0;
     return e;
 }
 

@@ -7,7 +7,7 @@ make -s lib
 O=build/prof; mkdir -p $O
 CS=sparsex_amd/csrc
 for f in common config partition stats encoder input reorder csx_emit gpu_emit stream_index dist api; do
-    [ $O/$f.o -nt $CS/$f.cpp ] || g++ -std=c++17 -O2 -g -fno-omit-frame-pointer -Iinclude -I$CS -pthread -c $CS/$f.cpp -o $O/$f.o
+    [ $O/$f.o -nt $CS/$f.cpp ] && [ -z "$(find $CS include -name "*.h*" -newer $O/$f.o)" ] || g++ -std=c++17 -O2 -g -fno-omit-frame-pointer -Iinclude -I$CS -pthread -c $CS/$f.cpp -o $O/$f.o
 done
 gcc -O2 -g -pg -Iinclude -c tools/prof_tune.c -o $O/prof_tune.o
 gcc -O3 -c tools/synth/nlpkkt_gen.c -o $O/nlpkkt_gen.o
