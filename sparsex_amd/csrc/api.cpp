@@ -913,8 +913,10 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     }
     const bool tune_spill = spill_mode == "auto" && !A->deterministic && !A->has_symsegs;
     const bool tune_wt = wt_mode == "auto" && !A->deterministic && !A->has_symsegs;
+    const double t_auto = now_sec();
     if (A->dev && A->nnz_stored >= 100000 && (autotune || tune_spill || tune_wt))
         autotune_launch(A.get(), autotune, tune_spill, tune_wt);
+    const double t_auto_end = now_sec();
     // column phases (auto): where the leftovers dominate and x is far larger than the L2 of an
     // XCD, the gathers miss it more often than not (syn-webbase: 1.6 M line fills for 2.5 M
     // gathers); slices of the columns that fit are measured against the plain stream
@@ -955,10 +957,13 @@ static spx_matrix_t *do_tune(spx_input_t *in)
         }
         log_msg(LOG_INFO, "column slices: %zu on XCD groups %.2f us, plain %.2f us per SpMV\n", K, 1e6 * t_ph, 1e6 * t_plain);
     }
+    const double t_release = now_sec();
     if (!cfg.get_bool("spx.rt.keep_encoded")) {
         A->parts.clear();
         A->parts.shrink_to_fit();
     }
+    log_msg(LOG_INFO, "launch parameters measured in %.2f s, encoded partitions released in %.2f s\n", t_auto_end - t_auto,
+            now_sec() - t_release);
     A->emit_seconds = now_sec() - t1;
     return A.release();
 }

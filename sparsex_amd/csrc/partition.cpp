@@ -129,12 +129,14 @@ static void sort_elems(std::vector<Elem> &elems, size_t n, idx_t max_row, std::v
     std::vector<uint32_t> start((size_t) max_row + 2, 0);      // rows are 1-based
     for (size_t i = 0; i < n; ++i) ++start[(size_t) elems[i].row + 1];
     for (size_t r = 1; r <= (size_t) max_row; ++r) start[r + 1] += start[r];
-    if (scratch.size() < n) scratch.resize(n);      // (kept by the partition: fresh pages cost more than the pass)
+    // (the second buffer is kept by the partition -- fresh pages cost more than the pass -- and the
+    // two change places afterwards; what lies behind the first n elements is not live in either)
+    if (scratch.size() < elems.size()) scratch.resize(elems.size());
     Elem *out = scratch.data();
     for (size_t i = 0; i < n; ++i) out[start[(size_t) elems[i].row]++] = elems[i];
     bool in_order = true;
     for (size_t i = 1; i < n && in_order; ++i) in_order = key(out[i - 1]) < key(out[i]);
-    std::copy(out, out + n, elems.begin());
+    elems.swap(scratch);
     if (!in_order) std::sort(elems.begin(), elems.begin() + n, less);
 }
 
