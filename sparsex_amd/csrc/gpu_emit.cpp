@@ -880,6 +880,7 @@ static void append_upper_segments(std::vector<Single> &pts, Partition &out)
     }
     sort_by_key_then(segs, [](const Seg &a) { return (int64_t) a.col; },
                      [](const Seg &a, const Seg &b) { return a.width != b.width ? a.width < b.width : a.row < b.row; });
+    out.elems.reserve(out.elems.size() + segs.size());      // (an element per group of segments: at most one per segment)
     std::vector<val_t> vals;
     for (size_t i = 0; i < segs.size();) {
         const size_t w = segs[i].width;

@@ -12,7 +12,7 @@ from sparsex_amd import synth
 import bench
 torch.cuda.set_device(0)
 csr = synth._rows("nlpkkt", 240, 0, None, None, synth.SEED_BASE + 4)
-for sym in ("false", "true", "false"):
+for sym in ("false", "true"):
     sx.lib().spx_log_info_console()
     t = time.time()
     A = bench.tune(csr, {"spx.rt.nr_threads": 32, "spx.rt.keep_encoded": "false", "spx.matrix.symmetric": sym})
@@ -21,5 +21,5 @@ for sym in ("false", "true", "false"):
         sym, i.tune_seconds, i.emit_seconds, time.time() - t), flush=True)
     A.destroy()
 PY
-grep -v "^\[INFO\]: \(Format\|launch\)" $OUT/tune_phases.txt | grep "==\|partitions\|descriptor stream" | cut -c1-200
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -3
+grep -v "^\[INFO\]: \(Format\|launch\)" $OUT/tune_phases.txt | grep "==\|partitions\|descriptor stream\|ranges\|launch param" | cut -c1-200
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_reference_client.py -x -q -m gpu 2>&1 | tail -3
