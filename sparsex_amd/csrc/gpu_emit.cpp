@@ -958,51 +958,58 @@ void append_sym_expanded(const Partition &lower, Partition &out, bool remine_upp
 }
 
 // Cuts the strictly lower points into dense 8x8 tiles (eight stacked row
-// segments of width 8) and the rest.
+// segments of width 8) and the rest (in no particular order: every user sorts it).
 static void extract_tiles(std::vector<Single> &pts, std::vector<SymTile> &tiles,
                           std::vector<Single> &rest)
 {
     sort_singles(pts);
-    struct Seg { idx_t row, col; uint32_t first; uint32_t width; };
-    std::vector<Seg> segs;
+    // only full segments can be part of a tile: runs of eight consecutive columns of a row that
+    // start on a column that is a multiple of eight (0-based), so that the eight column sums of a
+    // tile are one aligned 64-byte piece of y.  Segments are cut as the tiles' columns would cut
+    // them -- at every multiple of eight -- and the shorter ones are not looked at again.
+    struct Seg { idx_t row, col; uint32_t first; };
+    std::vector<Seg> full;
     for (size_t i = 0; i < pts.size();) {
-        // (segments end where the column number reaches a multiple of eight, so that a
-        // full one starts on such a column: the eight column sums of a tile then are
-        // one aligned 64-byte piece of y)
         size_t j = i + 1;
         while (j < pts.size() && j - i < 8 && pts[j].row == pts[i].row &&
                pts[j].col == pts[j - 1].col + 1 && (pts[j].col - 1) % 8 != 0)
             ++j;
-        segs.push_back(Seg{pts[i].row, pts[i].col, (uint32_t) i, (uint32_t)(j - i)});
+        if (j - i == 8) full.push_back(Seg{pts[i].row, pts[i].col, (uint32_t) i});
         i = j;
     }
-    sort_by_key_then(segs, [](const Seg &a) { return (int64_t) a.col; },
-                     [](const Seg &a, const Seg &b) { return a.width != b.width ? a.width < b.width : a.row < b.row; });
-    for (size_t i = 0; i < segs.size();) {
+    if (full.empty()) {                       // (a stencil: runs of three)
+        if (rest.empty()) rest.swap(pts);
+        else rest.insert(rest.end(), pts.begin(), pts.end());
+        return;
+    }
+    sort_by_key_then(full, [](const Seg &a) { return (int64_t) a.col; },
+                     [](const Seg &a, const Seg &b) { return a.row < b.row; });
+    std::vector<char> in_tile(pts.size(), 0);
+    size_t n_in_tiles = 0;
+    for (size_t i = 0; i < full.size();) {
         size_t j = i + 1;
-        while (j < segs.size() && segs[j].col == segs[i].col && segs[j].width == segs[i].width &&
-               segs[j].row == segs[j - 1].row + 1)
-            ++j;
+        while (j < full.size() && full[j].col == full[i].col && full[j].row == full[j - 1].row + 1) ++j;
+        // tiles start on rows that are multiples of eight (0-based, global): a
+        // row-block border then never has to cut one (see emit_gpu, step 2)
         size_t k = i;
-        if (segs[i].width == 8) {
-            // tiles start on rows that are multiples of eight (0-based, global): a
-            // row-block border then never has to cut one (see emit_gpu, step 2)
-            while (k < j && (segs[k].row - 1) % 8 != 0) ++k;
-            for (size_t q = i; q < k && q < j; ++q)
-                for (uint32_t w = 0; w < segs[q].width; ++w) rest.push_back(pts[segs[q].first + w]);
-            for (; k + 8 <= j; k += 8) {
-                SymTile t;
-                t.row0 = segs[k].row - 1;          // points are 1-based
-                t.col0 = segs[k].col - 1;
-                for (size_t r = 0; r < 8; ++r)
-                    for (size_t w = 0; w < 8; ++w) t.v[r * 8 + w] = pts[segs[k + r].first + w].val;
-                tiles.push_back(t);
-            }
+        while (k < j && (full[k].row - 1) % 8 != 0) ++k;
+        for (; k + 8 <= j; k += 8) {
+            SymTile t;
+            t.row0 = full[k].row - 1;          // points are 1-based
+            t.col0 = full[k].col - 1;
+            for (size_t r = 0; r < 8; ++r)
+                for (size_t w = 0; w < 8; ++w) {
+                    t.v[r * 8 + w] = pts[full[k + r].first + w].val;
+                    in_tile[full[k + r].first + w] = 1;
+                }
+            tiles.push_back(t);
+            n_in_tiles += 64;
         }
-        for (; k < j; ++k)
-            for (uint32_t w = 0; w < segs[k].width; ++w) rest.push_back(pts[segs[k].first + w]);
         i = j;
     }
+    rest.reserve(rest.size() + pts.size() - n_in_tiles);
+    for (size_t i = 0; i < pts.size(); ++i)
+        if (!in_tile[i]) rest.push_back(pts[i]);
     std::sort(tiles.begin(), tiles.end(), [](const SymTile &a, const SymTile &b) {
         return a.row0 != b.row0 ? a.row0 < b.row0 : a.col0 < b.col0;
     });
