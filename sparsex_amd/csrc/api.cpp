@@ -320,7 +320,7 @@ static bool stream_has_tiles(const GpuStream &s)
 // single entries can be found (spx_mat_get_entry / spx_mat_set_entry).
 static void keep_index(spx_matrix_t *A, GpuStream &&gs)
 {
-    std::vector<val_t>().swap(gs.values);
+    ValVec().swap(gs.values);
     std::vector<val_t>().swap(gs.dvalues);
     std::vector<val_t>().swap(gs.mirror_val);
     std::vector<uint32_t>().swap(gs.fix_idx);
@@ -1281,16 +1281,16 @@ namespace {
 
 const char kMagic[8] = {'S', 'P', 'X', 'H', 'I', 'P', '1', '4'};
 
-template <typename T>
-bool put_vec(FILE *f, const std::vector<T> &v)
+template <typename T, typename A>
+bool put_vec(FILE *f, const std::vector<T, A> &v)
 {
     uint64_t n = v.size();
     if (fwrite(&n, sizeof(n), 1, f) != 1) return false;
     return n == 0 || fwrite(v.data(), sizeof(T), n, f) == n;
 }
 
-template <typename T>
-bool get_vec(FILE *f, std::vector<T> &v)
+template <typename T, typename A>
+bool get_vec(FILE *f, std::vector<T, A> &v)
 {
     uint64_t n = 0;
     if (fread(&n, sizeof(n), 1, f) != 1) return false;

@@ -635,7 +635,7 @@ void Encoder::encode_all(std::ostream *log)
         enc_seq_.push_back(type);
     }
     spm_->transform(ENC_H);
-    std::vector<Elem>().swap(spm_->scratch);
+    ElemVec().swap(spm_->scratch);
     if (log) {
         *log << "Encoding sequence: ";
         if (enc_seq_.empty()) *log << enc_full_name(ENC_NONE);
@@ -657,7 +657,7 @@ void Encoder::encode_serial(const XformSeq &seq)
         enc_seq_.push_back(s.type);
     }
     spm_->transform(ENC_H);
-    std::vector<Elem>().swap(spm_->scratch);
+    ElemVec().swap(spm_->scratch);
 }
 
 }  // namespace spx

@@ -88,7 +88,8 @@ struct Plan {
     bool split;             // one over-long row, chunked
 };
 
-inline void pad_to(std::vector<val_t> &v, size_t mult)
+template <class V>
+inline void pad_to(V &v, size_t mult)
 {
     while (v.size() % mult) v.push_back(0.0);
 }

@@ -29,7 +29,7 @@ struct SymSeg {
 };
 
 struct GpuStream {
-    std::vector<val_t> values;
+    ValVec values;                // (6 GB on the contract matrix: big_alloc.hpp)
     std::vector<SpxUnitDesc> descs;
     std::vector<SpxPass> passes;
     std::vector<uint8_t> cidx;

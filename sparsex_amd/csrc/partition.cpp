@@ -117,7 +117,7 @@ void Partition::set_rowptr(size_t count)
 // new row numbers usually IS the sort; where it is not (block rows from row-major order, windows
 // far shorter than their row range) the comparison sort finishes the job.  Coordinates are unique:
 // either way the result is the order std::sort gives.
-static void sort_elems(std::vector<Elem> &elems, size_t n, idx_t max_row, std::vector<Elem> &scratch)
+static void sort_elems(ElemVec &elems, size_t n, idx_t max_row, ElemVec &scratch)
 {
     auto key = [](const Elem &e) { return (uint64_t) (uint32_t) e.row << 32 | (uint32_t) e.col; };
     auto less = [&](const Elem &a, const Elem &b) { return key(a) < key(b); };
@@ -201,7 +201,7 @@ static void split_rows(const Partition &src, Partition &dst, bool first_half)
     dst.type = ENC_H;
     dst.row_start = src.row_start;
     dst.nr_cols = src.nr_cols;
-    dst.pool = std::vector<val_t>();
+    dst.pool = ValVec();
     for (size_t j = 0; j < src.elems_size; ++j) {
         const Elem &e = src.elems[j];
         bool left = e.col < src.row_start + 1;

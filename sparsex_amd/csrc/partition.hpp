@@ -11,6 +11,7 @@
 #pragma once
 
 #include "common.hpp"
+#include "big_alloc.hpp"
 
 #include <vector>
 
@@ -35,6 +36,9 @@ struct Elem {
 };
 
 static_assert(sizeof(Elem) == 32, "saved matrices hold arrays of Elem as they are");
+
+typedef std::vector<Elem, BigAlloc<Elem>> ElemVec;   // (25 GB on the contract matrix: see big_alloc.hpp)
+typedef std::vector<val_t, BigAlloc<val_t>> ValVec;  // (the interleaved values of the descriptor stream)
 
 inline bool elem_less(const Elem &a, const Elem &b)
 {
@@ -67,11 +71,11 @@ public:
     size_t nnz = 0;              // nonzeros of the partition (never shrinks)
     int type = ENC_NONE;         // current iteration order
     idx_t row_start = 0;         // first row in the whole matrix (0-based)
-    std::vector<Elem> elems;     // only the first elems_size entries are live
+    ElemVec elems;               // only the first elems_size entries are live
     size_t elems_size = 0;
-    std::vector<Elem> scratch;   // transform()'s second buffer while the partition is being mined
+    ElemVec scratch;             // transform()'s second buffer while the partition is being mined
     std::vector<idx_t> rowptr;   // rowptr.size()-1 == last non-empty row
-    std::vector<val_t> pool;     // values of encoded units
+    ValVec pool;                 // values of encoded units
 
     size_t rowptr_size() const { return rowptr.size(); }
 

@@ -924,8 +924,8 @@ int device_count()
 struct Placement {
     struct Item { void **dst; const void *src; size_t copy_bytes, alloc_bytes; };
     std::vector<Item> items;
-    template <typename T>
-    void put(T **dst, const std::vector<T> &v, size_t slack_elems = 0)
+    template <typename T, typename A>
+    void put(T **dst, const std::vector<T, A> &v, size_t slack_elems = 0)
     {
         size_t bytes = (v.size() + slack_elems) * sizeof(T);
         if (bytes == 0) bytes = sizeof(T);
@@ -1661,8 +1661,8 @@ void device_host_free(void *p)
     if (p) (void) hipHostFree(p);
 }
 
-template <typename T>
-static void download(std::vector<T> &v, const T *d, size_t n)
+template <typename T, typename A>
+static void download(std::vector<T, A> &v, const T *d, size_t n)
 {
     v.resize(n);
     if (n) HIP_CHECK(hipMemcpy(v.data(), d, n * sizeof(T), hipMemcpyDeviceToHost));

@@ -3,6 +3,7 @@
 # then the stream hashes on the box (must equal the ones taken before the change) and the parity file of the suite
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/r04p; mkdir -p $OUT; cd $ROOT
+echo "transparent_hugepage: $(cat /sys/kernel/mm/transparent_hugepage/enabled) defrag: $(cat /sys/kernel/mm/transparent_hugepage/defrag)" > $OUT/thp.txt; cat $OUT/thp.txt
 python3 - > $OUT/tune_phases.txt 2>&1 <<'PY'
 import sys, time, os
 sys.path.insert(0, ".")
@@ -21,5 +22,5 @@ for sym in ("false", "true"):
         sym, i.tune_seconds, i.emit_seconds, time.time() - t), flush=True)
     A.destroy()
 PY
-grep -v "^\[INFO\]: \(Format\|launch\)" $OUT/tune_phases.txt | grep "==\|partitions\|descriptor stream\|ranges\|launch param" | cut -c1-200
+grep -v "^\[INFO\]: \(Format\|launch\)" $OUT/tune_phases.txt | grep "==\|partitions\|descriptor stream\|ranges\|released" | cut -c1-200
 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_reference_client.py -x -q -m gpu 2>&1 | tail -3
