@@ -359,7 +359,7 @@ static void emit_and_upload(spx_matrix_t *A)
     // pieces (partitions, row ranges) are emitted concurrently into streams of
     // their own and joined in order; threads left over work inside a piece
     auto emit_pieces = [&](std::vector<Partition> &pieces, const std::vector<std::vector<SymTile>> *tl,
-                           const std::vector<std::vector<SymSeg>> *sl = nullptr) {
+                           const std::vector<SymSegVec> *sl = nullptr) {
         const size_t n = pieces.size();
         std::vector<GpuStream> locs(n);
         const unsigned inner = (unsigned) std::max<size_t>(1, hw / std::max<size_t>(1, std::min<size_t>(n, hw)));
@@ -455,7 +455,7 @@ static void emit_and_upload(spx_matrix_t *A)
             std::vector<MirrorPoint> thin;
             // read-once row segments need the atomic hand-over (their fall-back adds straight
             // to y) and so exclude the deterministic mode
-            std::vector<std::vector<SymSeg>> segs;
+            std::vector<SymSegVec> segs;
             size_t n_seg_elems = 0, n_lower = 0;
             for (const Partition &pt : A->parts) n_lower += pt.nnz;
             const size_t min_lower = (size_t) 16 << 20;       // (auto: see below)
@@ -487,6 +487,12 @@ static void emit_and_upload(spx_matrix_t *A)
             // triangle lies in the multiplier rows -- need no row-block)
             if (use_segs) gp.skip_empty = true;
             emit_pieces(fulls, &tiles, use_segs ? &segs : nullptr);
+            // (handed back on all host threads, like the encoded partitions further down)
+            parallel_for(fulls.size(), hw, [&](size_t i) {
+                fulls[i] = Partition();
+                if (i < segs.size()) SymSegVec().swap(segs[i]);
+                if (i < tiles.size()) std::vector<SymTile>().swap(tiles[i]);
+            });
             // thinly spread mirror image on rows of other processes: a CSR over those rows
             for (size_t k = 0; k < thin.size(); ++k) {
                 if (k == 0 || thin[k].row != thin[k - 1].row) {

@@ -20,6 +20,7 @@ struct Piece {
 };
 
 struct Single { idx_t row, col; val_t val; };   // 0-based row (partition), 0-based col
+typedef std::vector<Single, BigAlloc<Single>> SingleVec;   // (the symmetric path holds a triangle's points in these: 6 GB on the contract matrix)
 struct RowSeg { idx_t row, col; uint8_t width; val_t v[SPX_MAX_SEG_WIDTH]; };   // same numbering
 
 // Sorts by an integer key first and by `within` among equal keys.  The keys of a row-block's or a
@@ -27,9 +28,10 @@ struct RowSeg { idx_t row, col; uint8_t width; val_t v[SPX_MAX_SEG_WIDTH]; };   
 // counting pass over the keys and a short sort inside every bucket replaces the comparison sort
 // (whose quicksort also degenerates on the runs that mined units leave).  Where (key, within) is a
 // total order -- coordinates are unique -- the result is the one std::sort gives.
-template <class T, class KeyOf, class Within>
-void sort_by_key_then(std::vector<T> &v, KeyOf key_of, Within within)
+template <class V, class KeyOf, class Within>
+void sort_by_key_then(V &v, KeyOf key_of, Within within)
 {
+    typedef typename V::value_type T;
     const size_t n = v.size();
     if (n < 2) return;
     auto less = [&](const T &a, const T &b) {
@@ -52,7 +54,7 @@ void sort_by_key_then(std::vector<T> &v, KeyOf key_of, Within within)
     std::vector<uint32_t> start(span + 1, 0);
     for (const T &e : v) ++start[(size_t) (key_of(e) - lo) + 1];
     for (size_t r = 0; r < span; ++r) start[r + 1] += start[r];
-    std::vector<T> out(n);
+    V out(n);
     {
         std::vector<uint32_t> pos(start.begin(), start.end() - 1);
         for (const T &e : v) out[pos[(size_t) (key_of(e) - lo)]++] = e;
@@ -72,13 +74,14 @@ void sort_by_key_then(std::vector<T> &v, KeyOf key_of, Within within)
     v.swap(out);
 }
 
-template <class T, class RowOf, class ColOf>
-void sort_by_row_col(std::vector<T> &v, RowOf row_of, ColOf col_of)
+template <class V, class RowOf, class ColOf>
+void sort_by_row_col(V &v, RowOf row_of, ColOf col_of)
 {
+    typedef typename V::value_type T;
     sort_by_key_then(v, row_of, [&](const T &a, const T &b) { return col_of(a) < col_of(b); });
 }
 
-inline void sort_singles(std::vector<Single> &v)
+inline void sort_singles(SingleVec &v)
 {
     sort_by_row_col(v, [](const Single &s) { return (int64_t) s.row; }, [](const Single &s) { return s.col; });
 }
@@ -115,14 +118,14 @@ public:
     struct Part {
         idx_t lo, hi;
         const std::vector<Piece> *pieces;
-        std::vector<Single> *singles;
+        SingleVec *singles;
         const std::vector<const SymTile *> *tiles;
         const std::vector<RowSeg> *rowsegs;
         const std::vector<const SymSeg *> *symsegs;
     };
     // emits one row-block for rows [lo, hi) from the given pieces/singles
     void emit(idx_t lo, idx_t hi, const std::vector<Piece> &pieces,
-              std::vector<Single> &singles, uint8_t flags, uint32_t carry_slot,
+              SingleVec &singles, uint8_t flags, uint32_t carry_slot,
               const std::vector<const SymTile *> *tiles = nullptr,
               const std::vector<RowSeg> *rowsegs = nullptr,
               const std::vector<const SymSeg *> *symsegs = nullptr)
@@ -162,7 +165,7 @@ private:
         if (it == slot_groups_.end() || *it != g) return SPX_NO_SLOT;
         return (uint32_t)(it - slot_groups_.begin()) * 8u + (uint32_t)(c & 7);
     }
-    void emit_gather_passes(SpxRowBlock &rb, std::vector<Single> &singles, idx_t lo);
+    void emit_gather_passes(SpxRowBlock &rb, SingleVec &singles, idx_t lo);
     void emit_tile_passes(SpxRowBlock &rb, const std::vector<const SymTile *> &tiles, uint32_t row_base = 0);
 
     const Partition &p_;
@@ -447,7 +450,7 @@ void RbBuilder::emit_unit_passes(SpxRowBlock &rb, bool sym, uint32_t row_base)
 // become the row-block's x window: the workgroup stages x[window] in LDS with
 // coalesced loads and these leftovers gather from LDS (SPX_PASS_GATHER_LDS, u16
 // offsets); the others gather through L2 as before.
-void RbBuilder::emit_gather_passes(SpxRowBlock &rb, std::vector<Single> &singles, idx_t lo)
+void RbBuilder::emit_gather_passes(SpxRowBlock &rb, SingleVec &singles, idx_t lo)
 {
     sort_singles(singles);
     const size_t n = singles.size();
@@ -491,9 +494,9 @@ void RbBuilder::emit_gather_passes(SpxRowBlock &rb, std::vector<Single> &singles
         for (idx_t c : cols) inside += c >= wlo && c <= whi;
         if (inside < 64 || best <= 0) whi = wlo - 1;     // too few to be worth a pass of their own
     }
-    std::vector<Single> near;
+    SingleVec near;
     if (whi >= wlo) {
-        std::vector<Single> far;
+        SingleVec far;
         for (const Single &s : singles) (s.col >= wlo && s.col <= whi ? near : far).push_back(s);
         singles.swap(far);
         rb.xwin_base = (uint32_t) wlo;
@@ -510,7 +513,7 @@ void RbBuilder::emit_gather_passes(SpxRowBlock &rb, std::vector<Single> &singles
     // shorter ones are padded (zero value, offset 0; the piece's length travels with
     // its row in `segrows`, the lanes skip what is not there).  A pass is closed
     // early when the padding would pass 30 % of it.
-    auto emit_set = [&](const std::vector<Single> &set, uint8_t kind, idx_t base, unsigned width,
+    auto emit_set = [&](const SingleVec &set, uint8_t kind, idx_t base, unsigned width,
                         size_t area) {
         const size_t m = set.size();
         std::vector<Piece2> pcs;
@@ -810,10 +813,10 @@ void RbBuilder::emit(std::vector<Part> &parts, uint8_t flags, uint32_t carry_slo
         emit_unit_passes(rb, false, (uint32_t)(pt.lo - lo));
     }
     // the leftovers of all parts together (their rows count from the row-block's first)
-    std::vector<Single> merged;
+    SingleVec merged;
     if (parts.size() > 1)
         for (const Part &pt : parts) merged.insert(merged.end(), pt.singles->begin(), pt.singles->end());
-    std::vector<Single> &singles = parts.size() > 1 ? merged : *parts.front().singles;
+    SingleVec &singles = parts.size() > 1 ? merged : *parts.front().singles;
     const size_t n_delta = singles.size();
     emit_gather_passes(rb, singles, lo);
     // keep whole-lane over-reads of the last pass inside the arrays
@@ -866,7 +869,7 @@ static Elem mirror_unit(const Elem &e, const val_t *src, Partition &out)
 // shaped (a horizontal unit becomes a vertical one: one lane and one LDS add
 // per nonzero), while eight stacked horizontal units mirror to a dense block
 // that this finds again.
-static void append_upper_segments(std::vector<Single> &pts, Partition &out)
+static void append_upper_segments(SingleVec &pts, Partition &out)
 {
     sort_singles(pts);
     struct Seg { idx_t row, col; uint32_t first; uint32_t width; };
@@ -929,7 +932,7 @@ void append_sym_expanded(const Partition &lower, Partition &out, bool remine_upp
     out.row_start = 0;
     out.nr_cols = lower.nr_cols;
     out.nr_rows = std::max<size_t>(out.nr_rows, (size_t) rs + lower.nr_rows);
-    std::vector<Single> upper;      // 1-based coordinates of the mirrored nonzeros
+    SingleVec upper;      // 1-based coordinates of the mirrored nonzeros
     if (remine_upper) upper.reserve(lower.nnz);
     for (size_t i = 0; i < lower.elems_size; ++i) {
         Elem e = lower.elems[i];
@@ -960,8 +963,8 @@ void append_sym_expanded(const Partition &lower, Partition &out, bool remine_upp
 
 // Cuts the strictly lower points into dense 8x8 tiles (eight stacked row
 // segments of width 8) and the rest (in no particular order: every user sorts it).
-static void extract_tiles(std::vector<Single> &pts, std::vector<SymTile> &tiles,
-                          std::vector<Single> &rest)
+static void extract_tiles(SingleVec &pts, std::vector<SymTile> &tiles,
+                          SingleVec &rest)
 {
     sort_singles(pts);
     // only full segments can be part of a tile: runs of eight consecutive columns of a row that
@@ -1076,7 +1079,7 @@ void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<Sy
                       bool want_tiles, std::vector<Partition> &outs,
                       std::vector<std::vector<SymTile>> &tiles, unsigned nthreads,
                       std::vector<MirrorPoint> *sparse_mirror,
-                      std::vector<std::vector<SymSeg>> *symsegs, size_t min_run)
+                      std::vector<SymSegVec> *symsegs, size_t min_run)
 {
     const size_t P = lowers.size(), R = ranges.size();
     auto clock = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1105,12 +1108,12 @@ void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<Sy
 
     // 1. every partition: its strictly lower points (1-based global), dense
     // aligned 8x8 tiles apart
-    std::vector<std::vector<Single>> rest(P);
+    std::vector<SingleVec> rest(P);
     std::vector<std::vector<SymTile>> ptiles(P);
     parallel_for(P, nthreads, [&](size_t i) {
         const Partition &lower = lowers[i];
         const idx_t rs = lower.row_start;
-        std::vector<Single> pts;
+        SingleVec pts;
         pts.reserve(lower.nnz);
         for (size_t k = 0; k < lower.elems_size; ++k) {
             const Elem &e = lower.elems[k];
@@ -1180,13 +1183,14 @@ void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<Sy
     // 2b. read-once row segments: of what is not in a tile, the runs of three and more
     // consecutive columns of a row (cut into pieces of at most eight) are neither mirrored:
     // a lane will add their transposed products to the slots of its row-block
-    std::vector<std::vector<SymSeg>> psegs(P);
+    std::vector<SymSegVec> psegs(P);
     if (symsegs) {
-        symsegs->assign(R, std::vector<SymSeg>());
+        symsegs->assign(R, SymSegVec());
         parallel_for(P, nthreads, [&](size_t i) {
-            std::vector<Single> &pts = rest[i];
+            SingleVec &pts = rest[i];
             sort_singles(pts);
-            std::vector<Single> loose;
+            SingleVec loose;
+            psegs[i].reserve(pts.size() / std::max<size_t>(std::min<size_t>(min_run, 4), 1) / 2 + 1);
             for (size_t a = 0; a < pts.size();) {
                 size_t b = a + 1;
                 while (b < pts.size() && pts[b].row == pts[a].row && pts[b].col == pts[b - 1].col + 1) ++b;
@@ -1225,7 +1229,7 @@ void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<Sy
 
     lap(2);
     // 3. mirror image of what is not in a tile, dealt to the range of its row
-    std::vector<std::vector<std::vector<Single>>> bucket(P, std::vector<std::vector<Single>>(R));
+    std::vector<std::vector<SingleVec>> bucket(P, std::vector<SingleVec>(R));
     parallel_for(P, nthreads, [&](size_t i) {
         size_t j = 0;
         for (const Single &s : rest[i]) {
@@ -1240,19 +1244,19 @@ void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<Sy
     // the range
     std::vector<std::vector<MirrorPoint>> thin(R);
     parallel_for(R, nthreads, [&](size_t j) {
-        std::vector<Single> pts;
+        SingleVec pts;
         size_t total = 0;
         for (size_t i = 0; i < P; ++i) total += bucket[i][j].size() + (own_range[i] == j ? rest[i].size() : 0);
         pts.reserve(total + total / 8);
         for (size_t i = 0; i < P; ++i) {
             if (own_range[i] == j) {
                 pts.insert(pts.end(), rest[i].begin(), rest[i].end());
-                std::vector<Single>().swap(rest[i]);
+                SingleVec().swap(rest[i]);
                 tiles[j].swap(ptiles[i]);
                 if (symsegs) (*symsegs)[j].swap(psegs[i]);
             }
             pts.insert(pts.end(), bucket[i][j].begin(), bucket[i][j].end());
-            std::vector<Single>().swap(bucket[i][j]);
+            SingleVec().swap(bucket[i][j]);
         }
         sort_singles(pts);
         // A range that holds only mirror image (rows of other processes): stretches of
@@ -1261,7 +1265,7 @@ void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<Sy
         bool mirror_only = true;
         for (size_t i = 0; i < P; ++i) mirror_only = mirror_only && own_range[i] != j;
         if (sparse_mirror && mirror_only && !pts.empty()) {
-            std::vector<Single> keep;
+            SingleVec keep;
             for (size_t a = 0; a < pts.size();) {
                 const idx_t chunk = (pts[a].row - 1 - ranges[j].lo) / 512;
                 size_t b = a;
@@ -1384,8 +1388,8 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsi
     const std::vector<SymTile> &tiles = prm.tiles ? *prm.tiles : no_tiles;
     for (const SymTile &t : tiles)
         for (idx_t r = 0; r < 8; ++r) cnt[(size_t)(t.row0 - p.row_start + r)] += 8;
-    static const std::vector<SymSeg> no_segs;
-    const std::vector<SymSeg> &symsegs = prm.symsegs ? *prm.symsegs : no_segs;
+    static const SymSegVec no_segs;
+    const SymSegVec &symsegs = prm.symsegs ? *prm.symsegs : no_segs;
     for (const SymSeg &sg : symsegs) cnt[(size_t)(sg.row - p.row_start)] += sg.width;
 
     // 2. row ranges of the row-blocks.  Symmetric tiles sit on rows that are
@@ -1443,7 +1447,7 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsi
     // 3. cut every unit at row-block borders
     std::vector<std::vector<Piece>> pieces(plans.size());
     std::vector<std::vector<Piece>> lin_pieces(plans.size());   // of one-nonzero-per-lane units
-    std::vector<std::vector<Single>> singles(plans.size());
+    std::vector<SingleVec> singles(plans.size());
     auto add_singles = [&](const Elem &u, size_t k0, size_t k1) {
         for (size_t k = k0; k < k1; ++k) {
             idx_t r, c;
@@ -1517,7 +1521,7 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsi
         // of its own (4 bytes of index per nonzero, a gather pass) where the unit is one 8-byte
         // descriptor for the whole run: the main diagonal of a KKT system, whose rows hold their
         // stencil far from it, is such a unit.  Those stay what the miner made them.
-        std::vector<Single> pts;
+        SingleVec pts;
         {
             struct Pt { Single s; uint32_t piece; };
             std::vector<Pt> all;
@@ -1706,7 +1710,7 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsi
             return;
         }
         // an over-long row: everything is a single here; chunk it
-        std::vector<Single> &all = singles[i];
+        SingleVec &all = singles[i];
         std::sort(all.begin(), all.end(),
                   [](const Single &x, const Single &y) { return x.col < y.col; });
         const size_t chunk = SPX_MAX_RB_ELEMS / 2;
@@ -1717,7 +1721,7 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsi
         std::vector<Piece> none;
         for (size_t b = 0; b < all.size(); b += chunk) {
             size_t e2 = std::min(all.size(), b + chunk);
-            std::vector<Single> part(all.begin() + b, all.begin() + e2);
+            SingleVec part(all.begin() + b, all.begin() + e2);
             bld.emit(pl.row_lo, pl.row_hi, none, part, SPX_RB_SHARED, dst.n_carry);
             ++dst.n_carry;
             ++sr.n_slots;

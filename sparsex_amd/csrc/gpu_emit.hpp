@@ -27,6 +27,7 @@ struct SymSeg {
     uint8_t width;         // 3..8
     val_t v[8];
 };
+typedef std::vector<SymSeg, BigAlloc<SymSeg>> SymSegVec;   // (ten gigabytes on the contract matrix)
 
 struct GpuStream {
     ValVec values;                // (6 GB on the contract matrix: big_alloc.hpp)
@@ -119,7 +120,7 @@ struct GpuEmitParams {
     bool sym_once = true;         // spx.gpu.sym_once: dense 8x8 tiles of a symmetric matrix are
                                   // read once (one process holding the whole matrix only)
     const std::vector<SymTile> *tiles = nullptr;   // symmetric, fused: tiles read once (sorted by row0)
-    const std::vector<SymSeg> *symsegs = nullptr;  // symmetric: lower row segments read once (sorted by row)
+    const SymSegVec *symsegs = nullptr;  // symmetric: lower row segments read once (sorted by row)
 };
 
 // Appends the row-blocks of partition `p` (horizontal order) to `out`.
@@ -170,7 +171,7 @@ void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<Sy
                       bool want_tiles, std::vector<Partition> &outs,
                       std::vector<std::vector<SymTile>> &tiles, unsigned nthreads,
                       std::vector<MirrorPoint> *sparse_mirror = nullptr,
-                      std::vector<std::vector<SymSeg>> *symsegs = nullptr, size_t min_run = 2);
+                      std::vector<SymSegVec> *symsegs = nullptr, size_t min_run = 2);
 
 // coordinates (1-based, horizontal order) of element k of a unit
 inline void unit_elem_coords(const Elem &u, size_t k, idx_t &r, idx_t &c)
