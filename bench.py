@@ -346,6 +346,27 @@ def host_topology():
     return out
 
 
+def huge_page_copy(a):
+    """A copy of `a` whose pages are asked for as transparent huge pages before they are first
+    touched (madvise on the 2 MB-aligned inside of the new array): the CPU baseline streams
+    gigabytes through them, and the library's own preprocessor gets the same treatment
+    (csrc/big_alloc.hpp).  A no-op where the system does not offer them."""
+    import ctypes as C
+    out = np.empty_like(a)
+    if out.nbytes >= (8 << 20):
+        two_mb = 2 << 20
+        lo = (out.ctypes.data + two_mb - 1) // two_mb * two_mb
+        hi = (out.ctypes.data + out.nbytes) // two_mb * two_mb
+        if hi > lo:
+            try:
+                libc = C.CDLL(None, use_errno=True)
+                libc.madvise(C.c_void_p(lo), C.c_size_t(hi - lo), 14)       # MADV_HUGEPAGE
+            except (OSError, AttributeError):
+                pass
+    out[...] = a
+    return out
+
+
 def pick_cpus(threads):
     """CPUs for `threads` pinned workers: one hardware thread per physical core, the
     sockets filled evenly and in turn (partition i next to partition i + 1), SMT
@@ -397,7 +418,7 @@ def _time_baseline(ex, csr, x, n, threads, symmetric, loops, batches=5):
             os.sched_setaffinity(0, {cpu_list[i]})
             for k in ("values", "ctl", "dvalues"):
                 if e.get(k) is not None:
-                    e[k] = np.array(e[k], copy=True)
+                    e[k] = huge_page_copy(np.asarray(e[k]))
     finally:
         os.sched_setaffinity(0, home)
     # the reference's own template code, one specialised routine per partition, where
@@ -537,7 +558,7 @@ def cpu_baseline(csr, symmetric, budget_s=20.0, sample=""):
             "kind": kind, "single_thread": single,
             "sample": "%smedian of 5 batches x %d SpMVs (alpha=0.5), one partition per pinned thread, "
                       "threads spread over the %d socket%s (one per physical core first), every partition's arrays "
-                      "first-touched on its worker's CPU, %s; thread counts tried (GFLOP/s): %s; host has %d "
+                      "first-touched on its worker's CPU in transparent huge pages, %s; thread counts tried (GFLOP/s): %s; host has %d "
                       "hardware threads on %d physical cores" % (
                           sample, loops, sockets, "s" if sockets > 1 else "",
                           "local buffers + conflict-map reduction" if symmetric
