@@ -192,10 +192,12 @@ void Encoder::generate_stats(Partition *sp, StatsCollection &stats)
     // (as a point at their anchor): the reference marks pattern members only
     // on temporary copies (:631-643, Element.hpp:138-151), so its InPattern
     // test never fires on the matrix itself.
-    size_t nr = sp->rowptr_size() - 1;
-    for (size_t i = 0; i < nr; ++i) {
-        for (idx_t j = sp->rowptr[i]; j < sp->rowptr[i + 1]; ++j)
-            cols_buff_.push_back(sp->elems[j].col);
+    // (walked element by element: in column or diagonal order most "rows" of a sampling window are
+    // empty, and an empty row has nothing to say)
+    const size_t n = sp->elems_size;
+    for (size_t j = 0; j < n;) {
+        const idx_t row = sp->elems[j].row;
+        for (; j < n && sp->elems[j].row == row; ++j) cols_buff_.push_back(sp->elems[j].col);
         update_stats(sp, cols_buff_, stats);
     }
 }
@@ -314,10 +316,10 @@ void Encoder::gen_all_stats(StatsCollection &stats)
             samples_nnz += sort_splits_nzeros_[sel];
             for (int t = ENC_H; t < ENC_MAX; ++t) {
                 if (ignore_[(size_t) t]) continue;
-                window.transform(t);
+                window.transform(t, false);
                 generate_stats(&window, stats);
             }
-            window.transform(ENC_H);
+            window.transform(ENC_H, false);
             spm_->put_window(window);
         }
         if (samples_nnz)

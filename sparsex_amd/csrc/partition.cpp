@@ -140,7 +140,7 @@ static void sort_elems(ElemVec &elems, size_t n, idx_t max_row, ElemVec &scratch
     if (!in_order) std::sort(elems.begin(), elems.begin() + n, less);
 }
 
-void Partition::transform(int t)
+void Partition::transform(int t, bool with_rowptr)
 {
     if (type == t) return;
     const idx_t nr = (idx_t) nr_rows, nc = (idx_t) nr_cols;
@@ -153,7 +153,12 @@ void Partition::transform(int t)
     // (the reference sorts band-by-band when both orders belong to the same row/column family,
     // SparsePartition.hpp:704-734)
     sort_elems(elems, elems_size, max_row, scratch);
-    if (elems_size) set_rowptr(elems_size);
+    if (!with_rowptr) {
+        rowptr.clear();
+        rowptr.push_back(0);
+    } else if (elems_size) {
+        set_rowptr(elems_size);
+    }
     type = t;
 }
 

@@ -85,7 +85,9 @@ public:
 
     // re-coordinates every element for iteration order t and sorts
     // (SparsePartition::Transform, SparsePartition.hpp:680-744)
-    void transform(int t);
+    // (with_rowptr = false: for a sampling window that is only walked element by element -- in
+    // column or diagonal order its row pointer would have a slot for every column of the matrix)
+    void transform(int t, bool with_rowptr = true);
 
     // sampling windows: move rows [rs, rs+length) out / back
     // (GetWindow / PutWindow, SparsePartition.hpp:775-839)
