@@ -963,16 +963,15 @@ static spx_matrix_t *do_tune(spx_input_t *in)
         }
         log_msg(LOG_INFO, "column slices: %zu on XCD groups %.2f us, plain %.2f us per SpMV\n", K, 1e6 * t_ph, 1e6 * t_plain);
     }
-    const double t_release = now_sec();
     if (!cfg.get_bool("spx.rt.keep_encoded")) {
-        // (on all host threads: handing 25 GB of the contract matrix back page by page took 3.6 s on one)
-        std::vector<Partition> &ps = A->parts;
-        parallel_for(ps.size(), host_threads(), [&](size_t i) { ps[i] = Partition(); });
-        A->parts.clear();
-        A->parts.shrink_to_fit();
+        std::vector<Partition> *old = new std::vector<Partition>();
+        old->swap(A->parts);
+        A->release_thread = std::thread([old] {
+            parallel_for(old->size(), host_threads(), [&](size_t i) { (*old)[i] = Partition(); });
+            delete old;
+        });
     }
-    log_msg(LOG_INFO, "launch parameters measured in %.2f s, encoded partitions released in %.2f s\n", t_auto_end - t_auto,
-            now_sec() - t_release);
+    log_msg(LOG_INFO, "launch parameters measured in %.2f s\n", t_auto_end - t_auto);
     A->emit_seconds = now_sec() - t1;
     return A.release();
 }

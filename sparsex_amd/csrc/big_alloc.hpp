@@ -5,7 +5,7 @@
 // its lock) and as many pages to hand back afterwards -- the time `spx_mat_tune` spent building the
 // partitions and releasing them was mostly that.  Blocks of 32 MB and more are therefore mapped on
 // their own, aligned to 2 MB and marked for transparent huge pages (a no-op where the system does
-// not offer them); smaller ones go to malloc as before.
+// not offer them; SPX_NO_HUGE_PAGES=1 switches the marking off); smaller ones go to malloc as before.
 #pragma once
 
 #include <cstddef>
@@ -41,7 +41,10 @@ struct BigAlloc {
         if (p > raw) munmap(raw, (size_t) (p - raw));
         if (p + len < raw + len + kHuge) munmap(p + len, (size_t) (raw + len + kHuge - (p + len)));
 #ifdef MADV_HUGEPAGE
-        madvise(p, len, MADV_HUGEPAGE);
+        // (SPX_NO_HUGE_PAGES=1 in the environment leaves the pages to the system's default: on a host
+        // whose memory is fragmented a huge-page fault may wait for compaction)
+        static const bool off = std::getenv("SPX_NO_HUGE_PAGES") != nullptr;
+        if (!off) madvise(p, len, MADV_HUGEPAGE);
 #endif
         return reinterpret_cast<T *>(p);
     }
