@@ -23,4 +23,4 @@ for sym in ("false", "true"):
     A.destroy()
 PY
 grep -v "^\[INFO\]: \(Format\|launch\)" $OUT/tune_phases.txt | grep "==\|partitions\|descriptor stream\|ranges\|released" | cut -c1-200
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_reference_client.py -x -q -m gpu 2>&1 | tail -3
+( time timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_reference_client.py -x -q -m gpu --durations=6 ) 2>&1 | tail -14
