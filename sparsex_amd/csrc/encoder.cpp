@@ -625,6 +625,9 @@ void Encoder::encode_all(std::ostream *log)
     if (!spm_->nnz) return;
     encoded_stats_.clear();
     enc_seq_.clear();
+    // (the values of all units together cannot outnumber the nonzeros: address space now, pages as
+    // they are written, no copy each time the pool doubles)
+    if (spm_->nnz * sizeof(val_t) >= ((size_t) 32 << 20)) spm_->pool.reserve(spm_->pool.size() + spm_->nnz);
     for (;;) {
         StatsCollection type_stats;
         gen_all_stats(type_stats);

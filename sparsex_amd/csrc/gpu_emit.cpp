@@ -292,12 +292,21 @@ void RbBuilder::stack_groups()
         kept.push_back(g);
     };
     auto diag_id = [&](uint32_t k) { return (int64_t) runs[k].col0 - (int64_t) runs[k].row0; };
+    // index lists are sorted through one packed 64-bit key per run (width: 8 bits, a column or a
+    // diagonal: 33, the row inside the row-block: 16) instead of a comparison that looks three
+    // fields up per step; the keys are unique (no two runs start on the same nonzero)
+    struct Keyed { uint64_t key; uint32_t idx; };
+    std::vector<Keyed> keyed;
+    auto sort_by_key = [&](std::vector<uint32_t> &idx, auto key_of) {
+        keyed.resize(idx.size());
+        for (size_t i = 0; i < idx.size(); ++i) keyed[i] = Keyed{key_of(idx[i]), idx[i]};
+        std::sort(keyed.begin(), keyed.end(), [](const Keyed &a, const Keyed &b) { return a.key < b.key; });
+        for (size_t i = 0; i < idx.size(); ++i) idx[i] = keyed[i].idx;
+    };
     // chains along diagonals; `min_len` segments at least; returns what is left
     auto diagonal_chains = [&](std::vector<uint32_t> idx, size_t min_len) {
-        std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) {
-            if (runs[a].width != runs[b].width) return runs[a].width < runs[b].width;
-            if (diag_id(a) != diag_id(b)) return diag_id(a) < diag_id(b);
-            return runs[a].row0 < runs[b].row0;
+        sort_by_key(idx, [&](uint32_t k) {
+            return (uint64_t) runs[k].width << 56 | (uint64_t) (diag_id(k) + 65536) << 16 | runs[k].row0;
         });
         std::vector<uint32_t> left;
         for (size_t i = 0; i < idx.size();) {
@@ -327,10 +336,8 @@ void RbBuilder::stack_groups()
     for (uint32_t k = 0; k < idx.size(); ++k) idx[k] = k;
     idx = diagonal_chains(idx, 8);
     // dense blocks
-    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) {
-        if (runs[a].width != runs[b].width) return runs[a].width < runs[b].width;
-        if (runs[a].col0 != runs[b].col0) return runs[a].col0 < runs[b].col0;
-        return runs[a].row0 < runs[b].row0;
+    sort_by_key(idx, [&](uint32_t k) {
+        return (uint64_t) runs[k].width << 56 | (uint64_t) runs[k].col0 << 16 | runs[k].row0;
     });
     std::vector<uint32_t> lone;
     for (size_t i = 0; i < idx.size();) {
@@ -344,9 +351,7 @@ void RbBuilder::stack_groups()
         i = j;
     }
     // full chunks next to each other in one row
-    std::sort(lone.begin(), lone.end(), [&](uint32_t a, uint32_t b) {
-        return runs[a].row0 != runs[b].row0 ? runs[a].row0 < runs[b].row0 : runs[a].col0 < runs[b].col0;
-    });
+    sort_by_key(lone, [&](uint32_t k) { return (uint64_t) runs[k].row0 << 32 | runs[k].col0; });
     std::vector<uint32_t> rest;
     for (size_t i = 0; i < lone.size();) {
         size_t j = i + 1;
