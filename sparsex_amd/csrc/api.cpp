@@ -371,45 +371,53 @@ static void emit_and_upload(spx_matrix_t *A)
             emit_gpu(pieces[i], g, locs[i], inner);
         });
         const double t_room = now_sec();
-        // (the joined arrays are sized once: growing a 6 GB vector piece by piece copies it again and again)
+        // The joined arrays are sized once (growing a 6 GB vector piece by piece copies it again and again), and the
+        // values -- nearly all of the bytes -- are copied to their places by all host threads at once: the array is
+        // sized without being written (big_alloc.hpp), so that its pages are first touched by the copying threads.
+        // Offsets as append_stream would choose them: every non-empty piece starts on an even element.
+        std::vector<uint64_t> v_at(n, UINT64_MAX);
         {
             size_t nv = gs.values.size(), nd = gs.descs.size(), np = gs.passes.size(), nc = gs.cidx.size(),
                    ns = gs.segrows.size(), nr = gs.rbs.size();
-            for (const GpuStream &l : locs) {
-                nv += l.values.size() + 2;
+            for (size_t i = 0; i < n; ++i) {
+                const GpuStream &l = locs[i];
+                if (!(l.rbs.empty() && l.shared.empty())) {
+                    nv += nv % 2;
+                    v_at[i] = nv;
+                    nv += l.values.size();
+                }
                 nd += l.descs.size();
                 np += l.passes.size();
                 nc += l.cidx.size() + 16;
                 ns += l.segrows.size();
                 nr += l.rbs.size();
             }
-            // (the first piece is taken over as it is -- append_stream swaps into an empty stream -- and
-            // the room for the others is made behind it in one step)
-            if (n) append_stream(gs, std::move(locs[0]));
-            if (n > 1) {
-                gs.values.reserve(nv);
-                gs.descs.reserve(nd);
-                gs.passes.reserve(np);
-                gs.cidx.reserve(nc);
-                gs.segrows.reserve(ns);
-                gs.rbs.reserve(nr);
-                // The pages behind the first piece are touched by all host threads before the pieces are copied
-                // in one after the other: a fresh 6 GB region faults in at ~1 GB/s on one thread, and that was
-                // most of the time the join took.  (Storage the vector has reserved and not yet given out; a
-                // double needs no construction.)
-                if ((nv - gs.values.size()) * sizeof(val_t) > ((size_t) 64 << 20)) {
-                    val_t *base = gs.values.data();
-                    const size_t lo = gs.values.size(), hi = gs.values.capacity(), step = 4096 / sizeof(val_t);
-                    const size_t chunk = (size_t) 8 << 20, nchunk = (hi - lo + chunk - 1) / chunk;
-                    parallel_for(nchunk, hw, [&](size_t k) {
-                        const size_t b = lo + k * chunk, e = std::min(hi, b + chunk);
-                        for (size_t i = b; i < e; i += step) base[i] = 0.0;
-                    });
-                }
+            const size_t had = gs.values.size();
+            gs.values.resize(nv);
+            gs.descs.reserve(nd);
+            gs.passes.reserve(np);
+            gs.cidx.reserve(nc);
+            gs.segrows.reserve(ns);
+            gs.rbs.reserve(nr);
+            val_t *base = gs.values.data();
+            struct Copy { const val_t *src; size_t at, len; };
+            std::vector<Copy> copies;
+            const size_t chunk = (size_t) 4 << 20;          // 32 MB of values per task
+            size_t end = had;
+            for (size_t i = 0; i < n; ++i) {
+                if (v_at[i] == UINT64_MAX) continue;
+                for (size_t k = end; k < v_at[i]; ++k) base[k] = 0.0;       // (the padding element in between)
+                const size_t len = locs[i].values.size();
+                for (size_t o = 0; o < len; o += chunk)
+                    copies.push_back(Copy{locs[i].values.data() + o, (size_t) v_at[i] + o, std::min(chunk, len - o)});
+                end = v_at[i] + len;
             }
+            parallel_for(copies.size(), hw, [&](size_t k) {
+                std::memcpy(base + copies[k].at, copies[k].src, copies[k].len * sizeof(val_t));
+            });
         }
         const double t_join = now_sec();
-        for (size_t i = 1; i < n; ++i) append_stream(gs, std::move(locs[i]));
+        for (size_t i = 0; i < n; ++i) append_stream(gs, std::move(locs[i]), v_at[i]);
         log_msg(LOG_INFO, "descriptor stream: %zu pieces emitted in %.2f s, room made in %.2f s, joined in %.2f s\n", n,
                 t_room - t_pieces, t_join - t_room, now_sec() - t_join);
     };

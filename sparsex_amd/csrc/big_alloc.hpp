@@ -11,6 +11,7 @@
 #include <cstddef>
 #include <cstdlib>
 #include <new>
+#include <utility>
 #include <sys/mman.h>
 
 namespace spx {
@@ -54,6 +55,16 @@ struct BigAlloc {
         const size_t bytes = n * sizeof(T);
         if (bytes < kThreshold) std::free(p);
         else munmap(p, mapped_len(bytes));
+    }
+
+    // (elements come into being default-initialised: `v.resize(n)` of doubles or of the plain structs kept
+    // here sizes the array without writing to it -- the caller fills it, on several threads where it is
+    // large; `v.resize(n, x)` and `v.assign(n, x)` still fill)
+    template <class U> void construct(U *p) { ::new (static_cast<void *>(p)) U; }
+    template <class U, class A0, class... Args>
+    void construct(U *p, A0 &&a0, Args &&...args)
+    {
+        ::new (static_cast<void *>(p)) U(std::forward<A0>(a0), std::forward<Args>(args)...);
     }
 
     template <class U> bool operator==(const BigAlloc<U> &) const noexcept { return true; }

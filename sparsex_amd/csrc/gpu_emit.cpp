@@ -1026,20 +1026,23 @@ static void extract_tiles(SingleVec &pts, std::vector<SymTile> &tiles,
 
 // Joins `src` to the end of `dst` (both packed, i.e. not finalized): offsets
 // of the appended row-blocks are shifted behind what `dst` already holds.
-void append_stream(GpuStream &dst, GpuStream &&src)
+void append_stream(GpuStream &dst, GpuStream &&src, uint64_t values_placed_at)
 {
     assert(!dst.pass_stride && !src.pass_stride);
     if (src.rbs.empty() && src.shared.empty()) {
         dst.lds_doubles = std::max(dst.lds_doubles, src.lds_doubles);
         return;
     }
-    pad_to(dst.values, 2);
+    // (values_placed_at: the caller has copied the piece's values into dst.values at that offset
+    // already -- see emit_and_upload, which does it for all pieces at once on all host threads)
+    const bool placed = values_placed_at != UINT64_MAX;
+    if (!placed) pad_to(dst.values, 2);
     while (dst.cidx.size() % 16) dst.cidx.push_back(0);
-    const uint64_t v0 = dst.values.size();
+    const uint64_t v0 = placed ? values_placed_at : dst.values.size();
     const uint32_t p0 = (uint32_t) dst.passes.size(), d0 = (uint32_t) dst.descs.size();
     const uint32_t c0 = (uint32_t)(dst.cidx.size() / 16), s0 = (uint32_t) dst.segrows.size();
     const uint32_t k0 = dst.n_carry, sp0 = (uint32_t) dst.spill_col.size();
-    if (dst.rbs.empty() && dst.values.empty()) {
+    if (!placed && dst.rbs.empty() && dst.values.empty()) {
         // (first piece: take the arrays as they are)
         dst.values.swap(src.values);
         dst.descs.swap(src.descs);
@@ -1061,7 +1064,7 @@ void append_stream(GpuStream &dst, GpuStream &&src)
             if (rb.flags & SPX_RB_SHARED) rb.carry_slot += k0;
         }
         for (SpxSharedRow &sr : src.shared) sr.first_slot += k0;
-        dst.values.insert(dst.values.end(), src.values.begin(), src.values.end());
+        if (!placed) dst.values.insert(dst.values.end(), src.values.begin(), src.values.end());
         dst.descs.insert(dst.descs.end(), src.descs.begin(), src.descs.end());
         dst.passes.insert(dst.passes.end(), src.passes.begin(), src.passes.end());
         dst.cidx.insert(dst.cidx.end(), src.cidx.begin(), src.cidx.end());

@@ -130,7 +130,7 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsi
 
 // Joins `src` to the end of `dst` (neither finalized yet): what per-partition /
 // per-range emitter threads produced becomes one stream.
-void append_stream(GpuStream &dst, GpuStream &&src);
+void append_stream(GpuStream &dst, GpuStream &&src, uint64_t values_placed_at = UINT64_MAX);
 
 // Lays the pass headers out at a fixed stride per row-block (the largest pass
 // count), so that a workgroup can fetch its first headers without waiting for
