@@ -495,12 +495,26 @@ static void emit_and_upload(spx_matrix_t *A)
             // triangle lies in the multiplier rows -- need no row-block)
             if (use_segs) gp.skip_empty = true;
             emit_pieces(fulls, &tiles, use_segs ? &segs : nullptr);
-            // (handed back on all host threads, like the encoded partitions further down)
-            parallel_for(fulls.size(), hw, [&](size_t i) {
-                fulls[i] = Partition();
-                if (i < segs.size()) SymSegVec().swap(segs[i]);
-                if (i < tiles.size()) std::vector<SymTile>().swap(tiles[i]);
-            });
+            // (handed back by a thread of the matrix handle, like the encoded partitions further down)
+            {
+                struct Gone {
+                    std::vector<Partition> fulls;
+                    std::vector<SymSegVec> segs;
+                    std::vector<std::vector<SymTile>> tiles;
+                };
+                Gone *g = new Gone();
+                g->fulls.swap(fulls);
+                g->segs.swap(segs);
+                g->tiles.swap(tiles);
+                A->release_later([g] {
+                    parallel_for(g->fulls.size(), host_threads(), [&](size_t i) {
+                        g->fulls[i] = Partition();
+                        if (i < g->segs.size()) SymSegVec().swap(g->segs[i]);
+                        if (i < g->tiles.size()) std::vector<SymTile>().swap(g->tiles[i]);
+                    });
+                    delete g;
+                });
+            }
             // thinly spread mirror image on rows of other processes: a CSR over those rows
             for (size_t k = 0; k < thin.size(); ++k) {
                 if (k == 0 || thin[k].row != thin[k - 1].row) {
@@ -974,7 +988,7 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     if (!cfg.get_bool("spx.rt.keep_encoded")) {
         std::vector<Partition> *old = new std::vector<Partition>();
         old->swap(A->parts);
-        A->release_thread = std::thread([old] {
+        A->release_later([old] {
             parallel_for(old->size(), host_threads(), [&](size_t i) { (*old)[i] = Partition(); });
             delete old;
         });

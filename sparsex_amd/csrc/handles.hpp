@@ -44,11 +44,17 @@ struct matrix {
     size_t first_part = 0, last_part = 0;   // owned partitions [first, last)
     std::vector<PartBounds> bounds;    // all P partitions
     std::vector<Partition> parts;      // encoded, horizontal order (owned ones)
-    // spx.rt.keep_encoded=false: the encoded partitions are handed back behind the caller's back after the
-    // tune (the kernel clears what it takes back: 1.6 s for the 25 GB of the contract matrix on sixteen
-    // threads, and nothing waits for it); joined when the matrix goes
-    std::thread release_thread;
-    ~matrix() { if (release_thread.joinable()) release_thread.join(); }
+    // Large intermediates of the tune -- the encoded partitions with spx.rt.keep_encoded=false, the symmetric
+    // path's expanded ranges -- are handed back behind the caller's back (the kernel clears what it takes
+    // back: 1.6 s for the 25 GB of the contract matrix on sixteen threads, and nothing waits for it); the
+    // threads are joined when the matrix goes
+    std::vector<std::thread> release_threads;
+    template <class F> void release_later(F &&f) { release_threads.emplace_back(std::forward<F>(f)); }
+    ~matrix()
+    {
+        for (std::thread &t : release_threads)
+            if (t.joinable()) t.join();
+    }
     std::vector<std::vector<val_t>> diag;   // symmetric: per owned partition
     std::vector<std::unique_ptr<CsxStream>> exported;
     std::vector<std::vector<spx_index_t>> exported_rows_info;
