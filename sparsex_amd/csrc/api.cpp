@@ -415,6 +415,10 @@ static void emit_and_upload(spx_matrix_t *A)
             parallel_for(copies.size(), hw, [&](size_t k) {
                 std::memcpy(base + copies[k].at, copies[k].src, copies[k].len * sizeof(val_t));
             });
+            // (and the pieces' own copies go, on all threads as well)
+            parallel_for(n, hw, [&](size_t i) {
+                if (v_at[i] != UINT64_MAX) ValVec().swap(locs[i].values);
+            });
         }
         const double t_join = now_sec();
         for (size_t i = 0; i < n; ++i) append_stream(gs, std::move(locs[i]), v_at[i]);

@@ -1741,6 +1741,9 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsi
         else emit_plan(jobs[k].first, bld, dst);
     };
     if (nthreads <= 1 || jobs.size() < 64) {
+        // (address space for the values up front -- the nonzeros plus an eighth of padding: pages come as they
+        // are written, and a 200 MB array is not copied again each time it doubles)
+        if (p.nnz * sizeof(val_t) >= ((size_t) 32 << 20)) out.values.reserve(out.values.size() + p.nnz + p.nnz / 8 + 1024);
         RbBuilder bld(p, out, prm.stack_segments, prm.x_window, prm.inline_desc);
         for (size_t k = 0; k < jobs.size(); ++k) emit_job(k, bld, out);
         return;
