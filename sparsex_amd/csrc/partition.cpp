@@ -117,27 +117,65 @@ void Partition::set_rowptr(size_t count)
 // new row numbers usually IS the sort; where it is not (block rows from row-major order, windows
 // far shorter than their row range) the comparison sort finishes the job.  Coordinates are unique:
 // either way the result is the order std::sort gives.
-static void sort_elems(ElemVec &elems, size_t n, idx_t max_row, ElemVec &scratch)
+// (`counts`: the caller has counted the elements of every new row already -- counts[row + 1], rows
+// 1-based -- while it changed the coordinates; `rowptr`: where to build the row pointer on the way
+// through the ordered elements.  Returns whether it did build it.)
+static bool sort_elems(ElemVec &elems, size_t n, idx_t max_row, ElemVec &scratch, std::vector<uint32_t> &counts,
+                       std::vector<idx_t> *rowptr)
 {
     auto key = [](const Elem &e) { return (uint64_t) (uint32_t) e.row << 32 | (uint32_t) e.col; };
     auto less = [&](const Elem &a, const Elem &b) { return key(a) < key(b); };
-    if (n < 2) return;
+    if (n < 2) return false;
     if (n < 256 || n > 0xfffffff0ull || (uint64_t) max_row > 8 * (uint64_t) n) {
         std::sort(elems.begin(), elems.begin() + n, less);
-        return;
+        return false;
     }
-    std::vector<uint32_t> start((size_t) max_row + 2, 0);      // rows are 1-based
-    for (size_t i = 0; i < n; ++i) ++start[(size_t) elems[i].row + 1];
+    std::vector<uint32_t> &start = counts;                     // rows are 1-based
+    if (start.empty()) {
+        start.assign((size_t) max_row + 2, 0);
+        for (size_t i = 0; i < n; ++i) ++start[(size_t) elems[i].row + 1];
+    }
     for (size_t r = 1; r <= (size_t) max_row; ++r) start[r + 1] += start[r];
     // (the second buffer is kept by the partition -- fresh pages cost more than the pass -- and the
     // two change places afterwards; what lies behind the first n elements is not live in either)
     if (scratch.size() < elems.size()) scratch.resize(elems.size());
     Elem *out = scratch.data();
     for (size_t i = 0; i < n; ++i) out[start[(size_t) elems[i].row]++] = elems[i];
+    // one more walk: are they in order, and (set_rowptr's loop) where do the rows begin
     bool in_order = true;
-    for (size_t i = 1; i < n && in_order; ++i) in_order = key(out[i - 1]) < key(out[i]);
+    if (rowptr) {
+        rowptr->clear();
+        rowptr->push_back(0);
+    }
+    idx_t row_prev = 1;
+    for (size_t i = 0; i < n; ++i) {
+        if (i && !(key(out[i - 1]) < key(out[i]))) {
+            in_order = false;
+            break;
+        }
+        if (rowptr && out[i].row != row_prev) {
+            rowptr->insert(rowptr->end(), (size_t) (out[i].row - row_prev), (idx_t) i);
+            row_prev = out[i].row;
+        }
+    }
     elems.swap(scratch);
-    if (!in_order) std::sort(elems.begin(), elems.begin() + n, less);
+    if (!in_order) {
+        std::sort(elems.begin(), elems.begin() + n, less);
+        return false;
+    }
+    if (rowptr && (size_t) rowptr->back() != n) rowptr->push_back((idx_t) n);
+    return rowptr != nullptr;
+}
+
+// the largest row number an element can get in iteration order t (a bound, for sizing the counters)
+static uint64_t row_bound(int t, uint64_t nr, uint64_t nc)
+{
+    if (t == ENC_H) return nr;
+    if (t == ENC_V) return nc;
+    if (t == ENC_D || t == ENC_AD) return nr + nc;
+    if (enc_is_block_row(t)) return nr / (uint64_t) enc_block_align(t) + 1;
+    if (enc_is_block_col(t)) return nc / (uint64_t) enc_block_align(t) + 1;
+    return 0;
 }
 
 void Partition::transform(int t, bool with_rowptr)
@@ -145,19 +183,31 @@ void Partition::transform(int t, bool with_rowptr)
     if (type == t) return;
     const idx_t nr = (idx_t) nr_rows, nc = (idx_t) nr_cols;
     const int from = type;
+    const size_t n = elems_size;
+    // the new rows are counted while the coordinates change, where the counting pass is going to be used
+    const uint64_t bound = row_bound(t, nr_rows, nr_cols);
+    std::vector<uint32_t> counts;
+    bool counted = n >= 256 && n <= 0xfffffff0ull && bound > 0 && bound <= 8 * (uint64_t) n;
+    if (counted) counts.assign((size_t) bound + 2, 0);
     idx_t max_row = 0;
-    for (size_t i = 0; i < elems_size; ++i) {
+    for (size_t i = 0; i < n; ++i) {
         xform(from, t, elems[i].row, elems[i].col, nr, nc);
-        max_row = std::max(max_row, elems[i].row);
+        const idx_t r = elems[i].row;
+        max_row = std::max(max_row, r);
+        if (counted) {
+            if (r >= 1 && (uint64_t) r <= bound) ++counts[(size_t) r + 1];
+            else counted = false;                          // (not expected: the slow way then)
+        }
     }
+    if (!counted) counts.clear();
     // (the reference sorts band-by-band when both orders belong to the same row/column family,
     // SparsePartition.hpp:704-734)
-    sort_elems(elems, elems_size, max_row, scratch);
+    const bool have_rowptr = sort_elems(elems, n, max_row, scratch, counts, with_rowptr ? &rowptr : nullptr);
     if (!with_rowptr) {
         rowptr.clear();
         rowptr.push_back(0);
-    } else if (elems_size) {
-        set_rowptr(elems_size);
+    } else if (n && !have_rowptr) {
+        set_rowptr(n);
     }
     type = t;
 }
