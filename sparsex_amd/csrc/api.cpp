@@ -422,7 +422,7 @@ static void emit_and_upload(spx_matrix_t *A)
         }
         const double t_join = now_sec();
         for (size_t i = 0; i < n; ++i) append_stream(gs, std::move(locs[i]), v_at[i]);
-        log_msg(LOG_INFO, "descriptor stream: %zu pieces emitted in %.2f s, room made in %.2f s, joined in %.2f s\n", n,
+        log_msg(LOG_INFO, "descriptor stream: %zu pieces emitted in %.2f s, values placed in %.2f s, index arrays joined in %.2f s\n", n,
                 t_room - t_pieces, t_join - t_room, now_sec() - t_join);
     };
     if (sym) {
