@@ -257,6 +257,8 @@ static void split_rows(const Partition &src, Partition &dst, bool first_half)
     dst.row_start = src.row_start;
     dst.nr_cols = src.nr_cols;
     dst.pool = ValVec();
+    // (address space for all of them: pages come as they are written, and nothing is copied when the array grows)
+    if (src.elems_size * sizeof(Elem) >= ((size_t) 32 << 20)) dst.elems.reserve(src.elems_size);
     for (size_t j = 0; j < src.elems_size; ++j) {
         const Elem &e = src.elems[j];
         bool left = e.col < src.row_start + 1;
@@ -286,6 +288,9 @@ void PartitionSym::merge()
     size_t nr = lower.rowptr.size() - 1;
     out.rowptr.clear();
     out.rowptr.push_back(0);
+    out.rowptr.reserve(nr + 1);
+    out.elems.reserve(m1.elems_size + m2.elems_size);
+    out.pool.reserve(m1.pool.size() + m2.pool.size());
     auto take = [&](Partition &m, size_t i) {
         if (m.rowptr.size() - 1 <= i) return;
         for (idx_t j = m.rowptr[i]; j < m.rowptr[i + 1]; ++j) {
