@@ -24,6 +24,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <atomic>
@@ -355,6 +356,12 @@ static void emit_and_upload(spx_matrix_t *A)
     if (A->auto_rb) gp.target_elems = auto_target_elems(A, A->rb_scale);
     GpuStream gs;
     const unsigned hw = host_threads();
+    // (what is to be handed back once the stream is uploaded; run on the spot if the function is left early)
+    struct Deferred {
+        std::function<void()> f;
+        ~Deferred() { if (f) f(); }
+    } deferred;
+    std::function<void()> &release_after_upload = deferred.f;
     const double t_emit0 = now_sec();
     // pieces (partitions, row ranges) are emitted concurrently into streams of
     // their own and joined in order; threads left over work inside a piece
@@ -510,14 +517,16 @@ static void emit_and_upload(spx_matrix_t *A)
                 g->fulls.swap(fulls);
                 g->segs.swap(segs);
                 g->tiles.swap(tiles);
-                A->release_later([g] {
+                // (started once the stream is in HBM: sixteen threads handing pages back would be in the way of the
+                // finalisation below)
+                release_after_upload = [g] {
                     parallel_for(g->fulls.size(), host_threads(), [&](size_t i) {
                         g->fulls[i] = Partition();
                         if (i < g->segs.size()) SymSegVec().swap(g->segs[i]);
                         if (i < g->tiles.size()) std::vector<SymTile>().swap(g->tiles[i]);
                     });
                     delete g;
-                });
+                };
             }
             // thinly spread mirror image on rows of other processes: a CSR over those rows
             for (size_t k = 0; k < thin.size(); ++k) {
@@ -622,6 +631,11 @@ static void emit_and_upload(spx_matrix_t *A)
         keep_index(A, std::move(gs));
     } else {
         A->host_stream.reset(new GpuStream(std::move(gs)));
+    }
+    if (release_after_upload) {
+        std::function<void()> f;
+        f.swap(release_after_upload);
+        A->release_later(std::move(f));
     }
 }
 
