@@ -351,14 +351,38 @@ typedef struct {
                                 passes side by side per wavefront is in use          */
     int32_t col_slices;      /* general path, spx.gpu.col_phases: K > 1 column slices in one
                                 launch (a group of XCDs each), -K: launched in turn, else 1 */
+    int32_t unit_windows;    /* general path, spx.gpu.unit_windows: 1 = the product stages the columns
+                                its unit passes read in LDS (one set of windows per row-block) and
+                                runs the unit passes as a software pipeline (csx_spmv_xw_kernel)   */
+    int32_t unit_window_lds; /* ... bytes of LDS per workgroup of that kernel (0: no windows planned) */
+    int64_t unit_window_elems;  /* ... nonzeros whose x comes from LDS (of n_unit_elems)            */
+    int64_t unit_window_staged; /* ... doubles of x staged per product                              */
 } spx_hip_info_t;
 
 spx_error_t spx_hip_mat_info(const spx_matrix_t *A, spx_hip_info_t *info);
+
+/* The unit windows of x (spx.gpu.unit_windows) planned from the matrix' descriptor stream with the given
+ * budget (most doubles of x a row-block may stage in LDS) and gap (column intervals closer than this are
+ * staged as one): what csx_spmv_xw_kernel is handed next to the stream -- for inspection and tests; works
+ * on host-only matrices.  The arrays belong to the matrix and live until the next call or
+ * spx_mat_destroy().  Layouts: sparsex_amd/csrc/xwindows.hpp. */
+typedef struct {
+    const uint32_t *tab;        /* n_rowblocks x 16 entries of {uint32, uint32}: 2 of pass ranges, 14 windows */
+    const uint32_t *xdescs;     /* n_descs x {col0 or LDS offset, bits}                                       */
+    const void *passes;         /* n_passes pass headers of 24 bytes (flag 2: the pass reads x from LDS)      */
+    size_t n_rowblocks, n_descs, n_passes;
+    size_t rowblocks_with_windows, rowblocks_with_units;
+    uint64_t staged_doubles;    /* doubles of x staged per product                                            */
+    uint64_t unit_elems, unit_elems_lds;   /* nonzeros in unit passes / in unit passes that read LDS          */
+    uint32_t lds_doubles;       /* LDS of a launch, doubles: y tile + leftover window + unit windows          */
+} spx_hip_xw_plan_t;
+spx_error_t spx_hip_mat_unit_windows(spx_matrix_t *A, uint32_t budget, uint32_t gap, spx_hip_xw_plan_t *plan);
 /* The same for a caller compiled against another revision of this header: at most `size` bytes
  * (the caller's sizeof(spx_hip_info_t)) are written -- the struct only ever grows at its end.
  * spx_hip_mat_info() writes sizeof(spx_hip_info_t) of THIS header; SPX_HIP_ABI_VERSION changes
- * whenever the struct grows (round 3 added quad and col_slices: version 3; unchanged since). */
-#define SPX_HIP_ABI_VERSION 3
+ * whenever the struct grows (round 3 added quad and col_slices: version 3; round 5 the four
+ * unit_window fields: version 4). */
+#define SPX_HIP_ABI_VERSION 4
 spx_error_t spx_hip_mat_info_sized(const spx_matrix_t *A, void *info, size_t size);
 int spx_hip_abi_version(void);
 

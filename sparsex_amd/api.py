@@ -49,7 +49,17 @@ class HipInfo(C.Structure):
                 ("device", C.c_int32), ("waves", C.c_int32), ("sym_tiles", C.c_int32),
                 ("tune_seconds", C.c_double),
                 ("emit_seconds", C.c_double), ("wave_tiles", C.c_int32), ("sym_segments", C.c_int32),
-                ("quad", C.c_int32), ("col_slices", C.c_int32)]
+                ("quad", C.c_int32), ("col_slices", C.c_int32),
+                ("unit_windows", C.c_int32), ("unit_window_lds", C.c_int32),
+                ("unit_window_elems", C.c_int64), ("unit_window_staged", C.c_int64)]
+
+
+class XwPlan(C.Structure):
+    _fields_ = [("tab", C.POINTER(C.c_uint32)), ("xdescs", C.POINTER(C.c_uint32)), ("passes", C.c_void_p),
+                ("n_rowblocks", C.c_size_t), ("n_descs", C.c_size_t), ("n_passes", C.c_size_t),
+                ("rowblocks_with_windows", C.c_size_t), ("rowblocks_with_units", C.c_size_t),
+                ("staged_doubles", C.c_uint64), ("unit_elems", C.c_uint64), ("unit_elems_lds", C.c_uint64),
+                ("lds_doubles", C.c_uint32)]
 
 
 class CsxExport(C.Structure):
@@ -252,6 +262,25 @@ class Matrix:
         if lib().spx_hip_mat_info(self.handle, C.byref(inf)) != SPX_SUCCESS:
             raise SpxError("spx_hip_mat_info failed")
         return inf
+
+    def unit_windows(self, budget=4096, gap=16):
+        """The unit windows of x planned from the stream (spx_hip_mat_unit_windows) as numpy copies:
+        tab [n_rowblocks, 16, 2] u32, xdescs [n_descs, 2] u32, passes as raw bytes [n_passes, 24]."""
+        pl = XwPlan()
+        L = lib()
+        L.spx_hip_mat_unit_windows.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(XwPlan)]
+        if L.spx_hip_mat_unit_windows(self.handle, budget, gap, C.byref(pl)) != SPX_SUCCESS:
+            raise SpxError("spx_hip_mat_unit_windows failed")
+        out = {k: getattr(pl, k) for k in ("n_rowblocks", "n_descs", "n_passes", "rowblocks_with_windows",
+                                           "rowblocks_with_units", "staged_doubles", "unit_elems",
+                                           "unit_elems_lds", "lds_doubles")}
+        out["tab"] = np.ctypeslib.as_array(pl.tab, shape=(pl.n_rowblocks * 32,)).reshape(-1, 16, 2).copy() \
+            if pl.n_rowblocks else np.zeros((0, 16, 2), np.uint32)
+        out["xdescs"] = np.ctypeslib.as_array(pl.xdescs, shape=(pl.n_descs * 2,)).reshape(-1, 2).copy() \
+            if pl.n_descs else np.zeros((0, 2), np.uint32)
+        raw = C.string_at(pl.passes, pl.n_passes * 24) if pl.n_passes else b""
+        out["passes"] = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 24).copy()
+        return out
 
     def export_csx(self, part=0):
         """Reference-format CSX arrays of one partition as numpy copies."""

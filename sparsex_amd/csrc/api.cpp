@@ -598,6 +598,9 @@ static void emit_and_upload(spx_matrix_t *A)
     gs.waves = (uint32_t) A->waves;
     gs.band_order = Config::instance().get_bool("spx.gpu.band_order");
     gs.arena = Config::instance().get_bool("spx.gpu.arena");
+    gs.xw_budget = (A->unit_windows != 0 && !A->deterministic && !sym) ? A->xw_budget : 0u;
+    gs.xw_gap = A->xw_gap;
+    gs.xw_on = A->xw_on;
     gs.sym_atomic = A->sym_atomic && !A->deterministic;
     gs.deterministic = A->deterministic;
     gs.wave_tiles = A->deterministic || A->wave_tiles == 1;
@@ -643,7 +646,7 @@ static void emit_and_upload(spx_matrix_t *A)
 // workgroups) like two wavefronts per workgroup and smaller row-blocks,
 // leftover-heavy ones eight wavefronts, the rest the default.  A handful of
 // candidates, a few hundred launches each; the fastest stays.
-static void autotune_launch(spx_matrix_t *A, bool tune_waves, bool tune_spill, bool tune_wave_tiles)
+static void autotune_launch(spx_matrix_t *A, bool tune_waves, bool tune_spill, bool tune_wave_tiles, bool tune_xw)
 {
     // launches per timing: a hundred for a product of microseconds, fewer where one launch takes a
     // millisecond (about 20 ms of launches per timing either way; four timings per variant: on the
@@ -651,60 +654,88 @@ static void autotune_launch(spx_matrix_t *A, bool tune_waves, bool tune_spill, b
     const double t_est = device_time_spmv(A->dev, 2, 3);
     const int N = (int) std::min(100.0, std::max(8.0, 0.02 / std::max(t_est, 1e-7)));
     const int W = std::max(2, N / 10);
+    auto best_time = [&]() {
+        double best = device_time_spmv(A->dev, W, N);
+        for (int rep = 0; rep < 3; ++rep) best = std::min(best, device_time_spmv(A->dev, 0, N));
+        return best;
+    };
+    // the unit windows of x in LDS (csx_spmv_xw_kernel) against the plain kernel, whatever else is
+    // being varied: `xw` receives the state the returned time belongs to
+    auto time_xw = [&](bool &xw) {
+        if (!tune_xw || !device_has_xw(A->dev)) {
+            xw = device_get_xw(A->dev);
+            return best_time();
+        }
+        device_set_xw(A->dev, false);
+        const double t0 = best_time();
+        device_set_xw(A->dev, true);
+        const double t1 = best_time();
+        xw = t1 < 0.985 * t0;
+        device_set_xw(A->dev, xw);
+        return std::min(t0, xw ? t1 : t0);
+    };
     if (!tune_waves) {
         // (the wavefront count is pinned: only the hand-over of the tiles' sums is measured)
-        if (tune_wave_tiles && !device_has_tiles(A->dev)) {
+        if (tune_wave_tiles && !device_has_tiles(A->dev) && !(A->unit_windows == 1 && device_has_xw(A->dev))) {
             auto t_of = [&](bool on) {
                 device_set_wave_tiles(A->dev, on);
-                double best = device_time_spmv(A->dev, W, N);
-                for (int rep = 0; rep < 3; ++rep) best = std::min(best, device_time_spmv(A->dev, 0, N));
-                return best;
+                return best_time();
             };
             const double t0 = t_of(false), t1 = t_of(true);
             A->wave_tiles = t1 < 0.985 * t0 ? 1 : 0;
             device_set_wave_tiles(A->dev, A->wave_tiles == 1);
         }
+        if (tune_xw && device_has_xw(A->dev) && A->wave_tiles != 1) {
+            bool xw = false;
+            (void) time_xw(xw);
+            A->xw_on = xw;
+        }
         if (!tune_spill || !device_has_spill(A->dev)) return;
         auto t_of = [&](bool atomic) {
             device_set_sym_atomic(A->dev, atomic);
-            double best = device_time_spmv(A->dev, W, N);
-            for (int rep = 0; rep < 3; ++rep) best = std::min(best, device_time_spmv(A->dev, 0, N));
-            return best;
+            return best_time();
         };
         const double tl = t_of(false), ta = t_of(true);
         A->sym_atomic = ta < 0.985 * tl;
         device_set_sym_atomic(A->dev, A->sym_atomic);
         return;
     }
-    auto time_with = [&](int waves) {
+    auto time_with = [&](int waves, bool &xw) {
         device_set_waves(A->dev, waves);
-        double best = device_time_spmv(A->dev, W, N);
-        for (int rep = 0; rep < 3; ++rep) best = std::min(best, device_time_spmv(A->dev, 0, N));
-        return best;
+        return time_xw(xw);
     };
     // default row-blocks: 4 and 8 wavefronts
-    const double t4 = time_with(4), t8 = time_with(8);
+    bool xw4 = false, xw8 = false;
+    const double t4 = time_with(4, xw4), t8 = time_with(8, xw8);
     int best_waves = t8 < 0.985 * t4 ? 8 : 4;
+    bool best_xw = best_waves == 8 ? xw8 : xw4;
     double best_t = std::min(t4, t8), best_scale = 1.0;
+    device_set_xw(A->dev, best_xw);
+    A->xw_on = best_xw;
     // a y tile per wavefront (no two wavefronts add to the same LDS address; more LDS,
     // a reduction before the write-out): pays where rows are spread over many passes
     // (syn-nlpkkt 291 -> 274 us), costs where the kernel is launch-bound (syn-cant 7.2 -> 7.9)
-    if (tune_wave_tiles && !device_has_tiles(A->dev)) {
+    // (not against unit windows that were asked for: the per-wavefront tiles run through the plain kernel)
+    if (tune_wave_tiles && !device_has_tiles(A->dev) && !(A->unit_windows == 1 && device_has_xw(A->dev))) {
         device_set_wave_tiles(A->dev, true);
-        const double tw = time_with(best_waves);
+        device_set_waves(A->dev, best_waves);
+        const double tw = best_time();
         if (tw < 0.985 * best_t) {
             best_t = tw;
             A->wave_tiles = 1;
+            best_xw = false;              // (the per-wavefront tiles run through the plain kernel)
         } else {
             device_set_wave_tiles(A->dev, false);
             A->wave_tiles = 0;
+            device_set_xw(A->dev, best_xw);
         }
     }
     // symmetric tiles: the transposed sums through the spill array and a second
     // kernel, or straight into y with global atomics
     if (tune_spill && device_has_spill(A->dev)) {
         device_set_sym_atomic(A->dev, !A->sym_atomic);
-        const double ta = time_with(best_waves);
+        device_set_waves(A->dev, best_waves);
+        const double ta = best_time();
         if (ta < 0.985 * best_t) {
             best_t = ta;
             A->sym_atomic = !A->sym_atomic;
@@ -719,13 +750,16 @@ static void autotune_launch(spx_matrix_t *A, bool tune_waves, bool tune_spill, b
             A->rb_scale = scale;
             A->waves = 2;
             emit_and_upload(A);
-            const double t2 = time_with(2);
+            bool xw2 = false;
+            const double t2 = time_with(2, xw2);
             if (t2 < 0.985 * best_t) {
                 best_t = t2;
                 best_waves = 2;
                 best_scale = scale;
+                best_xw = xw2;
             }
         }
+        A->xw_on = best_xw;
         if (A->rb_scale != best_scale) {
             A->rb_scale = best_scale;
             A->waves = best_waves;
@@ -741,20 +775,26 @@ static void autotune_launch(spx_matrix_t *A, bool tune_waves, bool tune_spill, b
         A->rb_scale = 2.0;
         A->waves = best_waves;
         emit_and_upload(A);
-        const double tb = time_with(best_waves);
+        bool xwb = false;
+        const double tb = time_with(best_waves, xwb);
         if (tb < 0.985 * best_t) {
             best_t = tb;
             best_scale = 2.0;
+            best_xw = xwb;
+            A->xw_on = best_xw;
         } else {
             A->rb_scale = best_scale;
+            A->xw_on = best_xw;
             emit_and_upload(A);
         }
     }
     A->rb_scale = best_scale;
     A->waves = best_waves;
+    A->xw_on = best_xw;
     device_set_waves(A->dev, best_waves);
-    log_msg(LOG_INFO, "launch autotune: %d wavefronts per workgroup, row-block scale %.2f (%.2f us per SpMV)\n",
-            best_waves, best_scale, 1e6 * best_t);
+    device_set_xw(A->dev, best_xw);
+    log_msg(LOG_INFO, "launch autotune: %d wavefronts per workgroup, row-block scale %.2f, unit windows %s (%.2f us per SpMV)\n",
+            best_waves, best_scale, best_xw ? "on" : "off", 1e6 * best_t);
 }
 
 static spx_matrix_t *do_tune(spx_input_t *in)
@@ -940,6 +980,22 @@ static spx_matrix_t *do_tune(spx_input_t *in)
         throw FatalError("bad spx.gpu.wave_tiles");
     }
     A->wave_tiles = wt_mode == "true" ? 1 : 0;          // (auto: off until measured)
+    const std::string xw_mode = cfg.get_str("spx.gpu.unit_windows");
+    if (xw_mode != "auto" && xw_mode != "true" && xw_mode != "false") {
+        log_msg(LOG_ERR, "spx.gpu.unit_windows: true, false or auto\n");
+        throw FatalError("bad spx.gpu.unit_windows");
+    }
+    {
+        const long xb = cfg.get_long("spx.gpu.unit_window_doubles"), xg = cfg.get_long("spx.gpu.unit_window_gap");
+        if (xb < 0 || xb > 16384 || xg < 0 || xg > 255) {
+            log_msg(LOG_ERR, "spx.gpu.unit_window_doubles: 0 .. 16384, spx.gpu.unit_window_gap: 0 .. 255\n");
+            throw FatalError("bad spx.gpu.unit_window_doubles / spx.gpu.unit_window_gap");
+        }
+        A->xw_budget = (uint32_t) xb;
+        A->xw_gap = (uint32_t) xg;
+    }
+    A->unit_windows = xw_mode == "auto" ? -1 : (xw_mode == "true" ? 1 : 0);
+    A->xw_on = xw_mode == "true";                       // (auto: off until measured)
     const std::string ph_mode = cfg.get_str("spx.gpu.col_phases");
     const bool ph_conc = ph_mode.size() == 2 && ph_mode[0] == 'c';
     long ph_fixed = ph_mode == "auto" ? 0 : strtol(ph_mode.c_str() + (ph_conc ? 1 : 0), nullptr, 10);
@@ -959,9 +1015,10 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     }
     const bool tune_spill = spill_mode == "auto" && !A->deterministic && !A->has_symsegs;
     const bool tune_wt = wt_mode == "auto" && !A->deterministic && !A->has_symsegs;
+    const bool tune_xw = xw_mode == "auto" && !A->deterministic && !sym;
     const double t_auto = now_sec();
-    if (A->dev && A->nnz_stored >= 100000 && (autotune || tune_spill || tune_wt))
-        autotune_launch(A.get(), autotune, tune_spill, tune_wt);
+    if (A->dev && A->nnz_stored >= 100000 && (autotune || tune_spill || tune_wt || tune_xw))
+        autotune_launch(A.get(), autotune, tune_spill, tune_wt, tune_xw);
     const double t_auto_end = now_sec();
     // column phases (auto): where the leftovers dominate and x is far larger than the L2 of an
     // XCD, the gathers miss it more often than not (syn-webbase: 1.6 M line fills for 2.5 M
@@ -1476,7 +1533,9 @@ spx_error_t spx_mat_save(const spx_matrix_t *A, const char *filename)
     h.waves = gs->waves;
     h.n_encoded = (uint32_t) A->parts.size();
     h.sym_atomic = gs->sym_atomic ? 1u : 0u;
-    h.pad3 = (gs->deterministic ? 1u : 0u) | (gs->wave_tiles ? 2u : 0u);
+    // (bit 2: the product runs with the unit windows of x in LDS; bits 8-15 / 16-31: their gap and budget)
+    h.pad3 = (gs->deterministic ? 1u : 0u) | (gs->wave_tiles ? 2u : 0u) | (gs->xw_on ? 4u : 0u) |
+             ((gs->xw_gap & 255u) << 8) | (std::min<uint32_t>(gs->xw_budget, 65535u) << 16);
     h.checksum = stream_checksum(*gs);
     bool good = fwrite(kMagic, 1, 8, f) == 8 && fwrite(&h, sizeof(h), 1, f) == 1;
     std::vector<int32_t> bnd;
@@ -1565,6 +1624,9 @@ spx_matrix_t *spx_mat_restore(const char *filename)
         gs->sym_atomic = h.sym_atomic != 0;
         gs->deterministic = (h.pad3 & 1u) != 0;
         gs->wave_tiles = (h.pad3 & 2u) != 0;
+        gs->xw_on = (h.pad3 & 4u) != 0;
+        gs->xw_gap = (h.pad3 >> 8) & 255u;
+        gs->xw_budget = gs->xw_on ? (h.pad3 >> 16) : 0u;
         gs->nnz_stored = h.nnz_stored; gs->n_unit_elems = h.n_unit_elems;
         gs->n_delta_elems = h.n_delta_elems; gs->n_units = h.n_units;
         good = stream_checksum(*gs) == h.checksum;
@@ -1600,6 +1662,10 @@ spx_matrix_t *spx_mat_restore(const char *filename)
     A->sym_atomic = gs->sym_atomic;
     A->deterministic = gs->deterministic;
     A->wave_tiles = gs->wave_tiles ? 1 : 0;
+    A->xw_on = gs->xw_on;
+    A->unit_windows = gs->xw_on ? 1 : 0;
+    A->xw_budget = gs->xw_budget;
+    A->xw_gap = gs->xw_gap;
     {
         // (column slices: what spx_hip_mat_info reports comes from the flags the stream carries)
         size_t slices = 1;
@@ -1962,6 +2028,40 @@ spx_error_t spx_hip_matvec_dist(spx_value_t alpha, const spx_matrix_t *A,
 
 int spx_hip_abi_version(void) { return SPX_HIP_ABI_VERSION; }
 
+spx_error_t spx_hip_mat_unit_windows(spx_matrix_t *A, uint32_t budget, uint32_t gap, spx_hip_xw_plan_t *out)
+{
+    if (!A || !out) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid argument"); return SPX_FAILURE; }
+    const GpuStream *s = A->host_stream ? A->host_stream.get() : A->index.get();
+    if (!s) { SETERROR_1(SPX_ERR_TUNED_MAT, "matrix holds no descriptor stream"); return SPX_FAILURE; }
+    std::lock_guard<std::mutex> lk(A->mtx);
+    try {
+        std::unique_ptr<XwPlan> plan(new XwPlan);
+        plan_unit_xwindows(*s, (size_t) A->ncols, A->symmetric ? 0u : budget, gap, *plan, host_threads());
+        A->xw_inspect = std::move(plan);
+    } catch (const FatalError &e) {
+        SETERROR_1(SPX_ERR_TUNED_MAT, e.what.c_str());
+        return SPX_FAILURE;
+    } catch (const std::exception &e) {
+        SETERROR_1(SPX_ERR_MEM_ALLOC, e.what());
+        return SPX_FAILURE;
+    }
+    const XwPlan &p = *A->xw_inspect;
+    memset(out, 0, sizeof(*out));
+    out->tab = reinterpret_cast<const uint32_t *>(p.tab.data());
+    out->xdescs = reinterpret_cast<const uint32_t *>(p.xdescs.data());
+    out->passes = p.passes.data();
+    out->n_rowblocks = s->rbs.size();
+    out->n_descs = p.xdescs.size();
+    out->n_passes = p.passes.size();
+    out->rowblocks_with_windows = p.n_rb_windows;
+    out->rowblocks_with_units = p.n_rb_units;
+    out->staged_doubles = p.staged_doubles;
+    out->unit_elems = p.unit_elems;
+    out->unit_elems_lds = p.unit_elems_lds;
+    out->lds_doubles = p.lds_doubles;
+    return SPX_SUCCESS;
+}
+
 spx_error_t spx_hip_mat_info_sized(const spx_matrix_t *A, void *info, size_t size)
 {
     spx_hip_info_t full;
@@ -2004,6 +2104,15 @@ spx_error_t spx_hip_mat_info(const spx_matrix_t *A, spx_hip_info_t *info)
     info->sym_segments = A->has_symsegs ? (A->has_symtiles ? 1 : 2) : 0;
     info->col_slices = A->col_phases > 1 ? (A->col_concurrent ? (int32_t) A->col_phases : -(int32_t) A->col_phases) : 1;
     info->quad = 0;                  // (reserved: the four-pass kernel variant of round 3 is gone)
+    if (A->dev && device_has_xw(A->dev)) {
+        uint64_t el = 0, ue = 0, st = 0;
+        uint32_t lds = 0;
+        device_xw_info(A->dev, el, ue, st, lds);
+        info->unit_windows = device_get_xw(A->dev) ? 1 : 0;
+        info->unit_window_lds = (int32_t) lds;
+        info->unit_window_elems = (int64_t) el;
+        info->unit_window_staged = (int64_t) st;
+    }
     info->tune_seconds = A->tune_seconds;
     info->emit_seconds = A->emit_seconds;
     return SPX_SUCCESS;

@@ -81,6 +81,14 @@ bool device_has_tiles(const DeviceMatrix *m);
 void device_set_waves(DeviceMatrix *m, int waves);
 int device_get_waves(const DeviceMatrix *m);
 
+// unit windows of x in LDS + pipelined unit passes (csx_spmv_xw_kernel; xwindows.hpp): available where
+// the stream was uploaded with a window budget and some row-block's columns fit it
+bool device_has_xw(const DeviceMatrix *m);
+void device_set_xw(DeviceMatrix *m, bool on);
+bool device_get_xw(const DeviceMatrix *m);
+void device_xw_info(const DeviceMatrix *m, uint64_t &elems_lds, uint64_t &unit_elems, uint64_t &staged_doubles,
+                    uint32_t &lds_bytes);
+
 // seconds per SpMV (alpha = 1, beta = 0) over `launches` back-to-back launches
 // on a private stream with scratch vectors -- what spx_mat_tune() measures to
 // choose launch parameters

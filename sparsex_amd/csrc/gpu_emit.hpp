@@ -77,6 +77,11 @@ struct GpuStream {
     uint32_t waves = 4;           // wavefronts per workgroup the kernel is launched with
     bool band_order = false;      // spx.gpu.band_order: launch order by strips across recurring bands of x (device side only)
     bool arena = false;           // spx.gpu.arena: all arrays of the stream in one HBM allocation (device side only)
+    // spx.gpu.unit_windows (device side only, xwindows.hpp): most doubles of x a row-block may stage in
+    // LDS for its unit passes (0: none planned), intervals closer than `xw_gap` doubles are merged, and
+    // whether the product starts out using them (the launch tuner measures both)
+    uint32_t xw_budget = 0, xw_gap = 16;
+    bool xw_on = false;
     // accounting
     size_t nnz_stored = 0;        // nonzeros held in `values` (without padding)
     size_t n_unit_elems = 0;

@@ -9,6 +9,7 @@
 #include "device.hpp"
 #include "gpu_emit.hpp"
 #include "input.hpp"
+#include "xwindows.hpp"
 
 #include <memory>
 #include <mutex>
@@ -86,6 +87,10 @@ struct matrix {
     bool has_symsegs = false;   // the stream holds read-once row segments (SPX_PASS_SYMSEG): atomic hand-over only
     int spill_mode = -1;        // spx.gpu.sym_spill as asked for: 0 lists, 1 atomic, -1 auto
     int wave_tiles = -1;        // per-wavefront y tiles: 1 / 0, -1 = measured at tune time (spx.gpu.wave_tiles)
+    int unit_windows = -1;      // spx.gpu.unit_windows: 1 / 0, -1 = measured at tune time
+    bool xw_on = false;         // ... the product runs with the unit windows of x in LDS (csx_spmv_xw_kernel)
+    uint32_t xw_budget = 4096, xw_gap = 16;   // spx.gpu.unit_window_doubles, spx.gpu.unit_window_gap
+    std::unique_ptr<spx::XwPlan> xw_inspect;    // what spx_hip_mat_unit_windows handed out last
     int device_ordinal = -1;
     std::vector<std::vector<idx_t>> spans;    // per partition and row: reach of its units
     std::vector<idx_t> max_span;              // per partition

@@ -19,10 +19,13 @@
 #include "device.hpp"
 #include "stream_index.hpp"
 #include "threads.hpp"
+#include "spmv_device.hpp"
+#include "xwindows.hpp"
 
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -30,6 +33,10 @@
 #include <vector>
 
 namespace spx {
+
+// spmv_xw_kernels.hip
+void launch_spmv_xw(int waves, unsigned blocks, size_t lds_bytes, void *stream, const KernelArgs &a, const XcdSplit &xs);
+void spmv_xw_allow_lds(size_t bytes);
 
 #define HIP_CHECK(expr)                                                         \
     do {                                                                        \
@@ -41,228 +48,6 @@ namespace spx {
             throw FatalError(m_);                                               \
         }                                                                       \
     } while (0)
-
-struct KernelArgs {
-    const SpxRowBlock *rbs;
-    const SpxPass *passes;
-    const double *values;
-    const SpxUnitDesc *descs;
-    const uint8_t *cidx;
-    const uint16_t *segrows;
-    const double *x;
-    double *y;
-    double *carry;
-    const double *dvalues;   // symmetric, fused: diagonal added at the write-out (else null)
-    double *spill;           // symmetric tiles: transposed sums of columns owned by other row-blocks
-    const uint32_t *slot_col;  // ... or (atomic hand-over) the first column of every group of eight slots
-    double alpha, beta;
-    const double *dvalues_priv;   // atomic hand-over: diagonal for the row-blocks that store their rows
-    double beta_priv;             // ... and the caller's beta for them (beta above is 1 after the init pass)
-    uint32_t n_rb;
-    uint32_t pass_stride;    // pass headers of row-block i start at passes[i * pass_stride]
-};
-
-// XCD-aware order of the row-blocks: workgroup b runs on XCD b % 8; XCD x walks the row-blocks
-// [first[x], first[x + 1]) in turn, a contiguous part of the matrix that holds an eighth of its
-// VALUES (not of its row-blocks: a symmetric KKT matrix keeps its stored triangle in the second
-// half of its rows, and an eighth of the row-blocks by count left five XCDs without work)
-struct XcdSplit {
-    uint32_t first[9];
-};
-
-// wavefronts per workgroup: the kernels exist for 2, 4 and 8 (spx.gpu.waves, or
-// measured at tune time: small matrices like 2, leftover-heavy ones 8)
-constexpr int MAX_WAVES_PER_BLOCK = 8;
-
-// Loads of the matrix stream (values, descriptors): plain loads.  (Marking them non-temporal, so that
-// they would not push x out of the L2, measured slower on every workload: profiles/r03/ablation.md
-// section 4.)
-typedef double spx_d2_t __attribute__((ext_vector_type(2)));
-// two doubles at any 8-byte aligned address as ONE load (global_load_dwordx4 needs no 16-byte
-// alignment on gfx9): the x of a row segment comes in pairs wherever its first column lies
-typedef double spx_d2u_t __attribute__((ext_vector_type(2), aligned(8)));
-__device__ __forceinline__ double2 ld_stream(const double2 *p) { return *p; }
-__device__ __forceinline__ double ld_stream(const double *p) { return *p; }
-__device__ __forceinline__ uint2 ld_stream(const uint2 *p) { return *p; }
-
-// set bits of `mask` in lanes 1..lane (bit 0 is never set by the emitter)
-__device__ __forceinline__ uint32_t starts_upto(uint64_t mask, int lane)
-{
-    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                     __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
-    return below + (uint32_t)((mask >> lane) & 1ull);
-}
-
-// B unit passes of the same width at once: lane l owns one row segment of W
-// consecutive columns in each of them.  All descriptor loads go out first,
-// then all value loads, then the x gathers: one memory round trip per stage
-// for the whole batch instead of one per pass.
-//
-// G (gather pass): the lane's segment is a piece of one row's leftover
-// nonzeros; its row comes from the row-block's u16 rows and every nonzero has
-// its own column offset (element-major [W][nseg]) instead of a descriptor.
-//
-// G == 2 (SPX_PASS_GATHER_LDS): the same, but the columns lie in the row-block's
-// x window, which the workgroup has staged in LDS (`win`): u16 offsets, ds_read.
-template <int W, int B, int G>
-__device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlock &rb,
-                                            const SpxPass (&ps)[B], double *tile,
-                                            const double *win, int lane)
-{
-    bool active[B];
-    uint32_t l[B], nseg[B];
-    uint2 q[B];
-    uint32_t goff[B][G ? W : 1];
-#pragma unroll
-    for (int b = 0; b < B; ++b) {
-        nseg[b] = ps[b].nseg;
-        active[b] = (uint32_t) lane < nseg[b];
-        l[b] = active[b] ? (uint32_t) lane : 0u;         // idle lanes shadow lane 0
-        if (G) {
-            q[b].x = a.segrows[rb.seg_off + ps[b].seg0 + l[b]];
-            const uint8_t *cidx = a.cidx + ((size_t) rb.cidx_off + (G == 2 ? rb.near_off : 0u)) * 16u;
-            const uint32_t e0 = ps[b].elem0 + l[b];
-            if (G == 1 && rb.cidx_width == 4) {
-#pragma unroll
-                for (int w = 0; w < W; ++w)
-                    goff[b][w] = reinterpret_cast<const uint32_t *>(cidx)[e0 + (uint32_t) w * nseg[b]];
-            } else if (G == 1 && rb.cidx_width == 3) {
-                // 24-bit offsets: the low halves, then (array of its own) the high bytes
-                const uint8_t *hi = cidx + (size_t) rb.hi_off * 16u;
-#pragma unroll
-                for (int w = 0; w < W; ++w) {
-                    const uint32_t e = e0 + (uint32_t) w * nseg[b];
-                    goff[b][w] = (uint32_t) reinterpret_cast<const uint16_t *>(cidx)[e] | ((uint32_t) hi[e] << 16);
-                }
-            } else {
-#pragma unroll
-                for (int w = 0; w < W; ++w)
-                    goff[b][w] = reinterpret_cast<const uint16_t *>(cidx)[e0 + (uint32_t) w * nseg[b]];
-            }
-        } else {
-            if (ps[b].flags & SPX_PASSF_INLINE) {
-                // the pass' only descriptor came with its header (wave-uniform, in SGPRs)
-                q[b].x = (uint32_t) ps[b].mask;
-                q[b].y = (uint32_t) (ps[b].mask >> 32);
-            } else
-            {
-                const uint64_t mk = (ps[b].flags & SPX_PASSF_INLINE) ? 0ull : ps[b].mask;
-                const uint32_t rank = (uint32_t) ps[b].rank0 + (active[b] ? starts_upto(mk, lane) : 0u);
-                q[b] = ld_stream(reinterpret_cast<const uint2 *>(a.descs + rb.desc_off + rank));
-            }
-        }
-    }
-    double2 v2[B][W / 2 > 0 ? W / 2 : 1];
-    double v1[B];
-#pragma unroll
-    for (int b = 0; b < B; ++b) {
-        const double *vals = a.values + rb.val_off + ps[b].val_off;
-#pragma unroll
-        for (int p = 0; p < W / 2; ++p)
-            v2[b][p] = ld_stream(reinterpret_cast<const double2 *>(vals + (uint32_t) p * 2u * nseg[b] + l[b] * 2u));
-        if (W & 1) v1[b] = ld_stream(vals + (uint32_t) (W / 2) * 2u * nseg[b] + l[b]);
-    }
-    int row[B];
-    double acc[B];
-    double x[B][W];
-#pragma unroll
-    for (int b = 0; b < B; ++b) {
-        if (G == 2) {
-            // (a piece shorter than the pass is padded: nothing is multiplied there)
-            row[b] = (int) SPX_SEGROW_ROW(q[b].x);
-            const int len = (int) SPX_SEGROW_LEN(q[b].x);
-#pragma unroll
-            for (int w = 0; w < W; ++w) {
-                const double xv = win[goff[b][w]];
-                x[b][w] = w < len ? xv : 0.0;
-            }
-        } else if (G) {
-            row[b] = (int) SPX_SEGROW_ROW(q[b].x);
-            const int len = (int) SPX_SEGROW_LEN(q[b].x);
-            const double *xp = a.x + rb.cbase;
-#pragma unroll
-            for (int w = 0; w < W; ++w) {
-                const double xv = xp[goff[b][w]];
-                x[b][w] = w < len ? xv : 0.0;
-            }
-        } else {
-            // segment index inside its unit, then its row / first column
-            const uint32_t bits = q[b].y;
-            const int s = (int) ((ps[b].seg0 + l[b] - ((bits >> 9) & 8191u)) & 0xffffu);
-            const uint32_t kind = (bits >> 22) & 7u;
-            const int step = (int) (bits >> 25);
-            const int drow = kind == SPX_KIND_BLOCK ? 1 : (kind >= SPX_KIND_VERT ? step : 0);
-            const int dcol = (kind == SPX_KIND_HORIZ || kind == SPX_KIND_DIAG)
-                                 ? step : (kind == SPX_KIND_ADIAG ? -step : 0);
-            row[b] = (int) (ps[b].elem0 + (bits & 511u)) + s * drow;
-            const uint32_t col = q[b].x + (uint32_t) (s * dcol);
-            const double *xp = a.x + col;
-            // The x loads cost address-unit issue slots like the value loads do: they come in pairs
-            // at any alignment, W / 2 + (W & 1) load instructions instead of W.  (One full-width load
-            // per diagonal stack with the other W - 1 columns taken from the neighbouring lanes by
-            // DPP shifts was built and measured slower: profiles/r03/ablation.md section 6.)
-            if (W >= 2) {
-                const spx_d2u_t *xp2 = reinterpret_cast<const spx_d2u_t *>(xp);
-#pragma unroll
-                for (int p = 0; p < W / 2; ++p) {
-                    const spx_d2u_t xx = xp2[p];
-                    x[b][2 * p] = xx.x;
-                    x[b][2 * p + 1] = xx.y;
-                }
-                if (W & 1) x[b][W - 1] = xp[W - 1];
-            } else {
-#pragma unroll
-                for (int w = 0; w < W; ++w) x[b][w] = xp[w];
-            }
-        }
-        double t = 0.0;
-#pragma unroll
-        for (int p = 0; p < W / 2; ++p) {
-            t = fma(v2[b][p].x, x[b][2 * p], t);
-            t = fma(v2[b][p].y, x[b][2 * p + 1], t);
-        }
-        if (W & 1) t = fma(v1[b], x[b][W - 1], t);
-        acc[b] = t;
-    }
-    if (G == 1 && rb.n_rows == 1) {
-        // a chunk of one over-long row: every lane targets tile[0]
-        double t = 0.0;
-#pragma unroll
-        for (int b = 0; b < B; ++b) t += active[b] ? acc[b] : 0.0;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) t += __shfl_xor(t, d);
-        if (lane == 0) atomicAdd(&tile[0], t);
-        return;
-    }
-#pragma unroll
-    for (int b = 0; b < B; ++b)
-        if (active[b]) atomicAdd(&tile[row[b]], acc[b]);
-}
-
-template <int B, int G>
-__device__ __forceinline__ void run_units(const KernelArgs &a, const SpxRowBlock &rb,
-                                          const SpxPass (&ps)[B], double *tile, const double *win,
-                                          int lane)
-{
-    switch (ps[0].width) {         // wave-uniform
-    case 1: unit_passes<1, B, G>(a, rb, ps, tile, win, lane); break;
-    case 2: unit_passes<2, B, G>(a, rb, ps, tile, win, lane); break;
-    case 3: unit_passes<3, B, G>(a, rb, ps, tile, win, lane); break;
-    case 4: unit_passes<4, B, G>(a, rb, ps, tile, win, lane); break;
-    case 5: unit_passes<5, 1, G>(a, rb, {ps[0]}, tile, win, lane);
-            if (B > 1) unit_passes<5, 1, G>(a, rb, {ps[B - 1]}, tile, win, lane);
-            break;
-    case 6: unit_passes<6, 1, G>(a, rb, {ps[0]}, tile, win, lane);
-            if (B > 1) unit_passes<6, 1, G>(a, rb, {ps[B - 1]}, tile, win, lane);
-            break;
-    case 7: unit_passes<7, 1, G>(a, rb, {ps[0]}, tile, win, lane);
-            if (B > 1) unit_passes<7, 1, G>(a, rb, {ps[B - 1]}, tile, win, lane);
-            break;
-    default: unit_passes<8, 1, G>(a, rb, {ps[0]}, tile, win, lane);
-            if (B > 1) unit_passes<8, 1, G>(a, rb, {ps[B - 1]}, tile, win, lane);
-            break;
-    }
-}
 
 // lane ^ 1, ^ 2, ^ 4 inside groups of eight lanes as DPP moves (VALU) instead of
 // ds_bpermute (__shfl_xor goes through the LDS crossbar): quad_perm for 1 and 2,
@@ -489,14 +274,6 @@ __device__ __forceinline__ bool run_symseg2(const KernelArgs &a, const SpxRowBlo
     return true;
 }
 
-__device__ __forceinline__ void run_pass(const KernelArgs &a, const SpxRowBlock &rb,
-                                         const SpxPass &ps, double *tile, const double *win, int lane)
-{
-    if (ps.kind == SPX_PASS_GATHER) run_units<1, 1>(a, rb, {ps}, tile, win, lane);
-    else if (ps.kind == SPX_PASS_GATHER_LDS) run_units<1, 2>(a, rb, {ps}, tile, win, lane);
-    else run_units<1, 0>(a, rb, {ps}, tile, win, lane);
-}
-
 // One workgroup owns one row-block; its wavefronts take the passes in turn
 // (wave w: passes w, w+4, ...) and accumulate into one y tile in LDS, which
 // is written out (y = alpha*tile + beta*y) at the end.
@@ -649,19 +426,6 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &x
         for (int i = threadIdx.x; i < n_slots; i += BLOCK_THREADS) a.spill[rb.spill_off + i] = lds[i];
 }
 
-#define SPX_KERNEL_PARAMS                                                                        \
-    const SpxRowBlock *rbs_, const SpxPass *passes_, uint32_t n_rb_, uint32_t pass_stride_,      \
-    XcdSplit xcd_split, const double *values_, const SpxUnitDesc *descs_, \
-    const uint8_t *cidx_, const uint16_t *segrows_, const double *x_, double *y_,               \
-    double *carry_, const double *dvalues_, double *spill_, const uint32_t *slot_col_,         \
-    double alpha_, double beta_, const double *dvalues_priv_, double beta_priv_
-#define SPX_KERNEL_ARGS(a)                                                                       \
-    KernelArgs a;                                                                                \
-    a.rbs = rbs_; a.passes = passes_; a.n_rb = n_rb_; a.pass_stride = pass_stride_;              \
-    a.values = values_; a.descs = descs_; a.cidx = cidx_; a.segrows = segrows_; a.x = x_;        \
-    a.y = y_; a.carry = carry_; a.dvalues = dvalues_; a.spill = spill_; a.slot_col = slot_col_;  \
-    a.alpha = alpha_; a.dvalues_priv = dvalues_priv_; a.beta_priv = beta_priv_;                  \
-    a.beta = beta_
 
 // (Individual scalar arguments, most urgent first.  Preloading them into SGPRs
 // at wave launch -- hipcc -mllvm -amdgpu-kernarg-preload-count=16 -- was
@@ -910,6 +674,16 @@ struct DeviceMatrix {
     std::vector<uint32_t> chunk_longest;
     std::vector<size_t> chunk_bounds;
     size_t chunk_asked = 0;
+    // unit windows of x in LDS (xwindows.hpp; plain general streams): a second set of pass headers and
+    // descriptors for csx_spmv_xw_kernel, the window table, the LDS a launch needs
+    SpxPass *passes_xw = nullptr;
+    SpxUnitDesc *xdescs = nullptr;
+    XwEntry *xw_tab = nullptr;
+    uint32_t lds_doubles_xw = 0;
+    uint32_t xw_budget = 0, xw_gap = 0;   // as the stream was uploaded (kept for spx_mat_save)
+    bool xw_on = false;           // the product runs through csx_spmv_xw_kernel
+    uint64_t xw_elems = 0, xw_unit_elems = 0, xw_staged = 0;
+    size_t xw_rowblocks = 0;
 };
 
 int device_count()
@@ -1186,6 +960,44 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
         device_free(m);
         throw;
     }
+    // unit windows (plain general streams in stream order, one launch): planned from the stream as it
+    // is, uploaded next to it; whether the product uses them is the caller's (the launch tuner's) choice
+    m->xw_budget = s.xw_budget;
+    m->xw_gap = s.xw_gap;
+    if (s.xw_budget && !symmetric && !m->accum && m->launch_order.empty() && m->xcd_split.size() == 1 &&
+        !s.rbs.empty()) {
+        try {
+            XwPlan plan;
+            plan_unit_xwindows(s, ncols, s.xw_budget, s.xw_gap, plan, host_threads());
+            if (plan.n_rb_windows) {
+                auto up = [&](auto **dst, const auto &v, size_t slack) {
+                    typedef typename std::remove_reference<decltype(v[0])>::type T;
+                    const size_t bytes = (v.size() + slack) * sizeof(T);
+                    HIP_CHECK(hipMalloc(reinterpret_cast<void **>(dst), bytes));
+                    HIP_CHECK(hipMemset(*dst, 0, bytes));
+                    HIP_CHECK(hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+                };
+                up(&m->passes_xw, plan.passes, (size_t) s.pass_stride + 6 * MAX_WAVES_PER_BLOCK);
+                up(&m->xdescs, plan.xdescs, 8);
+                up(&m->xw_tab, plan.tab, 0);
+                m->lds_doubles_xw = plan.lds_doubles;
+                m->xw_elems = plan.unit_elems_lds;
+                m->xw_unit_elems = plan.unit_elems;
+                m->xw_staged = plan.staged_doubles;
+                m->xw_rowblocks = plan.n_rb_windows;
+                m->xw_on = s.xw_on;
+                if ((size_t) m->lds_doubles_xw * sizeof(double) > 64u * 1024u) spmv_xw_allow_lds(160u * 1024u);
+                log_msg(LOG_INFO, "unit windows: %zu of %zu row-blocks, %.1f %% of the unit nonzeros read x from LDS, "
+                        "%.2f doubles staged per such nonzero, %u KB of LDS per workgroup\n", plan.n_rb_windows, plan.n_rb_units,
+                        100.0 * (double) plan.unit_elems_lds / (double) std::max<uint64_t>(plan.unit_elems, 1),
+                        (double) plan.staged_doubles / (double) std::max<uint64_t>(plan.unit_elems_lds, 1),
+                        (unsigned) (m->lds_doubles_xw * sizeof(double) / 1024u));
+            }
+        } catch (...) {
+            device_free(m);
+            throw;
+        }
+    }
     if (getenv("SPX_LOG_PLACEMENT"))
         log_msg(LOG_ERR, "placement: arena %p (%zu MB) values %p descs %p passes %p rbs %p\n", m->arena, m->arena_bytes >> 20,
                 (void *) m->values, (void *) m->descs, (void *) m->passes, (void *) m->rbs);
@@ -1212,6 +1024,9 @@ void device_free(DeviceMatrix *m)
         if (m->mirror_col) (void) hipFree(m->mirror_col);
         if (m->mirror_val) (void) hipFree(m->mirror_val);
     }
+    if (m->passes_xw) (void) hipFree(m->passes_xw);
+    if (m->xdescs) (void) hipFree(m->xdescs);
+    if (m->xw_tab) (void) hipFree(m->xw_tab);
     if (m->d_x) (void) hipFree(m->d_x);
     if (m->d_y) (void) hipFree(m->d_y);
     if (m->p_x) (void) hipHostFree(m->p_x);
@@ -1346,6 +1161,12 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
             if (m->waves == 2) SPX_LAUNCH(csx_spmv_accum_kernel, 2, lds);
             else if (m->waves == 8) SPX_LAUNCH(csx_spmv_accum_kernel, 8, lds);
             else SPX_LAUNCH(csx_spmv_accum_kernel, 4, lds);
+        } else if (blocks && m->xw_on && m->passes_xw) {
+            KernelArgs ax = a;
+            ax.passes = m->passes_xw;
+            ax.descs = m->xdescs;
+            ax.xw_tab = m->xw_tab;
+            launch_spmv_xw(m->waves, blocks, (size_t) m->lds_doubles_xw * sizeof(double), stream, ax, xcd_now);
         } else if (blocks) {
             const size_t lds = m->lds_doubles * sizeof(double);
             if (m->waves == 2) SPX_LAUNCH(csx_spmv_kernel, 2, lds);
@@ -1437,7 +1258,16 @@ void device_spmv_chunk(DeviceMatrix *m, size_t k, double alpha, const double *d_
         if (m->wave_tiles) SPX_LAUNCH_CHUNK_K(csx_spmv_det_kernel, W);                                       \
         else SPX_LAUNCH_CHUNK_K(csx_spmv_kernel, W);                                                         \
     } while (0)
-    if (m->waves == 2) SPX_LAUNCH_CHUNK(2);
+    if (m->xw_on && m->passes_xw && !m->wave_tiles) {
+        KernelArgs ax;
+        memset(&ax, 0, sizeof(ax));
+        ax.rbs = m->rbs; ax.passes = m->passes_xw; ax.values = m->values; ax.descs = m->xdescs;
+        ax.cidx = m->cidx; ax.segrows = m->segrows; ax.x = d_x; ax.y = d_y; ax.carry = m->carry;
+        ax.alpha = alpha; ax.beta = beta; ax.n_rb = m->n_rb; ax.pass_stride = m->pass_stride;
+        ax.xw_tab = m->xw_tab;
+        launch_spmv_xw(m->waves, blocks, (size_t) m->lds_doubles_xw * sizeof(double), stream, ax, xs);
+    }
+    else if (m->waves == 2) SPX_LAUNCH_CHUNK(2);
     else if (m->waves == 8) SPX_LAUNCH_CHUNK(8);
     else SPX_LAUNCH_CHUNK(4);
 #undef SPX_LAUNCH_CHUNK_K
@@ -1497,6 +1327,17 @@ void device_set_waves(DeviceMatrix *m, int waves)
 }
 
 int device_get_waves(const DeviceMatrix *m) { return m->waves; }
+
+bool device_has_xw(const DeviceMatrix *m) { return m->passes_xw != nullptr; }
+void device_set_xw(DeviceMatrix *m, bool on) { m->xw_on = on && m->passes_xw && !m->wave_tiles; }
+bool device_get_xw(const DeviceMatrix *m) { return m->xw_on && m->passes_xw && !m->wave_tiles; }
+void device_xw_info(const DeviceMatrix *m, uint64_t &elems_lds, uint64_t &unit_elems, uint64_t &staged, uint32_t &lds_bytes)
+{
+    elems_lds = m->xw_elems;
+    unit_elems = m->xw_unit_elems;
+    staged = m->xw_staged;
+    lds_bytes = (uint32_t) (m->lds_doubles_xw * sizeof(double));
+}
 
 static void ensure_staging(DeviceMatrix *m)
 {
@@ -1707,6 +1548,9 @@ void device_download(const DeviceMatrix *m, GpuStream &s)
     s.sym_atomic = m->sym_atomic;
     s.deterministic = m->deterministic;
     s.wave_tiles = m->wave_tiles;
+    s.xw_on = device_get_xw(m);
+    s.xw_budget = m->xw_budget;
+    s.xw_gap = m->xw_gap;
     if (m->n_spill) download(s.slot_group_col, m->slot_col, m->n_slot_col);
     if (m->n_spill) {
         download(s.fix_ptr, m->fix_ptr, m->n_fix_ptr);

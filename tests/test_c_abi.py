@@ -235,5 +235,5 @@ def test_round4_extensions_reject_bad_arguments():
     assert L.spx_hip_mat_info_sized(A.handle, buf, 24) == sx.SPX_SUCCESS
     assert all(b == 0xAB for b in bytes(buf)[24:]) and any(b != 0xAB for b in bytes(buf)[:24])
     assert L.spx_hip_mat_info_sized(A.handle, None, 24) == sx.SPX_FAILURE
-    assert L.spx_hip_abi_version() == 3
+    assert L.spx_hip_abi_version() == 4
     sx.options_reset()
