@@ -601,6 +601,7 @@ static void emit_and_upload(spx_matrix_t *A)
     gs.xw_budget = (A->unit_windows != 0 && !A->deterministic && !sym) ? A->xw_budget : 0u;
     gs.xw_gap = A->xw_gap;
     gs.xw_on = A->xw_on;
+    gs.xw_depth = (uint32_t) A->xw_depth;
     gs.sym_atomic = A->sym_atomic && !A->deterministic;
     gs.deterministic = A->deterministic;
     gs.wave_tiles = A->deterministic || A->wave_tiles == 1;
@@ -993,6 +994,12 @@ static spx_matrix_t *do_tune(spx_input_t *in)
         }
         A->xw_budget = (uint32_t) xb;
         A->xw_gap = (uint32_t) xg;
+        const long xd = cfg.get_long("spx.gpu.unit_window_depth");
+        if (xd < 2 || xd > 4) {
+            log_msg(LOG_ERR, "spx.gpu.unit_window_depth: 2, 3 or 4\n");
+            throw FatalError("bad spx.gpu.unit_window_depth");
+        }
+        A->xw_depth = (int) xd;
     }
     A->unit_windows = xw_mode == "auto" ? -1 : (xw_mode == "true" ? 1 : 0);
     A->xw_on = xw_mode == "true";                       // (auto: off until measured)
@@ -1534,8 +1541,8 @@ spx_error_t spx_mat_save(const spx_matrix_t *A, const char *filename)
     h.n_encoded = (uint32_t) A->parts.size();
     h.sym_atomic = gs->sym_atomic ? 1u : 0u;
     // (bit 2: the product runs with the unit windows of x in LDS; bits 8-15 / 16-31: their gap and budget)
-    h.pad3 = (gs->deterministic ? 1u : 0u) | (gs->wave_tiles ? 2u : 0u) | (gs->xw_on ? 4u : 0u) |
-             ((gs->xw_gap & 255u) << 8) | (std::min<uint32_t>(gs->xw_budget, 65535u) << 16);
+    h.pad3 = (gs->deterministic ? 1u : 0u) | (gs->wave_tiles ? 2u : 0u);
+    if (gs->xw_on) h.pad3 |= 4u | ((gs->xw_gap & 255u) << 8) | (std::min<uint32_t>(gs->xw_budget, 65535u) << 16);
     h.checksum = stream_checksum(*gs);
     bool good = fwrite(kMagic, 1, 8, f) == 8 && fwrite(&h, sizeof(h), 1, f) == 1;
     std::vector<int32_t> bnd;
@@ -1625,7 +1632,7 @@ spx_matrix_t *spx_mat_restore(const char *filename)
         gs->deterministic = (h.pad3 & 1u) != 0;
         gs->wave_tiles = (h.pad3 & 2u) != 0;
         gs->xw_on = (h.pad3 & 4u) != 0;
-        gs->xw_gap = (h.pad3 >> 8) & 255u;
+        gs->xw_gap = gs->xw_on ? ((h.pad3 >> 8) & 255u) : 16u;
         gs->xw_budget = gs->xw_on ? (h.pad3 >> 16) : 0u;
         gs->nnz_stored = h.nnz_stored; gs->n_unit_elems = h.n_unit_elems;
         gs->n_delta_elems = h.n_delta_elems; gs->n_units = h.n_units;
@@ -2027,6 +2034,13 @@ spx_error_t spx_hip_matvec_dist(spx_value_t alpha, const spx_matrix_t *A,
 // ======================================================================================
 
 int spx_hip_abi_version(void) { return SPX_HIP_ABI_VERSION; }
+
+// (experiment builds only, tools/build_variant.sh -DSPX_XW_PROFILE: shader clocks per phase of a workgroup of
+// csx_spmv_xw_kernel, summed since the last call; SPX_FAILURE in a regular build)
+spx_error_t spx_hip_debug_counters(unsigned long long out[8])
+{
+    return out && spmv_xw_profile(out) ? SPX_SUCCESS : SPX_FAILURE;
+}
 
 spx_error_t spx_hip_mat_unit_windows(spx_matrix_t *A, uint32_t budget, uint32_t gap, spx_hip_xw_plan_t *out)
 {

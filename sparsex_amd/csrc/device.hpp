@@ -86,8 +86,14 @@ int device_get_waves(const DeviceMatrix *m);
 bool device_has_xw(const DeviceMatrix *m);
 void device_set_xw(DeviceMatrix *m, bool on);
 bool device_get_xw(const DeviceMatrix *m);
+void device_set_xw_depth(DeviceMatrix *m, int depth);      // rounds of unit passes in flight per wavefront: 2, 3 or 4
+int device_get_xw_depth(const DeviceMatrix *m);
 void device_xw_info(const DeviceMatrix *m, uint64_t &elems_lds, uint64_t &unit_elems, uint64_t &staged_doubles,
                     uint32_t &lds_bytes);
+
+// experiment builds (-DSPX_XW_PROFILE): clock counters of csx_spmv_xw_kernel's workgroups, read and cleared;
+// false in a regular build
+bool spmv_xw_profile(unsigned long long out[8]);
 
 // seconds per SpMV (alpha = 1, beta = 0) over `launches` back-to-back launches
 // on a private stream with scratch vectors -- what spx_mat_tune() measures to

@@ -80,7 +80,7 @@ struct GpuStream {
     // spx.gpu.unit_windows (device side only, xwindows.hpp): most doubles of x a row-block may stage in
     // LDS for its unit passes (0: none planned), intervals closer than `xw_gap` doubles are merged, and
     // whether the product starts out using them (the launch tuner measures both)
-    uint32_t xw_budget = 0, xw_gap = 16;
+    uint32_t xw_budget = 0, xw_gap = 16, xw_depth = 2;     // (xw_depth: rounds of unit passes in flight per wavefront)
     bool xw_on = false;
     // accounting
     size_t nnz_stored = 0;        // nonzeros held in `values` (without padding)

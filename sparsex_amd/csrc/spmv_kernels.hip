@@ -35,7 +35,7 @@
 namespace spx {
 
 // spmv_xw_kernels.hip
-void launch_spmv_xw(int waves, unsigned blocks, size_t lds_bytes, void *stream, const KernelArgs &a, const XcdSplit &xs);
+void launch_spmv_xw(int waves, int depth, unsigned blocks, size_t lds_bytes, void *stream, const KernelArgs &a, const XcdSplit &xs);
 void spmv_xw_allow_lds(size_t bytes);
 
 #define HIP_CHECK(expr)                                                         \
@@ -682,6 +682,7 @@ struct DeviceMatrix {
     uint32_t lds_doubles_xw = 0;
     uint32_t xw_budget = 0, xw_gap = 0;   // as the stream was uploaded (kept for spx_mat_save)
     bool xw_on = false;           // the product runs through csx_spmv_xw_kernel
+    int xw_depth = 2;             // ... rounds in flight per wavefront (2, 3 or 4)
     uint64_t xw_elems = 0, xw_unit_elems = 0, xw_staged = 0;
     size_t xw_rowblocks = 0;
 };
@@ -986,6 +987,7 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
                 m->xw_staged = plan.staged_doubles;
                 m->xw_rowblocks = plan.n_rb_windows;
                 m->xw_on = s.xw_on;
+                m->xw_depth = s.xw_depth < 2 ? 2 : (s.xw_depth > 4 ? 4 : (int) s.xw_depth);
                 if ((size_t) m->lds_doubles_xw * sizeof(double) > 64u * 1024u) spmv_xw_allow_lds(160u * 1024u);
                 log_msg(LOG_INFO, "unit windows: %zu of %zu row-blocks, %.1f %% of the unit nonzeros read x from LDS, "
                         "%.2f doubles staged per such nonzero, %u KB of LDS per workgroup\n", plan.n_rb_windows, plan.n_rb_units,
@@ -1166,7 +1168,7 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
             ax.passes = m->passes_xw;
             ax.descs = m->xdescs;
             ax.xw_tab = m->xw_tab;
-            launch_spmv_xw(m->waves, blocks, (size_t) m->lds_doubles_xw * sizeof(double), stream, ax, xcd_now);
+            launch_spmv_xw(m->waves, m->xw_depth, blocks, (size_t) m->lds_doubles_xw * sizeof(double), stream, ax, xcd_now);
         } else if (blocks) {
             const size_t lds = m->lds_doubles * sizeof(double);
             if (m->waves == 2) SPX_LAUNCH(csx_spmv_kernel, 2, lds);
@@ -1265,7 +1267,7 @@ void device_spmv_chunk(DeviceMatrix *m, size_t k, double alpha, const double *d_
         ax.cidx = m->cidx; ax.segrows = m->segrows; ax.x = d_x; ax.y = d_y; ax.carry = m->carry;
         ax.alpha = alpha; ax.beta = beta; ax.n_rb = m->n_rb; ax.pass_stride = m->pass_stride;
         ax.xw_tab = m->xw_tab;
-        launch_spmv_xw(m->waves, blocks, (size_t) m->lds_doubles_xw * sizeof(double), stream, ax, xs);
+        launch_spmv_xw(m->waves, m->xw_depth, blocks, (size_t) m->lds_doubles_xw * sizeof(double), stream, ax, xs);
     }
     else if (m->waves == 2) SPX_LAUNCH_CHUNK(2);
     else if (m->waves == 8) SPX_LAUNCH_CHUNK(8);
@@ -1330,6 +1332,8 @@ int device_get_waves(const DeviceMatrix *m) { return m->waves; }
 
 bool device_has_xw(const DeviceMatrix *m) { return m->passes_xw != nullptr; }
 void device_set_xw(DeviceMatrix *m, bool on) { m->xw_on = on && m->passes_xw && !m->wave_tiles; }
+void device_set_xw_depth(DeviceMatrix *m, int depth) { m->xw_depth = depth < 2 ? 2 : (depth > 4 ? 4 : depth); }
+int device_get_xw_depth(const DeviceMatrix *m) { return m->xw_depth; }
 bool device_get_xw(const DeviceMatrix *m) { return m->xw_on && m->passes_xw && !m->wave_tiles; }
 void device_xw_info(const DeviceMatrix *m, uint64_t &elems_lds, uint64_t &unit_elems, uint64_t &staged, uint32_t &lds_bytes)
 {
@@ -1551,6 +1555,7 @@ void device_download(const DeviceMatrix *m, GpuStream &s)
     s.xw_on = device_get_xw(m);
     s.xw_budget = m->xw_budget;
     s.xw_gap = m->xw_gap;
+    s.xw_depth = (uint32_t) m->xw_depth;
     if (m->n_spill) download(s.slot_group_col, m->slot_col, m->n_slot_col);
     if (m->n_spill) {
         download(s.fix_ptr, m->fix_ptr, m->n_fix_ptr);

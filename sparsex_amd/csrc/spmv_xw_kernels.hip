@@ -8,6 +8,9 @@
 #include "spmv_device.hpp"
 
 #include <cstddef>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 
 namespace spx {
 
@@ -64,85 +67,158 @@ __device__ __forceinline__ PassWords load_pass(spx_const_words_t passes, int ind
     return h;
 }
 
-template <int W, int B>
+// the pass headers of the row-block in LDS (the workgroup copies them there in its prologue: one coalesced
+// load instead of a scalar load from memory per pass and wavefront): entry `index` as six dwords, the same
+// for every lane, then into SGPRs
+__device__ __forceinline__ PassWords lds_pass(const uint32_t *hdr, int index)
+{
+    const uint2 *p = reinterpret_cast<const uint2 *>(hdr + 6 * index);
+    const uint2 a = p[0], b = p[1], c = p[2];
+    PassWords h;
+    h.w[0] = (uint32_t) __builtin_amdgcn_readfirstlane((int) a.x);
+    h.w[1] = (uint32_t) __builtin_amdgcn_readfirstlane((int) a.y);
+    h.w[2] = (uint32_t) __builtin_amdgcn_readfirstlane((int) b.x);
+    h.w[3] = (uint32_t) __builtin_amdgcn_readfirstlane((int) b.y);
+    h.w[4] = (uint32_t) __builtin_amdgcn_readfirstlane((int) c.x);
+    h.w[5] = (uint32_t) __builtin_amdgcn_readfirstlane((int) c.y);
+    return h;
+}
+
+// a pass that is not there (the second half of a round at the end of a wavefront's list): the first
+// one's addresses, no lanes
+__device__ __forceinline__ PassWords no_pass(const PassWords &like)
+{
+    PassWords h = like;
+    h.w[4] &= ~0xffu;
+    return h;
+}
+
+// One stage of the pipeline: B unit passes of ANY width 1..4, three loads each -- the lane's descriptor
+// and two 16-byte loads at 8-byte granularity that between them hold its values whatever the width
+// (W = 1: {v0, -}; 2: {v0, v1}; 3: {v0, v1}, {v2, -}; 4: {v0, v1}, {v2, v3}; "-" is whatever follows in
+// the value array, never used).  The same number of loads for every pass is what lets passes of
+// different widths follow each other in one pipeline, and lets the compiler count its loads.
+template <int B>
 struct XwStage {
-    uint2 q[B];                                   // {offset of segment 0 in the unit windows, descriptor bits}
-    uint32_t segl[B];                             // segments of the row-block in front of the lane's | active << 16
-    double2 v2[B][W / 2 > 0 ? W / 2 : 1];
-    double v1[B];
+    uint2 q[B];                // {offset of segment 0 in the unit windows, descriptor bits}
+    uint32_t segl[B];          // segments of the row-block in front of the lane's | lane active << 16
+    uint32_t width[B];         // (wave-uniform)
+    uint32_t row0[B];          // (wave-uniform) first row of the pass' part of the row-block (SpxPass::elem0)
+    spx_d2u_t va[B], vb[B];
 };
 
-// The loads of B unit passes of width W: descriptors where the header holds none, values.  Everything the
-// second half needs of the headers goes into the stage with them (an inline descriptor is copied, the lane's
-// segment number and whether it is there at all are packed into one register): the headers themselves are
-// dead once their loads are out, which is what lets the wavefront hold those of the next two rounds.
-template <int W, int B>
+// The loads of a stage.  Everything the second half needs of the headers goes into the stage with them:
+// the headers are dead once their loads are out.  (The descriptor comes from the descriptor array also
+// where the header holds a copy: x comes from LDS once the values are there, so the copy would save no
+// round trip here.)
+template <int B>
 __device__ __forceinline__ void xw_issue(const KernelArgs &a, const SpxRowBlock &rb, const PassWords (&ps)[B],
-                                         XwStage<W, B> &S, int lane)
+                                         XwStage<B> &S, int lane)
 {
 #pragma unroll
     for (int b = 0; b < B; ++b) {
-        const uint32_t nseg = ps[b].nseg();
+        const uint32_t nseg = ps[b].nseg(), W = ps[b].width();
         const bool active = (uint32_t) lane < nseg;
         const uint32_t l = active ? (uint32_t) lane : 0u;
         S.segl[b] = ps[b].seg0() + l + (active ? 0x10000u : 0u);
-        // (always from the descriptor array, also where the header holds a copy: x comes from LDS once the
-        // values are there, so the copy saves no round trip here, and a fixed number of loads per round
-        // is what lets the compiler count them -- with a branch around this load it waited for the
-        // previous round's values before requesting the next ones)
+        S.width[b] = W;
+        S.row0[b] = ps[b].w[5];
         const uint64_t mk = (ps[b].flags() & SPX_PASSF_INLINE) ? 0ull : ps[b].mask();
         const uint32_t rank = ps[b].rank0() + (active ? starts_upto(mk, lane) : 0u);
         S.q[b] = ld_stream(reinterpret_cast<const uint2 *>(a.descs + rb.desc_off + rank));
         const double *vals = a.values + rb.val_off + ps[b].val_off();
-#pragma unroll
-        for (int p = 0; p < W / 2; ++p)
-            S.v2[b][p] = ld_stream(reinterpret_cast<const double2 *>(vals + (uint32_t) p * 2u * nseg + l * 2u));
-        if (W & 1) S.v1[b] = ld_stream(vals + (uint32_t) (W / 2) * 2u * nseg + l);
+        const uint32_t off_a = W == 1u ? l : 2u * l;
+        const uint32_t off_b = W == 3u ? 2u * nseg + l : (W == 4u ? 2u * nseg + 2u * l : off_a);
+        S.va[b] = *reinterpret_cast<const spx_d2u_t *>(vals + off_a);
+        S.vb[b] = *reinterpret_cast<const spx_d2u_t *>(vals + off_b);
     }
 }
 
 // ... and what follows once they have arrived: rows and window offsets, x from LDS, W FMAs, one LDS add
-// (unit passes of a general stream: SpxPass::elem0 is 0)
-template <int W, int B>
-__device__ __forceinline__ void xw_finish(const XwStage<W, B> &S, double *tile, const double *xw)
+template <int W>
+__device__ __forceinline__ void xw_finish_pass(uint2 q, uint32_t segl, uint32_t row0, spx_d2u_t va, spx_d2u_t vb,
+                                               double *tile, const double *xw)
 {
+    const uint32_t c0 = q.x, bits = q.y;
+    const int s = (int) ((segl - ((bits >> 9) & 8191u)) & 0xffffu);
+    const uint32_t kind = (bits >> 22) & 7u;
+    const int step = (int) (bits >> 25);
+    const int drow = kind == SPX_KIND_BLOCK ? 1 : (kind >= SPX_KIND_VERT ? step : 0);
+    const int dcol = (kind == SPX_KIND_HORIZ || kind == SPX_KIND_DIAG)
+                         ? step : (kind == SPX_KIND_ADIAG ? -step : 0);
+    const int row = (int) (row0 + (bits & 511u)) + s * drow;
+    const double *xp = xw + (int) (c0 + (uint32_t) (s * dcol));      // (c0: an offset into the unit windows)
+#ifdef SPX_XW_ABL_NOX          // (variant builds, tools/build_variant.sh: results wrong on purpose)
+    const double one[4] = {1.0, 1.0, 1.0, 1.0};
+    xp = one;
+#endif
+    double t = va.x * xp[0];
+    if (W >= 2) t = fma(va.y, xp[1], t);
+    if (W >= 3) t = fma(vb.x, xp[2], t);
+    if (W >= 4) t = fma(vb.y, xp[3], t);
+#ifdef SPX_XW_ABL_NOADD
+    if (t == 1.2345e300 && row == 12345) atomicAdd(&tile[row], t);
+#else
+    if (segl >> 16) atomicAdd(&tile[row], t);
+#endif
+}
+
+template <int B>
+__device__ __forceinline__ void xw_finish(const XwStage<B> &S, double *tile, const double *xw)
+{
+#ifdef SPX_XW_ABL_NOFINISH     // (variant build: the loaded values are only consumed)
 #pragma unroll
     for (int b = 0; b < B; ++b) {
-        const uint32_t c0 = S.q[b].x, bits = S.q[b].y;
-        const int s = (int) ((S.segl[b] - ((bits >> 9) & 8191u)) & 0xffffu);
-        const uint32_t kind = (bits >> 22) & 7u;
-        const int step = (int) (bits >> 25);
-        const int drow = kind == SPX_KIND_BLOCK ? 1 : (kind >= SPX_KIND_VERT ? step : 0);
-        const int dcol = (kind == SPX_KIND_HORIZ || kind == SPX_KIND_DIAG)
-                             ? step : (kind == SPX_KIND_ADIAG ? -step : 0);
-        const int row = (int) (bits & 511u) + s * drow;
-        const double *xp = xw + (int) (c0 + (uint32_t) (s * dcol));      // (c0: an offset into the unit windows)
-        double t = 0.0;
-#ifdef SPX_XW_ABL_NOX          // (variant builds, tools/build_variant.sh: results wrong on purpose)
-        const double one[8] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
-        xp = one;
+        const double t = S.va[b].x + S.vb[b].x;
+        if (t == 1.2345e300 && S.q[b].y == 12345u) atomicAdd(&tile[0], t);
+    }
+    return;
 #endif
 #pragma unroll
-        for (int p = 0; p < W / 2; ++p) {
-            t = fma(S.v2[b][p].x, xp[2 * p], t);
-            t = fma(S.v2[b][p].y, xp[2 * p + 1], t);
+    for (int b = 0; b < B; ++b) {
+        switch (S.width[b]) {          // wave-uniform
+        case 1: xw_finish_pass<1>(S.q[b], S.segl[b], S.row0[b], S.va[b], S.vb[b], tile, xw); break;
+        case 2: xw_finish_pass<2>(S.q[b], S.segl[b], S.row0[b], S.va[b], S.vb[b], tile, xw); break;
+        case 3: xw_finish_pass<3>(S.q[b], S.segl[b], S.row0[b], S.va[b], S.vb[b], tile, xw); break;
+        default: xw_finish_pass<4>(S.q[b], S.segl[b], S.row0[b], S.va[b], S.vb[b], tile, xw); break;
         }
-        if (W & 1) t = fma(S.v1[b], xp[W - 1], t);
-#ifdef SPX_XW_ABL_NOADD
-        if (t == 1.2345e300 && row == 12345) atomicAdd(&tile[row], t);
-#else
-        if (S.segl[b] >> 16) atomicAdd(&tile[row], t);
-#endif
     }
 }
 
+// a unit pass of width 5..8 that reads LDS, on its own (not pipelined)
 template <int W>
-__device__ __forceinline__ void xw_single(const KernelArgs &a, const SpxRowBlock &rb, const PassWords &ps,
-                                          double *tile, const double *xw, int lane)
+__device__ __forceinline__ void xw_wide(const KernelArgs &a, const SpxRowBlock &rb, const PassWords &ps,
+                                        double *tile, const double *xw, int lane)
 {
-    XwStage<W, 1> S;
-    xw_issue<W, 1>(a, rb, {ps}, S, lane);
-    xw_finish<W, 1>(S, tile, xw);
+    const uint32_t nseg = ps.nseg();
+    const bool active = (uint32_t) lane < nseg;
+    const uint32_t l = active ? (uint32_t) lane : 0u;
+    const uint64_t mk = (ps.flags() & SPX_PASSF_INLINE) ? 0ull : ps.mask();
+    const uint32_t rank = ps.rank0() + (active ? starts_upto(mk, lane) : 0u);
+    const uint2 q = ld_stream(reinterpret_cast<const uint2 *>(a.descs + rb.desc_off + rank));
+    const double *vals = a.values + rb.val_off + ps.val_off();
+    double2 v2[W / 2];
+    double v1 = 0.0;
+#pragma unroll
+    for (int p = 0; p < W / 2; ++p)
+        v2[p] = ld_stream(reinterpret_cast<const double2 *>(vals + (uint32_t) p * 2u * nseg + l * 2u));
+    if (W & 1) v1 = ld_stream(vals + (uint32_t) (W / 2) * 2u * nseg + l);
+    const uint32_t bits = q.y;
+    const int s = (int) ((ps.seg0() + l - ((bits >> 9) & 8191u)) & 0xffffu);
+    const uint32_t kind = (bits >> 22) & 7u;
+    const int step = (int) (bits >> 25);
+    const int drow = kind == SPX_KIND_BLOCK ? 1 : (kind >= SPX_KIND_VERT ? step : 0);
+    const int dcol = (kind == SPX_KIND_HORIZ || kind == SPX_KIND_DIAG) ? step : (kind == SPX_KIND_ADIAG ? -step : 0);
+    const int row = (int) (ps.w[5] + (bits & 511u)) + s * drow;
+    const double *xp = xw + (int) (q.x + (uint32_t) (s * dcol));
+    double t = 0.0;
+#pragma unroll
+    for (int p = 0; p < W / 2; ++p) {
+        t = fma(v2[p].x, xp[2 * p], t);
+        t = fma(v2[p].y, xp[2 * p + 1], t);
+    }
+    if (W & 1) t = fma(v1, xp[W - 1], t);
+    if (active) atomicAdd(&tile[row], t);
 }
 
 // one pass of any kind on its own
@@ -150,93 +226,124 @@ __device__ __forceinline__ void xw_one(const KernelArgs &a, const SpxRowBlock &r
                                        double *tile, const double *win, const double *xw, int lane)
 {
     if (ps.kind() == SPX_PASS_UNIT && (ps.flags() & SPX_PASSF_XLDS)) {
+        if (ps.width() <= 4u) {
+            XwStage<1> S;
+            xw_issue<1>(a, rb, {ps}, S, lane);
+            xw_finish<1>(S, tile, xw);
+            return;
+        }
         switch (ps.width()) {            // wave-uniform
-        case 1: xw_single<1>(a, rb, ps, tile, xw, lane); break;
-        case 2: xw_single<2>(a, rb, ps, tile, xw, lane); break;
-        case 3: xw_single<3>(a, rb, ps, tile, xw, lane); break;
-        case 4: xw_single<4>(a, rb, ps, tile, xw, lane); break;
-        case 5: xw_single<5>(a, rb, ps, tile, xw, lane); break;
-        case 6: xw_single<6>(a, rb, ps, tile, xw, lane); break;
-        case 7: xw_single<7>(a, rb, ps, tile, xw, lane); break;
-        default: xw_single<8>(a, rb, ps, tile, xw, lane); break;
+        case 5: xw_wide<5>(a, rb, ps, tile, xw, lane); break;
+        case 6: xw_wide<6>(a, rb, ps, tile, xw, lane); break;
+        case 7: xw_wide<7>(a, rb, ps, tile, xw, lane); break;
+        default: xw_wide<8>(a, rb, ps, tile, xw, lane); break;
         }
     } else {
         run_pass(a, rb, ps.pass(), tile, win, lane);
     }
 }
 
-// Runs `n_rounds` >= 1 rounds t, t + 2 WAVES, ... -- pairs of unit passes of width W that read LDS, known
-// from the row-block's table, not from their headers -- as a two-stage pipeline.  On entry (c0, c1) are the
-// headers of round t and (n0, n1) those of the round after it; on return they are those of the first
-// round that was not run, `t` its first pass.
-// (A counted loop without a branch around any load: the compiler counts outstanding loads per path, and
-// with the loads of the next round under a condition -- "is there a next round" read from its headers --
-// it waited for every load before every use, which undid the pipeline.)
-template <int W, int WAVES>
-__device__ __forceinline__ void xw_run(const KernelArgs &a, const SpxRowBlock &rb, spx_const_words_t passes,
-                                       int n_rounds, int &t, PassWords &c0, PassWords &c1, PassWords &n0, PassWords &n1,
-                                       double *tile, const double *xw, int lane)
+// A wavefront takes the passes t, t + WAVES, t + 2 WAVES, ... of its row-block.  Those of them that lie in
+// the row-block's range [lo, hi) of narrow unit passes that read LDS (xwindows.hpp) run through the
+// pipeline, two to a round (an odd one out at the end shares its round with an empty pass): how many of
+// them follow from pass t on
+template <int WAVES>
+__device__ __forceinline__ int xw_in_range(int t, int lo, int hi)
 {
-    // (the headers of the round after next are requested AFTER the loads of the next round went out and
-    // are first looked at a whole round later: scalar loads complete out of order, so the wait in front of
-    // their first use is a wait for everything scalar in flight)
-#define SPX_XW_TAKE()                                                                             \
-    do {                                                                                          \
-        c0 = n0; c1 = n1;                                                                         \
-        t += 2 * WAVES;                                                                           \
-    } while (0)
-#define SPX_XW_FETCH()                                                                            \
-    do {                                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        n0 = load_pass(passes, t + 2 * WAVES); n1 = load_pass(passes, t + 3 * WAVES);             \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-    } while (0)
-    XwStage<W, 2> A, B;
-    xw_issue<W, 2>(a, rb, {c0, c1}, A, lane);
-    int r = 1;
-    for (; r + 1 < n_rounds; r += 2) {
-        SPX_XW_TAKE();
-        xw_issue<W, 2>(a, rb, {c0, c1}, B, lane);
-        SPX_XW_FETCH();
-        xw_finish<W, 2>(A, tile, xw);
-        SPX_XW_TAKE();
-        xw_issue<W, 2>(a, rb, {c0, c1}, A, lane);
-        SPX_XW_FETCH();
-        xw_finish<W, 2>(B, tile, xw);
-    }
-    if (r < n_rounds) {
-        SPX_XW_TAKE();
-        xw_issue<W, 2>(a, rb, {c0, c1}, B, lane);
-        SPX_XW_FETCH();
-        xw_finish<W, 2>(A, tile, xw);
-        xw_finish<W, 2>(B, tile, xw);
-    } else {
-        xw_finish<W, 2>(A, tile, xw);
-    }
-    SPX_XW_TAKE();
-    SPX_XW_FETCH();
-#undef SPX_XW_TAKE
-#undef SPX_XW_FETCH
+    return (t >= lo && t < hi) ? (hi - 1 - t) / WAVES + 1 : 0;
 }
 
-template <int WAVES>
+// Runs the `n_in` >= 1 passes t, t + WAVES, ... in rounds of two as a pipeline of D stages: D rounds are in
+// flight at any time -- the loads of round r + D go out as soon as the FMAs and LDS adds of round r have
+// freed its registers.  `st[0]` holds the loads of the first round, already issued.  On return t is the
+// wavefront's next pass.
+// (No branch around any load: the compiler counts outstanding loads per path, and with loads under a
+// condition -- "is there a next round" -- it waited for every load before every use, which undid the
+// pipeline.  Rounds that are not there run as empty rounds instead: no lanes, the addresses of the run's
+// first pass, so their six loads hit lines that are in the L1 anyway; a run ends with at most 2 D - 2 of
+// them.)
+template <int WAVES, int D>
+__device__ __forceinline__ void xw_run(const KernelArgs &a, const SpxRowBlock &rb, const uint32_t *hdr, int hi,
+                                       int n_in, int &t, XwStage<2> (&st)[D], double *tile, const double *xw, int lane)
+{
+    const int n_rounds = (n_in + 1) / 2, t0 = t;
+    // headers of round r (from LDS), or an empty round
+    auto headers = [&](int r, PassWords &c0, PassWords &c1) {
+        const bool there = r < n_rounds;
+        const int tt = there ? t0 + 2 * WAVES * r : t0;
+        c0 = lds_pass(hdr, tt);
+        c1 = lds_pass(hdr, tt + WAVES);
+        if (tt + WAVES >= hi) c1 = no_pass(c0);
+        if (!there) {
+            c0 = no_pass(c0);
+            c1 = c0;
+        }
+    };
+    PassWords c0, c1;
+#pragma unroll
+    for (int d = 1; d < D; ++d) {
+        headers(d, c0, c1);
+        xw_issue<2>(a, rb, {c0, c1}, st[d], lane);
+    }
+    for (int base = 0; base < n_rounds; base += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            xw_finish<2>(st[d], tile, xw);
+            headers(base + d + D, c0, c1);
+            xw_issue<2>(a, rb, {c0, c1}, st[d], lane);
+        }
+    }
+    t = t0 + n_in * WAVES;
+}
+
+#ifdef SPX_XW_PROFILE
+// (variant build: where a workgroup's life goes -- shader clock stamps of wavefront 0 of every workgroup of
+// the LAST launch, eight per row-block: [0] start, [1] row-block header there, [2] first barrier passed,
+// [3] its passes done, [4] second barrier passed, [5] end; written to a file by spmv_xw_profile)
+__device__ long long *spx_xw_prof_buf;
+static long long *g_prof_dev = nullptr;
+static size_t g_prof_rb = 0;
+#define SPX_XW_TICK(k)                                                                            \
+    do {                                                                                          \
+        if (threadIdx.x == 0 && spx_xw_prof_buf) spx_xw_prof_buf[(size_t) rb_idx * 8u + (k)] = clock64();   \
+    } while (0)
+#else
+#define SPX_XW_TICK(k) do { } while (0)
+#endif
+
+template <int WAVES, int D>
 __device__ __forceinline__ void spmv_body_xw(const KernelArgs &a, const XcdSplit &xs, double *lds)
 {
+#ifdef SPX_XW_PROFILE
+    const long long tick0_ = clock64();
+#endif
     constexpr int BLOCK_THREADS = 64 * WAVES;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t xcd = blockIdx.x & 7u;
     const uint32_t rb_idx = xs.first[xcd] + (blockIdx.x >> 3);
     if (rb_idx >= xs.first[xcd + 1u]) return;
+#ifdef SPX_XW_PROFILE
+    if (threadIdx.x == 0 && spx_xw_prof_buf) {
+        spx_xw_prof_buf[(size_t) rb_idx * 8u] = tick0_;
+        spx_xw_prof_buf[(size_t) rb_idx * 8u + 6u] = (long long) __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+        spx_xw_prof_buf[(size_t) rb_idx * 8u + 7u] = (long long) wall_clock64();
+    }
+#endif
 
-    spx_const_words_t passes = (spx_const_words_t) (uintptr_t) (a.passes + (size_t) rb_idx * a.pass_stride);
+    // first round trip: the row-block header, the table of its unit windows (one entry per lane; handed to
+    // the whole wavefront with v_readlane), the wavefront's first two pass headers (scalar), and -- on their
+    // way to LDS -- all pass headers of the row-block (pass_stride of them whatever the row-block uses:
+    // no need to wait for its header to know how many)
+    const SpxPass *pass0 = a.passes + (size_t) rb_idx * a.pass_stride;
+    spx_const_words_t passes = (spx_const_words_t) (uintptr_t) pass0;
     const SpxRowBlock rb = a.rbs[rb_idx];
-    // the window table of the row-block: one entry per lane (a single load; the entries are handed
-    // to the whole wavefront with v_readlane when their turn comes)
     const uint2 xw_entry = *reinterpret_cast<const uint2 *>(a.xw_tab + (size_t) rb_idx * XW_TAB + (lane & (XW_TAB - 1)));
     PassWords c0 = load_pass(passes, wave), c1 = load_pass(passes, wave + WAVES);       // (the table is padded)
-    PassWords n0 = load_pass(passes, wave + 2 * WAVES), n1 = load_pass(passes, wave + 3 * WAVES);
     const int n_rows = rb.n_rows;
+#ifdef SPX_XW_PROFILE
+    if (n_rows >= 0) SPX_XW_TICK(1);
+#endif
     double *tile = lds;
     for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS) lds[i] = 0.0;
     double *win = lds + n_rows;
@@ -249,6 +356,10 @@ __device__ __forceinline__ void spmv_body_xw(const KernelArgs &a, const XcdSplit
     // (global_load_lds_dwordx4: asynchronous, no registers; lane i's 16 bytes land at the wavefront's
     // LDS address + 16 i)
     double *xw = lds + ((n_rows + (int) rb.xwin_len + 1) & ~1);
+    const uint32_t range = (uint32_t) __builtin_amdgcn_readlane((int) xw_entry.x, 0);
+    const uint32_t xw_total = (uint32_t) __builtin_amdgcn_readlane((int) xw_entry.y, 0);
+    const int lo = (int) (range & 0xffffu), hi = (int) (range >> 16);
+    uint32_t *hdr = reinterpret_cast<uint32_t *>(xw + xw_total);
     uint32_t odd_base = 0, odd_at = 0xffffffffu;
 #ifndef SPX_XW_ABL_NOSTAGE
 #pragma unroll
@@ -270,47 +381,47 @@ __device__ __forceinline__ void spmv_body_xw(const KernelArgs &a, const XcdSplit
     }
 #endif
     if (odd_at != 0xffffffffu && threadIdx.x == 0) xw[odd_at] = a.x[odd_base];
-    __syncthreads();
-
-    // where the pipeline may run: per width 1..4 the passes [lo, hi) of the row-block that are unit passes of
-    // that width reading LDS (the first entries of the table)
-    const uint32_t range12_lo = (uint32_t) __builtin_amdgcn_readlane((int) xw_entry.x, 0);
-    const uint32_t range12_hi = (uint32_t) __builtin_amdgcn_readlane((int) xw_entry.y, 0);
-    const uint32_t range34_lo = (uint32_t) __builtin_amdgcn_readlane((int) xw_entry.x, 1);
-    const uint32_t range34_hi = (uint32_t) __builtin_amdgcn_readlane((int) xw_entry.y, 1);
+    // ... and the pass headers behind them, the same way: pass_stride + 4 WAVES of them (the table is padded),
+    // a kilobyte per wavefront and step
+    {
+        const uint32_t n_words = 6u * (a.pass_stride + 4u * (uint32_t) WAVES);
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(pass0);
+        for (uint32_t c = (uint32_t) wave * 256u; c < n_words; c += (uint32_t) WAVES * 256u) {
+            const uint32_t i = c + 4u * (uint32_t) lane;
+            if (i < n_words)
+                __builtin_amdgcn_global_load_lds(src + i, (__attribute__((address_space(3))) void *) (hdr + c), 16, 0, 0);
+        }
+    }
+    // the loads of the wavefront's first round go out in front of the barrier, next to the windows
     const int n_pass = rb.n_pass;
     int t = wave;
-    while (t < n_pass) {
-        // rounds from t on whose two passes both lie inside one of the ranges
-        int n_rounds = 0, width = 0;
-        {
-            const uint32_t rg[4] = {range12_lo, range12_hi, range34_lo, range34_hi};
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const int lo = (int) (rg[w] & 0xffffu), hi = (int) (rg[w] >> 16);
-                if (t >= lo && t + WAVES < hi) {
-                    n_rounds = (hi - 1 - WAVES - t) / (2 * WAVES) + 1;
-                    width = w + 1;
-                }
-            }
-        }
-        if (n_rounds > 0) {
-            switch (width) {        // wave-uniform
-            case 1: xw_run<1, WAVES>(a, rb, passes, n_rounds, t, c0, c1, n0, n1, tile, xw, lane); break;
-            case 2: xw_run<2, WAVES>(a, rb, passes, n_rounds, t, c0, c1, n0, n1, tile, xw, lane); break;
-            case 3: xw_run<3, WAVES>(a, rb, passes, n_rounds, t, c0, c1, n0, n1, tile, xw, lane); break;
-            default: xw_run<4, WAVES>(a, rb, passes, n_rounds, t, c0, c1, n0, n1, tile, xw, lane); break;
-            }
-            continue;
-        }
-        const bool two = t + WAVES < n_pass;
-        xw_one(a, rb, c0, tile, win, xw, lane);
-        if (two) xw_one(a, rb, c1, tile, win, xw, lane);
-        c0 = n0; c1 = n1;
-        n0 = load_pass(passes, t + 4 * WAVES); n1 = load_pass(passes, t + 5 * WAVES);
-        t += 2 * WAVES;
+    const int n_first = xw_in_range<WAVES>(t, lo, hi);
+    XwStage<2> st[D];
+    if (n_first > 0) {
+        if (t + WAVES >= hi) c1 = no_pass(c0);
+        xw_issue<2>(a, rb, {c0, c1}, st[0], lane);
     }
     __syncthreads();
+    SPX_XW_TICK(2);
+
+    if (n_first > 0) xw_run<WAVES, D>(a, rb, hdr, hi, n_first, t, st, tile, xw, lane);
+    while (t < n_pass) {
+        const int n_in = xw_in_range<WAVES>(t, lo, hi);
+        c0 = lds_pass(hdr, t);
+        c1 = lds_pass(hdr, t + WAVES);
+        if (n_in > 0) {
+            if (t + WAVES >= hi) c1 = no_pass(c0);
+            xw_issue<2>(a, rb, {c0, c1}, st[0], lane);
+            xw_run<WAVES, D>(a, rb, hdr, hi, n_in, t, st, tile, xw, lane);
+            continue;
+        }
+        xw_one(a, rb, c0, tile, win, xw, lane);
+        if (t + WAVES < n_pass) xw_one(a, rb, c1, tile, win, xw, lane);
+        t += 2 * WAVES;
+    }
+    SPX_XW_TICK(3);
+    __syncthreads();
+    SPX_XW_TICK(4);
 
     if (rb.flags & SPX_RB_SHARED) {
         if (threadIdx.x == 0) a.carry[rb.carry_slot] = tile[0];
@@ -322,41 +433,79 @@ __device__ __forceinline__ void spmv_body_xw(const KernelArgs &a, const XcdSplit
             a.y[g] = tt;
         }
     }
+    SPX_XW_TICK(5);
 }
 
-// the same product with the unit windows of x staged in LDS and the unit passes pipelined (spmv_body_xw)
-template <int WAVES>
+template <int WAVES, int D>
 __global__ __launch_bounds__(64 * WAVES)
 void csx_spmv_xw_kernel(SPX_KERNEL_PARAMS, const XwEntry *xw_tab_)
 {
     SPX_KERNEL_ARGS(a);
     a.xw_tab = xw_tab_;
-    extern __shared__ double lds_dyn[];      // y tile, the leftovers' x window, the unit windows
-    spmv_body_xw<WAVES>(a, xcd_split, lds_dyn);
+    extern __shared__ double lds_dyn[];      // y tile, the leftovers' x window, the unit windows, the pass headers
+    spmv_body_xw<WAVES, D>(a, xcd_split, lds_dyn);
 }
 
-void launch_spmv_xw(int waves, unsigned blocks, size_t lds_bytes, void *stream_, const KernelArgs &a,
+void launch_spmv_xw(int waves, int depth, unsigned blocks, size_t lds_bytes, void *stream_, const KernelArgs &a,
                     const XcdSplit &xs)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-#define SPX_LAUNCH_XW(W)                                                                           \
-    hipLaunchKernelGGL(csx_spmv_xw_kernel<W>, dim3(blocks), dim3(64 * W), lds_bytes, stream, a.rbs,  \
+#ifdef SPX_XW_PROFILE
+    if (getenv("SPX_XW_PROFILE_OUT") && g_prof_rb < a.n_rb) {
+        if (g_prof_dev) (void) hipFree(g_prof_dev);
+        g_prof_rb = a.n_rb;
+        (void) hipMalloc(reinterpret_cast<void **>(&g_prof_dev), g_prof_rb * 64);
+        (void) hipMemset(g_prof_dev, 0, g_prof_rb * 64);
+        (void) hipMemcpyToSymbol(HIP_SYMBOL(spx_xw_prof_buf), &g_prof_dev, sizeof(g_prof_dev));
+    }
+#endif
+#define SPX_LAUNCH_XW(W, DD)                                                                        \
+    hipLaunchKernelGGL((csx_spmv_xw_kernel<W, DD>), dim3(blocks), dim3(64 * W), lds_bytes, stream, a.rbs,  \
                        a.passes, a.n_rb, a.pass_stride, xs, a.values, a.descs, a.cidx, a.segrows,   \
                        a.x, a.y, a.carry, a.dvalues, a.spill, a.slot_col, a.alpha, a.beta,           \
                        a.dvalues_priv, a.beta_priv, a.xw_tab)
-    if (waves == 2) SPX_LAUNCH_XW(2);
-    else if (waves == 8) SPX_LAUNCH_XW(8);
-    else SPX_LAUNCH_XW(4);
+#define SPX_LAUNCH_XW_D(W)                                                                          \
+    do {                                                                                            \
+        if (depth >= 4) SPX_LAUNCH_XW(W, 4);                                                        \
+        else if (depth == 3) SPX_LAUNCH_XW(W, 3);                                                   \
+        else SPX_LAUNCH_XW(W, 2);                                                                   \
+    } while (0)
+    if (waves == 2) SPX_LAUNCH_XW_D(2);
+    else if (waves == 8) SPX_LAUNCH_XW_D(8);
+    else SPX_LAUNCH_XW_D(4);
+#undef SPX_LAUNCH_XW_D
 #undef SPX_LAUNCH_XW
+}
+
+// (variant build with -DSPX_XW_PROFILE: the stamps of the last launch go to the file SPX_XW_PROFILE_OUT names)
+bool spmv_xw_profile(unsigned long long out[8])
+{
+#ifdef SPX_XW_PROFILE
+    const char *path = getenv("SPX_XW_PROFILE_OUT");
+    if (!path || !g_prof_dev || hipDeviceSynchronize() != hipSuccess) return false;
+    std::vector<long long> h(g_prof_rb * 8);
+    if (hipMemcpy(h.data(), g_prof_dev, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    FILE *f = fopen(path, "wb");
+    if (!f) return false;
+    fwrite(h.data(), 8, h.size(), f);
+    fclose(f);
+    out[0] = g_prof_rb;
+    return true;
+#else
+    (void) out;
+    return false;
+#endif
 }
 
 // row-blocks whose windows need more than the default 64 KB of dynamic LDS
 void spmv_xw_allow_lds(size_t bytes)
 {
     const int b = (int) bytes;
-    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&csx_spmv_xw_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, b);
-    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&csx_spmv_xw_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, b);
-    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&csx_spmv_xw_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, b);
+#define SPX_XW_ATTR(W, DD) (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&csx_spmv_xw_kernel<W, DD>), hipFuncAttributeMaxDynamicSharedMemorySize, b)
+    SPX_XW_ATTR(2, 2); SPX_XW_ATTR(4, 2); SPX_XW_ATTR(8, 2);
+    SPX_XW_ATTR(2, 3); SPX_XW_ATTR(4, 3); SPX_XW_ATTR(8, 3);
+    SPX_XW_ATTR(2, 4); SPX_XW_ATTR(4, 4); SPX_XW_ATTR(8, 4);
+#undef SPX_XW_ATTR
 }
 
 }  // namespace spx

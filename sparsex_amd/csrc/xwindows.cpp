@@ -124,23 +124,20 @@ RbResult plan_rowblock(const GpuStream &s, size_t rb_idx, size_t ncols, uint32_t
             ps.mask = (uint64_t) d.col0 | ((uint64_t) d.bits << 32);
         }
     }
-    // the pass ranges of the pipeline: per width 1..4 the longest run of unit passes that read LDS
+    // the pass range of the pipeline: the longest run of unit passes of width <= 4 that read LDS
     {
-        uint32_t range[4] = {0u, 0u, 0u, 0u};
-        uint32_t t = 0;
+        uint32_t best_lo = 0, best_hi = 0, t = 0;
         while (t < rb.n_pass) {
-            const SpxPass &ps = px[t];
-            uint32_t e = t + 1;
-            if (ps.kind == SPX_PASS_UNIT && (ps.flags & SPX_PASSF_XLDS) && ps.width >= 1 && ps.width <= 4) {
-                while (e < rb.n_pass && px[e].kind == SPX_PASS_UNIT && (px[e].flags & SPX_PASSF_XLDS) && px[e].width == ps.width) ++e;
-                uint32_t &r = range[ps.width - 1];
-                if (e - t > (r >> 16) - (r & 0xffffu)) r = t | (e << 16);
-            }
-            t = e;
+            uint32_t e = t;
+            while (e < rb.n_pass && px[e].kind == SPX_PASS_UNIT && (px[e].flags & SPX_PASSF_XLDS) && px[e].width <= 4 &&
+                   px[e].nseg > 0)
+                ++e;
+            if (e - t > best_hi - best_lo) { best_lo = t; best_hi = e; }
+            t = e > t ? e : t + 1;
         }
         XwEntry *rg = plan.tab.data() + rb_idx * XW_TAB;
-        rg[0].base = range[0]; rg[0].off_len = range[1];
-        rg[1].base = range[2]; rg[1].off_len = range[3];
+        rg[0].base = best_lo | (best_hi << 16);
+        rg[0].off_len = at;
     }
     res.windows = true;
     res.total = at;
@@ -171,7 +168,7 @@ void plan_unit_xwindows(const GpuStream &s, size_t ncols, uint32_t budget, uint3
             const SpxRowBlock &rb = s.rbs[i];
             // y tile, leftover window, then (on an even offset) the unit windows
             const uint32_t front = ((uint32_t) rb.n_rows + rb.xwin_len + 1u) & ~1u;
-            lds_of[c] = std::max(lds_of[c], front + r.total);
+            lds_of[c] = std::max(lds_of[c], front + r.total + 3u * (s.pass_stride + 4u * 8u) + 8u);
             staged_of[c] += r.total;
             elems_of[c] += r.elems;
             if (r.windows) elems_lds_of[c] += r.elems;

@@ -12,12 +12,13 @@
 // quarter of the L1 requests.
 //
 // What the plan holds (all per device copy):
-//   tab      XW_TAB entries of 8 bytes per row-block.  The first XW_RANGES hold, for the widths W = 1..4,
-//            the passes [lo, hi) of the row-block (lo | hi << 16, four 32-bit words) that are unit passes
-//            of width W with SPX_PASSF_XLDS -- the longest run of them; the kernel pipelines pairs of
-//            passes inside these ranges without looking at their headers first.  Then XW_MAX windows:
-//            {first column, LDS offset | length << 16}; length 0 ends the list.  Offsets and lengths in
-//            doubles, offsets even (16-byte LDS stores); only the last window may have an odd length.
+//   tab      XW_TAB entries of 8 bytes per row-block.  Entry 0: {lo | hi << 16, total}: the passes [lo, hi)
+//            of the row-block are unit passes of width <= 4 with SPX_PASSF_XLDS (the longest run of
+//            them) -- the kernel runs them as a software pipeline without looking at their headers first
+//            -- and `total` is the length of the unit windows in doubles (the pass headers follow them in
+//            LDS); entry 1 is spare.  Then XW_MAX windows: {first column, LDS offset | length << 16};
+//            length 0 ends the list.  Offsets and lengths in doubles, offsets even (16-byte LDS stores);
+//            only the last window may have an odd length.
 //   xdescs   a copy of GpuStream::descs in which `col0` of every unit of a row-block WITH windows
 //            is the LDS offset (in doubles, from the start of the unit windows) of that column
 //   passes   a copy of GpuStream::passes: unit passes of such row-blocks carry SPX_PASSF_XLDS, and
@@ -47,7 +48,7 @@ struct XwPlan {
     std::vector<XwEntry> tab;              // rbs.size() * XW_TAB
     std::vector<SpxUnitDesc> xdescs;       // descs.size()
     std::vector<SpxPass> passes;           // passes.size()
-    uint32_t lds_doubles = 0;              // LDS of a launch: max over the row-blocks of y tile + leftover window + unit windows
+    uint32_t lds_doubles = 0;              // LDS of a launch: max over the row-blocks of y tile + leftover window + unit windows + pass headers
     size_t n_rb_windows = 0;               // row-blocks that got windows
     size_t n_rb_units = 0;                 // row-blocks that hold unit passes at all
     uint64_t staged_doubles = 0;           // doubles of x staged per product

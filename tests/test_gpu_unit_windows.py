@@ -35,6 +35,9 @@ OPTS = [
     {"spx.preproc.sampling": "none", "spx.gpu.unit_window_doubles": "600"},            # some row-blocks do not fit
     {"spx.preproc.sampling": "none", "spx.gpu.unit_window_gap": "0", "spx.gpu.stack_segments": "false"},
     {"spx.preproc.xform": "none"},                                                     # no mined units: leftovers only
+    # row-blocks joined from planned ones (their passes carry the first row of their part)
+    {"spx.gpu.rowblock_elems": "20000", "spx.gpu.rowblock_rows": "2048", "spx.gpu.unit_window_doubles": "12000"},
+    {"spx.preproc.sampling": "none", "spx.gpu.rowblock_elems": "1200", "spx.gpu.rowblock_rows": "1024", "spx.gpu.waves": "8"},
 ]
 
 

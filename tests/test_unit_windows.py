@@ -117,20 +117,20 @@ def test_windows_name_the_columns_of_the_stream(tmp_path, name, gen, opts, budge
         for t in range(int(rb["n_pass"])):
             if t not in unit:
                 assert ps_x[t] == ps_plain[t]
-        # the pass ranges of the pipeline: unit passes of that width that read LDS, nothing else
-        rg = [int(tab[bi, 0, 0]), int(tab[bi, 0, 1]), int(tab[bi, 1, 0]), int(tab[bi, 1, 1])]
-        for w, r in enumerate(rg):
-            a, b = r & 0xffff, r >> 16
-            assert a <= b <= int(rb["n_pass"])
-            for t in range(a, b):
-                assert ps_x[t]["kind"] == 0 and int(ps_x[t]["flags"]) & XLDS and int(ps_x[t]["width"]) == w + 1
-            # ... and the longest such run
-            runs, cur = [0], 0
-            for t in range(int(rb["n_pass"])):
-                ok = ps_x[t]["kind"] == 0 and int(ps_x[t]["flags"]) & XLDS and int(ps_x[t]["width"]) == w + 1
-                cur = cur + 1 if ok else 0
-                runs.append(cur)
-            assert b - a == max(runs)
+        # the pass range of the pipeline: unit passes of width <= 4 that read LDS, nothing else -- the longest
+        # such run -- and the length of the windows (the kernel puts the pass headers behind them)
+        r = int(tab[bi, 0, 0])
+        a, b = r & 0xffff, r >> 16
+        assert a <= b <= int(rb["n_pass"]) and int(tab[bi, 0, 1]) == total and not tab[bi, 1].any()
+        narrow = [bool(ps_x[t]["kind"] == 0 and int(ps_x[t]["flags"]) & XLDS and int(ps_x[t]["width"]) <= 4)
+                  for t in range(int(rb["n_pass"]))]
+        assert all(narrow[a:b])
+        runs, cur = [0], 0
+        for ok in narrow:
+            cur = cur + 1 if ok else 0
+            runs.append(cur)
+        assert b - a == max(runs)
+        assert front + total + 3 * (s.pass_stride + 32) <= plan["lds_doubles"]
     assert n_win == plan["rowblocks_with_windows"] and n_unit_rb == plan["rowblocks_with_units"]
     assert staged == plan["staged_doubles"] and elems == plan["unit_elems"] and elems_lds == plan["unit_elems_lds"]
     if name.startswith("nlpkkt") and budget >= 4096:
