@@ -82,6 +82,8 @@ struct GpuStream {
     // whether the product starts out using them (the launch tuner measures both)
     uint32_t xw_budget = 0, xw_gap = 16, xw_depth = 2;     // (xw_depth: rounds of unit passes in flight per wavefront)
     bool xw_on = false;
+    bool xwp = false;             // spx.gpu.persistent: persistent workgroups (csx_spmv_xwp_kernel) where the stream allows
+    uint32_t xwp_waves = 4, xwp_wgs = 0;   // ... wavefronts per workgroup (4 | 8), workgroups per CU (0: what the LDS allows)
     // accounting
     size_t nnz_stored = 0;        // nonzeros held in `values` (without padding)
     size_t n_unit_elems = 0;

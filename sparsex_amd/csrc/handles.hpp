@@ -92,6 +92,7 @@ struct matrix {
     uint32_t xw_budget = 4096, xw_gap = 16;   // spx.gpu.unit_window_doubles, spx.gpu.unit_window_gap
     int xw_depth = 2;           // spx.gpu.unit_window_depth: rounds in flight per wavefront (0 = measured)
     std::unique_ptr<spx::XwPlan> xw_inspect;    // what spx_hip_mat_unit_windows handed out last
+    std::unique_ptr<spx::XwpPlan> xwp_inspect;  // ... and spx_hip_mat_persistent_plan
     int device_ordinal = -1;
     std::vector<std::vector<idx_t>> spans;    // per partition and row: reach of its units
     std::vector<idx_t> max_span;              // per partition

@@ -38,6 +38,15 @@ OPTS = [
     # row-blocks joined from planned ones (their passes carry the first row of their part)
     {"spx.gpu.rowblock_elems": "20000", "spx.gpu.rowblock_rows": "2048", "spx.gpu.unit_window_doubles": "12000"},
     {"spx.preproc.sampling": "none", "spx.gpu.rowblock_elems": "1200", "spx.gpu.rowblock_rows": "1024", "spx.gpu.waves": "8"},
+    # persistent workgroups (csx_spmv_xwp_kernel): one list of rounds per wavefront over all its row-blocks
+    {"spx.gpu.persistent": "true"},
+    {"spx.preproc.sampling": "none", "spx.gpu.persistent": "true", "spx.gpu.unit_window_depth": "3"},
+    {"spx.preproc.sampling": "none", "spx.gpu.persistent": "true", "spx.gpu.persistent_waves": "8", "spx.gpu.unit_window_depth": "4"},
+    {"spx.preproc.sampling": "none", "spx.gpu.persistent": "true", "spx.gpu.rowblock_elems": "300", "spx.gpu.rowblock_rows": "7",
+     "spx.gpu.persistent_wgs": "1"},
+    {"spx.preproc.sampling": "none", "spx.gpu.persistent": "true", "spx.gpu.rowblock_elems": "1500", "spx.gpu.rowblock_rows": "1024",
+     "spx.gpu.persistent_wgs": "2", "spx.gpu.unit_window_depth": "4"},
+    {"spx.preproc.xform": "none", "spx.gpu.persistent": "true"},
 ]
 
 
