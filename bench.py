@@ -639,7 +639,8 @@ def kernel_name(info, symmetric, world):
     w = int(info.waves)
     tiles = int(info.sym_tiles)
     gen = "csx_spmv_det_kernel<%d> (a y tile per wavefront)" % w if int(info.wave_tiles) else (
-        "csx_spmv_quad_kernel<%d>" % w if int(info.quad) else "csx_spmv_kernel<%d>" % w)
+        "csx_spmv_xw_kernel<%d> (unit windows of x in LDS, %d KB per workgroup; unit passes pipelined)" % (
+            w, int(info.unit_window_lds) // 1024) if int(getattr(info, "unit_windows", 0)) else "csx_spmv_kernel<%d>" % w)
     if not symmetric:
         k = int(info.col_slices)
         if k > 1:

@@ -347,10 +347,8 @@ typedef struct {
     int32_t sym_segments;    /* the stream holds row segments of the lower triangle
                                 that are read once and used twice (SPX_PASS_SYMSEG):
                                 1 = next to dense tiles, 2 = and no tiles           */
-    int32_t quad;            /* (was reserved) general path, spx.gpu.persistent: 0, or the geometry of the
-                                persistent unit-window kernel in use: workgroups per XCD (bits 0-15) |
-                                wavefronts that run passes per workgroup << 16 | (1 << 24 where some
-                                passes stay outside its pipeline)                    */
+    int32_t quad;            /* reserved (0): round 3's kernel variant with four narrow unit
+                                passes side by side per wavefront is in use          */
     int32_t col_slices;      /* general path, spx.gpu.col_phases: K > 1 column slices in one
                                 launch (a group of XCDs each), -K: launched in turn, else 1 */
     int32_t unit_windows;    /* general path, spx.gpu.unit_windows: 1 = the product stages the columns
@@ -379,30 +377,6 @@ typedef struct {
     uint32_t lds_doubles;       /* LDS of a launch, doubles: y tile + leftover window + unit windows          */
 } spx_hip_xw_plan_t;
 spx_error_t spx_hip_mat_unit_windows(spx_matrix_t *A, uint32_t budget, uint32_t gap, spx_hip_xw_plan_t *plan);
-
-/* The round lists of the persistent form of that kernel (spx.gpu.persistent; csx_spmv_xwp_kernel) for a launch
- * of `wgs_per_xcd` workgroups per XCD with `waves` wavefronts each, the row-blocks dealt to the eight XCDs in
- * equal parts by count: the window plan (with the columns of the leftover passes taken into the windows where
- * they fit) and, per (workgroup, wavefront), its list of rounds -- for inspection and tests; works on host-only
- * matrices.  Layouts: sparsex_amd/csrc/xwindows.hpp (XwpRound: 16 words per round).  The arrays belong to the
- * matrix and live until the next call or spx_mat_destroy(). */
-typedef struct {
-    spx_hip_xw_plan_t windows;
-    const uint32_t *gather_base;   /* per pass header: first entry of its leftover descriptors, or 0xFFFFFFFF     */
-    const uint32_t *gdesc;         /* n_gdesc x {two LDS offsets (16 bits each), row | valid columns << 16}       */
-    size_t n_gdesc;
-    const uint32_t *rounds;        /* n_rounds x 16 words                                                         */
-    const uint64_t *list_start;    /* 8 * wgs_per_xcd * waves + 1: where the list of (workgroup b, wavefront w),
-                                      index b * waves + w, starts in `rounds`                                      */
-    const uint32_t *list_rounds;   /* ... and how many rounds it holds (empty rounds follow: tail_rounds of them) */
-    size_t n_rounds, n_lists;
-    uint32_t first[9];             /* row-blocks [first[x], first[x + 1]) belong to XCD x                          */
-    uint32_t tail_rounds, max_rows, max_window;
-    uint64_t generic_passes;       /* passes that stay outside the pipeline                                       */
-    int32_t usable;                /* 0: the persistent kernel is not for this stream                              */
-} spx_hip_xwp_plan_t;
-spx_error_t spx_hip_mat_persistent_plan(spx_matrix_t *A, uint32_t budget, uint32_t gap, uint32_t waves,
-                                        uint32_t wgs_per_xcd, spx_hip_xwp_plan_t *plan);
 /* The same for a caller compiled against another revision of this header: at most `size` bytes
  * (the caller's sizeof(spx_hip_info_t)) are written -- the struct only ever grows at its end.
  * spx_hip_mat_info() writes sizeof(spx_hip_info_t) of THIS header; SPX_HIP_ABI_VERSION changes

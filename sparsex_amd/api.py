@@ -62,14 +62,6 @@ class XwPlan(C.Structure):
                 ("lds_doubles", C.c_uint32)]
 
 
-class XwpPlan(C.Structure):
-    _fields_ = [("windows", XwPlan), ("gather_base", C.POINTER(C.c_uint32)), ("gdesc", C.POINTER(C.c_uint32)),
-                ("n_gdesc", C.c_size_t), ("rounds", C.POINTER(C.c_uint32)), ("list_start", C.POINTER(C.c_uint64)),
-                ("list_rounds", C.POINTER(C.c_uint32)), ("n_rounds", C.c_size_t), ("n_lists", C.c_size_t),
-                ("first", C.c_uint32 * 9), ("tail_rounds", C.c_uint32), ("max_rows", C.c_uint32),
-                ("max_window", C.c_uint32), ("generic_passes", C.c_uint64), ("usable", C.c_int32)]
-
-
 class CsxExport(C.Structure):
     _fields_ = [("values", C.POINTER(C.c_double)), ("ctl", C.POINTER(C.c_uint8)),
                 ("ctl_size", C.c_int64), ("nnz", C.c_int), ("ncols", C.c_int),
@@ -288,34 +280,6 @@ class Matrix:
             if pl.n_descs else np.zeros((0, 2), np.uint32)
         raw = C.string_at(pl.passes, pl.n_passes * 24) if pl.n_passes else b""
         out["passes"] = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 24).copy()
-        return out
-
-    def persistent_plan(self, budget=4096, gap=16, waves=4, wgs_per_xcd=2):
-        """The round lists of the persistent kernel (spx_hip_mat_persistent_plan) as numpy copies."""
-        pl = XwpPlan()
-        L = lib()
-        L.spx_hip_mat_persistent_plan.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(XwpPlan)]
-        if L.spx_hip_mat_persistent_plan(self.handle, budget, gap, waves, wgs_per_xcd, C.byref(pl)) != SPX_SUCCESS:
-            raise SpxError("spx_hip_mat_persistent_plan failed")
-        w = pl.windows
-
-        def arr(ptr, n, shape=None):
-            if not n:
-                return np.zeros(0 if shape is None else (0,) + shape[1:], np.uint32)
-            a = np.ctypeslib.as_array(ptr, shape=(n,)).copy()
-            return a if shape is None else a.reshape(shape)
-        out = {k: getattr(pl, k) for k in ("n_gdesc", "n_rounds", "n_lists", "tail_rounds", "max_rows", "max_window",
-                                           "generic_passes", "usable")}
-        out["first"] = list(pl.first)
-        out["tab"] = arr(w.tab, w.n_rowblocks * 32, (-1, 16, 2))
-        out["xdescs"] = arr(w.xdescs, w.n_descs * 2, (-1, 2))
-        raw = C.string_at(w.passes, w.n_passes * 24) if w.n_passes else b""
-        out["passes"] = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 24).copy()
-        out["gather_base"] = arr(pl.gather_base, w.n_passes)
-        out["gdesc"] = arr(pl.gdesc, pl.n_gdesc * 2, (-1, 2))
-        out["rounds"] = arr(pl.rounds, pl.n_rounds * 16, (-1, 16))
-        out["list_start"] = np.ctypeslib.as_array(pl.list_start, shape=(pl.n_lists + 1,)).copy()
-        out["list_rounds"] = arr(pl.list_rounds, pl.n_lists)
         return out
 
     def export_csx(self, part=0):

@@ -601,10 +601,6 @@ static void emit_and_upload(spx_matrix_t *A)
     gs.xw_budget = (A->unit_windows != 0 && !A->deterministic && !sym) ? A->xw_budget : 0u;
     gs.xw_gap = A->xw_gap;
     gs.xw_on = A->xw_on;
-    gs.xw_depth = (uint32_t) A->xw_depth;
-    gs.xwp = Config::instance().get_bool("spx.gpu.persistent");
-    gs.xwp_waves = (uint32_t) Config::instance().get_long("spx.gpu.persistent_waves");
-    gs.xwp_wgs = (uint32_t) std::max<long>(0, std::min<long>(8, Config::instance().get_long("spx.gpu.persistent_wgs")));
     gs.sym_atomic = A->sym_atomic && !A->deterministic;
     gs.deterministic = A->deterministic;
     gs.wave_tiles = A->deterministic || A->wave_tiles == 1;
@@ -997,12 +993,6 @@ static spx_matrix_t *do_tune(spx_input_t *in)
         }
         A->xw_budget = (uint32_t) xb;
         A->xw_gap = (uint32_t) xg;
-        const long xd = cfg.get_long("spx.gpu.unit_window_depth");
-        if (xd < 2 || xd > 4) {
-            log_msg(LOG_ERR, "spx.gpu.unit_window_depth: 2, 3 or 4\n");
-            throw FatalError("bad spx.gpu.unit_window_depth");
-        }
-        A->xw_depth = (int) xd;
     }
     A->unit_windows = xw_mode == "auto" ? -1 : (xw_mode == "true" ? 1 : 0);
     A->xw_on = xw_mode == "true";                       // (auto: off until measured)
@@ -2079,61 +2069,6 @@ spx_error_t spx_hip_mat_unit_windows(spx_matrix_t *A, uint32_t budget, uint32_t 
     return SPX_SUCCESS;
 }
 
-spx_error_t spx_hip_mat_persistent_plan(spx_matrix_t *A, uint32_t budget, uint32_t gap, uint32_t waves,
-                                        uint32_t wgs_per_xcd, spx_hip_xwp_plan_t *out)
-{
-    if (!A || !out || waves == 0 || wgs_per_xcd == 0) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid argument"); return SPX_FAILURE; }
-    const GpuStream *s = A->host_stream ? A->host_stream.get() : A->index.get();
-    if (!s) { SETERROR_1(SPX_ERR_TUNED_MAT, "matrix holds no descriptor stream"); return SPX_FAILURE; }
-    std::lock_guard<std::mutex> lk(A->mtx);
-    uint32_t first[9];
-    for (uint32_t x = 0; x <= 8; ++x) first[x] = (uint32_t) ((uint64_t) s->rbs.size() * x / 8u);
-    try {
-        std::unique_ptr<XwPlan> plan(new XwPlan);
-        std::unique_ptr<XwpPlan> pp(new XwpPlan);
-        plan_unit_xwindows(*s, (size_t) A->ncols, A->symmetric ? 0u : budget, gap, *plan, host_threads(), true);
-        plan_persistent_rounds(*s, *plan, first, waves, wgs_per_xcd, 16u, *pp, host_threads());
-        A->xw_inspect = std::move(plan);
-        A->xwp_inspect = std::move(pp);
-    } catch (const FatalError &e) {
-        SETERROR_1(SPX_ERR_TUNED_MAT, e.what.c_str());
-        return SPX_FAILURE;
-    } catch (const std::exception &e) {
-        SETERROR_1(SPX_ERR_MEM_ALLOC, e.what());
-        return SPX_FAILURE;
-    }
-    const XwPlan &p = *A->xw_inspect;
-    const XwpPlan &q = *A->xwp_inspect;
-    memset(out, 0, sizeof(*out));
-    out->windows.tab = reinterpret_cast<const uint32_t *>(p.tab.data());
-    out->windows.xdescs = reinterpret_cast<const uint32_t *>(p.xdescs.data());
-    out->windows.passes = p.passes.data();
-    out->windows.n_rowblocks = s->rbs.size();
-    out->windows.n_descs = p.xdescs.size();
-    out->windows.n_passes = p.passes.size();
-    out->windows.rowblocks_with_windows = p.n_rb_windows;
-    out->windows.rowblocks_with_units = p.n_rb_units;
-    out->windows.staged_doubles = p.staged_doubles;
-    out->windows.unit_elems = p.unit_elems;
-    out->windows.unit_elems_lds = p.unit_elems_lds;
-    out->windows.lds_doubles = p.lds_doubles;
-    out->gather_base = p.gather_base.data();
-    out->gdesc = p.gdesc.data();
-    out->n_gdesc = p.gdesc.size() / 2;
-    out->rounds = reinterpret_cast<const uint32_t *>(q.rounds.data());
-    out->list_start = q.stream_off.data();
-    out->list_rounds = q.stream_len.data();
-    out->n_rounds = q.rounds.size();
-    out->n_lists = q.stream_len.size();
-    for (int x = 0; x <= 8; ++x) out->first[x] = first[x];
-    out->tail_rounds = q.tail_rounds;
-    out->max_rows = q.max_rows;
-    out->max_window = q.max_window;
-    out->generic_passes = q.generic_passes;
-    out->usable = q.usable ? 1 : 0;
-    return SPX_SUCCESS;
-}
-
 spx_error_t spx_hip_mat_info_sized(const spx_matrix_t *A, void *info, size_t size)
 {
     spx_hip_info_t full;
@@ -2175,13 +2110,12 @@ spx_error_t spx_hip_mat_info(const spx_matrix_t *A, spx_hip_info_t *info)
     info->wave_tiles = A->dev ? (device_get_wave_tiles(A->dev) ? 1 : 0) : (A->wave_tiles == 1 || A->deterministic ? 1 : 0);
     info->sym_segments = A->has_symsegs ? (A->has_symtiles ? 1 : 2) : 0;
     info->col_slices = A->col_phases > 1 ? (A->col_concurrent ? (int32_t) A->col_phases : -(int32_t) A->col_phases) : 1;
-    info->quad = 0;
+    info->quad = 0;                  // (reserved: the four-pass kernel variant of round 3 is gone)
     if (A->dev && device_has_xw(A->dev)) {
         uint64_t el = 0, ue = 0, st = 0;
         uint32_t lds = 0;
         device_xw_info(A->dev, el, ue, st, lds);
         info->unit_windows = device_get_xw(A->dev) ? 1 : 0;
-        info->quad = (int32_t) device_get_xwp(A->dev);     // (persistent workgroups: geometry, see sparsex_hip.h)
         info->unit_window_lds = (int32_t) lds;
         info->unit_window_elems = (int64_t) el;
         info->unit_window_staged = (int64_t) st;

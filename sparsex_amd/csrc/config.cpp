@@ -66,12 +66,8 @@ void Config::reset_defaults()
     props_["spx.gpu.sym_spill"] = "auto";      // symmetric tiles' transposed sums: lists | atomic | auto (measured)
     props_["spx.gpu.sym_remine"] = "true";     // symmetric: re-cut the mirrored triangle into row segments
     props_["spx.gpu.unit_windows"] = "auto";   // general path: the columns of a row-block's unit passes staged in LDS, unit passes pipelined: true | false | auto (measured)
-    props_["spx.gpu.unit_window_doubles"] = "4096";  // ... most doubles of x a row-block may stage for them
+    props_["spx.gpu.unit_window_doubles"] = "3072";  // ... most doubles of x a row-block may stage for them
     props_["spx.gpu.unit_window_gap"] = "16";  // ... column intervals closer than this are staged as one
-    props_["spx.gpu.persistent"] = "false";    // ... with persistent workgroups: every wavefront runs one list of rounds over all its row-blocks
-    props_["spx.gpu.persistent_waves"] = "4";  // ... wavefronts per persistent workgroup: 4 or 8
-    props_["spx.gpu.persistent_wgs"] = "0";    // ... persistent workgroups per CU (0: as many as the LDS allows, at most 4)
-    props_["spx.gpu.unit_window_depth"] = "2"; // ... rounds (pairs of unit passes) a wavefront keeps in flight: 2, 3 or 4
 }
 
 bool Config::set(const std::string &key, const std::string &value)

@@ -86,9 +86,6 @@ int device_get_waves(const DeviceMatrix *m);
 bool device_has_xw(const DeviceMatrix *m);
 void device_set_xw(DeviceMatrix *m, bool on);
 bool device_get_xw(const DeviceMatrix *m);
-uint32_t device_get_xwp(const DeviceMatrix *m);            // persistent workgroups in use: see spmv_kernels.hip
-void device_set_xw_depth(DeviceMatrix *m, int depth);      // rounds of unit passes in flight per wavefront: 2, 3 or 4
-int device_get_xw_depth(const DeviceMatrix *m);
 void device_xw_info(const DeviceMatrix *m, uint64_t &elems_lds, uint64_t &unit_elems, uint64_t &staged_doubles,
                     uint32_t &lds_bytes);
 

@@ -80,10 +80,8 @@ struct GpuStream {
     // spx.gpu.unit_windows (device side only, xwindows.hpp): most doubles of x a row-block may stage in
     // LDS for its unit passes (0: none planned), intervals closer than `xw_gap` doubles are merged, and
     // whether the product starts out using them (the launch tuner measures both)
-    uint32_t xw_budget = 0, xw_gap = 16, xw_depth = 2;     // (xw_depth: rounds of unit passes in flight per wavefront)
+    uint32_t xw_budget = 0, xw_gap = 16;
     bool xw_on = false;
-    bool xwp = false;             // spx.gpu.persistent: persistent workgroups (csx_spmv_xwp_kernel) where the stream allows
-    uint32_t xwp_waves = 4, xwp_wgs = 0;   // ... wavefronts per workgroup (4 | 8), workgroups per CU (0: what the LDS allows)
     // accounting
     size_t nnz_stored = 0;        // nonzeros held in `values` (without padding)
     size_t n_unit_elems = 0;

@@ -89,10 +89,8 @@ struct matrix {
     int wave_tiles = -1;        // per-wavefront y tiles: 1 / 0, -1 = measured at tune time (spx.gpu.wave_tiles)
     int unit_windows = -1;      // spx.gpu.unit_windows: 1 / 0, -1 = measured at tune time
     bool xw_on = false;         // ... the product runs with the unit windows of x in LDS (csx_spmv_xw_kernel)
-    uint32_t xw_budget = 4096, xw_gap = 16;   // spx.gpu.unit_window_doubles, spx.gpu.unit_window_gap
-    int xw_depth = 2;           // spx.gpu.unit_window_depth: rounds in flight per wavefront (0 = measured)
+    uint32_t xw_budget = 3072, xw_gap = 16;   // spx.gpu.unit_window_doubles, spx.gpu.unit_window_gap
     std::unique_ptr<spx::XwPlan> xw_inspect;    // what spx_hip_mat_unit_windows handed out last
-    std::unique_ptr<spx::XwpPlan> xwp_inspect;  // ... and spx_hip_mat_persistent_plan
     int device_ordinal = -1;
     std::vector<std::vector<idx_t>> spans;    // per partition and row: reach of its units
     std::vector<idx_t> max_span;              // per partition

@@ -35,16 +35,8 @@
 namespace spx {
 
 // spmv_xw_kernels.hip
-void launch_spmv_xw(int waves, int depth, unsigned blocks, size_t lds_bytes, void *stream, const KernelArgs &a, const XcdSplit &xs);
+void launch_spmv_xw(int waves, unsigned blocks, size_t lds_bytes, void *stream, const KernelArgs &a, const XcdSplit &xs);
 void spmv_xw_allow_lds(size_t bytes);
-// spmv_xwp_kernels.hip (the argument block is defined there; built here through xwp_launch)
-void xwp_launch(int waves, int depth, unsigned blocks, size_t lds_bytes, void *stream, const SpxRowBlock *rbs,
-                const SpxPass *passes, const double *values, const SpxUnitDesc *descs, const uint8_t *cidx,
-                const uint16_t *segrows, const double *x, double *y, const XwEntry *xw_tab,
-                const XwpRound *rounds, const uint64_t *stream_off, const uint32_t *stream_len, double alpha, double beta,
-                const uint32_t first[9], uint32_t wgs_per_xcd, uint32_t pass_stride, uint32_t region, uint32_t tile_rows,
-                bool generic);
-void spmv_xwp_allow_lds(size_t bytes);
 
 #define HIP_CHECK(expr)                                                         \
     do {                                                                        \
@@ -690,16 +682,6 @@ struct DeviceMatrix {
     uint32_t lds_doubles_xw = 0;
     uint32_t xw_budget = 0, xw_gap = 0;   // as the stream was uploaded (kept for spx_mat_save)
     bool xw_on = false;           // the product runs through csx_spmv_xw_kernel
-    int xw_depth = 2;             // ... rounds in flight per wavefront (2, 3 or 4)
-    // ... or, with persistent workgroups (csx_spmv_xwp_kernel): the precompiled round lists and the launch
-    // geometry they were laid out for
-    XwpRound *xwp_rounds = nullptr;
-    uint64_t *xwp_off = nullptr;
-    uint32_t *xwp_len = nullptr;
-    bool xwp_on = false, xwp_generic = true;
-    int xwp_waves = 4;
-    uint32_t xwp_wgs_per_xcd = 0, xwp_region = 0, xwp_tile_rows = 0;
-    size_t xwp_rounds_n = 0;
     uint64_t xw_elems = 0, xw_unit_elems = 0, xw_staged = 0;
     size_t xw_rowblocks = 0;
 };
@@ -986,7 +968,7 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
         !s.rbs.empty()) {
         try {
             XwPlan plan;
-            plan_unit_xwindows(s, ncols, s.xw_budget, s.xw_gap, plan, host_threads(), s.xwp);
+            plan_unit_xwindows(s, ncols, s.xw_budget, s.xw_gap, plan, host_threads());
             if (plan.n_rb_windows) {
                 auto up = [&](auto **dst, const auto &v, size_t slack) {
                     typedef typename std::remove_reference<decltype(v[0])>::type T;
@@ -996,12 +978,7 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
                     HIP_CHECK(hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
                 };
                 up(&m->passes_xw, plan.passes, (size_t) s.pass_stride + 6 * MAX_WAVES_PER_BLOCK);
-                {
-                    // (the descriptors of the leftover halves of the persistent kernel follow the unit descriptors)
-                    std::vector<SpxUnitDesc> all = plan.xdescs;
-                    for (size_t k = 0; k + 1 < plan.gdesc.size(); k += 2) all.push_back(SpxUnitDesc{plan.gdesc[k], plan.gdesc[k + 1]});
-                    up(&m->xdescs, all, 8);
-                }
+                up(&m->xdescs, plan.xdescs, 8);
                 up(&m->xw_tab, plan.tab, 0);
                 m->lds_doubles_xw = plan.lds_doubles;
                 m->xw_elems = plan.unit_elems_lds;
@@ -1009,47 +986,7 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
                 m->xw_staged = plan.staged_doubles;
                 m->xw_rowblocks = plan.n_rb_windows;
                 m->xw_on = s.xw_on;
-                m->xw_depth = s.xw_depth < 2 ? 2 : (s.xw_depth > 4 ? 4 : (int) s.xw_depth);
                 if ((size_t) m->lds_doubles_xw * sizeof(double) > 64u * 1024u) spmv_xw_allow_lds(160u * 1024u);
-                // persistent workgroups: the round lists for the geometry the LDS allows
-                if (s.xwp) {
-                    XwpPlan pp;
-                    // (region sizes first: a plan with one workgroup per XCD tells the largest tile and windows)
-                    uint32_t max_rows = 0, max_window = 0;
-                    for (size_t i = 0; i < s.rbs.size(); ++i) {
-                        max_rows = std::max<uint32_t>(max_rows, s.rbs[i].n_rows);
-                        max_window = std::max(max_window, plan.tab[i * XW_TAB].off_len);
-                    }
-                    const uint32_t tile_rows = (max_rows + 1u) & ~1u, region = tile_rows + ((max_window + 1u) & ~1u) + 8u;
-                    const size_t lds_bytes = 2u * (size_t) region * sizeof(double);
-                    const int waves = (s.xwp_waves == 8 || s.xwp_waves == 7 || s.xwp_waves == 3) ? (int) s.xwp_waves : 4;
-                    int cus = 256;
-                    {
-                        hipDeviceProp_t prop;
-                        if (hipGetDeviceProperties(&prop, m->device) == hipSuccess && prop.multiProcessorCount >= 8) cus = prop.multiProcessorCount;
-                    }
-                    uint32_t per_cu = (uint32_t) std::max<size_t>(1, std::min<size_t>(waves >= 7 ? 2 : 4, (160u * 1024u) / lds_bytes));
-                    if (s.xwp_wgs) per_cu = s.xwp_wgs;
-                    const uint32_t G = (uint32_t) (cus / 8) * per_cu;
-                    plan_persistent_rounds(s, plan, m->xcd_split[0].first, (uint32_t) waves, G, 16u, pp, host_threads());
-                    if (pp.usable && lds_bytes <= 160u * 1024u) {
-                        up(&m->xwp_rounds, pp.rounds, 0);
-                        up(&m->xwp_off, pp.stream_off, 0);
-                        up(&m->xwp_len, pp.stream_len, 0);
-                        m->xwp_rounds_n = pp.rounds.size();
-                        m->xwp_on = true;
-                        m->xwp_generic = pp.generic_passes != 0;
-                        m->xwp_waves = waves;
-                        m->xwp_wgs_per_xcd = G;
-                        m->xwp_region = region;
-                        m->xwp_tile_rows = tile_rows;
-                        spmv_xwp_allow_lds(160u * 1024u);
-                        log_msg(LOG_INFO, "persistent workgroups: %u per XCD of %d wavefronts, %zu KB of LDS each, %zu rounds, %llu passes outside the pipeline\n",
-                                G, waves, lds_bytes / 1024u, pp.rounds.size(), (unsigned long long) pp.generic_passes);
-                    } else {
-                        log_msg(LOG_INFO, "persistent workgroups: not for this stream\n");
-                    }
-                }
                 log_msg(LOG_INFO, "unit windows: %zu of %zu row-blocks, %.1f %% of the unit nonzeros read x from LDS, "
                         "%.2f doubles staged per such nonzero, %u KB of LDS per workgroup\n", plan.n_rb_windows, plan.n_rb_units,
                         100.0 * (double) plan.unit_elems_lds / (double) std::max<uint64_t>(plan.unit_elems, 1),
@@ -1090,9 +1027,6 @@ void device_free(DeviceMatrix *m)
     if (m->passes_xw) (void) hipFree(m->passes_xw);
     if (m->xdescs) (void) hipFree(m->xdescs);
     if (m->xw_tab) (void) hipFree(m->xw_tab);
-    if (m->xwp_rounds) (void) hipFree(m->xwp_rounds);
-    if (m->xwp_off) (void) hipFree(m->xwp_off);
-    if (m->xwp_len) (void) hipFree(m->xwp_len);
     if (m->d_x) (void) hipFree(m->d_x);
     if (m->d_y) (void) hipFree(m->d_y);
     if (m->p_x) (void) hipHostFree(m->p_x);
@@ -1227,17 +1161,12 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
             if (m->waves == 2) SPX_LAUNCH(csx_spmv_accum_kernel, 2, lds);
             else if (m->waves == 8) SPX_LAUNCH(csx_spmv_accum_kernel, 8, lds);
             else SPX_LAUNCH(csx_spmv_accum_kernel, 4, lds);
-        } else if (blocks && m->xw_on && m->xwp_on && m->xwp_rounds) {
-            xwp_launch(m->xwp_waves, m->xw_depth, 8u * m->xwp_wgs_per_xcd, 2u * (size_t) m->xwp_region * sizeof(double), stream,
-                       m->rbs, m->passes_xw, m->values, m->xdescs, m->cidx, m->segrows, d_x, d_y, m->xw_tab, m->xwp_rounds,
-                       m->xwp_off, m->xwp_len, a.alpha, a.beta, xcd_now.first, m->xwp_wgs_per_xcd, m->pass_stride,
-                       m->xwp_region, m->xwp_tile_rows, m->xwp_generic);
         } else if (blocks && m->xw_on && m->passes_xw) {
             KernelArgs ax = a;
             ax.passes = m->passes_xw;
             ax.descs = m->xdescs;
             ax.xw_tab = m->xw_tab;
-            launch_spmv_xw(m->waves, m->xw_depth, blocks, (size_t) m->lds_doubles_xw * sizeof(double), stream, ax, xcd_now);
+            launch_spmv_xw(m->waves, blocks, (size_t) m->lds_doubles_xw * sizeof(double), stream, ax, xcd_now);
         } else if (blocks) {
             const size_t lds = m->lds_doubles * sizeof(double);
             if (m->waves == 2) SPX_LAUNCH(csx_spmv_kernel, 2, lds);
@@ -1336,7 +1265,7 @@ void device_spmv_chunk(DeviceMatrix *m, size_t k, double alpha, const double *d_
         ax.cidx = m->cidx; ax.segrows = m->segrows; ax.x = d_x; ax.y = d_y; ax.carry = m->carry;
         ax.alpha = alpha; ax.beta = beta; ax.n_rb = m->n_rb; ax.pass_stride = m->pass_stride;
         ax.xw_tab = m->xw_tab;
-        launch_spmv_xw(m->waves, m->xw_depth, blocks, (size_t) m->lds_doubles_xw * sizeof(double), stream, ax, xs);
+        launch_spmv_xw(m->waves, blocks, (size_t) m->lds_doubles_xw * sizeof(double), stream, ax, xs);
     }
     else if (m->waves == 2) SPX_LAUNCH_CHUNK(2);
     else if (m->waves == 8) SPX_LAUNCH_CHUNK(8);
@@ -1400,15 +1329,7 @@ void device_set_waves(DeviceMatrix *m, int waves)
 int device_get_waves(const DeviceMatrix *m) { return m->waves; }
 
 bool device_has_xw(const DeviceMatrix *m) { return m->passes_xw != nullptr; }
-// 0: not persistent; else workgroups per XCD | wavefronts << 16 | (passes outside the pipeline ? 1 << 24 : 0)
-uint32_t device_get_xwp(const DeviceMatrix *m)
-{
-    if (!(m->xw_on && m->xwp_on && m->xwp_rounds && !m->wave_tiles)) return 0;
-    return m->xwp_wgs_per_xcd | ((uint32_t) m->xwp_waves << 16) | (m->xwp_generic ? 1u << 24 : 0u);
-}
 void device_set_xw(DeviceMatrix *m, bool on) { m->xw_on = on && m->passes_xw && !m->wave_tiles; }
-void device_set_xw_depth(DeviceMatrix *m, int depth) { m->xw_depth = depth < 2 ? 2 : (depth > 4 ? 4 : depth); }
-int device_get_xw_depth(const DeviceMatrix *m) { return m->xw_depth; }
 bool device_get_xw(const DeviceMatrix *m) { return m->xw_on && m->passes_xw && !m->wave_tiles; }
 void device_xw_info(const DeviceMatrix *m, uint64_t &elems_lds, uint64_t &unit_elems, uint64_t &staged, uint32_t &lds_bytes)
 {
@@ -1630,7 +1551,6 @@ void device_download(const DeviceMatrix *m, GpuStream &s)
     s.xw_on = device_get_xw(m);
     s.xw_budget = m->xw_budget;
     s.xw_gap = m->xw_gap;
-    s.xw_depth = (uint32_t) m->xw_depth;
     if (m->n_spill) download(s.slot_group_col, m->slot_col, m->n_slot_col);
     if (m->n_spill) {
         download(s.fix_ptr, m->fix_ptr, m->n_fix_ptr);

@@ -253,47 +253,48 @@ __device__ __forceinline__ int xw_in_range(int t, int lo, int hi)
     return (t >= lo && t < hi) ? (hi - 1 - t) / WAVES + 1 : 0;
 }
 
-// Runs the `n_in` >= 1 passes t, t + WAVES, ... in rounds of two as a pipeline of D stages: D rounds are in
-// flight at any time -- the loads of round r + D go out as soon as the FMAs and LDS adds of round r have
-// freed its registers.  `st[0]` holds the loads of the first round, already issued.  On return t is the
-// wavefront's next pass.
-// (No branch around any load: the compiler counts outstanding loads per path, and with loads under a
-// condition -- "is there a next round" -- it waited for every load before every use, which undid the
-// pipeline.  Rounds that are not there run as empty rounds instead: no lanes, the addresses of the run's
-// first pass, so their six loads hit lines that are in the L1 anyway; a run ends with at most 2 D - 2 of
-// them.)
-template <int WAVES, int D>
+// Runs the `n_in` >= 1 passes t, t + WAVES, ... in rounds of two as a two-stage pipeline: the loads of the
+// next round go out before the FMAs and LDS adds of the current one.  `A` holds the loads of the first
+// round, already issued.  On return t is the wavefront's next pass.
+// (A counted loop without a branch around any load: the compiler counts outstanding loads per path, and
+// with the loads of the next round under a condition it waited for every load before every use, which
+// undid the pipeline.  Deeper pipelines were measured -- three and four rounds in flight, with empty rounds
+// at the ends so that no load sits under a branch: slower on the five rounds a wavefront has per row-block,
+// and what they gain in flight they lose in wavefronts per SIMD: profiles/r05/ablation.md.)
+template <int WAVES>
 __device__ __forceinline__ void xw_run(const KernelArgs &a, const SpxRowBlock &rb, const uint32_t *hdr, int hi,
-                                       int n_in, int &t, XwStage<2> (&st)[D], double *tile, const double *xw, int lane)
+                                       int n_in, int &t, XwStage<2> &A, double *tile, const double *xw, int lane)
 {
-    const int n_rounds = (n_in + 1) / 2, t0 = t;
-    // headers of round r (from LDS), or an empty round
-    auto headers = [&](int r, PassWords &c0, PassWords &c1) {
-        const bool there = r < n_rounds;
-        const int tt = there ? t0 + 2 * WAVES * r : t0;
-        c0 = lds_pass(hdr, tt);
-        c1 = lds_pass(hdr, tt + WAVES);
-        if (tt + WAVES >= hi) c1 = no_pass(c0);
-        if (!there) {
-            c0 = no_pass(c0);
-            c1 = c0;
-        }
-    };
+    XwStage<2> B;
     PassWords c0, c1;
-#pragma unroll
-    for (int d = 1; d < D; ++d) {
-        headers(d, c0, c1);
-        xw_issue<2>(a, rb, {c0, c1}, st[d], lane);
+    const int n_rounds = (n_in + 1) / 2, t_end = t + n_in * WAVES;
+    // (headers of the next round: read from LDS while the current round's second half runs)
+#define SPX_XW_HEADERS()                                                                          \
+    do {                                                                                          \
+        t += 2 * WAVES;                                                                           \
+        c0 = lds_pass(hdr, t);                                                                    \
+        c1 = lds_pass(hdr, t + WAVES);                                                            \
+        if (t + WAVES >= hi) c1 = no_pass(c0);                                                    \
+    } while (0)
+    int r = 1;
+    for (; r + 1 < n_rounds; r += 2) {
+        SPX_XW_HEADERS();
+        xw_issue<2>(a, rb, {c0, c1}, B, lane);
+        xw_finish<2>(A, tile, xw);
+        SPX_XW_HEADERS();
+        xw_issue<2>(a, rb, {c0, c1}, A, lane);
+        xw_finish<2>(B, tile, xw);
     }
-    for (int base = 0; base < n_rounds; base += D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            xw_finish<2>(st[d], tile, xw);
-            headers(base + d + D, c0, c1);
-            xw_issue<2>(a, rb, {c0, c1}, st[d], lane);
-        }
+    if (r < n_rounds) {
+        SPX_XW_HEADERS();
+        xw_issue<2>(a, rb, {c0, c1}, B, lane);
+        xw_finish<2>(A, tile, xw);
+        xw_finish<2>(B, tile, xw);
+    } else {
+        xw_finish<2>(A, tile, xw);
     }
-    t = t0 + n_in * WAVES;
+    t = t_end;
+#undef SPX_XW_HEADERS
 }
 
 #ifdef SPX_XW_PROFILE
@@ -311,7 +312,7 @@ static size_t g_prof_rb = 0;
 #define SPX_XW_TICK(k) do { } while (0)
 #endif
 
-template <int WAVES, int D>
+template <int WAVES>
 __device__ __forceinline__ void spmv_body_xw(const KernelArgs &a, const XcdSplit &xs, double *lds)
 {
 #ifdef SPX_XW_PROFILE
@@ -396,23 +397,23 @@ __device__ __forceinline__ void spmv_body_xw(const KernelArgs &a, const XcdSplit
     const int n_pass = rb.n_pass;
     int t = wave;
     const int n_first = xw_in_range<WAVES>(t, lo, hi);
-    XwStage<2> st[D];
+    XwStage<2> A;
     if (n_first > 0) {
         if (t + WAVES >= hi) c1 = no_pass(c0);
-        xw_issue<2>(a, rb, {c0, c1}, st[0], lane);
+        xw_issue<2>(a, rb, {c0, c1}, A, lane);
     }
     __syncthreads();
     SPX_XW_TICK(2);
 
-    if (n_first > 0) xw_run<WAVES, D>(a, rb, hdr, hi, n_first, t, st, tile, xw, lane);
+    if (n_first > 0) xw_run<WAVES>(a, rb, hdr, hi, n_first, t, A, tile, xw, lane);
     while (t < n_pass) {
         const int n_in = xw_in_range<WAVES>(t, lo, hi);
         c0 = lds_pass(hdr, t);
         c1 = lds_pass(hdr, t + WAVES);
         if (n_in > 0) {
             if (t + WAVES >= hi) c1 = no_pass(c0);
-            xw_issue<2>(a, rb, {c0, c1}, st[0], lane);
-            xw_run<WAVES, D>(a, rb, hdr, hi, n_in, t, st, tile, xw, lane);
+            xw_issue<2>(a, rb, {c0, c1}, A, lane);
+            xw_run<WAVES>(a, rb, hdr, hi, n_in, t, A, tile, xw, lane);
             continue;
         }
         xw_one(a, rb, c0, tile, win, xw, lane);
@@ -436,18 +437,17 @@ __device__ __forceinline__ void spmv_body_xw(const KernelArgs &a, const XcdSplit
     SPX_XW_TICK(5);
 }
 
-template <int WAVES, int D>
+template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES)
 void csx_spmv_xw_kernel(SPX_KERNEL_PARAMS, const XwEntry *xw_tab_)
 {
     SPX_KERNEL_ARGS(a);
     a.xw_tab = xw_tab_;
     extern __shared__ double lds_dyn[];      // y tile, the leftovers' x window, the unit windows, the pass headers
-    spmv_body_xw<WAVES, D>(a, xcd_split, lds_dyn);
+    spmv_body_xw<WAVES>(a, xcd_split, lds_dyn);
 }
 
-void launch_spmv_xw(int waves, int depth, unsigned blocks, size_t lds_bytes, void *stream_, const KernelArgs &a,
-                    const XcdSplit &xs)
+void launch_spmv_xw(int waves, unsigned blocks, size_t lds_bytes, void *stream_, const KernelArgs &a, const XcdSplit &xs)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
 #ifdef SPX_XW_PROFILE
@@ -459,21 +459,14 @@ void launch_spmv_xw(int waves, int depth, unsigned blocks, size_t lds_bytes, voi
         (void) hipMemcpyToSymbol(HIP_SYMBOL(spx_xw_prof_buf), &g_prof_dev, sizeof(g_prof_dev));
     }
 #endif
-#define SPX_LAUNCH_XW(W, DD)                                                                        \
-    hipLaunchKernelGGL((csx_spmv_xw_kernel<W, DD>), dim3(blocks), dim3(64 * W), lds_bytes, stream, a.rbs,  \
+#define SPX_LAUNCH_XW(W)                                                                           \
+    hipLaunchKernelGGL(csx_spmv_xw_kernel<W>, dim3(blocks), dim3(64 * W), lds_bytes, stream, a.rbs,  \
                        a.passes, a.n_rb, a.pass_stride, xs, a.values, a.descs, a.cidx, a.segrows,   \
                        a.x, a.y, a.carry, a.dvalues, a.spill, a.slot_col, a.alpha, a.beta,           \
                        a.dvalues_priv, a.beta_priv, a.xw_tab)
-#define SPX_LAUNCH_XW_D(W)                                                                          \
-    do {                                                                                            \
-        if (depth >= 4) SPX_LAUNCH_XW(W, 4);                                                        \
-        else if (depth == 3) SPX_LAUNCH_XW(W, 3);                                                   \
-        else SPX_LAUNCH_XW(W, 2);                                                                   \
-    } while (0)
-    if (waves == 2) SPX_LAUNCH_XW_D(2);
-    else if (waves == 8) SPX_LAUNCH_XW_D(8);
-    else SPX_LAUNCH_XW_D(4);
-#undef SPX_LAUNCH_XW_D
+    if (waves == 2) SPX_LAUNCH_XW(2);
+    else if (waves == 8) SPX_LAUNCH_XW(8);
+    else SPX_LAUNCH_XW(4);
 #undef SPX_LAUNCH_XW
 }
 
@@ -501,11 +494,9 @@ bool spmv_xw_profile(unsigned long long out[8])
 void spmv_xw_allow_lds(size_t bytes)
 {
     const int b = (int) bytes;
-#define SPX_XW_ATTR(W, DD) (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&csx_spmv_xw_kernel<W, DD>), hipFuncAttributeMaxDynamicSharedMemorySize, b)
-    SPX_XW_ATTR(2, 2); SPX_XW_ATTR(4, 2); SPX_XW_ATTR(8, 2);
-    SPX_XW_ATTR(2, 3); SPX_XW_ATTR(4, 3); SPX_XW_ATTR(8, 3);
-    SPX_XW_ATTR(2, 4); SPX_XW_ATTR(4, 4); SPX_XW_ATTR(8, 4);
-#undef SPX_XW_ATTR
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&csx_spmv_xw_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, b);
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&csx_spmv_xw_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, b);
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&csx_spmv_xw_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, b);
 }
 
 }  // namespace spx

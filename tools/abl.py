@@ -105,8 +105,6 @@ def main():
                 print("PROFILE   first start to last end %.0f clocks; sum of lives / span = %.1f workgroups in flight" % (
                     span, life.sum() / span), flush=True)
         xw = "xw %d KB LDS" % (info.unit_window_lds // 1024) if info.unit_windows else "-"
-        if info.quad:
-            xw += ", persistent %d x %d wavefronts%s" % ((info.quad & 0xffff) // 32, (info.quad >> 16) & 0xff, " (gen)" if info.quad >> 24 else "")
         print("| %s | %s | %s | %.2f | %.1f | %.3f | %d | %d | %d, %s | %.2f | %.2f | %.3f |" % (
             label, "symmetric" if args.symmetric else "general", name if not body else "%s (`%s`)" % (name, body),
             1e6 * t, 2.0 * nnz / t / 1e9, info.index_bytes / max(int(info.nnz_stored), 1), int(info.nnz_stored),
