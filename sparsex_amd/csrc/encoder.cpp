@@ -10,30 +10,48 @@ namespace spx {
 
 namespace {
 
-struct Rle { size_t freq; idx_t val; };
+// A row's free elements, given by their ascending positions in the current iteration order (1-based), read
+// as maximal runs of equal steps: run = elements [first, first + count), each `step` behind its predecessor
+// (the place in front of the row counts as position 0).  This is what the reference obtains by delta-
+// encoding the positions in place and run-length-encoding the deltas (:457-466, :468-500); here the
+// positions stay what they are and every consumer indexes them directly.
+struct StepRun {
+    size_t first, count;
+    idx_t step;
+};
 
-// in-place delta encoding; element 0 keeps its absolute value (:457-466)
-void delta_encode(std::vector<idx_t> &xs)
+bool next_step_run(const std::vector<idx_t> &pos, size_t at, StepRun &run)
 {
-    for (size_t i = xs.size() - 1; i > 0; --i) xs[i] -= xs[i - 1];
+    if (at >= pos.size()) return false;
+    run.first = at;
+    run.step = pos[at] - (at ? pos[at - 1] : 0);
+    size_t end = at + 1;
+    while (end < pos.size() && pos[end] - pos[end - 1] == run.step) ++end;
+    run.count = end - at;
+    return true;
 }
 
-void rl_encode(const std::vector<idx_t> &in, std::vector<Rle> &out)
+// In a block order (blocks of `align` rows or columns, linearised one block column after the other) a run
+// of step one is a band of consecutive linear positions; the element right in front of the run lies on
+// the band too.  Cut at the block columns the band reads: `front` elements up to the first boundary,
+// `whole` elements in whole block columns, `back` elements behind the last boundary (:1099-1123,
+// :1207-1229, :1421-1440 compute the same three numbers from the run's start column).
+struct Band {
+    size_t first;                 // index of the band's first element (the run's, or the one in front of it)
+    size_t front, whole, back;
+};
+
+Band align_band(const std::vector<idx_t> &pos, const StepRun &run, size_t align)
 {
-    out.clear();
-    Rle r;
-    r.freq = 1;
-    r.val = in[0];
-    for (size_t i = 1; i < in.size(); ++i) {
-        if (in[i] != r.val) {
-            out.push_back(r);
-            r.freq = 1;
-            r.val = in[i];
-        } else {
-            ++r.freq;
-        }
-    }
-    out.push_back(r);
+    Band b;
+    b.first = run.first ? run.first - 1 : 0;
+    size_t count = run.count + (run.first ? 1 : 0);
+    const size_t into_column = (size_t) (pos[b.first] - 1) % align;
+    b.front = into_column ? align - into_column : 0;
+    count = count > b.front ? count - b.front : 0;
+    b.back = count % align;
+    b.whole = count - b.back;
+    return b;
 }
 
 idx_t max_delta(const std::vector<idx_t> &xs)   // :408-424
@@ -234,11 +252,7 @@ void Encoder::update_stats(Partition *sp, std::vector<idx_t> &xs,
     }
     if (xs.empty()) return;
 
-    std::vector<Rle> rles;
-    delta_encode(xs);
-    rl_encode(xs, rles);
-
-    // What a run of `len` equal deltas is worth: units of at most max_limit elements; a last piece
+    // What a run of `len` equal steps is worth: units of at most max_limit elements; a last piece
     // shorter than min_limit is no unit and its elements do not count (:1376-1398)
     auto worth = [this](size_t len) {
         size_t units = len / prm_.max_limit, covered = len;
@@ -247,15 +261,16 @@ void Encoder::update_stats(Partition *sp, std::vector<idx_t> &xs,
         else covered -= last;
         return StatsData(covered, units);
     };
-    // A run counts as `freq` elements -- or freq + 1 when the element in front of it is free to
+    // A run counts as `count` elements -- or count + 1 when the element in front of it is free to
     // join: there is one (this is not the row's first run) and the run before did not become a
-    // unit itself (:1359-1367).  It must have more than one delta and reach min_limit that way.
+    // unit itself (:1359-1367).  It must have more than one step and reach min_limit that way.
     bool at_row_start = true, prev_became_unit = false;
-    for (const Rle &run : rles) {
-        const size_t len = run.freq + ((!at_row_start && !prev_became_unit) ? 1 : 0);
-        prev_became_unit = run.freq > 1 && len >= prm_.min_limit;
-        if (prev_became_unit) stats.append(Instantiation(sp->type, (size_t) run.val), worth(len));
-        if (run.val != 0) at_row_start = false;
+    StepRun run;
+    for (size_t at = 0; next_step_run(xs, at, run); at = run.first + run.count) {
+        const size_t len = run.count + ((!at_row_start && !prev_became_unit) ? 1 : 0);
+        prev_became_unit = run.count > 1 && len >= prm_.min_limit;
+        if (prev_became_unit) stats.append(Instantiation(sp->type, (size_t) run.step), worth(len));
+        if (run.step != 0) at_row_start = false;
     }
     xs.clear();
 }
@@ -263,35 +278,12 @@ void Encoder::update_stats(Partition *sp, std::vector<idx_t> &xs,
 void Encoder::update_stats_block(int type, std::vector<idx_t> &xs, size_t align,
                                  StatsCollection &stats)
 {
-    // :1410-1487 -- in a block iteration order a delta-1 run is a band of
-    // full block columns once its start is aligned to the block boundary.
-    if (xs.empty()) return;
-    std::vector<Rle> rles;
-    delta_encode(xs);
-    rl_encode(xs, rles);
-
-    idx_t unit_start = 0;
-    for (const Rle &rle : rles) {
-        unit_start += rle.val;
-        if (rle.val == 1) {
-            size_t nr_elem, skip_front;
-            if (unit_start == 1) {
-                skip_front = 0;
-                nr_elem = rle.freq;
-            } else {
-                // the run really starts at the previous element
-                skip_front = (size_t)(unit_start - 2) % align;
-                if (skip_front != 0) skip_front = align - skip_front;
-                nr_elem = rle.freq + 1;
-            }
-            if (nr_elem > skip_front) nr_elem -= skip_front;
-            else nr_elem = 0;
-            size_t other_dim = nr_elem / align;
-            if (other_dim >= 2)
-                stats.append(Instantiation(type, other_dim),
-                             StatsData(other_dim * align, 1));
-        }
-        unit_start += rle.val * (idx_t)(rle.freq - 1);
+    // every band of at least two whole block columns is a candidate block of that many columns (:1410-1487)
+    StepRun run;
+    for (size_t at = 0; next_step_run(xs, at, run); at = run.first + run.count) {
+        if (run.step != 1) continue;
+        const size_t columns = align_band(xs, run, align).whole / align;
+        if (columns >= 2) stats.append(Instantiation(type, columns), StatsData(columns * align, 1));
     }
     xs.clear();
 }
@@ -386,202 +378,83 @@ Elem Encoder::make_unit(idx_t row, idx_t col, const val_t *vals, size_t size,
     return e;
 }
 
-void Encoder::do_encode(idx_t row_no, std::vector<idx_t> &xs,
-                        std::vector<val_t> &vs, ElemSink &out)
+// Which blocks a band of `columns` whole block columns is cut into, as column counts in order (none: the band
+// stays single elements).  Without spx.matrix.split_blocks: the band's own size must have been selected;
+// it is cut into equal blocks no larger than max_limit elements, what does not fill one stays behind
+// (:1125-1160).  With it: the selected sizes of this type, largest first, as often as each still fits
+// (:1243-1262).
+void Encoder::cut_band(int type, size_t columns, size_t align, std::vector<size_t> &blocks) const
 {
-    const int type = spm_->type;
-    if (enc_is_block(type)) {
-        if (!prm_.split_blocks) do_encode_block(row_no, xs, vs, out);
-        else do_encode_block_alt(row_no, xs, vs, out);
+    blocks.clear();
+    if (columns < 2) return;
+    if (!prm_.split_blocks) {
+        if (!encoded_inst_.count(Instantiation(type, columns))) return;
+        const size_t cap = prm_.max_limit / align, each = std::min(cap, columns);
+        blocks.assign(std::max<size_t>(1, columns / cap), each);
         return;
     }
-
-    // :1019-1082
-    size_t vi = 0;
-    std::vector<Rle> rles;
-    delta_encode(xs);
-    rl_encode(xs, rles);
-
-    idx_t col = 0;
-    for (const Rle &rle : rles) {
-        size_t rle_freq = rle.freq;
-        if (rle_freq != 1 &&
-            encoded_inst_.count(Instantiation(type, (size_t) rle.val))) {
-            size_t rle_start;
-            col += rle.val;
-            if (col != rle.val) {
-                // not the first run of the row: take the stray element in
-                // front of the run along, unless it belongs to a unit
-                rle_start = (size_t) col;
-                rle_freq = rle.freq;
-                if (!out.back().is_unit()) {
-                    rle_start -= (size_t) rle.val;
-                    rle_freq++;
-                    out.pop_back();
-                    --vi;
-                }
-            } else {
-                rle_start = (size_t) col;
-                rle_freq = rle.freq;
-            }
-            while (rle_freq >= prm_.min_limit) {
-                size_t curr = std::min(prm_.max_limit, rle_freq);
-                out.push_back(make_unit(row_no, (idx_t) rle_start, &vs[vi], curr,
-                                        type, (size_t) rle.val));
-                vi += curr;
-                rle_start += (size_t) rle.val * curr;
-                rle_freq -= curr;
-            }
-            // leave col at the last element covered so far
-            col = (idx_t) rle_start - rle.val;
-        }
-        for (size_t i = 0; i < rle_freq; ++i) {
-            col += rle.val;
-            out.push_back(make_single(row_no, col, vs[vi++]));
-        }
+    for (auto it = encoded_inst_.rbegin(); it != encoded_inst_.rend(); ++it) {
+        if (it->first != type) continue;
+        for (; columns >= it->second; columns -= it->second) blocks.push_back(it->second);
     }
-    assert(vi == vs.size());
-    xs.clear();
-    vs.clear();
 }
 
-void Encoder::do_encode_block(idx_t row_no, std::vector<idx_t> &xs,
-                              std::vector<val_t> &vs, ElemSink &out)
+// Encodes one stretch of a row's free elements (positions ascending in the current order, with their
+// values) into units of the selected instantiations and single elements, appended to `out`.
+void Encoder::encode_stretch(idx_t row_no, std::vector<idx_t> &pos, std::vector<val_t> &vals, ElemSink &out)
 {
-    // :1085-1192 (split_blocks disabled)
     const int type = spm_->type;
     const size_t align = (size_t) enc_block_align(type);
-    size_t vi = 0;
-    std::vector<Rle> rles;
-    delta_encode(xs);
-    rl_encode(xs, rles);
-
-    idx_t col = 0;
-    for (const Rle &rle : rles) {
-        size_t skip_front, skip_back, nr_elem;
-        col += rle.val;
-        if (col == 1) {
-            skip_front = 0;
-            nr_elem = rle.freq;
-        } else {
-            skip_front = (size_t)(col - 2) % align;
-            if (skip_front != 0) skip_front = align - skip_front;
-            nr_elem = rle.freq + 1;
-        }
-        if (nr_elem > skip_front) nr_elem -= skip_front;
-        else nr_elem = 0;
-        skip_back = nr_elem % align;
-        if (nr_elem > skip_back) nr_elem -= skip_back;
-        else nr_elem = 0;
-
-        if (rle.val == 1 &&
-            encoded_inst_.count(Instantiation(type, nr_elem / align)) &&
-            nr_elem >= 2 * align) {
-            size_t rle_start;
-            if (col != 1) {
-                rle_start = (size_t) col - 1;
-                out.pop_back();
-                --vi;
+    auto singles = [&](size_t from, size_t to) {
+        for (size_t k = from; k < to; ++k) out.push_back(make_single(row_no, pos[k], vals[k]));
+    };
+    StepRun run;
+    for (size_t at = 0; next_step_run(pos, at, run); at = run.first + run.count) {
+        const size_t end = run.first + run.count;
+        if (align) {
+            // block orders: a band of step one, cut at its block columns, becomes blocks (:1085-1290)
+            Band band = Band();
+            if (run.step == 1) {
+                band = align_band(pos, run, align);
+                cut_band(type, band.whole / align, align, blocks_buff_);
             } else {
-                rle_start = (size_t) col;
+                blocks_buff_.clear();
             }
-            for (size_t i = 0; i < skip_front; ++i)
-                out.push_back(make_single(row_no, (idx_t)(rle_start + i), vs[vi++]));
-
-            size_t max_limit = prm_.max_limit / align * align;
-            size_t nr_blocks = nr_elem / max_limit;
-            size_t nr_elem_block = std::min(max_limit, nr_elem);
-            if (nr_blocks == 0) nr_blocks = 1;
-            else skip_back += nr_elem - nr_elem_block * nr_blocks;
-
-            for (size_t i = 0; i < nr_blocks; ++i) {
-                out.push_back(make_unit(row_no,
-                                        (idx_t)(rle_start + skip_front + i * nr_elem_block),
-                                        &vs[vi], nr_elem_block, type,
-                                        nr_elem_block / align));
-                vi += nr_elem_block;
+            if (blocks_buff_.empty()) {
+                singles(run.first, end);
+                continue;
             }
-            for (size_t i = 0; i < skip_back; ++i)
-                out.push_back(make_single(
-                    row_no,
-                    (idx_t)(rle_start + skip_front + nr_elem_block * nr_blocks + i),
-                    vs[vi++]));
-        } else {
-            for (size_t i = 0; i < rle.freq; ++i)
-                out.push_back(make_single(row_no, col + (idx_t) i * rle.val, vs[vi++]));
+            // (the element in front of the run was written as a single element: the band takes it back)
+            if (band.first != run.first) out.pop_back();
+            size_t k = band.first + band.front;
+            singles(band.first, k);
+            for (const size_t columns : blocks_buff_) {
+                out.push_back(make_unit(row_no, pos[k], &vals[k], columns * align, type, columns));
+                k += columns * align;
+            }
+            singles(k, end);
+            continue;
         }
-        col += rle.val * (idx_t)(rle.freq - 1);
-    }
-    assert(vi == vs.size());
-    xs.clear();
-    vs.clear();
-}
-
-void Encoder::do_encode_block_alt(idx_t row_no, std::vector<idx_t> &xs,
-                                  std::vector<val_t> &vs, ElemSink &out)
-{
-    // :1194-1290 -- greedy cover of an aligned band with the accepted block
-    // sizes, largest first
-    const int type = spm_->type;
-    const size_t align = (size_t) enc_block_align(type);
-    size_t vi = 0;
-    std::vector<Rle> rles;
-    delta_encode(xs);
-    rl_encode(xs, rles);
-
-    idx_t col = 0;
-    for (const Rle &rle : rles) {
-        size_t skip_front, skip_back, nr_elem;
-        col += rle.val;
-        if (col == 1) {
-            skip_front = 0;
-            nr_elem = rle.freq;
-        } else {
-            skip_front = (size_t)(col - 2) % align;
-            if (skip_front != 0) skip_front = align - skip_front;
-            nr_elem = rle.freq + 1;
-        }
-        if (nr_elem > skip_front) nr_elem -= skip_front;
-        else nr_elem = 0;
-        skip_back = nr_elem % align;
-        nr_elem -= skip_back;
-        if (rle.val == 1 && nr_elem >= 2 * align) {
-            size_t rle_start;
-            if (col != 1) {
-                rle_start = (size_t) col - 1;
+        // linear orders: a run of a selected step becomes units of min_limit .. max_limit elements; a single
+        // element in front of it -- not one that a unit of this stretch ends with -- joins the run (:1019-1082)
+        size_t first = run.first, count = run.count;
+        if (run.count != 1 && encoded_inst_.count(Instantiation(type, (size_t) run.step))) {
+            if (first > 0 && !out.back().is_unit()) {
                 out.pop_back();
-                --vi;
-            } else {
-                rle_start = (size_t) col;
+                --first;
+                ++count;
             }
-            for (size_t i = 0; i < skip_front; ++i)
-                out.push_back(make_single(row_no, (idx_t)(rle_start++), vs[vi++]));
-
-            size_t other_dim = nr_elem / align;
-            for (auto it = encoded_inst_.rbegin(); it != encoded_inst_.rend(); ++it) {
-                if (it->first != type) continue;
-                while (other_dim >= it->second) {
-                    size_t nr_elem_block = align * it->second;
-                    out.push_back(make_unit(row_no, (idx_t) rle_start, &vs[vi],
-                                            nr_elem_block, type, it->second));
-                    rle_start += nr_elem_block;
-                    vi += nr_elem_block;
-                    nr_elem -= nr_elem_block;
-                    other_dim -= it->second;
-                }
+            while (count >= prm_.min_limit) {
+                const size_t take = std::min(prm_.max_limit, count);
+                out.push_back(make_unit(row_no, pos[first], &vals[first], take, type, (size_t) run.step));
+                first += take;
+                count -= take;
             }
-            skip_back += nr_elem;
-            for (size_t i = 0; i < skip_back; ++i)
-                out.push_back(make_single(row_no, (idx_t)(rle_start++), vs[vi++]));
-        } else {
-            for (size_t i = 0; i < rle.freq; ++i)
-                out.push_back(make_single(row_no, col + (idx_t) i * rle.val, vs[vi++]));
         }
-        col += rle.val * (idx_t)(rle.freq - 1);
+        singles(first, first + count);
     }
-    assert(vi == vs.size());
-    xs.clear();
-    vs.clear();
+    pos.clear();
+    vals.clear();
 }
 
 void Encoder::encode_row(size_t row, ElemSink &newrow)
@@ -597,10 +470,10 @@ void Encoder::encode_row(size_t row, ElemSink &newrow)
             vals_buff_.push_back(e.val);
             continue;
         }
-        if (!cols_buff_.empty()) do_encode(row_no, cols_buff_, vals_buff_, newrow);
+        if (!cols_buff_.empty()) encode_stretch(row_no, cols_buff_, vals_buff_, newrow);
         newrow.push_back(e);
     }
-    if (!cols_buff_.empty()) do_encode(row_no, cols_buff_, vals_buff_, newrow);
+    if (!cols_buff_.empty()) encode_stretch(row_no, cols_buff_, vals_buff_, newrow);
 }
 
 void Encoder::encode(int type)

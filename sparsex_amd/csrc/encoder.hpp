@@ -78,9 +78,8 @@ private:
         size_t size() const { return n; }
     };
     void encode_row(size_t row, ElemSink &newrow);
-    void do_encode(idx_t row_no, std::vector<idx_t> &xs, std::vector<val_t> &vs, ElemSink &out);
-    void do_encode_block(idx_t row_no, std::vector<idx_t> &xs, std::vector<val_t> &vs, ElemSink &out);
-    void do_encode_block_alt(idx_t row_no, std::vector<idx_t> &xs, std::vector<val_t> &vs, ElemSink &out);
+    void encode_stretch(idx_t row_no, std::vector<idx_t> &pos, std::vector<val_t> &vals, ElemSink &out);
+    void cut_band(int type, size_t columns, size_t align, std::vector<size_t> &blocks) const;
     Elem make_unit(idx_t row, idx_t col, const val_t *vals, size_t size,
                    int type, size_t delta);
 
@@ -101,6 +100,7 @@ private:
     std::vector<int> enc_seq_;
     std::vector<idx_t> cols_buff_;
     std::vector<val_t> vals_buff_;
+    std::vector<size_t> blocks_buff_;     // block column counts of the band being cut (encode_stretch)
 };
 
 }  // namespace spx
