@@ -87,6 +87,19 @@ double now_sec()
 
 }  // namespace
 
+// Nothing leaves a C entry point as an exception -- through `extern "C"` that is std::terminate, and
+// spx_mat_tune alone holds tens of gigabytes at contract size.  Every entry point below is a function-try-
+// block that ends with SPX_C_BOUNDARY: what the inner handlers of a function do not catch becomes an error
+// through the handler and the function's failure value, the reference's convention for what cannot be done
+// (include/sparsex/error.h:99-115; src/api/matvec.c:259-322: spx_mat_tune returns SPX_INVALID_MAT).  A failed
+// allocation is SPX_ERR_MEM_ALLOC, which the default handler, like the reference's, treats as fatal (exit(1),
+// src/api/error.c:64-88); a handler set by the client sees the code and the call returns its failure value.
+#define SPX_C_BOUNDARY(RETURN_STATEMENT)                                                                      \
+    catch (const spx::FatalError &e_) { SETERROR_1(SPX_ERR_TUNED_MAT, e_.what.c_str()); RETURN_STATEMENT }      \
+    catch (const std::bad_alloc &) { SETERROR_0(SPX_ERR_MEM_ALLOC); RETURN_STATEMENT }                         \
+    catch (const std::exception &e_) { SETERROR_1(SPX_ERR_TUNED_MAT, e_.what()); RETURN_STATEMENT }            \
+    catch (...) { SETERROR_1(SPX_ERR_TUNED_MAT, "unknown exception"); RETURN_STATEMENT }
+
 extern "C" {
 
 // ======================================================================================
@@ -150,9 +163,9 @@ void err_handle(spx_error_t code, const char *sourcefile, unsigned long lineno,
 spx_errhandler_t spx_err_get_handler() { return g_handler; }
 
 void spx_err_set_handler(spx_errhandler_t new_handler)
-{
+try {
     g_handler = new_handler ? new_handler : err_handle;
-}
+} SPX_C_BOUNDARY(return;)
 
 // ======================================================================================
 //  common.h
@@ -172,10 +185,10 @@ void spx_log_verbose_file() { log_set_file(g_logfile); log_set_level(LOG_VERB); 
 void spx_log_debug_file() { log_set_file(g_logfile); log_set_level(LOG_DBG); }
 void spx_log_all_console() { log_set_file(NULL); log_set_level(LOG_DBG); }
 void spx_log_all_file(const char *file)
-{
+try {
     log_set_file(file ? file : g_logfile);
     log_set_level(LOG_DBG);
-}
+} SPX_C_BOUNDARY(return;)
 void spx_log_set_file(const char *file) { log_set_file(file); }
 
 void spx_init() { log_set_level(LOG_WARN); }
@@ -209,7 +222,7 @@ void free_internal(void *ptr, const char *sourcefile, unsigned long lineno,
 spx_input_t *spx_input_load_csr(const spx_index_t *rowptr, const spx_index_t *colind,
                                 const spx_value_t *values, spx_index_t nrows,
                                 spx_index_t ncols, ...)
-{
+try {
     va_list ap;
     va_start(ap, ncols);
     spx_option_t indexing = va_arg(ap, spx_option_t);
@@ -243,10 +256,10 @@ spx_input_t *spx_input_load_csr(const spx_index_t *rowptr, const spx_index_t *co
     A->nnz = rowptr[nrows] - (one_based ? 1 : 0);
     A->mat = new CsrInput(rowptr, colind, values, nrows, ncols, !one_based);
     return A;
-}
+} SPX_C_BOUNDARY(return SPX_INVALID_INPUT;)
 
 spx_input_t *spx_input_load_mmf(const char *filename)
-{
+try {
     if (!filename) {
         SETERROR_0(SPX_ERR_FILE);
         return SPX_INVALID_INPUT;
@@ -269,10 +282,10 @@ spx_input_t *spx_input_load_mmf(const char *filename)
     A->ncols = (spx_index_t) m->nr_cols;
     A->nnz = (spx_index_t) m->nnz;
     return A;
-}
+} SPX_C_BOUNDARY(return SPX_INVALID_INPUT;)
 
 spx_error_t spx_input_destroy(spx_input_t *A)
-{
+try {
     if (!A) {
         SETERROR_1(SPX_ERR_ARG_INVALID, "invalid input handle");
         return SPX_FAILURE;
@@ -280,7 +293,7 @@ spx_error_t spx_input_destroy(spx_input_t *A)
     delete A->mat;
     delete A;
     return SPX_SUCCESS;
-}
+} SPX_C_BOUNDARY(return SPX_FAILURE;)
 
 // ======================================================================================
 //  tuning
@@ -1074,7 +1087,7 @@ static spx_matrix_t *do_tune(spx_input_t *in)
 }
 
 spx_matrix_t *spx_mat_tune(spx_input_t *in, ...)
-{
+try {
     if (!in) {
         SETERROR_1(SPX_ERR_ARG_INVALID, "invalid input matrix");
         return SPX_INVALID_MAT;
@@ -1135,10 +1148,10 @@ spx_matrix_t *spx_mat_tune(spx_input_t *in, ...)
         std::copy(perm.begin(), perm.end(), A->permutation);
     }
     return A;
-}
+} SPX_C_BOUNDARY(return SPX_INVALID_MAT;)
 
 spx_error_t spx_mat_destroy(spx_matrix_t *A)
-{
+try {
     if (!A) {
         SETERROR_1(SPX_ERR_ARG_INVALID, "invalid matrix handle");
         return SPX_FAILURE;
@@ -1148,7 +1161,7 @@ spx_error_t spx_mat_destroy(spx_matrix_t *A)
     if (A->permutation) free(A->permutation);
     delete A;
     return SPX_SUCCESS;
-}
+} SPX_C_BOUNDARY(return SPX_FAILURE;)
 
 // ---- get / set entry ------------------------------------------------------------------
 // Random access into the tuned matrix (reference: src/api/matvec.c:324-407,
@@ -1290,7 +1303,7 @@ extern "C" {
 
 spx_error_t spx_mat_get_entry(const spx_matrix_t *A_, spx_index_t row, spx_index_t column,
                               spx_value_t *value, ...)
-{
+try {
     va_list ap;
     va_start(ap, value);
     spx_option_t indexing = va_arg(ap, spx_option_t);
@@ -1322,11 +1335,11 @@ spx_error_t spx_mat_get_entry(const spx_matrix_t *A_, spx_index_t row, spx_index
         return SPX_FAILURE;
     }
     return SPX_SUCCESS;
-}
+} SPX_C_BOUNDARY(return SPX_FAILURE;)
 
 spx_error_t spx_mat_set_entry(spx_matrix_t *A, spx_index_t row, spx_index_t column,
                               spx_value_t value, ...)
-{
+try {
     va_list ap;
     va_start(ap, value);
     spx_option_t indexing = va_arg(ap, spx_option_t);
@@ -1368,7 +1381,7 @@ spx_error_t spx_mat_set_entry(spx_matrix_t *A, spx_index_t row, spx_index_t colu
         A->exported_rows_info.clear();
     }
     return SPX_SUCCESS;
-}
+} SPX_C_BOUNDARY(return SPX_FAILURE;)
 
 // ---- save / restore -----------------------------------------------------------------
 // The reference archives every partition's ctl/values/id_map/rows_info with
@@ -1486,7 +1499,7 @@ extern "C" {
 
 
 spx_error_t spx_mat_save(const spx_matrix_t *A, const char *filename)
-{
+try {
     if (!A) {
         SETERROR_1(SPX_ERR_ARG_INVALID, "invalid matrix handle");
         return SPX_FAILURE;
@@ -1563,10 +1576,10 @@ spx_error_t spx_mat_save(const spx_matrix_t *A, const char *filename)
         return SPX_FAILURE;
     }
     return SPX_SUCCESS;
-}
+} SPX_C_BOUNDARY(return SPX_FAILURE;)
 
 spx_matrix_t *spx_mat_restore(const char *filename)
-{
+try {
     if (!filename) {
         SETERROR_0(SPX_ERR_FILE);
         return SPX_INVALID_MAT;
@@ -1698,25 +1711,25 @@ spx_matrix_t *spx_mat_restore(const char *filename)
     }
     A->emit_seconds = now_sec() - t0;
     return A.release();
-}
+} SPX_C_BOUNDARY(return SPX_INVALID_MAT;)
 
 spx_index_t spx_mat_get_nrows(const spx_matrix_t *A)
-{
+try {
     if (!A) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid matrix handle"); return SPX_FAILURE; }
     return A->nrows;
-}
+} SPX_C_BOUNDARY(return 0;)
 
 spx_index_t spx_mat_get_ncols(const spx_matrix_t *A)
-{
+try {
     if (!A) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid matrix handle"); return SPX_FAILURE; }
     return A->ncols;
-}
+} SPX_C_BOUNDARY(return 0;)
 
 spx_index_t spx_mat_get_nnz(const spx_matrix_t *A)
-{
+try {
     if (!A) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid matrix handle"); return SPX_FAILURE; }
     return A->nnz;
-}
+} SPX_C_BOUNDARY(return 0;)
 
 static spx_partition_t *part_alloc(size_t n)
 {
@@ -1731,7 +1744,7 @@ static spx_partition_t *part_alloc(size_t n)
 }
 
 spx_partition_t *spx_mat_get_partition(const spx_matrix_t *A)
-{
+try {
     if (!A) {
         SETERROR_1(SPX_ERR_ARG_INVALID, "invalid matrix handle");
         return SPX_INVALID_PART;
@@ -1742,22 +1755,22 @@ spx_partition_t *spx_mat_get_partition(const spx_matrix_t *A)
         p->row_end[i] = A->bounds[i].row_start + A->bounds[i].nr_rows;
     }
     return p;
-}
+} SPX_C_BOUNDARY(return SPX_INVALID_PART;)
 
 spx_index_t *spx_partition_get_rs(const spx_partition_t *p)
-{
+try {
     if (!p) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid partition handle"); return NULL; }
     return p->row_start;
-}
+} SPX_C_BOUNDARY(return nullptr;)
 
 spx_index_t *spx_partition_get_re(const spx_partition_t *p)
-{
+try {
     if (!p) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid partition handle"); return NULL; }
     return p->row_end;
-}
+} SPX_C_BOUNDARY(return nullptr;)
 
 spx_perm_t *spx_mat_get_perm(const spx_matrix_t *A)
-{
+try {
     if (!A) {
         SETERROR_1(SPX_ERR_ARG_INVALID, "invalid matrix handle");
         return SPX_INVALID_PERM;
@@ -1767,11 +1780,11 @@ spx_perm_t *spx_mat_get_perm(const spx_matrix_t *A)
         return SPX_INVALID_PERM;
     }
     return A->permutation;
-}
+} SPX_C_BOUNDARY(return SPX_INVALID_PERM;)
 
 spx_partition_t *spx_partition_csr(const spx_index_t *rowptr, spx_index_t nr_rows,
                                    size_t nr_threads)
-{
+try {
     // src/api/matvec.c:689-737
     spx_partition_t *ret = part_alloc(nr_threads);
     size_t nnz_per_split = (size_t)(rowptr[nr_rows] - 1) / nr_threads;
@@ -1791,10 +1804,10 @@ spx_partition_t *spx_partition_csr(const spx_index_t *rowptr, spx_index_t nr_row
     if (curr_nnz < nnz_per_split && split_cnt < nr_threads)
         ret->row_end[split_cnt] = i + 1;
     return ret;
-}
+} SPX_C_BOUNDARY(return SPX_INVALID_PART;)
 
 spx_error_t spx_partition_destroy(spx_partition_t *p)
-{
+try {
     if (!p) {
         SETERROR_1(SPX_ERR_ARG_INVALID, "invalid partition handle");
         return SPX_FAILURE;
@@ -1803,36 +1816,36 @@ spx_error_t spx_partition_destroy(spx_partition_t *p)
     free(p->row_start); free(p->row_end);
     free(p);
     return SPX_SUCCESS;
-}
+} SPX_C_BOUNDARY(return SPX_FAILURE;)
 
 // ======================================================================================
 //  options
 // ======================================================================================
 
 void spx_option_set(const char *option, const char *value)
-{
+try {
     if (!option || !value) { SETWARNING(SPX_WARN_TUNING_OPT); return; }
     try {
         Config::instance().set(option, value);
     } catch (const FatalError &) {
         exit(1);    // invalid enumerated value: the reference exits (Encodings.cpp:171-186)
     }
-}
+} SPX_C_BOUNDARY(return;)
 
 void spx_options_set_from_env()
-{
+try {
     try {
         Config::instance().load_from_env();
     } catch (const FatalError &) {
         exit(1);
     }
-}
+} SPX_C_BOUNDARY(return;)
 
 void spx_hip_options_reset(void) { Config::instance().reset_defaults(); }
 
 spx_error_t spx_hip_dist_reorder(const spx_index_t *rowptr, const spx_index_t *colind, spx_index_t nrows,
                                  int indexing, int world, int mode, int flags, spx_index_t *perm)
-{
+try {
     if (!rowptr || !colind || !perm || nrows < 0 || world < 1 ||
         (indexing != SPX_INDEX_ZERO_BASED && indexing != SPX_INDEX_ONE_BASED) ||
         (mode != SPX_DIST_REORDER_RCM && mode != SPX_DIST_REORDER_RCM_OWNER)) {
@@ -1847,18 +1860,15 @@ spx_error_t spx_hip_dist_reorder(const spx_index_t *rowptr, const spx_index_t *c
     } catch (const FatalError &e) {
         SETERROR_1(SPX_ERR_ARG_INVALID, e.what.c_str());
         return SPX_FAILURE;
-    } catch (const std::bad_alloc &) {
-        SETERROR_0(SPX_ERR_MEM_ALLOC);
-        return SPX_FAILURE;
     }
     return SPX_SUCCESS;
-}
+} SPX_C_BOUNDARY(return SPX_FAILURE;)
 
 void spx_hip_xform(int from, int to, spx_index_t *row, spx_index_t *col,
                    spx_index_t nr_rows, spx_index_t nr_cols)
-{
+try {
     xform(from, to, *row, *col, nr_rows, nr_cols);
-}
+} SPX_C_BOUNDARY(return;)
 
 // ======================================================================================
 //  SpMV
@@ -1905,23 +1915,23 @@ static spx_error_t run_host(const spx_matrix_t *A, spx_value_t alpha, const spx_
 
 spx_error_t spx_matvec_mult(spx_value_t alpha, const spx_matrix_t *A, const spx_vector_t *x,
                             spx_vector_t *y)
-{
+try {
     if (check_mv(A, x, y) != SPX_SUCCESS) return SPX_FAILURE;
     return run_host(A, alpha, x, 0.0, y);
-}
+} SPX_C_BOUNDARY(return SPX_FAILURE;)
 
 spx_error_t spx_matvec_kernel(spx_value_t alpha, const spx_matrix_t *A, const spx_vector_t *x,
                               spx_value_t beta, spx_vector_t *y)
-{
+try {
     if (check_mv(A, x, y) != SPX_SUCCESS) return SPX_FAILURE;
     return run_host(A, alpha, x, beta, y);
-}
+} SPX_C_BOUNDARY(return SPX_FAILURE;)
 
 spx_error_t spx_matvec_kernel_csr(spx_matrix_t **A, spx_index_t nrows, spx_index_t ncols,
                                   const spx_index_t *rowptr, const spx_index_t *colind,
                                   const spx_value_t *values, spx_value_t alpha,
                                   const spx_vector_t *x, spx_value_t beta, spx_vector_t *y)
-{
+try {
     if (!x) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid vector x"); return SPX_FAILURE; }
     if (!y) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid vector y"); return SPX_FAILURE; }
     if (!A) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid matrix handle"); return SPX_FAILURE; }
@@ -1941,7 +1951,7 @@ spx_error_t spx_matvec_kernel_csr(spx_matrix_t **A, spx_index_t nrows, spx_index
         if (!*A) return SPX_FAILURE;
     }
     return spx_matvec_kernel(alpha, *A, x, beta, y);
-}
+} SPX_C_BOUNDARY(return SPX_FAILURE;)
 
 static spx_error_t check_dev(const spx_matrix_t *A, const void *x, const void *y)
 {
@@ -1958,14 +1968,14 @@ static spx_error_t check_dev(const spx_matrix_t *A, const void *x, const void *y
 
 spx_error_t spx_hip_matvec_mult(spx_value_t alpha, const spx_matrix_t *A,
                                 const spx_value_t *x_dev, spx_value_t *y_dev, void *stream)
-{
+try {
     return spx_hip_matvec_kernel(alpha, A, x_dev, 0.0, y_dev, stream);
-}
+} SPX_C_BOUNDARY(return SPX_FAILURE;)
 
 spx_error_t spx_hip_matvec_kernel(spx_value_t alpha, const spx_matrix_t *A,
                                   const spx_value_t *x_dev, spx_value_t beta,
                                   spx_value_t *y_dev, void *stream)
-{
+try {
     if (check_dev(A, x_dev, y_dev) != SPX_SUCCESS) return SPX_FAILURE;
     try {
         device_spmv(A->dev, alpha, x_dev, beta, y_dev, stream);
@@ -1974,11 +1984,11 @@ spx_error_t spx_hip_matvec_kernel(spx_value_t alpha, const spx_matrix_t *A,
         return SPX_FAILURE;
     }
     return SPX_SUCCESS;
-}
+} SPX_C_BOUNDARY(return SPX_FAILURE;)
 
 spx_error_t spx_hip_matvec_parts(spx_value_t alpha, const spx_matrix_t *A, const spx_value_t *x_dev,
                                  spx_value_t beta, spx_value_t *y_dev, int parts, void *stream, int *launched)
-{
+try {
     if (check_dev(A, x_dev, y_dev) != SPX_SUCCESS) return SPX_FAILURE;
     try {
         std::vector<size_t> bounds;
@@ -1996,12 +2006,12 @@ spx_error_t spx_hip_matvec_parts(spx_value_t alpha, const spx_matrix_t *A, const
         return SPX_FAILURE;
     }
     return SPX_SUCCESS;
-}
+} SPX_C_BOUNDARY(return SPX_FAILURE;)
 
 spx_error_t spx_hip_matvec_dist(spx_value_t alpha, const spx_matrix_t *A,
                                 const spx_value_t *x_dev, spx_value_t beta,
                                 spx_value_t *y_dev, int flags, void *stream)
-{
+try {
     if (check_dev(A, x_dev, y_dev) != SPX_SUCCESS) return SPX_FAILURE;
     if (!A->dist) {
         SETERROR_1(SPX_ERR_TUNED_MAT, "matrix has no exchange plan (spx_hip_mat_dist_attach)");
@@ -2020,7 +2030,7 @@ spx_error_t spx_hip_matvec_dist(spx_value_t alpha, const spx_matrix_t *A,
         return SPX_FAILURE;
     }
     return SPX_SUCCESS;
-}
+} SPX_C_BOUNDARY(return SPX_FAILURE;)
 
 // ======================================================================================
 //  extensions: info / export
@@ -2031,12 +2041,12 @@ int spx_hip_abi_version(void) { return SPX_HIP_ABI_VERSION; }
 // (experiment builds only, tools/build_variant.sh -DSPX_XW_PROFILE: shader clocks per phase of a workgroup of
 // csx_spmv_xw_kernel, summed since the last call; SPX_FAILURE in a regular build)
 spx_error_t spx_hip_debug_counters(unsigned long long out[8])
-{
+try {
     return out && spmv_xw_profile(out) ? SPX_SUCCESS : SPX_FAILURE;
-}
+} SPX_C_BOUNDARY(return 0;)
 
 spx_error_t spx_hip_mat_unit_windows(spx_matrix_t *A, uint32_t budget, uint32_t gap, spx_hip_xw_plan_t *out)
-{
+try {
     if (!A || !out) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid argument"); return SPX_FAILURE; }
     const GpuStream *s = A->host_stream ? A->host_stream.get() : A->index.get();
     if (!s) { SETERROR_1(SPX_ERR_TUNED_MAT, "matrix holds no descriptor stream"); return SPX_FAILURE; }
@@ -2067,10 +2077,10 @@ spx_error_t spx_hip_mat_unit_windows(spx_matrix_t *A, uint32_t budget, uint32_t 
     out->unit_elems_lds = p.unit_elems_lds;
     out->lds_doubles = p.lds_doubles;
     return SPX_SUCCESS;
-}
+} SPX_C_BOUNDARY(return SPX_FAILURE;)
 
 spx_error_t spx_hip_mat_info_sized(const spx_matrix_t *A, void *info, size_t size)
-{
+try {
     spx_hip_info_t full;
     if (!info || spx_hip_mat_info(A, &full) != SPX_SUCCESS) {
         if (!info) SETERROR_1(SPX_ERR_ARG_INVALID, "invalid argument");
@@ -2078,10 +2088,10 @@ spx_error_t spx_hip_mat_info_sized(const spx_matrix_t *A, void *info, size_t siz
     }
     memcpy(info, &full, std::min(size, sizeof(full)));
     return SPX_SUCCESS;
-}
+} SPX_C_BOUNDARY(return SPX_FAILURE;)
 
 spx_error_t spx_hip_mat_info(const spx_matrix_t *A, spx_hip_info_t *info)
-{
+try {
     if (!A || !info) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid argument"); return SPX_FAILURE; }
     memset(info, 0, sizeof(*info));
     info->nnz = A->nnz;
@@ -2123,7 +2133,7 @@ spx_error_t spx_hip_mat_info(const spx_matrix_t *A, spx_hip_info_t *info)
     info->tune_seconds = A->tune_seconds;
     info->emit_seconds = A->emit_seconds;
     return SPX_SUCCESS;
-}
+} SPX_C_BOUNDARY(return SPX_FAILURE;)
 
 static bool owned_part(const spx_matrix_t *A, int part)
 {
@@ -2132,7 +2142,7 @@ static bool owned_part(const spx_matrix_t *A, int part)
 }
 
 spx_error_t spx_hip_mat_export_csx(const spx_matrix_t *A_, int part, spx_csx_export_t *out)
-{
+try {
     spx_matrix_t *A = const_cast<spx_matrix_t *>(A_);
     if (!A || !out) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid argument"); return SPX_FAILURE; }
     if (!owned_part(A, part)) {
@@ -2177,11 +2187,11 @@ spx_error_t spx_hip_mat_export_csx(const spx_matrix_t *A_, int part, spx_csx_exp
     out->rows_info = A->exported_rows_info[li].data();
     out->dvalues = A->symmetric ? s.dvalues.data() : NULL;
     return SPX_SUCCESS;
-}
+} SPX_C_BOUNDARY(return SPX_FAILURE;)
 
 int64_t spx_hip_mat_export_units(const spx_matrix_t *A, int part, spx_unit_record_t *recs,
                                  int64_t cap)
-{
+try {
     if (!A || !owned_part(A, part)) {
         SETERROR_1(SPX_ERR_ARG_INVALID, "partition not held by this process");
         return -1;
@@ -2196,12 +2206,12 @@ int64_t spx_hip_mat_export_units(const spx_matrix_t *A, int part, spx_unit_recor
         recs[i].col = e.col;
     }
     return (int64_t) p.elems_size;
-}
+} SPX_C_BOUNDARY(return 0;)
 
 const char *spx_hip_mat_tune_log(const spx_matrix_t *A)
-{
+try {
     return A ? A->log.c_str() : "";
-}
+} SPX_C_BOUNDARY(return nullptr;)
 
 // ======================================================================================
 //  vectors (host side; reference src/internals/Vector.cpp)
@@ -2229,17 +2239,17 @@ static spx_vector_t *vec_alloc(size_t size)
 }
 
 spx_vector_t *spx_vec_create(size_t size, const spx_partition_t *p)
-{
+try {
     if (p == SPX_INVALID_PART) {
         SETERROR_1(SPX_ERR_ARG_INVALID, "invalid partition handle");
         return SPX_INVALID_VEC;
     }
     return vec_alloc(size);
-}
+} SPX_C_BOUNDARY(return SPX_INVALID_VEC;)
 
 spx_vector_t *spx_vec_create_from_buff(spx_value_t *buff, spx_value_t **tuned, size_t size,
                                        const spx_partition_t *p, spx_vecmode_t mode)
-{
+try {
     if (!buff) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid buffer"); return SPX_INVALID_VEC; }
     if (!check_vecmode(mode)) {
         SETERROR_1(SPX_ERR_ARG_INVALID, "invalid vector mode");
@@ -2258,19 +2268,19 @@ spx_vector_t *spx_vec_create_from_buff(spx_value_t *buff, spx_value_t **tuned, s
     v->vec_mode = (int) mode;
     if (tuned) *tuned = buff;
     return v;
-}
+} SPX_C_BOUNDARY(return SPX_INVALID_VEC;)
 
 void spx_vec_init_rand_range(spx_vector_t *v, spx_value_t max, spx_value_t min)
-{
+try {
     vec_touch(v);
     for (size_t i = 0; i < v->size; i++) {
         spx_value_t val = ((spx_value_t)(rand() + i) / ((spx_value_t) RAND_MAX + 1));
         v->elements[i] = min + val * (max - min);
     }
-}
+} SPX_C_BOUNDARY(return;)
 
 spx_vector_t *spx_vec_create_random(size_t size, const spx_partition_t *p)
-{
+try {
     if (p == SPX_INVALID_PART) {
         SETERROR_1(SPX_ERR_ARG_INVALID, "invalid partition handle");
         return SPX_INVALID_VEC;
@@ -2279,22 +2289,22 @@ spx_vector_t *spx_vec_create_random(size_t size, const spx_partition_t *p)
     // values in (-0.1, 0.1], same argument order as Vector.cpp:161-167
     spx_vec_init_rand_range(v, (spx_value_t) -0.1, (spx_value_t) 0.1);
     return v;
-}
+} SPX_C_BOUNDARY(return SPX_INVALID_VEC;)
 
 void spx_vec_init(spx_vector_t *v, spx_value_t val)
-{
+try {
     vec_touch(v);
     for (size_t i = 0; i < v->size; i++) v->elements[i] = val;
-}
+} SPX_C_BOUNDARY(return;)
 
 void spx_vec_init_part(spx_vector_t *v, spx_value_t val, spx_index_t start, spx_index_t end)
-{
+try {
     vec_touch(v);
     for (spx_index_t i = start; i < end; i++) v->elements[i] = val;
-}
+} SPX_C_BOUNDARY(return;)
 
 spx_error_t spx_vec_set_entry(spx_vector_t *v, spx_index_t idx, spx_value_t val, ...)
-{
+try {
     va_list ap;
     va_start(ap, val);
     spx_option_t indexing = va_arg(ap, spx_option_t);
@@ -2309,31 +2319,31 @@ spx_error_t spx_vec_set_entry(spx_vector_t *v, spx_index_t idx, spx_value_t val,
     v->elements[pos] = val;
     vec_touch(v);
     return SPX_SUCCESS;
-}
+} SPX_C_BOUNDARY(return SPX_FAILURE;)
 
 void spx_vec_scale(spx_vector_t *v1, spx_vector_t *v2, spx_value_t num)
-{
+try {
     vec_touch(v2);
     for (size_t i = 0; i < v1->size; i++) v2->elements[i] = num * v1->elements[i];
-}
+} SPX_C_BOUNDARY(return;)
 
 void spx_vec_scale_add(spx_vector_t *v1, spx_vector_t *v2, spx_vector_t *v3, spx_value_t num)
-{
+try {
     vec_touch(v3);
     for (size_t i = 0; i < v1->size; i++)
         v3->elements[i] = v1->elements[i] + num * v2->elements[i];
-}
+} SPX_C_BOUNDARY(return;)
 
 void spx_vec_scale_add_part(spx_vector_t *v1, spx_vector_t *v2, spx_vector_t *v3,
                             spx_value_t num, spx_index_t start, spx_index_t end)
-{
+try {
     vec_touch(v3);
     for (spx_index_t i = start; i < end; i++)
         v3->elements[i] = v1->elements[i] + num * v2->elements[i];
-}
+} SPX_C_BOUNDARY(return;)
 
 void spx_vec_add(spx_vector_t *v1, spx_vector_t *v2, spx_vector_t *v3)
-{
+try {
     vec_touch(v3);
     if (v1->size != v2->size || v1->size != v3->size) {
         fprintf(stderr, "v1->size=%lu v2->size=%lu v3->size=%lu differ\n",
@@ -2341,47 +2351,47 @@ void spx_vec_add(spx_vector_t *v1, spx_vector_t *v2, spx_vector_t *v3)
         exit(1);
     }
     for (size_t i = 0; i < v1->size; i++) v3->elements[i] = v1->elements[i] + v2->elements[i];
-}
+} SPX_C_BOUNDARY(return;)
 
 void spx_vec_add_part(spx_vector_t *v1, spx_vector_t *v2, spx_vector_t *v3,
                       spx_index_t start, spx_index_t end)
-{
+try {
     vec_touch(v3);
     for (spx_index_t i = start; i < end; i++)
         v3->elements[i] = v1->elements[i] + v2->elements[i];
-}
+} SPX_C_BOUNDARY(return;)
 
 void spx_vec_sub(spx_vector_t *v1, spx_vector_t *v2, spx_vector_t *v3)
-{
+try {
     vec_touch(v3);
     for (size_t i = 0; i < v1->size; i++) v3->elements[i] = v1->elements[i] - v2->elements[i];
-}
+} SPX_C_BOUNDARY(return;)
 
 void spx_vec_sub_part(spx_vector_t *v1, spx_vector_t *v2, spx_vector_t *v3,
                       spx_index_t start, spx_index_t end)
-{
+try {
     vec_touch(v3);
     for (spx_index_t i = start; i < end; i++)
         v3->elements[i] = v1->elements[i] - v2->elements[i];
-}
+} SPX_C_BOUNDARY(return;)
 
 spx_value_t spx_vec_mul(const spx_vector_t *v1, const spx_vector_t *v2)
-{
+try {
     spx_value_t ret = 0;
     for (size_t i = 0; i < v1->size; i++) ret += v1->elements[i] * v2->elements[i];
     return ret;
-}
+} SPX_C_BOUNDARY(return 0;)
 
 spx_value_t spx_vec_mul_part(const spx_vector_t *v1, const spx_vector_t *v2,
                              spx_index_t start, spx_index_t end)
-{
+try {
     spx_value_t ret = 0;
     for (spx_index_t i = start; i < end; i++) ret += v1->elements[i] * v2->elements[i];
     return ret;
-}
+} SPX_C_BOUNDARY(return 0;)
 
 spx_error_t spx_vec_reorder(spx_vector_t *v, spx_perm_t *p)
-{
+try {
     if (p == SPX_INVALID_PERM) {
         SETERROR_1(SPX_ERR_ARG_INVALID, "invalid permutation");
         return SPX_FAILURE;
@@ -2391,10 +2401,10 @@ spx_error_t spx_vec_reorder(spx_vector_t *v, spx_perm_t *p)
     memcpy(v->elements, tmp.data(), v->size * sizeof(spx_value_t));
     vec_touch(v);
     return SPX_SUCCESS;
-}
+} SPX_C_BOUNDARY(return SPX_FAILURE;)
 
 spx_error_t spx_vec_inv_reorder(spx_vector_t *v, spx_perm_t *p)
-{
+try {
     if (p == SPX_INVALID_PERM) {
         SETERROR_1(SPX_ERR_ARG_INVALID, "invalid permutation");
         return SPX_FAILURE;
@@ -2404,16 +2414,16 @@ spx_error_t spx_vec_inv_reorder(spx_vector_t *v, spx_perm_t *p)
     memcpy(v->elements, tmp.data(), v->size * sizeof(spx_value_t));
     vec_touch(v);
     return SPX_SUCCESS;
-}
+} SPX_C_BOUNDARY(return SPX_FAILURE;)
 
 void spx_vec_copy(const spx_vector_t *v1, spx_vector_t *v2)
-{
+try {
     vec_touch(v2);
     memcpy(v2->elements, v1->elements, v1->size * sizeof(spx_value_t));
-}
+} SPX_C_BOUNDARY(return;)
 
 int spx_vec_compare(const spx_vector_t *v1, const spx_vector_t *v2)
-{
+try {
     // relative tolerance 1e-6 per element (Vector.cpp:51-57, :396-413)
     if (v1->size != v2->size) {
         fprintf(stderr, "v1->size=%lu v2->size=%lu differ\n", (unsigned long) v1->size,
@@ -2428,22 +2438,22 @@ int spx_vec_compare(const spx_vector_t *v1, const spx_vector_t *v2)
         }
     }
     return 0;
-}
+} SPX_C_BOUNDARY(return 0;)
 
 void spx_vec_print(const spx_vector_t *v)
-{
+try {
     printf("[ ");
     for (size_t i = 0; i < v->size; i++) printf("%g ", v->elements[i]);
     printf("]\n");
-}
+} SPX_C_BOUNDARY(return;)
 
 void spx_vec_destroy(spx_vector_t *v)
-{
+try {
     if (!v) return;
     vec_forget(v);
     if (v->alloc_type == ALLOC_STD) free(v->elements);
     else if (v->alloc_type == ALLOC_PINNED) device_host_free(v->elements);
     free(v);
-}
+} SPX_C_BOUNDARY(return;)
 
 }  // extern "C"

@@ -381,10 +381,23 @@ void dist_complete(DistPlan *p, double *d_y, bool gather, bool halo, void *strea
 
 // ---- C API -------------------------------------------------------------------------------------
 
+// Nothing leaves a C entry point as an exception -- through `extern "C"` that is std::terminate, and
+// spx_mat_tune alone holds tens of gigabytes at contract size.  Every entry point of this file is a function-try-
+// block that ends with SPX_C_BOUNDARY: what the inner handlers of a function do not catch becomes an error
+// through the handler and the function's failure value, the reference's convention for what cannot be done
+// (include/sparsex/error.h:99-115; src/api/matvec.c:259-322: spx_mat_tune returns SPX_INVALID_MAT).  A failed
+// allocation is SPX_ERR_MEM_ALLOC, which the default handler, like the reference's, treats as fatal (exit(1),
+// src/api/error.c:64-88); a handler set by the client sees the code and the call returns its failure value.
+#define SPX_C_BOUNDARY(RETURN_STATEMENT)                                                                      \
+    catch (const spx::FatalError &e_) { SETERROR_1(SPX_ERR_TUNED_MAT, e_.what.c_str()); RETURN_STATEMENT }      \
+    catch (const std::bad_alloc &) { SETERROR_0(SPX_ERR_MEM_ALLOC); RETURN_STATEMENT }                         \
+    catch (const std::exception &e_) { SETERROR_1(SPX_ERR_TUNED_MAT, e_.what()); RETURN_STATEMENT }            \
+    catch (...) { SETERROR_1(SPX_ERR_TUNED_MAT, "unknown exception"); RETURN_STATEMENT }
+
 extern "C" {
 
 spx_error_t spx_hip_mat_dist_attach(spx_matrix_t *A, const spx_hip_transport_t *t)
-{
+try {
     if (!A || !t) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid argument"); return SPX_FAILURE; }
     try {
         if (A->dist) {
@@ -418,10 +431,10 @@ spx_error_t spx_hip_mat_dist_attach(spx_matrix_t *A, const spx_hip_transport_t *
         return SPX_FAILURE;
     }
     return SPX_SUCCESS;
-}
+} SPX_C_BOUNDARY(return SPX_FAILURE;)
 
 spx_error_t spx_hip_mat_dist_plan(const spx_matrix_t *A, spx_hip_dist_plan_t *plan)
-{
+try {
     if (!A || !plan || !A->dist) {
         SETERROR_1(SPX_ERR_ARG_INVALID, "matrix has no exchange plan (spx_hip_mat_dist_attach)");
         return SPX_FAILURE;
@@ -445,21 +458,21 @@ spx_error_t spx_hip_mat_dist_plan(const spx_matrix_t *A, spx_hip_dist_plan_t *pl
     plan->fix_pos = p.fix_pos.data();
     plan->any_exchange = p.any_exchange ? 1 : 0;
     return SPX_SUCCESS;
-}
+} SPX_C_BOUNDARY(return SPX_FAILURE;)
 
 int spx_hip_mat_dist_parts(const spx_matrix_t *A)
-{
+try {
     return (A && A->dist) ? (int) A->dist->my_chunks : 0;
-}
+} SPX_C_BOUNDARY(return 0;)
 
 int spx_hip_mat_dist_rounds(const spx_matrix_t *A)
-{
+try {
     return (A && A->dist) ? (int) A->dist->rounds : 0;
-}
+} SPX_C_BOUNDARY(return 0;)
 
 spx_error_t spx_hip_mat_dist_round(const spx_matrix_t *A, int round, const size_t **send_off, const size_t **send_cnt,
                                    const size_t **recv_off, const size_t **recv_cnt)
-{
+try {
     if (!A || !A->dist || round < 0 || (size_t) round >= A->dist->rounds || !send_off || !send_cnt || !recv_off || !recv_cnt) {
         SETERROR_1(SPX_ERR_ARG_INVALID, "no such round of the overlapped step");
         return SPX_FAILURE;
@@ -469,10 +482,10 @@ spx_error_t spx_hip_mat_dist_round(const spx_matrix_t *A, int round, const size_
     *recv_off = A->dist->rd_recv_off[(size_t) round].data();
     *recv_cnt = A->dist->rd_recv_cnt[(size_t) round].data();
     return SPX_SUCCESS;
-}
+} SPX_C_BOUNDARY(return SPX_FAILURE;)
 
 spx_error_t spx_hip_mat_dist_halo(const spx_matrix_t *A, spx_hip_dist_halo_t *halo)
-{
+try {
     if (!A || !halo || !A->dist) {
         SETERROR_1(SPX_ERR_ARG_INVALID, "matrix has no exchange plan (spx_hip_mat_dist_attach)");
         return SPX_FAILURE;
@@ -488,6 +501,6 @@ spx_error_t spx_hip_mat_dist_halo(const spx_matrix_t *A, spx_hip_dist_halo_t *ha
     halo->send_off = p.halo_send_off.data();
     halo->send_cnt = p.halo_send_cnt.data();
     return SPX_SUCCESS;
-}
+} SPX_C_BOUNDARY(return SPX_FAILURE;)
 
 }  // extern "C"

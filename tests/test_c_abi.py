@@ -237,3 +237,55 @@ def test_round4_extensions_reject_bad_arguments():
     assert L.spx_hip_mat_info_sized(A.handle, None, 24) == sx.SPX_FAILURE
     assert L.spx_hip_abi_version() == 4
     sx.options_reset()
+
+
+_ALLOC_FAILURE_CHILD = r"""
+import ctypes as C, os, resource, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import sparsex_amd as sx
+from sparsex_amd import synth
+L = sx.lib()
+codes = []
+H = C.CFUNCTYPE(None, C.c_int, C.c_char_p, C.c_ulong, C.c_char_p, C.c_char_p)
+if %(custom)d:
+    handler = H(lambda code, f, line, fn, msg: codes.append(code))
+    L.spx_err_set_handler.argtypes = [H]
+    L.spx_err_set_handler(handler)
+rp, ci, va, n = synth.syn_nlpkkt(34)                  # 2.1 M nonzeros: the tune wants several hundred MB
+sx.options_reset()
+sx.option_set("spx.rt.host_only", "true")
+sx.option_set("spx.rt.nr_threads", "2")
+inp = L.spx_input_load_csr(rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p),
+                           va.ctypes.data_as(C.c_void_p), C.c_int(n), C.c_int(n), C.c_int(0))
+assert inp
+# from here on the address space may not grow by more than a few dozen MB
+with open("/proc/self/statm") as f:
+    now = int(f.read().split()[0]) * os.sysconf("SC_PAGE_SIZE")
+resource.setrlimit(resource.RLIMIT_AS, (now + (48 << 20), now + (48 << 20)))
+A = L.spx_mat_tune(C.c_void_p(inp), 0)
+print("RESULT", "null" if not A else "matrix", sorted(set(codes)), flush=True)
+os._exit(0 if not A else 3)
+"""
+
+
+@pytest.mark.parametrize("custom_handler", [True, False])
+def test_allocation_failure_ends_at_the_c_boundary(custom_handler):
+    """std::bad_alloc (or a thread that cannot be started) inside spx_mat_tune must not cross the C ABI:
+    with a client's error handler installed the call reports SPX_ERR_MEM_ALLOC or SPX_ERR_TUNED_MAT and
+    returns SPX_INVALID_MAT; with the default handler a failed allocation is fatal the reference's way,
+    exit(1) -- never a signal (an exception through extern "C" is std::terminate -> SIGABRT)."""
+    import subprocess, sys
+    from helpers import ROOT
+    code = _ALLOC_FAILURE_CHILD % {"root": ROOT, "custom": 1 if custom_handler else 0}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode >= 0, "killed by signal %d: %s" % (-r.returncode, r.stderr[-2000:])
+    if custom_handler:
+        assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+        assert "RESULT null" in r.stdout
+        # SPX_ERR_TUNED_MAT = 5, SPX_ERR_MEM_ALLOC = 19 (include/sparsex/error.h)
+        got = eval(r.stdout.split("null", 1)[1])
+        assert got and set(got) <= {5, 19}
+    else:
+        assert r.returncode in (0, 1), (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+        assert "terminate called" not in r.stderr
