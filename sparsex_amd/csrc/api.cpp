@@ -249,6 +249,18 @@ try {
         SETERROR_1(SPX_ERR_ARG_INVALID, "invalid values argument");
         return SPX_INVALID_INPUT;
     }
+    // (the row pointers bound everything that is read of colind and values later: they start at the index
+    // base and never step back.  The reference does not look, Csr.hpp:60-70; a library that hands the arrays
+    // to sixty-four host threads and a GPU must)
+    {
+        const spx_index_t base = one_based ? 1 : 0;
+        bool good = rowptr[0] == base;
+        for (spx_index_t r = 0; r < nrows && good; ++r) good = rowptr[r + 1] >= rowptr[r];
+        if (!good) {
+            SETERROR_1(SPX_ERR_ARG_INVALID, "invalid rowptr argument: not ascending from the index base");
+            return SPX_INVALID_INPUT;
+        }
+    }
     spx_input_t *A = new input;
     A->type = 'C';
     A->nrows = nrows;
@@ -651,6 +663,7 @@ static void emit_and_upload(spx_matrix_t *A)
     if (release_after_upload) {
         std::function<void()> f;
         f.swap(release_after_upload);
+        A->release_wait();               // (one release at a time)
         A->release_later(std::move(f));
     }
 }
@@ -664,10 +677,13 @@ static void autotune_launch(spx_matrix_t *A, bool tune_waves, bool tune_spill, b
     // launches per timing: a hundred for a product of microseconds, fewer where one launch takes a
     // millisecond (about 20 ms of launches per timing either way; four timings per variant: on the
     // contract matrix the hundred cost 1.7 s per variant for the same answer)
+    // (nothing of ours may keep the host busy while launches are timed: a timing is as few as eight launches)
+    A->release_wait();
     const double t_est = device_time_spmv(A->dev, 2, 3);
     const int N = (int) std::min(100.0, std::max(8.0, 0.02 / std::max(t_est, 1e-7)));
     const int W = std::max(2, N / 10);
     auto best_time = [&]() {
+        A->release_wait();               // (a re-emission hands its ranges back on a thread of its own)
         double best = device_time_spmv(A->dev, W, N);
         for (int rep = 0; rep < 3; ++rep) best = std::min(best, device_time_spmv(A->dev, 0, N));
         return best;

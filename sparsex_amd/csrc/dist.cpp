@@ -248,10 +248,13 @@ DistPlan *dist_build_plan(const spx_hip_transport_t &t, idx_t own_lo, idx_t own_
 void dist_plan_overlap(DistPlan *p, const std::vector<size_t> &chunk_rows)
 {
     const size_t W = (size_t) p->world, me = (size_t) p->rank;
-    constexpr size_t KMAX = 64;
+    constexpr size_t KMAX = DIST_MAX_CHUNKS;
     const spx_hip_transport_t &t = p->transport;
-    p->my_chunks = chunk_rows.size() > 1 ? std::min(chunk_rows.size() - 1, KMAX) : 0;
-    p->chunk_rows.assign(chunk_rows.begin(), chunk_rows.begin() + (p->my_chunks ? p->my_chunks + 1 : 0));
+    // (a cut into more parts than the exchange has room for must not be shortened here: the device would
+    // still launch, pack and send the parts behind the last one that was planned)
+    if (chunk_rows.size() > KMAX + 1) throw FatalError("overlapped step: more than " + std::to_string(KMAX) + " parts");
+    p->my_chunks = chunk_rows.size() > 1 ? chunk_rows.size() - 1 : 0;
+    p->chunk_rows = p->my_chunks ? chunk_rows : std::vector<size_t>();
     // everybody's part bounds: {K, bounds[0..K]} padded to KMAX + 2 words
     const size_t L = KMAX + 2;
     std::vector<uint64_t> send(L, 0), recv(W * L, 0);
@@ -265,9 +268,10 @@ void dist_plan_overlap(DistPlan *p, const std::vector<size_t> &chunk_rows)
             throw FatalError("transport: host exchange failed");
     }
     std::copy(send.begin(), send.end(), recv.begin() + me * L);
-    size_t R = 1;
+    size_t R = 0;
     for (size_t q = 0; q < W; ++q) R = std::max<size_t>(R, (size_t) recv[q * L]);
     p->rounds = R;
+    if (R == 0) return;               // nobody cuts its product: no overlapped step (spx.rt.dist_chunks <= 1 everywhere)
     // round of a row of process q: the part that holds it (a process without parts: round 0)
     auto round_of = [&](size_t q, idx_t row) -> size_t {
         const size_t K = (size_t) recv[q * L];
@@ -409,13 +413,16 @@ try {
         // the overlapped step (general path, spx.rt.dist_chunks parts; collective as well)
         {
             std::vector<size_t> bounds;
-            const long K = Config::instance().get_long("spx.rt.dist_chunks");
+            // (at most DIST_MAX_CHUNKS parts: what the plan exchange has room for)
+            const long K = std::min<long>((long) DIST_MAX_CHUNKS, Config::instance().get_long("spx.rt.dist_chunks"));
             if (A->dev && !A->symmetric && K > 1) device_plan_chunks(A->dev, (size_t) K, bounds);
             if (!A->dev && !A->symmetric && K > 1 && A->own_hi - A->own_lo >= 2 * K) {
                 // (host-only matrix: equal parts of the rows, so that the plan itself can be tested without a GPU)
                 for (long k = 0; k <= K; ++k) bounds.push_back((size_t) A->own_lo + (size_t)(A->own_hi - A->own_lo) * (size_t) k / (size_t) K);
             }
-            if (K > 1) dist_plan_overlap(A->dist, bounds);
+            // (collective: every process takes part, also one that does not cut its own product -- a process
+            // configured with one part would otherwise leave the others waiting in the exchange of the bounds)
+            dist_plan_overlap(A->dist, bounds);
         }
         // the exchange takes over what the caller-side all-reduce needed: rows this
         // process neither owns nor adds to are nobody's business any more

@@ -16,6 +16,8 @@ namespace spx {
 
 struct DistDevice;     // device arrays of a plan (dist_kernels.hip)
 
+constexpr size_t DIST_MAX_CHUNKS = 64;     // parts of the own product in the overlapped step (spx.rt.dist_chunks is clamped to it)
+
 struct DistPlan {
     spx_hip_transport_t transport;
     int rank = 0, world = 1;

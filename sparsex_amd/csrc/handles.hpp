@@ -11,6 +11,7 @@
 #include "input.hpp"
 #include "xwindows.hpp"
 
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -50,12 +51,25 @@ struct matrix {
     // back: 1.6 s for the 25 GB of the contract matrix on sixteen threads, and nothing waits for it); the
     // threads are joined when the matrix goes
     std::vector<std::thread> release_threads;
-    template <class F> void release_later(F &&f) { release_threads.emplace_back(std::forward<F>(f)); }
-    ~matrix()
+    // (a thread that cannot be started does the work here and now: the closure must run, it owns the memory)
+    template <class F> void release_later(F &&f)
+    {
+        std::function<void()> work(std::forward<F>(f));
+        try {
+            release_threads.emplace_back([work] { work(); });
+        } catch (const std::exception &) {
+            work();
+        }
+    }
+    // waits for what is still being handed back: before anything is timed (the threads keep every host CPU
+    // and the kernel's mmap lock busy), before a new release starts, and when the matrix goes
+    void release_wait()
     {
         for (std::thread &t : release_threads)
             if (t.joinable()) t.join();
+        release_threads.clear();
     }
+    ~matrix() { release_wait(); }
     std::vector<std::vector<val_t>> diag;   // symmetric: per owned partition
     std::vector<std::unique_ptr<CsxStream>> exported;
     std::vector<std::vector<spx_index_t>> exported_rows_info;

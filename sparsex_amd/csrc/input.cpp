@@ -402,18 +402,26 @@ bool csr_view(MatrixInput &in, CsrView &v)
     v.values = c->values_;
     v.nrows = in.nr_rows;
     v.base = c->zero_based_ ? 0 : 1;
+    // the row pointers first, on their own: they start at the base, never step back and end at the element
+    // count -- only then do they bound what is read of colind (a pointer array like [0, 5, 1000000] with ten
+    // elements must end in "element count mismatch" from the general walk, not in a read far behind colind)
+    if (v.rowptr[0] != v.base || v.rowptr[v.nrows] < v.base || v.at(v.nrows) != in.nnz) return false;
     std::atomic<bool> ok(true);
     const size_t CH = 1 << 16, nch = (v.nrows + CH - 1) / CH;
     parallel_for(nch, host_threads(), [&](size_t k) {
+        const size_t r1 = std::min(v.nrows, (k + 1) * CH);
+        for (size_t r = k * CH; r < r1; ++r)
+            if (v.rowptr[r + 1] < v.rowptr[r]) { ok = false; return; }
+    });
+    if (!ok.load()) return false;
+    parallel_for(nch, host_threads(), [&](size_t k) {
         if (!ok.load(std::memory_order_relaxed)) return;
         const size_t r1 = std::min(v.nrows, (k + 1) * CH);
-        for (size_t r = k * CH; r < r1; ++r) {
-            if (v.rowptr[r + 1] < v.rowptr[r] || v.rowptr[r] < v.base) { ok = false; return; }
+        for (size_t r = k * CH; r < r1; ++r)
             for (size_t j = v.at(r) + 1; j < v.at(r + 1); ++j)
                 if (v.colind[j] <= v.colind[j - 1]) { ok = false; return; }
-        }
     });
-    return ok.load() && v.at(v.nrows) == in.nnz;
+    return ok.load();
 }
 
 // last row in [lo, hi) that holds an element, or hi if none does

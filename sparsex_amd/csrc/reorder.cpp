@@ -156,6 +156,13 @@ void dist_reorder_csr(const idx_t *rowptr, const idx_t *colind, size_t n, bool z
 {
     if (world < 1) throw FatalError("dist reorder: bad number of processes");
     const idx_t base = zero_based ? 0 : 1;
+    // (the arrays are the caller's: row pointers that start at the base and never step back, columns inside
+    // the matrix -- checked before either branch walks them)
+    if (n && rowptr[0] != base) throw FatalError("dist reorder: row pointers do not start at the index base");
+    for (size_t v = 0; v < n; ++v)
+        if (rowptr[v + 1] < rowptr[v]) throw FatalError("dist reorder: row pointers step back");
+    for (idx_t k = 0; n && k < rowptr[n] - base; ++k)
+        if (colind[k] < base || (size_t)(colind[k] - base) >= n) throw FatalError("dist reorder: column outside the matrix");
     std::vector<size_t> weight(n);
     for (size_t v = 0; v < n; ++v) weight[v] = (size_t)(rowptr[v + 1] - rowptr[v]);
     std::vector<idx_t> order;

@@ -102,3 +102,23 @@ def test_gpu_empty_matrix():
     y = np.arange(30, dtype=np.float64)
     A.matvec_kernel(1.0, np.ones(20), 3.0, y)
     assert np.array_equal(y, 3.0 * np.arange(30))
+
+
+def test_malformed_row_pointers_do_not_read_behind_colind():
+    """Row pointers that step back ([0, 1000000, 10]: ten elements by the last pointer, which is how the C API
+    learns the element count, Csr.hpp:66) must be refused before anything is read at colind[1000000]."""
+    import ctypes as C
+    L = sx.lib()
+    rp = np.array([0, 1000000, 10], dtype=np.int32)
+    ci = np.arange(10, dtype=np.int32)
+    va = np.ones(10)
+    sx.options_reset()
+    sx.option_set("spx.rt.host_only", "true")
+    inp = L.spx_input_load_csr(rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p),
+                               va.ctypes.data_as(C.c_void_p), C.c_int(2), C.c_int(2000000), C.c_int(0))
+    assert not inp
+    # the partition-aware renumbering validates its arrays on every path
+    for sym in (False, True):
+        with pytest.raises(sx.SpxError):
+            sx.dist_reorder(rp, ci, 2, 2, pattern_symmetric=sym)
+    sx.options_reset()

@@ -152,7 +152,7 @@ def _slice_worker(rank, world, port, symmetric, gen, tmpdir, ret, parts=None):
         # entry travels exactly once, and after the last round the halo is what the one-shot exchange brought
         rounds = A.dist_rounds()
         if not symmetric:
-            assert len(rounds) == (max(parts) if parts else 4)
+            assert len(rounds) == (min(64, max(parts)) if parts else 4)
             y2 = y.copy()
             y2[halo["recv_cols"]] = np.nan
             sendbuf = y[halo["send_rows"]].copy()
@@ -211,4 +211,19 @@ def test_rounds_with_different_part_counts_gloo(tmp_path):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_slice_worker, args=(world, port, False, "nlpkkt", str(tmp_path), ret, [2, 5, 3]), nprocs=world, join=True)
+    assert all(ret[r][0] for r in range(world))
+
+
+def test_rounds_when_one_rank_does_not_cut_and_one_asks_for_too_many_gloo(tmp_path):
+    """A rank configured with ONE part takes part in the (collective) planning all the same -- it used to skip
+    the exchange of the part bounds and leave the others waiting -- and a rank that asks for more parts
+    than the plan has room for gets the 64 the plan allows, not a truncated list."""
+    world = 3
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_slice_worker, args=(world, port, False, "nlpkkt", str(tmp_path), ret, [1, 200, 3]), nprocs=world, join=True)
     assert all(ret[r][0] for r in range(world))
