@@ -2008,13 +2008,12 @@ try {
     if (check_dev(A, x_dev, y_dev) != SPX_SUCCESS) return SPX_FAILURE;
     try {
         std::vector<size_t> bounds;
-        const size_t K = (A->symmetric || parts < 2) ? 0 : device_plan_chunks(A->dev, (size_t) parts, bounds);
+        // (a cut of its own, slot 1: the one an attached exchange plan walks is left alone)
+        const size_t K = (A->symmetric || parts < 2) ? 0 : device_plan_chunks(A->dev, (size_t) parts, bounds, 1);
         if (K == 0) {
             device_spmv(A->dev, alpha, x_dev, beta, y_dev, stream);
         } else {
-            for (size_t k = 0; k < K; ++k) device_spmv_chunk(A->dev, k, alpha, x_dev, beta, y_dev, stream);
-            // (an attached plan keeps its own cut: put it back)
-            if (A->dist && A->dist->my_chunks && A->dist->my_chunks != K) device_plan_chunks(A->dev, A->dist->my_chunks, bounds);
+            for (size_t k = 0; k < K; ++k) device_spmv_chunk(A->dev, k, alpha, x_dev, beta, y_dev, stream, 1);
         }
         if (launched) *launched = K ? (int) K : 1;
     } catch (const FatalError &e) {
@@ -2053,13 +2052,6 @@ try {
 // ======================================================================================
 
 int spx_hip_abi_version(void) { return SPX_HIP_ABI_VERSION; }
-
-// (experiment builds only, tools/build_variant.sh -DSPX_XW_PROFILE: shader clocks per phase of a workgroup of
-// csx_spmv_xw_kernel, summed since the last call; SPX_FAILURE in a regular build)
-spx_error_t spx_hip_debug_counters(unsigned long long out[8])
-try {
-    return out && spmv_xw_profile(out) ? SPX_SUCCESS : SPX_FAILURE;
-} SPX_C_BOUNDARY(return 0;)
 
 spx_error_t spx_hip_mat_unit_windows(spx_matrix_t *A, uint32_t budget, uint32_t gap, spx_hip_xw_plan_t *out)
 try {

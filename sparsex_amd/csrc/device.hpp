@@ -31,9 +31,10 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
 // the exchange of a row-partitioned matrix can start on the rows of part k while part k + 1 is
 // computed (dist.cpp).  Plain general streams only: device_plan_chunks returns 0 for the others;
 // `row_bounds` receives the first row of every part and the end of the own rows.
-size_t device_plan_chunks(DeviceMatrix *m, size_t K, std::vector<size_t> &row_bounds);
+// `slot`: 0 = the cut of an attached exchange plan, 1 = a caller's own (spx_hip_matvec_parts): independent of each other
+size_t device_plan_chunks(DeviceMatrix *m, size_t K, std::vector<size_t> &row_bounds, int slot = 0);
 void device_spmv_chunk(DeviceMatrix *m, size_t k, double alpha, const double *d_x, double beta,
-                       double *d_y, void *stream);
+                       double *d_y, void *stream, int slot = 0);
 
 // host-vector convenience path used by spx_matvec_*: H2D x (and y when
 // beta != 0), kernel, D2H y; synchronous.  Vectors the library allocated itself
@@ -88,10 +89,6 @@ void device_set_xw(DeviceMatrix *m, bool on);
 bool device_get_xw(const DeviceMatrix *m);
 void device_xw_info(const DeviceMatrix *m, uint64_t &elems_lds, uint64_t &unit_elems, uint64_t &staged_doubles,
                     uint32_t &lds_bytes);
-
-// experiment builds (-DSPX_XW_PROFILE): clock counters of csx_spmv_xw_kernel's workgroups, read and cleared;
-// false in a regular build
-bool spmv_xw_profile(unsigned long long out[8]);
 
 // seconds per SpMV (alpha = 1, beta = 0) over `launches` back-to-back launches
 // on a private stream with scratch vectors -- what spx_mat_tune() measures to

@@ -670,10 +670,15 @@ struct DeviceMatrix {
     // matrix overlaps with the product): work in front of every row-block, its first row
     std::vector<uint64_t> rb_upto;
     std::vector<uint32_t> rb_row0;
-    std::vector<XcdSplit> chunk_split;
-    std::vector<uint32_t> chunk_longest;
-    std::vector<size_t> chunk_bounds;
-    size_t chunk_asked = 0;
+    // (two cuts side by side: slot 0 belongs to an attached exchange plan, slot 1 to spx_hip_matvec_parts --
+    // a caller's ad-hoc cut must not change the one an overlapped step on another stream is walking)
+    struct ChunkPlan {
+        std::vector<XcdSplit> split;
+        std::vector<uint32_t> longest;
+        std::vector<size_t> bounds;
+        size_t asked = 0;
+    };
+    ChunkPlan chunks[2];
     // unit windows of x in LDS (xwindows.hpp; plain general streams): a second set of pass headers and
     // descriptors for csx_spmv_xw_kernel, the window table, the LDS a launch needs
     SpxPass *passes_xw = nullptr;
@@ -1192,16 +1197,17 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
 // (general path, plain stream: one launch phase, no column slices, no rows split over row-blocks,
 // stream order = row order).  Returns the number of parts (0: this stream cannot be cut) and the
 // first row of every part (+ the end) in `row_bounds`.
-size_t device_plan_chunks(DeviceMatrix *m, size_t K, std::vector<size_t> &row_bounds)
+size_t device_plan_chunks(DeviceMatrix *m, size_t K, std::vector<size_t> &row_bounds, int slot)
 {
-    if (K >= 2 && K == m->chunk_asked && !m->chunk_split.empty()) {      // (the same cut as last time)
-        row_bounds = m->chunk_bounds;
-        return m->chunk_split.size();
+    DeviceMatrix::ChunkPlan &cp = m->chunks[slot ? 1 : 0];
+    if (K >= 2 && K == cp.asked && !cp.split.empty()) {      // (the same cut as last time)
+        row_bounds = cp.bounds;
+        return cp.split.size();
     }
     row_bounds.clear();
-    m->chunk_split.clear();
-    m->chunk_longest.clear();
-    m->chunk_asked = K;
+    cp.split.clear();
+    cp.longest.clear();
+    cp.asked = K;
     const size_t n = m->n_rb;
     if (m->symmetric || m->accum || m->n_shared || m->xcd_split.size() != 1 || !m->launch_order.empty() ||
         n < 64 || K < 2 || m->rb_upto.size() != n + 1)
@@ -1228,23 +1234,24 @@ size_t device_plan_chunks(DeviceMatrix *m, size_t K, std::vector<size_t> &row_bo
         xs.first[8] = (uint32_t) hi;
         uint32_t longest = 0;
         for (uint32_t x = 0; x < 8; ++x) longest = std::max(longest, xs.first[x + 1] - xs.first[x]);
-        m->chunk_split.push_back(xs);
-        m->chunk_longest.push_back(longest);
+        cp.split.push_back(xs);
+        cp.longest.push_back(longest);
         row_bounds.push_back(lo < n ? (size_t) m->rb_row0[lo] : m->own_hi);
     }
     row_bounds[0] = m->own_lo;
     row_bounds.push_back(m->own_hi);
-    m->chunk_bounds = row_bounds;
+    cp.bounds = row_bounds;
     return K;
 }
 
-void device_spmv_chunk(DeviceMatrix *m, size_t k, double alpha, const double *d_x, double beta, double *d_y, void *stream_)
+void device_spmv_chunk(DeviceMatrix *m, size_t k, double alpha, const double *d_x, double beta, double *d_y, void *stream_, int slot)
 {
-    if (k >= m->chunk_split.size()) throw FatalError("no such part of the stream (device_plan_chunks)");
+    const DeviceMatrix::ChunkPlan &cp = m->chunks[slot ? 1 : 0];
+    if (k >= cp.split.size()) throw FatalError("no such part of the stream (device_plan_chunks)");
     m->launched_since_edit = true;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const XcdSplit xs = m->chunk_split[k];
-    const uint32_t blocks = 8u * m->chunk_longest[k];
+    const XcdSplit xs = cp.split[k];
+    const uint32_t blocks = 8u * cp.longest[k];
     if (!blocks) return;
     // (the launch tuner may have settled on a y tile per wavefront: the same parts through that kernel)
     const size_t lds = (m->wave_tiles ? (size_t) m->waves : 1u) * m->lds_doubles * sizeof(double);

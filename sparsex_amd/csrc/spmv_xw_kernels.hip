@@ -148,32 +148,16 @@ __device__ __forceinline__ void xw_finish_pass(uint2 q, uint32_t segl, uint32_t 
                          ? step : (kind == SPX_KIND_ADIAG ? -step : 0);
     const int row = (int) (row0 + (bits & 511u)) + s * drow;
     const double *xp = xw + (int) (c0 + (uint32_t) (s * dcol));      // (c0: an offset into the unit windows)
-#ifdef SPX_XW_ABL_NOX          // (variant builds, tools/build_variant.sh: results wrong on purpose)
-    const double one[4] = {1.0, 1.0, 1.0, 1.0};
-    xp = one;
-#endif
     double t = va.x * xp[0];
     if (W >= 2) t = fma(va.y, xp[1], t);
     if (W >= 3) t = fma(vb.x, xp[2], t);
     if (W >= 4) t = fma(vb.y, xp[3], t);
-#ifdef SPX_XW_ABL_NOADD
-    if (t == 1.2345e300 && row == 12345) atomicAdd(&tile[row], t);
-#else
     if (segl >> 16) atomicAdd(&tile[row], t);
-#endif
 }
 
 template <int B>
 __device__ __forceinline__ void xw_finish(const XwStage<B> &S, double *tile, const double *xw)
 {
-#ifdef SPX_XW_ABL_NOFINISH     // (variant build: the loaded values are only consumed)
-#pragma unroll
-    for (int b = 0; b < B; ++b) {
-        const double t = S.va[b].x + S.vb[b].x;
-        if (t == 1.2345e300 && S.q[b].y == 12345u) atomicAdd(&tile[0], t);
-    }
-    return;
-#endif
 #pragma unroll
     for (int b = 0; b < B; ++b) {
         switch (S.width[b]) {          // wave-uniform
@@ -297,40 +281,15 @@ __device__ __forceinline__ void xw_run(const KernelArgs &a, const SpxRowBlock &r
 #undef SPX_XW_HEADERS
 }
 
-#ifdef SPX_XW_PROFILE
-// (variant build: where a workgroup's life goes -- shader clock stamps of wavefront 0 of every workgroup of
-// the LAST launch, eight per row-block: [0] start, [1] row-block header there, [2] first barrier passed,
-// [3] its passes done, [4] second barrier passed, [5] end; written to a file by spmv_xw_profile)
-__device__ long long *spx_xw_prof_buf;
-static long long *g_prof_dev = nullptr;
-static size_t g_prof_rb = 0;
-#define SPX_XW_TICK(k)                                                                            \
-    do {                                                                                          \
-        if (threadIdx.x == 0 && spx_xw_prof_buf) spx_xw_prof_buf[(size_t) rb_idx * 8u + (k)] = clock64();   \
-    } while (0)
-#else
-#define SPX_XW_TICK(k) do { } while (0)
-#endif
-
 template <int WAVES>
 __device__ __forceinline__ void spmv_body_xw(const KernelArgs &a, const XcdSplit &xs, double *lds)
 {
-#ifdef SPX_XW_PROFILE
-    const long long tick0_ = clock64();
-#endif
     constexpr int BLOCK_THREADS = 64 * WAVES;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t xcd = blockIdx.x & 7u;
     const uint32_t rb_idx = xs.first[xcd] + (blockIdx.x >> 3);
     if (rb_idx >= xs.first[xcd + 1u]) return;
-#ifdef SPX_XW_PROFILE
-    if (threadIdx.x == 0 && spx_xw_prof_buf) {
-        spx_xw_prof_buf[(size_t) rb_idx * 8u] = tick0_;
-        spx_xw_prof_buf[(size_t) rb_idx * 8u + 6u] = (long long) __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
-        spx_xw_prof_buf[(size_t) rb_idx * 8u + 7u] = (long long) wall_clock64();
-    }
-#endif
 
     // first round trip: the row-block header, the table of its unit windows (one entry per lane; handed to
     // the whole wavefront with v_readlane), the wavefront's first two pass headers (scalar), and -- on their
@@ -342,9 +301,6 @@ __device__ __forceinline__ void spmv_body_xw(const KernelArgs &a, const XcdSplit
     const uint2 xw_entry = *reinterpret_cast<const uint2 *>(a.xw_tab + (size_t) rb_idx * XW_TAB + (lane & (XW_TAB - 1)));
     PassWords c0 = load_pass(passes, wave), c1 = load_pass(passes, wave + WAVES);       // (the table is padded)
     const int n_rows = rb.n_rows;
-#ifdef SPX_XW_PROFILE
-    if (n_rows >= 0) SPX_XW_TICK(1);
-#endif
     double *tile = lds;
     for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS) lds[i] = 0.0;
     double *win = lds + n_rows;
@@ -362,7 +318,6 @@ __device__ __forceinline__ void spmv_body_xw(const KernelArgs &a, const XcdSplit
     const int lo = (int) (range & 0xffffu), hi = (int) (range >> 16);
     uint32_t *hdr = reinterpret_cast<uint32_t *>(xw + xw_total);
     uint32_t odd_base = 0, odd_at = 0xffffffffu;
-#ifndef SPX_XW_ABL_NOSTAGE
 #pragma unroll
     for (uint32_t k = 0; k < XW_MAX; ++k) {
         const uint32_t base = (uint32_t) __builtin_amdgcn_readlane((int) xw_entry.x, (int) (XW_RANGES + k));
@@ -380,7 +335,6 @@ __device__ __forceinline__ void spmv_body_xw(const KernelArgs &a, const XcdSplit
             odd_at = off + len - 1u;
         }
     }
-#endif
     if (odd_at != 0xffffffffu && threadIdx.x == 0) xw[odd_at] = a.x[odd_base];
     // ... and the pass headers behind them, the same way: pass_stride + 4 WAVES of them (the table is padded),
     // a kilobyte per wavefront and step
@@ -403,7 +357,6 @@ __device__ __forceinline__ void spmv_body_xw(const KernelArgs &a, const XcdSplit
         xw_issue<2>(a, rb, {c0, c1}, A, lane);
     }
     __syncthreads();
-    SPX_XW_TICK(2);
 
     if (n_first > 0) xw_run<WAVES>(a, rb, hdr, hi, n_first, t, A, tile, xw, lane);
     while (t < n_pass) {
@@ -420,9 +373,7 @@ __device__ __forceinline__ void spmv_body_xw(const KernelArgs &a, const XcdSplit
         if (t + WAVES < n_pass) xw_one(a, rb, c1, tile, win, xw, lane);
         t += 2 * WAVES;
     }
-    SPX_XW_TICK(3);
     __syncthreads();
-    SPX_XW_TICK(4);
 
     if (rb.flags & SPX_RB_SHARED) {
         if (threadIdx.x == 0) a.carry[rb.carry_slot] = tile[0];
@@ -434,7 +385,6 @@ __device__ __forceinline__ void spmv_body_xw(const KernelArgs &a, const XcdSplit
             a.y[g] = tt;
         }
     }
-    SPX_XW_TICK(5);
 }
 
 template <int WAVES>
@@ -450,15 +400,6 @@ void csx_spmv_xw_kernel(SPX_KERNEL_PARAMS, const XwEntry *xw_tab_)
 void launch_spmv_xw(int waves, unsigned blocks, size_t lds_bytes, void *stream_, const KernelArgs &a, const XcdSplit &xs)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-#ifdef SPX_XW_PROFILE
-    if (getenv("SPX_XW_PROFILE_OUT") && g_prof_rb < a.n_rb) {
-        if (g_prof_dev) (void) hipFree(g_prof_dev);
-        g_prof_rb = a.n_rb;
-        (void) hipMalloc(reinterpret_cast<void **>(&g_prof_dev), g_prof_rb * 64);
-        (void) hipMemset(g_prof_dev, 0, g_prof_rb * 64);
-        (void) hipMemcpyToSymbol(HIP_SYMBOL(spx_xw_prof_buf), &g_prof_dev, sizeof(g_prof_dev));
-    }
-#endif
 #define SPX_LAUNCH_XW(W)                                                                           \
     hipLaunchKernelGGL(csx_spmv_xw_kernel<W>, dim3(blocks), dim3(64 * W), lds_bytes, stream, a.rbs,  \
                        a.passes, a.n_rb, a.pass_stride, xs, a.values, a.descs, a.cidx, a.segrows,   \
@@ -468,26 +409,6 @@ void launch_spmv_xw(int waves, unsigned blocks, size_t lds_bytes, void *stream_,
     else if (waves == 8) SPX_LAUNCH_XW(8);
     else SPX_LAUNCH_XW(4);
 #undef SPX_LAUNCH_XW
-}
-
-// (variant build with -DSPX_XW_PROFILE: the stamps of the last launch go to the file SPX_XW_PROFILE_OUT names)
-bool spmv_xw_profile(unsigned long long out[8])
-{
-#ifdef SPX_XW_PROFILE
-    const char *path = getenv("SPX_XW_PROFILE_OUT");
-    if (!path || !g_prof_dev || hipDeviceSynchronize() != hipSuccess) return false;
-    std::vector<long long> h(g_prof_rb * 8);
-    if (hipMemcpy(h.data(), g_prof_dev, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return false;
-    FILE *f = fopen(path, "wb");
-    if (!f) return false;
-    fwrite(h.data(), 8, h.size(), f);
-    fclose(f);
-    out[0] = g_prof_rb;
-    return true;
-#else
-    (void) out;
-    return false;
-#endif
 }
 
 // row-blocks whose windows need more than the default 64 KB of dynamic LDS

@@ -87,23 +87,6 @@ def main():
             torch.cuda.synchronize()
             ts.append(1e-3 * e0.elapsed_time(e1) / args.steps)
         t = float(np.median(ts))
-        if os.environ.get("SPX_XW_PROFILE_OUT"):         # (variant build with -DSPX_XW_PROFILE)
-            import ctypes
-            buf = (ctypes.c_ulonglong * 8)()
-            if sx.lib().spx_hip_debug_counters(buf) == 0:
-                st = np.fromfile(os.environ["SPX_XW_PROFILE_OUT"], dtype=np.int64).reshape(-1, 8)
-                st = st[st[:, 5] > 0]
-                d = np.diff(st[:, :6], axis=1).astype(np.float64)
-                life = (st[:, 5] - st[:, 0]).astype(np.float64)
-                names = ["header", "to barrier", "passes (wave 0)", "wait at barrier", "write-out"]
-                print("PROFILE %s: %d workgroups, shader clocks: life median %.0f mean %.0f p90 %.0f" % (
-                    name, len(st), np.median(life), life.mean(), np.percentile(life, 90)))
-                for k, nm in enumerate(names):
-                    print("PROFILE   %-16s median %7.0f mean %7.0f p90 %7.0f  (%.1f %% of the mean life)" % (
-                        nm, np.median(d[:, k]), d[:, k].mean(), np.percentile(d[:, k], 90), 100.0 * d[:, k].mean() / life.mean()))
-                span = float(st[:, 5].max() - st[:, 0].min())
-                print("PROFILE   first start to last end %.0f clocks; sum of lives / span = %.1f workgroups in flight" % (
-                    span, life.sum() / span), flush=True)
         xw = "xw %d KB LDS" % (info.unit_window_lds // 1024) if info.unit_windows else "-"
         print("| %s | %s | %s | %.2f | %.1f | %.3f | %d | %d | %d, %s | %.2f | %.2f | %.3f |" % (
             label, "symmetric" if args.symmetric else "general", name if not body else "%s (`%s`)" % (name, body),
