@@ -77,8 +77,16 @@
  *   spx.rt.dist_chunks      SPX_DIST_OVERLAP: parts the own product is cut into (default 4; 1: no rounds planned --
  *                           on every process or on none: planning the rounds is collective; the counts may differ)
  *   spx.gpu.x_window        "false": leftovers never gather from an LDS window of x
- *   spx.vec.device          "true": vectors the library creates keep x's HBM copy
- *                           between spx_matvec_* calls
+ *   spx.gpu.unit_windows    general path: "auto" (default: measured at tune time) | "true" | "false" -- the columns a
+ *                           row-block's unit passes read are staged in LDS once per workgroup and the unit passes run
+ *                           as a software pipeline (csx_spmv_xw_kernel); spx.gpu.unit_window_doubles (3072): most
+ *                           doubles of x a row-block may stage (row-blocks that need more gather through L2);
+ *                           spx.gpu.unit_window_gap (16): column intervals closer than this are staged as one
+ *   spx.vec.device          "true" (default): vectors the library creates (spx_vec_create*, page-locked) keep x's HBM
+ *                           copy between spx_matvec_* calls: the copy is reused while no spx_vec_* call has changed the
+ *                           vector and a fingerprint of its contents stands (a client that pokes single elements
+ *                           through v->elements sets "false"); views of user buffers (SPX_VEC_AS_IS) always travel
+ *   spx.rt.dist_chunks      at most 64 parts (larger values are clamped)
  *   spx.gpu.sym_once        "false": symmetric path reads lower triangle and mirror
  *                           image (default: dense 8x8 tiles are read once)
  *   spx.gpu.sym_remine      "false": symmetric path mirrors unit by unit

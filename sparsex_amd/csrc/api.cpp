@@ -43,11 +43,14 @@ enum { ALLOC_STD = 1, ALLOC_OTHER = 4,          // Vector.cpp:36-41
        ALLOC_PINNED = 8 };                      // this build: page-locked, copied to/from HBM directly
 enum { VEC_MODE_INVALID = 45 };                // Vector.cpp:43-47
 
-// spx.vec.device: vectors the library created carry a version that every
-// spx_vec_* mutator advances; spx_matvec_* reuse x's copy in HBM while it stands
-// (a relinked reference client's 128-loop, test/src/sparsex_test.c:161-163,
-// uploads x once).  Opt-in: a caller that writes through v->elements directly
-// must not use it.
+// spx.vec.device (default true): vectors the library created (spx_vec_create, spx_vec_create_random,
+// spx_vec_create_from_buff with SPX_VEC_TUNE -- page-locked memory of the library's own) carry a version that
+// every spx_vec_* mutator advances; spx_matvec_* reuse x's copy in HBM while it stands: a relinked reference
+// client's 128-loop (test/src/sparsex_test.c:161-163) or one of its examples uploads x once and pays the way
+// back of y only.  Views of user buffers (SPX_VEC_AS_IS) are never tracked.  `struct vector_struct` is public,
+// so a client CAN write through v->elements behind the library's back; the version handed to the device side
+// therefore includes a fingerprint of the contents (a few hundred samples and both ends: a rewritten vector
+// is seen, a single poked element may not be -- such a client sets spx.vec.device=false).
 std::mutex g_vec_mtx;
 std::unordered_map<const spx_vector_t *, uint64_t> g_vec_version;
 std::atomic<uint64_t> g_version_clock(1);
@@ -74,9 +77,28 @@ void vec_forget(const spx_vector_t *v)
 
 uint64_t vec_version(const spx_vector_t *v)
 {
-    std::lock_guard<std::mutex> lk(g_vec_mtx);
-    auto it = g_vec_version.find(v);
-    return it == g_vec_version.end() ? 0 : it->second;
+    uint64_t ver = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_vec_mtx);
+        auto it = g_vec_version.find(v);
+        if (it == g_vec_version.end()) return 0;
+        ver = it->second;
+    }
+    // fingerprint: 509 samples spread over the vector, its first and last elements
+    uint64_t h = 0xCBF29CE484222325ull ^ (uint64_t) v->size;
+    auto mix = [&h](double d) {
+        uint64_t b;
+        memcpy(&b, &d, sizeof(b));
+        h = (h ^ b) * 0x100000001B3ull;
+    };
+    const size_t n = v->size;
+    if (n) {
+        const size_t step = n / 509 + 1;
+        for (size_t i = 0; i < n; i += step) mix(v->elements[i]);
+        mix(v->elements[n - 1]);
+    }
+    const uint64_t out = ver * 0x9E3779B97F4A7C15ull ^ h;
+    return out ? out : 1;
 }
 
 double now_sec()

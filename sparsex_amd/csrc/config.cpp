@@ -40,7 +40,7 @@ void Config::reset_defaults()
     props_["spx.rt.gpu_rank"] = "0";         // this process' slice of the partitions
     props_["spx.rt.gpu_world"] = "1";
     props_["spx.rt.device"] = "-1";          // HIP device ordinal, -1 = current
-    props_["spx.vec.device"] = "false";      // vectors the library creates keep their HBM copy between calls
+    props_["spx.vec.device"] = "true";       // vectors the library creates keep their HBM copy between calls (false: every call uploads x)
     props_["spx.rt.dist_chunks"] = "4";      // SPX_DIST_OVERLAP: parts of the own product the halo exchange is pipelined over (1: no plan)
     props_["spx.rt.dist_reorder"] = "none";  // with gpu_world > 1 and the whole matrix: none | rcm | rcm_owner in front of the cut
     props_["spx.rt.row_offset"] = "0";       // the input holds rows [offset, offset + its rows) ...

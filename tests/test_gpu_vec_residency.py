@@ -1,4 +1,4 @@
-"""spx.vec.device (opt-in): vectors created by the library carry a version that every
+"""spx.vec.device (default on): vectors created by the library carry a version that every
 spx_vec_* mutator advances; spx_matvec_* reuse x's copy in HBM while the version stands, so
 the 128-loop of a relinked reference client (test/src/sparsex_test.c:161-163) uploads x once.
 Results must follow every change made through the API."""
@@ -48,6 +48,11 @@ def test_x_stays_in_hbm_between_calls(resident):
     check_y(csr, xa.copy(), ya.copy(), 0.5)
     assert L.spx_vec_set_entry(x, 5, 7.25, sx.SPX_INDEX_ZERO_BASED) == 0
     assert xa[5] == 7.25
+    assert L.spx_matvec_mult(0.5, C.c_void_p(A.handle), x, y) == 0
+    check_y(csr, xa.copy(), ya.copy(), 0.5)
+    # a client that rewrites the vector through the public struct, behind the library's back: the fingerprint
+    # of the contents sees it and x travels again
+    xa[:] = np.cos(np.arange(n))
     assert L.spx_matvec_mult(0.5, C.c_void_p(A.handle), x, y) == 0
     check_y(csr, xa.copy(), ya.copy(), 0.5)
     t0 = time.perf_counter()
