@@ -650,6 +650,26 @@ def measured_traffic(key, kernel=None):
     return e["hbm_bytes_per_launch"]
 
 
+def traffic_range(key, kernel, info):
+    """[low, high] for `traffic`: FETCH_SIZE counts 32-byte units for wide coalesced reads (hence its doubling, the
+    guide's gfx950 correction) but 64 bytes per scattered 8-byte miss (profiles/r02/fetch_size_calibration.txt), so
+    the doubling is right for the coalesced share of the reads -- the values and the index, whose bytes are known --
+    and anything between x 1 and x 2 for the rest (x: gathers through L2, or the coalesced staging of the unit
+    windows).  high = the doubled figure (`traffic`), low = the rest counted once."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            e = json.load(f)[key]
+    except (OSError, KeyError, ValueError):
+        return None
+    high = measured_traffic(key, kernel)
+    if high is None or "fetch_size_kib_per_launch" not in e:
+        return None
+    counted = 1024.0 * e["fetch_size_kib_per_launch"]                       # counter units as bytes, before the doubling
+    coalesced = 0.5 * (float(info.value_bytes) + float(info.index_bytes))   # ... of which the stream, at half weight
+    rest = max(0.0, counted - coalesced)
+    return [int(high - rest), int(high)]
+
+
 def traffic_note(key, kernel):
     """Why `traffic` is null although the configuration was profiled."""
     try:
@@ -800,6 +820,7 @@ def run_config(torch, sx, name, symmetric, steps, warmup, cpu_budget, T, csr=Non
                         "kernel": kernel_name(info, symmetric, 1), "avg_launch_us": round(1e6 * launch_s, 3),
                         "algorithmic_bytes_per_launch": int(b_alg),
                         "traffic": measured_traffic(traffic_key or (name + ("-sym" if symmetric else "")), kernel_name(info, symmetric, 1)),
+                        "traffic_range": traffic_range(traffic_key or (name + ("-sym" if symmetric else "")), kernel_name(info, symmetric, 1), info),
                         "traffic_source": traffic_note(traffic_key or (name + ("-sym" if symmetric else "")), kernel_name(info, symmetric, 1))},
            "cache_resident": bool(info.value_bytes + info.index_bytes < MALL_BYTES),
            "index_bytes_per_nnz": round(info.index_bytes / max(int(info.nnz_stored), 1), 3),
@@ -1143,6 +1164,7 @@ def run_path(ctx, args, symmetric):
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": measured_traffic(tkey, kernel_name(info, symmetric, world)) if std else None,
+                     "traffic_range": traffic_range(tkey, kernel_name(info, symmetric, world), info) if std else None,
                      "traffic_source": traffic_note(tkey, kernel_name(info, symmetric, world)) if std else None,
                      "kernel": kernel_name(info, symmetric, world),
                      "algorithmic_bytes_per_launch": int(b_alg),
@@ -1302,6 +1324,10 @@ def main():
                 note += "(the whole edge-%d matrix: --cpu-baseline-full; the default run keeps to the sample so that it " \
                         "finishes within minutes) " % args.edge
             out["cpu_baseline"] = cpu_baseline(csr_s, args.symmetric, 30.0, note)
+            # (what the number was taken on, as a field of its own and not only inside the description)
+            out["cpu_baseline"]["scope"] = ("sample: syn-nlpkkt at grid edge %d, %d nonzeros (1/%d of the bench matrix)" % (
+                SAMPLE_EDGE, int(csr_s[0][-1]), round(wl.nnz / max(int(csr_s[0][-1]), 1)))
+                if note.startswith("sample: syn-nlpkkt at grid edge") else "the whole bench matrix")
             del csr_s
         if world == 1 and not args.no_configs and args.workload == "syn-nlpkkt" and not args.mtx:
             cfgs = {}

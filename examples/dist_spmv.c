@@ -124,6 +124,18 @@ int main(int argc, char **argv)
     printf("rank %d of %d: halo of x: %ld entries received, %ld sent; max |y - exact| on own rows + halo = %.3e\n", rank,
            world, (long) halo.n_recv, (long) halo.n_send, err_h);
     err = fmax(err, err_h);
+    /* the figures the predicted step is made of (tests/test_dist_plan_volumes.py holds them):
+       bytes received per step, the busiest peer (one xGMI link carries that), rounds of the overlapped step */
+    {
+        size_t busiest = 0;
+        for (int q = 0; q < world; q++) {
+            if (halo.recv_cnt[q] > busiest) busiest = halo.recv_cnt[q];
+            if (halo.send_cnt[q] > busiest) busiest = halo.send_cnt[q];
+        }
+        printf("rank %d of %d: per step %.3f MB received (a whole slice handed round: %.3f MB), busiest peer %.3f MB, "
+               "%d rounds behind %d launches\n", rank, world, 8e-6 * (double) halo.n_recv, 8e-6 * (double) (n - rows),
+               8e-6 * (double) busiest, spx_hip_mat_dist_rounds(A), spx_hip_mat_dist_parts(A));
+    }
 
     spx_hip_vec_destroy(x);
     spx_hip_vec_destroy(y);

@@ -135,17 +135,24 @@ def generate_source(id_map, symmetric, row_jumps, full_colind):
     hooks = {"spmv_func_definitions": "\n".join(defs)}
     fixed, call = row_and_column_hooks(symmetric, row_jumps, full_colind)
     hooks.update(fixed)
-    if len(entries) == 1:
-        hooks["body_hook"] = "yr += " + list(entries.values())[0] + call
-    else:
-        body = "switch (patt_id) {\n"
-        for slot in sorted(entries):
-            body += "\t\tcase %d:\n\t\t\tyr += %s%s\n\t\t\tbreak;\n" % (slot, entries[slot], call)
-        body += ("\t\tdefault:\n\t\t\tfprintf(stderr, \"[BUG] unknown pattern\\n\");\n"
-                 "\t\t\texit(1);\n\t\t};")
-        hooks["body_hook"] = body
+    hooks["body_hook"] = body_hook_text(entries, call)
     main = _read("src/templates/csx%s_spmv_tmpl.c" % sfx)
     return _subst(main, hooks)
+
+
+def body_hook_text(entries, call):
+    """${body_hook} as CsxJit::DoHook writes it (include/sparsex/internals/CsxJit.hpp:637-672): one routine is
+    called directly, several through a switch over the pattern slot.  `entries`: {slot: routine name}; `call`: the
+    argument list with its semicolon.  tests/test_oracle_golden.py rebuilds the same text from the expression in
+    the header itself and compares."""
+    if len(entries) == 1:
+        return "yr += " + list(entries.values())[0] + call
+    body = "switch (patt_id) {\n"
+    for slot in sorted(entries):
+        body += "\t\tcase %d:\n\t\t\tyr += %s%s\n\t\t\tbreak;\n" % (slot, entries[slot], call)
+    body += ("\t\tdefault:\n\t\t\tfprintf(stderr, \"[BUG] unknown pattern\\n\");\n"
+             "\t\t\texit(1);\n\t\t};")
+    return body
 
 
 def build(id_map, symmetric=False, row_jumps=False, full_colind=False, opt="-O2"):

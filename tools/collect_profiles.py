@@ -42,26 +42,31 @@ for w, key in KEYS.items():
         want = re.search(r"csx_spmv[a-z_]*kernel<\d>", name).group(0)
     except Exception:
         pass
-    kib, kern = {}, None
+    # per counter: {kernel (as the profiler names it): (launches, KiB per launch)}; ONE kernel is chosen for both
+    # counters -- the one the un-profiled line names where the profiled run launched it, else the SpMV kernel
+    # with the most launches in both files -- and the entry is labelled with the kernel whose numbers it holds
+    seen = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         p = os.path.join(src, "pmc_%s.txt" % c)
+        seen[c] = {}
         if not os.path.exists(p):
             continue
-        best = -1
         for line in open(p):
             if "csx_spmv" not in line:
                 continue
-            n = int(re.search(r"launches=([0-9]+)", line).group(1))
-            hit = want is not None and ("::" + want + "(") in line
-            if hit or (want is None and n > best) or (best < 0 and not hit and c not in kib):
-                best = n
-                kib[c] = float(re.search(r"per_launch=([0-9.]+)", line).group(1))
-                kern = line.split(" launches=")[0].strip()
-                if hit:
-                    break
+            name = line.split(" launches=")[0].strip()
+            seen[c][name] = (int(re.search(r"launches=([0-9]+)", line).group(1)),
+                             float(re.search(r"per_launch=([0-9.]+)", line).group(1)))
+    both = [k for k in seen["FETCH_SIZE"] if k in seen["WRITE_SIZE"]]
+    kib, kern = {}, None
+    if both:
+        named = [k for k in both if want is not None and ("::" + want + "(") in k]
+        kern = named[0] if named else max(both, key=lambda k: seen["FETCH_SIZE"][k][0])
+        kib = {c: seen[c][kern][1] for c in ("FETCH_SIZE", "WRITE_SIZE")}
     if len(kib) == 2:
         traffic[key] = {
             "kernel": kern,
+            "kernel_is_the_plain_line_s": bool(want is not None and ("::" + want + "(") in kern),
             "fetch_size_kib_per_launch": kib["FETCH_SIZE"],
             "write_size_kib_per_launch": kib["WRITE_SIZE"],
             "hbm_bytes_per_launch": int((2 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024),
