@@ -56,9 +56,25 @@ typedef double spx_d2_t __attribute__((ext_vector_type(2)));
 // two doubles at any 8-byte aligned address as ONE load (global_load_dwordx4 needs no 16-byte
 // alignment on gfx9): the x of a row segment comes in pairs wherever its first column lies
 typedef double spx_d2u_t __attribute__((ext_vector_type(2), aligned(8)));
+#ifdef SPX_EXPERIMENT_NT_STREAM      /* (experiment build: the matrix stream non-temporal, so that it does not push x out of the L2) */
+__device__ __forceinline__ double2 ld_stream(const double2 *p)
+{
+    const spx_d2_t v = __builtin_nontemporal_load(reinterpret_cast<const spx_d2_t *>(p));
+    return double2{v.x, v.y};
+}
+__device__ __forceinline__ double ld_stream(const double *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ uint2 ld_stream(const uint2 *p)
+{
+    const unsigned long long v = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(p));
+    return uint2{(uint32_t) v, (uint32_t) (v >> 32)};
+}
+#define SPX_LD_INDEX(expr) __builtin_nontemporal_load(&(expr))
+#else
 __device__ __forceinline__ double2 ld_stream(const double2 *p) { return *p; }
 __device__ __forceinline__ double ld_stream(const double *p) { return *p; }
 __device__ __forceinline__ uint2 ld_stream(const uint2 *p) { return *p; }
+#define SPX_LD_INDEX(expr) (expr)
+#endif
 
 // set bits of `mask` in lanes 1..lane (bit 0 is never set by the emitter)
 __device__ __forceinline__ uint32_t starts_upto(uint64_t mask, int lane)
@@ -94,25 +110,25 @@ __device__ __forceinline__ void unit_passes(const KernelArgs &a, const SpxRowBlo
         active[b] = (uint32_t) lane < nseg[b];
         l[b] = active[b] ? (uint32_t) lane : 0u;         // idle lanes shadow lane 0
         if (G) {
-            q[b].x = a.segrows[rb.seg_off + ps[b].seg0 + l[b]];
+            q[b].x = SPX_LD_INDEX(a.segrows[rb.seg_off + ps[b].seg0 + l[b]]);
             const uint8_t *cidx = a.cidx + ((size_t) rb.cidx_off + (G == 2 ? rb.near_off : 0u)) * 16u;
             const uint32_t e0 = ps[b].elem0 + l[b];
             if (G == 1 && rb.cidx_width == 4) {
 #pragma unroll
                 for (int w = 0; w < W; ++w)
-                    goff[b][w] = reinterpret_cast<const uint32_t *>(cidx)[e0 + (uint32_t) w * nseg[b]];
+                    goff[b][w] = SPX_LD_INDEX(reinterpret_cast<const uint32_t *>(cidx)[e0 + (uint32_t) w * nseg[b]]);
             } else if (G == 1 && rb.cidx_width == 3) {
                 // 24-bit offsets: the low halves, then (array of its own) the high bytes
                 const uint8_t *hi = cidx + (size_t) rb.hi_off * 16u;
 #pragma unroll
                 for (int w = 0; w < W; ++w) {
                     const uint32_t e = e0 + (uint32_t) w * nseg[b];
-                    goff[b][w] = (uint32_t) reinterpret_cast<const uint16_t *>(cidx)[e] | ((uint32_t) hi[e] << 16);
+                    goff[b][w] = (uint32_t) SPX_LD_INDEX(reinterpret_cast<const uint16_t *>(cidx)[e]) | ((uint32_t) SPX_LD_INDEX(hi[e]) << 16);
                 }
             } else {
 #pragma unroll
                 for (int w = 0; w < W; ++w)
-                    goff[b][w] = reinterpret_cast<const uint16_t *>(cidx)[e0 + (uint32_t) w * nseg[b]];
+                    goff[b][w] = SPX_LD_INDEX(reinterpret_cast<const uint16_t *>(cidx)[e0 + (uint32_t) w * nseg[b]]);
             }
         } else {
             if (ps[b].flags & SPX_PASSF_INLINE) {
