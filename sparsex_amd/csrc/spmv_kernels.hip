@@ -222,10 +222,16 @@ __device__ __forceinline__ void symseg_passes(const KernelArgs &a, const SpxRowB
         sdc[b] = s * dcol;
         col[b] = q[b].x + (uint32_t) sdc[b];
         const double *xp = a.x + col[b];
+#ifdef SPX_ABL_SYM_NOX
+        xr[b] = a.x[lane]; (void) xp;
+#pragma unroll
+        for (int w = 0; w < W; ++w) x[b][w] = a.x[lane + w];
+#else
         xr[b] = a.x[rb.row0 + (uint32_t) row[b]];
         // (x in unaligned pairs, as the unit passes load it, measured 2.3 % slower here: one load per column)
 #pragma unroll
         for (int w = 0; w < W; ++w) x[b][w] = xp[w];
+#endif
     }
 #pragma unroll
     for (int b = 0; b < B; ++b) {
@@ -236,8 +242,20 @@ __device__ __forceinline__ void symseg_passes(const KernelArgs &a, const SpxRowB
         atomicAdd(&tile[row[b]], t);
         if (slot0[b] != SPX_NO_SLOT) {
             double *sl = slots + slot0[b] + (uint32_t) sdc[b];
+#ifdef SPX_ABL_SYM_NOSLOTADD
+            double u = 0.0;
+#pragma unroll
+            for (int w = 0; w < W; ++w) u += v[b][w] * xr[b];
+            if (u == 1.2345e-300) sl[0] = u;
+#elif defined(SPX_ABL_SYM_ONEADD)
+            double u = 0.0;
+#pragma unroll
+            for (int w = 0; w < W; ++w) u += v[b][w] * xr[b];
+            atomicAdd(&sl[0], u);
+#else
 #pragma unroll
             for (int w = 0; w < W; ++w) atomicAdd(&sl[w], v[b][w] * xr[b]);
+#endif
         } else {
             double *yp = a.y + col[b];
 #pragma unroll
@@ -339,6 +357,38 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &x
     // wave w takes passes w, w + W, ..., two at a time when they have the same shape (they mostly
     // do: passes are sorted by width), so that their loads overlap
     const int n_pass = rb.n_pass;
+#ifdef SPX_EXPERIMENT_SYM_QUAD
+    if (SEGS && !TILES) {
+        // (experiment: four read-once passes per round)
+        for (int t = wave; t < n_pass; t += 4 * WAVES_PER_BLOCK) {
+            SpxPass q[4];
+            int present = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int idx = t + k * WAVES_PER_BLOCK;
+                q[k] = passes[idx < n_pass ? idx : t];
+                if (idx < n_pass) present = k + 1; else q[k].nseg = 0;
+            }
+            bool same = q[0].kind == SPX_PASS_SYMSEG && q[0].width <= 4 && q[0].width >= 2;
+#pragma unroll
+            for (int k = 1; k < 4; ++k) same = same && q[k].kind == SPX_PASS_SYMSEG && q[k].width == q[0].width;
+            if (same) {
+                switch (q[0].width) {
+                case 2: symseg_passes<2, 4>(a, rb, {q[0], q[1], q[2], q[3]}, mine, tile, lane); break;
+                case 3: symseg_passes<3, 4>(a, rb, {q[0], q[1], q[2], q[3]}, mine, tile, lane); break;
+                default: symseg_passes<4, 4>(a, rb, {q[0], q[1], q[2], q[3]}, mine, tile, lane); break;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (k >= present) break;
+                    if (q[k].kind == SPX_PASS_SYMSEG) run_symseg(a, rb, q[k], mine, tile, lane);
+                    else run_pass(a, rb, q[k], tile, win, lane);
+                }
+            }
+        }
+    } else
+#endif
     for (int t = wave; t < n_pass; t += 2 * WAVES_PER_BLOCK) {
         const bool two = t + WAVES_PER_BLOCK < n_pass;
         if (SEGS && (p0.kind == SPX_PASS_SYMSEG || (two && p1.kind == SPX_PASS_SYMSEG))) {
@@ -410,8 +460,10 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &x
             for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS)
                 atomicAdd(&a.y[(size_t) rb.row0 + i], a.alpha * tile[i]);
         }
+#ifndef SPX_ABL_SYM_NOHANDOVER
         for (int i = threadIdx.x; i < n_slots; i += BLOCK_THREADS)
             atomicAdd(&a.y[(size_t) gcol_lds[i >> 3] + (i & 7)], a.alpha * lds[i]);
+#endif
     } else {
         for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS) {
             const size_t g = (size_t) rb.row0 + i;
