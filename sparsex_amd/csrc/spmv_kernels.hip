@@ -160,6 +160,14 @@ __device__ __forceinline__ void symtile_pass(const KernelArgs &a, const SpxRowBl
     }
 }
 
+// (experiment builds, results wrong on purpose -- profiles/r05/ablation.md: SPX_ABL_SYM_NOSLOTADD no LDS adds of the
+// transposed products, SPX_ABL_SYM_ONEADD one instead of W, SPX_ABL_SYM_NOX every x load from one cached line,
+// SPX_ABL_SYM_NOHANDOVER the slots are not added to y; SPX_ABL_SYM_STREAM all of them: what the stream alone costs)
+#ifdef SPX_ABL_SYM_STREAM
+#define SPX_ABL_SYM_NOSLOTADD
+#define SPX_ABL_SYM_NOX
+#define SPX_ABL_SYM_NOHANDOVER
+#endif
 // A pass of read-once row segments of a symmetric matrix (SPX_PASS_SYMSEG): a unit pass
 // whose lanes, besides the row sum a(r, c..c+W-1) . x[c..], add the W transposed products
 // a(r, c+w) * x[r] to the slots of their columns (consecutive slots, consecutive LDS
@@ -357,38 +365,6 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &x
     // wave w takes passes w, w + W, ..., two at a time when they have the same shape (they mostly
     // do: passes are sorted by width), so that their loads overlap
     const int n_pass = rb.n_pass;
-#ifdef SPX_EXPERIMENT_SYM_QUAD
-    if (SEGS && !TILES) {
-        // (experiment: four read-once passes per round)
-        for (int t = wave; t < n_pass; t += 4 * WAVES_PER_BLOCK) {
-            SpxPass q[4];
-            int present = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int idx = t + k * WAVES_PER_BLOCK;
-                q[k] = passes[idx < n_pass ? idx : t];
-                if (idx < n_pass) present = k + 1; else q[k].nseg = 0;
-            }
-            bool same = q[0].kind == SPX_PASS_SYMSEG && q[0].width <= 4 && q[0].width >= 2;
-#pragma unroll
-            for (int k = 1; k < 4; ++k) same = same && q[k].kind == SPX_PASS_SYMSEG && q[k].width == q[0].width;
-            if (same) {
-                switch (q[0].width) {
-                case 2: symseg_passes<2, 4>(a, rb, {q[0], q[1], q[2], q[3]}, mine, tile, lane); break;
-                case 3: symseg_passes<3, 4>(a, rb, {q[0], q[1], q[2], q[3]}, mine, tile, lane); break;
-                default: symseg_passes<4, 4>(a, rb, {q[0], q[1], q[2], q[3]}, mine, tile, lane); break;
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (k >= present) break;
-                    if (q[k].kind == SPX_PASS_SYMSEG) run_symseg(a, rb, q[k], mine, tile, lane);
-                    else run_pass(a, rb, q[k], tile, win, lane);
-                }
-            }
-        }
-    } else
-#endif
     for (int t = wave; t < n_pass; t += 2 * WAVES_PER_BLOCK) {
         const bool two = t + WAVES_PER_BLOCK < n_pass;
         if (SEGS && (p0.kind == SPX_PASS_SYMSEG || (two && p1.kind == SPX_PASS_SYMSEG))) {
