@@ -603,6 +603,7 @@ def host_api_rate(A, xh, n, nnz, calls=20):
     # ... and what an unchanged reference client gets (its vectors come from spx_vec_create_random / spx_vec_create:
     # page-locked, x's HBM copy reused between calls -- spx.vec.device, on by default): only y travels
     import ctypes as C
+    import sparsex_amd as sx
     from sparsex_amd.api import VectorStruct
     L = sx.lib()
     L.spx_vec_create_random.restype = C.POINTER(VectorStruct)
