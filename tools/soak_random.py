@@ -27,6 +27,13 @@ for seed in range(a, b):
     if not sym:
         o["spx.gpu.col_phases"] = ["1", "c2", "c4", "2", "3", "c8", "auto"][seed % 7]
     o["spx.gpu.keep_units"] = "false" if seed % 5 == 0 else "true"
+    # round 5: the unit windows of x (forced on three times out of four; they apply where the stream is not sliced
+    # and has no launch order), small and large budgets, gaps, joined row-blocks
+    o["spx.gpu.unit_windows"] = ["true", "auto", "true", "false", "true"][seed % 5]
+    o["spx.gpu.unit_window_doubles"] = str([64, 3072, 512, 8192, 1024, 12000][seed % 6])
+    o["spx.gpu.unit_window_gap"] = str([0, 16, 200, 2][seed % 4])
+    if not sym and seed % 7 == 3:
+        o["spx.gpu.rowblock_elems"] = "16384"
     o["spx.gpu.band_order"] = "true" if seed % 4 == 1 else "false"
     try:
         A = tune(csr, o, sym=sym)
