@@ -129,8 +129,13 @@ __device__ __forceinline__ void xw_issue(const KernelArgs &a, const SpxRowBlock 
         const double *vals = a.values + rb.val_off + ps[b].val_off();
         const uint32_t off_a = W == 1u ? l : 2u * l;
         const uint32_t off_b = W == 3u ? 2u * nseg + l : (W == 4u ? 2u * nseg + 2u * l : off_a);
+#ifdef SPX_EXPERIMENT_NT_STREAM       /* (experiment build, spmv_device.hpp: the matrix stream non-temporal) */
+        S.va[b] = __builtin_nontemporal_load(reinterpret_cast<const spx_d2u_t *>(vals + off_a));
+        S.vb[b] = __builtin_nontemporal_load(reinterpret_cast<const spx_d2u_t *>(vals + off_b));
+#else
         S.va[b] = *reinterpret_cast<const spx_d2u_t *>(vals + off_a);
         S.vb[b] = *reinterpret_cast<const spx_d2u_t *>(vals + off_b);
+#endif
     }
 }
 
