@@ -1002,7 +1002,11 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
         try {
             XwPlan plan;
             plan_unit_xwindows(s, ncols, s.xw_budget, s.xw_gap, plan, host_threads());
-            if (plan.n_rb_windows) {
+            if (plan.n_rb_windows && (size_t) plan.lds_doubles * sizeof(double) > 160u * 1024u) {
+                // (a budget and row-blocks so large that a workgroup would not fit a CU's LDS: the plain kernel runs)
+                log_msg(LOG_INFO, "unit windows: %u KB of LDS per workgroup do not fit, not used\n",
+                        (unsigned) ((size_t) plan.lds_doubles * sizeof(double) / 1024u));
+            } else if (plan.n_rb_windows) {
                 auto up = [&](auto **dst, const auto &v, size_t slack) {
                     typedef typename std::remove_reference<decltype(v[0])>::type T;
                     const size_t bytes = (v.size() + slack) * sizeof(T);
