@@ -352,31 +352,6 @@ __device__ __forceinline__ void spmv_body_xw(const KernelArgs &a, const XcdSplit
                 __builtin_amdgcn_global_load_lds(src + i, (__attribute__((address_space(3))) void *) (hdr + c), 16, 0, 0);
         }
     }
-#ifdef SPX_EXPERIMENT_XW_PREFETCH
-    // (experiment: the headers of the row-block this XCD starts SPX_EXPERIMENT_XW_PREFETCH workgroups from now are
-    // pulled into the L2 -- loaded into an unused piece of LDS -- so that that workgroup's first round trip is an L2 hit)
-    {
-        const uint32_t ahead = rb_idx + (uint32_t) SPX_EXPERIMENT_XW_PREFETCH;
-        if (ahead < xs.first[xcd + 1u]) {
-            const uint32_t n_words = 6u * (a.pass_stride + 4u * (uint32_t) WAVES);
-            uint32_t *junk = hdr + ((n_words + 3u) & ~3u);
-            const uint32_t n_ahead = 6u * a.pass_stride;
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(a.passes + (size_t) ahead * a.pass_stride);
-            for (uint32_t c = (uint32_t) wave * 256u; c < n_ahead; c += (uint32_t) WAVES * 256u) {
-                const uint32_t i = c + 4u * (uint32_t) lane;
-                if (i < n_ahead)
-                    __builtin_amdgcn_global_load_lds(src + i, (__attribute__((address_space(3))) void *) (junk + c), 16, 0, 0);
-            }
-            uint32_t *junk2 = junk + ((n_ahead + 255u) & ~255u);
-            if (wave == 0 && lane < 4)
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(a.rbs + ahead) + 4 * lane,
-                                                 (__attribute__((address_space(3))) void *) junk2, 16, 0, 0);
-            if (wave == WAVES - 1 && lane < 8)
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t *>(a.xw_tab + (size_t) ahead * XW_TAB) + 4 * lane,
-                                                 (__attribute__((address_space(3))) void *) (junk2 + 64), 16, 0, 0);
-        }
-    }
-#endif
     // the loads of the wavefront's first round go out in front of the barrier, next to the windows
     const int n_pass = rb.n_pass;
     int t = wave;
@@ -430,9 +405,6 @@ void csx_spmv_xw_kernel(SPX_KERNEL_PARAMS, const XwEntry *xw_tab_)
 void launch_spmv_xw(int waves, unsigned blocks, size_t lds_bytes, void *stream_, const KernelArgs &a, const XcdSplit &xs)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-#ifdef SPX_EXPERIMENT_XW_PREFETCH
-    lds_bytes += ((24u * (size_t) a.pass_stride + 1023u) & ~(size_t) 1023u) + 512u;
-#endif
 #define SPX_LAUNCH_XW(W)                                                                           \
     hipLaunchKernelGGL(csx_spmv_xw_kernel<W>, dim3(blocks), dim3(64 * W), lds_bytes, stream, a.rbs,  \
                        a.passes, a.n_rb, a.pass_stride, xs, a.values, a.descs, a.cidx, a.segrows,   \
