@@ -149,3 +149,32 @@ def test_deterministic_mode_does_not_use_the_windows():
     A.matvec_mult(1.0, x, y)
     check_y(csr, x, y, 1.0)
     sx.options_reset()
+
+
+@pytest.mark.parametrize("xoff,yoff", [(0, 0), (1, 0), (0, 1), (1, 1), (3, 5)])
+def test_device_vectors_at_any_8_byte_alignment(xoff, yoff):
+    """spx_hip_matvec_mult takes any double* (reference: spx_matvec_mult takes any vector_t, matvec.c:551-584): x
+    and y that start 8 bytes off a 16-byte boundary -- the windows are staged 16 bytes per lane."""
+    csr = synth.syn_nlpkkt(14)
+    n = csr[3]
+    A = tune(csr, dict(ON, **{"spx.preproc.sampling": "none"}))
+    assert A.info().unit_windows == 1
+    xh = synth.random_x(n)
+    xbuf = torch.zeros(n + 8, dtype=torch.float64, device="cuda")
+    ybuf = torch.full((n + 8,), float("nan"), dtype=torch.float64, device="cuda")
+    xd, yd = xbuf[xoff:xoff + n], ybuf[yoff:yoff + n]
+    xd.copy_(torch.from_numpy(xh))
+    assert xd.data_ptr() % 16 == 8 * (xoff % 2)
+    st = torch.cuda.current_stream().cuda_stream
+    A.hip_matvec_mult(0.5, xd.data_ptr(), yd.data_ptr(), st)
+    torch.cuda.synchronize()
+    check_y(csr, xh, yd.cpu().numpy(), 0.5)
+    y0 = synth.random_x(n, seed=5)
+    yd.copy_(torch.from_numpy(y0))
+    A.hip_matvec_kernel(2.0, xd.data_ptr(), -0.5, yd.data_ptr(), st)
+    torch.cuda.synchronize()
+    check_y(csr, xh, yd.cpu().numpy(), 2.0, -0.5, y0)
+    # nothing was written outside y
+    out = ybuf.cpu().numpy()
+    assert np.all(np.isnan(out[:yoff])) and np.all(np.isnan(out[yoff + n:]))
+    sx.options_reset()
