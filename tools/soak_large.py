@@ -95,6 +95,11 @@ def options(seed, symmetric):
         o["spx.gpu.keep_units"] = "false"
     if rng.rand() < 0.3:
         o["spx.gpu.band_order"] = "true"
+    # round 5: the unit windows (a generator of its own, so that the draws above stay what they were)
+    r5 = np.random.RandomState(9500 + seed)
+    o["spx.gpu.unit_windows"] = str(r5.choice(["true", "true", "auto", "false"]))
+    o["spx.gpu.unit_window_doubles"] = str(r5.choice([256, 1024, 3072, 8192, 16384]))
+    o["spx.gpu.unit_window_gap"] = str(r5.choice([0, 16, 100, 255]))
     return o
 
 
