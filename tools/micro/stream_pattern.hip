@@ -8,6 +8,11 @@
 //   mode 3  as mode 1, but the chunk is read as the values of width-3 passes are: pieces of 1536 bytes per
 //           wavefront, a 16-byte load per lane on the first kilobyte and an 8-byte load per lane on the rest
 //   mode 4  as mode 3 behind one dependent 8-byte load per workgroup (the row-block header's round trip)
+//   mode 6  as mode 1, and every workgroup ends with 304 doubles written (a row-block's rows of y: 2.4 KB per
+//           64 KB read): plain stores, non-temporal stores, stores into a small region that stays in the L2,
+//           and the same bytes written by one workgroup in 64 (64 x 304 doubles at once)
+//   mode 5  as mode 1, and every workgroup also reads XKB (argv[3], default 24) kilobytes of a region small enough
+//           to stay in its XCD's L2 (what the staging of x asks of the L2-to-L1 path on top of the stream)
 // LDS bytes per workgroup (argv[2]) bound the workgroups per CU like the kernels' tiles and windows do.
 // build: hipcc --offload-arch=gfx950 -O3 tools/micro/stream_pattern.hip -o gpurun_out/stream_pattern
 #include <hip/hip_runtime.h>
@@ -75,6 +80,107 @@ __global__ __launch_bounds__(256) void pattern_kernel(const double2 *p, size_t n
     if (acc == 1.2345) out[0] = acc + lds[0];
 }
 
+
+// mode 6: the stream as in mode 1, then the workgroup's rows of y
+//   STORE 0 none, 1 plain, 2 non-temporal, 3 plain into an L2-resident region, 4 every 64th workgroup writes 64 tiles,
+//   5 tiles of 298 doubles packed one behind the other (they begin and end inside 128-byte lines)
+template <int U, int STORE>
+__global__ __launch_bounds__(256) void pattern_wr_kernel(const double2 *p, size_t n_chunks, unsigned chunk16, double *y, double *out)
+{
+    extern __shared__ double lds[];
+    double acc = 0.0;
+    const size_t per = (n_chunks + 7) / 8;
+    const size_t chunk = (size_t) (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per || chunk >= n_chunks) return;
+    const double2 *q = p + chunk * chunk16;
+    for (unsigned i = threadIdx.x; i + (U - 1) * 256u < chunk16; i += U * 256u) {
+        double2 v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) v[k] = q[i + k * 256u];
+#pragma unroll
+        for (int k = 0; k < U; ++k) acc += v[k].x + v[k].y;
+    }
+    __syncthreads();
+    if (STORE == 1 || STORE == 2 || STORE == 3) {
+        double *dst = y + (STORE == 3 ? (size_t) (blockIdx.x & 255u) * 304u : chunk * 304u);
+        for (unsigned i = threadIdx.x; i < 304u; i += 256u) {
+            if (STORE == 2) __builtin_nontemporal_store(acc, dst + i);
+            else dst[i] = acc;
+        }
+    } else if (STORE == 5) {
+        double *dst = y + chunk * 298u + 1u;
+        for (unsigned i = threadIdx.x; i < 298u; i += 256u) dst[i] = acc;
+    } else if (STORE == 4) {
+        if (((blockIdx.x >> 3) & 63u) == 0u) {
+            double *dst = y + chunk * 304u;
+            for (unsigned i = threadIdx.x; i < 64u * 304u; i += 256u) dst[i] = acc;
+        }
+    }
+    if (acc == 1.2345) out[0] = acc + lds[0];
+}
+
+template <int STORE>
+static void run_wr(const double2 *p, size_t n_chunks, unsigned chunk16, double *y, double *out, unsigned blocks, size_t lds)
+{
+    hipEvent_t e0, e1;
+    (void) hipEventCreate(&e0); (void) hipEventCreate(&e1);
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&pattern_wr_kernel<4, STORE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    pattern_wr_kernel<4, STORE><<<blocks, 256, lds>>>(p, n_chunks, chunk16, y, out);
+    (void) hipDeviceSynchronize();
+    (void) hipEventRecord(e0);
+    for (int r = 0; r < 10; ++r) pattern_wr_kernel<4, STORE><<<blocks, 256, lds>>>(p, n_chunks, chunk16, y, out);
+    (void) hipEventRecord(e1); (void) hipEventSynchronize(e1);
+    float ms; (void) hipEventElapsedTime(&ms, e0, e1);
+    static const char *what[] = {"no stores", "plain stores", "non-temporal stores", "stores into an L2-resident region",
+                                 "one workgroup in 64 stores 64 tiles", "298 doubles, tiles packed (partial lines)"};
+    printf("mode 6 U=4 chunk %u KB, 2.4 KB written per chunk, %-36s: stream %.1f GB/s\n", chunk16 * 16 / 1024, what[STORE],
+           10.0 * n_chunks * chunk16 * 16 / (ms * 1e6));
+}
+
+// mode 5: the stream as in mode 1 plus xkb kilobytes per workgroup from an L2-resident region
+template <int U>
+__global__ __launch_bounds__(256) void pattern_l2_kernel(const double2 *p, size_t n_chunks, unsigned chunk16, const double2 *hot,
+                                                         unsigned xkb, double *out)
+{
+    extern __shared__ double lds[];
+    double acc = 0.0;
+    const size_t per = (n_chunks + 7) / 8;
+    const size_t chunk = (size_t) (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per || chunk >= n_chunks) return;
+    // the workgroup's piece of the hot region: 32 pieces per XCD, reused by every 32nd workgroup of that XCD
+    const double2 *h = hot + ((size_t) (blockIdx.x & 7u) * 32u + ((blockIdx.x >> 3) & 31u)) * (size_t) (xkb * 64u);
+    for (unsigned i = threadIdx.x; i < xkb * 64u; i += 256u) {
+        const double2 v = h[i];
+        acc += v.x + v.y;
+    }
+    const double2 *q = p + chunk * chunk16;
+    for (unsigned i = threadIdx.x; i + (U - 1) * 256u < chunk16; i += U * 256u) {
+        double2 v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) v[k] = q[i + k * 256u];
+#pragma unroll
+        for (int k = 0; k < U; ++k) acc += v[k].x + v[k].y;
+    }
+    if (acc == 1.2345) out[0] = acc + lds[0];
+}
+
+static void run_l2(const double2 *p, size_t n_chunks, unsigned chunk16, const double2 *hot, unsigned xkb, double *out,
+                   unsigned blocks, size_t lds)
+{
+    hipEvent_t e0, e1;
+    (void) hipEventCreate(&e0); (void) hipEventCreate(&e1);
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&pattern_l2_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    pattern_l2_kernel<4><<<blocks, 256, lds>>>(p, n_chunks, chunk16, hot, xkb, out);
+    (void) hipDeviceSynchronize();
+    (void) hipEventRecord(e0);
+    for (int r = 0; r < 10; ++r) pattern_l2_kernel<4><<<blocks, 256, lds>>>(p, n_chunks, chunk16, hot, xkb, out);
+    (void) hipEventRecord(e1); (void) hipEventSynchronize(e1);
+    float ms; (void) hipEventElapsedTime(&ms, e0, e1);
+    const double stream = 10.0 * n_chunks * chunk16 * 16, l2 = 10.0 * n_chunks * xkb * 1024.0;
+    printf("mode 5 U=4 chunk %u KB + %2u KB from the L2, lds %zu KB: stream %.1f GB/s, stream + L2 reads %.1f GB/s\n",
+           chunk16 * 16 / 1024, xkb, lds / 1024, stream / (ms * 1e6), (stream + l2) / (ms * 1e6));
+}
+
 template <int U, int MODE>
 static void run(const double2 *p, size_t n_chunks, unsigned chunk16, double *out, unsigned blocks, size_t lds)
 {
@@ -123,6 +229,29 @@ int main(int argc, char **argv)
         run<4, 3>(p, n_chunks, chunk16, out, blocks1, lds);
         run<2, 4>(p, n_chunks, chunk16, out, blocks1, lds);
         run<4, 4>(p, n_chunks, chunk16, out, blocks1, lds);
+    }
+    // mode 6: y is a buffer of its own
+    {
+        double *y;
+        if (hipMalloc(&y, (n_chunks + 64) * 304 * sizeof(double)) != hipSuccess) return 1;
+        for (int rep = 0; rep < 2; ++rep) {
+            run_wr<0>(p, n_chunks, chunk16, y, out, blocks1, lds);
+            run_wr<1>(p, n_chunks, chunk16, y, out, blocks1, lds);
+            run_wr<2>(p, n_chunks, chunk16, y, out, blocks1, lds);
+            run_wr<3>(p, n_chunks, chunk16, y, out, blocks1, lds);
+            run_wr<4>(p, n_chunks, chunk16, y, out, blocks1, lds);
+            run_wr<5>(p, n_chunks, chunk16, y, out, blocks1, lds);
+        }
+        (void) hipFree(y);
+    }
+    // mode 5: the hot region is the last 64 MB of the buffer; the stream covers the rest
+    {
+        const size_t hot_bytes = (size_t) 64 << 20;
+        const size_t n_str = (bytes - hot_bytes) / 16 / chunk16;
+        const double2 *hot = p + (bytes - hot_bytes) / 16;
+        const unsigned b5 = (unsigned) (((n_str + 7) / 8) * 8);
+        for (unsigned xkb : {0u, 8u, 16u, 24u, 32u, 48u})
+            if ((size_t) 8 * 32 * xkb * 1024 <= hot_bytes) run_l2(p, n_str, chunk16, hot, xkb, out, b5, lds);
     }
     return 0;
 }
