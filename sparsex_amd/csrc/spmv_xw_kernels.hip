@@ -125,11 +125,7 @@ __device__ __forceinline__ void xw_issue(const KernelArgs &a, const SpxRowBlock 
         S.row0[b] = ps[b].w[5];
         const uint64_t mk = (ps[b].flags() & SPX_PASSF_INLINE) ? 0ull : ps[b].mask();
         const uint32_t rank = ps[b].rank0() + (active ? starts_upto(mk, lane) : 0u);
-#ifdef SPX_BISECT_NODESC
-        S.q[b] = uint2{rank, (uint32_t) (ps[b].mask() >> 32)};
-#else
         S.q[b] = ld_stream(reinterpret_cast<const uint2 *>(a.descs + rb.desc_off + rank));
-#endif
         const double *vals = a.values + rb.val_off + ps[b].val_off();
         const uint32_t off_a = W == 1u ? l : 2u * l;
         const uint32_t off_b = W == 3u ? 2u * nseg + l : (W == 4u ? 2u * nseg + 2u * l : off_a);
@@ -148,14 +144,6 @@ template <int W>
 __device__ __forceinline__ void xw_finish_pass(uint2 q, uint32_t segl, uint32_t row0, spx_d2u_t va, spx_d2u_t vb,
                                                double *tile, const double *xw)
 {
-#ifdef SPX_BISECT_NOFINISH
-    {
-        const double t0 = va.x + va.y + vb.x + vb.y + (double) q.x + (double) q.y;
-        if (t0 == 1.2345e-300) tile[row0 & 1u] = t0 + xw[0];
-        (void) segl;
-        return;
-    }
-#endif
     const uint32_t c0 = q.x, bits = q.y;
     const int s = (int) ((segl - ((bits >> 9) & 8191u)) & 0xffffu);
     const uint32_t kind = (bits >> 22) & 7u;
@@ -262,13 +250,8 @@ __device__ __forceinline__ int xw_in_range(int t, int lo, int hi)
 // undid the pipeline.  Deeper pipelines were measured -- three and four rounds in flight, with empty rounds
 // at the ends so that no load sits under a branch: slower on the five rounds a wavefront has per row-block,
 // and what they gain in flight they lose in wavefronts per SIMD: profiles/r05/ablation.md.)
-#ifdef SPX_BISECT_NOHDRLDS
-#define SPX_BISECT_PASS(hdr, t) load_pass(gpasses, (t))
-#else
-#define SPX_BISECT_PASS(hdr, t) lds_pass((hdr), (t))
-#endif
 template <int WAVES>
-__device__ __forceinline__ void xw_run(const KernelArgs &a, const SpxRowBlock &rb, spx_const_words_t gpasses, const uint32_t *hdr, int hi,
+__device__ __forceinline__ void xw_run(const KernelArgs &a, const SpxRowBlock &rb, const uint32_t *hdr, int hi,
                                        int n_in, int &t, XwStage<2> &A, double *tile, const double *xw, int lane)
 {
     XwStage<2> B;
@@ -278,8 +261,8 @@ __device__ __forceinline__ void xw_run(const KernelArgs &a, const SpxRowBlock &r
 #define SPX_XW_HEADERS()                                                                          \
     do {                                                                                          \
         t += 2 * WAVES;                                                                           \
-        c0 = SPX_BISECT_PASS(hdr, t);                                                             \
-        c1 = SPX_BISECT_PASS(hdr, t + WAVES);                                                     \
+        c0 = lds_pass(hdr, t);                                                                    \
+        c1 = lds_pass(hdr, t + WAVES);                                                            \
         if (t + WAVES >= hi) c1 = no_pass(c0);                                                    \
     } while (0)
     int r = 1;
@@ -340,7 +323,6 @@ __device__ __forceinline__ void spmv_body_xw(const KernelArgs &a, const XcdSplit
     const int lo = (int) (range & 0xffffu), hi = (int) (range >> 16);
     uint32_t *hdr = reinterpret_cast<uint32_t *>(xw + xw_total);
     uint32_t odd_base = 0, odd_at = 0xffffffffu;
-#ifndef SPX_BISECT_NOSTAGE
 #pragma unroll
     for (uint32_t k = 0; k < XW_MAX; ++k) {
         const uint32_t base = (uint32_t) __builtin_amdgcn_readlane((int) xw_entry.x, (int) (XW_RANGES + k));
@@ -358,11 +340,9 @@ __device__ __forceinline__ void spmv_body_xw(const KernelArgs &a, const XcdSplit
             odd_at = off + len - 1u;
         }
     }
-#endif
     if (odd_at != 0xffffffffu && threadIdx.x == 0) xw[odd_at] = a.x[odd_base];
     // ... and the pass headers behind them, the same way: pass_stride + 4 WAVES of them (the table is padded),
     // a kilobyte per wavefront and step
-#ifndef SPX_BISECT_NOHDRLDS
     {
         const uint32_t n_words = 6u * (a.pass_stride + 4u * (uint32_t) WAVES);
         const uint32_t *src = reinterpret_cast<const uint32_t *>(pass0);
@@ -372,7 +352,6 @@ __device__ __forceinline__ void spmv_body_xw(const KernelArgs &a, const XcdSplit
                 __builtin_amdgcn_global_load_lds(src + i, (__attribute__((address_space(3))) void *) (hdr + c), 16, 0, 0);
         }
     }
-#endif
     // the loads of the wavefront's first round go out in front of the barrier, next to the windows
     const int n_pass = rb.n_pass;
     int t = wave;
@@ -382,33 +361,25 @@ __device__ __forceinline__ void spmv_body_xw(const KernelArgs &a, const XcdSplit
         if (t + WAVES >= hi) c1 = no_pass(c0);
         xw_issue<2>(a, rb, {c0, c1}, A, lane);
     }
-#ifndef SPX_BISECT_NOBARRIER
     __syncthreads();
-#endif
 
-    if (n_first > 0) xw_run<WAVES>(a, rb, passes, hdr, hi, n_first, t, A, tile, xw, lane);
+    if (n_first > 0) xw_run<WAVES>(a, rb, hdr, hi, n_first, t, A, tile, xw, lane);
     while (t < n_pass) {
         const int n_in = xw_in_range<WAVES>(t, lo, hi);
-        const spx_const_words_t gpasses = passes;
-        (void) gpasses;
-        c0 = SPX_BISECT_PASS(hdr, t);
-        c1 = SPX_BISECT_PASS(hdr, t + WAVES);
+        c0 = lds_pass(hdr, t);
+        c1 = lds_pass(hdr, t + WAVES);
         if (n_in > 0) {
             if (t + WAVES >= hi) c1 = no_pass(c0);
             xw_issue<2>(a, rb, {c0, c1}, A, lane);
-            xw_run<WAVES>(a, rb, passes, hdr, hi, n_in, t, A, tile, xw, lane);
+            xw_run<WAVES>(a, rb, hdr, hi, n_in, t, A, tile, xw, lane);
             continue;
         }
         xw_one(a, rb, c0, tile, win, xw, lane);
         if (t + WAVES < n_pass) xw_one(a, rb, c1, tile, win, xw, lane);
         t += 2 * WAVES;
     }
-#ifndef SPX_BISECT_NOBARRIER
     __syncthreads();
-#endif
-#ifdef SPX_BISECT_NOWRITE
-    if (a.pass_stride == 0xffffffffu)
-#endif
+
     if (rb.flags & SPX_RB_SHARED) {
         if (threadIdx.x == 0) a.carry[rb.carry_slot] = tile[0];
     } else {
