@@ -380,44 +380,11 @@ __device__ __forceinline__ void spmv_body_xw(const KernelArgs &a, const XcdSplit
     }
     __syncthreads();
 
-#ifdef SPX_BISECT_NOWRITE
-    if (a.pass_stride == 0xffffffffu)
-#endif
     if (rb.flags & SPX_RB_SHARED) {
         if (threadIdx.x == 0) a.carry[rb.carry_slot] = tile[0];
     } else {
-#if defined(SPX_BISECT_WRITE16) || defined(SPX_BISECT_WRITE_W0)
-        if (a.beta == 0.0) {
-#ifdef SPX_BISECT_WRITE_W0
-            const int first = lane, stride = 64;
-            if (wave != 0) return;
-#else
-            const int first = threadIdx.x, stride = BLOCK_THREADS;
-#endif
-#ifdef SPX_BISECT_WRITE16
-            for (int i = 2 * first; i < n_rows; i += 2 * stride) {
-                double *dst = a.y + (size_t) rb.row0 + i;
-                if (i + 1 < n_rows) {
-                    spx_d2u_t v;
-                    v.x = a.alpha * tile[i];
-                    v.y = a.alpha * tile[i + 1];
-                    *reinterpret_cast<spx_d2u_t *>(dst) = v;
-                } else {
-                    dst[0] = a.alpha * tile[i];
-                }
-            }
-#else
-            for (int i = first; i < n_rows; i += stride) a.y[(size_t) rb.row0 + i] = a.alpha * tile[i];
-#endif
-            return;
-        }
-#endif
         for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS) {
-#ifdef SPX_BISECT_YHOT
-            const size_t g = (((size_t) rb.row0 + i) & 0xffffu) + (size_t) (blockIdx.x & 7u) * 0x10000u;    // 512 KB per XCD
-#else
             const size_t g = (size_t) rb.row0 + i;
-#endif
             double tt = a.alpha * tile[i];
             if (a.beta != 0.0) tt += a.beta * a.y[g];
             a.y[g] = tt;
