@@ -362,10 +362,6 @@ __device__ __forceinline__ void spmv_body_xw(const KernelArgs &a, const XcdSplit
         xw_issue<2>(a, rb, {c0, c1}, A, lane);
     }
     __syncthreads();
-#ifdef SPX_BISECT_EARLYSTORE
-    // (experiment: the row-block's stores go out here, with whatever the tile holds, and not at the end)
-    for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS) a.y[(size_t) rb.row0 + i] = a.alpha * tile[i];
-#endif
 
     if (n_first > 0) xw_run<WAVES>(a, rb, hdr, hi, n_first, t, A, tile, xw, lane);
     while (t < n_pass) {
@@ -384,9 +380,6 @@ __device__ __forceinline__ void spmv_body_xw(const KernelArgs &a, const XcdSplit
     }
     __syncthreads();
 
-#ifdef SPX_BISECT_EARLYSTORE
-    if (a.pass_stride == 0xffffffffu)
-#endif
     if (rb.flags & SPX_RB_SHARED) {
         if (threadIdx.x == 0) a.carry[rb.carry_slot] = tile[0];
     } else {
