@@ -4,15 +4,20 @@
 // (src/internals/Vector.cpp:206-394: VecInit, VecScale, VecScaleAdd, VecAdd,
 // VecSub, VecMult, VecCopy) behind the spx_hip_vec_* entry points of
 // include/sparsex_hip.h.  All of them are pure streaming kernels (HBM-bound,
-// 16 bytes per lane and access, grid-stride); the dot product reduces per
-// wavefront with DPP shuffles, per block through LDS and across blocks in a
-// second tiny kernel, in a fixed order (bitwise reproducible).
+// 16 bytes per lane and access).  Every workgroup takes ONE contiguous 64 KB
+// chunk of each operand, workgroup b on XCD b % 8 and every XCD walking its own
+// contiguous eighth of the vector -- the access pattern of the SpMV kernels, which
+// reads 6.3-6.5 TB/s where a grid-stride sweep of a few thousand workgroups reads
+// 5.5-6.1 (tools/micro/stream_pattern.hip, profiles/r05/ablation.md).  The dot
+// product reduces per wavefront with DPP shuffles, per block through LDS and across
+// blocks in a second tiny kernel, in a fixed order (bitwise reproducible).
 #include <sparsex_hip.h>
 
 #include "common.hpp"
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <string>
 
 using namespace spx;
@@ -27,44 +32,85 @@ struct spx_hip_vec {
 namespace {
 
 constexpr int VEC_BLOCK = 256;
-constexpr int VEC_MAX_BLOCKS = 2048;    // 256 CUs x 8 blocks
+constexpr unsigned VEC_CHUNK_MAX = 4096;  // double2 per workgroup and operand: 64 KB (the dot product: reads only)
+constexpr unsigned VEC_CHUNK_MAP = 1024;  // ... 16 KB: four accesses per lane (kernels that write; measured best, tools/vec_bench.py)
+constexpr unsigned VEC_CHUNK_MIN = 1024;
+constexpr unsigned VEC_MIN_BLOCKS = 2048; // a vector is cut finely enough for eight workgroups per CU where it is long enough
 
-inline unsigned grid_for(size_t n)
+// chunks of a vector of n doubles, and the grid that covers them: 8 x the chunks of an XCD's eighth
+struct VecGrid {
+    size_t nchunks, per;
+    unsigned blocks, chunk;
+};
+
+inline VecGrid grid_for(size_t n, unsigned max_chunk)
 {
-    size_t per_block = (size_t) VEC_BLOCK * 2;          // two doubles per thread and step
-    size_t b = (n + per_block - 1) / per_block;
-    if (b < 1) b = 1;
-    if (b > (size_t) VEC_MAX_BLOCKS) b = VEC_MAX_BLOCKS;
-    return (unsigned) b;
+    VecGrid g;
+    g.chunk = max_chunk;
+    static const long forced = getenv("SPX_VEC_CHUNK") ? atol(getenv("SPX_VEC_CHUNK")) : 0;   // (sweeps: tools/vec_bench.py)
+    if (forced >= 256 && forced % 256 == 0) g.chunk = (unsigned) forced;
+    else
+        while (g.chunk > VEC_CHUNK_MIN && (n / 2 + g.chunk - 1) / g.chunk < VEC_MIN_BLOCKS) g.chunk /= 2;
+    g.nchunks = (n / 2 + g.chunk - 1) / g.chunk;
+    if (g.nchunks < 1) g.nchunks = 1;
+    g.per = (g.nchunks + 7) / 8;
+    g.blocks = (unsigned) (g.per * 8);
+    return g;
+}
+
+// doubles of dot-product scratch for a vector of n doubles: one per workgroup, and the result behind them
+inline size_t partials_for(size_t n) { return (n / 2 + 255) / 256 + 16; }     // (the finest cut there is)
+
+// the [lo, hi) range of double2 elements of workgroup b; false: no chunk
+__device__ __forceinline__ bool vec_chunk(size_t n2, size_t nchunks, size_t per, unsigned chunk_len, size_t &lo, size_t &hi)
+{
+    const size_t chunk = (size_t) (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per || chunk >= nchunks) return false;
+    lo = chunk * chunk_len;
+    hi = lo + chunk_len < n2 ? lo + chunk_len : n2;
+    return lo < hi;
 }
 
 // kind: 0 init (d = s), 1 scale (d = s*a), 2 axpy (d = a + s*b), 3 copy (d = a)
 template <int KIND>
+__device__ __forceinline__ double2 vec_map_one(double2 va, double2 vb, double s)
+{
+    if (KIND == 0) return make_double2(s, s);
+    if (KIND == 1) return make_double2(s * va.x, s * va.y);
+    if (KIND == 3) return va;
+    return make_double2(va.x + s * vb.x, va.y + s * vb.y);
+}
+
+template <int KIND>
 __global__ __launch_bounds__(VEC_BLOCK) void vec_map_kernel(double *__restrict__ d,
                                                             const double *__restrict__ a,
                                                             const double *__restrict__ b,
-                                                            double s, size_t n)
+                                                            double s, size_t n, size_t nchunks, size_t per, unsigned chunk_len)
 {
-    const size_t n2 = n / 2;
-    const size_t stride = (size_t) gridDim.x * VEC_BLOCK;
-    for (size_t i = (size_t) blockIdx.x * VEC_BLOCK + threadIdx.x; i < n2; i += stride) {
-        double2 r;
-        if (KIND == 0) {
-            r = make_double2(s, s);
-        } else {
-            const double2 va = reinterpret_cast<const double2 *>(a)[i];
-            if (KIND == 1) r = make_double2(s * va.x, s * va.y);
-            else if (KIND == 3) r = va;
-            else {
-                const double2 vb = reinterpret_cast<const double2 *>(b)[i];
-                r = make_double2(va.x + s * vb.x, va.y + s * vb.y);
-            }
-        }
-        reinterpret_cast<double2 *>(d)[i] = r;
-    }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const size_t i = n - 1;
         d[i] = KIND == 0 ? s : KIND == 1 ? s * a[i] : KIND == 3 ? a[i] : a[i] + s * b[i];
+    }
+    size_t lo, hi;
+    if (!vec_chunk(n / 2, nchunks, per, chunk_len, lo, hi)) return;
+    const double2 *a2 = reinterpret_cast<const double2 *>(a), *b2 = reinterpret_cast<const double2 *>(b);
+    double2 *d2 = reinterpret_cast<double2 *>(d);
+    size_t i = lo + threadIdx.x;
+    // four accesses per operand in flight
+    for (; i + 3 * VEC_BLOCK < hi; i += 4 * VEC_BLOCK) {
+        double2 va[4], vb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            va[k] = KIND == 0 ? make_double2(0.0, 0.0) : a2[i + k * VEC_BLOCK];
+            vb[k] = KIND == 2 ? b2[i + k * VEC_BLOCK] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d2[i + k * VEC_BLOCK] = vec_map_one<KIND>(va[k], vb[k], s);
+    }
+    for (; i < hi; i += VEC_BLOCK) {
+        const double2 va = KIND == 0 ? make_double2(0.0, 0.0) : a2[i];
+        const double2 vb = KIND == 2 ? b2[i] : make_double2(0.0, 0.0);
+        d2[i] = vec_map_one<KIND>(va, vb, s);
     }
 }
 
@@ -77,35 +123,59 @@ __device__ __forceinline__ double wave_sum(double v)
 
 __global__ __launch_bounds__(VEC_BLOCK) void vec_dot_kernel(const double *__restrict__ a,
                                                             const double *__restrict__ b,
-                                                            double *__restrict__ partials, size_t n)
+                                                            double *__restrict__ partials, size_t n,
+                                                            size_t nchunks, size_t per, unsigned chunk_len)
 {
     __shared__ double wsum[VEC_BLOCK / 64];
-    const size_t n2 = n / 2;
-    const size_t stride = (size_t) gridDim.x * VEC_BLOCK;
     double acc = 0.0;
-    for (size_t i = (size_t) blockIdx.x * VEC_BLOCK + threadIdx.x; i < n2; i += stride) {
-        const double2 va = reinterpret_cast<const double2 *>(a)[i];
-        const double2 vb = reinterpret_cast<const double2 *>(b)[i];
-        acc = fma(va.x, vb.x, acc);
-        acc = fma(va.y, vb.y, acc);
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) acc = a[n - 1] * b[n - 1];
+    size_t lo, hi;
+    if (vec_chunk(n / 2, nchunks, per, chunk_len, lo, hi)) {
+        const double2 *a2 = reinterpret_cast<const double2 *>(a), *b2 = reinterpret_cast<const double2 *>(b);
+        size_t i = lo + threadIdx.x;
+        for (; i + 3 * VEC_BLOCK < hi; i += 4 * VEC_BLOCK) {
+            double2 va[4], vb[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                va[k] = a2[i + k * VEC_BLOCK];
+                vb[k] = b2[i + k * VEC_BLOCK];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc = fma(va[k].x, vb[k].x, acc);
+                acc = fma(va[k].y, vb[k].y, acc);
+            }
+        }
+        for (; i < hi; i += VEC_BLOCK) {
+            const double2 va = a2[i], vb = b2[i];
+            acc = fma(va.x, vb.x, acc);
+            acc = fma(va.y, vb.y, acc);
+        }
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) acc = fma(a[n - 1], b[n - 1], acc);
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int w = 0; w < VEC_BLOCK / 64; ++w) t += wsum[w];
-        partials[blockIdx.x] = t;
+        partials[blockIdx.x] = t;            // (a workgroup without a chunk: 0)
     }
 }
 
-__global__ __launch_bounds__(64) void vec_dot_final_kernel(double *partials, unsigned nblocks)
+// the workgroups' sums in workgroup order (thread t: t, t + 256, ...; then the wavefronts, then the block)
+__global__ __launch_bounds__(VEC_BLOCK) void vec_dot_final_kernel(double *partials, unsigned nblocks)
 {
+    __shared__ double wsum[VEC_BLOCK / 64];
     double acc = 0.0;
-    for (unsigned i = threadIdx.x; i < nblocks; i += 64) acc += partials[i];
+    for (unsigned i = threadIdx.x; i < nblocks; i += VEC_BLOCK) acc += partials[i];
     acc = wave_sum(acc);
-    if (threadIdx.x == 0) partials[VEC_MAX_BLOCKS] = acc;
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < VEC_BLOCK / 64; ++w) t += wsum[w];
+        partials[nblocks] = t;
+    }
 }
 
 bool ok(hipError_t e, const char *what)
@@ -135,9 +205,10 @@ spx_error_t map(spx_hip_vec_t *d, const spx_hip_vec_t *a, const spx_hip_vec_t *b
                 void *stream)
 {
     if (d->size == 0) return SPX_SUCCESS;
-    hipLaunchKernelGGL(vec_map_kernel<KIND>, dim3(grid_for(d->size)), dim3(VEC_BLOCK), 0,
+    const VecGrid g = grid_for(d->size, VEC_CHUNK_MAP);
+    hipLaunchKernelGGL(vec_map_kernel<KIND>, dim3(g.blocks), dim3(VEC_BLOCK), 0,
                        static_cast<hipStream_t>(stream), d->data, a ? a->data : nullptr,
-                       b ? b->data : nullptr, s, d->size);
+                       b ? b->data : nullptr, s, d->size, g.nchunks, g.per, g.chunk);
     VEC_TRY(hipGetLastError());
     return SPX_SUCCESS;
 }
@@ -157,7 +228,7 @@ spx_hip_vec_t *spx_hip_vec_create(size_t size)
             "hipMalloc") ||
         !ok(hipMemset(v->data, 0, (size ? size : 1) * sizeof(double)), "hipMemset") ||
         !ok(hipMalloc(reinterpret_cast<void **>(&v->partials),
-                      (VEC_MAX_BLOCKS + 1) * sizeof(double)), "hipMalloc")) {
+                      partials_for(size) * sizeof(double)), "hipMalloc")) {
         if (v->data) (void) hipFree(v->data);
         delete v;
         SETERROR_1(SPX_ERR_VEC, "device vector allocation failed (no usable HIP device?)");
@@ -253,12 +324,12 @@ spx_error_t spx_hip_vec_mul(const spx_hip_vec_t *v1, const spx_hip_vec_t *v2, sp
     if (same_size(v1, v2) != SPX_SUCCESS) return SPX_FAILURE;
     if (!result) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid result pointer"); return SPX_FAILURE; }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const unsigned blocks = grid_for(v1->size);
-    hipLaunchKernelGGL(vec_dot_kernel, dim3(blocks), dim3(VEC_BLOCK), 0, stream, v1->data,
-                       v2->data, v1->partials, v1->size);
-    hipLaunchKernelGGL(vec_dot_final_kernel, dim3(1), dim3(64), 0, stream, v1->partials, blocks);
+    const VecGrid g = grid_for(v1->size, VEC_CHUNK_MAX);
+    hipLaunchKernelGGL(vec_dot_kernel, dim3(g.blocks), dim3(VEC_BLOCK), 0, stream, v1->data,
+                       v2->data, v1->partials, v1->size, g.nchunks, g.per, g.chunk);
+    hipLaunchKernelGGL(vec_dot_final_kernel, dim3(1), dim3(VEC_BLOCK), 0, stream, v1->partials, g.blocks);
     VEC_TRY(hipGetLastError());
-    VEC_TRY(hipMemcpyAsync(result, v1->partials + VEC_MAX_BLOCKS, sizeof(double),
+    VEC_TRY(hipMemcpyAsync(result, v1->partials + g.blocks, sizeof(double),
                            hipMemcpyDeviceToHost, stream));
     VEC_TRY(hipStreamSynchronize(stream));
     return SPX_SUCCESS;

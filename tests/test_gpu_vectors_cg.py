@@ -14,7 +14,9 @@ from helpers import tune
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n", [1, 2, 63, 64, 1000, 12345, 1 << 20])
+# (sizes around the kernels' chunks: 1024 / 4096 pairs of doubles per workgroup, eight XCD lists, an odd last element)
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 1000, 2047, 2048, 2049, 8191, 8193, 12345, 16 * 2048 + 1, 1 << 20,
+                               (1 << 20) + 2049, 4 * 2048 * 2048 + 5, 27993600])
 def test_blas1_against_numpy(n):
     rng = np.random.RandomState(n % 97)
     a, b = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)

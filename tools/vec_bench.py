@@ -3,7 +3,7 @@ import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sparsex_amd as sx
-for n in [1 << 20, 1 << 24, 1 << 27]:
+for n in [1 << 20, 1 << 24, 27993600, 1 << 27, 1 << 28]:
     a, b, c = sx.DeviceVector(n), sx.DeviceVector(n), sx.DeviceVector(n)
     a.init(1.0); b.init(2.0)
     def t(f, reps=50):
