@@ -35,6 +35,7 @@ constexpr int VEC_BLOCK = 256;
 constexpr unsigned VEC_CHUNK_MAX = 4096;  // double2 per workgroup and operand: 64 KB (the dot product: reads only)
 constexpr unsigned VEC_CHUNK_MAP = 1024;  // ... 16 KB: four accesses per lane (kernels that write; measured best, tools/vec_bench.py)
 constexpr unsigned VEC_CHUNK_MIN = 1024;
+constexpr unsigned VEC_DOT_BLOCKS = 4096; // most workgroups of the dot product (each ends with a store)
 constexpr unsigned VEC_MIN_BLOCKS = 2048; // a vector is cut finely enough for eight workgroups per CU where it is long enough
 
 // chunks of a vector of n doubles, and the grid that covers them: 8 x the chunks of an XCD's eighth
@@ -121,6 +122,8 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// SAME: a vector with itself (a norm): every line is loaded once
+template <bool SAME>
 __global__ __launch_bounds__(VEC_BLOCK) void vec_dot_kernel(const double *__restrict__ a,
                                                             const double *__restrict__ b,
                                                             double *__restrict__ partials, size_t n,
@@ -129,16 +132,22 @@ __global__ __launch_bounds__(VEC_BLOCK) void vec_dot_kernel(const double *__rest
     __shared__ double wsum[VEC_BLOCK / 64];
     double acc = 0.0;
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) acc = a[n - 1] * b[n - 1];
-    size_t lo, hi;
-    if (vec_chunk(n / 2, nchunks, per, chunk_len, lo, hi)) {
-        const double2 *a2 = reinterpret_cast<const double2 *>(a), *b2 = reinterpret_cast<const double2 *>(b);
+    // the workgroup's chunks: slot, slot + slots, ... of its XCD's eighth (gridDim.x / 8 slots per XCD; every
+    // workgroup ends with one store, and stores are dear next to a stream of reads: profiles/r05/ablation.md
+    // section 1b -- hence a bounded number of workgroups that each take several chunks)
+    const double2 *a2 = reinterpret_cast<const double2 *>(a), *b2 = reinterpret_cast<const double2 *>(b);
+    const size_t n2 = n / 2, slots = gridDim.x >> 3;
+    for (size_t c = blockIdx.x >> 3; c < per; c += slots) {
+        const size_t chunk = (size_t) (blockIdx.x & 7u) * per + c;
+        if (chunk >= nchunks) break;
+        const size_t lo = chunk * chunk_len, hi = lo + chunk_len < n2 ? lo + chunk_len : n2;
         size_t i = lo + threadIdx.x;
         for (; i + 3 * VEC_BLOCK < hi; i += 4 * VEC_BLOCK) {
             double2 va[4], vb[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 va[k] = a2[i + k * VEC_BLOCK];
-                vb[k] = b2[i + k * VEC_BLOCK];
+                vb[k] = SAME ? va[k] : b2[i + k * VEC_BLOCK];
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -147,7 +156,7 @@ __global__ __launch_bounds__(VEC_BLOCK) void vec_dot_kernel(const double *__rest
             }
         }
         for (; i < hi; i += VEC_BLOCK) {
-            const double2 va = a2[i], vb = b2[i];
+            const double2 va = a2[i], vb = SAME ? va : b2[i];
             acc = fma(va.x, vb.x, acc);
             acc = fma(va.y, vb.y, acc);
         }
@@ -324,9 +333,17 @@ spx_error_t spx_hip_vec_mul(const spx_hip_vec_t *v1, const spx_hip_vec_t *v2, sp
     if (same_size(v1, v2) != SPX_SUCCESS) return SPX_FAILURE;
     if (!result) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid result pointer"); return SPX_FAILURE; }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const VecGrid g = grid_for(v1->size, VEC_CHUNK_MAX);
-    hipLaunchKernelGGL(vec_dot_kernel, dim3(g.blocks), dim3(VEC_BLOCK), 0, stream, v1->data,
-                       v2->data, v1->partials, v1->size, g.nchunks, g.per, g.chunk);
+    VecGrid g = grid_for(v1->size, VEC_CHUNK_MAX);
+    {
+        static const long cap = getenv("SPX_VEC_DOT_BLOCKS") ? atol(getenv("SPX_VEC_DOT_BLOCKS")) : VEC_DOT_BLOCKS;   // (sweeps)
+        if (cap >= 8 && g.blocks > (unsigned) cap) g.blocks = (unsigned) cap & ~7u;
+    }
+    if (v1->data == v2->data)
+        hipLaunchKernelGGL(vec_dot_kernel<true>, dim3(g.blocks), dim3(VEC_BLOCK), 0, stream, v1->data,
+                           v2->data, v1->partials, v1->size, g.nchunks, g.per, g.chunk);
+    else
+        hipLaunchKernelGGL(vec_dot_kernel<false>, dim3(g.blocks), dim3(VEC_BLOCK), 0, stream, v1->data,
+                           v2->data, v1->partials, v1->size, g.nchunks, g.per, g.chunk);
     hipLaunchKernelGGL(vec_dot_final_kernel, dim3(1), dim3(VEC_BLOCK), 0, stream, v1->partials, g.blocks);
     VEC_TRY(hipGetLastError());
     VEC_TRY(hipMemcpyAsync(result, v1->partials + g.blocks, sizeof(double),

@@ -14,6 +14,7 @@ for n in [1 << 20, 1 << 24, 27993600, 1 << 27, 1 << 28]:
     ts = {"scale_add (24 B/elem)": (t(lambda: a.scale_add_into(b, c, 0.5)), 24),
           "scale (16 B/elem)": (t(lambda: a.scale_into(c, 0.5)), 16),
           "copy (16 B/elem)": (t(lambda: a.copy_into(c)), 16),
-          "dot (16 B/elem, incl. D2H of the result)": (t(lambda: a.dot(b)), 16)}
+          "dot (16 B/elem, incl. D2H of the result)": (t(lambda: a.dot(b)), 16),
+          "dot with itself (8 B/elem, incl. D2H)": (t(lambda: a.dot(a)), 8)}
     for k, (sec, bpe) in ts.items():
         print("n=%9d %-42s %8.1f us  %7.1f GB/s" % (n, k, sec * 1e6, n * bpe / sec / 1e9))
