@@ -11,6 +11,8 @@
 //   mode 6  as mode 1, and every workgroup ends with 304 doubles written (a row-block's rows of y: 2.4 KB per
 //           64 KB read): plain stores, non-temporal stores, stores into a small region that stays in the L2,
 //           and the same bytes written by one workgroup in 64 (64 x 304 doubles at once)
+//   mode 7  as mode 6 with plain stores, but a workgroup takes K consecutive chunks of its XCD's list one after the
+//           other and writes each one's 304 doubles as it goes (1 / K as many workgroups, the same stores)
 //   mode 5  as mode 1, and every workgroup also reads XKB (argv[3], default 24) kilobytes of a region small enough
 //           to stay in its XCD's L2 (what the staging of x asks of the L2-to-L1 path on top of the stream)
 // LDS bytes per workgroup (argv[2]) bound the workgroups per CU like the kernels' tiles and windows do.
@@ -137,6 +139,50 @@ static void run_wr(const double2 *p, size_t n_chunks, unsigned chunk16, double *
            10.0 * n_chunks * chunk16 * 16 / (ms * 1e6));
 }
 
+// mode 7: K chunks per workgroup, each followed by its stores
+template <int U>
+__global__ __launch_bounds__(256) void pattern_multi_kernel(const double2 *p, size_t n_chunks, unsigned chunk16, double *y,
+                                                            unsigned K, double *out)
+{
+    extern __shared__ double lds[];
+    const size_t per = (n_chunks + 7) / 8;
+    double acc = 0.0;
+    for (unsigned k = 0; k < K; ++k) {
+        const size_t slot = (size_t) (blockIdx.x >> 3) * K + k;
+        const size_t chunk = (size_t) (blockIdx.x & 7u) * per + slot;
+        if (slot >= per || chunk >= n_chunks) break;
+        const double2 *q = p + chunk * chunk16;
+        for (unsigned i = threadIdx.x; i + (U - 1) * 256u < chunk16; i += U * 256u) {
+            double2 v[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) v[j] = q[i + j * 256u];
+#pragma unroll
+            for (int j = 0; j < U; ++j) acc += v[j].x + v[j].y;
+        }
+        __syncthreads();
+        double *dst = y + chunk * 304u;
+        for (unsigned i = threadIdx.x; i < 304u; i += 256u) dst[i] = acc;
+    }
+    if (acc == 1.2345) out[0] = acc + lds[0];
+}
+
+static void run_multi(const double2 *p, size_t n_chunks, unsigned chunk16, double *y, unsigned K, double *out, size_t lds)
+{
+    hipEvent_t e0, e1;
+    (void) hipEventCreate(&e0); (void) hipEventCreate(&e1);
+    (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&pattern_multi_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const size_t per = (n_chunks + 7) / 8;
+    const unsigned blocks = (unsigned) (((per + K - 1) / K) * 8);
+    pattern_multi_kernel<4><<<blocks, 256, lds>>>(p, n_chunks, chunk16, y, K, out);
+    (void) hipDeviceSynchronize();
+    (void) hipEventRecord(e0);
+    for (int r = 0; r < 10; ++r) pattern_multi_kernel<4><<<blocks, 256, lds>>>(p, n_chunks, chunk16, y, K, out);
+    (void) hipEventRecord(e1); (void) hipEventSynchronize(e1);
+    float ms; (void) hipEventElapsedTime(&ms, e0, e1);
+    printf("mode 7 U=4 chunk %u KB, 2.4 KB written per chunk, %2u chunks per workgroup (%6u workgroups): stream %.1f GB/s\n",
+           chunk16 * 16 / 1024, K, blocks, 10.0 * n_chunks * chunk16 * 16 / (ms * 1e6));
+}
+
 // mode 5: the stream as in mode 1 plus xkb kilobytes per workgroup from an L2-resident region
 template <int U>
 __global__ __launch_bounds__(256) void pattern_l2_kernel(const double2 *p, size_t n_chunks, unsigned chunk16, const double2 *hot,
@@ -242,6 +288,7 @@ int main(int argc, char **argv)
             run_wr<4>(p, n_chunks, chunk16, y, out, blocks1, lds);
             run_wr<5>(p, n_chunks, chunk16, y, out, blocks1, lds);
         }
+        for (unsigned K : {1u, 2u, 4u, 8u, 24u}) run_multi(p, n_chunks, chunk16, y, K, out, lds);
         (void) hipFree(y);
     }
     // mode 5: the hot region is the last 64 MB of the buffer; the stream covers the rest
