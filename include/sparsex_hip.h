@@ -394,6 +394,10 @@ spx_error_t spx_hip_mat_unit_windows(spx_matrix_t *A, uint32_t budget, uint32_t 
 spx_error_t spx_hip_mat_info_sized(const spx_matrix_t *A, void *info, size_t size);
 int spx_hip_abi_version(void);
 
+/* Diagnostic: the number of parts the last spx_matvec_mult / spx_matvec_kernel on HOST vectors ran in (a large y
+ * travels back part by part behind the product; 0: the product ran in one piece). */
+int spx_hip_mat_host_parts(const spx_matrix_t *A);
+
 /* ---- export in the reference's CSX layout --------------------------------------
  * `part` is a global partition number owned by this process.  The arrays
  * stay owned by the matrix and live until spx_mat_destroy().

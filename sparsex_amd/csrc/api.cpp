@@ -2075,6 +2075,8 @@ try {
 
 int spx_hip_abi_version(void) { return SPX_HIP_ABI_VERSION; }
 
+int spx_hip_mat_host_parts(const spx_matrix_t *A) { return A && A->dev ? device_host_parts(A->dev) : 0; }
+
 spx_error_t spx_hip_mat_unit_windows(spx_matrix_t *A, uint32_t budget, uint32_t gap, spx_hip_xw_plan_t *out)
 try {
     if (!A || !out) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid argument"); return SPX_FAILURE; }

@@ -85,6 +85,7 @@ int device_get_waves(const DeviceMatrix *m);
 // unit windows of x in LDS + pipelined unit passes (csx_spmv_xw_kernel; xwindows.hpp): available where
 // the stream was uploaded with a window budget and some row-block's columns fit it
 bool device_has_xw(const DeviceMatrix *m);
+int device_host_parts(const DeviceMatrix *m);   // parts of the last product on host vectors whose y went back part by part (0: whole)
 void device_set_xw(DeviceMatrix *m, bool on);
 bool device_get_xw(const DeviceMatrix *m);
 void device_xw_info(const DeviceMatrix *m, uint64_t &elems_lds, uint64_t &unit_elems, uint64_t &staged_doubles,

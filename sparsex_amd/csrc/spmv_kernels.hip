@@ -685,7 +685,10 @@ struct DeviceMatrix {
     double *p_x = nullptr, *p_y = nullptr;      // pinned
     uint64_t x_version = 0;                      // contents of d_x (0: unknown)
     hipStream_t host_stream = nullptr;
+    hipStream_t copy_stream = nullptr;          // the way back of y, part by part behind the product (device_spmv_host)
     std::vector<hipEvent_t> stage_events;       // one behind every piece of a staged download
+    std::vector<hipEvent_t> part_events;        // one behind every part of a product whose y travels back in parts
+    int host_parts = 0;                         // parts of the last product on host vectors (0: in one piece)
     size_t value_bytes = 0, index_bytes = 0;
     size_t n_values = 0, n_descs = 0, n_passes = 0, n_cidx = 0, n_segrows = 0;
     // every array of the stream lives in ONE allocation (2 MB-aligned pieces): one mapping, one
@@ -706,7 +709,7 @@ struct DeviceMatrix {
         std::vector<size_t> bounds;
         size_t asked = 0;
     };
-    ChunkPlan chunks[2];
+    ChunkPlan chunks[3];                        // 0: an attached exchange plan's, 1: spx_hip_matvec_parts', 2: the host entry point's
     // unit windows of x in LDS (xwindows.hpp; plain general streams): a second set of pass headers and
     // descriptors for csx_spmv_xw_kernel, the window table, the LDS a launch needs
     SpxPass *passes_xw = nullptr;
@@ -1069,7 +1072,9 @@ void device_free(DeviceMatrix *m)
     if (m->p_x) (void) hipHostFree(m->p_x);
     if (m->p_y) (void) hipHostFree(m->p_y);
     if (m->host_stream) (void) hipStreamDestroy(m->host_stream);
+    if (m->copy_stream) (void) hipStreamDestroy(m->copy_stream);
     for (hipEvent_t e : m->stage_events) (void) hipEventDestroy(e);
+    for (hipEvent_t e : m->part_events) (void) hipEventDestroy(e);
     delete m;
 }
 
@@ -1231,7 +1236,7 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
 // first row of every part (+ the end) in `row_bounds`.
 size_t device_plan_chunks(DeviceMatrix *m, size_t K, std::vector<size_t> &row_bounds, int slot)
 {
-    DeviceMatrix::ChunkPlan &cp = m->chunks[slot ? 1 : 0];
+    DeviceMatrix::ChunkPlan &cp = m->chunks[slot < 0 || slot > 2 ? 0 : slot];
     if (K >= 2 && K == cp.asked && !cp.split.empty()) {      // (the same cut as last time)
         row_bounds = cp.bounds;
         return cp.split.size();
@@ -1278,7 +1283,7 @@ size_t device_plan_chunks(DeviceMatrix *m, size_t K, std::vector<size_t> &row_bo
 
 void device_spmv_chunk(DeviceMatrix *m, size_t k, double alpha, const double *d_x, double beta, double *d_y, void *stream_, int slot)
 {
-    const DeviceMatrix::ChunkPlan &cp = m->chunks[slot ? 1 : 0];
+    const DeviceMatrix::ChunkPlan &cp = m->chunks[slot < 0 || slot > 2 ? 0 : slot];
     if (k >= cp.split.size()) throw FatalError("no such part of the stream (device_plan_chunks)");
     m->launched_since_edit = true;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -1367,6 +1372,8 @@ void device_set_waves(DeviceMatrix *m, int waves)
 
 int device_get_waves(const DeviceMatrix *m) { return m->waves; }
 
+int device_host_parts(const DeviceMatrix *m) { return m ? m->host_parts : 0; }
+
 bool device_has_xw(const DeviceMatrix *m) { return m->passes_xw != nullptr; }
 void device_set_xw(DeviceMatrix *m, bool on) { m->xw_on = on && m->passes_xw && !m->wave_tiles; }
 bool device_get_xw(const DeviceMatrix *m) { return m->xw_on && m->passes_xw && !m->wave_tiles; }
@@ -1432,6 +1439,8 @@ double device_time_spmv(DeviceMatrix *m, int warmup, int launches)
 namespace {
 
 constexpr size_t STAGE_PIECE = (size_t) 16 << 20;      // bytes
+constexpr size_t HOST_PARTS = 8;                       // parts of a product whose y goes back part by part ...
+constexpr size_t HOST_PARTS_MIN_BYTES = (size_t) 32 << 20;   // ... where y is at least this large
 
 void copy_threads(void *dst, const void *src, size_t bytes)
 {
@@ -1481,6 +1490,47 @@ void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x, bool x_p
         if (y_pinned) HIP_CHECK(hipMemcpyAsync(m->d_y, h_y, yb, hipMemcpyHostToDevice, st));
         else upload_staged(m->d_y, m->p_y, h_y, yb, st);
     }
+    // A large y goes back in parts behind the product: the stream is cut into parts of whole rows (where it can be:
+    // device_plan_chunks), every part's rows start on their way as soon as its kernel has ended, on a stream of
+    // their own, while the next part runs -- the download of the bench matrix's 224 MB takes three times as long as
+    // its product.
+    static const size_t parts_from = getenv("SPX_HOST_PARTS_MIN_BYTES") ? (size_t) atoll(getenv("SPX_HOST_PARTS_MIN_BYTES"))
+                                                                        : HOST_PARTS_MIN_BYTES;    // (tests: small matrices)
+    if (!after && whole && yb >= parts_from) {
+        std::vector<size_t> bounds;
+        const size_t K = device_plan_chunks(m, HOST_PARTS, bounds, 2);
+        m->host_parts = (int) K;
+        if (K >= 2) {
+            if (!m->copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
+            while (m->part_events.size() < 2 * K) {
+                hipEvent_t e;
+                HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                m->part_events.push_back(e);
+            }
+            for (size_t k = 0; k < K; ++k) {
+                device_spmv_chunk(m, k, alpha, m->d_x, beta, m->d_y, st, 2);
+                HIP_CHECK(hipEventRecord(m->part_events[k], st));
+                HIP_CHECK(hipStreamWaitEvent(m->copy_stream, m->part_events[k], 0));
+                const size_t off = bounds[k] * sizeof(double), n = (bounds[k + 1] - bounds[k]) * sizeof(double);
+                if (!n) continue;
+                char *dst = reinterpret_cast<char *>(y_pinned ? h_y : m->p_y) + off;
+                HIP_CHECK(hipMemcpyAsync(dst, reinterpret_cast<char *>(m->d_y) + off, n, hipMemcpyDeviceToHost, m->copy_stream));
+                if (!y_pinned) HIP_CHECK(hipEventRecord(m->part_events[K + k], m->copy_stream));
+            }
+            if (y_pinned) {
+                HIP_CHECK(hipStreamSynchronize(m->copy_stream));
+                return;
+            }
+            for (size_t k = 0; k < K; ++k) {
+                const size_t off = bounds[k] * sizeof(double), n = (bounds[k + 1] - bounds[k]) * sizeof(double);
+                if (!n) continue;
+                HIP_CHECK(hipEventSynchronize(m->part_events[K + k]));
+                copy_threads(reinterpret_cast<char *>(h_y) + off, reinterpret_cast<char *>(m->p_y) + off, n);
+            }
+            return;
+        }
+    }
+    m->host_parts = 0;
     device_spmv(m, alpha, m->d_x, beta, m->d_y, st);
     if (after) after(m->d_y, st);
     if (y_pinned) {

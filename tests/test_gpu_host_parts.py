@@ -1,0 +1,74 @@
+"""spx_matvec_mult / spx_matvec_kernel on HOST vectors (reference src/api/matvec.c:551-620) where y is large: the
+product runs in parts of whole rows and every part's rows travel back while the next part runs
+(device_spmv_host).  SPX_HOST_PARTS_MIN_BYTES (read once per process) lowers the size from which that happens, so
+that small matrices exercise it: both kinds of vectors (views of user buffers, vectors the library created), beta
+zero and non-zero, matrices the stream of which can and cannot be cut."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import ctypes as C, sys
+import numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import sparsex_amd as sx
+from sparsex_amd import synth
+from sparsex_amd.api import VectorStruct
+from helpers import tune, check_y
+cases = [("kkt", synth.syn_nlpkkt(22), {}), ("cant", synth.syn_cant(0.4), {}), ("web", synth.syn_webbase(0.2), {}),
+         ("kkt-sym", synth.syn_nlpkkt(16), {"spx.matrix.symmetric": "true"}),
+         ("kkt-plain", synth.syn_nlpkkt(22), {"spx.gpu.unit_windows": "false", "spx.gpu.waves": "8"})]
+L = sx.lib()
+L.spx_hip_mat_host_parts.restype = C.c_int
+L.spx_vec_create_random.restype = C.POINTER(VectorStruct); L.spx_vec_create_random.argtypes = [C.c_size_t, C.c_void_p]
+L.spx_vec_create.restype = C.POINTER(VectorStruct); L.spx_vec_create.argtypes = [C.c_size_t, C.c_void_p]
+L.spx_mat_get_partition.restype = C.c_void_p
+for name, csr, opts in cases:
+    n = csr[3]
+    A = tune(csr, opts, sym=opts.get("spx.matrix.symmetric") == "true")
+    x = synth.random_x(n)
+    # views of user buffers
+    y = np.full(n, np.nan)
+    A.matvec_mult(0.5, x, y)
+    check_y(csr, x, y, 0.5)
+    parts = L.spx_hip_mat_host_parts(C.c_void_p(A.handle))
+    if not %(expect_parts)s or name == "kkt-sym":                   # (symmetric streams are not cut)
+        assert parts == 0, (name, parts)
+    elif name != "web":                                             # (web: cut unless the tuner chose column slices)
+        assert parts >= 2, (name, parts)
+    y0 = synth.random_x(n, seed=3)
+    y = y0.copy()
+    A.matvec_kernel(2.0, x, -0.5, y)
+    check_y(csr, x, y, 2.0, -0.5, y0)
+    # vectors the library created (page-locked, x resident between calls)
+    part = C.c_void_p(L.spx_mat_get_partition(C.c_void_p(A.handle)))
+    xv, yv = L.spx_vec_create_random(n, part), L.spx_vec_create(n, part)
+    xa = np.ctypeslib.as_array(xv.contents.elements, shape=(n,))
+    ya = np.ctypeslib.as_array(yv.contents.elements, shape=(n,))
+    for rep in range(2):
+        ya[:] = np.nan
+        assert L.spx_matvec_mult(C.c_double(0.5), C.c_void_p(A.handle), xv, yv) == 0
+        check_y(csr, xa.copy(), ya.copy(), 0.5)
+    ya[:] = y0
+    L.spx_matvec_kernel.argtypes = [C.c_double, C.c_void_p, C.POINTER(VectorStruct), C.c_double, C.POINTER(VectorStruct)]
+    assert L.spx_matvec_kernel(2.0, C.c_void_p(A.handle), xv, -0.5, yv) == 0
+    check_y(csr, xa.copy(), ya.copy(), 2.0, -0.5, y0)
+    L.spx_vec_destroy(xv); L.spx_vec_destroy(yv)
+    A.destroy()
+    sx.options_reset()
+    print("ok", name)
+'''
+
+
+@pytest.mark.parametrize("min_bytes", ["1024", "1000000000000"])
+def test_host_vectors_with_and_without_parts(min_bytes):
+    env = dict(os.environ, SPX_HOST_PARTS_MIN_BYTES=min_bytes)
+    code = CHILD % {"root": ROOT, "tests": os.path.join(ROOT, "tests"), "expect_parts": str(min_bytes == "1024")}
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.count("ok ") == 5
