@@ -109,6 +109,10 @@ __global__ __launch_bounds__(256) void pattern_wr_kernel(const double2 *p, size_
             if (STORE == 2) __builtin_nontemporal_store(acc, dst + i);
             else dst[i] = acc;
         }
+    } else if (STORE == 6) {
+        if (threadIdx.x == 0) y[chunk] = acc;                    // one lane, 8 bytes (a dot product's partial sum)
+    } else if (STORE == 7) {
+        if (threadIdx.x == 0) atomicAdd(y + (chunk & 1023u), acc);   // ... as an atomic add to one of 1024 doubles
     } else if (STORE == 5) {
         double *dst = y + chunk * 298u + 1u;
         for (unsigned i = threadIdx.x; i < 298u; i += 256u) dst[i] = acc;
@@ -134,7 +138,8 @@ static void run_wr(const double2 *p, size_t n_chunks, unsigned chunk16, double *
     (void) hipEventRecord(e1); (void) hipEventSynchronize(e1);
     float ms; (void) hipEventElapsedTime(&ms, e0, e1);
     static const char *what[] = {"no stores", "plain stores", "non-temporal stores", "stores into an L2-resident region",
-                                 "one workgroup in 64 stores 64 tiles", "298 doubles, tiles packed (partial lines)"};
+                                 "one workgroup in 64 stores 64 tiles", "298 doubles, tiles packed (partial lines)",
+                                 "ONE lane stores 8 bytes", "one lane adds atomically to 1 of 1024"};
     printf("mode 6 U=4 chunk %u KB, 2.4 KB written per chunk, %-36s: stream %.1f GB/s\n", chunk16 * 16 / 1024, what[STORE],
            10.0 * n_chunks * chunk16 * 16 / (ms * 1e6));
 }
@@ -287,6 +292,8 @@ int main(int argc, char **argv)
             run_wr<3>(p, n_chunks, chunk16, y, out, blocks1, lds);
             run_wr<4>(p, n_chunks, chunk16, y, out, blocks1, lds);
             run_wr<5>(p, n_chunks, chunk16, y, out, blocks1, lds);
+            run_wr<6>(p, n_chunks, chunk16, y, out, blocks1, lds);
+            run_wr<7>(p, n_chunks, chunk16, y, out, blocks1, lds);
         }
         for (unsigned K : {1u, 2u, 4u, 8u, 24u}) run_multi(p, n_chunks, chunk16, y, K, out, lds);
         (void) hipFree(y);
