@@ -297,6 +297,20 @@ int main(int argc, char **argv)
         }
         for (unsigned K : {1u, 2u, 4u, 8u, 24u}) run_multi(p, n_chunks, chunk16, y, K, out, lds);
         (void) hipFree(y);
+        // ... and y in memory allocated otherwise: fine-grained, uncached
+        for (unsigned flag : {(unsigned) hipDeviceMallocFinegrained, (unsigned) hipDeviceMallocUncached}) {
+            double *y2 = nullptr;
+            if (hipExtMallocWithFlags(reinterpret_cast<void **>(&y2), (n_chunks + 64) * 304 * sizeof(double), flag) != hipSuccess) {
+                printf("hipExtMallocWithFlags(%u) failed\n", flag);
+                (void) hipGetLastError();
+                continue;
+            }
+            printf("y allocated with hipExtMallocWithFlags(%s):\n", flag == (unsigned) hipDeviceMallocFinegrained ? "hipDeviceMallocFinegrained" : "hipDeviceMallocUncached");
+            run_wr<0>(p, n_chunks, chunk16, y2, out, blocks1, lds);
+            run_wr<1>(p, n_chunks, chunk16, y2, out, blocks1, lds);
+            run_wr<2>(p, n_chunks, chunk16, y2, out, blocks1, lds);
+            (void) hipFree(y2);
+        }
     }
     // mode 5: the hot region is the last 64 MB of the buffer; the stream covers the rest
     {
