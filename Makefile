@@ -13,9 +13,9 @@ LIB       := $(LIBDIR)/libsparsex.so
 SYNLIB    := $(LIBDIR)/libspxsynth.so
 
 HOST_SRCS := common.cpp config.cpp partition.cpp stats.cpp encoder.cpp input.cpp reorder.cpp \
-             csx_emit.cpp gpu_emit.cpp stream_index.cpp xwindows.cpp dist.cpp api.cpp
+             csx_emit.cpp gpu_emit.cpp stream_index.cpp xwindows.cpp sxplan.cpp dist.cpp api.cpp
 HOST_OBJS := $(HOST_SRCS:%.cpp=$(OBJDIR)/%.o)
-HIP_OBJ   := $(OBJDIR)/spmv_kernels.o $(OBJDIR)/spmv_xw_kernels.o $(OBJDIR)/vec_kernels.o $(OBJDIR)/dist_kernels.o
+HIP_OBJ   := $(OBJDIR)/spmv_kernels.o $(OBJDIR)/spmv_xw_kernels.o $(OBJDIR)/spmv_sx_kernels.o $(OBJDIR)/vec_kernels.o $(OBJDIR)/dist_kernels.o
 
 CXXFLAGS  := -std=c++17 -O2 -g -fPIC -Wall -Iinclude -I$(CSRC) -pthread
 HIPFLAGS  := --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -munsafe-fp-atomics \

@@ -648,6 +648,8 @@ static void emit_and_upload(spx_matrix_t *A)
     gs.xw_budget = (A->unit_windows != 0 && !A->deterministic && !sym) ? A->xw_budget : 0u;
     gs.xw_gap = A->xw_gap;
     gs.xw_on = A->xw_on;
+    gs.sx_plan = sym && A->sym_pipeline != 0 && !A->deterministic && A->wave_tiles != 1;
+    gs.sx_on = A->sx_on;
     gs.sym_atomic = A->sym_atomic && !A->deterministic;
     gs.deterministic = A->deterministic;
     gs.wave_tiles = A->deterministic || A->wave_tiles == 1;
@@ -985,6 +987,7 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     A->emit_params.recut_linear = cfg.get_bool("spx.gpu.recut_linear");
     A->emit_params.keep_units = cfg.get_bool("spx.gpu.keep_units");
     A->emit_params.inline_desc = cfg.get_bool("spx.gpu.inline_desc");
+    A->emit_params.sym_pure_passes = cfg.get_bool("spx.gpu.sym_pure_passes");
     A->emit_params.x_window = cfg.get_bool("spx.gpu.x_window");
     {
         const std::string m = cfg.get_str("spx.gpu.sym_segments");
@@ -1047,6 +1050,13 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     }
     A->unit_windows = xw_mode == "auto" ? -1 : (xw_mode == "true" ? 1 : 0);
     A->xw_on = xw_mode == "true";                       // (auto: off until measured)
+    const std::string sx_mode = cfg.get_str("spx.gpu.sym_pipeline");
+    if (sx_mode != "auto" && sx_mode != "true" && sx_mode != "false") {
+        log_msg(LOG_ERR, "spx.gpu.sym_pipeline: true, false or auto\n");
+        throw FatalError("bad spx.gpu.sym_pipeline");
+    }
+    A->sym_pipeline = sx_mode == "auto" ? -1 : (sx_mode == "true" ? 1 : 0);
+    A->sx_on = sx_mode == "true";                       // (auto: off until measured)
     const std::string ph_mode = cfg.get_str("spx.gpu.col_phases");
     const bool ph_conc = ph_mode.size() == 2 && ph_mode[0] == 'c';
     long ph_fixed = ph_mode == "auto" ? 0 : strtol(ph_mode.c_str() + (ph_conc ? 1 : 0), nullptr, 10);
@@ -1070,6 +1080,23 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     const double t_auto = now_sec();
     if (A->dev && A->nnz_stored >= 100000 && (autotune || tune_spill || tune_wt || tune_xw))
         autotune_launch(A.get(), autotune, tune_spill, tune_wt, tune_xw);
+    // the read-once passes pipelined (csx_spmv_sx_kernel) against the plain read-once kernel, with whatever
+    // the launch tuner settled on
+    if (A->dev && sym && A->sym_pipeline == -1 && device_has_sx(A->dev)) {
+        A->release_wait();
+        const double t_est = device_time_spmv(A->dev, 2, 3);
+        const int N = (int) std::min(100.0, std::max(8.0, 0.02 / std::max(t_est, 1e-7)));
+        auto best_of = [&](bool on) {
+            device_set_sx(A->dev, on);
+            double best = device_time_spmv(A->dev, std::max(2, N / 10), N);
+            for (int rep = 0; rep < 3; ++rep) best = std::min(best, device_time_spmv(A->dev, 0, N));
+            return best;
+        };
+        const double t0 = best_of(false), t1 = best_of(true);
+        A->sx_on = t1 < 0.985 * t0;
+        device_set_sx(A->dev, A->sx_on);
+        log_msg(LOG_INFO, "read-once pipeline: %s (%.2f us per SpMV with, %.2f without)\n", A->sx_on ? "on" : "off", 1e6 * t1, 1e6 * t0);
+    }
     const double t_auto_end = now_sec();
     // column phases (auto): where the leftovers dominate and x is far larger than the L2 of an
     // XCD, the gathers miss it more often than not (syn-webbase: 1.6 M line fills for 2.5 M
@@ -1586,6 +1613,7 @@ try {
     h.sym_atomic = gs->sym_atomic ? 1u : 0u;
     // (bit 2: the product runs with the unit windows of x in LDS; bits 8-15 / 16-31: their gap and budget)
     h.pad3 = (gs->deterministic ? 1u : 0u) | (gs->wave_tiles ? 2u : 0u);
+    if (gs->sx_on) h.pad3 |= 8u;                       // (bit 3: the read-once passes run pipelined)
     if (gs->xw_on) h.pad3 |= 4u | ((gs->xw_gap & 255u) << 8) | (std::min<uint32_t>(gs->xw_budget, 65535u) << 16);
     h.checksum = stream_checksum(*gs);
     bool good = fwrite(kMagic, 1, 8, f) == 8 && fwrite(&h, sizeof(h), 1, f) == 1;
@@ -1676,6 +1704,8 @@ try {
         gs->deterministic = (h.pad3 & 1u) != 0;
         gs->wave_tiles = (h.pad3 & 2u) != 0;
         gs->xw_on = (h.pad3 & 4u) != 0;
+        gs->sx_on = (h.pad3 & 8u) != 0;
+        gs->sx_plan = gs->sx_on;
         gs->xw_gap = gs->xw_on ? ((h.pad3 >> 8) & 255u) : 16u;
         gs->xw_budget = gs->xw_on ? (h.pad3 >> 16) : 0u;
         gs->nnz_stored = h.nnz_stored; gs->n_unit_elems = h.n_unit_elems;
@@ -1715,6 +1745,8 @@ try {
     A->wave_tiles = gs->wave_tiles ? 1 : 0;
     A->xw_on = gs->xw_on;
     A->unit_windows = gs->xw_on ? 1 : 0;
+    A->sx_on = gs->sx_on;
+    A->sym_pipeline = gs->sx_on ? 1 : 0;
     A->xw_budget = gs->xw_budget;
     A->xw_gap = gs->xw_gap;
     {

@@ -65,6 +65,8 @@ void Config::reset_defaults()
     props_["spx.gpu.sym_wide_rows"] = "1024";  // rows of a row-block with read-once segments (several planned row-blocks side by side)
     props_["spx.gpu.sym_spill"] = "auto";      // symmetric tiles' transposed sums: lists | atomic | auto (measured)
     props_["spx.gpu.sym_remine"] = "true";     // symmetric: re-cut the mirrored triangle into row segments
+    props_["spx.gpu.sym_pure_passes"] = "true"; // symmetric, read-once segments: long runs fill passes of their own (one descriptor, in the header)
+    props_["spx.gpu.sym_pipeline"] = "auto";   // ... and those passes run pipelined, x requested with the values (csx_spmv_sx_kernel): true | false | auto (measured)
     props_["spx.gpu.unit_windows"] = "auto";   // general path: the columns of a row-block's unit passes staged in LDS, unit passes pipelined: true | false | auto (measured)
     props_["spx.gpu.unit_window_doubles"] = "3072";  // ... most doubles of x a row-block may stage for them
     props_["spx.gpu.unit_window_gap"] = "16";  // ... column intervals closer than this are staged as one

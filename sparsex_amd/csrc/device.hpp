@@ -91,6 +91,13 @@ bool device_get_xw(const DeviceMatrix *m);
 void device_xw_info(const DeviceMatrix *m, uint64_t &elems_lds, uint64_t &unit_elems, uint64_t &staged_doubles,
                     uint32_t &lds_bytes);
 
+// the read-once passes of a symmetric stream pipelined (csx_spmv_sx_kernel; sxplan.hpp): available where the
+// stream holds read-once row segments, no tiles, and was uploaded with GpuStream::sx_plan
+bool device_has_sx(const DeviceMatrix *m);
+void device_set_sx(DeviceMatrix *m, bool on);
+bool device_get_sx(const DeviceMatrix *m);
+void device_sx_info(const DeviceMatrix *m, uint64_t &elems_sx, uint64_t &elems_sym, size_t &rowblocks);
+
 // seconds per SpMV (alpha = 1, beta = 0) over `launches` back-to-back launches
 // on a private stream with scratch vectors -- what spx_mat_tune() measures to
 // choose launch parameters

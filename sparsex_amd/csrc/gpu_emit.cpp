@@ -107,12 +107,17 @@ struct Group {
     uint8_t step;
     uint32_t voff;       // into RbBuilder::gvals_
     uint32_t slot0 = SPX_NO_SLOT;   // SPX_PASS_SYMSEG: slot of segment 0's first column
+    bool pure = false;              // read-once segments, spx.gpu.sym_pure_passes: fills passes of its own (split_pure_groups)
 };
+
+// (read-once passes of one unit: a run of this many segments and more gets passes of its own)
+constexpr uint32_t PURE_MIN_SEGS = 32;
 
 class RbBuilder {
 public:
-    RbBuilder(const Partition &p, GpuStream &out, bool stack = true, bool x_window = true, bool inline_desc = true)
-        : p_(p), out_(out), stack_(stack), x_window_(x_window), inline_desc_(inline_desc) {}
+    RbBuilder(const Partition &p, GpuStream &out, bool stack = true, bool x_window = true, bool inline_desc = true,
+              bool pure_passes = false)
+        : p_(p), out_(out), stack_(stack), x_window_(x_window), inline_desc_(inline_desc), pure_passes_(pure_passes) {}
 
     // rows [lo, hi) of the partition with what the planner cut out for them
     struct Part {
@@ -152,7 +157,11 @@ private:
     }
     void groups_from_piece(const Piece &pc, idx_t lo);
     void stack_groups();
-    void emit_unit_passes(SpxRowBlock &rb, bool sym = false, uint32_t row_base = 0);
+    // which groups a call of emit_unit_passes takes: all of them, or (read-once segments with passes of their own)
+    // only the groups marked `pure`, each filling passes that hold nothing else / only the others
+    enum PassSet { ALL_GROUPS, PURE_GROUPS, MIXED_GROUPS };
+    void emit_unit_passes(SpxRowBlock &rb, bool sym = false, uint32_t row_base = 0, PassSet which = ALL_GROUPS);
+    void split_pure_groups();
     void assign_slots(SpxRowBlock &rb, const std::vector<const SymTile *> *tiles,
                       const std::vector<const SymSeg *> *symsegs);
     void slot_symseg_groups(const SpxRowBlock &rb);
@@ -173,6 +182,7 @@ private:
     bool stack_;
     bool x_window_;
     bool inline_desc_;
+    bool pure_passes_;
     std::vector<Group> groups_;
     std::vector<val_t> gvals_;
     std::vector<idx_t> slot_groups_;   // first columns of the row-block's slot groups (ascending)
@@ -371,7 +381,47 @@ void RbBuilder::stack_groups()
     gvals_.swap(vals);
 }
 
-void RbBuilder::emit_unit_passes(SpxRowBlock &rb, bool sym, uint32_t row_base)
+// Read-once segments, spx.gpu.sym_pure_passes: a long run of segments (a diagonal chain of a stencil, the rows
+// of a block) is given passes that hold nothing but its own lanes.  Such a pass has ONE descriptor, which
+// travels in its header (SPX_PASSF_INLINE): the kernel knows every lane's row, columns and slot from the
+// header alone and requests x together with the values (csx_spmv_sx_kernel), instead of after a descriptor
+// load.  The last pass of a run may be partly filled -- idle lanes cost no bytes -- but a tail shorter than
+// PURE_MIN_SEGS is cut off as a unit of its own (8 + 8 bytes of descriptor) and shares passes with the
+// other short ones.
+void RbBuilder::split_pure_groups()
+{
+    std::vector<Group> out;
+    out.reserve(groups_.size() + 16);
+    for (Group g : groups_) {
+        if (g.nseg < PURE_MIN_SEGS) {
+            out.push_back(g);
+            continue;
+        }
+        const uint32_t tail = g.nseg % SPX_PASS_SEGS;
+        if (tail == 0 || tail >= PURE_MIN_SEGS) {
+            g.pure = true;
+            out.push_back(g);
+            continue;
+        }
+        const int dcol = (g.kind == SPX_KIND_HORIZ || g.kind == SPX_KIND_DIAG) ? (int) g.step
+                         : (g.kind == SPX_KIND_ADIAG ? -(int) g.step : 0);
+        const int drow = g.kind == SPX_KIND_BLOCK ? 1 : (g.kind >= SPX_KIND_VERT ? (int) g.step : 0);
+        const uint32_t head = g.nseg - tail;
+        Group t = g;
+        t.row0 = (uint16_t)(g.row0 + head * (uint32_t) drow);
+        t.col0 = (uint32_t)((int64_t) g.col0 + (int64_t) head * dcol);
+        t.nseg = (uint16_t) tail;
+        t.voff = g.voff + head * g.width;
+        if (g.slot0 != SPX_NO_SLOT) t.slot0 = (uint32_t)((int64_t) g.slot0 + (int64_t) head * dcol);
+        g.nseg = (uint16_t) head;
+        g.pure = true;
+        out.push_back(g);
+        out.push_back(t);
+    }
+    groups_.swap(out);
+}
+
+void RbBuilder::emit_unit_passes(SpxRowBlock &rb, bool sym, uint32_t row_base, PassSet which)
 {
     // passes hold segments of one width: order the groups by width
     std::vector<uint32_t> order(groups_.size());
@@ -418,7 +468,9 @@ void RbBuilder::emit_unit_passes(SpxRowBlock &rb, bool sym, uint32_t row_base)
     uint8_t cur_w = 0;
     for (uint32_t gi : order) {
         const Group &g = groups_[gi];
-        if (g.width != cur_w) {
+        if (which == PURE_GROUPS && !g.pure) continue;
+        if (which == MIXED_GROUPS && g.pure) continue;
+        if (g.width != cur_w || which == PURE_GROUPS) {
             flush(cur_w);
             cur_w = g.width;
         }
@@ -789,20 +841,39 @@ void RbBuilder::emit(std::vector<Part> &parts, uint8_t flags, uint32_t carry_slo
     for (const Part &pt : parts)
         if (pt.tiles) emit_tile_passes(rb, *pt.tiles, (uint32_t)(pt.lo - lo));
     size_t n_sym = 0, n_unit = 0;
-    for (const Part &pt : parts) {
-        if (!pt.symsegs || pt.symsegs->empty()) continue;
-        // row segments of the lower triangle that are read once: grouped like any others,
-        // then given their slots
-        groups_.clear();
-        gvals_.clear();
-        for (const SymSeg *sg : *pt.symsegs) {
-            add_group(sg->row - p_.row_start - pt.lo, sg->col, 1, sg->width, SPX_KIND_HORIZ, 0);
-            gvals_.insert(gvals_.end(), sg->v, sg->v + sg->width);
+    {
+        // row segments of the lower triangle that are read once: grouped like any others, then given
+        // their slots.  With passes of their own for the long runs (split_pure_groups) those passes
+        // come first, of all parts, and the mixed ones behind them: the kernel pipelines the
+        // leading run of a row-block's passes
+        struct SymPart { std::vector<Group> groups; std::vector<val_t> vals; uint32_t row_base; };
+        std::vector<SymPart> sym_parts;
+        for (const Part &pt : parts) {
+            if (!pt.symsegs || pt.symsegs->empty()) continue;
+            groups_.clear();
+            gvals_.clear();
+            for (const SymSeg *sg : *pt.symsegs) {
+                add_group(sg->row - p_.row_start - pt.lo, sg->col, 1, sg->width, SPX_KIND_HORIZ, 0);
+                gvals_.insert(gvals_.end(), sg->v, sg->v + sg->width);
+            }
+            n_sym += gvals_.size();
+            if (stack_) stack_groups();
+            slot_symseg_groups(rb);
+            if (pure_passes_) split_pure_groups();
+            sym_parts.push_back(SymPart{});
+            sym_parts.back().groups.swap(groups_);
+            sym_parts.back().vals.swap(gvals_);
+            sym_parts.back().row_base = (uint32_t)(pt.lo - lo);
         }
-        n_sym += gvals_.size();
-        if (stack_) stack_groups();
-        slot_symseg_groups(rb);
-        emit_unit_passes(rb, true, (uint32_t)(pt.lo - lo));
+        for (int round = 0; round < (pure_passes_ ? 2 : 1); ++round)
+            for (SymPart &sp : sym_parts) {
+                groups_.swap(sp.groups);
+                gvals_.swap(sp.vals);
+                emit_unit_passes(rb, true, sp.row_base,
+                                 !pure_passes_ ? ALL_GROUPS : (round == 0 ? PURE_GROUPS : MIXED_GROUPS));
+                groups_.swap(sp.groups);
+                gvals_.swap(sp.vals);
+            }
     }
     for (const Part &pt : parts) {
         groups_.clear();
@@ -1744,7 +1815,7 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsi
         // (address space for the values up front -- the nonzeros plus an eighth of padding: pages come as they
         // are written, and a 200 MB array is not copied again each time it doubles)
         if (p.nnz * sizeof(val_t) >= ((size_t) 32 << 20)) out.values.reserve(out.values.size() + p.nnz + p.nnz / 8 + 1024);
-        RbBuilder bld(p, out, prm.stack_segments, prm.x_window, prm.inline_desc);
+        RbBuilder bld(p, out, prm.stack_segments, prm.x_window, prm.inline_desc, prm.sym_pure_passes);
         for (size_t k = 0; k < jobs.size(); ++k) emit_job(k, bld, out);
         return;
     }
@@ -1752,7 +1823,7 @@ void emit_gpu(const Partition &p, const GpuEmitParams &prm, GpuStream &out, unsi
     std::vector<GpuStream> locs(n_chunks);
     parallel_for(n_chunks, nthreads, [&](size_t c) {
         const size_t lo = jobs.size() * c / n_chunks, hi = jobs.size() * (c + 1) / n_chunks;
-        RbBuilder bld(p, locs[c], prm.stack_segments, prm.x_window, prm.inline_desc);
+        RbBuilder bld(p, locs[c], prm.stack_segments, prm.x_window, prm.inline_desc, prm.sym_pure_passes);
         for (size_t k = lo; k < hi; ++k) emit_job(k, bld, locs[c]);
     });
     for (GpuStream &l : locs) append_stream(out, std::move(l));

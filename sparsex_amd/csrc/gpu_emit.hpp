@@ -82,6 +82,9 @@ struct GpuStream {
     // whether the product starts out using them (the launch tuner measures both)
     uint32_t xw_budget = 0, xw_gap = 16;
     bool xw_on = false;
+    // spx.gpu.sym_pipeline (device side only, sxplan.hpp): plan the read-once pipeline at upload, and whether
+    // the product starts out using it (the launch tuner measures both)
+    bool sx_plan = false, sx_on = false;
     // accounting
     size_t nnz_stored = 0;        // nonzeros held in `values` (without padding)
     size_t n_unit_elems = 0;
@@ -122,6 +125,8 @@ struct GpuEmitParams {
                                   // whose columns lie close together
     int sym_segments = -1;        // spx.gpu.sym_segments: 1 / 0, -1 = where most of the lower triangle
                                   // lies in runs of three and more columns
+    bool sym_pure_passes = true;  // spx.gpu.sym_pure_passes: long runs of read-once segments fill passes of
+                                  // their own (one descriptor, in the header: csx_spmv_sx_kernel pipelines them)
     bool sym_once = true;         // spx.gpu.sym_once: dense 8x8 tiles of a symmetric matrix are
                                   // read once (one process holding the whole matrix only)
     const std::vector<SymTile> *tiles = nullptr;   // symmetric, fused: tiles read once (sorted by row0)

@@ -12,6 +12,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdint>
 
 namespace spx {
@@ -51,30 +52,15 @@ constexpr int MAX_WAVES_PER_BLOCK = 8;
 
 // Loads of the matrix stream (values, descriptors): plain loads.  (Marking them non-temporal, so that
 // they would not push x out of the L2, measured slower on every workload: profiles/r03/ablation.md
-// section 4.)
+// section 4, profiles/r05/xw_nontemporal_raw.md; the experiment hook is gone, the record stays.)
 typedef double spx_d2_t __attribute__((ext_vector_type(2)));
 // two doubles at any 8-byte aligned address as ONE load (global_load_dwordx4 needs no 16-byte
 // alignment on gfx9): the x of a row segment comes in pairs wherever its first column lies
 typedef double spx_d2u_t __attribute__((ext_vector_type(2), aligned(8)));
-#ifdef SPX_EXPERIMENT_NT_STREAM      /* (experiment build: the matrix stream non-temporal, so that it does not push x out of the L2) */
-__device__ __forceinline__ double2 ld_stream(const double2 *p)
-{
-    const spx_d2_t v = __builtin_nontemporal_load(reinterpret_cast<const spx_d2_t *>(p));
-    return double2{v.x, v.y};
-}
-__device__ __forceinline__ double ld_stream(const double *p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ uint2 ld_stream(const uint2 *p)
-{
-    const unsigned long long v = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(p));
-    return uint2{(uint32_t) v, (uint32_t) (v >> 32)};
-}
-#define SPX_LD_INDEX(expr) __builtin_nontemporal_load(&(expr))
-#else
 __device__ __forceinline__ double2 ld_stream(const double2 *p) { return *p; }
 __device__ __forceinline__ double ld_stream(const double *p) { return *p; }
 __device__ __forceinline__ uint2 ld_stream(const uint2 *p) { return *p; }
 #define SPX_LD_INDEX(expr) (expr)
-#endif
 
 // set bits of `mask` in lanes 1..lane (bit 0 is never set by the emitter)
 __device__ __forceinline__ uint32_t starts_upto(uint64_t mask, int lane)
@@ -261,6 +247,69 @@ __device__ __forceinline__ void run_pass(const KernelArgs &a, const SpxRowBlock 
     if (ps.kind == SPX_PASS_GATHER) run_units<1, 1>(a, rb, {ps}, tile, win, lane);
     else if (ps.kind == SPX_PASS_GATHER_LDS) run_units<1, 2>(a, rb, {ps}, tile, win, lane);
     else run_units<1, 0>(a, rb, {ps}, tile, win, lane);
+}
+
+// ---- pass headers as six dwords (the pipelined kernels: spmv_xw_kernels.hip, spmv_sx_kernels.hip) ----
+// Read through the constant address space -- the stream is never written while a product runs, and only so
+// does the compiler keep fetching them with scalar loads once a kernel contains LDS DMA -- and as whole
+// dwords: a byte field read on its own becomes a VECTOR byte load (gfx950 has no scalar one).
+typedef const __attribute__((address_space(4))) uint32_t *spx_const_words_t;
+struct PassWords {
+    uint32_t w[6];
+    __device__ __forceinline__ uint64_t mask() const { return (uint64_t) w[0] | ((uint64_t) w[1] << 32); }
+    __device__ __forceinline__ uint32_t val_off() const { return w[2]; }
+    __device__ __forceinline__ uint32_t rank0() const { return w[3] & 0xffffu; }
+    __device__ __forceinline__ uint32_t seg0() const { return w[3] >> 16; }
+    __device__ __forceinline__ uint32_t nseg() const { return w[4] & 0xffu; }
+    __device__ __forceinline__ uint32_t width() const { return (w[4] >> 8) & 0xffu; }
+    __device__ __forceinline__ uint32_t kind() const { return (w[4] >> 16) & 0xffu; }
+    __device__ __forceinline__ uint32_t flags() const { return w[4] >> 24; }
+    __device__ __forceinline__ SpxPass pass() const
+    {
+        SpxPass ps;
+        ps.mask = mask(); ps.val_off = w[2]; ps.rank0 = (uint16_t) rank0(); ps.seg0 = (uint16_t) seg0();
+        ps.nseg = (uint8_t) nseg(); ps.width = (uint8_t) width(); ps.kind = (uint8_t) kind();
+        ps.flags = (uint8_t) flags(); ps.elem0 = w[5];
+        return ps;
+    }
+};
+static_assert(sizeof(SpxPass) == 24 && offsetof(SpxPass, val_off) == 8 && offsetof(SpxPass, rank0) == 12 &&
+              offsetof(SpxPass, seg0) == 14 && offsetof(SpxPass, nseg) == 16 && offsetof(SpxPass, width) == 17 &&
+              offsetof(SpxPass, kind) == 18 && offsetof(SpxPass, flags) == 19 && offsetof(SpxPass, elem0) == 20,
+              "PassWords mirrors SpxPass");
+__device__ __forceinline__ PassWords load_pass(spx_const_words_t passes, int index)
+{
+    const spx_const_words_t p = passes + 6 * index;
+    PassWords h;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) h.w[k] = p[k];
+    return h;
+}
+
+// the pass headers of the row-block in LDS (the workgroup copies them there in its prologue: one coalesced
+// load instead of a scalar load from memory per pass and wavefront): entry `index` as six dwords, the same
+// for every lane, then into SGPRs
+__device__ __forceinline__ PassWords lds_pass(const uint32_t *hdr, int index)
+{
+    const uint2 *p = reinterpret_cast<const uint2 *>(hdr + 6 * index);
+    const uint2 a = p[0], b = p[1], c = p[2];
+    PassWords h;
+    h.w[0] = (uint32_t) __builtin_amdgcn_readfirstlane((int) a.x);
+    h.w[1] = (uint32_t) __builtin_amdgcn_readfirstlane((int) a.y);
+    h.w[2] = (uint32_t) __builtin_amdgcn_readfirstlane((int) b.x);
+    h.w[3] = (uint32_t) __builtin_amdgcn_readfirstlane((int) b.y);
+    h.w[4] = (uint32_t) __builtin_amdgcn_readfirstlane((int) c.x);
+    h.w[5] = (uint32_t) __builtin_amdgcn_readfirstlane((int) c.y);
+    return h;
+}
+
+// a pass that is not there (the second half of a round at the end of a wavefront's list): the first
+// one's addresses, no lanes
+__device__ __forceinline__ PassWords no_pass(const PassWords &like)
+{
+    PassWords h = like;
+    h.w[4] &= ~0xffu;
+    return h;
 }
 
 #define SPX_KERNEL_PARAMS                                                                        \

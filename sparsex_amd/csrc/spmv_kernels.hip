@@ -20,7 +20,10 @@
 #include "stream_index.hpp"
 #include "threads.hpp"
 #include "spmv_device.hpp"
+#include "spmv_sym_device.hpp"
+#include "spx_abl.hpp"
 #include "xwindows.hpp"
+#include "sxplan.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -33,6 +36,12 @@
 #include <vector>
 
 namespace spx {
+
+// spmv_sx_kernels.hip
+void launch_spmv_sx(int waves, unsigned blocks, size_t lds_bytes, void *stream, const KernelArgs &a, const XcdSplit &xs,
+                    const uint32_t *sx_tab);
+size_t spmv_sx_header_bytes(uint32_t pass_stride);
+void spmv_sx_allow_lds(size_t bytes);
 
 // spmv_xw_kernels.hip
 void launch_spmv_xw(int waves, unsigned blocks, size_t lds_bytes, void *stream, const KernelArgs &a, const XcdSplit &xs);
@@ -49,256 +58,6 @@ void spmv_xw_allow_lds(size_t bytes);
         }                                                                       \
     } while (0)
 
-// lane ^ 1, ^ 2, ^ 4 inside groups of eight lanes as DPP moves (VALU) instead of
-// ds_bpermute (__shfl_xor goes through the LDS crossbar): quad_perm for 1 and 2,
-// row_half_mirror followed by a reversed quad for 4 (lane i <- 7-i <- (7-i)^3 = i^4).
-template <int DPP_CTRL>
-__device__ __forceinline__ double dpp_mov_f64(double v)
-{
-    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), DPP_CTRL, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), DPP_CTRL, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double xchg1(double v)
-{
-    return dpp_mov_f64<0xB1>(v);                       // quad_perm [1,0,3,2]
-}
-__device__ __forceinline__ double xchg2(double v)
-{
-    return dpp_mov_f64<0x4E>(v);                       // quad_perm [2,3,0,1]
-}
-__device__ __forceinline__ double xchg4(double v)
-{
-    return dpp_mov_f64<0x1B>(dpp_mov_f64<0x141>(v));   // row_half_mirror, then quad_perm [3,2,1,0]
-}
-
-// A pass of symmetric tiles (SPX_PASS_SYMTILE): lanes 8t..8t+7 hold the rows of
-// the dense 8x8 tile t of the stored lower triangle.  Each value is read once
-// and used twice: a(r,c)*x[c] summed along the lane's row goes to the y tile,
-// a(r,c)*x[r] summed over the tile's eight lanes goes to the slot of column c.
-// The column sums are formed in registers by a three-step exchange within the
-// eight lanes (4 + 2 + 1 values travel), so that each lane ends up with ONE
-// column and the LDS adds of a tile hit eight different addresses -- lanes
-// that add to the same address are serialised at ~3 clocks each.
-__device__ __forceinline__ void symtile_pass(const KernelArgs &a, const SpxRowBlock &rb,
-                                             const SpxPass &ps, double *slots, double *tile,
-                                             int lane)
-{
-    const uint32_t nseg = ps.nseg;
-    const bool active = (uint32_t) lane < nseg;
-    const uint32_t l = active ? (uint32_t) lane : 0u;
-    const uint2 q = *reinterpret_cast<const uint2 *>(a.descs + rb.desc_off + ps.rank0 + (l >> 3));
-    const double *vals = a.values + rb.val_off + ps.val_off;
-    double2 v2[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-        v2[p] = ld_stream(reinterpret_cast<const double2 *>(vals + (uint32_t) p * 2u * nseg + l * 2u));
-    const int i = (int) (l & 7u);
-    const int row = (int) (ps.elem0 + (q.y & 511u)) + i;
-    const uint32_t slot = q.y >> 9;
-    const double xr = a.x[rb.row0 + (uint32_t) row];
-    const double *xp = a.x + q.x;
-    double v[8], t = 0.0, p8[8];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        v[2 * p] = v2[p].x;
-        v[2 * p + 1] = v2[p].y;
-    }
-    // (tiles start on columns that are multiples of eight: where x itself is 16-byte
-    // aligned the eight x values of the tile come as four 16-byte loads)
-    double xc[8];
-    if ((reinterpret_cast<uintptr_t>(a.x) & 15u) == 0) {
-        const double2 *xp2 = reinterpret_cast<const double2 *>(xp);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const double2 xx = xp2[p];
-            xc[2 * p] = xx.x;
-            xc[2 * p + 1] = xx.y;
-        }
-    } else {
-#pragma unroll
-        for (int w = 0; w < 8; ++w) xc[w] = xp[w];
-    }
-#pragma unroll
-    for (int w = 0; w < 8; ++w) {
-        t = fma(v[w], xc[w], t);
-        p8[w] = active ? v[w] * xr : 0.0;
-    }
-    // exchange with lane^4: lanes 0-3 collect columns 0-3, lanes 4-7 columns 4-7
-    double p4[4];
-    {
-        const bool hi = (i & 4) != 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const double send = hi ? p8[w] : p8[w + 4];
-            const double keep = hi ? p8[w + 4] : p8[w];
-            p4[w] = keep + xchg4(send);
-        }
-    }
-    // lane^2: lanes with bit 1 clear keep the lower two of their four columns
-    double p2[2];
-    {
-        const bool hi = (i & 2) != 0;
-#pragma unroll
-        for (int w = 0; w < 2; ++w) {
-            const double send = hi ? p4[w] : p4[w + 2];
-            const double keep = hi ? p4[w + 2] : p4[w];
-            p2[w] = keep + xchg2(send);
-        }
-    }
-    // lane^1: one column each -- lane i of the tile holds column i
-    double cs;
-    {
-        const bool hi = (i & 1) != 0;
-        const double send = hi ? p2[0] : p2[1];
-        const double keep = hi ? p2[1] : p2[0];
-        cs = keep + xchg1(send);
-    }
-    if (active) {
-        atomicAdd(&tile[row], t);
-        atomicAdd(&slots[slot + (uint32_t) i], cs);
-    }
-}
-
-// (experiment builds, results wrong on purpose -- profiles/r05/ablation.md: SPX_ABL_SYM_NOSLOTADD no LDS adds of the
-// transposed products, SPX_ABL_SYM_ONEADD one instead of W, SPX_ABL_SYM_NOX every x load from one cached line,
-// SPX_ABL_SYM_NOHANDOVER the slots are not added to y; SPX_ABL_SYM_STREAM all of them: what the stream alone costs)
-#ifdef SPX_ABL_SYM_STREAM
-#define SPX_ABL_SYM_NOSLOTADD
-#define SPX_ABL_SYM_NOX
-#define SPX_ABL_SYM_NOHANDOVER
-#endif
-// A pass of read-once row segments of a symmetric matrix (SPX_PASS_SYMSEG): a unit pass
-// whose lanes, besides the row sum a(r, c..c+W-1) . x[c..], add the W transposed products
-// a(r, c+w) * x[r] to the slots of their columns (consecutive slots, consecutive LDS
-// addresses; lanes of neighbouring rows mostly hit different ones) -- every value is read
-// once and used twice.  A segment without slots adds straight to y (global atomics; the
-// kernel's hand-over is atomic anyway).
-template <int W, int B>
-__device__ __forceinline__ void symseg_passes(const KernelArgs &a, const SpxRowBlock &rb,
-                                              const SpxPass (&ps)[B], double *slots, double *tile, int lane)
-{
-    // (B passes of the same width at once, stage by stage like the unit passes: all descriptors,
-    // then all values, then x -- the pass is a chain of dependent loads, and with three values
-    // per lane one pass alone keeps too little in flight: the ablation build that hands nothing
-    // over still took 0.96 of the full kernel's 1.07 ms on the bench matrix)
-    bool active[B];
-    uint32_t l[B], nseg[B], slot0[B];
-    uint2 q[B];
-#pragma unroll
-    for (int b = 0; b < B; ++b) {
-        nseg[b] = ps[b].nseg;
-        active[b] = (uint32_t) lane < nseg[b];
-        l[b] = active[b] ? (uint32_t) lane : 0u;
-        if (ps[b].flags & SPX_PASSF_INLINE) {
-            // (the pass' only descriptor came with its header; its slot entry is needed last)
-            q[b].x = (uint32_t) ps[b].mask;
-            q[b].y = (uint32_t) (ps[b].mask >> 32);
-            slot0[b] = a.descs[rb.desc_off + (uint32_t) ps[b].rank0 + 1u].col0;
-        } else
-        {
-            const uint64_t mk = (ps[b].flags & SPX_PASSF_INLINE) ? 0ull : ps[b].mask;
-            const uint32_t rank = (uint32_t) ps[b].rank0 + 2u * (active[b] ? starts_upto(mk, lane) : 0u);
-            q[b] = ld_stream(reinterpret_cast<const uint2 *>(a.descs + rb.desc_off + rank));
-            slot0[b] = a.descs[rb.desc_off + rank + 1u].col0;
-        }
-    }
-    double v[B][W];
-#pragma unroll
-    for (int b = 0; b < B; ++b) {
-        const double *vals = a.values + rb.val_off + ps[b].val_off;
-#pragma unroll
-        for (int p = 0; p < W / 2; ++p) {
-            const double2 vv = ld_stream(reinterpret_cast<const double2 *>(vals + (uint32_t) p * 2u * nseg[b] + l[b] * 2u));
-            v[b][2 * p] = vv.x;
-            v[b][2 * p + 1] = vv.y;
-        }
-        if (W & 1) v[b][W - 1] = ld_stream(vals + (uint32_t) (W / 2) * 2u * nseg[b] + l[b]);
-    }
-    int row[B], sdc[B];
-    uint32_t col[B];
-    double xr[B], x[B][W];
-#pragma unroll
-    for (int b = 0; b < B; ++b) {
-        const uint32_t bits = q[b].y;
-        const int s = (int) ((ps[b].seg0 + l[b] - ((bits >> 9) & 8191u)) & 0xffffu);
-        const uint32_t kind = (bits >> 22) & 7u;
-        const int step = (int) (bits >> 25);
-        const int drow = kind == SPX_KIND_BLOCK ? 1 : (kind >= SPX_KIND_VERT ? step : 0);
-        const int dcol = (kind == SPX_KIND_HORIZ || kind == SPX_KIND_DIAG) ? step : (kind == SPX_KIND_ADIAG ? -step : 0);
-        row[b] = (int) (ps[b].elem0 + (bits & 511u)) + s * drow;
-        sdc[b] = s * dcol;
-        col[b] = q[b].x + (uint32_t) sdc[b];
-        const double *xp = a.x + col[b];
-#ifdef SPX_ABL_SYM_NOX
-        xr[b] = a.x[lane]; (void) xp;
-#pragma unroll
-        for (int w = 0; w < W; ++w) x[b][w] = a.x[lane + w];
-#else
-        xr[b] = a.x[rb.row0 + (uint32_t) row[b]];
-        // (x in unaligned pairs, as the unit passes load it, measured 2.3 % slower here: one load per column)
-#pragma unroll
-        for (int w = 0; w < W; ++w) x[b][w] = xp[w];
-#endif
-    }
-#pragma unroll
-    for (int b = 0; b < B; ++b) {
-        double t = 0.0;
-#pragma unroll
-        for (int w = 0; w < W; ++w) t = fma(v[b][w], x[b][w], t);
-        if (!active[b]) continue;
-        atomicAdd(&tile[row[b]], t);
-        if (slot0[b] != SPX_NO_SLOT) {
-            double *sl = slots + slot0[b] + (uint32_t) sdc[b];
-#ifdef SPX_ABL_SYM_NOSLOTADD
-            double u = 0.0;
-#pragma unroll
-            for (int w = 0; w < W; ++w) u += v[b][w] * xr[b];
-            if (u == 1.2345e-300) sl[0] = u;
-#elif defined(SPX_ABL_SYM_ONEADD)
-            double u = 0.0;
-#pragma unroll
-            for (int w = 0; w < W; ++w) u += v[b][w] * xr[b];
-            atomicAdd(&sl[0], u);
-#else
-#pragma unroll
-            for (int w = 0; w < W; ++w) atomicAdd(&sl[w], v[b][w] * xr[b]);
-#endif
-        } else {
-            double *yp = a.y + col[b];
-#pragma unroll
-            for (int w = 0; w < W; ++w) atomicAdd(&yp[w], a.alpha * (v[b][w] * xr[b]));
-        }
-    }
-}
-
-__device__ __forceinline__ void run_symseg(const KernelArgs &a, const SpxRowBlock &rb, const SpxPass &ps,
-                                           double *slots, double *tile, int lane)
-{
-    switch (ps.width) {            // wave-uniform
-    case 2: symseg_passes<2, 1>(a, rb, {ps}, slots, tile, lane); break;
-    case 3: symseg_passes<3, 1>(a, rb, {ps}, slots, tile, lane); break;
-    case 4: symseg_passes<4, 1>(a, rb, {ps}, slots, tile, lane); break;
-    case 5: symseg_passes<5, 1>(a, rb, {ps}, slots, tile, lane); break;
-    case 6: symseg_passes<6, 1>(a, rb, {ps}, slots, tile, lane); break;
-    case 7: symseg_passes<7, 1>(a, rb, {ps}, slots, tile, lane); break;
-    default: symseg_passes<8, 1>(a, rb, {ps}, slots, tile, lane); break;
-    }
-}
-
-// two read-once passes of the same width (<= 4: the registers of two wider ones would cost
-// the kernel its eight wavefronts per SIMD) side by side
-__device__ __forceinline__ bool run_symseg2(const KernelArgs &a, const SpxRowBlock &rb, const SpxPass &p0,
-                                            const SpxPass &p1, double *slots, double *tile, int lane)
-{
-    if (p0.width != p1.width || p0.width > 4) return false;
-    switch (p0.width) {
-    case 2: symseg_passes<2, 2>(a, rb, {p0, p1}, slots, tile, lane); break;
-    case 3: symseg_passes<3, 2>(a, rb, {p0, p1}, slots, tile, lane); break;
-    default: symseg_passes<4, 2>(a, rb, {p0, p1}, slots, tile, lane); break;
-    }
-    return true;
-}
 
 // One workgroup owns one row-block; its wavefronts take the passes in turn
 // (wave w: passes w, w+4, ...) and accumulate into one y tile in LDS, which
@@ -423,7 +182,9 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &x
     if (rb.flags & SPX_RB_SHARED) {
         if (threadIdx.x == 0) a.carry[rb.carry_slot] = tile[0];
     } else if (ATOMIC) {
-        if ((rb.flags & SPX_RB_PRIVATE) && a.dvalues_priv) {
+        if (abl::sym_no_own) {
+            // (experiment build: the own rows stay where they are)
+        } else if ((rb.flags & SPX_RB_PRIVATE) && a.dvalues_priv) {
             // nobody else adds to these rows (mark_private_rowblocks): stored, with the diagonal
             // term and beta * y; the init pass leaves them out
             for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS) {
@@ -436,10 +197,9 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &x
             for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS)
                 atomicAdd(&a.y[(size_t) rb.row0 + i], a.alpha * tile[i]);
         }
-#ifndef SPX_ABL_SYM_NOHANDOVER
-        for (int i = threadIdx.x; i < n_slots; i += BLOCK_THREADS)
-            atomicAdd(&a.y[(size_t) gcol_lds[i >> 3] + (i & 7)], a.alpha * lds[i]);
-#endif
+        if (!abl::sym_no_handover)
+            for (int i = threadIdx.x; i < n_slots; i += BLOCK_THREADS)
+                atomicAdd(&a.y[(size_t) gcol_lds[i >> 3] + (i & 7)], a.alpha * lds[i]);
     } else {
         for (int i = threadIdx.x; i < n_rows; i += BLOCK_THREADS) {
             const size_t g = (size_t) rb.row0 + i;
@@ -500,12 +260,8 @@ void csx_spmv_symseg_kernel(SPX_KERNEL_PARAMS)
 }
 
 // ... and the same for streams with such segments and no tiles at all (a stencil matrix)
-// (SPX_SYMSEG_NOTILE_ATTR: room for a kernel attribute, e.g. amdgpu_waves_per_eu, in a variant build)
-#ifndef SPX_SYMSEG_NOTILE_ATTR
-#define SPX_SYMSEG_NOTILE_ATTR
-#endif
 template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) SPX_SYMSEG_NOTILE_ATTR
+__global__ __launch_bounds__(64 * WAVES)
 void csx_spmv_symseg_notile_kernel(SPX_KERNEL_PARAMS)
 {
     SPX_KERNEL_ARGS(a);
@@ -720,6 +476,13 @@ struct DeviceMatrix {
     bool xw_on = false;           // the product runs through csx_spmv_xw_kernel
     uint64_t xw_elems = 0, xw_unit_elems = 0, xw_staged = 0;
     size_t xw_rowblocks = 0;
+    // the read-once passes pipelined (sxplan.hpp; symmetric streams of row segments without tiles): a second set
+    // of pass headers for csx_spmv_sx_kernel and the number of SX passes at the head of every row-block
+    SpxPass *passes_sx = nullptr;
+    uint32_t *sx_tab = nullptr;
+    bool sx_on = false;           // the product runs through csx_spmv_sx_kernel
+    uint64_t sx_elems = 0, sx_sym_elems = 0;
+    size_t sx_rowblocks = 0;
 };
 
 int device_count()
@@ -1038,6 +801,36 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
             throw;
         }
     }
+    // the read-once passes pipelined (symmetric streams of row segments, no tiles, stream order, one launch)
+    if (symmetric && s.sx_plan && m->has_symsegs && !m->has_symtiles && m->launch_order.empty() &&
+        m->xcd_split.size() == 1 && !s.rbs.empty() && !s.deterministic && !s.wave_tiles) {
+        try {
+            SxPlan plan;
+            plan_sym_pipeline(s, plan, host_threads());
+            const size_t lds_need = (size_t) m->lds_doubles * sizeof(double) + m->max_slot_groups * sizeof(uint32_t) +
+                                    spmv_sx_header_bytes(s.pass_stride);
+            if (plan.n_rb_sx && lds_need <= 160u * 1024u) {
+                const size_t pbytes = (plan.passes.size() + (size_t) s.pass_stride + 6 * MAX_WAVES_PER_BLOCK) * sizeof(SpxPass);
+                HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&m->passes_sx), pbytes));
+                HIP_CHECK(hipMemset(m->passes_sx, 0, pbytes));
+                HIP_CHECK(hipMemcpy(m->passes_sx, plan.passes.data(), plan.passes.size() * sizeof(SpxPass), hipMemcpyHostToDevice));
+                HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&m->sx_tab), plan.n_sx.size() * sizeof(uint32_t)));
+                HIP_CHECK(hipMemcpy(m->sx_tab, plan.n_sx.data(), plan.n_sx.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+                m->sx_elems = plan.sx_elems;
+                m->sx_sym_elems = plan.sym_elems;
+                m->sx_rowblocks = plan.n_rb_sx;
+                m->sx_on = s.sx_on;
+                if (lds_need > 64u * 1024u) spmv_sx_allow_lds(160u * 1024u);
+                log_msg(LOG_INFO, "read-once pipeline: %zu row-blocks, %llu of %llu read-once passes (%.1f %% of their nonzeros) "
+                        "carry their geometry in the header\n", plan.n_rb_sx, (unsigned long long) plan.sx_passes,
+                        (unsigned long long) plan.sym_passes,
+                        100.0 * (double) plan.sx_elems / (double) std::max<uint64_t>(plan.sym_elems, 1));
+            }
+        } catch (...) {
+            device_free(m);
+            throw;
+        }
+    }
     if (getenv("SPX_LOG_PLACEMENT"))
         log_msg(LOG_ERR, "placement: arena %p (%zu MB) values %p descs %p passes %p rbs %p\n", m->arena, m->arena_bytes >> 20,
                 (void *) m->values, (void *) m->descs, (void *) m->passes, (void *) m->rbs);
@@ -1064,6 +857,8 @@ void device_free(DeviceMatrix *m)
         if (m->mirror_col) (void) hipFree(m->mirror_col);
         if (m->mirror_val) (void) hipFree(m->mirror_val);
     }
+    if (m->passes_sx) (void) hipFree(m->passes_sx);
+    if (m->sx_tab) (void) hipFree(m->sx_tab);
     if (m->passes_xw) (void) hipFree(m->passes_xw);
     if (m->xdescs) (void) hipFree(m->xdescs);
     if (m->xw_tab) (void) hipFree(m->xw_tab);
@@ -1113,12 +908,12 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
         const int t = 256;
         const size_t first = m->init_limited ? m->init_lo : 0, last = m->init_limited ? m->own_hi : m->nrows;
         auto init_rows = [&](size_t lo, size_t hi) {
-            if (hi > lo)
+            if (hi > lo && !abl::sym_no_init)
                 hipLaunchKernelGGL(csx_sym_init_kernel, dim3((unsigned)((hi - lo + t - 1) / t)),
                                    dim3(t), 0, stream, d_y, d_x, m->dvalues, lo, hi,
                                    m->own_lo, m->own_hi, alpha, beta);
         };
-        if (m->sym_atomic && !m->wave_tiles && m->use_private) {
+        if (m->sym_atomic && !m->wave_tiles && m->use_private && !abl::sym_no_private) {
             // (row-blocks that nobody else adds to store their rows themselves: SPX_RB_PRIVATE)
             size_t at = first;
             for (const auto &r : m->private_rows) {
@@ -1180,7 +975,11 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
             // what other row-blocks spilled for them
             const size_t lds = m->lds_doubles * sizeof(double);
             const size_t lds_a = lds + m->max_slot_groups * sizeof(uint32_t);   // + the slot groups' columns
-            if (m->sym_atomic && m->has_symsegs && !m->has_symtiles) {
+            if (m->sym_atomic && m->has_symsegs && !m->has_symtiles && m->sx_on && m->passes_sx) {
+                KernelArgs as = a;
+                as.passes = m->passes_sx;
+                launch_spmv_sx(m->waves, blocks, lds_a + spmv_sx_header_bytes(m->pass_stride), stream, as, xcd_now, m->sx_tab);
+            } else if (m->sym_atomic && m->has_symsegs && !m->has_symtiles) {
                 // (16 wavefronts per workgroup, so that 2048-row row-blocks keep the SIMDs full, were
                 // measured: 0.90 ms against 0.835 with 8, syn-nlpkkt; not built)
                 if (m->waves == 2) SPX_LAUNCH(csx_spmv_symseg_notile_kernel, 2, lds_a);
@@ -1374,6 +1173,15 @@ int device_get_waves(const DeviceMatrix *m) { return m->waves; }
 
 int device_host_parts(const DeviceMatrix *m) { return m ? m->host_parts : 0; }
 
+bool device_has_sx(const DeviceMatrix *m) { return m->passes_sx != nullptr; }
+void device_set_sx(DeviceMatrix *m, bool on) { m->sx_on = on && m->passes_sx && m->sym_atomic && !m->wave_tiles; }
+bool device_get_sx(const DeviceMatrix *m) { return m->sx_on && m->passes_sx && m->sym_atomic && !m->wave_tiles; }
+void device_sx_info(const DeviceMatrix *m, uint64_t &elems_sx, uint64_t &elems_sym, size_t &rowblocks)
+{
+    elems_sx = m->sx_elems;
+    elems_sym = m->sx_sym_elems;
+    rowblocks = m->sx_rowblocks;
+}
 bool device_has_xw(const DeviceMatrix *m) { return m->passes_xw != nullptr; }
 void device_set_xw(DeviceMatrix *m, bool on) { m->xw_on = on && m->passes_xw && !m->wave_tiles; }
 bool device_get_xw(const DeviceMatrix *m) { return m->xw_on && m->passes_xw && !m->wave_tiles; }
@@ -1638,6 +1446,8 @@ void device_download(const DeviceMatrix *m, GpuStream &s)
     s.deterministic = m->deterministic;
     s.wave_tiles = m->wave_tiles;
     s.xw_on = device_get_xw(m);
+    s.sx_plan = m->passes_sx != nullptr;
+    s.sx_on = device_get_sx(m);
     s.xw_budget = m->xw_budget;
     s.xw_gap = m->xw_gap;
     if (m->n_spill) download(s.slot_group_col, m->slot_col, m->n_slot_col);

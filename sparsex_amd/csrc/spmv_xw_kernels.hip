@@ -33,65 +33,7 @@ namespace spx {
 // runs, and only so does the compiler keep fetching them with scalar loads (s_load into SGPRs, out of the
 // way of the vector memory counter) once the kernel contains LDS DMA, which it must assume writes memory --
 // and as six whole dwords: a byte field read on its own becomes a VECTOR byte load (gfx950 has no scalar
-// one), and the wait for it is a wait for every value load in flight.
-typedef const __attribute__((address_space(4))) uint32_t *spx_const_words_t;
-struct PassWords {
-    uint32_t w[6];
-    __device__ __forceinline__ uint64_t mask() const { return (uint64_t) w[0] | ((uint64_t) w[1] << 32); }
-    __device__ __forceinline__ uint32_t val_off() const { return w[2]; }
-    __device__ __forceinline__ uint32_t rank0() const { return w[3] & 0xffffu; }
-    __device__ __forceinline__ uint32_t seg0() const { return w[3] >> 16; }
-    __device__ __forceinline__ uint32_t nseg() const { return w[4] & 0xffu; }
-    __device__ __forceinline__ uint32_t width() const { return (w[4] >> 8) & 0xffu; }
-    __device__ __forceinline__ uint32_t kind() const { return (w[4] >> 16) & 0xffu; }
-    __device__ __forceinline__ uint32_t flags() const { return w[4] >> 24; }
-    __device__ __forceinline__ SpxPass pass() const
-    {
-        SpxPass ps;
-        ps.mask = mask(); ps.val_off = w[2]; ps.rank0 = (uint16_t) rank0(); ps.seg0 = (uint16_t) seg0();
-        ps.nseg = (uint8_t) nseg(); ps.width = (uint8_t) width(); ps.kind = (uint8_t) kind();
-        ps.flags = (uint8_t) flags(); ps.elem0 = w[5];
-        return ps;
-    }
-};
-static_assert(sizeof(SpxPass) == 24 && offsetof(SpxPass, val_off) == 8 && offsetof(SpxPass, rank0) == 12 &&
-              offsetof(SpxPass, seg0) == 14 && offsetof(SpxPass, nseg) == 16 && offsetof(SpxPass, width) == 17 &&
-              offsetof(SpxPass, kind) == 18 && offsetof(SpxPass, flags) == 19 && offsetof(SpxPass, elem0) == 20,
-              "PassWords mirrors SpxPass");
-__device__ __forceinline__ PassWords load_pass(spx_const_words_t passes, int index)
-{
-    const spx_const_words_t p = passes + 6 * index;
-    PassWords h;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) h.w[k] = p[k];
-    return h;
-}
-
-// the pass headers of the row-block in LDS (the workgroup copies them there in its prologue: one coalesced
-// load instead of a scalar load from memory per pass and wavefront): entry `index` as six dwords, the same
-// for every lane, then into SGPRs
-__device__ __forceinline__ PassWords lds_pass(const uint32_t *hdr, int index)
-{
-    const uint2 *p = reinterpret_cast<const uint2 *>(hdr + 6 * index);
-    const uint2 a = p[0], b = p[1], c = p[2];
-    PassWords h;
-    h.w[0] = (uint32_t) __builtin_amdgcn_readfirstlane((int) a.x);
-    h.w[1] = (uint32_t) __builtin_amdgcn_readfirstlane((int) a.y);
-    h.w[2] = (uint32_t) __builtin_amdgcn_readfirstlane((int) b.x);
-    h.w[3] = (uint32_t) __builtin_amdgcn_readfirstlane((int) b.y);
-    h.w[4] = (uint32_t) __builtin_amdgcn_readfirstlane((int) c.x);
-    h.w[5] = (uint32_t) __builtin_amdgcn_readfirstlane((int) c.y);
-    return h;
-}
-
-// a pass that is not there (the second half of a round at the end of a wavefront's list): the first
-// one's addresses, no lanes
-__device__ __forceinline__ PassWords no_pass(const PassWords &like)
-{
-    PassWords h = like;
-    h.w[4] &= ~0xffu;
-    return h;
-}
+// one), and the wait for it is a wait for every value load in flight (PassWords, spmv_device.hpp).
 
 // One stage of the pipeline: B unit passes of ANY width 1..4, three loads each -- the lane's descriptor
 // and two 16-byte loads at 8-byte granularity that between them hold its values whatever the width
@@ -129,13 +71,8 @@ __device__ __forceinline__ void xw_issue(const KernelArgs &a, const SpxRowBlock 
         const double *vals = a.values + rb.val_off + ps[b].val_off();
         const uint32_t off_a = W == 1u ? l : 2u * l;
         const uint32_t off_b = W == 3u ? 2u * nseg + l : (W == 4u ? 2u * nseg + 2u * l : off_a);
-#ifdef SPX_EXPERIMENT_NT_STREAM       /* (experiment build, spmv_device.hpp: the matrix stream non-temporal) */
-        S.va[b] = __builtin_nontemporal_load(reinterpret_cast<const spx_d2u_t *>(vals + off_a));
-        S.vb[b] = __builtin_nontemporal_load(reinterpret_cast<const spx_d2u_t *>(vals + off_b));
-#else
         S.va[b] = *reinterpret_cast<const spx_d2u_t *>(vals + off_a);
         S.vb[b] = *reinterpret_cast<const spx_d2u_t *>(vals + off_b);
-#endif
     }
 }
 

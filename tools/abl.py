@@ -66,6 +66,9 @@ def main():
             opts[k] = v
         A = bench.tune(csr, opts)
         info = A.info()
+        for ln in A.tune_log().splitlines():       # (what the tuner decided, for the record: stderr)
+            if any(k in ln for k in ("read-once pipeline", "launch autotune", "unit windows:", "column slices")):
+                print("[%s] %s" % (name, ln), file=sys.stderr)
         st_ = torch.cuda.current_stream().cuda_stream
         y.fill_(float("nan"))
         A.hip_matvec_mult(bench.ALPHA, x.data_ptr(), y.data_ptr(), st_)
