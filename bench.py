@@ -696,7 +696,9 @@ def kernel_name(info, symmetric, world):
         if k < -1:
             return gen + " x %d (column slices launched in turn)" % -k
         return gen
-    if tiles == 2 and int(info.sym_segments):
+    if tiles == 2 and int(info.sym_segments) == 2 and int(getattr(info, "sym_pipeline", 0)):
+        main = "csx_sym_init_kernel + csx_spmv_sx_kernel<%d> (read-once symseg passes pipelined, x requested with the values)" % w
+    elif tiles == 2 and int(info.sym_segments):
         main = "csx_sym_init_kernel + csx_spmv_symseg_%skernel<%d>" % ("notile_" if int(info.sym_segments) == 2 else "", w)
     elif tiles == 2:
         main = "csx_sym_init_kernel + csx_spmv_symtile_atomic_kernel<%d>" % w
@@ -1208,6 +1210,44 @@ def run_path(ctx, args, symmetric):
     return out, wl, T
 
 
+def self_launch(n, argv):
+    """Runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node n bench.py <argv>` as a CHILD process
+    (one rank per GPU, rendezvous on 127.0.0.1 at a port found by binding port 0), passes its output through
+    and returns its exit code.  The parent never initialises the GPU and never replaces itself (os.exec* from
+    a process that has touched the GPU takes this pool's nodes down); a launcher that outlives the run's
+    time limit is ended with its whole process group and the parent leaves with code 86."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (dmabuf IPC: RCCL across processes needs it on this image)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    limit = int(os.environ.get("SPX_BENCH_TOTAL_TIMEOUT", "1500")) + SETUP_TIMEOUT_S + 120
+    print("bench.py: --gpus %d without a launcher: starting %s" % (n, " ".join(cmd[1:8])), file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return child.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        print("bench.py: the %d ranks did not finish within %d s; ending them" % (n, limit), file=sys.stderr, flush=True)
+        try:
+            os.killpg(child.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        child.wait()
+        return 86
+    except KeyboardInterrupt:
+        try:
+            os.killpg(child.pid, signal.SIGTERM)
+        except ProcessLookupError:
+            pass
+        return 130
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1242,6 +1282,11 @@ def main():
                          "neighbours' unknowns instead of a whole slice (profiles/r04/slices_one_gpu_proxy_e240_raw.md)")
     args = ap.parse_args()
 
+    # `python3 bench.py --gpus N` (N > 1) started without a launcher: this process starts the N ranks itself,
+    # before it has imported torch or touched a GPU, relays rank 0's line and leaves with the launcher's code
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+
     import torch
     import torch.distributed as dist
     import sparsex_amd as sx
@@ -1254,8 +1299,19 @@ def main():
     # fewer GPUs than ranks (ranks then share devices and the exchange is staged
     # through the host); the default is RCCL
     backend = os.environ.get("SPX_BENCH_BACKEND", "nccl")
+    if os.environ.get("SPX_BENCH_LAUNCH_SELFTEST") == "1":
+        # (tests/test_bench_launch.py, no GPU: the ranks only show that they were started and can talk)
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"selftest": True, "n_gpus": world, "rank_sum": float(t.item())}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(int(os.environ.get("SPX_BENCH_LAUNCH_SELFTEST_RC", "0")) if rank == world - 1 else 0)
     if args.gpus > 1 or world > 1:
-        assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+        assert world == args.gpus, "--gpus %d, but the launcher started %d ranks (torch.distributed.run --nproc-per-node %d)" % (
+            args.gpus, world, args.gpus)
         # (SPX_BENCH_SHARE_GPU=1: experiment -- several RCCL ranks on one device, where RCCL allows it)
         share = backend != "nccl" or os.environ.get("SPX_BENCH_SHARE_GPU") == "1"
         dev_id = local_rank % torch.cuda.device_count() if share else local_rank

@@ -231,6 +231,9 @@ typedef struct spx_hip_transport {
 spx_error_t spx_hip_rccl_unique_id(void *id);
 spx_hip_transport_t *spx_hip_transport_rccl(const void *id, int rank, int world);
 void spx_hip_transport_destroy(spx_hip_transport_t *t);
+/* The number of ranks the transport's RCCL communicator holds (ncclCommCount), or -1 for a transport that
+ * was not made by spx_hip_transport_rccl or where librccl does not export the query. */
+int spx_hip_transport_rccl_ranks(const spx_hip_transport_t *t);
 
 /* Collective over the transport's processes; the matrix keeps a copy of *t
  * (the transport must outlive the matrix). */
@@ -365,6 +368,11 @@ typedef struct {
     int32_t unit_window_lds; /* ... bytes of LDS per workgroup of that kernel (0: no windows planned) */
     int64_t unit_window_elems;  /* ... nonzeros whose x comes from LDS (of n_unit_elems)            */
     int64_t unit_window_staged; /* ... doubles of x staged per product                              */
+    int32_t sym_pipeline;    /* symmetric path, spx.gpu.sym_pipeline: 1 = the read-once passes that carry their
+                                geometry in the header run pipelined, x requested with the values
+                                (csx_spmv_sx_kernel)                                                  */
+    int32_t reserved0;
+    int64_t sym_pipeline_elems; /* ... nonzeros in such passes (of the nonzeros in read-once passes)    */
 } spx_hip_info_t;
 
 spx_error_t spx_hip_mat_info(const spx_matrix_t *A, spx_hip_info_t *info);
@@ -385,12 +393,25 @@ typedef struct {
     uint32_t lds_doubles;       /* LDS of a launch, doubles: y tile + leftover window + unit windows          */
 } spx_hip_xw_plan_t;
 spx_error_t spx_hip_mat_unit_windows(spx_matrix_t *A, uint32_t budget, uint32_t gap, spx_hip_xw_plan_t *plan);
+
+/* The device-side pass headers of the pipelined read-once kernel (spx.gpu.sym_pipeline), planned from the
+ * matrix' descriptor stream: for inspection and tests; works on host-only matrices.  The arrays belong to the
+ * matrix and live until the next call or spx_mat_destroy().  Layout of an SX header: sparsex_amd/csrc/sxplan.hpp. */
+typedef struct {
+    const void *passes;         /* n_passes pass headers of 24 bytes (flag 4: an SX header)                    */
+    const uint32_t *n_sx;       /* per row-block: its passes [0, n_sx) are SX passes                            */
+    size_t n_rowblocks, n_passes;
+    size_t rowblocks_with_sx;
+    uint64_t sym_elems, sx_elems;     /* nonzeros in read-once passes / of those, in SX passes                  */
+    uint64_t sym_passes, sx_passes;
+} spx_hip_sx_plan_t;
+spx_error_t spx_hip_mat_sym_pipeline(spx_matrix_t *A, spx_hip_sx_plan_t *plan);
 /* The same for a caller compiled against another revision of this header: at most `size` bytes
  * (the caller's sizeof(spx_hip_info_t)) are written -- the struct only ever grows at its end.
  * spx_hip_mat_info() writes sizeof(spx_hip_info_t) of THIS header; SPX_HIP_ABI_VERSION changes
  * whenever the struct grows (round 3 added quad and col_slices: version 3; round 5 the four
- * unit_window fields: version 4). */
-#define SPX_HIP_ABI_VERSION 4
+ * unit_window fields: version 4; round 6 the sym_pipeline fields: version 5). */
+#define SPX_HIP_ABI_VERSION 5
 spx_error_t spx_hip_mat_info_sized(const spx_matrix_t *A, void *info, size_t size);
 int spx_hip_abi_version(void);
 

@@ -51,7 +51,14 @@ class HipInfo(C.Structure):
                 ("emit_seconds", C.c_double), ("wave_tiles", C.c_int32), ("sym_segments", C.c_int32),
                 ("quad", C.c_int32), ("col_slices", C.c_int32),
                 ("unit_windows", C.c_int32), ("unit_window_lds", C.c_int32),
-                ("unit_window_elems", C.c_int64), ("unit_window_staged", C.c_int64)]
+                ("unit_window_elems", C.c_int64), ("unit_window_staged", C.c_int64),
+                ("sym_pipeline", C.c_int32), ("reserved0", C.c_int32), ("sym_pipeline_elems", C.c_int64)]
+
+
+class SxPlan(C.Structure):
+    _fields_ = [("passes", C.c_void_p), ("n_sx", C.POINTER(C.c_uint32)), ("n_rowblocks", C.c_size_t),
+                ("n_passes", C.c_size_t), ("rowblocks_with_sx", C.c_size_t), ("sym_elems", C.c_uint64),
+                ("sx_elems", C.c_uint64), ("sym_passes", C.c_uint64), ("sx_passes", C.c_uint64)]
 
 
 class XwPlan(C.Structure):
@@ -281,6 +288,21 @@ class Matrix:
         raw = C.string_at(pl.passes, pl.n_passes * 24) if pl.n_passes else b""
         out["passes"] = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 24).copy()
         return out
+
+    def sym_pipeline(self):
+        """The device-side pass headers of the pipelined read-once kernel (spx_hip_mat_sym_pipeline) as numpy
+        copies: (passes as a [n, 6] uint32 array, SX passes per row-block, the plan's counters)."""
+        import numpy as np
+        pl = SxPlan()
+        L = lib()
+        L.spx_hip_mat_sym_pipeline.argtypes = [C.c_void_p, C.POINTER(SxPlan)]
+        if L.spx_hip_mat_sym_pipeline(self.handle, C.byref(pl)) != SPX_SUCCESS:
+            raise SpxError("spx_hip_mat_sym_pipeline failed")
+        passes = np.ctypeslib.as_array(C.cast(pl.passes, C.POINTER(C.c_uint32)), shape=(pl.n_passes, 6)).copy() \
+            if pl.n_passes else np.zeros((0, 6), np.uint32)
+        n_sx = np.ctypeslib.as_array(pl.n_sx, shape=(pl.n_rowblocks,)).copy() if pl.n_rowblocks else np.zeros(0, np.uint32)
+        return passes, n_sx, {k: int(getattr(pl, k)) for k in ("rowblocks_with_sx", "sym_elems", "sx_elems",
+                                                                "sym_passes", "sx_passes")}
 
     def export_csx(self, part=0):
         """Reference-format CSX arrays of one partition as numpy copies."""

@@ -2143,6 +2143,37 @@ try {
     return SPX_SUCCESS;
 } SPX_C_BOUNDARY(return SPX_FAILURE;)
 
+spx_error_t spx_hip_mat_sym_pipeline(spx_matrix_t *A, spx_hip_sx_plan_t *out)
+try {
+    if (!A || !out) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid argument"); return SPX_FAILURE; }
+    const GpuStream *s = A->host_stream ? A->host_stream.get() : A->index.get();
+    if (!s) { SETERROR_1(SPX_ERR_TUNED_MAT, "matrix holds no descriptor stream"); return SPX_FAILURE; }
+    std::lock_guard<std::mutex> lk(A->mtx);
+    try {
+        std::unique_ptr<SxPlan> plan(new SxPlan);
+        plan_sym_pipeline(*s, *plan, host_threads());
+        A->sx_inspect = std::move(plan);
+    } catch (const FatalError &e) {
+        SETERROR_1(SPX_ERR_TUNED_MAT, e.what.c_str());
+        return SPX_FAILURE;
+    } catch (const std::exception &e) {
+        SETERROR_1(SPX_ERR_MEM_ALLOC, e.what());
+        return SPX_FAILURE;
+    }
+    const SxPlan &p = *A->sx_inspect;
+    memset(out, 0, sizeof(*out));
+    out->passes = p.passes.data();
+    out->n_sx = p.n_sx.data();
+    out->n_rowblocks = s->rbs.size();
+    out->n_passes = p.passes.size();
+    out->rowblocks_with_sx = p.n_rb_sx;
+    out->sym_elems = p.sym_elems;
+    out->sx_elems = p.sx_elems;
+    out->sym_passes = p.sym_passes;
+    out->sx_passes = p.sx_passes;
+    return SPX_SUCCESS;
+} SPX_C_BOUNDARY(return SPX_FAILURE;)
+
 spx_error_t spx_hip_mat_info_sized(const spx_matrix_t *A, void *info, size_t size)
 try {
     spx_hip_info_t full;
@@ -2193,6 +2224,13 @@ try {
         info->unit_window_lds = (int32_t) lds;
         info->unit_window_elems = (int64_t) el;
         info->unit_window_staged = (int64_t) st;
+    }
+    if (A->dev && device_has_sx(A->dev)) {
+        uint64_t esx = 0, esym = 0;
+        size_t nrb = 0;
+        device_sx_info(A->dev, esx, esym, nrb);
+        info->sym_pipeline = device_get_sx(A->dev) ? 1 : 0;
+        info->sym_pipeline_elems = (int64_t) esx;
     }
     info->tune_seconds = A->tune_seconds;
     info->emit_seconds = A->emit_seconds;

@@ -248,6 +248,7 @@ struct Rccl {
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;      // (optional)
 };
 
 Rccl &rccl()
@@ -276,6 +277,7 @@ Rccl &rccl()
     SPX_SYM(Send, "ncclSend");
     SPX_SYM(Recv, "ncclRecv");
     SPX_SYM(GetErrorString, "ncclGetErrorString");
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.lib, "ncclCommCount"));
 #undef SPX_SYM
     return r;
 }
@@ -441,6 +443,20 @@ spx_hip_transport_t *spx_hip_transport_rccl(const void *id, int rank, int world)
     } catch (const spx::FatalError &e) {
         spx::log_msg(spx::LOG_ERR, "%s\n", e.what.c_str());
         return NULL;
+    }
+}
+
+int spx_hip_transport_rccl_ranks(const spx_hip_transport_t *t)
+{
+    if (!t || t->exchange_device != spx::rccl_exchange_device || !t->ctx) return -1;
+    try {
+        spx::Rccl &r = spx::rccl();
+        const spx::RcclCtx *c = static_cast<const spx::RcclCtx *>(t->ctx);
+        int n = -1;
+        if (!r.CommCount || !c->comm || r.CommCount(c->comm, &n) != ncclSuccess) return -1;
+        return n;
+    } catch (...) {
+        return -1;
     }
 }
 

@@ -111,7 +111,7 @@ struct Group {
 };
 
 // (read-once passes of one unit: a run of this many segments and more gets passes of its own)
-constexpr uint32_t PURE_MIN_SEGS = 32;
+constexpr uint32_t PURE_MIN_SEGS = 40;      // (a pass of its own is at least five eighths full)
 
 class RbBuilder {
 public:

@@ -10,6 +10,7 @@
 #include "gpu_emit.hpp"
 #include "input.hpp"
 #include "xwindows.hpp"
+#include "sxplan.hpp"
 
 #include <functional>
 #include <memory>
@@ -107,6 +108,7 @@ struct matrix {
     bool sx_on = false;         // ... the read-once passes run pipelined (csx_spmv_sx_kernel)
     uint32_t xw_budget = 3072, xw_gap = 16;   // spx.gpu.unit_window_doubles, spx.gpu.unit_window_gap
     std::unique_ptr<spx::XwPlan> xw_inspect;    // what spx_hip_mat_unit_windows handed out last
+    std::unique_ptr<spx::SxPlan> sx_inspect;    // ... and spx_hip_mat_sym_pipeline
     int device_ordinal = -1;
     std::vector<std::vector<idx_t>> spans;    // per partition and row: reach of its units
     std::vector<idx_t> max_span;              // per partition

@@ -802,13 +802,26 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
         }
     }
     // the read-once passes pipelined (symmetric streams of row segments, no tiles, stream order, one launch)
-    if (symmetric && s.sx_plan && m->has_symsegs && !m->has_symtiles && m->launch_order.empty() &&
+    if (symmetric && s.sx_plan && m->has_symsegs && !m->has_symtiles &&
         m->xcd_split.size() == 1 && !s.rbs.empty() && !s.deterministic && !s.wave_tiles) {
         try {
             SxPlan plan;
             plan_sym_pipeline(s, plan, host_threads());
             const size_t lds_need = (size_t) m->lds_doubles * sizeof(double) + m->max_slot_groups * sizeof(uint32_t) +
                                     spmv_sx_header_bytes(s.pass_stride);
+            if (!m->launch_order.empty()) {
+                // (row-blocks and their headers went up in launch order: the plan follows)
+                const size_t stride = s.pass_stride;
+                std::vector<SpxPass> po(plan.passes.size());
+                std::vector<uint32_t> no(plan.n_sx.size());
+                for (size_t i = 0; i < m->launch_order.size(); ++i) {
+                    std::copy(plan.passes.begin() + (size_t) m->launch_order[i] * stride,
+                              plan.passes.begin() + ((size_t) m->launch_order[i] + 1) * stride, po.begin() + i * stride);
+                    no[i] = plan.n_sx[m->launch_order[i]];
+                }
+                plan.passes.swap(po);
+                plan.n_sx.swap(no);
+            }
             if (plan.n_rb_sx && lds_need <= 160u * 1024u) {
                 const size_t pbytes = (plan.passes.size() + (size_t) s.pass_stride + 6 * MAX_WAVES_PER_BLOCK) * sizeof(SpxPass);
                 HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&m->passes_sx), pbytes));

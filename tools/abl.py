@@ -66,9 +66,6 @@ def main():
             opts[k] = v
         A = bench.tune(csr, opts)
         info = A.info()
-        for ln in A.tune_log().splitlines():       # (what the tuner decided, for the record: stderr)
-            if any(k in ln for k in ("read-once pipeline", "launch autotune", "unit windows:", "column slices")):
-                print("[%s] %s" % (name, ln), file=sys.stderr)
         st_ = torch.cuda.current_stream().cuda_stream
         y.fill_(float("nan"))
         A.hip_matvec_mult(bench.ALPHA, x.data_ptr(), y.data_ptr(), st_)
@@ -91,6 +88,8 @@ def main():
             ts.append(1e-3 * e0.elapsed_time(e1) / args.steps)
         t = float(np.median(ts))
         xw = "xw %d KB LDS" % (info.unit_window_lds // 1024) if info.unit_windows else "-"
+        if int(getattr(info, "sym_pipeline", 0)):
+            xw = "sx %.1f %% of stored nnz" % (100.0 * info.sym_pipeline_elems / max(int(info.nnz_stored), 1))
         print("| %s | %s | %s | %.2f | %.1f | %.3f | %d | %d | %d, %s | %.2f | %.2f | %.3f |" % (
             label, "symmetric" if args.symmetric else "general", name if not body else "%s (`%s`)" % (name, body),
             1e6 * t, 2.0 * nnz / t / 1e9, info.index_bytes / max(int(info.nnz_stored), 1), int(info.nnz_stored),
