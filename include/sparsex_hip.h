@@ -82,10 +82,13 @@
  *                           as a software pipeline (csx_spmv_xw_kernel); spx.gpu.unit_window_doubles (3072): most
  *                           doubles of x a row-block may stage (row-blocks that need more gather through L2);
  *                           spx.gpu.unit_window_gap (16): column intervals closer than this are staged as one
- *   spx.vec.device          "true" (default): vectors the library creates (spx_vec_create*, page-locked) keep x's HBM
- *                           copy between spx_matvec_* calls: the copy is reused while no spx_vec_* call has changed the
- *                           vector and a fingerprint of its contents stands (a client that pokes single elements
- *                           through v->elements sets "false"); views of user buffers (SPX_VEC_AS_IS) always travel
+ *   spx.vec.device          "false" (default) | "true" (also: env SPX_VEC_DEVICE through spx_options_set_from_env):
+ *                           vectors the library allocates itself (spx_vec_create, spx_vec_create_random; page-locked)
+ *                           keep x's HBM copy between spx_matvec_* calls, reused while no spx_vec_* call has changed
+ *                           the vector.  OPT-IN because struct vector_struct is public: a client that writes through
+ *                           v->elements must call spx_hip_vec_touch(v) afterwards (a sampled fingerprint of the
+ *                           contents is a second net only: a rewritten vector is seen, one poked element may not be).
+ *                           Views of user buffers (spx_vec_create_from_buff, both modes) always travel
  *   spx.rt.dist_chunks      at most 64 parts (larger values are clamped)
  *   spx.gpu.sym_once        "false": symmetric path reads lower triangle and mirror
  *                           image (default: dense 8x8 tiles are read once)
@@ -148,6 +151,10 @@ spx_error_t spx_hip_matvec_kernel(spx_value_t alpha, const spx_matrix_t *A,
  * spx_hip_vec_mul and the download, which synchronise the stream.
  */
 typedef struct spx_hip_vec spx_hip_vec_t;
+
+/* spx.vec.device=true only: tells the library that the client wrote to v->elements directly (a vector from
+ * spx_vec_create / spx_vec_create_random); the next spx_matvec_* uploads it again.  Harmless otherwise. */
+void spx_hip_vec_touch(const spx_vector_t *v);
 
 spx_hip_vec_t *spx_hip_vec_create(size_t size);                 /* zero-filled        */
 spx_hip_vec_t *spx_hip_vec_create_from_host(const spx_vector_t *v);

@@ -43,14 +43,16 @@ enum { ALLOC_STD = 1, ALLOC_OTHER = 4,          // Vector.cpp:36-41
        ALLOC_PINNED = 8 };                      // this build: page-locked, copied to/from HBM directly
 enum { VEC_MODE_INVALID = 45 };                // Vector.cpp:43-47
 
-// spx.vec.device (default true): vectors the library created (spx_vec_create, spx_vec_create_random,
-// spx_vec_create_from_buff with SPX_VEC_TUNE -- page-locked memory of the library's own) carry a version that
-// every spx_vec_* mutator advances; spx_matvec_* reuse x's copy in HBM while it stands: a relinked reference
+// spx.vec.device (default false; env SPX_VEC_DEVICE through spx_options_set_from_env): with "true", vectors the
+// library allocated itself (spx_vec_create, spx_vec_create_random -- page-locked memory of the library's own;
+// NEVER spx_vec_create_from_buff vectors, whose buffer is the client's in both modes) carry a version that every
+// spx_vec_* mutator advances, and spx_matvec_* reuse x's copy in HBM while it stands: a relinked reference
 // client's 128-loop (test/src/sparsex_test.c:161-163) or one of its examples uploads x once and pays the way
-// back of y only.  Views of user buffers (SPX_VEC_AS_IS) are never tracked.  `struct vector_struct` is public,
-// so a client CAN write through v->elements behind the library's back; the version handed to the device side
-// therefore includes a fingerprint of the contents (a few hundred samples and both ends: a rewritten vector
-// is seen, a single poked element may not be -- such a client sets spx.vec.device=false).
+// back of y only.  `struct vector_struct` is public, so a client CAN write through v->elements behind the
+// library's back: that is why this is opt-in.  A client that opts in and writes directly calls
+// spx_hip_vec_touch(v) afterwards.  The version handed to the device side also includes a fingerprint of the
+// contents (a few hundred samples and both ends) as a second net: a rewritten vector is seen even without the
+// call, a single poked element may not be.
 std::mutex g_vec_mtx;
 std::unordered_map<const spx_vector_t *, uint64_t> g_vec_version;
 std::atomic<uint64_t> g_version_clock(1);
@@ -715,7 +717,9 @@ static void autotune_launch(spx_matrix_t *A, bool tune_waves, bool tune_spill, b
     // the unit windows of x in LDS (csx_spmv_xw_kernel) against the plain kernel, whatever else is
     // being varied: `xw` receives the state the returned time belongs to
     auto time_xw = [&](bool &xw) {
-        if (!tune_xw || !device_has_xw(A->dev)) {
+        if (!tune_xw || !device_has_xw(A->dev) || A->wave_tiles == 1) {
+            // (nothing to choose: no windows planned, or a y tile per wavefront won -- device_set_xw does
+            // nothing then, and timing it "both ways" would compare a kernel with itself)
             xw = device_get_xw(A->dev);
             return best_time();
         }
@@ -777,6 +781,7 @@ static void autotune_launch(spx_matrix_t *A, bool tune_waves, bool tune_spill, b
             best_t = tw;
             A->wave_tiles = 1;
             best_xw = false;              // (the per-wavefront tiles run through the plain kernel)
+            A->xw_on = false;             // ... also in whatever is emitted again further down
         } else {
             device_set_wave_tiles(A->dev, false);
             A->wave_tiles = 0;
@@ -2107,7 +2112,10 @@ try {
 
 int spx_hip_abi_version(void) { return SPX_HIP_ABI_VERSION; }
 
-int spx_hip_mat_host_parts(const spx_matrix_t *A) { return A && A->dev ? device_host_parts(A->dev) : 0; }
+int spx_hip_mat_host_parts(const spx_matrix_t *A)
+try {
+    return A && A->dev ? device_host_parts(A->dev) : 0;
+} SPX_C_BOUNDARY(return 0;)
 
 spx_error_t spx_hip_mat_unit_windows(spx_matrix_t *A, uint32_t budget, uint32_t gap, spx_hip_xw_plan_t *out)
 try {
@@ -2361,7 +2369,8 @@ try {
         SETERROR_1(SPX_ERR_ARG_INVALID, "invalid partition handle");
         return SPX_INVALID_VEC;
     }
-    // both modes alias the user buffer, as on the reference's non-NUMA build
+    // both modes alias the user buffer, as on the reference's non-NUMA build (src/api/matvec.c:809-815): the
+    // client writes x through its own pointer, so such a vector is NEVER tracked for residency (no vec_track)
     spx_vector_t *v = (spx_vector_t *) malloc(sizeof(spx_vector_t));
     if (!v) { log_msg(LOG_ERR, "malloc failed\n"); exit(1); }
     v->elements = buff;
@@ -2379,6 +2388,11 @@ try {
         spx_value_t val = ((spx_value_t)(rand() + i) / ((spx_value_t) RAND_MAX + 1));
         v->elements[i] = min + val * (max - min);
     }
+} SPX_C_BOUNDARY(return;)
+
+void spx_hip_vec_touch(const spx_vector_t *v)
+try {
+    if (v) vec_touch(v);
 } SPX_C_BOUNDARY(return;)
 
 spx_vector_t *spx_vec_create_random(size_t size, const spx_partition_t *p)

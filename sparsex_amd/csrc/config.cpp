@@ -40,7 +40,7 @@ void Config::reset_defaults()
     props_["spx.rt.gpu_rank"] = "0";         // this process' slice of the partitions
     props_["spx.rt.gpu_world"] = "1";
     props_["spx.rt.device"] = "-1";          // HIP device ordinal, -1 = current
-    props_["spx.vec.device"] = "true";       // vectors the library creates keep their HBM copy between calls (false: every call uploads x)
+    props_["spx.vec.device"] = "false";      // true: vectors the library creates keep their HBM copy between calls (a client that writes through v->elements must then say so: spx_hip_vec_touch)
     props_["spx.rt.dist_chunks"] = "4";      // SPX_DIST_OVERLAP: parts of the own product the halo exchange is pipelined over (1: no plan)
     props_["spx.rt.dist_reorder"] = "none";  // with gpu_world > 1 and the whole matrix: none | rcm | rcm_owner in front of the cut
     props_["spx.rt.row_offset"] = "0";       // the input holds rows [offset, offset + its rows) ...
@@ -111,6 +111,8 @@ void Config::load_from_env()
         set("spx.preproc.sampling.portion", s);
     }
     if ((s = getenv("SAMPLING"))) set("spx.preproc.sampling", s);
+    // (this build's: lets an unchanged client binary that calls spx_options_set_from_env opt in to resident vectors)
+    if ((s = getenv("SPX_VEC_DEVICE"))) set("spx.vec.device", s);
 }
 
 std::string Config::get_str(const std::string &key) const

@@ -124,7 +124,10 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &x
     // wave w takes passes w, w + W, ..., two at a time when they have the same shape (they mostly
     // do: passes are sorted by width), so that their loads overlap
     const int n_pass = rb.n_pass;
-    for (int t = wave; t < n_pass; t += 2 * WAVES_PER_BLOCK) {
+    int t = wave;
+    // (symmetric tiles: the tile passes at the head of the wavefront's list, one round trip each)
+    if (SYM && TILES && !abl::sym_no_tile_run) symtile_run<WAVES_PER_BLOCK>(a, rb, passes, n_pass, t, p0, p1, mine, tile, lane);
+    for (; t < n_pass; t += 2 * WAVES_PER_BLOCK) {
         const bool two = t + WAVES_PER_BLOCK < n_pass;
         if (SEGS && (p0.kind == SPX_PASS_SYMSEG || (two && p1.kind == SPX_PASS_SYMSEG))) {
             // read-once row segments (atomic hand-over only); whatever shares the round runs on its own
@@ -1328,6 +1331,9 @@ void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x, bool x_p
                 HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
                 m->part_events.push_back(e);
             }
+            // (a failure in here must not leave copies queued that still write into the caller's y after the
+            // C entry point has returned its error: both streams are drained before the exception travels on)
+            try {
             for (size_t k = 0; k < K; ++k) {
                 device_spmv_chunk(m, k, alpha, m->d_x, beta, m->d_y, st, 2);
                 HIP_CHECK(hipEventRecord(m->part_events[k], st));
@@ -1349,6 +1355,13 @@ void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x, bool x_p
                 copy_threads(reinterpret_cast<char *>(h_y) + off, reinterpret_cast<char *>(m->p_y) + off, n);
             }
             return;
+            } catch (...) {
+                (void) hipStreamSynchronize(m->copy_stream);
+                (void) hipStreamSynchronize(st);
+                (void) hipGetLastError();
+                m->host_parts = 0;
+                throw;
+            }
         }
     }
     m->host_parts = 0;

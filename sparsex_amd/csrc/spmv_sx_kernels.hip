@@ -300,34 +300,24 @@ void csx_spmv_sx_kernel(SPX_KERNEL_PARAMS, const uint32_t *sx_tab_)
     spmv_body_sx<WAVES, B>(a, xcd_split, sx_tab_, lds_dyn);
 }
 
-// passes per round of the pipeline: two (90 VGPRs: five wavefronts per SIMD) or one (more workgroups per CU)
-static int sx_passes_per_round()
-{
-    static const int b = [] {
-        const char *e = getenv("SPX_SX_PASSES_PER_ROUND");
-        return e && atoi(e) == 1 ? 1 : 2;
-    }();
-    return b;
-}
+// (B: passes per round of the pipeline.  Two per round -- the unit-window kernel's choice -- take 90 VGPRs, five
+// wavefronts per SIMD, and measured 3-4 % slower than one per round at 64 VGPRs: 947 / 939 against 913 / 903 us on
+// the bench matrix, profiles/r06/sx_order_and_width.md; three workgroups of eight wavefronts per CU with one
+// round in flight behind the one being finished already cover the latency.)
+constexpr int SX_PASSES_PER_ROUND = 1;
 
 void launch_spmv_sx(int waves, unsigned blocks, size_t lds_bytes, void *stream_, const KernelArgs &a, const XcdSplit &xs,
                     const uint32_t *sx_tab)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-#define SPX_LAUNCH_SX(W, B)                                                                           \
-    hipLaunchKernelGGL((csx_spmv_sx_kernel<W, B>), dim3(blocks), dim3(64 * W), lds_bytes, stream, a.rbs,  \
+#define SPX_LAUNCH_SX(W)                                                                              \
+    hipLaunchKernelGGL((csx_spmv_sx_kernel<W, SX_PASSES_PER_ROUND>), dim3(blocks), dim3(64 * W), lds_bytes, stream, a.rbs,  \
                        a.passes, a.n_rb, a.pass_stride, xs, a.values, a.descs, a.cidx, a.segrows,   \
                        a.x, a.y, a.carry, a.dvalues, a.spill, a.slot_col, a.alpha, a.beta,           \
                        a.dvalues_priv, a.beta_priv, sx_tab)
-    if (sx_passes_per_round() == 1) {
-        if (waves == 2) SPX_LAUNCH_SX(2, 1);
-        else if (waves == 8) SPX_LAUNCH_SX(8, 1);
-        else SPX_LAUNCH_SX(4, 1);
-    } else {
-        if (waves == 2) SPX_LAUNCH_SX(2, 2);
-        else if (waves == 8) SPX_LAUNCH_SX(8, 2);
-        else SPX_LAUNCH_SX(4, 2);
-    }
+    if (waves == 2) SPX_LAUNCH_SX(2);
+    else if (waves == 8) SPX_LAUNCH_SX(8);
+    else SPX_LAUNCH_SX(4);
 #undef SPX_LAUNCH_SX
 }
 
@@ -340,9 +330,8 @@ size_t spmv_sx_header_bytes(uint32_t pass_stride)
 void spmv_sx_allow_lds(size_t bytes)
 {
     const int b = (int) bytes;
-#define SPX_ATTR_SX(W, B) (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&csx_spmv_sx_kernel<W, B>), hipFuncAttributeMaxDynamicSharedMemorySize, b)
-    SPX_ATTR_SX(2, 1); SPX_ATTR_SX(4, 1); SPX_ATTR_SX(8, 1);
-    SPX_ATTR_SX(2, 2); SPX_ATTR_SX(4, 2); SPX_ATTR_SX(8, 2);
+#define SPX_ATTR_SX(W) (void) hipFuncSetAttribute(reinterpret_cast<const void *>(&csx_spmv_sx_kernel<W, SX_PASSES_PER_ROUND>), hipFuncAttributeMaxDynamicSharedMemorySize, b)
+    SPX_ATTR_SX(2); SPX_ATTR_SX(4); SPX_ATTR_SX(8);
 #undef SPX_ATTR_SX
 }
 

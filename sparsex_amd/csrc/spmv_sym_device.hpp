@@ -43,14 +43,23 @@ __device__ __forceinline__ double xchg4(double v)
 // eight lanes (4 + 2 + 1 values travel), so that each lane ends up with ONE
 // column and the LDS adds of a tile hit eight different addresses -- lanes
 // that add to the same address are serialised at ~3 clocks each.
+// the lane's tile descriptor of a tile pass: {col0, row0 | slot << 9}
+__device__ __forceinline__ uint2 symtile_desc(const KernelArgs &a, const SpxRowBlock &rb, const SpxPass &ps, int lane)
+{
+    const uint32_t l = (uint32_t) lane < ps.nseg ? (uint32_t) lane : 0u;
+    return *reinterpret_cast<const uint2 *>(a.descs + rb.desc_off + ps.rank0 + (l >> 3));
+}
+
+// (`q`: the lane's tile descriptor, fetched by the caller -- a wavefront that runs several tile passes in a row
+// asks for the next pass' descriptors together with the values of the current one: one memory round trip per
+// pass instead of two, symtile_run below)
 __device__ __forceinline__ void symtile_pass(const KernelArgs &a, const SpxRowBlock &rb,
-                                             const SpxPass &ps, double *slots, double *tile,
+                                             const SpxPass &ps, const uint2 q, double *slots, double *tile,
                                              int lane)
 {
     const uint32_t nseg = ps.nseg;
     const bool active = (uint32_t) lane < nseg;
     const uint32_t l = active ? (uint32_t) lane : 0u;
-    const uint2 q = *reinterpret_cast<const uint2 *>(a.descs + rb.desc_off + ps.rank0 + (l >> 3));
     const double *vals = a.values + rb.val_off + ps.val_off;
     double2 v2[4];
 #pragma unroll
@@ -120,6 +129,39 @@ __device__ __forceinline__ void symtile_pass(const KernelArgs &a, const SpxRowBl
     if (active) {
         atomicAdd(&tile[row], t);
         atomicAdd(&slots[slot + (uint32_t) i], cs);
+    }
+}
+
+__device__ __forceinline__ void symtile_pass(const KernelArgs &a, const SpxRowBlock &rb, const SpxPass &ps,
+                                             double *slots, double *tile, int lane)
+{
+    symtile_pass(a, rb, ps, symtile_desc(a, rb, ps, lane), slots, tile, lane);
+}
+
+// The tile passes at the head of a wavefront's list (pass t, t + WAVES, ... while they are tile passes; the
+// emitter puts a row-block's tiles first), one memory round trip each: a tile's x addresses come from its
+// descriptor, and fetched inside the pass the descriptor costs a round trip of its own in front of the x loads
+// (a chain header -> descriptor -> x; syn-nd24k: sixteen passes of a row-block on four wavefronts, every one
+// of them two dependent round trips out of the Infinity Cache).  Here the descriptors of the NEXT pass are
+// requested in front of the loads of the current one, the pass header a pass further ahead still.
+// `p0` / `p1`: the headers of the passes t and t + WAVES, already loaded.  On return t is the wavefront's next
+// pass (not a tile pass, or past the end) and p0 / p1 are its header and the one WAVES behind it.
+template <int WAVES>
+__device__ __forceinline__ void symtile_run(const KernelArgs &a, const SpxRowBlock &rb, const SpxPass *passes, int n_pass,
+                                            int &t, SpxPass &p0, SpxPass &p1, double *slots, double *tile, int lane)
+{
+    if (t >= n_pass || p0.kind != SPX_PASS_SYMTILE) return;
+    uint2 q = symtile_desc(a, rb, p0, lane);
+    for (;;) {
+        const bool more = t + WAVES < n_pass && p1.kind == SPX_PASS_SYMTILE;         // (wave-uniform)
+        const SpxPass p2 = passes[t + 2 * WAVES];                                    // (the table is padded)
+        const uint2 qn = symtile_desc(a, rb, more ? p1 : p0, lane);
+        symtile_pass(a, rb, p0, q, slots, tile, lane);
+        t += WAVES;
+        p0 = p1;
+        p1 = p2;
+        q = qn;
+        if (!more) break;
     }
 }
 

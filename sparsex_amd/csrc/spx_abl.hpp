@@ -58,5 +58,11 @@ constexpr bool sym_no_private = true;
 constexpr bool sym_no_private = false;
 #endif
 
+#ifdef SPX_ABL_SYM_NOTILERUN         /* tile passes fetch their descriptors themselves (the form before round 6) */
+constexpr bool sym_no_tile_run = true;
+#else
+constexpr bool sym_no_tile_run = false;
+#endif
+
 }  // namespace abl
 }  // namespace spx

@@ -96,24 +96,33 @@ RbResult plan_rowblock(const GpuStream &s, size_t rb_idx, size_t ncols, uint32_t
     uint64_t total = 0;
     for (const Interval &w : win) total += (uint64_t) ((w.hi - w.lo + 1) & ~(int64_t) 1);
     if (total > budget || total > 65534u) return res;
-    // accepted: the table, then every descriptor and unit pass of the row-block
-    XwEntry *tab = plan.tab.data() + rb_idx * XW_TAB + XW_RANGES;
+    // the LDS offset of every window, and -- before anything of the plan is written -- of every descriptor's
+    // col0 (the column of its segment 0): a descriptor whose col0 lies in no window (its segment 0 is not
+    // among this row-block's unit passes; never in a stream of this emitter) leaves the row-block on the
+    // plain path as a whole, not half planned
     std::vector<uint32_t> off(win.size());
     uint32_t at = 0;
     for (size_t k = 0; k < win.size(); ++k) {
-        const uint32_t len = (uint32_t) (win[k].hi - win[k].lo);
         off[k] = at;
-        tab[k].base = (uint32_t) win[k].lo;
-        tab[k].off_len = at | (len << 16);
-        at += (len + 1u) & ~1u;
+        at += ((uint32_t) (win[k].hi - win[k].lo) + 1u) & ~1u;
     }
+    std::vector<uint32_t> xcol(span.size(), 0u);
     for (size_t rank = 0; rank < span.size(); ++rank) {
         if (span[rank].lo > span[rank].hi) continue;
-        SpxUnitDesc &d = plan.xdescs[(size_t) rb.desc_off + rank];
-        size_t k = (size_t) (std::upper_bound(win.begin(), win.end(), (int64_t) d.col0,
-                                              [](int64_t c, const Interval &w) { return c < w.lo; }) - win.begin()) - 1u;
-        d.col0 = (uint32_t) ((int64_t) d.col0 - win[k].lo + (int64_t) off[k]);
+        const int64_t c0 = (int64_t) s.descs[(size_t) rb.desc_off + rank].col0;
+        const size_t above = (size_t) (std::upper_bound(win.begin(), win.end(), c0,
+                                                        [](int64_t c, const Interval &w) { return c < w.lo; }) - win.begin());
+        if (above == 0 || c0 >= win[above - 1].hi) return res;
+        xcol[rank] = (uint32_t) (c0 - win[above - 1].lo + (int64_t) off[above - 1]);
     }
+    // accepted: the table, then every descriptor and unit pass of the row-block
+    XwEntry *tab = plan.tab.data() + rb_idx * XW_TAB + XW_RANGES;
+    for (size_t k = 0; k < win.size(); ++k) {
+        tab[k].base = (uint32_t) win[k].lo;
+        tab[k].off_len = off[k] | ((uint32_t) (win[k].hi - win[k].lo) << 16);
+    }
+    for (size_t rank = 0; rank < span.size(); ++rank)
+        if (span[rank].lo <= span[rank].hi) plan.xdescs[(size_t) rb.desc_off + rank].col0 = xcol[rank];
     SpxPass *px = plan.passes.data() + rb.pass_off;
     for (uint32_t t = 0; t < rb.n_pass; ++t) {
         SpxPass &ps = px[t];

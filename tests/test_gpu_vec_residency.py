@@ -1,4 +1,4 @@
-"""spx.vec.device (default on): vectors created by the library carry a version that every
+"""spx.vec.device (opt-in; default off since round 6): vectors created by the library carry a version that every
 spx_vec_* mutator advances; spx_matvec_* reuse x's copy in HBM while the version stands, so
 the 128-loop of a relinked reference client (test/src/sparsex_test.c:161-163) uploads x once.
 Results must follow every change made through the API."""
@@ -65,3 +65,36 @@ def test_x_stays_in_hbm_between_calls(resident):
     L.spx_vec_destroy(y)
     L.spx_partition_destroy.argtypes = [C.c_void_p]
     L.spx_partition_destroy(part)
+
+
+@pytest.mark.parametrize("resident", ["default", "true"])
+def test_one_element_written_through_the_public_struct(resident):
+    """`struct vector_struct` is public (include/sparsex/common.h; reference Vector.hpp:30-35): a client may poke one
+    element of a spx_vec_create'd vector -- the unit-vector sweep x[i-1] = 0, x[i] = 1.  With the DEFAULT options
+    every call must see it (x travels every time); a client that opted in to resident vectors says so with
+    spx_hip_vec_touch."""
+    csr = synth.syn_cant(0.1)
+    n = csr[3]
+    A = tune(csr, {} if resident == "default" else {"spx.vec.device": "true"})
+    L = sx.lib()
+    L.spx_mat_get_partition.restype = C.c_void_p
+    part = C.c_void_p(L.spx_mat_get_partition(C.c_void_p(A.handle)))
+    x, y, xa, ya = _vecs(n, part)
+    L.spx_hip_vec_touch.argtypes = [C.POINTER(VectorStruct)]
+    L.spx_hip_vec_touch.restype = None
+    xa[:] = 0.0
+    L.spx_hip_vec_touch(x)
+    for i in (n // 2, n // 2 + 1, n // 2 + 2, 3):          # (not among the few hundred sampled positions by design)
+        if i > 0:
+            xa[i - 1] = 0.0
+        xa[i] = 1.0
+        if resident == "true":
+            L.spx_hip_vec_touch(x)
+        assert L.spx_matvec_mult(1.0, C.c_void_p(A.handle), x, y) == 0
+        check_y(csr, xa.copy(), ya.copy(), 1.0)
+        xa[i] = 0.0
+    L.spx_vec_destroy(x)
+    L.spx_vec_destroy(y)
+    L.spx_partition_destroy.argtypes = [C.c_void_p]
+    L.spx_partition_destroy(part)
+    sx.options_reset()

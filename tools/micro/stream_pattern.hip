@@ -11,6 +11,7 @@
 //   mode 6  as mode 1, and every workgroup ends with 304 doubles written (a row-block's rows of y: 2.4 KB per
 //           64 KB read): plain stores, non-temporal stores, stores into a small region that stays in the L2,
 //           and the same bytes written by one workgroup in 64 (64 x 304 doubles at once)
+//           (round 6: also `sc1` / `sc0 sc1` stores, 8 and 16 bytes per lane)
 //   mode 7  as mode 6 with plain stores, but a workgroup takes K consecutive chunks of its XCD's list one after the
 //           other and writes each one's 304 doubles as it goes (1 / K as many workgroups, the same stores)
 //   mode 5  as mode 1, and every workgroup also reads XKB (argv[3], default 24) kilobytes of a region small enough
@@ -109,6 +110,29 @@ __global__ __launch_bounds__(256) void pattern_wr_kernel(const double2 *p, size_
             if (STORE == 2) __builtin_nontemporal_store(acc, dst + i);
             else dst[i] = acc;
         }
+    } else if (STORE == 8 || STORE == 9) {
+        // the store flavours of MI355X_MICROARCH.md that DROP the line from the XCD's L2 instead of keeping it:
+        // `sc1` (8) and `sc0 sc1` (9), 8 bytes per lane as the kernels' write-out issues them
+        double *dst = y + chunk * 304u;
+        for (unsigned i = threadIdx.x; i < 304u; i += 256u) {
+            if (STORE == 8) asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(dst + i), "v"(acc) : "memory");
+            else asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" :: "v"(dst + i), "v"(acc) : "memory");
+        }
+    } else if (STORE == 10 || STORE == 11) {
+        // ... and the same as 16 bytes per lane (152 lanes): plain (10) and sc1 (11)
+        double *dst = y + chunk * 304u;
+        const double2 v2 = double2{acc, acc};
+        typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+        const unsigned lo = (unsigned) __double2loint(acc), hi = (unsigned) __double2hiint(acc);
+        const v4u_t w4 = {lo, hi, lo, hi};
+        for (unsigned i = threadIdx.x; i < 152u; i += 256u) {
+            if (STORE == 10) reinterpret_cast<double2 *>(dst)[i] = v2;
+            else asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(reinterpret_cast<double2 *>(dst) + i), "v"(w4) : "memory");
+        }
+    } else if (STORE == 12) {
+        // the same 304 doubles added atomically (global_atomic_add_f64, no return): the symmetric kernels' hand-over
+        double *dst = y + chunk * 304u;
+        for (unsigned i = threadIdx.x; i < 304u; i += 256u) unsafeAtomicAdd(dst + i, acc);
     } else if (STORE == 6) {
         if (threadIdx.x == 0) y[chunk] = acc;                    // one lane, 8 bytes (a dot product's partial sum)
     } else if (STORE == 7) {
@@ -139,7 +163,10 @@ static void run_wr(const double2 *p, size_t n_chunks, unsigned chunk16, double *
     float ms; (void) hipEventElapsedTime(&ms, e0, e1);
     static const char *what[] = {"no stores", "plain stores", "non-temporal stores", "stores into an L2-resident region",
                                  "one workgroup in 64 stores 64 tiles", "298 doubles, tiles packed (partial lines)",
-                                 "ONE lane stores 8 bytes", "one lane adds atomically to 1 of 1024"};
+                                 "ONE lane stores 8 bytes", "one lane adds atomically to 1 of 1024",
+                                 "sc1 stores (8 bytes per lane)", "sc0 sc1 stores (8 bytes per lane)",
+                                 "plain stores, 16 bytes per lane", "sc1 stores, 16 bytes per lane",
+                                 "atomic adds (8 bytes per lane)"};
     printf("mode 6 U=4 chunk %u KB, 2.4 KB written per chunk, %-36s: stream %.1f GB/s\n", chunk16 * 16 / 1024, what[STORE],
            10.0 * n_chunks * chunk16 * 16 / (ms * 1e6));
 }
@@ -294,6 +321,12 @@ int main(int argc, char **argv)
             run_wr<5>(p, n_chunks, chunk16, y, out, blocks1, lds);
             run_wr<6>(p, n_chunks, chunk16, y, out, blocks1, lds);
             run_wr<7>(p, n_chunks, chunk16, y, out, blocks1, lds);
+            run_wr<8>(p, n_chunks, chunk16, y, out, blocks1, lds);
+            run_wr<9>(p, n_chunks, chunk16, y, out, blocks1, lds);
+            run_wr<10>(p, n_chunks, chunk16, y, out, blocks1, lds);
+            run_wr<11>(p, n_chunks, chunk16, y, out, blocks1, lds);
+            run_wr<12>(p, n_chunks, chunk16, y, out, blocks1, lds);
+            run_wr<1>(p, n_chunks, chunk16, y, out, blocks1, lds);
         }
         for (unsigned K : {1u, 2u, 4u, 8u, 24u}) run_multi(p, n_chunks, chunk16, y, K, out, lds);
         (void) hipFree(y);
