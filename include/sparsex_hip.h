@@ -378,7 +378,8 @@ typedef struct {
     int32_t sym_pipeline;    /* symmetric path, spx.gpu.sym_pipeline: 1 = the read-once passes that carry their
                                 geometry in the header run pipelined, x requested with the values
                                 (csx_spmv_sx_kernel)                                                  */
-    int32_t reserved0;
+    int32_t init_fold;       /* spx.gpu.init_fold: 1 = the init pass of a product whose row-blocks add to y runs as the
+                                first workgroups of the launch itself (no kernel in front)                */
     int64_t sym_pipeline_elems; /* ... nonzeros in such passes (of the nonzeros in read-once passes)    */
 } spx_hip_info_t;
 

@@ -52,7 +52,7 @@ class HipInfo(C.Structure):
                 ("quad", C.c_int32), ("col_slices", C.c_int32),
                 ("unit_windows", C.c_int32), ("unit_window_lds", C.c_int32),
                 ("unit_window_elems", C.c_int64), ("unit_window_staged", C.c_int64),
-                ("sym_pipeline", C.c_int32), ("reserved0", C.c_int32), ("sym_pipeline_elems", C.c_int64)]
+                ("sym_pipeline", C.c_int32), ("init_fold", C.c_int32), ("sym_pipeline_elems", C.c_int64)]
 
 
 class SxPlan(C.Structure):

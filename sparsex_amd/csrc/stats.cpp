@@ -88,87 +88,64 @@ void StatsCollection::filter_coverage(size_t nnz, double min_coverage,
     finish(*this, pp);
 }
 
-// ---- BlockSplitter (Statistics.cpp:28-87) -------------------------------------
+// ---- block splitting (what the reference's BlockSplitter does to the statistics of a block type,
+// src/internals/Statistics.cpp:28-87; the arithmetic must match it, including which remainders drop out) ----
+//
+// The statistics of a block type are keyed by the blocks' FREE dimension (the other one is the type's
+// alignment).  Two rules move what was counted under one dimension to smaller ones:
+//   1. a block larger than a unit can hold (dimension x alignment > max_unit) is counted as blocks of the
+//      largest dimension that fits;
+//   2. the largest dimension that covers at least `min_coverage` of the matrix absorbs every larger one
+//      (those are rare: as blocks of their own they would be filtered out, as pieces of the common size they
+//      count).  Dimensions below it are left alone, and if no dimension passes, nothing is folded.
+// Moving blocks of dimension `dim` to dimension `target` (redistribute) turns each into dim / target full blocks
+// and one leftover of dim % target columns/rows -- which stays in the statistics only if it is still a block,
+// i.e. at least two wide; a one-wide leftover drops out (its nonzeros are no longer counted as encoded).
 
 namespace {
 
-// Redistributes the stats of blocks with free dimension var_dim into chunks
-// of max_var_dim plus a remainder block.
-void split_block_data(size_t fixed_dim, size_t var_dim, size_t max_var_dim,
-                      const StatsData &data, InstStats &stats)
+void redistribute(InstStats &stats, size_t align, size_t dim, size_t target, const StatsData whole)
 {
-    size_t nr_chunks = var_dim / max_var_dim;
-    size_t rem_dim = var_dim % max_var_dim;
-    size_t max_block = max_var_dim * fixed_dim;
-    size_t nr_max_blocks = nr_chunks * data.units;
-    size_t rem_nnz = data.nnz - nr_max_blocks * max_block;
-    stats[max_var_dim] += StatsData(nr_max_blocks * max_block, nr_max_blocks, 0);
-    if (rem_dim >= 2)   // one-dimensional remainders are ignored
-        stats[rem_dim] += StatsData(rem_nnz, data.units, 0);
+    const size_t n_full = (dim / target) * whole.units;
+    const size_t nnz_full = n_full * target * align;
+    const size_t left = dim % target;
+    stats[target] += StatsData(nnz_full, n_full, 0);
+    if (left >= 2) stats[left] += StatsData(whole.nnz - nnz_full, whole.units, 0);
 }
 
-// The reference walks the map with reverse iterators while inserting smaller
-// keys; a reverse iterator steps to "the largest key below the current one
-// at the time of the step", which is what these helpers do.
-bool last_key(const InstStats &m, size_t &k)
+// the dimensions of `stats` above `floor_dim`, largest first
+std::vector<size_t> dims_above(const InstStats &stats, size_t floor_dim)
 {
-    if (m.empty()) return false;
-    k = m.rbegin()->first;
-    return true;
+    std::vector<size_t> out;
+    for (auto it = stats.rbegin(); it != stats.rend() && it->first > floor_dim; ++it) out.push_back(it->first);
+    return out;
 }
 
-bool prev_key(const InstStats &m, size_t &k)
-{
-    auto it = m.lower_bound(k);
-    if (it == m.begin()) return false;
-    --it;
-    k = it->first;
-    return true;
-}
-
-int split_type(int type, InstStats &stats, size_t max_unit, size_t nnz,
-               double min_coverage)
+// returns how many dimensions were moved (0: the statistics are unchanged)
+int split_type(int type, InstStats &stats, size_t max_unit, size_t nnz, double min_coverage)
 {
     if (!enc_is_block(type)) return 0;
-    size_t fixed_dim = (size_t) enc_block_align(type);
-    size_t max_block_dim = max_unit / fixed_dim;
-    int ret = 0;
-    std::vector<size_t> erase;
-
-    // 1. cut blocks larger than a unit can hold
-    size_t k;
-    bool ok = last_key(stats, k);
-    while (ok && k * fixed_dim > max_unit) {
-        StatsData d = stats[k];
-        split_block_data(fixed_dim, k, max_block_dim, d, stats);
-        erase.push_back(k);
-        ++ret;
-        ok = prev_key(stats, k);
+    const size_t align = (size_t) enc_block_align(type);
+    const size_t cap = max_unit / align;                 // largest free dimension a unit can hold
+    int moved = 0;
+    // (what a redistribution adds lies at or below its target, so the dimensions collected beforehand are
+    // exactly the ones the rule applies to; each is read before anything is added under its own key)
+    auto move_all = [&](const std::vector<size_t> &dims, size_t target) {
+        for (size_t d : dims) redistribute(stats, align, d, target, stats[d]);
+        for (size_t d : dims) stats.erase(d);
+        moved += (int) dims.size();
+    };
+    // rule 1
+    move_all(dims_above(stats, cap), cap);
+    // rule 2: the anchor is looked for in the statistics as rule 1 left them
+    auto covers = [&](const StatsData &d) { return !((double) d.nnz / (double) nnz < min_coverage); };
+    auto anchor = stats.rbegin();
+    while (anchor != stats.rend() && !covers(anchor->second)) ++anchor;
+    if (anchor != stats.rend()) {
+        const size_t into = anchor->first;
+        move_all(dims_above(stats, into), into);
     }
-    for (size_t d : erase) stats.erase(d);
-    erase.clear();
-
-    // 2. fold larger, low-coverage dimensions into the largest dimension
-    //    that passes the coverage threshold
-    size_t ki, kj;
-    bool oki = last_key(stats, ki);
-    bool okj = last_key(stats, kj);
-    while (oki) {
-        const StatsData &di = stats[ki];
-        if (!((double) di.nnz / (double) nnz < min_coverage)) {
-            while (okj && kj >= ki &&
-                   (double) stats[kj].nnz / (double) nnz < min_coverage) {
-                StatsData dj = stats[kj];
-                split_block_data(fixed_dim, kj, ki, dj, stats);
-                erase.push_back(kj);
-                ++ret;
-                okj = prev_key(stats, kj);
-            }
-        }
-        oki = prev_key(stats, ki);
-    }
-    for (size_t d : erase) stats.erase(d);
-    return ret;
+    return moved;
 }
 
 }  // namespace

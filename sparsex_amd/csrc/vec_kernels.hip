@@ -48,10 +48,8 @@ inline VecGrid grid_for(size_t n, unsigned max_chunk)
 {
     VecGrid g;
     g.chunk = max_chunk;
-    static const long forced = getenv("SPX_VEC_CHUNK") ? atol(getenv("SPX_VEC_CHUNK")) : 0;   // (sweeps: tools/vec_bench.py)
-    if (forced >= 256 && forced % 256 == 0) g.chunk = (unsigned) forced;
-    else
-        while (g.chunk > VEC_CHUNK_MIN && (n / 2 + g.chunk - 1) / g.chunk < VEC_MIN_BLOCKS) g.chunk /= 2;
+    // (chunk sizes and the dot product's workgroup bound were swept in round 5: profiles/r05/vec_bench_raw.txt)
+    while (g.chunk > VEC_CHUNK_MIN && (n / 2 + g.chunk - 1) / g.chunk < VEC_MIN_BLOCKS) g.chunk /= 2;
     g.nchunks = (n / 2 + g.chunk - 1) / g.chunk;
     if (g.nchunks < 1) g.nchunks = 1;
     g.per = (g.nchunks + 7) / 8;
@@ -334,10 +332,7 @@ spx_error_t spx_hip_vec_mul(const spx_hip_vec_t *v1, const spx_hip_vec_t *v2, sp
     if (!result) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid result pointer"); return SPX_FAILURE; }
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     VecGrid g = grid_for(v1->size, VEC_CHUNK_MAX);
-    {
-        static const long cap = getenv("SPX_VEC_DOT_BLOCKS") ? atol(getenv("SPX_VEC_DOT_BLOCKS")) : VEC_DOT_BLOCKS;   // (sweeps)
-        if (cap >= 8 && g.blocks > (unsigned) cap) g.blocks = (unsigned) cap & ~7u;
-    }
+    if (g.blocks > (unsigned) VEC_DOT_BLOCKS) g.blocks = (unsigned) VEC_DOT_BLOCKS & ~7u;
     if (v1->data == v2->data)
         hipLaunchKernelGGL(vec_dot_kernel<true>, dim3(g.blocks), dim3(VEC_BLOCK), 0, stream, v1->data,
                            v2->data, v1->partials, v1->size, g.nchunks, g.per, g.chunk);

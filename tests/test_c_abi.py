@@ -235,7 +235,10 @@ def test_round4_extensions_reject_bad_arguments():
     assert L.spx_hip_mat_info_sized(A.handle, buf, 24) == sx.SPX_SUCCESS
     assert all(b == 0xAB for b in bytes(buf)[24:]) and any(b != 0xAB for b in bytes(buf)[:24])
     assert L.spx_hip_mat_info_sized(A.handle, None, 24) == sx.SPX_FAILURE
-    assert L.spx_hip_abi_version() == 4
+    # (the header's: round 6 added sym_pipeline / init_fold / sym_pipeline_elems at the struct's end: version 5)
+    hdr = open(os.path.join(ROOT, "include", "sparsex_hip.h")).read()
+    assert L.spx_hip_abi_version() == int(re.search(r"#define SPX_HIP_ABI_VERSION (\d+)", hdr).group(1)) == 5
+    assert C.sizeof(sx.api.HipInfo) == 184
     sx.options_reset()
 
 
