@@ -179,6 +179,12 @@ spx_error_t spx_hip_vec_sub(const spx_hip_vec_t *v1, const spx_hip_vec_t *v2,
 spx_error_t spx_hip_vec_mul(const spx_hip_vec_t *v1, const spx_hip_vec_t *v2,
                             spx_value_t *result, void *stream);
 spx_error_t spx_hip_vec_copy(const spx_hip_vec_t *v1, spx_hip_vec_t *v2, void *stream);
+/* Diagnostic: a read stream with the stores of an SpMV in it.  `src` is read in chunks of `chunk_doubles` (a
+ * multiple of 2048), one per workgroup, workgroup b on XCD b % 8 as the SpMV kernels' row-blocks; every workgroup
+ * then stores `write_doubles` doubles to its stretch of `dst` (dst->size >= chunks * write_doubles).  Timed by
+ * the caller; what bench.py prints as roofline.measured_mixed_peak. */
+spx_error_t spx_hip_probe_read_write(const spx_hip_vec_t *src, spx_hip_vec_t *dst, size_t chunk_doubles,
+                                     size_t write_doubles, void *stream);
 /* y <- alpha*A*x + beta*y on device vectors (spx_matvec_kernel, matvec.c:586-620) */
 spx_error_t spx_hip_matvec_kernel_vec(spx_value_t alpha, const spx_matrix_t *A,
                                       const spx_hip_vec_t *x, spx_value_t beta,
@@ -378,8 +384,7 @@ typedef struct {
     int32_t sym_pipeline;    /* symmetric path, spx.gpu.sym_pipeline: 1 = the read-once passes that carry their
                                 geometry in the header run pipelined, x requested with the values
                                 (csx_spmv_sx_kernel)                                                  */
-    int32_t init_fold;       /* spx.gpu.init_fold: 1 = the init pass of a product whose row-blocks add to y runs as the
-                                first workgroups of the launch itself (no kernel in front)                */
+    int32_t reserved0;
     int64_t sym_pipeline_elems; /* ... nonzeros in such passes (of the nonzeros in read-once passes)    */
 } spx_hip_info_t;
 

@@ -52,7 +52,7 @@ class HipInfo(C.Structure):
                 ("quad", C.c_int32), ("col_slices", C.c_int32),
                 ("unit_windows", C.c_int32), ("unit_window_lds", C.c_int32),
                 ("unit_window_elems", C.c_int64), ("unit_window_staged", C.c_int64),
-                ("sym_pipeline", C.c_int32), ("init_fold", C.c_int32), ("sym_pipeline_elems", C.c_int64)]
+                ("sym_pipeline", C.c_int32), ("reserved0", C.c_int32), ("sym_pipeline_elems", C.c_int64)]
 
 
 class SxPlan(C.Structure):
@@ -441,6 +441,13 @@ class DeviceVector:
         self._check(lib().spx_hip_vec_mul(self.handle, other.handle, C.byref(r), stream),
                     "spx_hip_vec_mul")
         return r.value
+
+    def probe_read_write(self, dst, chunk_doubles, write_doubles, stream=0):
+        """Diagnostic (spx_hip_probe_read_write): this vector read in chunks, `write_doubles` stored per chunk to dst."""
+        L = lib()
+        L.spx_hip_probe_read_write.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+        self._check(L.spx_hip_probe_read_write(self.handle, dst.handle, chunk_doubles, write_doubles, C.c_void_p(stream)),
+                    "spx_hip_probe_read_write")
 
     def copy_into(self, dst, stream=0):
         self._check(lib().spx_hip_vec_copy(self.handle, dst.handle, stream), "spx_hip_vec_copy")

@@ -382,6 +382,10 @@ static void keep_index(spx_matrix_t *A, GpuStream &&gs)
 // Automatic row-block size: about five row-blocks per compute unit, so that a
 // small matrix runs as a single round of workgroups; `scale` is what the launch
 // autotuner multiplies it with.
+// row-blocks joined side by side (spx_matrix_t::rb_joined): rows, nonzeros, and the window budget that goes with them
+constexpr size_t JOINED_ROWS = 1024, JOINED_ELEMS = 24576;
+constexpr uint32_t JOINED_XW_BUDGET = 8192;
+
 static size_t auto_target_elems(const spx_matrix_t *A, double scale)
 {
     size_t local = 0;
@@ -403,6 +407,12 @@ static void emit_and_upload(spx_matrix_t *A)
     const bool sym = A->symmetric != 0;
     GpuEmitParams gp = A->emit_params;
     if (A->auto_rb) gp.target_elems = auto_target_elems(A, A->rb_scale);
+    if (A->rb_joined) {
+        // (general path, the launch tuner's choice for a matrix beyond the Infinity Cache: planned row-blocks
+        // joined side by side -- one y tile, one set of unit windows for three times the values)
+        gp.target_elems = JOINED_ELEMS;
+        gp.max_rows = std::max<size_t>(gp.max_rows, JOINED_ROWS);
+    }
     GpuStream gs;
     const unsigned hw = host_threads();
     // (what is to be handed back once the stream is uploaded; run on the spot if the function is left early)
@@ -647,12 +657,11 @@ static void emit_and_upload(spx_matrix_t *A)
     gs.waves = (uint32_t) A->waves;
     gs.band_order = Config::instance().get_bool("spx.gpu.band_order");
     gs.arena = Config::instance().get_bool("spx.gpu.arena");
-    gs.xw_budget = (A->unit_windows != 0 && !A->deterministic && !sym) ? A->xw_budget : 0u;
+    gs.xw_budget = (A->unit_windows != 0 && !A->deterministic && !sym) ? (A->rb_joined ? std::max(A->xw_budget, JOINED_XW_BUDGET) : A->xw_budget) : 0u;
     gs.xw_gap = A->xw_gap;
     gs.xw_on = A->xw_on;
     gs.sx_plan = sym && A->sym_pipeline != 0 && !A->deterministic && A->wave_tiles != 1;
     gs.sx_on = A->sx_on;
-    gs.init_fold = A->init_fold_on;
     gs.sym_atomic = A->sym_atomic && !A->deterministic;
     gs.deterministic = A->deterministic;
     gs.wave_tiles = A->deterministic || A->wave_tiles == 1;
@@ -850,10 +859,34 @@ static void autotune_launch(spx_matrix_t *A, bool tune_waves, bool tune_spill, b
     A->rb_scale = best_scale;
     A->waves = best_waves;
     A->xw_on = best_xw;
+    // A stream far beyond the Infinity Cache whose unit passes read x from LDS: row-blocks joined side by side,
+    // eight wavefronts -- longer-lived workgroups that stage half as much x per value byte (measured -1.7 ... -2 %
+    // on the bench matrix in two calls of round 5, profiles/r05/xw_budget_and_rowblock_size_raw.md; small
+    // matrices lose, so only here).  One more emission; kept only if it is faster.
+    if (A->auto_rb && best_xw && A->wave_tiles != 1 && A->emit_params.max_rows <= SPX_MAX_RB_ROWS &&
+        A->value_bytes > ((size_t) 1 << 30)) {
+        A->rb_joined = true;
+        A->waves = 8;
+        emit_and_upload(A);
+        bool xwj = false;
+        const double tj = time_with(8, xwj);
+        if (xwj && tj < 0.995 * best_t) {
+            best_t = tj;
+            best_waves = 8;
+            log_msg(LOG_INFO, "launch autotune: row-blocks joined side by side (%zu of them)\n", A->n_rowblocks);
+        } else {
+            A->rb_joined = false;
+            A->waves = best_waves;
+            A->xw_on = best_xw;
+            emit_and_upload(A);
+        }
+    }
+    A->waves = best_waves;
+    A->xw_on = best_xw;
     device_set_waves(A->dev, best_waves);
     device_set_xw(A->dev, best_xw);
-    log_msg(LOG_INFO, "launch autotune: %d wavefronts per workgroup, row-block scale %.2f, unit windows %s (%.2f us per SpMV)\n",
-            best_waves, best_scale, best_xw ? "on" : "off", 1e6 * best_t);
+    log_msg(LOG_INFO, "launch autotune: %d wavefronts per workgroup, row-block scale %.2f%s, unit windows %s (%.2f us per SpMV)\n",
+            best_waves, best_scale, A->rb_joined ? ", joined" : "", best_xw ? "on" : "off", 1e6 * best_t);
 }
 
 static spx_matrix_t *do_tune(spx_input_t *in)
@@ -1056,13 +1089,6 @@ static spx_matrix_t *do_tune(spx_input_t *in)
     }
     A->unit_windows = xw_mode == "auto" ? -1 : (xw_mode == "true" ? 1 : 0);
     A->xw_on = xw_mode == "true";                       // (auto: off until measured)
-    const std::string fold_mode = cfg.get_str("spx.gpu.init_fold");
-    if (fold_mode != "auto" && fold_mode != "true" && fold_mode != "false") {
-        log_msg(LOG_ERR, "spx.gpu.init_fold: true, false or auto\n");
-        throw FatalError("bad spx.gpu.init_fold");
-    }
-    A->init_fold = fold_mode == "auto" ? -1 : (fold_mode == "true" ? 1 : 0);
-    A->init_fold_on = fold_mode == "true" && !A->deterministic;      // (auto: off until measured)
     const std::string sx_mode = cfg.get_str("spx.gpu.sym_pipeline");
     if (sx_mode != "auto" && sx_mode != "true" && sx_mode != "false") {
         log_msg(LOG_ERR, "spx.gpu.sym_pipeline: true, false or auto\n");
@@ -1110,31 +1136,6 @@ static spx_matrix_t *do_tune(spx_input_t *in)
         device_set_sx(A->dev, A->sx_on);
         log_msg(LOG_INFO, "read-once pipeline: %s (%.2f us per SpMV with, %.2f without)\n", A->sx_on ? "on" : "off", 1e6 * t1, 1e6 * t0);
     }
-    // the init pass of an adding kernel folded into its launch, against the kernel of its own in front
-    auto tune_init_fold = [&]() {
-        if (!A->dev || A->init_fold != -1 || A->deterministic) return;
-        device_set_init_fold(A->dev, true);
-        if (!device_get_init_fold(A->dev)) {            // (this stream cannot)
-            device_set_init_fold(A->dev, false);
-            A->init_fold_on = false;
-            return;
-        }
-        A->release_wait();
-        const double t_est = device_time_spmv(A->dev, 2, 3);
-        const int N = (int) std::min(100.0, std::max(8.0, 0.02 / std::max(t_est, 1e-7)));
-        auto best_of = [&](bool on) {
-            device_set_init_fold(A->dev, on);
-            double best = device_time_spmv(A->dev, std::max(2, N / 10), N);
-            for (int rep = 0; rep < 3; ++rep) best = std::min(best, device_time_spmv(A->dev, 0, N));
-            return best;
-        };
-        const double t0 = best_of(false), t1 = best_of(true);
-        A->init_fold_on = t1 < 0.985 * t0;
-        device_set_init_fold(A->dev, A->init_fold_on);
-        log_msg(LOG_INFO, "init pass folded into the launch: %s (%.2f us per SpMV with, %.2f without)\n",
-                A->init_fold_on ? "on" : "off", 1e6 * t1, 1e6 * t0);
-    };
-    if (sym) tune_init_fold();
     const double t_auto_end = now_sec();
     // column phases (auto): where the leftovers dominate and x is far larger than the L2 of an
     // XCD, the gathers miss it more often than not (syn-webbase: 1.6 M line fills for 2.5 M
@@ -1176,7 +1177,7 @@ static spx_matrix_t *do_tune(spx_input_t *in)
         }
         log_msg(LOG_INFO, "column slices: %zu on XCD groups %.2f us, plain %.2f us per SpMV\n", K, 1e6 * t_ph, 1e6 * t_plain);
     }
-    if (!sym) tune_init_fold();
+
     if (!cfg.get_bool("spx.rt.keep_encoded")) {
         std::vector<Partition> *old = new std::vector<Partition>();
         old->swap(A->parts);
@@ -1652,7 +1653,6 @@ try {
     h.sym_atomic = gs->sym_atomic ? 1u : 0u;
     // (bit 2: the product runs with the unit windows of x in LDS; bits 8-15 / 16-31: their gap and budget)
     h.pad3 = (gs->deterministic ? 1u : 0u) | (gs->wave_tiles ? 2u : 0u);
-    if (gs->init_fold) h.pad3 |= 16u;                  // (bit 4: the init pass runs folded into the launch)
     if (gs->sx_on) h.pad3 |= 8u;                       // (bit 3: the read-once passes run pipelined)
     if (gs->xw_on) h.pad3 |= 4u | ((gs->xw_gap & 255u) << 8) | (std::min<uint32_t>(gs->xw_budget, 65535u) << 16);
     h.checksum = stream_checksum(*gs);
@@ -1745,7 +1745,6 @@ try {
         gs->wave_tiles = (h.pad3 & 2u) != 0;
         gs->xw_on = (h.pad3 & 4u) != 0;
         gs->sx_on = (h.pad3 & 8u) != 0;
-        gs->init_fold = (h.pad3 & 16u) != 0;
         gs->sx_plan = gs->sx_on;
         gs->xw_gap = gs->xw_on ? ((h.pad3 >> 8) & 255u) : 16u;
         gs->xw_budget = gs->xw_on ? (h.pad3 >> 16) : 0u;
@@ -1788,8 +1787,6 @@ try {
     A->unit_windows = gs->xw_on ? 1 : 0;
     A->sx_on = gs->sx_on;
     A->sym_pipeline = gs->sx_on ? 1 : 0;
-    A->init_fold_on = gs->init_fold;
-    A->init_fold = gs->init_fold ? 1 : 0;
     A->xw_budget = gs->xw_budget;
     A->xw_gap = gs->xw_gap;
     {
@@ -2280,7 +2277,6 @@ try {
         info->sym_pipeline = device_get_sx(A->dev) ? 1 : 0;
         info->sym_pipeline_elems = (int64_t) esx;
     }
-    info->init_fold = A->dev && device_get_init_fold(A->dev) ? 1 : 0;
     info->tune_seconds = A->tune_seconds;
     info->emit_seconds = A->emit_seconds;
     return SPX_SUCCESS;

@@ -67,7 +67,6 @@ void Config::reset_defaults()
     props_["spx.gpu.sym_remine"] = "true";     // symmetric: re-cut the mirrored triangle into row segments
     props_["spx.gpu.sym_pure_passes"] = "true"; // symmetric, read-once segments: long runs fill passes of their own (one descriptor, in the header)
     props_["spx.gpu.sym_pipeline"] = "auto";   // ... and those passes run pipelined, x requested with the values (csx_spmv_sx_kernel): true | false | auto (measured)
-    props_["spx.gpu.init_fold"] = "auto";      // kernels whose row-blocks add to y: the init pass (beta y + alpha diag x) as the first workgroups of the launch itself: true | false | auto (measured)
     props_["spx.gpu.unit_windows"] = "auto";   // general path: the columns of a row-block's unit passes staged in LDS, unit passes pipelined: true | false | auto (measured)
     props_["spx.gpu.unit_window_doubles"] = "3072";  // ... most doubles of x a row-block may stage for them
     props_["spx.gpu.unit_window_gap"] = "16";  // ... column intervals closer than this are staged as one

@@ -91,12 +91,6 @@ bool device_get_xw(const DeviceMatrix *m);
 void device_xw_info(const DeviceMatrix *m, uint64_t &elems_lds, uint64_t &unit_elems, uint64_t &staged_doubles,
                     uint32_t &lds_bytes);
 
-// the init pass (y <- beta y + alpha diag x, or beta y) of a product whose row-blocks add to y, run by the first
-// workgroups of the launch itself instead of a kernel in front (InitFold, spmv_device.hpp)
-bool device_can_fold(const DeviceMatrix *m);
-void device_set_init_fold(DeviceMatrix *m, bool on);
-bool device_get_init_fold(const DeviceMatrix *m);
-
 // the read-once passes of a symmetric stream pipelined (csx_spmv_sx_kernel; sxplan.hpp): available where the
 // stream holds read-once row segments, no tiles, and was uploaded with GpuStream::sx_plan
 bool device_has_sx(const DeviceMatrix *m);

@@ -85,9 +85,6 @@ struct GpuStream {
     // spx.gpu.sym_pipeline (device side only, sxplan.hpp): plan the read-once pipeline at upload, and whether
     // the product starts out using it (the launch tuner measures both)
     bool sx_plan = false, sx_on = false;
-    // spx.gpu.init_fold (device side only): the init pass of the adding kernels runs as the first workgroups of
-    // their launch (the launch tuner measures both)
-    bool init_fold = false;
     // accounting
     size_t nnz_stored = 0;        // nonzeros held in `values` (without padding)
     size_t n_unit_elems = 0;

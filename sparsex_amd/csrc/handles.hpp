@@ -104,8 +104,7 @@ struct matrix {
     int wave_tiles = -1;        // per-wavefront y tiles: 1 / 0, -1 = measured at tune time (spx.gpu.wave_tiles)
     int unit_windows = -1;      // spx.gpu.unit_windows: 1 / 0, -1 = measured at tune time
     bool xw_on = false;         // ... the product runs with the unit windows of x in LDS (csx_spmv_xw_kernel)
-    int init_fold = -1;         // spx.gpu.init_fold: 1 / 0, -1 = measured at tune time
-    bool init_fold_on = false;  // ... the init pass of the adding kernels runs as the first workgroups of their launch
+    bool rb_joined = false;     // general path: row-blocks joined side by side (the launch tuner's choice for streams far beyond the Infinity Cache)
     int sym_pipeline = -1;      // spx.gpu.sym_pipeline: 1 / 0, -1 = measured at tune time
     bool sx_on = false;         // ... the read-once passes run pipelined (csx_spmv_sx_kernel)
     uint32_t xw_budget = 3072, xw_gap = 16;   // spx.gpu.unit_window_doubles, spx.gpu.unit_window_gap

@@ -17,29 +17,6 @@
 
 namespace spx {
 
-// The first step of a product whose row-blocks ADD to y (the symmetric kernels with the atomic hand-over, the
-// column slices of the general path) folded into the launch itself: y <- beta * y + alpha * diag * x on the
-// owned rows, 0 elsewhere (csx_sym_init_kernel's work; `dvalues` null: y <- beta * y, csx_scale_kernel's).  The
-// first `n_blocks` workgroups of the grid do that, a stretch of `chunk` rows each, with write-through stores
-// (the adds that follow are performed at the memory side, not in an XCD's L2), and count themselves in
-// sync[0]; a row-block's workgroup waits for that count before it hands anything to y -- at the END of its
-// passes, so the init work overlaps with the stream instead of standing in front of it as a kernel of its
-// own.  The wait is for workgroups with LOWER block indices only, which the dispatcher starts first and which
-// wait for nobody.  The last row-block workgroup to finish (counted in sync[1]) puts both counters back to 0.
-struct InitFoldRows {             // (in HBM, one per matrix: what does not change from call to call)
-    uint32_t first, last;         // rows [first, last) are initialised ... (row numbers fit 32 bits: spx_index_t is int)
-    uint32_t own_lo, own_hi;      // ... the diagonal term and beta * y only inside [own_lo, own_hi)
-    uint32_t skip[8];             // up to four ranges [skip[2k], skip[2k+1]) left out (SPX_RB_PRIVATE rows store themselves)
-    const double *dvalues;        // diagonal (null: none)
-};
-constexpr uint32_t INIT_FOLD_CHUNK = 2048;      // rows per init workgroup
-struct InitFold {                 // (by value with the launch: kept small, kernel arguments live in scalar registers to the end)
-    uint32_t n_blocks;            // 0: not folded (a kernel of its own has run)
-    uint32_t n_work;              // row-block workgroups of the launch
-    uint32_t *sync;               // two counters in HBM, 0 between launches
-    const InitFoldRows *rows;
-};
-
 struct KernelArgs {
     const SpxRowBlock *rbs;
     const SpxPass *passes;
@@ -59,7 +36,6 @@ struct KernelArgs {
     uint32_t n_rb;
     uint32_t pass_stride;    // pass headers of row-block i start at passes[i * pass_stride]
     const XwEntry *xw_tab;   // unit windows of x (xwindows.hpp): XW_MAX entries per row-block, or null
-    InitFold fold;           // the init pass as the first workgroups of this launch (n_blocks 0: not)
 };
 
 // XCD-aware order of the row-blocks: workgroup b runs on XCD b % 8; XCD x walks the row-blocks
@@ -273,91 +249,6 @@ __device__ __forceinline__ void run_pass(const KernelArgs &a, const SpxRowBlock 
     else run_units<1, 0>(a, rb, {ps}, tile, win, lane);
 }
 
-// ---- the folded init pass (InitFold) -------------------------------------------------------------------
-// the value a row starts from, and whether it is initialised here at all
-__device__ __forceinline__ bool init_fold_value(const InitFoldRows &f, const double *x, const double *y, double alpha,
-                                                double beta, uint32_t i, double &v)
-{
-    bool skip = false;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) skip |= i >= f.skip[2 * k] && i < f.skip[2 * k + 1];
-    v = 0.0;
-    if (!skip && i >= f.own_lo && i < f.own_hi) {
-        if (f.dvalues) v = alpha * f.dvalues[i] * x[i];
-        if (beta != 0.0) v += beta * y[i];
-    }
-    return !skip;
-}
-
-// write-through stores (`sc0 sc1`: the line does not stay dirty in this XCD's L2 under the adds of the others,
-// which are performed at the memory side), 16 bytes per lane: a scalar write-through store is one fabric write
-// of its own and costs 2.7 x the time per byte (MI355X_MICROARCH.md, store flavours)
-__device__ __forceinline__ void store_through(double *p, double v)
-{
-    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void store_through2(double *p, double v0, double v1)
-{
-    typedef unsigned spx_u4_t __attribute__((ext_vector_type(4)));
-    const spx_u4_t w = {(unsigned) __double2loint(v0), (unsigned) __double2hiint(v0),
-                        (unsigned) __double2loint(v1), (unsigned) __double2hiint(v1)};
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(w) : "memory");      // (store-data hazard: the compiler does not see into the asm)
-}
-
-// an init workgroup: its stretch of rows, two per lane from the first 16-byte aligned element of y on
-// (`beta`: the caller's)
-__device__ __forceinline__ void init_fold_block(const InitFold &fold, const double *x, double *y, double alpha, double beta)
-{
-    const InitFoldRows f = *fold.rows;
-    uint32_t lo = f.first + blockIdx.x * INIT_FOLD_CHUNK;
-    const uint32_t hi = lo < f.last && f.last - lo > INIT_FOLD_CHUNK ? lo + INIT_FOLD_CHUNK : f.last;
-    if (lo < f.last && (reinterpret_cast<uintptr_t>(y + lo) & 15u)) {
-        double v;
-        if (threadIdx.x == 0 && init_fold_value(f, x, y, alpha, beta, lo, v)) store_through(y + lo, v);
-        ++lo;
-    }
-    if (lo < f.last) {
-        // (no unrolling: this loop must not set the register count of the kernel it is folded into)
-#pragma clang loop unroll(disable)
-        for (uint32_t i = lo + 2u * threadIdx.x; i < hi; i += 2u * blockDim.x) {
-            double v0, v1 = 0.0;
-            const bool w0 = init_fold_value(f, x, y, alpha, beta, i, v0);
-            const bool w1 = i + 1 < hi && init_fold_value(f, x, y, alpha, beta, i + 1, v1);
-            if (w0 && w1) store_through2(y + i, v0, v1);
-            else if (w0) store_through(y + i, v0);
-            else if (w1) store_through(y + i + 1, v1);
-        }
-    }
-    // all stores of the workgroup acknowledged, then one count
-    __builtin_amdgcn_s_waitcnt(0);          // vmcnt(0) expcnt(0) lgkmcnt(0)
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(&fold.sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// a row-block's workgroup, before it hands anything to y: lane 0 polls the count of init workgroups (they have
-// lower block indices: they were started first and wait for nobody); the caller's barrier follows.  Bounded:
-// a count that never arrives (it cannot, short of a lost launch) ends the wait after a fraction of a second instead of
-// hanging the device.
-__device__ __forceinline__ void init_fold_wait(const InitFold &f)
-{
-    if (f.n_blocks == 0 || threadIdx.x != 0) return;
-    for (uint32_t spin = 0; spin < (1u << 18); ++spin) {
-        if (__hip_atomic_load(&f.sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= f.n_blocks) break;
-        __builtin_amdgcn_s_sleep(8);
-    }
-}
-
-// ... and after its last add went out: the last workgroup of the launch puts the counters back
-__device__ __forceinline__ void init_fold_done(const InitFold &f)
-{
-    if (f.n_blocks == 0 || threadIdx.x != 0) return;
-    const uint32_t before = __hip_atomic_fetch_add(&f.sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (before + 1u == f.n_work) {
-        __hip_atomic_store(&f.sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&f.sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
 // ---- pass headers as six dwords (the pipelined kernels: spmv_xw_kernels.hip, spmv_sx_kernels.hip) ----
 // Read through the constant address space -- the stream is never written while a product runs, and only so
 // does the compiler keep fetching them with scalar loads once a kernel contains LDS DMA -- and as whole
@@ -426,13 +317,13 @@ __device__ __forceinline__ PassWords no_pass(const PassWords &like)
     XcdSplit xcd_split, const double *values_, const SpxUnitDesc *descs_, \
     const uint8_t *cidx_, const uint16_t *segrows_, const double *x_, double *y_,               \
     double *carry_, const double *dvalues_, double *spill_, const uint32_t *slot_col_,         \
-    double alpha_, double beta_, const double *dvalues_priv_, double beta_priv_, InitFold fold_
+    double alpha_, double beta_, const double *dvalues_priv_, double beta_priv_
 #define SPX_KERNEL_ARGS(a)                                                                       \
     KernelArgs a;                                                                                \
     a.rbs = rbs_; a.passes = passes_; a.n_rb = n_rb_; a.pass_stride = pass_stride_;              \
     a.values = values_; a.descs = descs_; a.cidx = cidx_; a.segrows = segrows_; a.x = x_;        \
     a.y = y_; a.carry = carry_; a.dvalues = dvalues_; a.spill = spill_; a.slot_col = slot_col_;  \
     a.alpha = alpha_; a.dvalues_priv = dvalues_priv_; a.beta_priv = beta_priv_;                  \
-    a.beta = beta_; a.xw_tab = nullptr; a.fold = fold_
+    a.beta = beta_; a.xw_tab = nullptr
 
 }  // namespace spx

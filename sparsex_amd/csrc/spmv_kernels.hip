@@ -83,17 +83,10 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &x
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // XCD-aware order: workgroup b runs on XCD b % 8 and takes that XCD's next row-block
     // (the grid is 8 x the longest of the eight lists)
-    uint32_t bid = blockIdx.x;
-    if (ATOMIC && a.fold.n_blocks) {
-        // the init pass folded into this launch (InitFold, spmv_device.hpp): the first workgroups do it
-        if (bid < a.fold.n_blocks) {
-            init_fold_block(a.fold, a.x, a.y, a.alpha, a.beta_priv);
-            return;
-        }
-        bid -= a.fold.n_blocks;           // (a multiple of 8: the XCD of a row-block's workgroup stays what it was)
-    }
-    const uint32_t xcd = bid & 7u;
-    const uint32_t rb_idx = xs.first[xcd] + (bid >> 3);
+    // XCD-aware order: workgroup b runs on XCD b % 8 and takes that XCD's next row-block
+    // (the grid is 8 x the longest of the eight lists)
+    const uint32_t xcd = blockIdx.x & 7u;
+    const uint32_t rb_idx = xs.first[xcd] + (blockIdx.x >> 3);
     if (rb_idx >= xs.first[xcd + 1u]) return;
 
     // the pass headers sit at a fixed stride, so the wave's first two are
@@ -175,7 +168,6 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &x
             p1 = passes[t + 3 * WAVES_PER_BLOCK];
         }
     }
-    if (ATOMIC) init_fold_wait(a.fold);       // (nothing is added to y before the folded init pass has put its start values there)
     __syncthreads();
     if (DET) {
         // the wavefronts' copies, summed in wavefront order into the first one
@@ -223,7 +215,6 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &x
     }
     if (SYM && !ATOMIC)
         for (int i = threadIdx.x; i < n_slots; i += BLOCK_THREADS) a.spill[rb.spill_off + i] = lds[i];
-    if (ATOMIC) init_fold_done(a.fold);
 }
 
 
@@ -490,12 +481,6 @@ struct DeviceMatrix {
     size_t xw_rowblocks = 0;
     // the read-once passes pipelined (sxplan.hpp; symmetric streams of row segments without tiles): a second set
     // of pass headers for csx_spmv_sx_kernel and the number of SX passes at the head of every row-block
-    // the init pass of the adding kernels as the first workgroups of their launch (InitFold, spmv_device.hpp)
-    uint32_t *fold_sync = nullptr;   // its two counters
-    InitFoldRows *fold_rows = nullptr;   // ... and what its workgroups need (as last written: fold_rows_host)
-    InitFoldRows fold_rows_host = {};
-    bool init_fold = false;          // the product runs that way (where the stream allows it: device_can_fold)
-    bool has_direct_adds = false;    // some read-once segment adds straight to y from inside its pass (no slot)
     SpxPass *passes_sx = nullptr;
     uint32_t *sx_tab = nullptr;
     bool sx_on = false;           // the product runs through csx_spmv_sx_kernel
@@ -814,34 +799,6 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
             throw;
         }
     }
-    // the folded init pass: two counters; and whether any read-once segment adds to y from inside its pass
-    try {
-        HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&m->fold_sync), 64));
-        HIP_CHECK(hipMemset(m->fold_sync, 0, 64));
-        HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&m->fold_rows), sizeof(InitFoldRows)));
-        HIP_CHECK(hipMemset(m->fold_rows, 0, sizeof(InitFoldRows)));
-    } catch (...) {
-        device_free(m);
-        throw;
-    }
-    m->init_fold = s.init_fold;
-    if (m->has_symsegs)
-        for (const SpxRowBlock &rb : s.rbs) {
-            for (uint32_t k = 0; k < rb.n_pass && !m->has_direct_adds; ++k) {
-                const SpxPass &ps = s.passes[(size_t) rb.pass_off + k];
-                if (ps.kind != SPX_PASS_SYMSEG) continue;
-                const uint64_t mask = spx_pass_mask(&ps);
-                uint32_t rank = ps.rank0;
-                for (uint32_t l = 0; l < ps.nseg; ++l) {
-                    if (l > 0 && ((mask >> l) & 1ull)) rank += 2;
-                    if (s.descs[(size_t) rb.desc_off + rank + 1u].col0 == SPX_NO_SLOT) {
-                        m->has_direct_adds = true;
-                        break;
-                    }
-                }
-            }
-            if (m->has_direct_adds) break;
-        }
     // the read-once passes pipelined (symmetric streams of row segments, no tiles, stream order, one launch)
     if (symmetric && s.sx_plan && m->has_symsegs && !m->has_symtiles &&
         m->xcd_split.size() == 1 && !s.rbs.empty() && !s.deterministic && !s.wave_tiles) {
@@ -908,8 +865,6 @@ void device_free(DeviceMatrix *m)
         if (m->mirror_col) (void) hipFree(m->mirror_col);
         if (m->mirror_val) (void) hipFree(m->mirror_val);
     }
-    if (m->fold_sync) (void) hipFree(m->fold_sync);
-    if (m->fold_rows) (void) hipFree(m->fold_rows);
     if (m->passes_sx) (void) hipFree(m->passes_sx);
     if (m->sx_tab) (void) hipFree(m->sx_tab);
     if (m->passes_xw) (void) hipFree(m->passes_xw);
@@ -952,36 +907,6 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
     uint32_t blocks = 0;
     XcdSplit xcd_now;
     const size_t n_launch = m->xcd_split.size();
-    a.fold = InitFold{};
-    // the init pass as the first workgroups of the launch, where the launch is one of the adding kernels
-    const bool fold = device_get_init_fold(m) && n_launch == 1 && !abl::sym_no_init;
-    // (what the init workgroups need lies in HBM with the matrix and is rewritten only when it changes: the rows
-    // to initialise, the rows that store themselves, the diagonal)
-    auto fold_rows = [&](size_t first, size_t last, const double *diag, bool skip_private) {
-        InitFoldRows r;
-        std::memset(&r, 0, sizeof(r));
-        r.first = (uint32_t) first; r.last = (uint32_t) last;
-        r.own_lo = (uint32_t) m->own_lo; r.own_hi = (uint32_t) m->own_hi;
-        r.dvalues = diag;
-        if (skip_private) {
-            size_t k = 0;
-            for (const auto &pr : m->private_rows) {
-                r.skip[2 * k] = (uint32_t) pr.first;
-                r.skip[2 * k + 1] = (uint32_t) pr.second;
-                ++k;
-            }
-        }
-        if (std::memcmp(&r, &m->fold_rows_host, sizeof(r)) != 0) {
-            HIP_CHECK(hipMemcpyAsync(m->fold_rows, &r, sizeof(r), hipMemcpyHostToDevice, stream));
-            m->fold_rows_host = r;
-        }
-        a.fold.n_blocks = (uint32_t) (((last - first + INIT_FOLD_CHUNK - 1) / INIT_FOLD_CHUNK + 7) & ~(size_t) 7);
-        a.fold.n_work = m->xcd_split[0].first[8] - m->xcd_split[0].first[0];
-        a.fold.sync = m->fold_sync;
-        a.fold.rows = m->fold_rows;
-        a.beta_priv = beta;               // (the caller's beta: the kernels' own beta is 1 behind an init pass)
-        if (a.fold.n_work == 0 || last <= first) a.fold.n_blocks = 0;
-    };
     if (m->symmetric && !fused) {
         // y <- beta*y + alpha*diag*x on the owned rows, 0 elsewhere; the
         // row-blocks (stored lower triangle and its mirror image) then
@@ -996,14 +921,7 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
                                    dim3(t), 0, stream, d_y, d_x, m->dvalues, lo, hi,
                                    m->own_lo, m->own_hi, alpha, beta);
         };
-        if (fold) {
-            const bool priv = m->use_private && !abl::sym_no_private;
-            fold_rows(first, last, m->dvalues, priv);
-            if (a.fold.n_blocks && priv) a.dvalues_priv = m->dvalues;
-        }
-        if (fold && a.fold.n_blocks) {
-            // (nothing to launch in front)
-        } else if (m->sym_atomic && !m->wave_tiles && m->use_private && !abl::sym_no_private) {
+        if (m->sym_atomic && !m->wave_tiles && m->use_private && !abl::sym_no_private) {
             // (row-blocks that nobody else adds to store their rows themselves: SPX_RB_PRIVATE)
             size_t at = first;
             for (const auto &r : m->private_rows) {
@@ -1030,8 +948,7 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
         // column slices in one launch: beta * y first, every row-block adds on top
         const int t = 256;
         const size_t lo = m->own_lo, hi = m->own_hi;
-        if (fold) fold_rows(lo, hi, nullptr, false);
-        if (hi > lo && !a.fold.n_blocks)
+        if (hi > lo)
             hipLaunchKernelGGL(csx_scale_kernel, dim3((unsigned)((hi - lo + t - 1) / t)), dim3(t), 0, stream, d_y, lo, hi, beta);
         a.beta = beta = 1.0;
     }
@@ -1040,12 +957,12 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
     hipLaunchKernelGGL(KERNEL<W>, dim3(blocks), dim3(64 * W), LDS, stream, a.rbs, a.passes,      \
                        a.n_rb, a.pass_stride, xcd_now, a.values, a.descs, a.cidx,                     \
                        a.segrows, a.x, a.y, a.carry, a.dvalues, a.spill, a.slot_col, a.alpha, a.beta, \
-                       a.dvalues_priv, a.beta_priv, a.fold)
+                       a.dvalues_priv, a.beta_priv)
     bool need_symfix = false;
     for (size_t ph = 0; ph < n_launch; ++ph) {
         // (column phases: slice k > 0 adds to what the slices in front of it stored)
         xcd_now = m->xcd_split[ph];
-        blocks = 8u * m->xcd_longest[ph] + a.fold.n_blocks;
+        blocks = 8u * m->xcd_longest[ph];
         if (ph > 0) a.beta = 1.0;
         if (blocks && m->wave_tiles && !m->accum) {
             // a copy of slots + y tile per wavefront: as many wavefronts as fit the LDS
@@ -1186,7 +1103,7 @@ void device_spmv_chunk(DeviceMatrix *m, size_t k, double alpha, const double *d_
     hipLaunchKernelGGL(KERNEL<W>, dim3(blocks), dim3(64 * W), lds, stream, m->rbs, m->passes, m->n_rb,       \
                        m->pass_stride, xs, m->values, m->descs, m->cidx, m->segrows, d_x, d_y, m->carry,        \
                        (const double *) nullptr, (double *) nullptr, (const uint32_t *) nullptr, alpha, beta,  \
-                       (const double *) nullptr, 0.0, InitFold{})
+                       (const double *) nullptr, 0.0)
 #define SPX_LAUNCH_CHUNK(W)                                                                                  \
     do {                                                                                                     \
         if (m->wave_tiles) SPX_LAUNCH_CHUNK_K(csx_spmv_det_kernel, W);                                       \
@@ -1264,18 +1181,6 @@ int device_get_waves(const DeviceMatrix *m) { return m->waves; }
 
 int device_host_parts(const DeviceMatrix *m) { return m ? m->host_parts : 0; }
 
-// the init pass folded into the launch: streams whose product is ONE launch of an adding kernel -- the symmetric
-// kernels with the atomic hand-over, the column slices of the general path -- and in which nothing is added to
-// y from inside a pass (a read-once segment without a slot does that) or stored to it by a kernel in between
-// (the thin mirror list)
-bool device_can_fold(const DeviceMatrix *m)
-{
-    if (!m->fold_sync || m->wave_tiles || m->xcd_split.size() != 1) return false;
-    if (m->symmetric) return m->sym_atomic && m->has_tiles && !(m->sym_fused && !m->sym_atomic) && !m->n_mirror_rows && !m->has_direct_adds;
-    return m->accum;
-}
-void device_set_init_fold(DeviceMatrix *m, bool on) { m->init_fold = on; }
-bool device_get_init_fold(const DeviceMatrix *m) { return m->init_fold && device_can_fold(m); }
 bool device_has_sx(const DeviceMatrix *m) { return m->passes_sx != nullptr; }
 void device_set_sx(DeviceMatrix *m, bool on) { m->sx_on = on && m->passes_sx && m->sym_atomic && !m->wave_tiles; }
 bool device_get_sx(const DeviceMatrix *m) { return m->sx_on && m->passes_sx && m->sym_atomic && !m->wave_tiles; }
@@ -1559,7 +1464,6 @@ void device_download(const DeviceMatrix *m, GpuStream &s)
     s.deterministic = m->deterministic;
     s.wave_tiles = m->wave_tiles;
     s.xw_on = device_get_xw(m);
-    s.init_fold = m->init_fold;
     s.sx_plan = m->passes_sx != nullptr;
     s.sx_on = device_get_sx(m);
     s.xw_budget = m->xw_budget;

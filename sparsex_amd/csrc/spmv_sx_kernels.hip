@@ -190,17 +190,8 @@ __device__ __forceinline__ void spmv_body_sx(const KernelArgs &a, const XcdSplit
     constexpr int BLOCK_THREADS = 64 * WAVES;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint32_t bid = blockIdx.x;
-    if (a.fold.n_blocks) {
-        // the init pass folded into this launch (InitFold, spmv_device.hpp): the first workgroups do it
-        if (bid < a.fold.n_blocks) {
-            init_fold_block(a.fold, a.x, a.y, a.alpha, a.beta_priv);
-            return;
-        }
-        bid -= a.fold.n_blocks;
-    }
-    const uint32_t xcd = bid & 7u;
-    const uint32_t rb_idx = xs.first[xcd] + (bid >> 3);
+    const uint32_t xcd = blockIdx.x & 7u;
+    const uint32_t rb_idx = xs.first[xcd] + (blockIdx.x >> 3);
     if (rb_idx >= xs.first[xcd + 1u]) return;
 
     // first round trip: the row-block header, the number of its SX passes, the wavefront's first two pass
@@ -275,7 +266,6 @@ __device__ __forceinline__ void spmv_body_sx(const KernelArgs &a, const XcdSplit
         }
         t += 2 * WAVES;
     }
-    init_fold_wait(a.fold);                   // (nothing is added to y before the folded init pass has put its start values there)
     __syncthreads();
 
     // ---------------- hand-over (as csx_spmv_symseg_notile_kernel) ---------------------------------------
@@ -299,11 +289,10 @@ __device__ __forceinline__ void spmv_body_sx(const KernelArgs &a, const XcdSplit
     if (!abl::sym_no_handover)
         for (int i = threadIdx.x; i < n_slots; i += BLOCK_THREADS)
             atomicAdd(&a.y[(size_t) gcol_lds[i >> 3] + (i & 7)], a.alpha * lds[i]);
-    init_fold_done(a.fold);
 }
 
 template <int WAVES, int B>
-__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(6, 8)))
+__global__ __launch_bounds__(64 * WAVES)
 void csx_spmv_sx_kernel(SPX_KERNEL_PARAMS, const uint32_t *sx_tab_)
 {
     SPX_KERNEL_ARGS(a);
@@ -325,7 +314,7 @@ void launch_spmv_sx(int waves, unsigned blocks, size_t lds_bytes, void *stream_,
     hipLaunchKernelGGL((csx_spmv_sx_kernel<W, SX_PASSES_PER_ROUND>), dim3(blocks), dim3(64 * W), lds_bytes, stream, a.rbs,  \
                        a.passes, a.n_rb, a.pass_stride, xs, a.values, a.descs, a.cidx, a.segrows,   \
                        a.x, a.y, a.carry, a.dvalues, a.spill, a.slot_col, a.alpha, a.beta,           \
-                       a.dvalues_priv, a.beta_priv, a.fold, sx_tab)
+                       a.dvalues_priv, a.beta_priv, sx_tab)
     if (waves == 2) SPX_LAUNCH_SX(2);
     else if (waves == 8) SPX_LAUNCH_SX(8);
     else SPX_LAUNCH_SX(4);

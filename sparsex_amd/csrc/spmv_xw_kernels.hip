@@ -346,7 +346,7 @@ void launch_spmv_xw(int waves, unsigned blocks, size_t lds_bytes, void *stream_,
     hipLaunchKernelGGL(csx_spmv_xw_kernel<W>, dim3(blocks), dim3(64 * W), lds_bytes, stream, a.rbs,  \
                        a.passes, a.n_rb, a.pass_stride, xs, a.values, a.descs, a.cidx, a.segrows,   \
                        a.x, a.y, a.carry, a.dvalues, a.spill, a.slot_col, a.alpha, a.beta,           \
-                       a.dvalues_priv, a.beta_priv, a.fold, a.xw_tab)
+                       a.dvalues_priv, a.beta_priv, a.xw_tab)
     if (waves == 2) SPX_LAUNCH_XW(2);
     else if (waves == 8) SPX_LAUNCH_XW(8);
     else SPX_LAUNCH_XW(4);

@@ -347,6 +347,50 @@ spx_error_t spx_hip_vec_mul(const spx_hip_vec_t *v1, const spx_hip_vec_t *v2, sp
     return SPX_SUCCESS;
 }
 
+// ---- the roof of a read stream with a few stores in it (diagnostic) -------------------------------------
+// What the SpMV kernels ask of the memory system is not a pure read: every workgroup ends with the stores of its
+// rows of y.  This probe has their shape -- workgroup b on XCD b % 8, a contiguous chunk of `src` read per
+// workgroup with 16-byte loads, then `wr` doubles stored to the workgroup's stretch of `dst` -- so that a
+// product's achieved rate can be set against a roof with the SAME read / write mix, measured on the same box
+// (bench.py: roofline.measured_mixed_peak; tools/micro/stream_pattern.hip mode 6 is the stand-alone form).
+__global__ __launch_bounds__(256) void vec_probe_rw_kernel(const double2 *src, size_t n_chunks, size_t per, unsigned chunk16,
+                                                           double *dst, unsigned wr)
+{
+    const size_t slot = blockIdx.x >> 3;
+    const size_t chunk = (size_t) (blockIdx.x & 7u) * per + slot;
+    if (slot >= per || chunk >= n_chunks) return;
+    const double2 *q = src + chunk * chunk16;
+    double acc = 0.0;
+    for (unsigned i = threadIdx.x; i + 3u * 256u < chunk16; i += 4u * 256u) {
+        const double2 a = q[i], b = q[i + 256u], c = q[i + 512u], d = q[i + 768u];
+        acc += (a.x + a.y) + (b.x + b.y) + (c.x + c.y) + (d.x + d.y);
+    }
+    __syncthreads();
+    double *out = dst + chunk * wr;
+    for (unsigned i = threadIdx.x; i < wr; i += 256u) out[i] = acc;
+}
+
+spx_error_t spx_hip_probe_read_write(const spx_hip_vec_t *src, spx_hip_vec_t *dst, size_t chunk_doubles,
+                                     size_t write_doubles, void *stream_)
+{
+    if (!src || !dst) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid device vector"); return SPX_FAILURE; }
+    if (chunk_doubles < 2048 || chunk_doubles % 2048 || write_doubles > chunk_doubles) {
+        SETERROR_1(SPX_ERR_ARG_INVALID, "chunk: a multiple of 2048 doubles; no more doubles written than read");
+        return SPX_FAILURE;
+    }
+    const size_t n_chunks = src->size / chunk_doubles;
+    if (n_chunks == 0 || dst->size < n_chunks * write_doubles) {
+        SETERROR_1(SPX_ERR_ARG_INVALID, "vectors too short for one chunk / for the stores of every chunk");
+        return SPX_FAILURE;
+    }
+    const size_t per = (n_chunks + 7) / 8;
+    hipLaunchKernelGGL(vec_probe_rw_kernel, dim3((unsigned) (per * 8)), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                       reinterpret_cast<const double2 *>(src->data), n_chunks, per, (unsigned) (chunk_doubles / 2), dst->data,
+                       (unsigned) write_doubles);
+    VEC_TRY(hipGetLastError());
+    return SPX_SUCCESS;
+}
+
 spx_error_t spx_hip_matvec_kernel_vec(spx_value_t alpha, const spx_matrix_t *A,
                                       const spx_hip_vec_t *x, spx_value_t beta,
                                       spx_hip_vec_t *y, void *stream)

@@ -39,7 +39,7 @@ for w, key in KEYS.items():
         cfg = {"cant": "syn-cant", "nd24k_sym": "syn-nd24k --symmetric", "webbase": "syn-webbase",
                "nlpkkt_sym": "syn-nlpkkt --symmetric (the bench matrix)"}.get(w)
         name = plain["configs"][cfg]["roofline"]["kernel"] if cfg else plain["roofline"]["kernel"]
-        want = re.search(r"csx_spmv[a-z_]*kernel<\d>", name).group(0)
+        want = re.search(r"csx_spmv[a-z_]*kernel<\d+(?:, \d+)*>", name).group(0)
     except Exception:
         pass
     # per counter: {kernel (as the profiler names it): (launches, KiB per launch)}; ONE kernel is chosen for both
