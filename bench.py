@@ -647,8 +647,10 @@ def host_api_rate(A, xh, n, nnz, calls=20):
     sec = (time.perf_counter() - t0) / calls
     out = {"entry": "spx_matvec_mult on views of user buffers (SPX_VEC_AS_IS: x up, kernel, y down; PCIe inclusive)",
            "us_per_call": round(sec * 1e6, 1), "gflops": round(2.0 * nnz / sec / 1e9, 1)}
-    # ... and what an unchanged reference client gets (its vectors come from spx_vec_create_random / spx_vec_create:
-    # page-locked, x's HBM copy reused between calls -- spx.vec.device, on by default): only y travels
+    # ... and what a reference client gets whose vectors come from spx_vec_create_random / spx_vec_create (page-locked
+    # library memory): by default x travels with every call like any other vector; with spx.vec.device=true (opt-in:
+    # the client promises to change x through spx_vec_* only, or to call spx_hip_vec_touch) x's HBM copy is reused
+    # between calls and only y travels
     import ctypes as C
     import sparsex_amd as sx
     from sparsex_amd.api import VectorStruct
@@ -660,20 +662,24 @@ def host_api_rate(A, xh, n, nnz, calls=20):
     L.spx_mat_get_partition.restype = C.c_void_p
     L.spx_partition_destroy.argtypes = [C.c_void_p]
     part = C.c_void_p(L.spx_mat_get_partition(C.c_void_p(A.handle)))
-    xv, yv = L.spx_vec_create_random(n, part), L.spx_vec_create(n, part)
-    try:
-        for _ in range(3):
-            L.spx_matvec_mult(C.c_double(ALPHA), C.c_void_p(A.handle), xv, yv)
-        t0 = time.perf_counter()
-        for _ in range(calls):
-            L.spx_matvec_mult(C.c_double(ALPHA), C.c_void_p(A.handle), xv, yv)
-        sec2 = (time.perf_counter() - t0) / calls
-        out["library_vectors"] = {"entry": "spx_matvec_mult on vectors from spx_vec_create* (x resident in HBM between calls, y down)",
-                                  "us_per_call": round(sec2 * 1e6, 1), "gflops": round(2.0 * nnz / sec2 / 1e9, 1)}
-    finally:
-        L.spx_vec_destroy(xv)
-        L.spx_vec_destroy(yv)
-        L.spx_partition_destroy(part)
+    for key, resident, what in (("library_vectors", "false", "default options: x up with every call, y down"),
+                                ("library_vectors_resident", "true", "spx.vec.device=true: x resident in HBM between calls, y down")):
+        sx.option_set("spx.vec.device", resident)           # (read when a vector is created)
+        xv, yv = L.spx_vec_create_random(n, part), L.spx_vec_create(n, part)
+        try:
+            for _ in range(3):
+                L.spx_matvec_mult(C.c_double(ALPHA), C.c_void_p(A.handle), xv, yv)
+            t0 = time.perf_counter()
+            for _ in range(calls):
+                L.spx_matvec_mult(C.c_double(ALPHA), C.c_void_p(A.handle), xv, yv)
+            sec2 = (time.perf_counter() - t0) / calls
+            out[key] = {"entry": "spx_matvec_mult on vectors from spx_vec_create* (%s)" % what,
+                        "us_per_call": round(sec2 * 1e6, 1), "gflops": round(2.0 * nnz / sec2 / 1e9, 1)}
+        finally:
+            L.spx_vec_destroy(xv)
+            L.spx_vec_destroy(yv)
+    sx.option_set("spx.vec.device", "false")
+    L.spx_partition_destroy(part)
     return out
 
 
@@ -1410,6 +1416,11 @@ def main():
                "ms_per_step": res.pop("ms_per_step"), "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": "f64"}
         out.update(res)
+        if world > 1:
+            # what the library's communicator itself counts (ncclCommCount): N on an N-GPU run over RCCL; null where the
+            # exchange went through another transport (gloo test path, the torch.distributed stand-by)
+            tr = ctx["transport"]
+            out["ranks_seen_by_rccl"] = tr.rccl_ranks() if hasattr(tr, "rccl_ranks") else None
     if world > 1 and not args.symmetric and not args.no_configs and args.workload in SYMMETRIC_WORKLOADS and not args.mtx:
         # the same matrix through the symmetric path in the same invocation: here the conflict rows
         # really travel (RCCL point-to-point) before the hand-round

@@ -619,6 +619,13 @@ class RcclTransport:
             raise SpxError("spx_hip_transport_rccl failed (see stderr)")
         self.rank, self.world = rank, world
 
+    def rccl_ranks(self):
+        """Ranks the RCCL communicator holds (ncclCommCount), -1 where librccl does not say."""
+        L = lib()
+        L.spx_hip_transport_rccl_ranks.argtypes = [C.POINTER(TransportStruct)]
+        L.spx_hip_transport_rccl_ranks.restype = C.c_int
+        return int(L.spx_hip_transport_rccl_ranks(self.ptr))
+
     def destroy(self):
         if self.ptr:
             lib().spx_hip_transport_destroy(self.ptr)

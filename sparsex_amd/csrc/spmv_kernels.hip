@@ -761,11 +761,24 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
     // is, uploaded next to it; whether the product uses them is the caller's (the launch tuner's) choice
     m->xw_budget = s.xw_budget;
     m->xw_gap = s.xw_gap;
-    if (s.xw_budget && !symmetric && !m->accum && m->launch_order.empty() && m->xcd_split.size() == 1 &&
-        !s.rbs.empty()) {
+    if (s.xw_budget && !symmetric && !m->accum && m->xcd_split.size() == 1 && !s.rbs.empty()) {
         try {
             XwPlan plan;
             plan_unit_xwindows(s, ncols, s.xw_budget, s.xw_gap, plan, host_threads());
+            if (!m->launch_order.empty()) {
+                // (row-blocks and their headers went up in launch order: the window table and the headers follow;
+                // the descriptors stay where they are -- a row-block finds them through its desc_off)
+                const size_t stride = s.pass_stride;
+                std::vector<SpxPass> po(plan.passes.size());
+                std::vector<XwEntry> to(plan.tab.size());
+                for (size_t i = 0; i < m->launch_order.size(); ++i) {
+                    const size_t from = m->launch_order[i];
+                    std::copy(plan.passes.begin() + from * stride, plan.passes.begin() + (from + 1) * stride, po.begin() + i * stride);
+                    std::copy(plan.tab.begin() + from * XW_TAB, plan.tab.begin() + (from + 1) * XW_TAB, to.begin() + i * XW_TAB);
+                }
+                plan.passes.swap(po);
+                plan.tab.swap(to);
+            }
             if (plan.n_rb_windows && (size_t) plan.lds_doubles * sizeof(double) > 160u * 1024u) {
                 // (a budget and row-blocks so large that a workgroup would not fit a CU's LDS: the plain kernel runs)
                 log_msg(LOG_INFO, "unit windows: %u KB of LDS per workgroup do not fit, not used\n",

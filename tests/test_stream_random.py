@@ -86,6 +86,12 @@ def random_sym_options(seed, o):
         o["spx.gpu.sym_segments"] = "true"
         o["spx.gpu.sym_wide_rows"] = str(rng.choice([512, 700, 1024, 2048]))
         o["spx.gpu.sym_segment_min"] = str(rng.choice([2, 3, 4]))
+    # round 6 (a generator of its own, so that the draws above stay what they were): the read-once pipeline and
+    # the passes of their own that feed it
+    r6 = np.random.RandomState(600000 + seed)
+    o["spx.gpu.sym_pipeline"] = str(r6.choice(["true", "auto", "false"]))
+    if r6.rand() < 0.3:
+        o["spx.gpu.sym_pure_passes"] = "false"
     return o
 
 

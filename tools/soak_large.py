@@ -100,6 +100,11 @@ def options(seed, symmetric):
     o["spx.gpu.unit_windows"] = str(r5.choice(["true", "true", "auto", "false"]))
     o["spx.gpu.unit_window_doubles"] = str(r5.choice([256, 1024, 3072, 8192, 16384]))
     o["spx.gpu.unit_window_gap"] = str(r5.choice([0, 16, 100, 255]))
+    # round 6: the read-once pipeline and the passes of their own (again a generator of its own)
+    r6 = np.random.RandomState(9600 + seed)
+    if symmetric:
+        o["spx.gpu.sym_pipeline"] = str(r6.choice(["true", "true", "auto", "false"]))
+        o["spx.gpu.sym_pure_passes"] = str(r6.choice(["true", "true", "false"]))
     return o
 
 
