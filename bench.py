@@ -1260,7 +1260,7 @@ def run_path(ctx, args, symmetric):
         out["roofline"]["measured_mixed_peak"] = round(mixed, 1)
         out["roofline"]["mixed_peak_write_share"] = round(share, 4)
         out["roofline"]["frac_of_measured_mixed_peak"] = round(achieved / mixed, 4)
-    if world == 1 and rank == 0:
+    if world == 1 and rank == 0 and not args.no_host_api:
         out["host_api"] = host_api_rate(A, xh, n, wl.nnz)
     if ablation:
         out["INVALID_ablation_build"] = os.environ.get("SPX_LIB_PATH", "")
@@ -1327,6 +1327,9 @@ def main():
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="time the CPU baseline on the whole bench matrix instead of its edge-%d sample (a minute or two "
                          "more of host time and ~60 GB of host memory at edge 240)" % SAMPLE_EDGE)
+    ap.add_argument("--no-host-api", action="store_true",
+                    help="skip the host-vector entry points (host_api): under a profiler their part-by-part launches of the "
+                         "same kernel would be averaged into the bench loop's")
     ap.add_argument("--no-configs", action="store_true",
                     help="N = 1: skip the other BASELINE configurations (cant, nd24k symmetric, webbase); "
                          "N > 1: skip the second run on the symmetric path")

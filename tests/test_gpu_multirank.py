@@ -202,3 +202,32 @@ def test_rccl_transport_single_rank():
         check_y(csr, xh, y.cpu().numpy(), 0.5)
         A.destroy()
     t.destroy()
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2` WITHOUT a launcher -- the way the driver starts the one-GPU run -- starts the two
+    ranks itself (a child torch.distributed.run, before the parent touches a GPU), passes rank 0's line through and
+    leaves with the child's code (tests/test_bench_launch.py holds the mechanics on the CPU).  Here the ranks do the
+    real step on the one GPU of this box over gloo; with RCCL the same line would carry ranks_seen_by_rccl = 2."""
+    env = dict(os.environ)
+    env.update({"SPX_BENCH_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--host-threads", "2", "--edge", "28"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    check_line(out, 2, "nlpkkt")
+    assert "ranks_seen_by_rccl" in out and out["ranks_seen_by_rccl"] is None      # (gloo carried the exchange)
+
+
+@pytest.mark.gpu
+def test_rccl_transport_counts_its_ranks():
+    import sparsex_amd as sx
+    t = sx.RcclTransport(sx.rccl_unique_id(), 0, 1)
+    assert t.rccl_ranks() == 1
+    t.destroy()

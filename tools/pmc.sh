@@ -7,7 +7,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc $CTRS --output-format csv -d "$OUT/pmc" -o run -- \
-    python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-configs $* > "$OUT/bench_pmc.log" 2>&1
+    python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-configs --no-host-api $* > "$OUT/bench_pmc.log" 2>&1
 python3 - "$OUT/pmc" <<'PY' | tee -a "$OUT/pmc_summary.txt"
 import csv, glob, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))

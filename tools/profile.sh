@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 100 --warmup 10 --no-cpu-baseline --no-configs $*"
+ARGS="--steps 100 --warmup 10 --no-cpu-baseline --no-configs --no-host-api $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o run -- \
     python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_trace.log" 2>&1
 grep '^{"metric"' "$OUT/bench_trace.log" | tail -1 > "$OUT/bench_line.json"
@@ -18,7 +18,7 @@ rm -rf "$OUT/trace"/*/*kernel_trace.csv "$OUT/trace"/*kernel_trace.csv 2>/dev/nu
 # counters: one pass each (FETCH_SIZE and WRITE_SIZE do not fit one pass)
 for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$C" -o run -- \
-        python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-configs $* > "$OUT/bench_pmc_$C.log" 2>&1
+        python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-configs --no-host-api $* > "$OUT/bench_pmc_$C.log" 2>&1
     python3 - "$OUT/pmc_$C" "$C" > "$OUT/pmc_$C.txt" <<'PY'
 import csv, glob, sys, collections
 d, name = sys.argv[1], sys.argv[2]

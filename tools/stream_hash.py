@@ -11,6 +11,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--edge", type=int, default=40)
     ap.add_argument("--threads", type=int, default=4)
+    ap.add_argument("--opt", action="append", default=[], help="extra option=value for every tune (ignored by a library that does not know it)")
     args = ap.parse_args()
     import sparsex_amd as sx
     from sparsex_amd import synth
@@ -28,6 +29,14 @@ def main():
                 opts = {"spx.rt.nr_threads": args.threads, "spx.rt.host_only": "true",
                         "spx.matrix.symmetric": "true" if sym else "false"}
                 opts.update(extra)
+                for kv in args.opt:
+                    k, v = kv.split("=", 1)
+                    try:
+                        sx.options_reset()
+                        sx.option_set(k, v)
+                        opts[k] = v
+                    except Exception:
+                        pass
                 t0 = time.time()
                 A = bench.tune(csr, opts)
                 dt = time.time() - t0
