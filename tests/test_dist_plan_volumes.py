@@ -1,4 +1,4 @@
-"""What a multi-GPU step moves, from the plan objects alone (tools/dist_volumes.py prints the
+"""What a multi-GPU step moves, from the plan objects alone (HISTORY.md section 8; tools/dist_volumes.py prints the
 same figures at bench sizes): 2, 4 and 8 ranks of the KKT stand-in, renumbered for the ranks (rcm_owner), every rank
 tuning only its rows, the exchange plans built for real -- the ranks are threads of this process joined by an
 in-memory transport, so the test needs neither a GPU nor a process group.  A change of the plan that makes the

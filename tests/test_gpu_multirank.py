@@ -134,7 +134,7 @@ def test_contract_matrix_on_eight_ranks(symmetric):
     tunes only its slice (96 M nonzeros, 0.77 GB of values), gloo carries the exchange.  bench.py
     gates every rank against the CSR product of its own rows for SPX_DIST_OWNED_ROWS, then with
     SPX_DIST_GATHER_Y (all ranks must hold the same y), then with SPX_DIST_HALO_X (own rows again,
-    and the halo entries against the gathered y).  The byte counts are those of DESIGN.md section 8."""
+    and the halo entries against the gathered y).  The byte counts are those of HISTORY.md section 8."""
     world, N = 8, 240
     n, P = 2 * N ** 3 + 6 * N ** 2, N ** 3 + 6 * N ** 2
     out = run_bench(world, ["--edge", str(N), "--no-configs", "--dist-reorder", "none"] + (["--symmetric"] if symmetric else []),
