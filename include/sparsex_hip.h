@@ -68,6 +68,16 @@
  *                           tile and common slots, so that a column several of them reach is
  *                           handed to y once (default 1024, at most 2048; measured on syn-nlpkkt,
  *                           734 M nonzeros: 512 0.842 ms, 1024 0.826 ms, 2048 0.92 ms)
+ *   spx.gpu.sym_pipeline    symmetric path, streams of read-once segments: "auto" (default: measured at tune time) |
+ *                           "true" | "false" -- passes whose lanes all belong to one unit carry their geometry in a
+ *                           device-side copy of their header, so that values and x are requested in one round trip
+ *                           and the passes run as a two-stage pipeline (csx_spmv_sx_kernel; the bench matrix 1.00 ->
+ *                           0.91 ms, edges 100-180 10-17 % faster: profiles/r06/NOTES.md)
+ *   spx.gpu.sym_pure_passes "true" (default): a long run of equal read-once segments (40 and more) fills passes of its
+ *                           own, i.e. passes with ONE descriptor -- what the pipeline above feeds on; "false": passes
+ *                           are filled regardless of units, as before round 6
+ *   spx.gpu.sym_segment_max widest segment a longer run of columns is cut into (default 8; with 4 every segment could
+ *                           ride the pipeline, measured slower: syn-kkt2f 122 -> 135 us, profiles/r06/segment_max_raw.md)
  *   spx.gpu.arena           "true": every array of a tuned matrix in ONE HBM allocation (2 MB-aligned pieces)
  *                           instead of one allocation each (default; the arena was built to test whether
  *                           placement explains the run-to-run spread: it does not, profiles/r04/spread.md)

@@ -540,7 +540,7 @@ static void emit_and_upload(spx_matrix_t *A)
             const bool want_segs = gp.sym_segments != 0 && !A->deterministic && A->spill_mode != 0 && !A->wave_tiles &&
                                    (gp.sym_segments == 1 || n_lower >= min_lower);
             build_sym_ranges(A->parts, ranges, gp.max_rows >= 8, fulls, tiles, hw,
-                             gs.sym_fused ? nullptr : &thin, want_segs ? &segs : nullptr, gp.sym_min_run);
+                             gs.sym_fused ? nullptr : &thin, want_segs ? &segs : nullptr, gp.sym_min_run, gp.sym_max_run);
             for (const auto &v : segs)
                 for (const SymSeg &sg : v) n_seg_elems += sg.width;
             // (auto: worth it where most of the stored triangle lies in such runs and the
@@ -1047,6 +1047,12 @@ static spx_matrix_t *do_tune(spx_input_t *in)
             throw FatalError("bad spx.gpu.sym_segment_min");
         }
         A->emit_params.sym_min_run = (size_t) mr;
+        const long xr = cfg.get_long("spx.gpu.sym_segment_max");
+        if (xr < mr || xr > SPX_MAX_SEG_WIDTH) {
+            log_msg(LOG_ERR, "spx.gpu.sym_segment_max: spx.gpu.sym_segment_min .. %d\n", SPX_MAX_SEG_WIDTH);
+            throw FatalError("bad spx.gpu.sym_segment_max");
+        }
+        A->emit_params.sym_max_run = (size_t) xr;
     }
     A->emit_params.stack_segments = cfg.get_bool("spx.gpu.stack_segments");
     {

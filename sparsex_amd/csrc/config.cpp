@@ -62,6 +62,7 @@ void Config::reset_defaults()
     props_["spx.gpu.x_window"] = "true";       // leftovers with nearby columns gather from an LDS window of x
     props_["spx.gpu.sym_segments"] = "auto";   // symmetric: row segments of the lower triangle read once (true | false | auto)
     props_["spx.gpu.sym_segment_min"] = "2";   // shortest run of consecutive columns that is read once
+    props_["spx.gpu.sym_segment_max"] = "8";   // ... and the widest segment a longer run is cut into (4: every segment can ride the read-once pipeline)
     props_["spx.gpu.sym_wide_rows"] = "1024";  // rows of a row-block with read-once segments (several planned row-blocks side by side)
     props_["spx.gpu.sym_spill"] = "auto";      // symmetric tiles' transposed sums: lists | atomic | auto (measured)
     props_["spx.gpu.sym_remine"] = "true";     // symmetric: re-cut the mirrored triangle into row segments

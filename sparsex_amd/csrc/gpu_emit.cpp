@@ -1158,7 +1158,7 @@ void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<Sy
                       bool want_tiles, std::vector<Partition> &outs,
                       std::vector<std::vector<SymTile>> &tiles, unsigned nthreads,
                       std::vector<MirrorPoint> *sparse_mirror,
-                      std::vector<SymSegVec> *symsegs, size_t min_run)
+                      std::vector<SymSegVec> *symsegs, size_t min_run, size_t max_run)
 {
     const size_t P = lowers.size(), R = ranges.size();
     auto clock = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1273,14 +1273,16 @@ void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<Sy
             for (size_t a = 0; a < pts.size();) {
                 size_t b = a + 1;
                 while (b < pts.size() && pts[b].row == pts[a].row && pts[b].col == pts[b - 1].col + 1) ++b;
-                // a run of b - a consecutive columns: pieces of eight, the remainder if >= min_run
+                // a run of b - a consecutive columns: pieces of WMAX (eight, or spx.gpu.sym_segment_max), the
+                // remainder if >= min_run
                 // (not on rows so long that they are chunked over several row-blocks)
                 size_t k = a;
+                const size_t WMAX = std::min<size_t>(std::max<size_t>(max_run, min_run), SPX_MAX_SEG_WIDTH);
                 const bool take = !long_row[(size_t) pts[a].row - 1];
-                for (; take && b - k >= min_run; k += std::min<size_t>(8, b - k)) {
-                    const size_t w = std::min<size_t>(8, b - k);
-                    if (b - k - w > 0 && b - k - w < min_run && w == 8 && b - k < 8 + min_run) {
-                        // (do not leave a tail shorter than that: split 9 and 10 as 5+4 / 5+5)
+                for (; take && b - k >= min_run; k += std::min<size_t>(WMAX, b - k)) {
+                    const size_t w = std::min<size_t>(WMAX, b - k);
+                    if (b - k - w > 0 && b - k - w < min_run && w == WMAX && b - k < WMAX + min_run) {
+                        // (do not leave a tail shorter than that: with pieces of eight, 9 and 10 are split 5+4 / 5+5)
                         const size_t w1 = (b - k + 1) / 2;
                         SymSeg sg;
                         sg.row = pts[k].row - 1; sg.col = pts[k].col - 1; sg.width = (uint8_t) w1;

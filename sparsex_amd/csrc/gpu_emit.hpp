@@ -110,6 +110,7 @@ struct GpuEmitParams {
     size_t target_elems = 2048;   // spx.gpu.rowblock_elems
     size_t max_rows = SPX_MAX_RB_ROWS;   // spx.gpu.rowblock_rows (<= SPX_MAX_RB_ROWS)
     size_t sym_min_run = 2;              // spx.gpu.sym_segment_min: shortest run of columns read once
+    size_t sym_max_run = SPX_MAX_SEG_WIDTH;   // spx.gpu.sym_segment_max: widest read-once segment a run is cut into
     size_t wide_rows = SPX_MAX_RB_ROWS;  // spx.gpu.sym_wide_rows: rows of a row-block made of several
                                          // planned ones (read-once segments only; <= SPX_MAX_WIDE_ROWS)
     bool skip_empty = false;      // accumulate mode: rows without nonzeros need no write
@@ -181,7 +182,7 @@ void build_sym_ranges(const std::vector<Partition> &lowers, const std::vector<Sy
                       bool want_tiles, std::vector<Partition> &outs,
                       std::vector<std::vector<SymTile>> &tiles, unsigned nthreads,
                       std::vector<MirrorPoint> *sparse_mirror = nullptr,
-                      std::vector<SymSegVec> *symsegs = nullptr, size_t min_run = 2);
+                      std::vector<SymSegVec> *symsegs = nullptr, size_t min_run = 2, size_t max_run = SPX_MAX_SEG_WIDTH);
 
 // coordinates (1-based, horizontal order) of element k of a unit
 inline void unit_elem_coords(const Elem &u, size_t k, idx_t &r, idx_t &c)

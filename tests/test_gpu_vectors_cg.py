@@ -10,6 +10,7 @@ import scipy.sparse.linalg as spla
 import sparsex_amd as sx
 from sparsex_amd import synth
 from helpers import tune
+import torch
 
 pytestmark = pytest.mark.gpu
 
@@ -69,3 +70,27 @@ def test_cg_on_device_matches_host_solver():
     assert info == 0
     assert np.allclose(xg, xh, rtol=1e-8, atol=1e-10)
     assert np.allclose(xg, xs, rtol=1e-8, atol=1e-10)
+
+
+def test_read_write_probe_reads_every_chunk_and_stores_its_share():
+    """spx_hip_probe_read_write (the roof bench.py prints as roofline.measured_mixed_peak): every workgroup reads its
+    chunk of src and stores the chunk's sum to its stretch of dst; bad shapes are refused."""
+    n_chunks, chunk, wr = 37, 4096, 144
+    h = np.arange(n_chunks * chunk, dtype=np.float64) % 7.0
+    src = sx.DeviceVector(host=h)
+    dst = sx.DeviceVector(n_chunks * wr)
+    dst.init(-1.0)
+    src.probe_read_write(dst, chunk, wr)
+    torch.cuda.synchronize()
+    got = dst.download().reshape(n_chunks, wr)
+    want = h.reshape(n_chunks, chunk).sum(axis=1)
+    assert np.allclose(got, want[:, None], rtol=1e-12)
+    with pytest.raises(sx.SpxError):
+        src.probe_read_write(dst, 1000, 10)            # not a multiple of 2048
+    with pytest.raises(sx.SpxError):
+        src.probe_read_write(dst, chunk, chunk + 1)    # more written than read
+    small = sx.DeviceVector(8)
+    with pytest.raises(sx.SpxError):
+        src.probe_read_write(small, chunk, wr)         # dst too short
+    for v in (src, dst, small):
+        v.destroy()

@@ -55,6 +55,19 @@ def big_matrix(seed, symmetric):
             for d in (0, 1):
                 for q in range(w):
                     rows.append(2 * k + d); cols.append(2 * k + off + q)
+    # round 6 (a generator of its own: the matrices of the seeds drawn so far gain these nonzeros, nothing else moves):
+    # every third seed also holds a few CLEAN bands of two to four consecutive columns below the diagonal -- long
+    # unbroken runs of equal segments, which fill read-once passes of their own (csx_spmv_sx_kernel)
+    if seed % 3 == 1:
+        r6 = np.random.RandomState(7600 + seed)
+        for _ in range(r6.randint(1, 4)):
+            w = r6.randint(2, 5)
+            off = -int(r6.randint(w + 1, max(w + 2, n // 4)))
+            lo = -off
+            hi = n if r6.rand() < 0.5 else min(n, lo + int(r6.randint(100, 5000)))
+            rr = np.arange(lo, hi)
+            for q in range(w):
+                rows.append(rr); cols.append(rr + off + q)
     r, c = np.concatenate(rows), np.concatenate(cols)
     ok = (r >= 0) & (r < n) & (c >= 0) & (c < n)
     r, c = r[ok], c[ok]
@@ -109,6 +122,8 @@ def options(seed, symmetric):
 
 
 bad = 0
+ran_sx = ran_xw = 0          # how many of the products ran through the pipelined kernels
+sx_share = []
 for seed in range(a0, b0):
     sym = seed % 3 != 0
     csr, m = big_matrix(seed, sym)
@@ -127,6 +142,10 @@ for seed in range(a0, b0):
             assert np.allclose(s.matvec(x), m @ x, rtol=1e-12, atol=1e-13), "decoded product"
         else:
             A = tune(csr, o, sym=sym)
+            inf = A.info()
+            ran_sx += int(getattr(inf, "sym_pipeline", 0) == 1)
+            sx_share.append(inf.sym_pipeline_elems / max(int(inf.nnz_stored), 1) if getattr(inf, "sym_pipeline", 0) == 1 else 0.0)
+            ran_xw += int(inf.unit_windows == 1)
             y = np.full(n, np.nan)
             A.matvec_mult(0.5, x, y)
             check_y(csr, x, y, 0.5)
@@ -162,5 +181,6 @@ for seed in range(a0, b0):
     except Exception as e:
         bad += 1
         print("seed %d FAILED: %s %s n %d %s" % (seed, type(e).__name__, str(e)[:200], n, o), flush=True)
-print("seeds [%d, %d): %d failures" % (a0, b0, bad))
+print("seeds [%d, %d): %d failures; csx_spmv_sx_kernel ran on %d matrices (up to %.0f %% of their stored nonzeros in SX passes), "
+      "csx_spmv_xw_kernel on %d" % (a0, b0, bad, ran_sx, 100.0 * max(sx_share or [0.0]), ran_xw))
 sys.exit(1 if bad else 0)
