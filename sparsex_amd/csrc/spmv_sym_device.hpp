@@ -94,7 +94,10 @@ __device__ __forceinline__ void symtile_pass(const KernelArgs &a, const SpxRowBl
 #pragma unroll
     for (int w = 0; w < 8; ++w) {
         t = fma(v[w], xc[w], t);
-        p8[w] = active ? v[w] * xr : 0.0;
+        // (no masking of idle lanes here: a pass holds whole tiles -- nseg is a multiple of eight -- and the exchange
+        // below stays inside a tile's eight lanes, so what an idle tile's lanes carry never reaches a live one; they
+        // are kept from adding at the end.  Sixteen conditional moves and their registers less.)
+        p8[w] = v[w] * xr;
     }
     // exchange with lane^4: lanes 0-3 collect columns 0-3, lanes 4-7 columns 4-7
     double p4[4];
