@@ -180,8 +180,11 @@ __device__ __forceinline__ void sx_run(const KernelArgs &a, const SpxRowBlock &r
 __device__ __forceinline__ void sx_other(const KernelArgs &a, const SpxRowBlock &rb, const SpxPass &ps, double *slots,
                                          double *tile, const double *win, int lane)
 {
-    if (ps.kind == SPX_PASS_SYMSEG) run_symseg(a, rb, ps, slots, tile, lane);
-    else run_pass(a, rb, ps, tile, win, lane);
+    if (ps.kind == SPX_PASS_SYMSEG) {
+        if (!abl::sym_no_mixed) run_symseg(a, rb, ps, slots, tile, lane);
+    } else {
+        run_pass(a, rb, ps, tile, win, lane);
+    }
 }
 
 template <int WAVES, int B>
@@ -257,7 +260,8 @@ __device__ __forceinline__ void spmv_body_sx(const KernelArgs &a, const XcdSplit
         const bool two = t + WAVES < n_pass;
         if (two) {
             const SpxPass p1 = lds_pass(hdr, t + WAVES).pass();
-            if (!(p0.kind == SPX_PASS_SYMSEG && p1.kind == SPX_PASS_SYMSEG && run_symseg2(a, rb, p0, p1, slots, tile, lane))) {
+            if (!(p0.kind == SPX_PASS_SYMSEG && p1.kind == SPX_PASS_SYMSEG &&
+                  (abl::sym_no_mixed || run_symseg2(a, rb, p0, p1, slots, tile, lane)))) {
                 sx_other(a, rb, p0, slots, tile, win, lane);
                 sx_other(a, rb, p1, slots, tile, win, lane);
             }

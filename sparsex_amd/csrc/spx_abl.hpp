@@ -64,5 +64,11 @@ constexpr bool sym_no_tile_run = true;
 constexpr bool sym_no_tile_run = false;
 #endif
 
+#ifdef SPX_ABL_SYM_NOMIXED           /* the pipelined kernel skips the read-once passes that hold several units */
+constexpr bool sym_no_mixed = true;
+#else
+constexpr bool sym_no_mixed = false;
+#endif
+
 }  // namespace abl
 }  // namespace spx

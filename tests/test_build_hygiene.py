@@ -21,7 +21,7 @@ CSRC = os.path.join(ROOT, "sparsex_amd", "csrc")
 SWITCHES = {"SPX_ABL_SYM_NOSLOTADD": ["sym_no_slot_add"], "SPX_ABL_SYM_ONEADD": ["sym_one_add"],
             "SPX_ABL_SYM_NOX": ["sym_no_x"], "SPX_ABL_SYM_NOHANDOVER": ["sym_no_handover"],
             "SPX_ABL_SYM_NOOWN": ["sym_no_own"], "SPX_ABL_SYM_NOINIT": ["sym_no_init"],
-            "SPX_ABL_SYM_NOPRIVATE": ["sym_no_private"], "SPX_ABL_SYM_NOTILERUN": ["sym_no_tile_run"],
+            "SPX_ABL_SYM_NOPRIVATE": ["sym_no_private"], "SPX_ABL_SYM_NOTILERUN": ["sym_no_tile_run"], "SPX_ABL_SYM_NOMIXED": ["sym_no_mixed"],
             "SPX_ABL_SYM_STREAM": ["sym_no_slot_add", "sym_no_x", "sym_no_handover"],
             "SPX_ABL_SYM_NOWRITES": ["sym_no_init", "sym_no_own", "sym_no_handover"]}
 ALL = sorted({s for v in SWITCHES.values() for s in v})

@@ -74,7 +74,7 @@ def test_cg_on_device_matches_host_solver():
 
 def test_read_write_probe_reads_every_chunk_and_stores_its_share():
     """spx_hip_probe_read_write (the roof bench.py prints as roofline.measured_mixed_peak): every workgroup reads its
-    chunk of src and stores the chunk's sum to its stretch of dst; bad shapes are refused."""
+    whole chunk of src and stores what its threads summed to its stretch of dst; bad shapes are refused."""
     n_chunks, chunk, wr = 37, 4096, 144
     h = np.arange(n_chunks * chunk, dtype=np.float64) % 7.0
     src = sx.DeviceVector(host=h)
@@ -83,8 +83,11 @@ def test_read_write_probe_reads_every_chunk_and_stores_its_share():
     src.probe_read_write(dst, chunk, wr)
     torch.cuda.synchronize()
     got = dst.download().reshape(n_chunks, wr)
-    want = h.reshape(n_chunks, chunk).sum(axis=1)
-    assert np.allclose(got, want[:, None], rtol=1e-12)
+    # (thread t of a workgroup sums the 16-byte pieces t, t + 256, ... of its chunk and stores that to its slots)
+    pairs = h.reshape(n_chunks, chunk // 2, 2).sum(axis=2)                  # x + y of every double2
+    per_thread = pairs.reshape(n_chunks, chunk // 512, 256).sum(axis=1)     # thread t: pieces congruent to t mod 256
+    assert np.allclose(got, per_thread[:, :wr], rtol=1e-12)
+    assert np.isclose(per_thread.sum(), h.sum())
     with pytest.raises(sx.SpxError):
         src.probe_read_write(dst, 1000, 10)            # not a multiple of 2048
     with pytest.raises(sx.SpxError):
