@@ -894,8 +894,24 @@ void device_free(DeviceMatrix *m)
     delete m;
 }
 
+// `part`: the product over ONE part of the row-blocks (symmetric streams cut by device_plan_chunks): the init pass
+// runs in front of the first part only, what follows the row-blocks behind the last one only
+struct SpmvPart {
+    XcdSplit split;
+    uint32_t longest;
+    bool first, last;
+};
+static void device_spmv_impl(DeviceMatrix *m, double alpha, const double *d_x, double beta, double *d_y, void *stream_,
+                             const SpmvPart *part);
+
 void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
                  double *d_y, void *stream_)
+{
+    device_spmv_impl(m, alpha, d_x, beta, d_y, stream_, nullptr);
+}
+
+static void device_spmv_impl(DeviceMatrix *m, double alpha, const double *d_x, double beta, double *d_y, void *stream_,
+                             const SpmvPart *part)
 {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     int cur = -1;
@@ -929,7 +945,7 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
         const int t = 256;
         const size_t first = m->init_limited ? m->init_lo : 0, last = m->init_limited ? m->own_hi : m->nrows;
         auto init_rows = [&](size_t lo, size_t hi) {
-            if (hi > lo && !abl::sym_no_init)
+            if (hi > lo && !abl::sym_no_init && (!part || part->first))
                 hipLaunchKernelGGL(csx_sym_init_kernel, dim3((unsigned)((hi - lo + t - 1) / t)),
                                    dim3(t), 0, stream, d_y, d_x, m->dvalues, lo, hi,
                                    m->own_lo, m->own_hi, alpha, beta);
@@ -951,7 +967,7 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
             init_rows(first, last);
         // the thin mirror list stores its rows; whatever else lands on them (spilled tile
         // sums) is added afterwards
-        if (m->n_mirror_rows)
+        if (m->n_mirror_rows && (!part || part->first))
             hipLaunchKernelGGL(csx_sym_mirror_rows_kernel, dim3((m->n_mirror_rows + 255) / 256), dim3(256), 0,
                                stream, m->mirror_rows, m->mirror_ptr, m->mirror_col, m->mirror_val, d_x, d_y,
                                alpha, m->n_mirror_rows);
@@ -974,8 +990,8 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
     bool need_symfix = false;
     for (size_t ph = 0; ph < n_launch; ++ph) {
         // (column phases: slice k > 0 adds to what the slices in front of it stored)
-        xcd_now = m->xcd_split[ph];
-        blocks = 8u * m->xcd_longest[ph];
+        xcd_now = part ? part->split : m->xcd_split[ph];
+        blocks = 8u * (part ? part->longest : m->xcd_longest[ph]);
         if (ph > 0) a.beta = 1.0;
         if (blocks && m->wave_tiles && !m->accum) {
             // a copy of slots + y tile per wavefront: as many wavefronts as fit the LDS
@@ -1037,6 +1053,10 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
         }
     }
 #undef SPX_LAUNCH
+    if (part && !part->last) {
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     if (m->n_shared)
         hipLaunchKernelGGL(csx_fixup_kernel, dim3((m->n_shared + 63) / 64), dim3(64), 0,
                            stream, m->shared, m->n_shared, m->carry, d_y, alpha, beta,
@@ -1066,11 +1086,26 @@ size_t device_plan_chunks(DeviceMatrix *m, size_t K, std::vector<size_t> &row_bo
     cp.longest.clear();
     cp.asked = K;
     const size_t n = m->n_rb;
-    if (m->symmetric || m->accum || m->n_shared || m->xcd_split.size() != 1 || !m->launch_order.empty() ||
+    if (m->accum || m->n_shared || m->xcd_split.size() != 1 || !m->launch_order.empty() ||
         n < 64 || K < 2 || m->rb_upto.size() != n + 1)
+        return 0;
+    // A symmetric stream can be cut where EVERY row-block stores its own rows and nobody else adds to them (one
+    // stretch of SPX_RB_PRIVATE rows, the atomic hand-over: a KKT system's multiplier rows): such rows are final when
+    // their row-block has run, whatever the later ones hand over to rows elsewhere.  The parts then cover that
+    // stretch only; the rows outside it -- which receive sums until the last row-block has run -- follow at the end.
+    if (m->symmetric &&
+        !(slot == 2 && m->sym_atomic && !m->wave_tiles && m->use_private && m->private_rows.size() == 1 &&
+          !m->n_mirror_rows && !m->init_limited && m->own_lo == 0 && m->own_hi == m->nrows))
         return 0;
     for (size_t i = 1; i < n; ++i)
         if (m->rb_row0[i] < m->rb_row0[i - 1]) return 0;
+    if (m->symmetric) {
+        // (the stretch of rows that store themselves must be the tail of the row-blocks: whatever row-blocks lie in
+        // front of it -- rows that others add to -- run with the first part and travel at the end)
+        const size_t p_lo = m->private_rows[0].first;
+        const size_t i0 = (size_t) (std::lower_bound(m->rb_row0.begin(), m->rb_row0.end(), (uint32_t) p_lo) - m->rb_row0.begin());
+        if (i0 >= n || m->rb_row0[i0] != p_lo || n - i0 != m->n_private_rb) return 0;
+    }
     K = std::min<size_t>(K, n / 32);
     std::vector<size_t> cut(K + 1, 0);
     for (size_t k = 1; k < K; ++k) {
@@ -1095,8 +1130,15 @@ size_t device_plan_chunks(DeviceMatrix *m, size_t K, std::vector<size_t> &row_bo
         cp.longest.push_back(longest);
         row_bounds.push_back(lo < n ? (size_t) m->rb_row0[lo] : m->own_hi);
     }
-    row_bounds[0] = m->own_lo;
-    row_bounds.push_back(m->own_hi);
+    if (m->symmetric)
+        for (size_t &b : row_bounds) b = std::max(b, m->private_rows[0].first);
+    if (m->symmetric) {
+        row_bounds[0] = m->private_rows[0].first;
+        row_bounds.push_back(m->private_rows[0].second);
+    } else {
+        row_bounds[0] = m->own_lo;
+        row_bounds.push_back(m->own_hi);
+    }
     cp.bounds = row_bounds;
     return K;
 }
@@ -1109,6 +1151,11 @@ void device_spmv_chunk(DeviceMatrix *m, size_t k, double alpha, const double *d_
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const XcdSplit xs = cp.split[k];
     const uint32_t blocks = 8u * cp.longest[k];
+    if (m->symmetric) {
+        SpmvPart part{xs, cp.longest[k], k == 0, k + 1 == cp.split.size()};
+        device_spmv_impl(m, alpha, d_x, beta, d_y, stream_, &part);
+        return;
+    }
     if (!blocks) return;
     // (the launch tuner may have settled on a y tile per wavefront: the same parts through that kernel)
     const size_t lds = (m->wave_tiles ? (size_t) m->waves : 1u) * m->lds_doubles * sizeof(double);
@@ -1331,7 +1378,15 @@ void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x, bool x_p
         m->host_parts = (int) K;
         if (K >= 2) {
             if (!m->copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
-            while (m->part_events.size() < 2 * K) {
+            // the pieces of y and the part each of them is final behind: a part's own rows; and (symmetric streams,
+            // whose parts cover the rows that store themselves only) whatever lies outside them behind the LAST part
+            struct Piece { size_t lo, hi, part; };
+            std::vector<Piece> pieces;
+            for (size_t k = 0; k < K; ++k)
+                if (bounds[k + 1] > bounds[k]) pieces.push_back(Piece{bounds[k], bounds[k + 1], k});
+            if (bounds[0] > 0) pieces.push_back(Piece{0, bounds[0], K - 1});
+            if (bounds[K] < m->nrows) pieces.push_back(Piece{bounds[K], m->nrows, K - 1});
+            while (m->part_events.size() < K + pieces.size()) {
                 hipEvent_t e;
                 HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
                 m->part_events.push_back(e);
@@ -1339,24 +1394,26 @@ void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x, bool x_p
             // (a failure in here must not leave copies queued that still write into the caller's y after the
             // C entry point has returned its error: both streams are drained before the exception travels on)
             try {
+            size_t next_piece = 0;
             for (size_t k = 0; k < K; ++k) {
                 device_spmv_chunk(m, k, alpha, m->d_x, beta, m->d_y, st, 2);
                 HIP_CHECK(hipEventRecord(m->part_events[k], st));
                 HIP_CHECK(hipStreamWaitEvent(m->copy_stream, m->part_events[k], 0));
-                const size_t off = bounds[k] * sizeof(double), n = (bounds[k + 1] - bounds[k]) * sizeof(double);
-                if (!n) continue;
-                char *dst = reinterpret_cast<char *>(y_pinned ? h_y : m->p_y) + off;
-                HIP_CHECK(hipMemcpyAsync(dst, reinterpret_cast<char *>(m->d_y) + off, n, hipMemcpyDeviceToHost, m->copy_stream));
-                if (!y_pinned) HIP_CHECK(hipEventRecord(m->part_events[K + k], m->copy_stream));
+                for (; next_piece < pieces.size() && pieces[next_piece].part == k; ++next_piece) {
+                    const Piece &pc = pieces[next_piece];
+                    const size_t off = pc.lo * sizeof(double), n = (pc.hi - pc.lo) * sizeof(double);
+                    char *dst = reinterpret_cast<char *>(y_pinned ? h_y : m->p_y) + off;
+                    HIP_CHECK(hipMemcpyAsync(dst, reinterpret_cast<char *>(m->d_y) + off, n, hipMemcpyDeviceToHost, m->copy_stream));
+                    if (!y_pinned) HIP_CHECK(hipEventRecord(m->part_events[K + next_piece], m->copy_stream));
+                }
             }
             if (y_pinned) {
                 HIP_CHECK(hipStreamSynchronize(m->copy_stream));
                 return;
             }
-            for (size_t k = 0; k < K; ++k) {
-                const size_t off = bounds[k] * sizeof(double), n = (bounds[k + 1] - bounds[k]) * sizeof(double);
-                if (!n) continue;
-                HIP_CHECK(hipEventSynchronize(m->part_events[K + k]));
+            for (size_t i = 0; i < pieces.size(); ++i) {
+                const size_t off = pieces[i].lo * sizeof(double), n = (pieces[i].hi - pieces[i].lo) * sizeof(double);
+                HIP_CHECK(hipEventSynchronize(m->part_events[K + i]));
                 copy_threads(reinterpret_cast<char *>(h_y) + off, reinterpret_cast<char *>(m->p_y) + off, n);
             }
             return;

@@ -2,7 +2,8 @@
 product runs in parts of whole rows and every part's rows travel back while the next part runs
 (device_spmv_host).  SPX_HOST_PARTS_MIN_BYTES (read once per process) lowers the size from which that happens, so
 that small matrices exercise it: both kinds of vectors (views of user buffers, vectors the library created), beta
-zero and non-zero, matrices the stream of which can and cannot be cut."""
+zero and non-zero, matrices the stream of which can and cannot be cut -- among them (round 6) symmetric streams whose
+row-blocks all store their own rows: those rows come back behind their parts, the rest behind the last one."""
 import os
 import subprocess
 import sys
@@ -22,7 +23,14 @@ from sparsex_amd.api import VectorStruct
 from helpers import tune, check_y
 cases = [("kkt", synth.syn_nlpkkt(22), {}), ("cant", synth.syn_cant(0.4), {}), ("web", synth.syn_webbase(0.2), {}),
          ("kkt-sym", synth.syn_nlpkkt(16), {"spx.matrix.symmetric": "true"}),
-         ("kkt-plain", synth.syn_nlpkkt(22), {"spx.gpu.unit_windows": "false", "spx.gpu.waves": "8"})]
+         ("kkt-plain", synth.syn_nlpkkt(22), {"spx.gpu.unit_windows": "false", "spx.gpu.waves": "8"}),
+         # symmetric, read-once segments: every row-block stores its own rows (the multiplier rows of the KKT system) --
+         # those travel back part by part, the state rows (which receive sums until the last row-block has run) at the end
+         ("kkt-sym-segments", synth.syn_nlpkkt(44), {"spx.matrix.symmetric": "true", "spx.gpu.sym_segments": "true"}),
+         ("kkt-sym-segments-plain", synth.syn_nlpkkt(40), {"spx.matrix.symmetric": "true", "spx.gpu.sym_segments": "true",
+                                                           "spx.gpu.sym_pipeline": "false", "spx.gpu.sym_wide_rows": "512"}),
+         # symmetric tiles: rows are added to from everywhere, the stream is not cut
+         ("nd24k-sym", synth.syn_nd24k(0.1), {"spx.matrix.symmetric": "true", "spx.gpu.sym_spill": "atomic"})]
 L = sx.lib()
 L.spx_hip_mat_host_parts.restype = C.c_int
 L.spx_vec_create_random.restype = C.POINTER(VectorStruct); L.spx_vec_create_random.argtypes = [C.c_size_t, C.c_void_p]
@@ -37,7 +45,7 @@ for name, csr, opts in cases:
     A.matvec_mult(0.5, x, y)
     check_y(csr, x, y, 0.5)
     parts = L.spx_hip_mat_host_parts(C.c_void_p(A.handle))
-    if not %(expect_parts)s or name == "kkt-sym":                   # (symmetric streams are not cut)
+    if not %(expect_parts)s or name in ("kkt-sym", "nd24k-sym"):    # (symmetric streams whose rows are added to from elsewhere are not cut)
         assert parts == 0, (name, parts)
     elif name != "web":                                             # (web: cut unless the tuner chose column slices)
         assert parts >= 2, (name, parts)
@@ -71,4 +79,4 @@ def test_host_vectors_with_and_without_parts(min_bytes):
     code = CHILD % {"root": ROOT, "tests": os.path.join(ROOT, "tests"), "expect_parts": str(min_bytes == "1024")}
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    assert r.stdout.count("ok ") == 5
+    assert r.stdout.count("ok ") == 8
