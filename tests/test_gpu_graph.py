@@ -12,12 +12,17 @@ from helpers import tune, check_y
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("sym", [False, True])
-def test_captured_spmv_replays(sym):
+@pytest.mark.parametrize("sym,gen,opts", [
+    (False, lambda: synth.syn_cant(0.05), {}),
+    (True, lambda: synth.syn_cant(0.05), {}),
+    # the pipelined read-once kernel (init kernel + csx_spmv_sx_kernel per product) inside a captured graph
+    (True, lambda: synth.syn_nlpkkt(44), {"spx.gpu.sym_segments": "true", "spx.gpu.sym_pipeline": "true"}),
+], ids=["general", "symmetric", "symmetric-pipelined"])
+def test_captured_spmv_replays(sym, gen, opts):
     import torch
-    csr = synth.syn_cant(0.05)
+    csr = gen()
     rp, ci, va, n = csr
-    A = tune(csr, {"spx.preproc.sampling": "none"}, sym=sym)
+    A = tune(csr, dict({"spx.preproc.sampling": "none"}, **opts), sym=sym)
     x = torch.from_numpy(synth.random_x(n)).cuda()
     y = torch.zeros(n, dtype=torch.float64, device="cuda")
     s = torch.cuda.current_stream().cuda_stream
