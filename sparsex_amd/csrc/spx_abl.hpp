@@ -5,7 +5,7 @@
 // default build leaves them off and that every variant still compiles).  An experiment build
 // (tools/build_variant.sh <name> "-DSPX_ABL_...") leaves one cost out at a time; its results are WRONG
 // on purpose and tools/abl.py labels its rows INVALID.  What each variant measured: profiles/r05/ablation.md
-// section 2, profiles/r06/sym_writes.md.
+// section 2, profiles/r06/sym_writes_raw.md.
 #pragma once
 
 namespace spx {
