@@ -51,6 +51,9 @@ def run_bench(world, extra, port=None, timeout=900, host_threads=2):
     ("nlpkkt", ["--edge", "28", "--dist-reorder", "none"], False),
     ("nlpkkt-sym", ["--edge", "28", "--symmetric", "--dist-reorder", "none"], False),
     ("nlpkkt-sym-segments", ["--edge", "28", "--symmetric", "--opt", "spx.gpu.sym_segments=true"], False),
+    # runs long enough for passes of their own: the pipelined read-once kernel on a rank's slice
+    ("nlpkkt-sym-pipelined", ["--edge", "48", "--symmetric", "--dist-reorder", "none", "--opt", "spx.gpu.sym_segments=true",
+                              "--opt", "spx.gpu.sym_pipeline=true"], False),
     ("kkt2f-sym", ["--workload", "syn-kkt2f", "--edge", "28", "--symmetric"], False),
     ("kkt2f-sym-segments", ["--workload", "syn-kkt2f", "--edge", "28", "--symmetric",
                             "--opt", "spx.gpu.sym_segments=true"], False),
@@ -64,7 +67,7 @@ def run_bench(world, extra, port=None, timeout=900, host_threads=2):
     ("nlpkkt-rcm", ["--edge", "28", "--dist-reorder", "rcm"], False),
     ("nlpkkt-rcm_owner", ["--edge", "28"], False),                       # (the default on several ranks)
     ("nd24k-rcm_owner", ["--workload", "syn-nd24k", "--scale", "0.15", "--dist-reorder", "rcm_owner"], True),
-], ids=["nlpkkt", "nlpkkt-sym", "nlpkkt-sym-segments", "kkt2f-sym", "kkt2f-sym-segments", "kkt2f-sym-auto",
+], ids=["nlpkkt", "nlpkkt-sym", "nlpkkt-sym-segments", "nlpkkt-sym-pipelined", "kkt2f-sym", "kkt2f-sym-segments", "kkt2f-sym-auto",
         "nd24k-sym", "nd24k-sym-atomic", "webbase", "nlpkkt-rcm", "nlpkkt-rcm_owner", "nd24k-rcm_owner"])
 def test_ranks_share_one_gpu(world, name, extra, tiles):
     out = run_bench(world, extra)
@@ -77,6 +80,8 @@ def check_line(out, world, name):
     assert ("symmetric" in out) == (not out["config"]["symmetric_path"] and name not in ("webbase", "nlpkkt-only"))
     if name in ("kkt2f-sym-segments", "kkt2f-sym-auto", "nlpkkt-sym-segments"):
         assert "symseg" in out["roofline"]["kernel"]
+    if name == "nlpkkt-sym-pipelined":
+        assert "csx_spmv_sx_kernel" in out["roofline"]["kernel"]
     for res in paths:
         assert res["parity"]["max_err_over_fp64_bound"] <= 1.0
         ranks = res["ranks"]

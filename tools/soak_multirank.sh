@@ -25,6 +25,11 @@ for w in 2 3 4; do
     run $w --edge $e --symmetric --opt spx.gpu.sym_spill=lists
     run $w --edge $e --opt spx.gpu.rowblock_rows=2048
   done
+  # round 6: slices whose runs are long enough for passes of their own -- the pipelined read-once kernel on a slice
+  # (limited init range, conflict rows, the exchange behind it), in the application's order and renumbered
+  run $w --edge 56 --symmetric --dist-reorder none --opt spx.gpu.sym_segments=true --opt spx.gpu.sym_pipeline=true
+  run $w --edge 50 --symmetric --opt spx.gpu.sym_segments=true --opt spx.gpu.sym_pipeline=true --opt spx.gpu.waves=4
+  run $w --edge 56 --symmetric --dist-reorder none --opt spx.gpu.sym_segments=true --opt spx.gpu.sym_pipeline=false
   run $w --workload syn-nd24k --scale 0.2 --symmetric --opt spx.gpu.sym_segments=true
   run $w --workload syn-cant --scale 0.5 --symmetric --opt spx.gpu.sym_segments=true --opt spx.gpu.sym_wide_rows=1024
   run $w --workload syn-cant --scale 0.5 --symmetric --opt spx.gpu.deterministic=true
