@@ -14,8 +14,8 @@
 //  * the pass headers of the row-block sit in LDS (copied there with global_load_lds_dwordx4 in the prologue);
 //  * an SX pass (all lanes one unit, geometry in the header: sxplan.hpp) asks for its values, x[row] and
 //    x[columns] in ONE round trip -- no descriptor load at all;
-//  * rounds of two SX passes run as a two-stage pipeline: the loads of the NEXT round go out before the FMAs
-//    and LDS adds of the current one.
+//  * rounds of B SX passes (B = SX_PASSES_PER_ROUND = 1: measured, see below) run as a two-stage pipeline: the
+//    loads of the NEXT round go out before the FMAs and LDS adds of the current one.
 // x comes through the vector memory path, not from LDS (the unit-window kernel's way): a row-block's slots
 // and y tile already take 44 KB, a window of x of the same shape would halve the workgroups per CU.  Loads
 // return in order, so x must travel WITH the values of its own round (a dependent x load behind the next
@@ -24,8 +24,6 @@
 #include "sxplan.hpp"
 
 #include <cstddef>
-#include <cstdio>
-#include <cstdlib>
 
 namespace spx {
 
@@ -197,8 +195,8 @@ __device__ __forceinline__ void spmv_body_sx(const KernelArgs &a, const XcdSplit
     const uint32_t rb_idx = xs.first[xcd] + (blockIdx.x >> 3);
     if (rb_idx >= xs.first[xcd + 1u]) return;
 
-    // first round trip: the row-block header, the number of its SX passes, the wavefront's first two pass
-    // headers (scalar), and -- on their way to LDS -- all pass headers of the row-block (pass_stride of them
+    // first round trip: the row-block header, the number of its SX passes, the headers of the wavefront's
+    // first round (scalar), and -- on their way to LDS -- all pass headers of the row-block (pass_stride of them
     // whatever the row-block uses: no need to wait for its header to know how many)
     const SpxPass *pass0 = a.passes + (size_t) rb_idx * a.pass_stride;
     spx_const_words_t passes = (spx_const_words_t) (uintptr_t) pass0;
@@ -306,7 +304,7 @@ void csx_spmv_sx_kernel(SPX_KERNEL_PARAMS, const uint32_t *sx_tab_)
 
 // (B: passes per round of the pipeline.  Two per round -- the unit-window kernel's choice -- take 90 VGPRs, five
 // wavefronts per SIMD, and measured 3-4 % slower than one per round at 64 VGPRs: 947 / 939 against 913 / 903 us on
-// the bench matrix, profiles/r06/sx_order_and_width.md; three workgroups of eight wavefronts per CU with one
+// the bench matrix, profiles/r06/sx_order_and_width_raw.md; three workgroups of eight wavefronts per CU with one
 // round in flight behind the one being finished already cover the latency.)
 constexpr int SX_PASSES_PER_ROUND = 1;
 
