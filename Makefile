@@ -21,7 +21,7 @@ CXXFLAGS  := -std=c++17 -O2 -g -fPIC -Wall -Iinclude -I$(CSRC) -pthread
 HIPFLAGS  := --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -munsafe-fp-atomics \
              -Iinclude -I$(CSRC)
 
-.PHONY: all lib oracle clean
+.PHONY: all lib oracle clean print-host-srcs print-hip-objs
 all: lib oracle
 
 lib: $(LIB) $(SYNLIB)
@@ -50,3 +50,9 @@ oracle:
 
 clean:
 	rm -rf build $(LIBDIR)/*.so oracle/*.so oracle/_ref
+
+# (for tools/build_asan.sh)
+print-host-srcs:
+	@echo $(HOST_SRCS)
+print-hip-objs:
+	@echo $(HIP_OBJ)

@@ -1413,8 +1413,7 @@ void finalize_stream(GpuStream &s, size_t nrows)
     }
     uint32_t stride = 1;
     for (const SpxRowBlock &rb : s.rbs) stride = std::max<uint32_t>(stride, rb.n_pass);
-    std::vector<SpxPass> strided(s.rbs.size() * (size_t) stride);
-    std::memset(strided.data(), 0, strided.size() * sizeof(SpxPass));
+    std::vector<SpxPass> strided(s.rbs.size() * (size_t) stride);       // (value-initialized: all zero)
     for (size_t i = 0; i < s.rbs.size(); ++i) {
         SpxRowBlock &rb = s.rbs[i];
         std::copy(s.passes.begin() + rb.pass_off, s.passes.begin() + rb.pass_off + rb.n_pass,

@@ -11,12 +11,16 @@ set -e
 cd "$(dirname "$0")/.."
 make lib > /dev/null
 mkdir -p build/asan sparsex_amd/lib/variants
-for f in common config partition stats encoder input reorder csx_emit gpu_emit stream_index dist api; do
-    g++ -std=c++17 -O1 -g -fPIC -fsanitize=address -fno-omit-frame-pointer -Iinclude -Isparsex_amd/csrc -pthread \
-        -c sparsex_amd/csrc/$f.cpp -o build/asan/$f.o &
+# the host sources and the HIP objects are the Makefile's lists
+HOST=$(make -s -f Makefile print-host-srcs)
+HIPO=$(make -s -f Makefile print-hip-objs)
+rm -f build/asan/*.o
+for f in $HOST; do
+    g++ -std=c++17 -O1 -g -fPIC -fsanitize=address,undefined -fno-omit-frame-pointer \
+        -Iinclude -Isparsex_amd/csrc -pthread -c sparsex_amd/csrc/$f -o build/asan/${f%.cpp}.o &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o sparsex_amd/lib/variants/libsparsex_asan.so \
-    build/asan/*.o build/obj/spmv_kernels.o build/obj/vec_kernels.o build/obj/dist_kernels.o -pthread -ldl \
+    build/asan/*.o $HIPO -pthread -ldl -lubsan \
     -L$(dirname $(gcc -print-file-name=libasan.so)) -lasan
 echo sparsex_amd/lib/variants/libsparsex_asan.so
