@@ -83,8 +83,6 @@ __device__ __forceinline__ void spmv_body(const KernelArgs &a, const XcdSplit &x
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // XCD-aware order: workgroup b runs on XCD b % 8 and takes that XCD's next row-block
     // (the grid is 8 x the longest of the eight lists)
-    // XCD-aware order: workgroup b runs on XCD b % 8 and takes that XCD's next row-block
-    // (the grid is 8 x the longest of the eight lists)
     const uint32_t xcd = blockIdx.x & 7u;
     const uint32_t rb_idx = xs.first[xcd] + (blockIdx.x >> 3);
     if (rb_idx >= xs.first[xcd + 1u]) return;
