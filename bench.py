@@ -638,23 +638,44 @@ def measured_mixed_peak(sx, torch, write_share, chunk_doubles=8192, elems=1 << 2
 def host_api_rate(A, xh, n, nnz, calls=20):
     """API-visible rate of the unchanged reference entry point: spx_matvec_mult on
     HOST vectors (x up, kernel, y down, synchronous) -- PCIe inclusive."""
-    yh = np.zeros(n)
-    for _ in range(3):
-        A.matvec_mult(ALPHA, xh, yh)
-    t0 = time.perf_counter()
-    for _ in range(calls):
-        A.matvec_mult(ALPHA, xh, yh)
-    sec = (time.perf_counter() - t0) / calls
-    out = {"entry": "spx_matvec_mult on views of user buffers (SPX_VEC_AS_IS: x up, kernel, y down; PCIe inclusive)",
-           "us_per_call": round(sec * 1e6, 1), "gflops": round(2.0 * nnz / sec / 1e9, 1)}
-    # ... and what a reference client gets whose vectors come from spx_vec_create_random / spx_vec_create (page-locked
-    # library memory): by default x travels with every call like any other vector; with spx.vec.device=true (opt-in:
-    # the client promises to change x through spx_vec_* only, or to call spx_hip_vec_touch) x's HBM copy is reused
-    # between calls and only y travels
     import ctypes as C
     import sparsex_amd as sx
     from sparsex_amd.api import VectorStruct
     L = sx.lib()
+    yh = np.zeros(n)
+    # views that live across the calls, as the reference's harness holds them (src/bench/SparsexModule.cpp:54-70:
+    # spx_vec_create_from_buff once, then the loop): from the second call on the client's buffers are page-locked
+    # where they lie (spx.vec.register) and travel without staging
+    L.spx_vec_create_from_buff.restype = C.POINTER(VectorStruct)
+    L.spx_vec_create_from_buff.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+    xw = L.spx_vec_create_from_buff(xh.ctypes.data, None, n, None, 43)       # SPX_VEC_AS_IS
+    yw = L.spx_vec_create_from_buff(yh.ctypes.data, None, n, None, 43)
+    try:
+        for _ in range(3):
+            L.spx_matvec_mult(C.c_double(ALPHA), C.c_void_p(A.handle), xw, yw)
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            L.spx_matvec_mult(C.c_double(ALPHA), C.c_void_p(A.handle), xw, yw)
+        sec = (time.perf_counter() - t0) / calls
+    finally:
+        L.spx_vec_destroy(xw)
+        L.spx_vec_destroy(yw)
+    out = {"entry": "spx_matvec_mult on views of user buffers that live across the calls (SPX_VEC_AS_IS, as the reference's "
+                    "harness: x up, kernel, y down; PCIe inclusive; buffers page-locked in place from the second call on)",
+           "us_per_call": round(sec * 1e6, 1), "gflops": round(2.0 * nnz / sec / 1e9, 1)}
+    # ... and with a view made for every call (never page-locked: x and y go through staging memory)
+    for _ in range(2):
+        A.matvec_mult(ALPHA, xh, yh)
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        A.matvec_mult(ALPHA, xh, yh)
+    sec1 = (time.perf_counter() - t0) / calls
+    out["view_per_call"] = {"entry": "a new view for every call (staged)", "us_per_call": round(sec1 * 1e6, 1),
+                            "gflops": round(2.0 * nnz / sec1 / 1e9, 1)}
+    # ... and what a reference client gets whose vectors come from spx_vec_create_random / spx_vec_create (page-locked
+    # library memory): by default x travels with every call like any other vector; with spx.vec.device=true (opt-in:
+    # the client promises to change x through spx_vec_* only, or to call spx_hip_vec_touch) x's HBM copy is reused
+    # between calls and only y travels
     L.spx_vec_create_random.restype = C.POINTER(VectorStruct)
     L.spx_vec_create_random.argtypes = [C.c_size_t, C.c_void_p]
     L.spx_vec_create.restype = C.POINTER(VectorStruct)

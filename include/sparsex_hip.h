@@ -441,6 +441,17 @@ int spx_hip_abi_version(void);
 /* Diagnostic: the number of parts the last spx_matvec_mult / spx_matvec_kernel on HOST vectors ran in (a large y
  * travels back part by part behind the product; 0: the product ran in one piece). */
 int spx_hip_mat_host_parts(const spx_matrix_t *A);
+/* ... and, where x of that call went up piece by piece in the order the parts needed it (general streams; the part
+ * that needs the fewest pieces not yet on the device runs first, so that x on its way up and finished rows of y on
+ * their way back share the link), the order the parts ran in: up to `cap` part numbers are written, the number of
+ * parts is returned; 0 when x went up as a whole or not at all (resident since the last call). */
+int spx_hip_mat_host_order(const spx_matrix_t *A, int32_t *order, int cap);
+/* Inspection (host side; works on a matrix tuned with spx.rt.host_only=true): which pieces of x -- of `piece`
+ * elements each, at most 64 of them -- every row-block of the stream reads: bit p of mask[i] for the columns
+ * [p * piece, (p + 1) * piece), a superset; row0 / n_rows: the row-block's rows.  Any of the arrays may be NULL; up
+ * to `cap` entries are written, the number of row-blocks is returned (-1: error).  The plan behind
+ * spx_hip_mat_host_order is made of these. */
+int64_t spx_hip_mat_x_pieces(spx_matrix_t *A, size_t piece, uint64_t *mask, uint32_t *row0, uint32_t *n_rows, size_t cap);
 
 /* ---- export in the reference's CSX layout --------------------------------------
  * `part` is a global partition number owned by this process.  The arrays

@@ -103,6 +103,57 @@ uint64_t vec_version(const spx_vector_t *v)
     return out ? out : 1;
 }
 
+// spx.vec.register (default auto): a spx_vec_create_from_buff vector is a view of the CLIENT's buffer, pageable
+// memory as a rule, and every spx_matvec_* on it copies x into page-locked staging memory and y back out of it --
+// on the bench matrix that host-side copying takes longer than the transfers.  A view that is used for a SECOND
+// product with the same buffer (the reference's bench loop, src/bench/SparsexModule.cpp:54-70; a client that
+// makes a view per call never gets here) has that buffer page-locked where it lies (hipHostRegister) and from
+// then on travels like a vector of the library's own; spx_vec_destroy releases it.  Nothing depends on it for
+// correctness: a buffer that cannot be locked, or was locked by someone else and released under us, goes through
+// staging or through the runtime's own pageable path.
+struct VecReg {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    unsigned uses = 0;
+    bool locked = false, ours = false, failed = false;
+};
+std::unordered_map<const spx_vector_t *, VecReg> g_vec_reg;
+
+bool vec_page_locked(const spx_vector_t *v)
+{
+    if (v->alloc_type == ALLOC_PINNED) return true;
+    const size_t bytes = v->size * sizeof(spx_value_t);
+    if (bytes < device_host_parts_min_bytes() || !v->elements) return false;      // (from where y travels in parts: 32 MB)
+    if (Config::instance().get_str("spx.vec.register") == "false") return false;
+    std::lock_guard<std::mutex> lk(g_vec_mtx);
+    VecReg &r = g_vec_reg[v];
+    if (r.ptr != (void *) v->elements || r.bytes != bytes) {
+        if (r.ours) device_host_unregister(r.ptr);
+        r = VecReg();
+        r.ptr = v->elements;
+        r.bytes = bytes;
+    }
+    ++r.uses;
+    if (!r.locked && !r.failed && r.uses >= 2) {
+        const int got = device_host_register(r.ptr, r.bytes);
+        r.locked = got != 0;
+        r.ours = got == 1;
+        r.failed = got == 0;
+        log_msg(LOG_INFO, "vector view of %.0f MB: %s\n", (double) bytes / 1048576.0,
+                got == 1 ? "page-locked in place" : (got == 2 ? "already page-locked" : "cannot be page-locked, staged"));
+    }
+    return r.locked;
+}
+
+void vec_release_lock(const spx_vector_t *v)
+{
+    std::lock_guard<std::mutex> lk(g_vec_mtx);
+    auto it = g_vec_reg.find(v);
+    if (it == g_vec_reg.end()) return;
+    if (it->second.ours) device_host_unregister(it->second.ptr);
+    g_vec_reg.erase(it);
+}
+
 double now_sec()
 {
     using namespace std::chrono;
@@ -2021,8 +2072,8 @@ static spx_error_t run_host(const spx_matrix_t *A, spx_value_t alpha, const spx_
         // with all of y in host memory, as the reference's caller expects
         std::function<void(double *, void *)> after;
         if (A->dist) after = [A](double *d_y, void *st) { dist_complete(A->dist, d_y, true, false, st); };
-        device_spmv_host(A->dev, alpha, x->elements, x->alloc_type == ALLOC_PINNED, beta,
-                         y->elements, y->alloc_type == ALLOC_PINNED, after, vec_version(x));
+        const bool x_locked = vec_page_locked(x), y_locked = vec_page_locked(y);
+        device_spmv_host(A->dev, alpha, x->elements, x_locked, beta, y->elements, y_locked, after, vec_version(x));
         vec_touch(y);
     } catch (const FatalError &e) {
         SETERROR_1(SPX_ERR_TUNED_MAT, e.what.c_str());
@@ -2160,6 +2211,11 @@ try {
     return A && A->dev ? device_host_parts(A->dev) : 0;
 } SPX_C_BOUNDARY(return 0;)
 
+int spx_hip_mat_host_order(const spx_matrix_t *A, int32_t *order, int cap)
+try {
+    return A && A->dev && (order || cap <= 0) ? device_host_order(A->dev, order, cap < 0 ? 0 : cap) : 0;
+} SPX_C_BOUNDARY(return 0;)
+
 spx_error_t spx_hip_mat_unit_windows(spx_matrix_t *A, uint32_t budget, uint32_t gap, spx_hip_xw_plan_t *out)
 try {
     if (!A || !out) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid argument"); return SPX_FAILURE; }
@@ -2193,6 +2249,22 @@ try {
     out->lds_doubles = p.lds_doubles;
     return SPX_SUCCESS;
 } SPX_C_BOUNDARY(return SPX_FAILURE;)
+
+int64_t spx_hip_mat_x_pieces(spx_matrix_t *A, size_t piece, uint64_t *mask, uint32_t *row0, uint32_t *n_rows, size_t cap)
+try {
+    if (!A || !piece) { SETERROR_1(SPX_ERR_ARG_INVALID, "invalid argument"); return -1; }
+    const GpuStream *s = A->host_stream ? A->host_stream.get() : A->index.get();
+    if (!s) { SETERROR_1(SPX_ERR_TUNED_MAT, "matrix holds no descriptor stream"); return -1; }
+    std::lock_guard<std::mutex> lk(A->mtx);
+    std::vector<uint64_t> m;
+    stream_rowblock_xpieces(*s, (size_t) A->ncols, piece, m, host_threads());
+    for (size_t i = 0; i < m.size() && i < cap; ++i) {
+        if (mask) mask[i] = m[i];
+        if (row0) row0[i] = s->rbs[i].row0;
+        if (n_rows) n_rows[i] = s->rbs[i].n_rows;
+    }
+    return (int64_t) m.size();
+} SPX_C_BOUNDARY(return -1;)
 
 spx_error_t spx_hip_mat_sym_pipeline(spx_matrix_t *A, spx_hip_sx_plan_t *out)
 try {
@@ -2610,6 +2682,7 @@ void spx_vec_destroy(spx_vector_t *v)
 try {
     if (!v) return;
     vec_forget(v);
+    vec_release_lock(v);
     if (v->alloc_type == ALLOC_STD) free(v->elements);
     else if (v->alloc_type == ALLOC_PINNED) device_host_free(v->elements);
     free(v);

@@ -33,8 +33,10 @@ void device_spmv(DeviceMatrix *m, double alpha, const double *d_x, double beta,
 // `row_bounds` receives the first row of every part and the end of the own rows.
 // `slot`: 0 = the cut of an attached exchange plan, 1 = a caller's own (spx_hip_matvec_parts): independent of each other
 size_t device_plan_chunks(DeviceMatrix *m, size_t K, std::vector<size_t> &row_bounds, int slot = 0);
+// `position` (symmetric streams, whose parts may run in any order): bit 0 = this part is launched first, bit 1 = last;
+// -1 = by its number
 void device_spmv_chunk(DeviceMatrix *m, size_t k, double alpha, const double *d_x, double beta,
-                       double *d_y, void *stream, int slot = 0);
+                       double *d_y, void *stream, int slot = 0, int position = -1);
 
 // host-vector convenience path used by spx_matvec_*: H2D x (and y when
 // beta != 0), kernel, D2H y; synchronous.  Vectors the library allocated itself
@@ -57,6 +59,10 @@ bool device_stream_is_capturing(void *stream);
 // no HIP device (the caller falls back to malloc)
 void *device_host_alloc(size_t bytes);
 void device_host_free(void *p);
+// a client's buffer page-locked where it lies (1: done, 2: it already was, 0: not possible) / released again
+size_t device_host_parts_min_bytes();    // vectors of this size and more: y back in parts, client buffers page-locked (32 MB; tests lower it)
+int device_host_register(void *p, size_t bytes);
+void device_host_unregister(void *p);
 
 // symmetric slice: the first kernel clears y on rows [first_row, own rows) only
 // (default 0: the whole partial vector is defined, for a caller-side all-reduce)
@@ -85,6 +91,7 @@ int device_get_waves(const DeviceMatrix *m);
 // unit windows of x in LDS + pipelined unit passes (csx_spmv_xw_kernel; xwindows.hpp): available where
 // the stream was uploaded with a window budget and some row-block's columns fit it
 bool device_has_xw(const DeviceMatrix *m);
+int device_host_order(const DeviceMatrix *m, int32_t *order, int cap);   // the order of those parts when x went up piece by piece as they needed it (returns their number; 0: x went up whole or not at all)
 int device_host_parts(const DeviceMatrix *m);   // parts of the last product on host vectors whose y went back part by part (0: whole)
 void device_set_xw(DeviceMatrix *m, bool on);
 bool device_get_xw(const DeviceMatrix *m);

@@ -446,6 +446,7 @@ struct DeviceMatrix {
     std::vector<hipEvent_t> stage_events;       // one behind every piece of a staged download
     std::vector<hipEvent_t> part_events;        // one behind every part of a product whose y travels back in parts
     int host_parts = 0;                         // parts of the last product on host vectors (0: in one piece)
+    bool host_x_by_need = false;                // ... and whether x went up in the order the parts needed it
     size_t value_bytes = 0, index_bytes = 0;
     size_t n_values = 0, n_descs = 0, n_passes = 0, n_cidx = 0, n_segrows = 0;
     // every array of the stream lives in ONE allocation (2 MB-aligned pieces): one mapping, one
@@ -465,6 +466,13 @@ struct DeviceMatrix {
         std::vector<uint32_t> longest;
         std::vector<size_t> bounds;
         size_t asked = 0;
+        // (slot 2, general streams with rb_xneed) the order in which the host entry point runs the parts -- the one
+        // that needs the fewest pieces of x not yet on the device first -- and the pieces that go up in front of each
+        std::vector<uint32_t> order;
+        std::vector<std::vector<uint32_t>> step_pieces;
+        // (symmetric streams) the row-blocks in front of the stretch the parts cover: launched with the last part
+        XcdSplit front;
+        uint32_t front_longest = 0;
     };
     ChunkPlan chunks[3];                        // 0: an attached exchange plan's, 1: spx_hip_matvec_parts', 2: the host entry point's
     // unit windows of x in LDS (xwindows.hpp; plain general streams): a second set of pass headers and
@@ -484,7 +492,35 @@ struct DeviceMatrix {
     bool sx_on = false;           // the product runs through csx_spmv_sx_kernel
     uint64_t sx_elems = 0, sx_sym_elems = 0;
     size_t sx_rowblocks = 0;
+    // which pieces of x (of xneed_piece doubles) every row-block reads (stream_rowblock_xpieces): general streams
+    // that the host entry point cuts into parts, whose x then travels in the order the parts need it
+    std::vector<uint64_t> rb_xneed;
+    size_t xneed_piece = 0;
+    hipStream_t up_stream = nullptr;            // ... on a stream of its own
 };
+
+// the host-vector entry point (device_spmv_host)
+constexpr size_t STAGE_PIECE = (size_t) 16 << 20;      // bytes
+constexpr size_t HOST_PARTS = 8;                       // parts of a product whose y goes back part by part ...
+constexpr size_t HOST_PARTS_X = 16;                    // ... (general streams whose x comes piece by piece: finer)
+constexpr size_t HOST_X_PIECE = (size_t) 4 << 20;      // ... in pieces of this many bytes
+constexpr size_t HOST_PARTS_MIN_BYTES = (size_t) 32 << 20;   // ... where y is at least this large
+
+static size_t host_parts_min_bytes()
+{
+    static const size_t v = getenv("SPX_HOST_PARTS_MIN_BYTES") ? (size_t) atoll(getenv("SPX_HOST_PARTS_MIN_BYTES"))
+                                                               : HOST_PARTS_MIN_BYTES;             // (tests: small matrices)
+    return v;
+}
+
+// doubles per piece of x: HOST_X_PIECE, or what keeps the vector within 64 of them
+static size_t host_xpiece_doubles(size_t ncols)
+{
+    static const size_t env = getenv("SPX_HOST_XPIECE_BYTES") ? (size_t) atoll(getenv("SPX_HOST_XPIECE_BYTES")) / sizeof(double) : 0;
+    size_t piece = env ? env : HOST_X_PIECE / sizeof(double);                                      // (tests: small pieces)
+    piece = std::max(piece, (ncols + 63) / 64);
+    return (piece + 511) & ~(size_t) 511;
+}
 
 int device_count()
 {
@@ -853,6 +889,19 @@ DeviceMatrix *device_upload(const GpuStream &s, size_t nrows, size_t ncols,
             throw;
         }
     }
+    // which pieces of x every row-block reads, where the host entry point can cut the stream into parts
+    // (device_plan_chunks' conditions): device_spmv_host sends x in the order the parts need it
+    if (!m->accum && !m->n_shared && m->xcd_split.size() == 1 && m->launch_order.empty() &&
+        (!symmetric || !m->n_mirror_rows) && m->n_rb >= 64 &&
+        m->nrows * sizeof(double) >= host_parts_min_bytes()) {
+        try {
+            m->xneed_piece = host_xpiece_doubles(m->ncols);
+            stream_rowblock_xpieces(s, m->ncols, m->xneed_piece, m->rb_xneed, host_threads());
+        } catch (...) {
+            device_free(m);
+            throw;
+        }
+    }
     return m;
 }
 
@@ -887,6 +936,7 @@ void device_free(DeviceMatrix *m)
     if (m->p_y) (void) hipHostFree(m->p_y);
     if (m->host_stream) (void) hipStreamDestroy(m->host_stream);
     if (m->copy_stream) (void) hipStreamDestroy(m->copy_stream);
+    if (m->up_stream) (void) hipStreamDestroy(m->up_stream);
     for (hipEvent_t e : m->stage_events) (void) hipEventDestroy(e);
     for (hipEvent_t e : m->part_events) (void) hipEventDestroy(e);
     delete m;
@@ -1082,6 +1132,8 @@ size_t device_plan_chunks(DeviceMatrix *m, size_t K, std::vector<size_t> &row_bo
     row_bounds.clear();
     cp.split.clear();
     cp.longest.clear();
+    cp.order.clear();
+    cp.step_pieces.clear();
     cp.asked = K;
     const size_t n = m->n_rb;
     if (m->accum || m->n_shared || m->xcd_split.size() != 1 || !m->launch_order.empty() ||
@@ -1097,23 +1149,22 @@ size_t device_plan_chunks(DeviceMatrix *m, size_t K, std::vector<size_t> &row_bo
         return 0;
     for (size_t i = 1; i < n; ++i)
         if (m->rb_row0[i] < m->rb_row0[i - 1]) return 0;
+    size_t base = 0;
+    cp.front_longest = 0;
     if (m->symmetric) {
-        // (the stretch of rows that store themselves must be the tail of the row-blocks: whatever row-blocks lie in
-        // front of it -- rows that others add to -- run with the first part and travel at the end)
+        // (the stretch of rows that store themselves must be the tail of the row-blocks: the parts cover it; whatever
+        // row-blocks lie in front of it -- rows that others add to, which travel at the end anyway -- run with the
+        // LAST part: on a KKT system they are the state rows that couple with every multiplier, and in the first
+        // part they would hold up its product until all of x has arrived)
         const size_t p_lo = m->private_rows[0].first;
         const size_t i0 = (size_t) (std::lower_bound(m->rb_row0.begin(), m->rb_row0.end(), (uint32_t) p_lo) - m->rb_row0.begin());
         if (i0 >= n || m->rb_row0[i0] != p_lo || n - i0 != m->n_private_rb) return 0;
+        base = i0;
     }
-    K = std::min<size_t>(K, n / 32);
-    std::vector<size_t> cut(K + 1, 0);
-    for (size_t k = 1; k < K; ++k) {
-        const uint64_t want = m->rb_upto[n] * k / K;
-        size_t i = (size_t)(std::lower_bound(m->rb_upto.begin(), m->rb_upto.end(), want) - m->rb_upto.begin());
-        cut[k] = std::min(std::max(i, cut[k - 1]), n);
-    }
-    cut[K] = n;
-    for (size_t k = 0; k < K; ++k) {
-        const size_t lo = cut[k], hi = cut[k + 1];
+    K = std::min<size_t>(K, (n - base) / 32);
+    if (K < 2) return 0;
+    // (the eight XCDs' shares of the row-blocks [lo, hi), by work)
+    auto split_of = [&](size_t lo, size_t hi, uint32_t &longest) {
         XcdSplit xs;
         xs.first[0] = (uint32_t) lo;
         for (uint32_t x = 1; x < 8; ++x) {
@@ -1122,9 +1173,22 @@ size_t device_plan_chunks(DeviceMatrix *m, size_t K, std::vector<size_t> &row_bo
             xs.first[x] = (uint32_t) std::min(std::max<size_t>(i, xs.first[x - 1]), hi);
         }
         xs.first[8] = (uint32_t) hi;
-        uint32_t longest = 0;
+        longest = 0;
         for (uint32_t x = 0; x < 8; ++x) longest = std::max(longest, xs.first[x + 1] - xs.first[x]);
-        cp.split.push_back(xs);
+        return xs;
+    };
+    if (base > 0) cp.front = split_of(0, base, cp.front_longest);
+    std::vector<size_t> cut(K + 1, base);
+    for (size_t k = 1; k < K; ++k) {
+        const uint64_t want = m->rb_upto[base] + (m->rb_upto[n] - m->rb_upto[base]) * k / K;
+        size_t i = (size_t)(std::lower_bound(m->rb_upto.begin(), m->rb_upto.end(), want) - m->rb_upto.begin());
+        cut[k] = std::min(std::max(i, cut[k - 1]), n);
+    }
+    cut[K] = n;
+    for (size_t k = 0; k < K; ++k) {
+        const size_t lo = cut[k], hi = cut[k + 1];
+        uint32_t longest = 0;
+        cp.split.push_back(split_of(lo, hi, longest));
         cp.longest.push_back(longest);
         row_bounds.push_back(lo < n ? (size_t) m->rb_row0[lo] : m->own_hi);
     }
@@ -1138,10 +1202,59 @@ size_t device_plan_chunks(DeviceMatrix *m, size_t K, std::vector<size_t> &row_bo
         row_bounds.push_back(m->own_hi);
     }
     cp.bounds = row_bounds;
+    cp.order.clear();
+    cp.step_pieces.clear();
+    if (slot == 2 && m->rb_xneed.size() == n && m->xneed_piece) {
+        const size_t P = (m->ncols + m->xneed_piece - 1) / m->xneed_piece;
+        std::vector<uint64_t> need(K, 0ull);
+        for (size_t k = 0; k < K; ++k)
+            for (size_t i = cut[k]; i < cut[k + 1]; ++i) need[k] |= m->rb_xneed[i];
+        uint64_t init_need = 0, front_need = 0;
+        if (m->symmetric) {
+            // the init pass in front of the part that runs first reads x of every row that does not store itself;
+            // the row-blocks in front of the parts run with the one that runs last
+            auto rows = [&](size_t lo, size_t hi) {
+                for (size_t pc = lo / m->xneed_piece; hi > lo && pc <= (hi - 1) / m->xneed_piece && pc < P; ++pc) init_need |= 1ull << pc;
+            };
+            rows(0, m->private_rows[0].first);
+            rows(m->private_rows[0].second, m->nrows);
+            for (size_t i = 0; i < base; ++i) front_need |= m->rb_xneed[i];
+        }
+        uint64_t have = 0;
+        std::vector<char> done(K, 0);
+        for (size_t step = 0; step < K; ++step) {
+            const uint64_t with = (step == 0 ? init_need : 0ull) | (step + 1 == K ? front_need : 0ull);
+            size_t best = K;
+            int best_new = 65;
+            for (size_t k = 0; k < K; ++k) {
+                const int fresh = __builtin_popcountll((need[k] | with) & ~have);
+                if (!done[k] && fresh < best_new) { best_new = fresh; best = k; }
+            }
+            need[best] |= with;
+            done[best] = 1;
+            cp.order.push_back((uint32_t) best);
+            std::vector<uint32_t> pcs;
+            for (size_t pc = 0; pc < P; ++pc)
+                if (((need[best] & ~have) >> pc) & 1ull) pcs.push_back((uint32_t) pc);
+            have |= need[best];
+            cp.step_pieces.push_back(pcs);
+        }
+        for (size_t pc = 0; pc < P; ++pc)            // (pieces nobody reads: with the last step, d_x is x as a whole)
+            if (!((have >> pc) & 1ull)) cp.step_pieces.back().push_back((uint32_t) pc);
+        std::string txt;
+        for (size_t j = 0; j < K; ++j) {
+            txt += (j ? ", " : "") + std::to_string(cp.order[j]) + " (";
+            for (size_t q = 0; q < cp.step_pieces[j].size(); ++q) txt += (q ? " " : "") + std::to_string(cp.step_pieces[j][q]);
+            txt += ")";
+        }
+        log_msg(LOG_INFO, "host vectors: %zu parts, x in %zu pieces of %.1f MB; part (pieces sent in front of it): %s\n", K, P,
+                (double) m->xneed_piece * sizeof(double) / 1048576.0, txt.c_str());
+    }
     return K;
 }
 
-void device_spmv_chunk(DeviceMatrix *m, size_t k, double alpha, const double *d_x, double beta, double *d_y, void *stream_, int slot)
+void device_spmv_chunk(DeviceMatrix *m, size_t k, double alpha, const double *d_x, double beta, double *d_y, void *stream_, int slot,
+                       int position)
 {
     const DeviceMatrix::ChunkPlan &cp = m->chunks[slot < 0 || slot > 2 ? 0 : slot];
     if (k >= cp.split.size()) throw FatalError("no such part of the stream (device_plan_chunks)");
@@ -1150,7 +1263,15 @@ void device_spmv_chunk(DeviceMatrix *m, size_t k, double alpha, const double *d_
     const XcdSplit xs = cp.split[k];
     const uint32_t blocks = 8u * cp.longest[k];
     if (m->symmetric) {
-        SpmvPart part{xs, cp.longest[k], k == 0, k + 1 == cp.split.size()};
+        // (the init pass goes in front of the part that is launched first, the row-blocks in front of the parts and
+        // whatever follows the product behind the one that is launched last: by number unless the caller says)
+        const bool first = position < 0 ? k == 0 : (position & 1) != 0;
+        const bool last = position < 0 ? k + 1 == cp.split.size() : (position & 2) != 0;
+        if (last && cp.front_longest) {
+            SpmvPart front{cp.front, cp.front_longest, false, false};
+            device_spmv_impl(m, alpha, d_x, beta, d_y, stream_, &front);
+        }
+        SpmvPart part{xs, cp.longest[k], first, last};
         device_spmv_impl(m, alpha, d_x, beta, d_y, stream_, &part);
         return;
     }
@@ -1239,6 +1360,14 @@ int device_get_waves(const DeviceMatrix *m) { return m->waves; }
 
 int device_host_parts(const DeviceMatrix *m) { return m ? m->host_parts : 0; }
 
+int device_host_order(const DeviceMatrix *m, int32_t *order, int cap)
+{
+    if (!m || m->host_parts < 2 || !m->host_x_by_need) return 0;
+    const DeviceMatrix::ChunkPlan &cp = m->chunks[2];
+    for (int j = 0; j < cap && j < (int) cp.order.size(); ++j) order[j] = (int32_t) cp.order[(size_t) j];
+    return (int) cp.order.size();
+}
+
 bool device_has_sx(const DeviceMatrix *m) { return m->passes_sx != nullptr; }
 void device_set_sx(DeviceMatrix *m, bool on) { m->sx_on = on && m->passes_sx && m->sym_atomic && !m->wave_tiles; }
 bool device_get_sx(const DeviceMatrix *m) { return m->sx_on && m->passes_sx && m->sym_atomic && !m->wave_tiles; }
@@ -1312,9 +1441,6 @@ double device_time_spmv(DeviceMatrix *m, int warmup, int launches)
 // single-threaded copy of 224 MB into the staging buffer took longer than the DMA.
 namespace {
 
-constexpr size_t STAGE_PIECE = (size_t) 16 << 20;      // bytes
-constexpr size_t HOST_PARTS = 8;                       // parts of a product whose y goes back part by part ...
-constexpr size_t HOST_PARTS_MIN_BYTES = (size_t) 32 << 20;   // ... where y is at least this large
 
 void copy_threads(void *dst, const void *src, size_t bytes)
 {
@@ -1351,77 +1477,112 @@ void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x, bool x_p
     const size_t xb = m->ncols * sizeof(double), yb = m->nrows * sizeof(double);
     ensure_staging(m);
     hipStream_t st = m->host_stream;
-    if (!x_version || x_version != m->x_version) {
+    // A large y goes back in parts behind the product: the stream is cut into parts of whole rows (where it can be:
+    // device_plan_chunks), every part's rows start on their way as soon as its kernel has ended, on a stream of
+    // their own, while the next part runs -- the download of the bench matrix's 224 MB takes three times as long as
+    // its product.  And x comes in pieces in the order the parts need them (general streams: the plan's `order`),
+    // so that the two directions of the link are busy at the same time.
+    const bool whole = m->own_lo == 0 && m->own_hi == m->nrows && (!m->symmetric || m->sym_fused);
+    std::vector<size_t> bounds;
+    // (by need: page-locked x only -- a pageable x goes through staging memory in large pieces, where the host's
+    // copying, not the link, sets the pace)
+    const bool send_x = !x_version || x_version != m->x_version;
+    const bool want_by_need = send_x && x_pinned && !m->rb_xneed.empty();
+    const size_t K = (!after && whole && yb >= host_parts_min_bytes())
+                         ? device_plan_chunks(m, want_by_need ? HOST_PARTS_X : HOST_PARTS, bounds, 2) : 0;
+    const DeviceMatrix::ChunkPlan &cp = m->chunks[2];
+    const bool x_by_need = want_by_need && K >= 2 && cp.order.size() == K && cp.step_pieces.size() == K;
+    if (send_x && !x_by_need) {
         if (x_pinned) HIP_CHECK(hipMemcpyAsync(m->d_x, h_x, xb, hipMemcpyHostToDevice, st));
         else upload_staged(m->d_x, m->p_x, h_x, xb, st);
         m->x_version = x_version;
     }
     // y travels to the device only when it is read: beta != 0, or this process
     // owns a slice of the rows and the others must keep the caller's values
-    const bool whole = m->own_lo == 0 && m->own_hi == m->nrows && (!m->symmetric || m->sym_fused);
     // (atomic hand-over reads y only through the init kernel's beta*y: nothing to upload when beta == 0)
     if (beta != 0.0 || !whole) {
         if (y_pinned) HIP_CHECK(hipMemcpyAsync(m->d_y, h_y, yb, hipMemcpyHostToDevice, st));
         else upload_staged(m->d_y, m->p_y, h_y, yb, st);
     }
-    // A large y goes back in parts behind the product: the stream is cut into parts of whole rows (where it can be:
-    // device_plan_chunks), every part's rows start on their way as soon as its kernel has ended, on a stream of
-    // their own, while the next part runs -- the download of the bench matrix's 224 MB takes three times as long as
-    // its product.
-    static const size_t parts_from = getenv("SPX_HOST_PARTS_MIN_BYTES") ? (size_t) atoll(getenv("SPX_HOST_PARTS_MIN_BYTES"))
-                                                                        : HOST_PARTS_MIN_BYTES;    // (tests: small matrices)
-    if (!after && whole && yb >= parts_from) {
-        std::vector<size_t> bounds;
-        const size_t K = device_plan_chunks(m, HOST_PARTS, bounds, 2);
-        m->host_parts = (int) K;
-        if (K >= 2) {
-            if (!m->copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
-            // the pieces of y and the part each of them is final behind: a part's own rows; and (symmetric streams,
-            // whose parts cover the rows that store themselves only) whatever lies outside them behind the LAST part
-            struct Piece { size_t lo, hi, part; };
-            std::vector<Piece> pieces;
-            for (size_t k = 0; k < K; ++k)
-                if (bounds[k + 1] > bounds[k]) pieces.push_back(Piece{bounds[k], bounds[k + 1], k});
-            if (bounds[0] > 0) pieces.push_back(Piece{0, bounds[0], K - 1});
-            if (bounds[K] < m->nrows) pieces.push_back(Piece{bounds[K], m->nrows, K - 1});
-            while (m->part_events.size() < K + pieces.size()) {
-                hipEvent_t e;
-                HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                m->part_events.push_back(e);
+    m->host_parts = (int) K;
+    m->host_x_by_need = x_by_need;
+    if (K >= 2) {
+        if (!m->copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
+        if (x_by_need && !m->up_stream) HIP_CHECK(hipStreamCreateWithFlags(&m->up_stream, hipStreamNonBlocking));
+        // the pieces of y and the part each of them is final behind: a part's own rows; and (symmetric streams,
+        // whose parts cover the rows that store themselves only) whatever lies outside them behind the LAST part
+        struct Piece { size_t lo, hi; };
+        std::vector<Piece> pieces;
+        std::vector<std::vector<size_t>> pieces_of(K);
+        auto add_piece = [&](size_t lo, size_t hi, size_t part) {
+            pieces_of[part].push_back(pieces.size());
+            pieces.push_back(Piece{lo, hi});
+        };
+        for (size_t k = 0; k < K; ++k)
+            if (bounds[k + 1] > bounds[k]) add_piece(bounds[k], bounds[k + 1], k);
+        const size_t k_last = cp.order.size() == K ? cp.order[K - 1] : K - 1;       // (the part that is launched last)
+        if (bounds[0] > 0) add_piece(0, bounds[0], k_last);
+        if (bounds[K] < m->nrows) add_piece(bounds[K], m->nrows, k_last);
+        // events: [0, K) behind the parts, then one behind every piece of y, then [.., + K) behind the steps of x
+        const size_t ev_piece = K, ev_up = K + pieces.size();
+        while (m->part_events.size() < ev_up + K) {
+            hipEvent_t e;
+            HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            m->part_events.push_back(e);
+        }
+        // (a failure in here must not leave copies queued that still write into the caller's y -- or read the
+        // caller's x -- after the C entry point has returned its error: the streams are drained before the
+        // exception travels on)
+        try {
+            if (x_by_need) {
+                // (whatever the product's stream was given before -- y on its way up -- is not waited for: x only)
+                m->x_version = 0;
             }
-            // (a failure in here must not leave copies queued that still write into the caller's y after the
-            // C entry point has returned its error: both streams are drained before the exception travels on)
-            try {
-            size_t next_piece = 0;
-            for (size_t k = 0; k < K; ++k) {
-                device_spmv_chunk(m, k, alpha, m->d_x, beta, m->d_y, st, 2);
+            for (size_t j = 0; j < K; ++j) {
+                const size_t k = cp.order.size() == K ? cp.order[j] : j;
+                if (x_by_need) {
+                    for (uint32_t pc : cp.step_pieces[j]) {
+                        const size_t off = (size_t) pc * m->xneed_piece * sizeof(double);
+                        if (off >= xb) continue;
+                        const size_t n = std::min(m->xneed_piece * sizeof(double), xb - off);
+                        HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char *>(m->d_x) + off, reinterpret_cast<const char *>(h_x) + off, n,
+                                                 hipMemcpyHostToDevice, m->up_stream));
+                    }
+                    HIP_CHECK(hipEventRecord(m->part_events[ev_up + j], m->up_stream));
+                    HIP_CHECK(hipStreamWaitEvent(st, m->part_events[ev_up + j], 0));
+                }
+                device_spmv_chunk(m, k, alpha, m->d_x, beta, m->d_y, st, 2, (j == 0 ? 1 : 0) | (j + 1 == K ? 2 : 0));
                 HIP_CHECK(hipEventRecord(m->part_events[k], st));
                 HIP_CHECK(hipStreamWaitEvent(m->copy_stream, m->part_events[k], 0));
-                for (; next_piece < pieces.size() && pieces[next_piece].part == k; ++next_piece) {
-                    const Piece &pc = pieces[next_piece];
-                    const size_t off = pc.lo * sizeof(double), n = (pc.hi - pc.lo) * sizeof(double);
+                for (size_t i : pieces_of[k]) {
+                    const size_t off = pieces[i].lo * sizeof(double), n = (pieces[i].hi - pieces[i].lo) * sizeof(double);
                     char *dst = reinterpret_cast<char *>(y_pinned ? h_y : m->p_y) + off;
                     HIP_CHECK(hipMemcpyAsync(dst, reinterpret_cast<char *>(m->d_y) + off, n, hipMemcpyDeviceToHost, m->copy_stream));
-                    if (!y_pinned) HIP_CHECK(hipEventRecord(m->part_events[K + next_piece], m->copy_stream));
+                    if (!y_pinned) HIP_CHECK(hipEventRecord(m->part_events[ev_piece + i], m->copy_stream));
                 }
             }
             if (y_pinned) {
                 HIP_CHECK(hipStreamSynchronize(m->copy_stream));
-                return;
+            } else {
+                // (in the order they were sent)
+                for (size_t j = 0; j < K; ++j)
+                    for (size_t i : pieces_of[cp.order.size() == K ? cp.order[j] : j]) {
+                        const size_t off = pieces[i].lo * sizeof(double), n = (pieces[i].hi - pieces[i].lo) * sizeof(double);
+                        HIP_CHECK(hipEventSynchronize(m->part_events[ev_piece + i]));
+                        copy_threads(reinterpret_cast<char *>(h_y) + off, reinterpret_cast<char *>(m->p_y) + off, n);
+                    }
             }
-            for (size_t i = 0; i < pieces.size(); ++i) {
-                const size_t off = pieces[i].lo * sizeof(double), n = (pieces[i].hi - pieces[i].lo) * sizeof(double);
-                HIP_CHECK(hipEventSynchronize(m->part_events[K + i]));
-                copy_threads(reinterpret_cast<char *>(h_y) + off, reinterpret_cast<char *>(m->p_y) + off, n);
-            }
+            if (x_by_need) m->x_version = x_version;
             return;
-            } catch (...) {
-                (void) hipStreamSynchronize(m->copy_stream);
-                (void) hipStreamSynchronize(st);
-                (void) hipGetLastError();
-                m->host_parts = 0;
-                throw;
-            }
+        } catch (...) {
+            if (m->up_stream) (void) hipStreamSynchronize(m->up_stream);
+            (void) hipStreamSynchronize(m->copy_stream);
+            (void) hipStreamSynchronize(st);
+            (void) hipGetLastError();
+            m->host_parts = 0;
+            m->host_x_by_need = false;
+            if (x_by_need) m->x_version = 0;
+            throw;
         }
     }
     m->host_parts = 0;
@@ -1483,6 +1644,23 @@ void *device_host_alloc(size_t bytes)
 void device_host_free(void *p)
 {
     if (p) (void) hipHostFree(p);
+}
+
+size_t device_host_parts_min_bytes() { return host_parts_min_bytes(); }
+
+int device_host_register(void *p, size_t bytes)
+{
+    if (!p || !bytes || device_count() <= 0) return 0;
+    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    if (e == hipSuccess) return 1;
+    (void) hipGetLastError();
+    return e == hipErrorHostMemoryAlreadyRegistered ? 2 : 0;
+}
+
+void device_host_unregister(void *p)
+{
+    if (!p) return;
+    if (hipHostUnregister(p) != hipSuccess) (void) hipGetLastError();
 }
 
 template <typename T, typename A>

@@ -1,6 +1,8 @@
 // stream_index.cpp -- see stream_index.hpp.
 #include "stream_index.hpp"
 
+#include "threads.hpp"
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -195,6 +197,53 @@ void stream_read_cols(const GpuStream &s, idx_t own_lo, idx_t own_hi, size_t nco
     for (uint32_t c : s.mirror_col) hit((int64_t) c);
     for (size_t c = 0; c < ncols; ++c)
         if (mark[c] && ((idx_t) c < own_lo || (idx_t) c >= own_hi)) cols.push_back((idx_t) c);
+}
+
+void stream_rowblock_xpieces(const GpuStream &s, size_t ncols, size_t piece, std::vector<uint64_t> &mask, unsigned nthreads)
+{
+    const size_t n = s.rbs.size();
+    mask.assign(n, 0ull);
+    if (!piece || piece * 64 < ncols) throw FatalError("pieces of x: more than 64");
+    const int64_t last = ncols ? (int64_t) ncols - 1 : 0;
+    constexpr size_t CHUNK = 64;
+    parallel_for((n + CHUNK - 1) / CHUNK, nthreads, [&](size_t c) {
+        for (size_t i = c * CHUNK; i < std::min(n, (c + 1) * CHUNK); ++i) {
+            const SpxRowBlock &rb = s.rbs[i];
+            uint64_t m = 0;
+            // columns [c0, c1] (clipped to the vector: idle lanes shadow others, padding may point anywhere)
+            auto hit = [&](int64_t c0, int64_t c1) {
+                c0 = std::min(std::max<int64_t>(c0, 0), last);
+                c1 = std::min(std::max<int64_t>(c1, 0), last);
+                for (size_t p = (size_t) c0 / piece; p <= (size_t) c1 / piece; ++p) m |= 1ull << p;
+            };
+            if (rb.xwin_len) hit((int64_t) rb.xwin_base, (int64_t) rb.xwin_base + rb.xwin_len - 1);
+            for (uint32_t t = 0; t < rb.n_pass; ++t) {
+                const SpxPass &ps = s.passes[(size_t) rb.pass_off + t];
+                const uint32_t nseg = ps.nseg, W = ps.width;
+                for (uint32_t l = 0; l < nseg; ++l) {
+                    if (is_gather(ps)) {
+                        if (ps.kind == SPX_PASS_GATHER_LDS) continue;       // (the window, above)
+                        for (uint32_t w = 0; w < W; ++w) {
+                            const int64_t col = gather_col(s, rb, ps, (size_t) ps.elem0 + l + (size_t) w * nseg);
+                            hit(col, col);
+                        }
+                    } else if (ps.kind == SPX_PASS_SYMTILE) {
+                        const SpxUnitDesc &d = s.descs[(size_t) rb.desc_off + ps.rank0 + (l >> 3)];
+                        hit((int64_t) d.col0, (int64_t) d.col0 + 7);
+                    } else {
+                        int64_t r, c0;
+                        unit_lane(s, rb, ps, l, r, c0);
+                        hit(c0, c0 + (int64_t) W);              // (+ the value-pair loads' second x of odd widths)
+                    }
+                }
+            }
+            // (symmetric streams: the diagonal term and the transposed products read x of the own rows)
+            if (rb.n_rows && !s.dvalues.empty()) hit((int64_t) rb.row0, (int64_t) rb.row0 + rb.n_rows - 1);
+            mask[i] = m;
+        }
+    });
+    for (uint32_t c : s.mirror_col)
+        if (!mask.empty()) mask[0] |= 1ull << ((size_t) std::min<int64_t>((int64_t) c, last) / piece);
 }
 
 void stream_locate_mirror(const GpuStream &s, idx_t row, idx_t col, std::vector<size_t> &out)

@@ -40,6 +40,14 @@ void stream_touched_rows(const GpuStream &s, idx_t below, std::vector<idx_t> &ro
 // threads share x); the closest is the column walk of its map, CsxBuild.hpp:432-451.
 void stream_read_cols(const GpuStream &s, idx_t own_lo, idx_t own_hi, size_t ncols, std::vector<idx_t> &cols);
 
+// Which parts of x a row-block reads: bit p of mask[i] is set when row-block i reads a column of
+// [p * piece, (p + 1) * piece) (padding lanes included: a superset is fine); at most 64 pieces
+// (piece * 64 >= ncols).  The host-vector entry point sends x in that order, the part of the product
+// that needs the fewest new pieces first (device_spmv_host): the reference's threads read x where the
+// client left it (src/internals/CsxKernels.cpp:35-61), here it has to cross PCIe first, and the rows
+// of y that are done cross it the other way meanwhile.
+void stream_rowblock_xpieces(const GpuStream &s, size_t ncols, size_t piece, std::vector<uint64_t> &mask, unsigned nthreads);
+
 // Launch order for matrices whose rows read x in bands that recur at a fixed row distance (a
 // 3-D stencil: the bands of the z-planes above and below; the distance S is N^2 rows).  Walking
 // the row-blocks of an XCD's part plane by plane, a band comes round again S rows -- some 190

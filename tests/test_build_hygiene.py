@@ -29,6 +29,7 @@ ALL = sorted({s for v in SWITCHES.values() for s in v})
 # environment variables the product sources may read, and why
 ALLOWED_ENV = {
     "SPX_HOST_PARTS_MIN_BYTES": "tests: the part-by-part return of y on small matrices",
+    "SPX_HOST_XPIECE_BYTES": "tests: x on its way up in many pieces on small matrices",
     "SPX_NO_CSR_FAST_PATH": "tests: the CSR fast path of the partition builder against the general one",
     "SPX_NO_HUGE_PAGES": "operations: hosts where transparent huge pages must not be asked for",
     "SPX_VEC_DEVICE": "spx_options_set_from_env: an unchanged client opts in to resident vectors",

@@ -3,7 +3,9 @@ product runs in parts of whole rows and every part's rows travel back while the 
 (device_spmv_host).  SPX_HOST_PARTS_MIN_BYTES (read once per process) lowers the size from which that happens, so
 that small matrices exercise it: both kinds of vectors (views of user buffers, vectors the library created), beta
 zero and non-zero, matrices the stream of which can and cannot be cut -- among them (round 6) symmetric streams whose
-row-blocks all store their own rows: those rows come back behind their parts, the rest behind the last one."""
+row-blocks all store their own rows: those rows come back behind their parts, the rest behind the last one.
+On general streams x goes up piece by piece in the order the parts need it (SPX_HOST_XPIECE_BYTES makes the pieces
+small enough for these matrices to have many) and the parts run in that order: spx_hip_mat_host_order."""
 import os
 import subprocess
 import sys
@@ -33,15 +35,23 @@ cases = [("kkt", synth.syn_nlpkkt(22), {}), ("cant", synth.syn_cant(0.4), {}), (
          ("nd24k-sym", synth.syn_nd24k(0.1), {"spx.matrix.symmetric": "true", "spx.gpu.sym_spill": "atomic"})]
 L = sx.lib()
 L.spx_hip_mat_host_parts.restype = C.c_int
+L.spx_hip_mat_host_order.restype = C.c_int
+L.spx_hip_mat_host_order.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
+def host_order(A):
+    buf = (C.c_int32 * 32)()
+    k = L.spx_hip_mat_host_order(C.c_void_p(A.handle), buf, 32)
+    return [buf[i] for i in range(min(k, 32))]
 L.spx_vec_create_random.restype = C.POINTER(VectorStruct); L.spx_vec_create_random.argtypes = [C.c_size_t, C.c_void_p]
 L.spx_vec_create.restype = C.POINTER(VectorStruct); L.spx_vec_create.argtypes = [C.c_size_t, C.c_void_p]
 L.spx_mat_get_partition.restype = C.c_void_p
+orders = {}
 for name, csr, opts in cases:
     n = csr[3]
     A = tune(csr, opts, sym=opts.get("spx.matrix.symmetric") == "true")
     x = synth.random_x(n)
-    # views of user buffers
+    # views of user buffers (first a product with another x: a piece of x that the plan forgot would still hold it)
     y = np.full(n, np.nan)
+    A.matvec_mult(0.5, np.full(n, np.nan), y)
     A.matvec_mult(0.5, x, y)
     check_y(csr, x, y, 0.5)
     parts = L.spx_hip_mat_host_parts(C.c_void_p(A.handle))
@@ -49,10 +59,37 @@ for name, csr, opts in cases:
         assert parts == 0, (name, parts)
     elif name != "web":                                             # (web: cut unless the tuner chose column slices)
         assert parts >= 2, (name, parts)
+    assert host_order(A) == [], (name, host_order(A))              # (a pageable x goes up whole, through staging)
     y0 = synth.random_x(n, seed=3)
     y = y0.copy()
     A.matvec_kernel(2.0, x, -0.5, y)
     check_y(csr, x, y, 2.0, -0.5, y0)
+    # a view that lives across products (the reference's bench loop, src/bench/SparsexModule.cpp:54-70): from the
+    # second product on its buffer is page-locked in place (spx.vec.register) and travels without staging
+    L.spx_vec_create_from_buff.restype = C.POINTER(VectorStruct)
+    L.spx_vec_create_from_buff.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+    xb, yb = synth.random_x(n, seed=5), np.full(n, np.nan)
+    xw = L.spx_vec_create_from_buff(xb.ctypes.data, None, n, None, 43)       # SPX_VEC_AS_IS
+    yw = L.spx_vec_create_from_buff(yb.ctypes.data, None, n, None, 43)
+    for rep in range(4):
+        if rep == 2:
+            xb[:] = synth.random_x(n, seed=6)          # (the client writes through its own pointer)
+        yb[:] = np.nan
+        assert L.spx_matvec_mult(C.c_double(0.5), C.c_void_p(A.handle), xw, yw) == 0
+        check_y(csr, xb.copy(), yb.copy(), 0.5)
+        order, parts_now = host_order(A), L.spx_hip_mat_host_parts(C.c_void_p(A.handle))
+        if rep >= 1 and parts >= 2:
+            # page-locked by now: x went up by need, every part ran once, in the order the plan chose (symmetric
+            # streams too: the init pass goes in front of whichever part runs first)
+            assert sorted(order) == list(range(parts_now)) and parts_now >= 2, (name, rep, parts_now, order)
+            orders[name] = order
+        else:
+            assert order == [], (name, rep, order)
+    yb[:] = y0
+    L.spx_matvec_kernel.argtypes = [C.c_double, C.c_void_p, C.POINTER(VectorStruct), C.c_double, C.POINTER(VectorStruct)]
+    assert L.spx_matvec_kernel(2.0, C.c_void_p(A.handle), xw, -0.5, yw) == 0
+    check_y(csr, xb.copy(), yb.copy(), 2.0, -0.5, y0)
+    L.spx_vec_destroy(xw); L.spx_vec_destroy(yw)
     # vectors the library created (page-locked, x resident between calls)
     part = C.c_void_p(L.spx_mat_get_partition(C.c_void_p(A.handle)))
     xv, yv = L.spx_vec_create_random(n, part), L.spx_vec_create(n, part)
@@ -62,6 +99,15 @@ for name, csr, opts in cases:
         ya[:] = np.nan
         assert L.spx_matvec_mult(C.c_double(0.5), C.c_void_p(A.handle), xv, yv) == 0
         check_y(csr, xa.copy(), ya.copy(), 0.5)
+        # (library vectors: x is resident after the first call unless spx.vec.device is off and it is sent again;
+        # either way, when it was sent to a cut general stream it went by need)
+        assert host_order(A) in ([], orders.get(name, [])), (name, rep, host_order(A), orders.get(name))
+    # a changed x is seen (the pieces are sent again, or the resident copy is refreshed)
+    xa[:] = synth.random_x(n, seed=11)
+    L.spx_hip_vec_touch(xv)
+    ya[:] = np.nan
+    assert L.spx_matvec_mult(C.c_double(0.5), C.c_void_p(A.handle), xv, yv) == 0
+    check_y(csr, xa.copy(), ya.copy(), 0.5)
     ya[:] = y0
     L.spx_matvec_kernel.argtypes = [C.c_double, C.c_void_p, C.POINTER(VectorStruct), C.c_double, C.POINTER(VectorStruct)]
     assert L.spx_matvec_kernel(2.0, C.c_void_p(A.handle), xv, -0.5, yv) == 0
@@ -73,9 +119,11 @@ for name, csr, opts in cases:
 '''
 
 
-@pytest.mark.parametrize("min_bytes", ["1024", "1000000000000"])
-def test_host_vectors_with_and_without_parts(min_bytes):
+@pytest.mark.parametrize("min_bytes,xpiece", [("1024", "8192"), ("1024", "0"), ("1000000000000", "8192")])
+def test_host_vectors_with_and_without_parts(min_bytes, xpiece):
     env = dict(os.environ, SPX_HOST_PARTS_MIN_BYTES=min_bytes)
+    if xpiece != "0":
+        env["SPX_HOST_XPIECE_BYTES"] = xpiece
     code = CHILD % {"root": ROOT, "tests": os.path.join(ROOT, "tests"), "expect_parts": str(min_bytes == "1024")}
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]

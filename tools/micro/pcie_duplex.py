@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""How much of the host link both directions get at the same time: 224 MB up, 224 MB down, one after the other and
+together on two streams (pinned host memory), in pieces of 16 MB as the host-vector entry point sends them."""
+import time
+import torch
+
+n = 28_000_000
+hx = torch.empty(n, dtype=torch.float64).pin_memory()
+hy = torch.empty(n, dtype=torch.float64).pin_memory()
+dx = torch.empty(n, dtype=torch.float64, device="cuda")
+dy = torch.empty(n, dtype=torch.float64, device="cuda")
+up, down = torch.cuda.Stream(), torch.cuda.Stream()
+P = 2 * 1024 * 1024
+
+
+def run(do_up, do_down):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for rep in range(5):
+        for off in range(0, n, P):
+            if do_up:
+                with torch.cuda.stream(up):
+                    dx[off:off + P].copy_(hx[off:off + P], non_blocking=True)
+            if do_down:
+                with torch.cuda.stream(down):
+                    hy[off:off + P].copy_(dy[off:off + P], non_blocking=True)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / 5 * 1e3
+
+
+for name, a, b in (("up only", True, False), ("down only", False, True), ("both at once", True, True)):
+    run(a, b)
+    print("%-14s %.2f ms per 224 MB each way" % (name, run(a, b)))
