@@ -1500,7 +1500,10 @@ void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x, bool x_p
     // y travels to the device only when it is read: beta != 0, or this process
     // owns a slice of the rows and the others must keep the caller's values
     // (atomic hand-over reads y only through the init kernel's beta*y: nothing to upload when beta == 0)
-    if (beta != 0.0 || !whole) {
+    // (... and where x goes up by need, a page-locked y that is read goes up the same way: a part reads its own
+    // rows, the init pass of a symmetric stream the rows that do not store themselves)
+    const bool y_by_need = x_by_need && y_pinned && beta != 0.0;
+    if ((beta != 0.0 || !whole) && !y_by_need) {
         if (y_pinned) HIP_CHECK(hipMemcpyAsync(m->d_y, h_y, yb, hipMemcpyHostToDevice, st));
         else upload_staged(m->d_y, m->p_y, h_y, yb, st);
     }
@@ -1521,6 +1524,7 @@ void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x, bool x_p
         for (size_t k = 0; k < K; ++k)
             if (bounds[k + 1] > bounds[k]) add_piece(bounds[k], bounds[k + 1], k);
         const size_t k_last = cp.order.size() == K ? cp.order[K - 1] : K - 1;       // (the part that is launched last)
+        const size_t n_own = pieces.size();                                          // (pieces [n_own, ..): outside the parts)
         if (bounds[0] > 0) add_piece(0, bounds[0], k_last);
         if (bounds[K] < m->nrows) add_piece(bounds[K], m->nrows, k_last);
         // events: [0, K) behind the parts, then one behind every piece of y, then [.., + K) behind the steps of x
@@ -1547,6 +1551,17 @@ void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x, bool x_p
                         const size_t n = std::min(m->xneed_piece * sizeof(double), xb - off);
                         HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char *>(m->d_x) + off, reinterpret_cast<const char *>(h_x) + off, n,
                                                  hipMemcpyHostToDevice, m->up_stream));
+                    }
+                    if (y_by_need) {
+                        auto send_y = [&](const Piece &pc) {
+                            const size_t off = pc.lo * sizeof(double), n = (pc.hi - pc.lo) * sizeof(double);
+                            HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char *>(m->d_y) + off, reinterpret_cast<const char *>(h_y) + off, n,
+                                                     hipMemcpyHostToDevice, m->up_stream));
+                        };
+                        if (j == 0)
+                            for (size_t i = n_own; i < pieces.size(); ++i) send_y(pieces[i]);
+                        for (size_t i : pieces_of[k])
+                            if (i < n_own) send_y(pieces[i]);
                     }
                     HIP_CHECK(hipEventRecord(m->part_events[ev_up + j], m->up_stream));
                     HIP_CHECK(hipStreamWaitEvent(st, m->part_events[ev_up + j], 0));

@@ -28,5 +28,12 @@ t0 = time.perf_counter()
 for rep in range(10):
     L.spx_matvec_mult(C.c_double(0.5), C.c_void_p(A.handle), xv, yv)
 print("library vectors: %.2f ms per spx_matvec_mult" % ((time.perf_counter() - t0) * 100))
+L.spx_matvec_kernel.argtypes = [C.c_double, C.c_void_p, C.POINTER(VectorStruct), C.c_double, C.POINTER(VectorStruct)]
+for rep in range(2):
+    L.spx_matvec_kernel(0.5, C.c_void_p(A.handle), xv, 0.25, yv)
+t0 = time.perf_counter()
+for rep in range(10):
+    L.spx_matvec_kernel(0.5, C.c_void_p(A.handle), xv, 0.25, yv)
+print("library vectors: %.2f ms per spx_matvec_kernel (beta != 0: y travels both ways)" % ((time.perf_counter() - t0) * 100))
 PY
 grep -E 'host vectors|library vectors' $OUT/host_order.txt | cut -c1-400
