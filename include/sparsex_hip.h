@@ -99,6 +99,12 @@
  *                           v->elements must call spx_hip_vec_touch(v) afterwards (a sampled fingerprint of the
  *                           contents is a second net only: a rewritten vector is seen, one poked element may not be).
  *                           Views of user buffers (spx_vec_create_from_buff, both modes) always travel
+ *   spx.vec.register        "auto" (default) | "false": the buffer of a view (spx_vec_create_from_buff) of 32 MB or
+ *                           more is page-locked where it lies (hipHostRegister) when the view is used for its SECOND
+ *                           spx_matvec_* with the same buffer, and released by spx_vec_destroy; it then travels like
+ *                           a vector of the library's own instead of through staging memory.  Invisible to the
+ *                           client (it keeps writing through its own pointer); a buffer that cannot be locked is
+ *                           staged.  The buffer must outlive the view (as src/api/matvec.c:780-815 assumes)
  *   spx.rt.dist_chunks      at most 64 parts (larger values are clamped)
  *   spx.gpu.sym_once        "false": symmetric path reads lower triangle and mirror
  *                           image (default: dense 8x8 tiles are read once)
