@@ -220,20 +220,29 @@ void stream_rowblock_xpieces(const GpuStream &s, size_t ncols, size_t piece, std
             for (uint32_t t = 0; t < rb.n_pass; ++t) {
                 const SpxPass &ps = s.passes[(size_t) rb.pass_off + t];
                 const uint32_t nseg = ps.nseg, W = ps.width;
-                for (uint32_t l = 0; l < nseg; ++l) {
-                    if (is_gather(ps)) {
-                        if (ps.kind == SPX_PASS_GATHER_LDS) continue;       // (the window, above)
+                if (ps.kind == SPX_PASS_GATHER_LDS || nseg == 0) continue;      // (the window, above)
+                if (is_gather(ps)) {
+                    for (uint32_t l = 0; l < nseg; ++l)
                         for (uint32_t w = 0; w < W; ++w) {
                             const int64_t col = gather_col(s, rb, ps, (size_t) ps.elem0 + l + (size_t) w * nseg);
                             hit(col, col);
                         }
-                    } else if (ps.kind == SPX_PASS_SYMTILE) {
+                } else if (ps.kind == SPX_PASS_SYMTILE) {
+                    for (uint32_t l = 0; l < nseg; l += 8) {
                         const SpxUnitDesc &d = s.descs[(size_t) rb.desc_off + ps.rank0 + (l >> 3)];
                         hit((int64_t) d.col0, (int64_t) d.col0 + 7);
-                    } else {
-                        int64_t r, c0;
-                        unit_lane(s, rb, ps, l, r, c0);
-                        hit(c0, c0 + (int64_t) W);              // (+ the value-pair loads' second x of odd widths)
+                    }
+                } else {
+                    // the lanes of a unit step through its columns evenly: its first and its last lane bound them
+                    const uint64_t starts = spx_pass_mask(&ps);
+                    uint32_t first = 0;
+                    for (uint32_t l = 1; l <= nseg; ++l) {
+                        if (l < nseg && !((starts >> l) & 1ull)) continue;
+                        int64_t r, ca, cb;
+                        unit_lane(s, rb, ps, first, r, ca);
+                        unit_lane(s, rb, ps, l - 1, r, cb);
+                        hit(std::min(ca, cb), std::max(ca, cb) + (int64_t) W);     // (+ the value-pair loads' second x of odd widths)
+                        first = l;
                     }
                 }
             }
