@@ -92,3 +92,47 @@ def test_full_size_symmetric_path_agrees_with_general(case):
     lhs, rhs = float(z @ ys), float(x @ zs)
     tol = float(np.abs(z) @ bound(a, x, 0.5) + np.abs(x) @ bound(a, z, 0.5)) + 1e-300
     assert abs(lhs - rhs) <= tol
+
+
+def test_full_size_library_vectors(case):
+    """spx_matvec_mult / spx_matvec_kernel on vectors the library created (page-locked): on the bench matrix x goes
+    up piece by piece in the order the parts of the product need it while finished rows of y come back, and with
+    beta != 0 a part's rows of y go up the same way (device_spmv_host) -- general and symmetric path against CSR.
+    A product with another x comes first: a piece the plan forgot would still hold it."""
+    import ctypes as C
+    from sparsex_amd.api import VectorStruct
+    name, csr, a, A, symmetric = case
+    n = csr[3]
+    L = sx.lib()
+    L.spx_vec_create_random.restype = C.POINTER(VectorStruct); L.spx_vec_create_random.argtypes = [C.c_size_t, C.c_void_p]
+    L.spx_vec_create.restype = C.POINTER(VectorStruct); L.spx_vec_create.argtypes = [C.c_size_t, C.c_void_p]
+    L.spx_mat_get_partition.restype = C.c_void_p
+    L.spx_matvec_kernel.argtypes = [C.c_double, C.c_void_p, C.POINTER(VectorStruct), C.c_double, C.POINTER(VectorStruct)]
+    L.spx_hip_mat_host_parts.restype = C.c_int
+    L.spx_hip_mat_host_order.restype = C.c_int
+    L.spx_hip_mat_host_order.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
+    mats = [A] + ([tune(csr, {"spx.rt.nr_threads": "8", "spx.rt.keep_encoded": "false"}, sym=True)] if symmetric else [])
+    for M in mats:
+        part = C.c_void_p(L.spx_mat_get_partition(C.c_void_p(M.handle)))
+        xv, yv = L.spx_vec_create_random(n, part), L.spx_vec_create(n, part)
+        xa = np.ctypeslib.as_array(xv.contents.elements, shape=(n,))
+        ya = np.ctypeslib.as_array(yv.contents.elements, shape=(n,))
+        x1, y0 = synth.random_x(n, seed=31), synth.random_x(n, seed=37)
+        xa[:] = np.nan
+        assert L.spx_matvec_mult(C.c_double(0.5), C.c_void_p(M.handle), xv, yv) == 0
+        xa[:] = x1
+        ya[:] = np.nan
+        assert L.spx_matvec_mult(C.c_double(0.5), C.c_void_p(M.handle), xv, yv) == 0
+        check_y(csr, x1, ya.copy(), 0.5)
+        parts = L.spx_hip_mat_host_parts(C.c_void_p(M.handle))
+        buf = (C.c_int32 * 64)()
+        k = L.spx_hip_mat_host_order(C.c_void_p(M.handle), buf, 64)
+        if n * 8 >= (32 << 20) and (M is A or name.startswith("syn-nlpkkt-e")):
+            # (the bench matrix: cut on both paths -- its symmetric stream's row-blocks all store their own rows)
+            assert parts >= 2 and sorted(buf[i] for i in range(k)) == list(range(parts)), (name, parts, k)
+        ya[:] = y0
+        assert L.spx_matvec_kernel(-1.25, C.c_void_p(M.handle), xv, 0.75, yv) == 0
+        check_y(csr, x1, ya.copy(), -1.25, 0.75, y0)
+        L.spx_vec_destroy(xv); L.spx_vec_destroy(yv)
+        if M is not A:
+            M.destroy()
