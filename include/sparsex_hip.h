@@ -106,6 +106,9 @@
  *                           client (it keeps writing through its own pointer); a buffer that cannot be locked is
  *                           staged.  The buffer must outlive the view (as src/api/matvec.c:780-815 assumes)
  *   spx.rt.dist_chunks      at most 64 parts (larger values are clamped)
+ *   spx.rt.host_parts       spx_matvec_* on host vectors of 32 MB or more: the number of parts the product runs in
+ *                           while y travels back (and x up) part by part; "0" (default): 24 where x goes up by need
+ *                           (16 on symmetric streams), else 8; at most 64.  Read at every call
  *   spx.gpu.sym_once        "false": symmetric path reads lower triangle and mirror
  *                           image (default: dense 8x8 tiles are read once)
  *   spx.gpu.sym_remine      "false": symmetric path mirrors unit by unit

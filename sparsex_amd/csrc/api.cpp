@@ -2073,6 +2073,7 @@ static spx_error_t run_host(const spx_matrix_t *A, spx_value_t alpha, const spx_
         std::function<void(double *, void *)> after;
         if (A->dist) after = [A](double *d_y, void *st) { dist_complete(A->dist, d_y, true, false, st); };
         const bool x_locked = vec_page_locked(x), y_locked = vec_page_locked(y);
+        device_set_host_parts(A->dev, (size_t) std::max<long>(0, Config::instance().get_long("spx.rt.host_parts")));
         device_spmv_host(A->dev, alpha, x->elements, x_locked, beta, y->elements, y_locked, after, vec_version(x));
         vec_touch(y);
     } catch (const FatalError &e) {

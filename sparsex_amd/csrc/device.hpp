@@ -92,6 +92,7 @@ int device_get_waves(const DeviceMatrix *m);
 // the stream was uploaded with a window budget and some row-block's columns fit it
 bool device_has_xw(const DeviceMatrix *m);
 int device_host_order(const DeviceMatrix *m, int32_t *order, int cap);   // the order of those parts when x went up piece by piece as they needed it (returns their number; 0: x went up whole or not at all)
+void device_set_host_parts(DeviceMatrix *m, size_t parts);   // spx.rt.host_parts: 0 = the built-in choice, else at most 64
 int device_host_parts(const DeviceMatrix *m);   // parts of the last product on host vectors whose y went back part by part (0: whole)
 void device_set_xw(DeviceMatrix *m, bool on);
 bool device_get_xw(const DeviceMatrix *m);

@@ -447,6 +447,7 @@ struct DeviceMatrix {
     std::vector<hipEvent_t> part_events;        // one behind every part of a product whose y travels back in parts
     int host_parts = 0;                         // parts of the last product on host vectors (0: in one piece)
     bool host_x_by_need = false;                // ... and whether x went up in the order the parts needed it
+    size_t host_parts_want = 0;                 // spx.rt.host_parts (0: HOST_PARTS / HOST_PARTS_X)
     size_t value_bytes = 0, index_bytes = 0;
     size_t n_values = 0, n_descs = 0, n_passes = 0, n_cidx = 0, n_segrows = 0;
     // every array of the stream lives in ONE allocation (2 MB-aligned pieces): one mapping, one
@@ -502,7 +503,7 @@ struct DeviceMatrix {
 // the host-vector entry point (device_spmv_host)
 constexpr size_t STAGE_PIECE = (size_t) 16 << 20;      // bytes
 constexpr size_t HOST_PARTS = 8;                       // parts of a product whose y goes back part by part ...
-constexpr size_t HOST_PARTS_X = 16;                    // ... (general streams whose x comes piece by piece: finer)
+constexpr size_t HOST_PARTS_X = 24, HOST_PARTS_X_SYM = 16;    // ... (x comes piece by piece: finer; swept on the bench matrix, profiles/r06/host_parts_sweep.txt)
 constexpr size_t HOST_X_PIECE = (size_t) 4 << 20;      // ... in pieces of this many bytes
 constexpr size_t HOST_PARTS_MIN_BYTES = (size_t) 32 << 20;   // ... where y is at least this large
 
@@ -1359,6 +1360,7 @@ void device_set_waves(DeviceMatrix *m, int waves)
 int device_get_waves(const DeviceMatrix *m) { return m->waves; }
 
 int device_host_parts(const DeviceMatrix *m) { return m ? m->host_parts : 0; }
+void device_set_host_parts(DeviceMatrix *m, size_t parts) { m->host_parts_want = std::min<size_t>(parts, 64); }
 
 int device_host_order(const DeviceMatrix *m, int32_t *order, int cap)
 {
@@ -1489,7 +1491,7 @@ void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x, bool x_p
     const bool send_x = !x_version || x_version != m->x_version;
     const bool want_by_need = send_x && x_pinned && !m->rb_xneed.empty();
     const size_t K = (!after && whole && yb >= host_parts_min_bytes())
-                         ? device_plan_chunks(m, want_by_need ? HOST_PARTS_X : HOST_PARTS, bounds, 2) : 0;
+                         ? device_plan_chunks(m, m->host_parts_want ? m->host_parts_want : (want_by_need ? (m->symmetric ? HOST_PARTS_X_SYM : HOST_PARTS_X) : HOST_PARTS), bounds, 2) : 0;
     const DeviceMatrix::ChunkPlan &cp = m->chunks[2];
     const bool x_by_need = want_by_need && K >= 2 && cp.order.size() == K && cp.step_pieces.size() == K;
     if (send_x && !x_by_need) {
