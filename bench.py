@@ -683,7 +683,7 @@ def host_api_rate(A, xh, n, nnz, calls=20):
     L.spx_mat_get_partition.restype = C.c_void_p
     L.spx_partition_destroy.argtypes = [C.c_void_p]
     part = C.c_void_p(L.spx_mat_get_partition(C.c_void_p(A.handle)))
-    for key, resident, what in (("library_vectors", "false", "default options: x up with every call, y down"),
+    for key, resident, what in (("library_vectors", "false", "default options: x up with every call in the order the parts of the product need it, their rows of y down meanwhile"),
                                 ("library_vectors_resident", "true", "spx.vec.device=true: x resident in HBM between calls, y down")):
         sx.option_set("spx.vec.device", resident)           # (read when a vector is created)
         xv, yv = L.spx_vec_create_random(n, part), L.spx_vec_create(n, part)
