@@ -3,6 +3,14 @@
 #include "threads.hpp"
 
 #include <cerrno>
+#include <charconv>
+#include <chrono>
+#include <cstring>
+#include <fstream>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -83,10 +91,10 @@ static std::string trim(const std::string &s)
     return s.substr(a, b - a + 1);
 }
 
-bool MmfInput::read_line(std::vector<std::string> &args)
+static bool read_line(std::istream &in, std::vector<std::string> &args)
 {
     std::string buff;
-    if (!std::getline(in_, buff)) return false;
+    if (!std::getline(in, buff)) return false;
     buff = trim(buff);
     args.clear();
     std::istringstream ss(buff);
@@ -107,13 +115,13 @@ static bool parse3(const std::vector<std::string> &a, long &y, long &x, double &
 
 MmfInput::MmfInput(const char *filename) : filename_(filename)
 {
-    in_.open(filename);
-    if (!in_.is_open()) {
+    std::ifstream in(filename);
+    if (!in.is_open()) {
         log_msg(LOG_ERR, "MMF file error\n");
         throw FatalError("cannot open MMF file");
     }
     std::vector<std::string> args;
-    if (!read_line(args) || args.empty()) {
+    if (!read_line(in, args) || args.empty()) {
         log_msg(LOG_ERR, "size line error in MMF file\n");
         throw FatalError("empty MMF file");
     }
@@ -158,166 +166,349 @@ MmfInput::MmfInput(const char *filename) : filename_(filename)
     // size line (after optional comment lines)
     bool skip_comments = !headerless || (!args.empty() && args[0][0] == '%');
     if (skip_comments) {
-        while (in_.peek() == '%')
-            in_.ignore(std::numeric_limits<std::streamsize>::max(), '\n');
-        if (!read_line(args)) {
+        while (in.peek() == '%')
+            in.ignore(std::numeric_limits<std::streamsize>::max(), '\n');
+        if (!read_line(in, args)) {
             log_msg(LOG_ERR, "size line error in MMF file\n");
             throw FatalError("size line");
         }
     }
     long r, c; double n;
-    if (!parse3(args, r, c, n)) {
+    if (!parse3(args, r, c, n) || r < 0 || c < 0 || n < 0 || r > (long) std::numeric_limits<idx_t>::max() ||
+        c > (long) std::numeric_limits<idx_t>::max()) {
         log_msg(LOG_ERR, "bad input, less arguments in line of MMF file\n");
         throw FatalError("size line");
     }
     nr_rows = (size_t) r;
     nr_cols = (size_t) c;
     declared_nnz_ = (size_t) n;
-    data_start_ = in_.tellg();
+    const std::streampos at = in.tellg();
+    data_start_ = at == std::streampos(-1) ? (size_t) -1 : (size_t) at;     // (-1: the size line was the last line)
     if (symmetric || col_wise) {
-        load_all();
-        nnz = matrix_.size();    // Mmf.hpp:86-92
+        load();
+        nnz = colind_.size();    // Mmf.hpp:86-92
     } else {
         nnz = declared_nnz_;
     }
-    rewind();
 }
 
-bool MmfInput::next_from_file(Triplet &t)
+namespace {
+
+inline double now_seconds()
 {
-    std::vector<std::string> args;
-    if (!read_line(args)) return false;
-    long r, c; double v;
-    if (!parse3(args, r, c, v)) {
-        log_msg(LOG_ERR, "bad input, less arguments in line of MMF file\n");
-        throw FatalError("bad entry line");
+    using namespace std::chrono;
+    return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+
+inline bool mm_blank(char ch) { return ch == ' ' || ch == '\t' || ch == '\r'; }
+
+// strtol's grammar on [p, lim): blanks, an optional sign, digits
+inline bool mm_long(const char *&p, const char *lim, long &out)
+{
+    while (p < lim && mm_blank(*p)) ++p;
+    bool neg = false;
+    if (p < lim && (*p == '+' || *p == '-')) { neg = *p == '-'; ++p; }
+    if (p >= lim || *p < '0' || *p > '9') return false;
+    long v = 0;
+    while (p < lim && *p >= '0' && *p <= '9') {
+        v = v * 10 + (*p - '0');
+        if (v > ((long) 1 << 40)) return false;            // (no index is that large)
+        ++p;
     }
-    if (zero_based) { ++r; ++c; }
-    t.row = (idx_t) r; t.col = (idx_t) c; t.val = v;
+    out = neg ? -v : v;
     return true;
 }
 
-void MmfInput::load_all()
+// strtod's grammar on [p, lim): std::from_chars where it takes the whole token, strtod itself (on a copy: the
+// mapping has no terminating null) for what from_chars leaves -- a leading '+', hexadecimal, out-of-range
+inline bool mm_double(const char *&p, const char *lim, double &out)
 {
-    // Mmf.hpp:445-478: read everything, mirror the stored triangle of a
-    // symmetric file, sort row-major
-    matrix_.reserve(symmetric ? declared_nnz_ * 2 : declared_nnz_);
-    // The file is read in large chunks and parsed in place (one "row col value"
-    // line per entry, as read_line()/parse3() demand): a SuiteSparse file of
-    // a few hundred million entries is minutes through line-by-line iostreams.
-    const size_t CHUNK = (size_t) 64 << 20;
-    std::string buf;
-    size_t have = 0;              // valid bytes in buf
-    size_t pos = 0;               // parse position
-    bool eof = false;
-    auto refill = [&]() {         // keeps the unparsed tail, appends the next chunk
-        if (pos > 0) {
-            buf.erase(0, pos);
-            have -= pos;
-            pos = 0;
+    while (p < lim && mm_blank(*p)) ++p;
+    if (p >= lim) return false;
+    const std::from_chars_result r = std::from_chars(p, lim, out);
+    if (r.ec == std::errc() && (r.ptr == lim || mm_blank(*r.ptr))) {
+        p = r.ptr;
+        return true;
+    }
+    char tmp[128];
+    const size_t n = std::min<size_t>((size_t) (lim - p), sizeof(tmp) - 1);
+    std::memcpy(tmp, p, n);
+    tmp[n] = '\0';
+    char *e = nullptr;
+    out = strtod(tmp, &e);
+    if (e == tmp) return false;
+    p += e - tmp;
+    return true;
+}
+
+struct MmPiece {
+    const char *begin = nullptr, *end = nullptr;
+    std::vector<Triplet> got;          // entries in file order (1-based after the base shift)
+    bool bad = false;                  // the line behind them does not parse
+    bool sorted = true;                // row-major ascending inside the piece
+};
+
+void mm_parse_piece(MmPiece &pc, bool zero_based)
+{
+    const char *p = pc.begin, *const end = pc.end;
+    pc.got.reserve((size_t) (end - p) / 24 + 16);
+    idx_t pr = 0, pcn = 0;
+    while (p < end) {
+        const char *eol = static_cast<const char *>(std::memchr(p, '\n', (size_t) (end - p)));
+        const char *lim = eol ? eol : end;
+        const char *q = p;
+        long r = 0, c = 0;
+        double v = 0.0;
+        bool ok = mm_long(q, lim, r) && mm_long(q, lim, c) && mm_double(q, lim, v);
+        while (ok && q < lim && mm_blank(*q)) ++q;
+        if (!ok || q != lim) {
+            pc.bad = true;
+            return;
         }
-        if (eof) return;
-        buf.resize(have + CHUNK);
-        in_.read(&buf[have], (std::streamsize) CHUNK);
-        const size_t got = (size_t) in_.gcount();
-        have += got;
-        buf.resize(have);
-        if (got < CHUNK) eof = true;
-    };
-    refill();
-    for (size_t i = 0; i < declared_nnz_; ++i) {
-        // a whole line must be in the buffer
-        size_t eol = buf.find('\n', pos);
-        if (eol == std::string::npos && !eof) {
-            refill();
-            eol = buf.find('\n', pos);
-        }
-        if (eol == std::string::npos) eol = have;
-        if (pos >= have) {
-            log_msg(LOG_ERR, "Requesting dereference, but mmf ended.\n");
-            throw FatalError("short MMF file");
-        }
-        // (strto* stop at the string's terminating null at the latest)
-        char *b = &buf[pos], *e = nullptr;
-        const char *lim = &buf[0] + eol;
-        auto blank = [](char ch) { return ch == ' ' || ch == '\t' || ch == '\r'; };
-        errno = 0;
-        const long r0 = strtol(b, &e, 10);
-        bool ok = e != b && e <= lim;
-        b = e;
-        const long c0 = ok ? strtol(b, &e, 10) : 0;
-        ok = ok && e != b && e <= lim;
-        b = e;
-        const double v = ok ? strtod(b, &e) : 0.0;
-        ok = ok && e != b && e <= lim;
-        while (ok && e < lim && blank(*e)) ++e;
-        if (!ok || e != lim) {
-            log_msg(LOG_ERR, "bad input, less arguments in line of MMF file\n");
-            throw FatalError("bad entry line");
-        }
-        pos = eol < have ? eol + 1 : have;
         Triplet t;
-        t.row = (idx_t)(zero_based ? r0 + 1 : r0);
-        t.col = (idx_t)(zero_based ? c0 + 1 : c0);
+        t.row = (idx_t) (zero_based ? r + 1 : r);
+        t.col = (idx_t) (zero_based ? c + 1 : c);
         t.val = v;
-        matrix_.push_back(t);
-        if (symmetric && t.row != t.col) {
-            Triplet m = t;
-            std::swap(m.row, m.col);
-            matrix_.push_back(m);
+        if (t.row < pr || (t.row == pr && t.col < pcn)) pc.sorted = false;
+        pr = t.row;
+        pcn = t.col;
+        pc.got.push_back(t);
+        p = eol ? eol + 1 : end;
+    }
+}
+
+struct MappedFile {
+    const char *data = nullptr;
+    size_t size = 0;
+    int fd = -1;
+    explicit MappedFile(const std::string &name)
+    {
+        fd = open(name.c_str(), O_RDONLY);
+        struct stat st;
+        if (fd < 0 || fstat(fd, &st) != 0) {
+            if (fd >= 0) close(fd);
+            log_msg(LOG_ERR, "MMF file error\n");
+            throw FatalError("cannot open MMF file");
+        }
+        size = (size_t) st.st_size;
+        if (size) {
+            void *m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) {
+                close(fd);
+                log_msg(LOG_ERR, "MMF file error\n");
+                throw FatalError("cannot map MMF file");
+            }
+            (void) madvise(m, size, MADV_SEQUENTIAL);
+            data = static_cast<const char *>(m);
         }
     }
-    std::sort(matrix_.begin(), matrix_.end(), [](const Triplet &a, const Triplet &b) {
-        return a.row < b.row || (a.row == b.row && a.col < b.col);
+    ~MappedFile()
+    {
+        if (data) munmap(const_cast<char *>(data), size);
+        if (fd >= 0) close(fd);
+    }
+    MappedFile(const MappedFile &) = delete;
+    MappedFile &operator=(const MappedFile &) = delete;
+};
+
+}  // namespace
+
+void MmfInput::load()
+{
+    if (loaded_) return;
+    const double t0 = now_seconds();
+    const unsigned T = host_threads();
+    std::vector<MmPiece> pieces;
+    {
+        MappedFile f(filename_);
+        const size_t lo = std::min(data_start_, f.size), len = f.size - lo;
+        // pieces of about 8 MB, cut behind line ends
+        const size_t n_pieces = std::max<size_t>(1, std::min<size_t>(len / ((size_t) 8 << 20) + 1, (size_t) 1 << 16));
+        pieces.resize(n_pieces);
+        std::vector<size_t> cut(n_pieces + 1, f.size);
+        cut[0] = lo;
+        for (size_t k = 1; k < n_pieces; ++k) {
+            size_t at = lo + len / n_pieces * k;
+            if (at <= cut[k - 1]) at = cut[k - 1];
+            if (at > lo && f.data[at - 1] != '\n') {
+                const void *nl = at < f.size ? std::memchr(f.data + at, '\n', f.size - at) : nullptr;
+                at = nl ? (size_t) (static_cast<const char *>(nl) - f.data) + 1 : f.size;
+            }
+            cut[k] = at;
+        }
+        for (size_t k = 0; k < n_pieces; ++k) {
+            pieces[k].begin = f.data + cut[k];
+            pieces[k].end = f.data + std::max(cut[k], cut[k + 1]);
+        }
+        const bool zb = zero_based;
+        parallel_for(n_pieces, T, [&](size_t k) { mm_parse_piece(pieces[k], zb); });
+    }
+    const double t_parsed = now_seconds();
+    // the entries the size line claims, in file order: a line that does not parse among them is an error, what
+    // follows them is not looked at (the reference reads that many lines and stops, Mmf.hpp:445-478)
+    std::vector<size_t> first(pieces.size() + 1, 0);
+    size_t have = 0;
+    for (size_t k = 0; k < pieces.size(); ++k) {
+        first[k] = have;
+        have += pieces[k].got.size();
+        if (pieces[k].bad) {
+            if (have < declared_nnz_) {
+                log_msg(LOG_ERR, "bad input, less arguments in line of MMF file\n");
+                throw FatalError("bad entry line");
+            }
+            for (size_t j = k + 1; j < pieces.size(); ++j) {         // (nothing behind a bad line counts)
+                first[j] = have;
+                pieces[j].got.clear();
+            }
+            break;
+        }
+    }
+    first[pieces.size()] = have;
+    if (have < declared_nnz_) {
+        log_msg(LOG_ERR, "Requesting dereference, but mmf ended (cnt: %zu/%zu).\n", have, declared_nnz_);
+        throw FatalError("short MMF file");
+    }
+    for (size_t k = 0; k < pieces.size(); ++k) {                 // keep the first declared_nnz_ entries
+        const size_t keep = first[k] >= declared_nnz_ ? 0 : std::min(pieces[k].got.size(), declared_nnz_ - first[k]);
+        pieces[k].got.resize(keep);
+    }
+    const bool streamed = !symmetric && !col_wise;
+    if (streamed) {
+        // entries of a file that promises row-major order must come sorted (Mmf.hpp:259-263)
+        bool sorted = true;
+        const Triplet *prev = nullptr;
+        for (const MmPiece &pc : pieces) {
+            if (pc.got.empty()) continue;
+            if (!pc.sorted && pc.got.size() > 1) {
+                // (`sorted` was tracked over the whole piece: look again over what was kept)
+                for (size_t i = 1; i < pc.got.size() && sorted; ++i)
+                    if (pc.got[i].row < pc.got[i - 1].row || (pc.got[i].row == pc.got[i - 1].row && pc.got[i].col < pc.got[i - 1].col))
+                        sorted = false;
+            }
+            if (prev && (pc.got.front().row < prev->row || (pc.got.front().row == prev->row && pc.got.front().col < prev->col)))
+                sorted = false;
+            prev = &pc.got.back();
+        }
+        if (!sorted) {
+            log_msg(LOG_ERR, "indices are not sorted in MMF file\n");
+            throw FatalError("unsorted MMF file");
+        }
+    }
+    // coordinates inside the matrix (the reference does not look; a counting sort must)
+    std::atomic<bool> inside(true);
+    const size_t n_rows = nr_rows, n_cols = nr_cols;
+    const bool sym = symmetric;
+    parallel_for(pieces.size(), T, [&](size_t k) {
+        for (const Triplet &t : pieces[k].got)
+            if (t.row < 1 || (size_t) t.row > n_rows || t.col < 1 || (size_t) t.col > n_cols ||
+                (sym && ((size_t) t.col > n_rows || (size_t) t.row > n_cols)))
+                inside.store(false, std::memory_order_relaxed);
     });
+    if (!inside.load()) {
+        log_msg(LOG_ERR, "bad input, an entry lies outside the matrix in MMF file\n");
+        throw FatalError("entry outside the matrix");
+    }
+    // rows: how many entries each holds (a symmetric file's off-diagonal entries count twice), where each starts
+    std::vector<uint32_t> count(n_rows + 1, 0u);
+    parallel_for(pieces.size(), T, [&](size_t k) {
+        for (const Triplet &t : pieces[k].got) {
+            __atomic_fetch_add(&count[(size_t) t.row - 1], 1u, __ATOMIC_RELAXED);
+            if (sym && t.row != t.col) __atomic_fetch_add(&count[(size_t) t.col - 1], 1u, __ATOMIC_RELAXED);
+        }
+    });
+    size_t total = 0;
+    for (size_t r = 0; r < n_rows; ++r) total += count[r];
+    if (total > (size_t) std::numeric_limits<idx_t>::max() - 1) {
+        log_msg(LOG_ERR, "MMF file holds more entries than the index type counts\n");
+        throw FatalError("too many entries");
+    }
+    rowptr_.assign(n_rows + 1, 1);
+    for (size_t r = 0; r < n_rows; ++r) rowptr_[r + 1] = rowptr_[r] + (idx_t) count[r];
+    const double t_counted = now_seconds();
+    colind_.resize(total);
+    values_.resize(total);
+    if (streamed) {
+        // already in place: entry i of the file is element i
+        parallel_for(pieces.size(), T, [&](size_t k) {
+            size_t at = first[k];
+            for (const Triplet &t : pieces[k].got) {
+                colind_[at] = t.col;
+                values_[at] = t.val;
+                ++at;
+            }
+        });
+    } else {
+        std::vector<uint32_t> fill(n_rows, 0u);
+        parallel_for(pieces.size(), T, [&](size_t k) {
+            for (const Triplet &t : pieces[k].got) {
+                size_t at = (size_t) (rowptr_[(size_t) t.row - 1] - 1) + __atomic_fetch_add(&fill[(size_t) t.row - 1], 1u, __ATOMIC_RELAXED);
+                colind_[at] = t.col;
+                values_[at] = t.val;
+                if (sym && t.row != t.col) {
+                    at = (size_t) (rowptr_[(size_t) t.col - 1] - 1) + __atomic_fetch_add(&fill[(size_t) t.col - 1], 1u, __ATOMIC_RELAXED);
+                    colind_[at] = t.row;
+                    values_[at] = t.val;
+                }
+            }
+            std::vector<Triplet>().swap(pieces[k].got);
+        });
+        // every row by column (entries of one place: by value, so that the result does not depend on which
+        // thread came first)
+        constexpr size_t ROWS = 4096;
+        parallel_for((n_rows + ROWS - 1) / ROWS, T, [&](size_t c) {
+            std::vector<std::pair<idx_t, val_t>> tmp;
+            for (size_t r = c * ROWS; r < std::min(n_rows, (c + 1) * ROWS); ++r) {
+                const size_t a = (size_t) (rowptr_[r] - 1), b = (size_t) (rowptr_[r + 1] - 1);
+                bool ascending = true;
+                for (size_t j = a + 1; j < b && ascending; ++j) ascending = colind_[j] > colind_[j - 1];
+                if (ascending) continue;
+                tmp.clear();
+                for (size_t j = a; j < b; ++j) tmp.emplace_back(colind_[j], values_[j]);
+                std::sort(tmp.begin(), tmp.end(), [](const std::pair<idx_t, val_t> &x, const std::pair<idx_t, val_t> &y) {
+                    if (x.first != y.first) return x.first < y.first;
+                    uint64_t bx, by;
+                    std::memcpy(&bx, &x.second, 8);
+                    std::memcpy(&by, &y.second, 8);
+                    return bx < by;
+                });
+                for (size_t j = a; j < b; ++j) {
+                    colind_[j] = tmp[j - a].first;
+                    values_[j] = tmp[j - a].second;
+                }
+            }
+        });
+    }
+    pieces.clear();
+    csr_.reset(new CsrInput(rowptr_.data(), colind_.data(), values_.data(), (idx_t) n_rows, (idx_t) n_cols, false));
     loaded_ = true;
+    const double t_end = now_seconds();
+    log_msg(LOG_INFO, "MMF file: %zu entries read, %zu elements in %zu rows, %.2f s on %u threads (parsed in %.2f s, rows counted in "
+            "%.2f s, placed and sorted in %.2f s)\n", declared_nnz_, total, n_rows, t_end - t0, T, t_parsed - t0, t_counted - t_parsed,
+            t_end - t_counted);
 }
 
 void MmfInput::rewind()
 {
-    cursor_ = 0;
-    if (!loaded_) {
-        in_.clear();
-        in_.seekg(data_start_);
-        have_cur_ = false;
-        streamed_ = 0;
-        row_prev_ = 1;
-        col_prev_ = 1;
-    }
+    load();
+    csr_->rewind();
 }
 
 bool MmfInput::peek(Triplet &t)
 {
-    if (loaded_) {
-        if (cursor_ >= matrix_.size()) return false;
-        t = matrix_[cursor_];
-        return true;
-    }
-    if (streamed_ >= nnz) return false;
-    if (!have_cur_) {
-        if (!next_from_file(cur_)) {
-            log_msg(LOG_ERR, "Requesting dereference, but mmf ended (cnt: %zu/%zu).\n",
-                    streamed_, nnz);
-            throw FatalError("short MMF file");
-        }
-        // entries of a header-less file must come sorted (Mmf.hpp:259-263)
-        if (cur_.row < row_prev_ || (cur_.row == row_prev_ && cur_.col < col_prev_)) {
-            log_msg(LOG_ERR, "indices are not sorted in MMF file\n");
-            throw FatalError("unsorted MMF file");
-        }
-        col_prev_ = cur_.col;
-        row_prev_ = cur_.row;
-        have_cur_ = true;
-    }
-    t = cur_;
-    return true;
+    load();
+    return csr_->peek(t);
 }
 
 void MmfInput::advance()
 {
-    if (loaded_) { ++cursor_; return; }
-    have_cur_ = false;
-    ++streamed_;
+    load();
+    csr_->advance();
+}
+
+CsrInput *MmfInput::as_csr()
+{
+    load();
+    return csr_.get();
 }
 
 // ---- partitioning ---------------------------------------------------------------------
@@ -395,7 +586,7 @@ struct CsrView {
 // rows in ascending column order and row pointers that never step back?  (else: the general walk)
 bool csr_view(MatrixInput &in, CsrView &v)
 {
-    CsrInput *c = dynamic_cast<CsrInput *>(&in);
+    CsrInput *c = in.as_csr();
     if (!c || in.nr_rows == 0) return false;
     v.rowptr = c->rowptr_;
     v.colind = c->colind_;

@@ -32,6 +32,9 @@ public:
     // false at the end of the stream; does not advance
     virtual bool peek(Triplet &t) = 0;
     virtual void advance() = 0;
+    // the input as CSR arrays, where it holds them (the partition builder then cuts them with all host threads
+    // instead of walking element by element); may load the input and throw what loading throws
+    virtual class CsrInput *as_csr() { return nullptr; }
 };
 
 class CsrInput : public MatrixInput {
@@ -41,6 +44,7 @@ public:
     void rewind() override;
     bool peek(Triplet &t) override;
     void advance() override;
+    CsrInput *as_csr() override { return this; }
 
     const idx_t *rowptr_, *colind_;
     const val_t *values_;
@@ -54,33 +58,35 @@ private:
     size_t sorted_for_row_ = (size_t) -1;
 };
 
+// A Matrix Market file.  The reference reads it entry by entry through an ifstream (Mmf.hpp:331-478) -- and a
+// SuiteSparse file of a few hundred million entries takes minutes that way.  Here the file is mapped, cut at line
+// ends into pieces that all host threads parse, and turned into CSR arrays (a counting sort by row, rows sorted by
+// column), which the partition builder then cuts like a client's CSR input.  What the reference's reader accepts
+// and rejects, and WHEN it rejects it, stays: a symmetric or not-row-sorted file is loaded, mirrored and sorted
+// when it is opened (Mmf.hpp:445-478; nnz = what it then holds, :86-92); a file that promises row-major order
+// (no banner, or the `row` keyword) is read when the tuner first asks for an element, must be sorted
+// (:259-263) and must hold the entries its size line claims.
 class MmfInput : public MatrixInput {
 public:
     explicit MmfInput(const char *filename);   // throws FatalError
     void rewind() override;
     bool peek(Triplet &t) override;
     void advance() override;
+    CsrInput *as_csr() override;
 
     bool symmetric = false;   // banner says symmetric (file holds one triangle)
     bool col_wise = true;     // entries not guaranteed row-major
     bool zero_based = false;
 private:
-    bool read_line(std::vector<std::string> &args);
-    bool next_from_file(Triplet &t);
-    void load_all();
+    void load();              // the whole file into rowptr_ / colind_ / values_ (1-based), once
 
-    std::ifstream in_;
     std::string filename_;
     size_t declared_nnz_ = 0;
-    bool loaded_ = false;               // whole file in memory, sorted
-    std::vector<Triplet> matrix_;
-    size_t cursor_ = 0;
-    std::streampos data_start_;
-    // streaming state (header-less, sorted files)
-    bool have_cur_ = false;
-    Triplet cur_{};
-    size_t streamed_ = 0;
-    idx_t row_prev_ = 1, col_prev_ = 1;
+    size_t data_start_ = 0;             // offset of the first entry line
+    bool loaded_ = false;
+    std::vector<idx_t> rowptr_, colind_;
+    std::vector<val_t> values_;
+    std::unique_ptr<CsrInput> csr_;
 };
 
 // Splits the stream into `nr` row partitions of (roughly) equal nonzero
