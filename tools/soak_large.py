@@ -1,6 +1,6 @@
 """Randomised parity on larger matrices (20 k - 300 k rows: many row-blocks, slot windows that
 overflow, wide row-blocks, x windows, 24-bit column offsets), on the GPU against CSR.
-usage: python tools/soak_large.py <first seed> <last seed> [--host | --roundtrip]   (--host: tune host-only
+usage: python tools/soak_large.py <first seed> <last seed> [--host | --roundtrip | --library-vectors]   (--host: tune host-only
 and check the decoded stream instead -- runs without a GPU; --roundtrip: also set entries, save, restore,
 multiply again; SOAK_SIZES=1000000,3000000 for matrices big enough for the size-dependent choices,
 e.g. read-once segments in "auto")"""
@@ -123,6 +123,7 @@ def options(seed, symmetric):
 
 bad = 0
 ran_sx = ran_xw = 0          # how many of the products ran through the pipelined kernels
+by_need = 0                  # (--library-vectors) how many had x sent piece by piece in the order the parts needed it
 sx_share = []
 for seed in range(a0, b0):
     sym = seed % 3 != 0
@@ -153,6 +154,36 @@ for seed in range(a0, b0):
             y = y0.copy()
             A.matvec_kernel(2.0, x, -0.5, y)
             check_y(csr, x, y, 2.0, -0.5, y0)
+            if "--library-vectors" in sys.argv:
+                # the same through vectors the library created (page-locked): with SPX_HOST_PARTS_MIN_BYTES and
+                # SPX_HOST_XPIECE_BYTES lowered, x (and y, beta != 0) go up piece by piece in the order the parts need
+                # them; a product with another x first, so that a piece the plan forgot shows
+                import ctypes as C
+                import sparsex_amd as sx
+                from sparsex_amd.api import VectorStruct
+                L = sx.lib()
+                L.spx_vec_create_random.restype = C.POINTER(VectorStruct); L.spx_vec_create_random.argtypes = [C.c_size_t, C.c_void_p]
+                L.spx_vec_create.restype = C.POINTER(VectorStruct); L.spx_vec_create.argtypes = [C.c_size_t, C.c_void_p]
+                L.spx_mat_get_partition.restype = C.c_void_p
+                L.spx_matvec_kernel.argtypes = [C.c_double, C.c_void_p, C.POINTER(VectorStruct), C.c_double, C.POINTER(VectorStruct)]
+                L.spx_hip_mat_host_order.restype = C.c_int
+                L.spx_hip_mat_host_order.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
+                part = C.c_void_p(L.spx_mat_get_partition(C.c_void_p(A.handle)))
+                xv, yv = L.spx_vec_create_random(n, part), L.spx_vec_create(n, part)
+                xa = np.ctypeslib.as_array(xv.contents.elements, shape=(n,))
+                ya = np.ctypeslib.as_array(yv.contents.elements, shape=(n,))
+                xa[:] = np.nan
+                assert L.spx_matvec_mult(C.c_double(0.5), C.c_void_p(A.handle), xv, yv) == 0
+                xa[:] = x
+                ya[:] = np.nan
+                assert L.spx_matvec_mult(C.c_double(0.5), C.c_void_p(A.handle), xv, yv) == 0
+                check_y(csr, x, ya.copy(), 0.5)
+                buf = (C.c_int32 * 64)()
+                by_need += int(L.spx_hip_mat_host_order(C.c_void_p(A.handle), buf, 64) >= 2)
+                ya[:] = y0
+                assert L.spx_matvec_kernel(2.0, C.c_void_p(A.handle), xv, -0.5, yv) == 0
+                check_y(csr, x, ya.copy(), 2.0, -0.5, y0)
+                L.spx_vec_destroy(xv); L.spx_vec_destroy(yv)
             if "--roundtrip" in sys.argv:
                 # a few entries changed, saved, restored in place of the tuned matrix, multiplied again
                 import sparsex_amd as sx
@@ -182,5 +213,5 @@ for seed in range(a0, b0):
         bad += 1
         print("seed %d FAILED: %s %s n %d %s" % (seed, type(e).__name__, str(e)[:200], n, o), flush=True)
 print("seeds [%d, %d): %d failures; csx_spmv_sx_kernel ran on %d matrices (up to %.0f %% of their stored nonzeros in SX passes), "
-      "csx_spmv_xw_kernel on %d" % (a0, b0, bad, ran_sx, 100.0 * max(sx_share or [0.0]), ran_xw))
+      "csx_spmv_xw_kernel on %d; x by need on %d" % (a0, b0, bad, ran_sx, 100.0 * max(sx_share or [0.0]), ran_xw, by_need))
 sys.exit(1 if bad else 0)
