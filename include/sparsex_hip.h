@@ -174,6 +174,10 @@ typedef struct spx_hip_vec spx_hip_vec_t;
 /* spx.vec.device=true only: tells the library that the client wrote to v->elements directly (a vector from
  * spx_vec_create / spx_vec_create_random); the next spx_matvec_* uploads it again.  Harmless otherwise. */
 void spx_hip_vec_touch(const spx_vector_t *v);
+/* Diagnostic: how the vector's host memory travels.  0: through staging memory (pageable); 1: page-locked memory of the
+ * library's own (spx_vec_create, spx_vec_create_random); 2: a client's buffer that the library page-locked in place
+ * (spx.vec.register, from the view's second product on); 3: a client's buffer that was page-locked already. */
+int spx_hip_vec_page_locked(const spx_vector_t *v);
 
 spx_hip_vec_t *spx_hip_vec_create(size_t size);                 /* zero-filled        */
 spx_hip_vec_t *spx_hip_vec_create_from_host(const spx_vector_t *v);

@@ -2679,6 +2679,15 @@ try {
     printf("]\n");
 } SPX_C_BOUNDARY(return;)
 
+int spx_hip_vec_page_locked(const spx_vector_t *v)
+try {
+    if (!v) return 0;
+    if (v->alloc_type == ALLOC_PINNED) return 1;
+    std::lock_guard<std::mutex> lk(g_vec_mtx);
+    auto it = g_vec_reg.find(v);
+    return it != g_vec_reg.end() && it->second.locked && it->second.ptr == (void *) v->elements ? (it->second.ours ? 2 : 3) : 0;
+} SPX_C_BOUNDARY(return 0;)
+
 void spx_vec_destroy(spx_vector_t *v)
 try {
     if (!v) return;

@@ -36,6 +36,8 @@ cases = [("kkt", synth.syn_nlpkkt(22), {}), ("cant", synth.syn_cant(0.4), {}), (
 L = sx.lib()
 L.spx_hip_mat_host_parts.restype = C.c_int
 L.spx_hip_mat_host_order.restype = C.c_int
+L.spx_hip_vec_page_locked.restype = C.c_int
+L.spx_hip_vec_page_locked.argtypes = [C.POINTER(VectorStruct)]
 L.spx_hip_mat_host_order.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
 def host_order(A):
     buf = (C.c_int32 * 32)()
@@ -78,7 +80,9 @@ for name, csr, opts in cases:
         assert L.spx_matvec_mult(C.c_double(0.5), C.c_void_p(A.handle), xw, yw) == 0
         check_y(csr, xb.copy(), yb.copy(), 0.5)
         order, parts_now = host_order(A), L.spx_hip_mat_host_parts(C.c_void_p(A.handle))
-        if rep >= 1 and parts >= 2:
+        locked = L.spx_hip_vec_page_locked(xw)
+        assert locked == (0 if rep == 0 else locked) and (rep == 0 or locked in (0, 2, 3)), (name, rep, locked)
+        if rep >= 1 and parts >= 2 and locked:      # (a box that cannot page-lock client memory stages it: locked == 0)
             # page-locked by now: x went up by need, every part ran once, in the order the plan chose (symmetric
             # streams too: the init pass goes in front of whichever part runs first)
             assert sorted(order) == list(range(parts_now)) and parts_now >= 2, (name, rep, parts_now, order)
@@ -101,7 +105,8 @@ for name, csr, opts in cases:
         check_y(csr, xa.copy(), ya.copy(), 0.5)
         # (library vectors: x is resident after the first call unless spx.vec.device is off and it is sent again;
         # either way, when it was sent to a cut general stream it went by need)
-        assert host_order(A) in ([], orders.get(name, [])), (name, rep, host_order(A), orders.get(name))
+        o = host_order(A)
+        assert o == [] or (sorted(o) == list(range(len(o))) and o == orders.get(name, o)), (name, rep, o, orders.get(name))
     # a changed x is seen (the pieces are sent again, or the resident copy is refreshed)
     xa[:] = synth.random_x(n, seed=11)
     L.spx_hip_vec_touch(xv)
