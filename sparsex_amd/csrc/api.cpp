@@ -1284,7 +1284,7 @@ try {
         }
     }
     if (option == SPX_MAT_REORDER) {
-        TripletInput *re = nullptr;
+        MatrixInput *re = nullptr;
         try {
             re = reorder_rcm(*in->mat, perm, re_mode, re_world);
         } catch (const FatalError &) {

@@ -313,6 +313,96 @@ struct MappedFile {
 
 }  // namespace
 
+void csr_from_triplets(const std::vector<TripletSpan> &spans, size_t n_rows, size_t n_cols, bool mirror, bool in_order,
+                       std::vector<idx_t> &rowptr, std::vector<idx_t> &colind, std::vector<val_t> &values, unsigned T)
+{
+    // coordinates inside the matrix (the reference's reader does not look; a counting sort must)
+    std::atomic<bool> inside(true);
+    parallel_for(spans.size(), T, [&](size_t k) {
+        for (size_t i = 0; i < spans[k].count; ++i) {
+            const Triplet &t = spans[k].first[i];
+            if (t.row < 1 || (size_t) t.row > n_rows || t.col < 1 || (size_t) t.col > n_cols ||
+                (mirror && ((size_t) t.col > n_rows || (size_t) t.row > n_cols)))
+                inside.store(false, std::memory_order_relaxed);
+        }
+    });
+    if (!inside.load()) {
+        log_msg(LOG_ERR, "bad input, an entry lies outside the matrix\n");
+        throw FatalError("entry outside the matrix");
+    }
+    // rows: how many entries each holds (a mirrored off-diagonal entry counts twice), where each starts
+    std::vector<uint32_t> count(n_rows + 1, 0u);
+    parallel_for(spans.size(), T, [&](size_t k) {
+        for (size_t i = 0; i < spans[k].count; ++i) {
+            const Triplet &t = spans[k].first[i];
+            __atomic_fetch_add(&count[(size_t) t.row - 1], 1u, __ATOMIC_RELAXED);
+            if (mirror && t.row != t.col) __atomic_fetch_add(&count[(size_t) t.col - 1], 1u, __ATOMIC_RELAXED);
+        }
+    });
+    size_t total = 0;
+    for (size_t r = 0; r < n_rows; ++r) total += count[r];
+    if (total > (size_t) std::numeric_limits<idx_t>::max() - 1) {
+        log_msg(LOG_ERR, "the matrix holds more entries than the index type counts\n");
+        throw FatalError("too many entries");
+    }
+    rowptr.assign(n_rows + 1, 1);
+    for (size_t r = 0; r < n_rows; ++r) rowptr[r + 1] = rowptr[r] + (idx_t) count[r];
+    colind.resize(total);
+    values.resize(total);
+    if (in_order) {
+        // already in place: entry i is element i
+        std::vector<size_t> first(spans.size() + 1, 0);
+        for (size_t k = 0; k < spans.size(); ++k) first[k + 1] = first[k] + spans[k].count;
+        parallel_for(spans.size(), T, [&](size_t k) {
+            size_t at = first[k];
+            for (size_t i = 0; i < spans[k].count; ++i, ++at) {
+                colind[at] = spans[k].first[i].col;
+                values[at] = spans[k].first[i].val;
+            }
+        });
+        return;
+    }
+    std::vector<uint32_t> fill(n_rows, 0u);
+    parallel_for(spans.size(), T, [&](size_t k) {
+        for (size_t i = 0; i < spans[k].count; ++i) {
+            const Triplet &t = spans[k].first[i];
+            size_t at = (size_t) (rowptr[(size_t) t.row - 1] - 1) + __atomic_fetch_add(&fill[(size_t) t.row - 1], 1u, __ATOMIC_RELAXED);
+            colind[at] = t.col;
+            values[at] = t.val;
+            if (mirror && t.row != t.col) {
+                at = (size_t) (rowptr[(size_t) t.col - 1] - 1) + __atomic_fetch_add(&fill[(size_t) t.col - 1], 1u, __ATOMIC_RELAXED);
+                colind[at] = t.row;
+                values[at] = t.val;
+            }
+        }
+    });
+    // every row by column (entries of one place: by value, so that the result does not depend on which thread
+    // came first)
+    constexpr size_t ROWS = 4096;
+    parallel_for((n_rows + ROWS - 1) / ROWS, T, [&](size_t c) {
+        std::vector<std::pair<idx_t, val_t>> tmp;
+        for (size_t r = c * ROWS; r < std::min(n_rows, (c + 1) * ROWS); ++r) {
+            const size_t a = (size_t) (rowptr[r] - 1), b = (size_t) (rowptr[r + 1] - 1);
+            bool ascending = true;
+            for (size_t j = a + 1; j < b && ascending; ++j) ascending = colind[j] > colind[j - 1];
+            if (ascending) continue;
+            tmp.clear();
+            for (size_t j = a; j < b; ++j) tmp.emplace_back(colind[j], values[j]);
+            std::sort(tmp.begin(), tmp.end(), [](const std::pair<idx_t, val_t> &x, const std::pair<idx_t, val_t> &y) {
+                if (x.first != y.first) return x.first < y.first;
+                uint64_t bx, by;
+                std::memcpy(&bx, &x.second, 8);
+                std::memcpy(&by, &y.second, 8);
+                return bx < by;
+            });
+            for (size_t j = a; j < b; ++j) {
+                colind[j] = tmp[j - a].first;
+                values[j] = tmp[j - a].second;
+            }
+        }
+    });
+}
+
 void MmfInput::load()
 {
     if (loaded_) return;
@@ -394,96 +484,18 @@ void MmfInput::load()
             throw FatalError("unsorted MMF file");
         }
     }
-    // coordinates inside the matrix (the reference does not look; a counting sort must)
-    std::atomic<bool> inside(true);
-    const size_t n_rows = nr_rows, n_cols = nr_cols;
-    const bool sym = symmetric;
-    parallel_for(pieces.size(), T, [&](size_t k) {
-        for (const Triplet &t : pieces[k].got)
-            if (t.row < 1 || (size_t) t.row > n_rows || t.col < 1 || (size_t) t.col > n_cols ||
-                (sym && ((size_t) t.col > n_rows || (size_t) t.row > n_cols)))
-                inside.store(false, std::memory_order_relaxed);
-    });
-    if (!inside.load()) {
-        log_msg(LOG_ERR, "bad input, an entry lies outside the matrix in MMF file\n");
-        throw FatalError("entry outside the matrix");
-    }
-    // rows: how many entries each holds (a symmetric file's off-diagonal entries count twice), where each starts
-    std::vector<uint32_t> count(n_rows + 1, 0u);
-    parallel_for(pieces.size(), T, [&](size_t k) {
-        for (const Triplet &t : pieces[k].got) {
-            __atomic_fetch_add(&count[(size_t) t.row - 1], 1u, __ATOMIC_RELAXED);
-            if (sym && t.row != t.col) __atomic_fetch_add(&count[(size_t) t.col - 1], 1u, __ATOMIC_RELAXED);
-        }
-    });
-    size_t total = 0;
-    for (size_t r = 0; r < n_rows; ++r) total += count[r];
-    if (total > (size_t) std::numeric_limits<idx_t>::max() - 1) {
-        log_msg(LOG_ERR, "MMF file holds more entries than the index type counts\n");
-        throw FatalError("too many entries");
-    }
-    rowptr_.assign(n_rows + 1, 1);
-    for (size_t r = 0; r < n_rows; ++r) rowptr_[r + 1] = rowptr_[r] + (idx_t) count[r];
+    std::vector<TripletSpan> spans;
+    for (const MmPiece &pc : pieces)
+        if (!pc.got.empty()) spans.push_back(TripletSpan{pc.got.data(), pc.got.size()});
     const double t_counted = now_seconds();
-    colind_.resize(total);
-    values_.resize(total);
-    if (streamed) {
-        // already in place: entry i of the file is element i
-        parallel_for(pieces.size(), T, [&](size_t k) {
-            size_t at = first[k];
-            for (const Triplet &t : pieces[k].got) {
-                colind_[at] = t.col;
-                values_[at] = t.val;
-                ++at;
-            }
-        });
-    } else {
-        std::vector<uint32_t> fill(n_rows, 0u);
-        parallel_for(pieces.size(), T, [&](size_t k) {
-            for (const Triplet &t : pieces[k].got) {
-                size_t at = (size_t) (rowptr_[(size_t) t.row - 1] - 1) + __atomic_fetch_add(&fill[(size_t) t.row - 1], 1u, __ATOMIC_RELAXED);
-                colind_[at] = t.col;
-                values_[at] = t.val;
-                if (sym && t.row != t.col) {
-                    at = (size_t) (rowptr_[(size_t) t.col - 1] - 1) + __atomic_fetch_add(&fill[(size_t) t.col - 1], 1u, __ATOMIC_RELAXED);
-                    colind_[at] = t.row;
-                    values_[at] = t.val;
-                }
-            }
-            std::vector<Triplet>().swap(pieces[k].got);
-        });
-        // every row by column (entries of one place: by value, so that the result does not depend on which
-        // thread came first)
-        constexpr size_t ROWS = 4096;
-        parallel_for((n_rows + ROWS - 1) / ROWS, T, [&](size_t c) {
-            std::vector<std::pair<idx_t, val_t>> tmp;
-            for (size_t r = c * ROWS; r < std::min(n_rows, (c + 1) * ROWS); ++r) {
-                const size_t a = (size_t) (rowptr_[r] - 1), b = (size_t) (rowptr_[r + 1] - 1);
-                bool ascending = true;
-                for (size_t j = a + 1; j < b && ascending; ++j) ascending = colind_[j] > colind_[j - 1];
-                if (ascending) continue;
-                tmp.clear();
-                for (size_t j = a; j < b; ++j) tmp.emplace_back(colind_[j], values_[j]);
-                std::sort(tmp.begin(), tmp.end(), [](const std::pair<idx_t, val_t> &x, const std::pair<idx_t, val_t> &y) {
-                    if (x.first != y.first) return x.first < y.first;
-                    uint64_t bx, by;
-                    std::memcpy(&bx, &x.second, 8);
-                    std::memcpy(&by, &y.second, 8);
-                    return bx < by;
-                });
-                for (size_t j = a; j < b; ++j) {
-                    colind_[j] = tmp[j - a].first;
-                    values_[j] = tmp[j - a].second;
-                }
-            }
-        });
-    }
+    csr_from_triplets(spans, nr_rows, nr_cols, symmetric, streamed, rowptr_, colind_, values_, T);
+    const size_t total = colind_.size(), n_rows = nr_rows, n_cols = nr_cols;
     pieces.clear();
     csr_.reset(new CsrInput(rowptr_.data(), colind_.data(), values_.data(), (idx_t) n_rows, (idx_t) n_cols, false));
     loaded_ = true;
     const double t_end = now_seconds();
-    log_msg(LOG_INFO, "MMF file: %zu entries read, %zu elements in %zu rows, %.2f s on %u threads (parsed in %.2f s, rows counted in "
-            "%.2f s, placed and sorted in %.2f s)\n", declared_nnz_, total, n_rows, t_end - t0, T, t_parsed - t0, t_counted - t_parsed,
+    log_msg(LOG_INFO, "MMF file: %zu entries read, %zu elements in %zu rows, %.2f s on %u threads (parsed in %.2f s, checked in "
+            "%.2f s, sorted into CSR in %.2f s)\n", declared_nnz_, total, n_rows, t_end - t0, T, t_parsed - t0, t_counted - t_parsed,
             t_end - t_counted);
 }
 

@@ -58,6 +58,33 @@ private:
     size_t sorted_for_row_ = (size_t) -1;
 };
 
+// Coordinate entries (1-based) sorted into CSR arrays (1-based, rows by ascending column; entries of one place by
+// value, so that the result does not depend on the threads): a counting sort over the rows on all host threads.
+// `spans`: the entries in pieces; `mirror`: an off-diagonal entry counts for (r, c) and (c, r) -- the stored
+// triangle of a symmetric file; `in_order`: the entries come row-major sorted already and stay where they are.
+// Throws FatalError for an entry outside the matrix or more entries than idx_t counts.
+struct TripletSpan { const Triplet *first; size_t count; };
+void csr_from_triplets(const std::vector<TripletSpan> &spans, size_t n_rows, size_t n_cols, bool mirror, bool in_order,
+                       std::vector<idx_t> &rowptr, std::vector<idx_t> &colind, std::vector<val_t> &values, unsigned nthreads);
+
+// CSR arrays of the library's own behind the MatrixInput interface (a reordered matrix, a file that was read)
+class OwnedCsrInput : public MatrixInput {
+public:
+    std::vector<idx_t> rowptr, colind;      // 1-based
+    std::vector<val_t> values;
+    void adopt()                            // after the arrays were filled
+    {
+        csr_.reset(new CsrInput(rowptr.data(), colind.data(), values.data(), (idx_t) nr_rows, (idx_t) nr_cols, false));
+        nnz = colind.size();
+    }
+    void rewind() override { csr_->rewind(); }
+    bool peek(Triplet &t) override { return csr_->peek(t); }
+    void advance() override { csr_->advance(); }
+    CsrInput *as_csr() override { return csr_.get(); }
+private:
+    std::unique_ptr<CsrInput> csr_;
+};
+
 // A Matrix Market file.  The reference reads it entry by entry through an ifstream (Mmf.hpp:331-478) -- and a
 // SuiteSparse file of a few hundred million entries takes minutes that way.  Here the file is mapped, cut at line
 // ends into pieces that all host threads parse, and turned into CSR arrays (a counting sort by row, rows sorted by

@@ -1,12 +1,23 @@
 // reorder.cpp -- see reorder.hpp
 #include "reorder.hpp"
 
+#include <chrono>
+
 #include "common.hpp"
+#include "threads.hpp"
+
+#include <atomic>
 
 #include <algorithm>
 #include <numeric>
 
 namespace spx {
+
+static double rcm_now()
+{
+    using namespace std::chrono;
+    return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
 
 namespace {
 
@@ -210,7 +221,7 @@ void dist_reorder_csr(const idx_t *rowptr, const idx_t *colind, size_t n, bool z
     else perm.swap(order);
 }
 
-TripletInput *reorder_rcm(MatrixInput &in, std::vector<idx_t> &perm, int mode, size_t world)
+OwnedCsrInput *reorder_rcm(MatrixInput &in, std::vector<idx_t> &perm, int mode, size_t world)
 {
     perm.clear();
     const size_t n = in.nr_rows;
@@ -218,71 +229,123 @@ TripletInput *reorder_rcm(MatrixInput &in, std::vector<idx_t> &perm, int mode, s
         log_msg(LOG_WARN, "no reordering available for this matrix (not square)\n");
         return nullptr;
     }
-    std::unique_ptr<TripletInput> out(new TripletInput);
-    out->nr_rows = in.nr_rows;
-    out->nr_cols = in.nr_cols;
-    out->elems.reserve(in.nnz);
-    Triplet t;
-    for (in.rewind(); in.peek(t); in.advance()) out->elems.push_back(t);
-    in.rewind();
-    out->nnz = out->elems.size();
+    const double t_0 = rcm_now();
+    const unsigned T = host_threads();
+    // the entries, 1-based: from the input's CSR arrays where it holds them (all threads), else element by element
+    std::vector<Triplet> elems;
+    CsrInput *c = in.as_csr();
+    if (c) {
+        const idx_t base = c->zero_based_ ? 0 : 1;
+        const size_t total = (size_t) (c->rowptr_[n] - base);
+        elems.resize(total);
+        constexpr size_t ROWS = 8192;
+        parallel_for((n + ROWS - 1) / ROWS, T, [&](size_t k) {
+            for (size_t r = k * ROWS; r < std::min(n, (k + 1) * ROWS); ++r)
+                for (size_t j = (size_t) (c->rowptr_[r] - base); j < (size_t) (c->rowptr_[r + 1] - base); ++j)
+                    elems[j] = Triplet{(idx_t) (r + 1), (idx_t) (c->colind_[j] + (c->zero_based_ ? 1 : 0)), c->values_[j]};
+        });
+    } else {
+        elems.reserve(in.nnz);
+        Triplet t;
+        for (in.rewind(); in.peek(t); in.advance()) elems.push_back(t);
+        in.rewind();
+    }
+    for (const Triplet &e : elems)
+        if (e.row < 1 || (size_t) e.row > n || e.col < 1 || (size_t) e.col > n) throw FatalError("entry outside the matrix");
+    constexpr size_t CHUNK = (size_t) 1 << 20;
+    const size_t n_chunks = (elems.size() + CHUNK - 1) / CHUNK;
 
-    // undirected pattern graph: both directions of every off-diagonal entry,
-    // duplicates removed
-    std::vector<size_t> ptr(n + 1, 0);
-    size_t off = 0;
-    for (const Triplet &e : out->elems)
-        if (e.row != e.col) {
-            ++ptr[(size_t) e.row];
-            ++ptr[(size_t) e.col];
-            ++off;
+    // undirected pattern graph: both directions of every off-diagonal entry, duplicates removed
+    std::vector<uint32_t> deg(n + 1, 0u);
+    std::atomic<size_t> off(0);
+    parallel_for(n_chunks, T, [&](size_t k) {
+        size_t mine = 0;
+        for (size_t i = k * CHUNK; i < std::min(elems.size(), (k + 1) * CHUNK); ++i) {
+            const Triplet &e = elems[i];
+            if (e.row == e.col) continue;
+            __atomic_fetch_add(&deg[(size_t) e.row - 1], 1u, __ATOMIC_RELAXED);
+            __atomic_fetch_add(&deg[(size_t) e.col - 1], 1u, __ATOMIC_RELAXED);
+            ++mine;
         }
-    if (off == 0) {
+        off.fetch_add(mine);
+    });
+    if (off.load() == 0) {
         log_msg(LOG_WARN, "no reordering available for this matrix\n");
         return nullptr;
     }
-    for (size_t i = 0; i < n; ++i) ptr[i + 1] += ptr[i];
+    std::vector<size_t> ptr(n + 1, 0);
+    for (size_t i = 0; i < n; ++i) ptr[i + 1] = ptr[i] + deg[i];
     std::vector<idx_t> adj(ptr[n]);
     {
-        std::vector<size_t> fill(ptr.begin(), ptr.end() - 1);
-        for (const Triplet &e : out->elems)
-            if (e.row != e.col) {
-                adj[fill[(size_t) e.row - 1]++] = e.col - 1;
-                adj[fill[(size_t) e.col - 1]++] = e.row - 1;
+        std::vector<uint32_t> fill(n, 0u);
+        parallel_for(n_chunks, T, [&](size_t k) {
+            for (size_t i = k * CHUNK; i < std::min(elems.size(), (k + 1) * CHUNK); ++i) {
+                const Triplet &e = elems[i];
+                if (e.row == e.col) continue;
+                adj[ptr[(size_t) e.row - 1] + __atomic_fetch_add(&fill[(size_t) e.row - 1], 1u, __ATOMIC_RELAXED)] = e.col - 1;
+                adj[ptr[(size_t) e.col - 1] + __atomic_fetch_add(&fill[(size_t) e.col - 1], 1u, __ATOMIC_RELAXED)] = e.row - 1;
             }
+        });
     }
+    // every vertex' neighbours sorted, duplicates dropped in place (all threads), then closed up
     std::vector<size_t> uptr(n + 1, 0);
-    size_t w = 0;
-    for (size_t v = 0; v < n; ++v) {
-        const size_t b = ptr[v], e = ptr[v + 1];
-        std::sort(adj.begin() + (ptrdiff_t) b, adj.begin() + (ptrdiff_t) e);
-        for (size_t k = b; k < e; ++k)
-            if (k == b || adj[k] != adj[k - 1]) adj[w++] = adj[k];
-        uptr[v + 1] = w;
+    {
+        constexpr size_t VERTS = 8192;
+        parallel_for((n + VERTS - 1) / VERTS, T, [&](size_t k) {
+            for (size_t v = k * VERTS; v < std::min(n, (k + 1) * VERTS); ++v) {
+                const size_t b = ptr[v], e = ptr[v + 1];
+                std::sort(adj.begin() + (ptrdiff_t) b, adj.begin() + (ptrdiff_t) e);
+                deg[v] = (uint32_t) (std::unique(adj.begin() + (ptrdiff_t) b, adj.begin() + (ptrdiff_t) e) - (adj.begin() + (ptrdiff_t) b));
+            }
+        });
+        size_t w = 0;
+        for (size_t v = 0; v < n; ++v) {
+            const size_t b = ptr[v];
+            if (w != b) std::copy(adj.begin() + (ptrdiff_t) b, adj.begin() + (ptrdiff_t) (b + deg[v]), adj.begin() + (ptrdiff_t) w);
+            w += deg[v];
+            uptr[v + 1] = w;
+        }
+        adj.resize(w);
     }
-    adj.resize(w);
 
     log_msg(LOG_INFO, "Reordering input matrix...\n");
-    size_t bw0 = 0, bw1 = 0;
+    const double t_graph = rcm_now();
     rcm_order(n, uptr, adj, perm);
+    const double t_order = rcm_now();
+    std::vector<idx_t>().swap(adj);
     if (mode == SPX_DIST_REORDER_RCM_OWNER && world > 1) {
         // the order only deals the rows to the processes; inside a process they keep their places
         std::vector<size_t> weight(n, 0);
-        for (const Triplet &e : out->elems) ++weight[(size_t) e.row - 1];
+        for (const Triplet &e : elems) ++weight[(size_t) e.row - 1];
         std::vector<idx_t> own;
         owner_order(perm, weight, world, own);
         perm.swap(own);
     }
-    for (Triplet &e : out->elems) {
-        bw0 = std::max<size_t>(bw0, (size_t) std::abs((long) e.row - (long) e.col));
-        e.row = perm[(size_t) e.row - 1] + 1;
-        e.col = perm[(size_t) e.col - 1] + 1;
-        bw1 = std::max<size_t>(bw1, (size_t) std::abs((long) e.row - (long) e.col));
-    }
-    std::sort(out->elems.begin(), out->elems.end(), [](const Triplet &a, const Triplet &b) {
-        return a.row != b.row ? a.row < b.row : a.col < b.col;
+    // P A P^T: the coordinates renumbered, then sorted into CSR arrays by rows (a counting sort, all threads)
+    std::vector<size_t> bw_before(n_chunks, 0), bw_after(n_chunks, 0);
+    parallel_for(n_chunks, T, [&](size_t k) {
+        size_t b0 = 0, b1 = 0;
+        for (size_t i = k * CHUNK; i < std::min(elems.size(), (k + 1) * CHUNK); ++i) {
+            Triplet &e = elems[i];
+            b0 = std::max<size_t>(b0, (size_t) std::abs((long) e.row - (long) e.col));
+            e.row = perm[(size_t) e.row - 1] + 1;
+            e.col = perm[(size_t) e.col - 1] + 1;
+            b1 = std::max<size_t>(b1, (size_t) std::abs((long) e.row - (long) e.col));
+        }
+        bw_before[k] = b0;
+        bw_after[k] = b1;
     });
+    const size_t bw0 = *std::max_element(bw_before.begin(), bw_before.end()), bw1 = *std::max_element(bw_after.begin(), bw_after.end());
+    std::unique_ptr<OwnedCsrInput> out(new OwnedCsrInput);
+    out->nr_rows = in.nr_rows;
+    out->nr_cols = in.nr_cols;
+    std::vector<TripletSpan> spans;
+    for (size_t k = 0; k < n_chunks; ++k) spans.push_back(TripletSpan{elems.data() + k * CHUNK, std::min(CHUNK, elems.size() - k * CHUNK)});
+    csr_from_triplets(spans, n, n, false, false, out->rowptr, out->colind, out->values, T);
+    out->adopt();
     log_msg(LOG_INFO, "Original Bandwidth: %zu\nFinal Bandwidth: %zu\nReordering complete\n", bw0, bw1);
+    log_msg(LOG_INFO, "reordering: pattern graph %.2f s, Cuthill-McKee order %.2f s, matrix permuted and sorted %.2f s\n",
+            t_graph - t_0, t_order - t_graph, rcm_now() - t_order);
     return out.release();
 }
 

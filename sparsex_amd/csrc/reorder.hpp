@@ -21,20 +21,6 @@
 namespace spx {
 
 // A matrix held as sorted triplets (what a reordered input becomes).
-class TripletInput : public MatrixInput {
-public:
-    std::vector<Triplet> elems;   // 1-based, row-major sorted
-    void rewind() override { cursor_ = 0; }
-    bool peek(Triplet &t) override
-    {
-        if (cursor_ >= elems.size()) return false;
-        t = elems[cursor_];
-        return true;
-    }
-    void advance() override { ++cursor_; }
-private:
-    size_t cursor_ = 0;
-};
 
 // perm[old vertex] = new vertex for the graph given as CSR adjacency
 // (undirected, no self loops).  Deterministic.
@@ -64,7 +50,8 @@ void dist_reorder_csr(const idx_t *rowptr, const idx_t *colind, size_t n, bool z
 // and leaves `perm` empty -- when no reordering is available (non-square
 // matrix, or no off-diagonal nonzero), as the reference does (Rcm.hpp:276-280).
 // (mode SPX_DIST_REORDER_RCM_OWNER with world > 1: owner_order over the RCM order, see above)
-TripletInput *reorder_rcm(MatrixInput &in, std::vector<idx_t> &perm, int mode = SPX_DIST_REORDER_RCM, size_t world = 1);
+// (the result holds CSR arrays of its own: the partition builder cuts them like a client's CSR input)
+OwnedCsrInput *reorder_rcm(MatrixInput &in, std::vector<idx_t> &perm, int mode = SPX_DIST_REORDER_RCM, size_t world = 1);
 
 // max |row - col| over the nonzeros (diagnostics, tests)
 size_t bandwidth(MatrixInput &in);
