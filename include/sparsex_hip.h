@@ -100,11 +100,11 @@
  *                           contents is a second net only: a rewritten vector is seen, one poked element may not be).
  *                           Views of user buffers (spx_vec_create_from_buff, both modes) always travel
  *   spx.vec.register        "auto" (default) | "false": the buffer of a view (spx_vec_create_from_buff) of 32 MB or
- *                           more is page-locked where it lies (hipHostRegister) when the view is used for its SECOND
- *                           spx_matvec_* with the same buffer, and released by spx_vec_destroy; it then travels like
- *                           a vector of the library's own instead of through staging memory.  Invisible to the
- *                           client (it keeps writing through its own pointer); a buffer that cannot be locked is
- *                           staged.  The buffer must outlive the view (as src/api/matvec.c:780-815 assumes)
+ *                           more is page-locked where it lies (hipHostRegister) at the view's first spx_matvec_*, and
+ *                           released by spx_vec_destroy; it then travels like a vector of the library's own instead
+ *                           of through staging memory.  Invisible to the client (it keeps writing through its own
+ *                           pointer); a buffer that cannot be locked is staged.  The buffer must outlive the view
+ *                           (as src/api/matvec.c:780-815 assumes)
  *   spx.rt.dist_chunks      at most 64 parts (larger values are clamped)
  *   spx.rt.host_parts       spx_matvec_* on host vectors of 32 MB or more: the number of parts the product runs in
  *                           while y travels back (and x up) part by part; "0" (default): 24 where x goes up by need
@@ -176,7 +176,7 @@ typedef struct spx_hip_vec spx_hip_vec_t;
 void spx_hip_vec_touch(const spx_vector_t *v);
 /* Diagnostic: how the vector's host memory travels.  0: through staging memory (pageable); 1: page-locked memory of the
  * library's own (spx_vec_create, spx_vec_create_random); 2: a client's buffer that the library page-locked in place
- * (spx.vec.register, from the view's second product on); 3: a client's buffer that was page-locked already. */
+ * (spx.vec.register, from the view's first product on); 3: a client's buffer that was page-locked already. */
 int spx_hip_vec_page_locked(const spx_vector_t *v);
 
 spx_hip_vec_t *spx_hip_vec_create(size_t size);                 /* zero-filled        */

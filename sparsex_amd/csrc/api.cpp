@@ -104,11 +104,12 @@ uint64_t vec_version(const spx_vector_t *v)
 }
 
 // spx.vec.register (default auto): a spx_vec_create_from_buff vector is a view of the CLIENT's buffer, pageable
-// memory as a rule, and every spx_matvec_* on it copies x into page-locked staging memory and y back out of it --
-// on the bench matrix that host-side copying takes longer than the transfers.  A view that is used for a SECOND
-// product with the same buffer (the reference's bench loop, src/bench/SparsexModule.cpp:54-70; a client that
-// makes a view per call never gets here) has that buffer page-locked where it lies (hipHostRegister) and from
-// then on travels like a vector of the library's own; spx_vec_destroy releases it.  Nothing depends on it for
+// memory as a rule, and every spx_matvec_* on it would copy x into page-locked staging memory and y back out of it --
+// on the bench matrix that host-side copying takes longer than the transfers.  Instead a view of 32 MB or more
+// has its buffer page-locked where it lies (hipHostRegister) at its first product and from then on travels like a
+// vector of the library's own; spx_vec_destroy releases it.  On this platform that costs next to nothing (0.6 ms
+// for 224 MB that the client has touched, tools/micro/host_register_cost.py), so that even a client that makes a
+// view per call gains (9.0 -> 6.1 ms per spx_matvec_mult on the bench matrix).  Nothing depends on it for
 // correctness: a buffer that cannot be locked, or was locked by someone else and released under us, goes through
 // staging or through the runtime's own pageable path.
 struct VecReg {
@@ -118,6 +119,7 @@ struct VecReg {
     bool locked = false, ours = false, failed = false;
 };
 std::unordered_map<const spx_vector_t *, VecReg> g_vec_reg;
+constexpr unsigned REGISTER_FROM_USE = 1;
 
 bool vec_page_locked(const spx_vector_t *v)
 {
@@ -134,7 +136,7 @@ bool vec_page_locked(const spx_vector_t *v)
         r.bytes = bytes;
     }
     ++r.uses;
-    if (!r.locked && !r.failed && r.uses >= 2) {
+    if (!r.locked && !r.failed && r.uses >= REGISTER_FROM_USE) {
         const int got = device_host_register(r.ptr, r.bytes);
         r.locked = got != 0;
         r.ours = got == 1;

@@ -40,7 +40,7 @@ void Config::reset_defaults()
     props_["spx.rt.gpu_rank"] = "0";         // this process' slice of the partitions
     props_["spx.rt.gpu_world"] = "1";
     props_["spx.rt.device"] = "-1";          // HIP device ordinal, -1 = current
-    props_["spx.vec.register"] = "auto";     // auto: a view of a client's buffer (spx_vec_create_from_buff) of 32 MB or more is page-locked in place when it is used for a second product; false: always staged
+    props_["spx.vec.register"] = "auto";     // auto: a view of a client's buffer (spx_vec_create_from_buff) of 32 MB or more is page-locked in place at its first product; false: always staged
     props_["spx.vec.device"] = "false";      // true: vectors the library creates keep their HBM copy between calls (a client that writes through v->elements must then say so: spx_hip_vec_touch)
     props_["spx.rt.host_parts"] = "0";       // spx_matvec_* on host vectors of 32 MB or more: parts the product runs in while y travels back (and x up) part by part; 0: 24 (symmetric streams: 16) where x goes up by need, else 8; at most 64
     props_["spx.rt.dist_chunks"] = "4";      // SPX_DIST_OVERLAP: parts of the own product the halo exchange is pipelined over (1: no plan)

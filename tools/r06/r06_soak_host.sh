@@ -5,5 +5,5 @@
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 OUT=$ROOT/gpurun_out/r06s; mkdir -p $OUT; cd $ROOT
 export SPX_HOST_PARTS_MIN_BYTES=1024 SPX_HOST_XPIECE_BYTES=16384
-SOAK_SIZES=${SOAK_SIZES:-} timeout 2400 python3 tools/soak_large.py ${1:-500} ${2:-620} --library-vectors > $OUT/soak_host.txt 2>&1
+timeout 2400 python3 tools/soak_large.py ${1:-500} ${2:-620} --library-vectors > $OUT/soak_host.txt 2>&1
 tail -1 $OUT/soak_host.txt; grep -c ' ok' $OUT/soak_host.txt; grep FAILED $OUT/soak_host.txt | head -5 | cut -c1-300
