@@ -18,6 +18,7 @@ int main(int argc, char **argv)
     int64_t edge = argc > 1 ? atoll(argv[1]) : 60;
     const char *threads = argc > 2 ? argv[2] : "1";
     const char *sym = argc > 3 ? argv[3] : "false";
+    const int reorder = argc > 4 && strcmp(argv[4], "reorder") == 0;
     int64_t n = 2 * edge * edge * edge + 6 * edge * edge, nnz = 0;
     int32_t *cnt = malloc(n * sizeof *cnt);
     spx_syn_nlpkkt_counts((int) edge, cnt);
@@ -36,9 +37,9 @@ int main(int argc, char **argv)
     spx_option_set("spx.matrix.symmetric", sym);
     spx_log_info_console();
     double t0 = now();
-    spx_matrix_t *A = spx_mat_tune(in);
-    printf("edge %lld: %lld rows, %lld nonzeros, tune %.2f s (%s threads, symmetric %s)\n", (long long) edge,
-           (long long) n, (long long) nnz, now() - t0, threads, sym);
+    spx_matrix_t *A = reorder ? spx_mat_tune(in, SPX_MAT_REORDER) : spx_mat_tune(in);
+    printf("edge %lld: %lld rows, %lld nonzeros, tune %.2f s (%s threads, symmetric %s%s)\n", (long long) edge,
+           (long long) n, (long long) nnz, now() - t0, threads, sym, reorder ? ", RCM reordered" : "");
     spx_mat_destroy(A);
     spx_input_destroy(in);
     return 0;
