@@ -8,14 +8,14 @@ NAME=$1; FLAGS=$2
 cd "$(dirname "$0")/.."
 make lib > /dev/null
 mkdir -p build/var sparsex_amd/lib/variants
-# (SPX_VARIANT_TU=spmv_xw_kernels rebuilds only that translation unit: seconds instead of minutes)
+# (SPX_VARIANT_TU="spmv_xw_kernels" rebuilds only that translation unit: seconds instead of minutes)
 VAR_OBJS=""
-for tu in ${SPX_VARIANT_TU:-spmv_kernels spmv_xw_kernels}; do
+for tu in ${SPX_VARIANT_TU:-spmv_kernels spmv_xw_kernels spmv_sx_kernels}; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O3 -fPIC -munsafe-fp-atomics -Iinclude -Isparsex_amd/csrc \
         $FLAGS -c sparsex_amd/csrc/$tu.hip -o build/var/${tu}_$NAME.o
     VAR_OBJS="$VAR_OBJS build/var/${tu}_$NAME.o"
 done
 OBJS=$(ls build/obj/*.o)
-for tu in ${SPX_VARIANT_TU:-spmv_kernels spmv_xw_kernels}; do OBJS=$(echo "$OBJS" | grep -v "/$tu.o"); done
+for tu in ${SPX_VARIANT_TU:-spmv_kernels spmv_xw_kernels spmv_sx_kernels}; do OBJS=$(echo "$OBJS" | grep -v "/$tu.o"); done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o sparsex_amd/lib/variants/libsparsex_$NAME.so $OBJS $VAR_OBJS -pthread -ldl
 echo sparsex_amd/lib/variants/libsparsex_$NAME.so
