@@ -304,6 +304,37 @@ class Matrix:
         return passes, n_sx, {k: int(getattr(pl, k)) for k in ("rowblocks_with_sx", "sym_elems", "sx_elems",
                                                                 "sym_passes", "sx_passes")}
 
+    def host_parts(self):
+        """Parts the last spx_matvec_* on host vectors ran in (spx_hip_mat_host_parts; 0: in one piece)."""
+        L = lib()
+        L.spx_hip_mat_host_parts.restype = C.c_int
+        return int(L.spx_hip_mat_host_parts(C.c_void_p(self.handle)))
+
+    def host_order(self):
+        """The order those parts ran in where x went up piece by piece as they needed it (spx_hip_mat_host_order);
+        [] when x went up whole or stayed resident."""
+        L = lib()
+        L.spx_hip_mat_host_order.restype = C.c_int
+        L.spx_hip_mat_host_order.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
+        buf = (C.c_int32 * 64)()
+        k = L.spx_hip_mat_host_order(C.c_void_p(self.handle), buf, 64)
+        return [int(buf[i]) for i in range(min(k, 64))]
+
+    def x_pieces(self, piece):
+        """Which pieces of x (of `piece` elements, at most 64 of them) every row-block reads (spx_hip_mat_x_pieces):
+        (masks as uint64, first rows, row counts), numpy copies; host side."""
+        import numpy as np
+        L = lib()
+        L.spx_hip_mat_x_pieces.restype = C.c_int64
+        L.spx_hip_mat_x_pieces.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        n = L.spx_hip_mat_x_pieces(C.c_void_p(self.handle), piece, None, None, None, 0)
+        if n < 0:
+            raise SpxError("spx_hip_mat_x_pieces failed")
+        m, r0, nr = np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        if n and L.spx_hip_mat_x_pieces(C.c_void_p(self.handle), piece, m.ctypes.data, r0.ctypes.data, nr.ctypes.data, n) != n:
+            raise SpxError("spx_hip_mat_x_pieces failed")
+        return m, r0, nr
+
     def export_csx(self, part=0):
         """Reference-format CSX arrays of one partition as numpy copies."""
         ex = CsxExport()

@@ -23,14 +23,7 @@ CASES = [("kkt", lambda: synth.syn_nlpkkt(20), {}, False),
 
 
 def masks(A, piece):
-    L = sx.lib()
-    L.spx_hip_mat_x_pieces.restype = C.c_int64
-    L.spx_hip_mat_x_pieces.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
-    n = L.spx_hip_mat_x_pieces(C.c_void_p(A.handle), piece, None, None, None, 0)
-    assert n >= 0
-    m, r0, nr = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint32)
-    assert L.spx_hip_mat_x_pieces(C.c_void_p(A.handle), piece, m.ctypes.data, r0.ctypes.data, nr.ctypes.data, n) == n
-    return m, r0, nr
+    return A.x_pieces(piece)
 
 
 @pytest.mark.parametrize("name,make,opts,sym", CASES, ids=[c[0] for c in CASES])
