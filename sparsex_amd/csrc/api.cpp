@@ -120,12 +120,19 @@ struct VecReg {
 };
 std::unordered_map<const spx_vector_t *, VecReg> g_vec_reg;
 constexpr unsigned REGISTER_FROM_USE = 1;
+constexpr size_t VEC_REGISTER_MIN_BYTES = (size_t) 32 << 20;
 
 bool vec_page_locked(const spx_vector_t *v)
 {
     if (v->alloc_type == ALLOC_PINNED) return true;
     const size_t bytes = v->size * sizeof(spx_value_t);
-    if (bytes < device_host_parts_min_bytes() || !v->elements) return false;      // (from where y travels in parts: 32 MB)
+    // 32 MB and more only, whatever the tests' thresholds: an allocation of that size is a mapping of its own (glibc's
+    // mmap threshold never grows beyond it), so that the pages that get locked hold nothing else of the process.
+    // Smaller arrays live on the heap among other objects -- among them the sources of the library's own pageable
+    // uploads, which the runtime pins in place for the time of a copy; with client arrays of some hundred KB
+    // page-locked next to those a soak ran into GPU memory access faults on heap addresses, one in some
+    // hundred matrices (profiles/r06/NOTES.md section 4); without them, and at the bench matrix' size, never.
+    if (bytes < VEC_REGISTER_MIN_BYTES || !v->elements) return false;
     if (Config::instance().get_str("spx.vec.register") == "false") return false;
     std::lock_guard<std::mutex> lk(g_vec_mtx);
     VecReg &r = g_vec_reg[v];

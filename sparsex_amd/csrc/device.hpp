@@ -60,7 +60,7 @@ bool device_stream_is_capturing(void *stream);
 void *device_host_alloc(size_t bytes);
 void device_host_free(void *p);
 // a client's buffer page-locked where it lies (1: done, 2: it already was, 0: not possible) / released again
-size_t device_host_parts_min_bytes();    // vectors of this size and more: y back in parts, client buffers page-locked (32 MB; tests lower it)
+size_t device_host_parts_min_bytes();    // vectors of this size and more: y back in parts (32 MB; tests lower it)
 int device_host_register(void *p, size_t bytes);
 void device_host_unregister(void *p);
 
