@@ -67,8 +67,9 @@ for name, csr, opts in cases:
     y = y0.copy()
     A.matvec_kernel(2.0, x, -0.5, y)
     check_y(csr, x, y, 2.0, -0.5, y0)
-    # a view that lives across products (the reference's bench loop, src/bench/SparsexModule.cpp:54-70): its buffer
-    # is page-locked in place at the first product (spx.vec.register) and travels without staging
+    # a view that lives across products (the reference's bench loop, src/bench/SparsexModule.cpp:54-70).  A buffer of
+    # 32 MB or more is page-locked in place at the first product (spx.vec.register) and travels without staging --
+    # tests/test_gpu_fullsize.py goes that way; these small ones are staged (spx_hip_vec_page_locked == 0)
     L.spx_vec_create_from_buff.restype = C.POINTER(VectorStruct)
     L.spx_vec_create_from_buff.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
     xb, yb = synth.random_x(n, seed=5), np.full(n, np.nan)
