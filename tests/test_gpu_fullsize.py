@@ -134,5 +134,25 @@ def test_full_size_library_vectors(case):
         assert L.spx_matvec_kernel(-1.25, C.c_void_p(M.handle), xv, 0.75, yv) == 0
         check_y(csr, x1, ya.copy(), -1.25, 0.75, y0)
         L.spx_vec_destroy(xv); L.spx_vec_destroy(yv)
+        # views of client arrays kept across products (the reference harness' pattern): from 32 MB on they are
+        # page-locked where they lie at the first product and travel like the library's own vectors
+        L.spx_vec_create_from_buff.restype = C.POINTER(VectorStruct)
+        L.spx_vec_create_from_buff.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+        L.spx_hip_vec_page_locked.restype = C.c_int
+        L.spx_hip_vec_page_locked.argtypes = [C.POINTER(VectorStruct)]
+        xb, yb = x1.copy(), np.full(n, np.nan)
+        xw = L.spx_vec_create_from_buff(xb.ctypes.data, None, n, None, 43)
+        yw = L.spx_vec_create_from_buff(yb.ctypes.data, None, n, None, 43)
+        assert L.spx_matvec_mult(C.c_double(0.5), C.c_void_p(M.handle), xw, yw) == 0
+        check_y(csr, x1, yb.copy(), 0.5)
+        locked = L.spx_hip_vec_page_locked(xw)
+        assert locked in ((0, 2, 3) if n * 8 >= (32 << 20) else (0,)), (name, locked)
+        if locked and L.spx_hip_mat_host_parts(C.c_void_p(M.handle)) >= 2:
+            k = L.spx_hip_mat_host_order(C.c_void_p(M.handle), buf, 64)
+            assert sorted(buf[i] for i in range(k)) == list(range(L.spx_hip_mat_host_parts(C.c_void_p(M.handle)))), (name, k)
+        yb[:] = y0
+        assert L.spx_matvec_kernel(-1.25, C.c_void_p(M.handle), xw, 0.75, yw) == 0
+        check_y(csr, x1, yb.copy(), -1.25, 0.75, y0)
+        L.spx_vec_destroy(xw); L.spx_vec_destroy(yw)
         if M is not A:
             M.destroy()
