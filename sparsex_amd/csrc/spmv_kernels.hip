@@ -1589,6 +1589,11 @@ void device_spmv_host(DeviceMatrix *m, double alpha, const double *h_x, bool x_p
                         copy_threads(reinterpret_cast<char *>(h_y) + off, reinterpret_cast<char *>(m->p_y) + off, n);
                     }
             }
+            // (everything that was enqueued has run by now -- the last rows of y were behind the last part, which was
+            // behind the last piece of x; the two waits cost some microseconds and make sure of it whatever the cut:
+            // the caller may release its vectors the moment this returns)
+            if (m->up_stream) HIP_CHECK(hipStreamSynchronize(m->up_stream));
+            HIP_CHECK(hipStreamSynchronize(st));
             if (x_by_need) m->x_version = x_version;
             return;
         } catch (...) {
