@@ -131,7 +131,9 @@ bool vec_page_locked(const spx_vector_t *v)
     // Smaller arrays live on the heap among other objects -- among them the sources of the library's own pageable
     // uploads, which the runtime pins in place for the time of a copy; with client arrays of some hundred KB
     // page-locked next to those a soak ran into GPU memory access faults on heap addresses, one in some
-    // hundred matrices (profiles/r06/NOTES.md section 4); without them, and at the bench matrix' size, never.
+    // hundred matrices (profiles/r06/NOTES.md section 4: heap pages that were page-locked and released stay mapped, are
+    // handed out again to the library's vectors, and a pageable hipMemcpy from those faulted); without them, and at the
+    // bench matrix' size (memory that is unmapped when the client frees it), never.
     if (bytes < VEC_REGISTER_MIN_BYTES || !v->elements) return false;
     if (Config::instance().get_str("spx.vec.register") == "false") return false;
     std::lock_guard<std::mutex> lk(g_vec_mtx);

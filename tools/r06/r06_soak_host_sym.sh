@@ -14,6 +14,8 @@ from sparsex_amd import synth
 from sparsex_amd.api import VectorStruct
 from helpers import tune, check_y
 L = sx.lib()
+if os.environ.get("R06_LOG") == "1":
+    L.spx_log_info_console()
 L.spx_vec_create_random.restype = C.POINTER(VectorStruct); L.spx_vec_create_random.argtypes = [C.c_size_t, C.c_void_p]
 L.spx_vec_create.restype = C.POINTER(VectorStruct); L.spx_vec_create.argtypes = [C.c_size_t, C.c_void_p]
 L.spx_vec_create_from_buff.restype = C.POINTER(VectorStruct)
