@@ -266,8 +266,11 @@ void mm_parse_piece(MmPiece &pc, bool zero_based)
             return;
         }
         Triplet t;
-        t.row = (idx_t) (zero_based ? r + 1 : r);
-        t.col = (idx_t) (zero_based ? c + 1 : c);
+        // (a coordinate beyond the index type must not wrap into the matrix: -1 fails the range check later)
+        const long R = zero_based ? r + 1 : r, Cc = zero_based ? c + 1 : c;
+        const long top = (long) std::numeric_limits<idx_t>::max();
+        t.row = (R < 0 || R > top) ? (idx_t) -1 : (idx_t) R;
+        t.col = (Cc < 0 || Cc > top) ? (idx_t) -1 : (idx_t) Cc;
         t.val = v;
         if (t.row < pr || (t.row == pr && t.col < pcn)) pc.sorted = false;
         pr = t.row;

@@ -233,6 +233,11 @@ def test_large_file_failure_modes(tmp_path, big):
     out.write_text("\n".join(text))
     with pytest.raises(sx.SpxError):
         sx.input_load_mmf(str(out))
+    # ... also one whose coordinate does not fit the index type (it must not wrap into the matrix)
+    text[len(text) // 2] = "%d 1 1.0" % (2 ** 32 + 1)
+    out.write_text("\n".join(text))
+    with pytest.raises(sx.SpxError):
+        sx.input_load_mmf(str(out))
     # a row-major file that is not sorted fails when the tuner reads it (as the reference: Mmf.hpp:259-263)
     unsorted = _write_big(tmp_path, "u.mtx", "%%MatrixMarket matrix coordinate real general row\n", n, rows + 1, ci + 1, va, o)
     inp = sx.input_load_mmf(unsorted)
