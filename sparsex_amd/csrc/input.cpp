@@ -174,7 +174,7 @@ MmfInput::MmfInput(const char *filename) : filename_(filename)
         }
     }
     long r, c; double n;
-    if (!parse3(args, r, c, n) || r < 0 || c < 0 || n < 0 || r > (long) std::numeric_limits<idx_t>::max() ||
+    if (!parse3(args, r, c, n) || r < 0 || c < 0 || !(n >= 0 && n < 1e15) || r > (long) std::numeric_limits<idx_t>::max() ||
         c > (long) std::numeric_limits<idx_t>::max()) {
         log_msg(LOG_ERR, "bad input, less arguments in line of MMF file\n");
         throw FatalError("size line");
